@@ -1,0 +1,539 @@
+#!/usr/bin/env python3
+"""Golden-vector generator for the quantize/prune hot path.
+
+Runs ONLY in the build container: it imports the real mlzxy/qsparse (v2.0.1) from the read-only
+checkout at /root/reference and records inputs -> outputs of the reference's own functions and
+layers as small .npz fixtures next to this file.  Nothing from the reference travels: the fixtures
+hold data only (seeded inputs, the reference's outputs, and per-step state trajectories).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate.py
+
+bf16 tensors are stored as their uint16 bit patterns under the key suffix ``__bf16``; every other
+array is stored in its own dtype.  ``meta`` (a JSON string) lists the cases of each file.
+
+Reference entry points exercised (file:line in /root/reference):
+  F1 ScalerQuantization.forward/backward       qsparse/quantize.py:87-131
+  F2 DecimalQuantization.forward/backward      qsparse/quantize.py:31-77
+  F3 LineQuantization.forward                  qsparse/quantize.py:141-185
+  F4 QuantizeLayer trajectories                qsparse/quantize.py:434-518 (+ quantizers :275-430)
+  F5 squeeze_tensor_to_shape                   qsparse/util.py:79-99
+  F6 calculate_mask_given_importance           qsparse/util.py:103-117
+  F7 PruneLayer trajectories                   qsparse/sparse.py:157-273 (+ callbacks :18-152)
+  F8 convert() module trees                    qsparse/convert.py:21-245
+  F9 state_dict schema + preload               qsparse/util.py:120-145
+  F10 prune->quantize pair trajectory (the headline pair, small shape)
+"""
+import io
+import json
+import os
+import sys
+import contextlib
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("QSPARSE_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import qsparse  # the real reference
+from qsparse import convert, prune, quantize
+from qsparse.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer,
+                              quantize_with_decimal, quantize_with_line, quantize_with_scaler)
+from qsparse.sparse import MagnitudePruningCallback, devise_layerwise_pruning_schedule
+from qsparse.util import (calculate_mask_given_importance, preload_qsparse_state_dict,
+                          squeeze_tensor_to_shape)
+
+assert qsparse.__version__ == "2.0.1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+qsparse.set_qsparse_options(log_on_created=False, log_during_train=False)
+
+
+def put(store, key, t):
+    """store a tensor / array / scalar under `key` (bf16 as uint16 bits)."""
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().clone()  # clone: layer state is updated in place later
+        if t.dtype == torch.bfloat16:
+            store[key + "__bf16"] = t.contiguous().view(torch.int16).numpy().view(np.uint16)
+            return
+        if t.dtype == torch.float16:
+            store[key + "__f16"] = t.contiguous().numpy()
+            return
+        store[key] = t.contiguous().numpy()
+    else:
+        store[key] = np.asarray(t)
+
+
+def save(name, store, meta):
+    store = dict(store)
+    store["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(meta['cases'])} cases")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+# --------------------------------------------------------------------------------------------
+# F1 / F2: scaler + decimal STE quantizers, forward and backward
+# --------------------------------------------------------------------------------------------
+def f1_f2():
+    for fname, fn in (("f1_scaler", quantize_with_scaler), ("f2_decimal", quantize_with_decimal)):
+        store, cases = {}, []
+        shape = (3, 6, 4, 4)
+        C = shape[1]
+        idx = 0
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            for bits in (4, 8):
+                for pkind in ("pyfloat", "zerodim", "t11", "chan1", "chan0"):
+                    for flip, passthrough in ((False, False), (True, False), (False, True)):
+                        if (flip or passthrough) and pkind not in ("t11", "chan1"):
+                            continue
+                        if dt == torch.float16 and (bits == 4 or pkind in ("zerodim", "chan0")):
+                            continue
+                        x = (torch.randn(shape, generator=gen(100 + idx)) * 2).to(dt)
+                        flat = x.view(-1)
+                        if fname == "f1_scaler":
+                            s0 = 0.1 if bits == 8 else 0.37
+                            # exact half-way quotients, and values far outside the code range
+                            hw = torch.tensor([0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 3.5, 1e3, -1e3, 300.25]) * s0
+                            flat[: len(hw)] = hw.to(dt)
+                            if pkind == "pyfloat":
+                                param = s0
+                            elif pkind == "zerodim":
+                                param = torch.tensor(s0)
+                            elif pkind == "t11":
+                                param = torch.full((1, 1), s0)
+                            else:
+                                n = C if pkind == "chan1" else shape[0]
+                                param = (torch.rand(n, 1, generator=gen(7 + idx)) * 0.3 + 0.01)
+                        else:
+                            d0 = 5 if bits == 8 else 2
+                            hw = torch.tensor([0.74, -0.74, 0.76, -0.76, 1.0, -1.0, 1.99, 700.3, -700.3]) / 2.0 ** d0
+                            flat[: len(hw)] = hw.to(dt)
+                            if pkind == "pyfloat":
+                                param = d0
+                            elif pkind == "zerodim":
+                                param = torch.tensor(float(d0))
+                            elif pkind == "t11":
+                                param = torch.full((1, 1), float(d0))
+                            else:
+                                n = C if pkind == "chan1" else shape[0]
+                                param = torch.randint(0, 8, (n, 1), generator=gen(7 + idx)).float()
+                        ci = {"chan1": 1, "chan0": 0}.get(pkind, -1)
+                        xin = x.clone().requires_grad_(True)
+                        y = fn(xin, bits, param, ci, False, passthrough, flip)
+                        gout = (torch.randn(shape, generator=gen(900 + idx)) * (3.0 if bits == 8 else 1.5))
+                        gout = gout.to(y.dtype)
+                        y.backward(gout.clone())
+                        # integer codes, computed with the reference's own expression
+                        with torch.no_grad():
+                            if fname == "f1_scaler":
+                                pv = param.view([-1 if i == ci else 1 for i in range(4)]) if (
+                                    isinstance(param, torch.Tensor) and param.numel() > 1) else param
+                                codes = (x / pv).round().int()
+                            else:
+                                toi = 2.0 ** param
+                                if isinstance(param, torch.Tensor) and param.numel() > 1:
+                                    toi = toi.view([-1 if i == ci else 1 for i in range(4)])
+                                codes = (x * toi).int()
+                        k = f"c{idx}_"
+                        put(store, k + "x", x)
+                        put(store, k + "param", param if isinstance(param, torch.Tensor) else np.float64(param))
+                        put(store, k + "y", y)
+                        put(store, k + "codes", codes)
+                        put(store, k + "gout", gout)
+                        put(store, k + "gx", xin.grad)
+                        cases.append(dict(id=idx, dtype=str(dt).replace("torch.", ""), bits=bits, pkind=pkind,
+                                          channel_index=ci, flip_axis=flip, backward_passthrough=passthrough,
+                                          y_dtype=str(y.dtype).replace("torch.", ""),
+                                          gx_dtype=str(xin.grad.dtype).replace("torch.", "")))
+                        idx += 1
+        save(fname, store, dict(cases=cases, shape=list(shape)))
+
+
+# --------------------------------------------------------------------------------------------
+# F3: line (asymmetric) quantizer
+# --------------------------------------------------------------------------------------------
+def f3():
+    store, cases = {}, []
+    shape = (3, 6, 5, 5)
+    idx = 0
+    for dt in (torch.float32, torch.bfloat16):
+        for bits in (4, 8):
+            for lkind in ("tuple", "t12", "chan1", "chan0"):
+                for fzp in (True, False):
+                    x = (torch.randn(shape, generator=gen(300 + idx)) * 1.5).to(dt)
+                    if lkind == "tuple":
+                        lines, ci = (-0.1, 0.9), -1
+                    elif lkind == "t12":
+                        lines, ci = torch.tensor([[-1.3, 2.1]]), -1
+                    else:
+                        ci = 1 if lkind == "chan1" else 0
+                        n = shape[ci]
+                        lo = -torch.rand(n, 1, generator=gen(40 + idx)) * 2
+                        hi = torch.rand(n, 1, generator=gen(41 + idx)) * 2 + 0.05
+                        lines = torch.cat([lo, hi], 1)
+                        lines[0, 1] = lines[0, 0]  # a degenerate row: step == 0 -> 1e-4
+                    y = quantize_with_line(x.clone(), bits, lines if not isinstance(lines, torch.Tensor) else lines.clone(),
+                                           ci, False, fzp)
+                    k = f"c{idx}_"
+                    put(store, k + "x", x)
+                    put(store, k + "lines", torch.tensor(lines).view(-1, 2) if not isinstance(lines, torch.Tensor) else lines)
+                    put(store, k + "y", y)
+                    cases.append(dict(id=idx, dtype=str(dt).replace("torch.", ""), bits=bits, lkind=lkind,
+                                      channel_index=ci, float_zero_point=fzp,
+                                      y_dtype=str(y.dtype).replace("torch.", "")))
+                    idx += 1
+    save("f3_line", store, dict(cases=cases, shape=list(shape)))
+
+
+# --------------------------------------------------------------------------------------------
+# F4: QuantizeLayer trajectories
+# --------------------------------------------------------------------------------------------
+def f4():
+    store, cases = {}, []
+    idx = 0
+    specs = []
+    for cbname in ("scaler", "decimal", "adaptive"):
+        specs.append(dict(cb=cbname, channelwise=-1, shape=(3, 5, 6, 6), timeout=2, steps=6, bits=8, dtype="float32"))
+        specs.append(dict(cb=cbname, channelwise=1, shape=(1, 5, 6, 6), timeout=1, steps=5, bits=4, dtype="float32"))
+        specs.append(dict(cb=cbname, channelwise=-1, shape=(3, 5, 6, 6), timeout=1, steps=5, bits=4, dtype="bfloat16"))
+    specs.append(dict(cb="adaptive", channelwise=1, shape=(4, 5, 6, 6), timeout=1, steps=5, bits=8, dtype="float32"))
+    specs.append(dict(cb="adaptive", channelwise=1, shape=(4, 5, 6, 6), timeout=1, steps=5, bits=8, dtype="bfloat16"))
+    specs.append(dict(cb="scaler", channelwise=-1, shape=(3, 5, 6, 6), timeout=0, steps=3, bits=8, dtype="float32"))
+    specs.append(dict(cb="scaler", channelwise=-1, shape=(2, 12), timeout=1, steps=4, bits=8, dtype="float32"))
+    mk = dict(scaler=ScalerQuantizer, decimal=DecimalQuantizer, adaptive=AdaptiveQuantizer)
+    for sp in specs:
+        dt = getattr(torch, sp["dtype"])
+        with quiet():
+            layer = quantize(bits=sp["bits"], channelwise=sp["channelwise"], timeout=sp["timeout"], callback=mk[sp["cb"]]())
+        layer.train()
+        k = f"c{idx}_"
+        for s in range(sp["steps"] + 2):
+            if s == sp["steps"]:
+                layer.eval()  # last two steps in eval mode
+            x = ((torch.rand(sp["shape"], generator=gen(1000 + 17 * idx + s)) - 0.5) * (4 + s)).to(dt)
+            with quiet():
+                y = layer(x)
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_weight", layer.weight)
+            put(store, k + f"s{s}_n_updates", layer._n_updates)
+        cases.append(dict(id=idx, **{**sp, "shape": list(sp["shape"])}, total_steps=sp["steps"] + 2))
+        idx += 1
+
+    # weight-side: quantize(Conv2d) with bias, channelwise=0; shared callback between weight and bias
+    for cbname in ("scaler", "decimal"):
+        torch.manual_seed(5)
+        conv = nn.Conv2d(4, 6, 3)
+        w0, b0 = conv.weight.detach().clone(), conv.bias.detach().clone()
+        with quiet():
+            qconv = quantize(conv, bits=8, bias_bits=8, timeout=2, channelwise=0, callback=mk[cbname]())
+        qconv.train()
+        k = f"c{idx}_"
+        put(store, k + "w0", w0)
+        put(store, k + "b0", b0)
+        steps = 5
+        for s in range(steps):
+            x = torch.rand((2, 4, 8, 8), generator=gen(2000 + s))
+            with quiet():
+                y = qconv(x)
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_y", y)
+            with quiet():
+                put(store, k + f"s{s}_qweight", qconv.weight)  # property: advances the schedule once more
+                put(store, k + f"s{s}_qbias", qconv.bias)
+            put(store, k + f"s{s}_wscale", qconv.quantize.weight)
+            put(store, k + f"s{s}_bscale", qconv.quantize_bias.weight)
+        cases.append(dict(id=idx, cb=cbname, kind="conv_weight", steps=steps, bits=8, timeout=2, channelwise=0))
+        idx += 1
+    save("f4_quantize_layer", store, dict(cases=cases))
+
+
+# --------------------------------------------------------------------------------------------
+# F5: squeeze_tensor_to_shape (staged means)
+# --------------------------------------------------------------------------------------------
+def f5():
+    store, cases = {}, []
+    idx = 0
+    for dt in (torch.float32, torch.bfloat16):
+        for shape, mshape in (((40, 6, 9, 8), (1, 6, 1, 1)),
+                              ((6, 6, 20, 8), (6, 6, 1, 1)),
+                              ((6, 6, 8, 8), (1, 1, 1, 1)),
+                              ((6, 6, 8, 40), (1, 6, 8, 1)),
+                              ((7, 5, 3, 9), (1, 5, 1, 1)),
+                              ((20, 33), (1, 33)),
+                              ((6, 10, 3, 3), (1, 10, 3, 3))):
+            x = (torch.randn(shape, generator=gen(500 + idx)) * torch.linspace(0.25, 4, shape[1]).view(
+                [1, -1] + [1] * (len(shape) - 2))).to(dt)
+            out = squeeze_tensor_to_shape(x.abs(), mshape)
+            k = f"c{idx}_"
+            put(store, k + "x", x)
+            put(store, k + "out", out)
+            cases.append(dict(id=idx, dtype=str(dt).replace("torch.", ""), shape=list(shape), mask_shape=list(mshape)))
+            idx += 1
+    save("f5_squeeze", store, dict(cases=cases))
+
+
+# --------------------------------------------------------------------------------------------
+# F6: calculate_mask_given_importance
+# --------------------------------------------------------------------------------------------
+def f6():
+    store, cases = {}, []
+    idx = 0
+    sched = [float(torch.tensor(0.75 * (1 - (1 - (i + 1) / 4) ** 3), dtype=torch.float32).item()) for i in range(4)]
+    for n_shape in ((1, 256, 1, 1), (5, 30, 7, 8), (32, 16, 3, 3), (1, 7, 1, 1)):
+        for kind in ("random", "ties", "negzero"):
+            imp = torch.rand(n_shape, generator=gen(600 + idx))
+            if kind == "ties":
+                imp = (imp * 6).floor() / 6
+            if kind == "negzero":
+                imp = imp - 0.5
+                imp.view(-1)[::5] = 0.0
+            for s in [0.0, 0.47, 0.5, 0.75, 0.999] + sched:
+                n = imp.numel()
+                if max(int(s * n - 1), 0) + 1 >= n:
+                    continue
+                mask = calculate_mask_given_importance(imp, s)
+                k = f"c{idx}_"
+                ikey = f"imp{len(n_shape)}_{n_shape[0]}_{n_shape[1]}_{kind}"
+                put(store, ikey, imp)
+                store[k + "mask"] = np.packbits(mask.numpy().reshape(-1))
+                cases.append(dict(id=idx, kind=kind, shape=list(n_shape), sparsity=s, imp_key=ikey))
+                idx += 1
+    save("f6_mask", store, dict(cases=cases))
+
+
+# --------------------------------------------------------------------------------------------
+# F7: PruneLayer trajectories
+# --------------------------------------------------------------------------------------------
+def f7():
+    store, cases = {}, []
+    idx = 0
+    specs = [
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=5, interval=2, repetition=3, rampup=False,
+             cb=dict(), dtype="float32", steps=16),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.75, start=3, interval=2, repetition=3, rampup=True,
+             cb=dict(), dtype="bfloat16", steps=14),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=2, interval=3, repetition=2, rampup=False,
+             cb=dict(running_average=False), dtype="float32", steps=12),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.6, start=2, interval=2, repetition=4, rampup=False,
+             cb=dict(mask_refresh_interval=3, stop_mask_refresh=9), dtype="bfloat16", steps=16),
+        dict(shape=(2, 6, 5, 5), dims=[0, 1, 2, 3], sparsity=0.5, start=2, interval=2, repetition=2, rampup=False,
+             cb=dict(), dtype="float32", steps=10),
+        dict(shape=(2, 6, 5, 5), dims=[1, 2, 3], sparsity=0.7, start=1, interval=2, repetition=2, rampup=False,
+             cb=dict(), dtype="bfloat16", steps=9),
+        dict(shape=(8, 24), dims=[1], sparsity=0.5, start=1, interval=1, repetition=3, rampup=False,
+             cb=dict(), dtype="float32", steps=8),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=2, interval=2, repetition=2, rampup=False,
+             cb=dict(l0=True), dtype="float32", steps=9, relu=True),
+    ]
+    for sp in specs:
+        dt = getattr(torch, sp["dtype"])
+        with quiet():
+            layer = prune(sparsity=sp["sparsity"], dimensions=set(sp["dims"]), start=sp["start"], interval=sp["interval"],
+                          repetition=sp["repetition"], rampup=sp["rampup"], callback=MagnitudePruningCallback(**sp["cb"]))
+        layer.train()
+        k = f"c{idx}_"
+        scale = torch.linspace(0.25, 4, sp["shape"][1]).view([1, -1] + [1] * (len(sp["shape"]) - 2))
+        for s in range(sp["steps"] + 2):
+            if s == sp["steps"]:
+                layer.eval()
+            x = torch.randn(sp["shape"], generator=gen(3000 + 31 * idx + s)) * scale
+            if sp.get("relu"):
+                x = x.relu()
+            x = x.to(dt).requires_grad_(True)
+            gout = torch.randn(sp["shape"], generator=gen(4000 + 31 * idx + s)).to(dt)
+            with quiet():
+                y = layer(x)
+            y.backward(gout)
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_gout", gout)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_gx", x.grad)
+            put(store, k + f"s{s}_mask", layer.mask)
+            put(store, k + f"s{s}_n_updates", layer._n_updates)
+            put(store, k + f"s{s}_cur_sparsity", layer._cur_sparsity)
+            put(store, k + f"s{s}_t", layer.callback.t)
+            if hasattr(layer.callback, "magnitude"):
+                put(store, k + f"s{s}_magnitude", layer.callback.magnitude)
+        cases.append(dict(id=idx, **{**sp, "shape": list(sp["shape"])}, total_steps=sp["steps"] + 2))
+        idx += 1
+
+    # weight-side: prune(Conv2d), unstructured over dims {0,1,2,3}? reference default dims={1}: per-input-channel
+    for cbkw, dims in ((dict(running_average=False), [1]), (dict(), [0, 1, 2, 3])):
+        torch.manual_seed(11)
+        conv = nn.Conv2d(10, 12, 3)
+        w0 = conv.weight.detach().clone()
+        with quiet():
+            pconv = prune(conv, sparsity=0.5, dimensions=set(dims), start=2, interval=2, repetition=2,
+                          callback=MagnitudePruningCallback(**cbkw))
+        pconv.train()
+        k = f"c{idx}_"
+        put(store, k + "w0", w0)
+        steps = 9
+        x = torch.rand((1, 10, 8, 8), generator=gen(77))
+        put(store, k + "x", x)
+        for s in range(steps):
+            with quiet():
+                y = pconv(x)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_mask", pconv.prune.mask)
+        cases.append(dict(id=idx, kind="conv_weight", dims=dims, cb=cbkw, steps=steps, sparsity=0.5, start=2, interval=2,
+                          repetition=2))
+        idx += 1
+    save("f7_prune_layer", store, dict(cases=cases))
+
+
+# --------------------------------------------------------------------------------------------
+# F8/F9: convert() trees, state_dict schema, preload round trip
+# --------------------------------------------------------------------------------------------
+class LeNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 6, kernel_size=5)
+        self.conv2 = nn.Conv2d(6, 16, kernel_size=5)
+        self.fc1 = nn.Linear(16 * 5 * 5, 120)
+        self.fc2 = nn.Linear(120, 84)
+        self.fc3 = nn.Linear(84, 10)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.conv1(x)), 2)
+        x = F.max_pool2d(F.relu(self.conv2(x)), 2)
+        x = x.view(x.size(0), -1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+
+
+class MnistNet(nn.Module):
+    """the CNN of the reference's MNIST example (architecture only), examples/mnist.py:17-44"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv_part = nn.Sequential(nn.Conv2d(1, 32, 3, 1), nn.BatchNorm2d(32), nn.ReLU(), nn.Conv2d(32, 64, 3, 1),
+                                       nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2), nn.Dropout(0.25))
+        self.linear_part = nn.Sequential(nn.Flatten(), nn.Linear(9216, 128), nn.BatchNorm1d(128), nn.ReLU(),
+                                         nn.Dropout(0.5), nn.Linear(128, 10))
+
+    def forward(self, x):
+        return F.log_softmax(self.linear_part(self.conv_part(x)), dim=1)
+
+
+def f8_f9():
+    trees = {}
+    with quiet():
+        excl = [(nn.Conv2d, [0]), (nn.Linear, [-1])]
+        m = convert(LeNet(), prune(sparsity=0.5, callback=MagnitudePruningCallback()),
+                    weight_layers=[nn.Conv2d, nn.Linear], activation_layers=[nn.Conv2d, nn.Linear],
+                    excluded_weight_layer_indexes=excl, excluded_activation_layer_indexes=excl)
+        m = convert(m, quantize(bits=8), weight_layers=[nn.Conv2d, nn.Linear],
+                    activation_layers=[nn.Conv2d, nn.Linear], input=True)
+    trees["lenet_pq"] = {k: v.__class__.__name__ for k, v in m.named_modules()}
+    trees["lenet_pq_str"] = str(m)
+    with quiet():
+        m = convert(MnistNet(), prune(sparsity=0.75, dimensions={1}), activation_layers=[nn.ReLU],
+                    excluded_activation_layer_indexes=[(nn.ReLU, [-1])])
+        m = convert(m, quantize(bits=4, channelwise=-1, timeout=50), activation_layers=[nn.ReLU],
+                    weight_layers=[nn.Conv2d, nn.Linear], input=True)
+    trees["mnist_pq"] = {k: v.__class__.__name__ for k, v in m.named_modules()}
+    trees["mnist_pq_str"] = str(m)
+    with quiet():
+        from collections import OrderedDict
+        net = nn.Sequential(OrderedDict([("conv1", nn.Conv2d(3, 6, kernel_size=5)), ("fc1", nn.Linear(84, 10))]))
+        c = convert(net, quantize(bits=8), activation_layers=[nn.Conv2d, nn.Linear], order="pre")
+        trees["order_pre_str"] = str(c)
+        c = convert(c, prune(sparsity=0.5), activation_layers=[nn.Conv2d, nn.Linear])
+        trees["order_pre_nested_str"] = str(c)
+
+    # F9: state dict schema + values after a short run of quantize(prune(conv))
+    def make_conv():
+        torch.manual_seed(3)
+        with quiet():
+            return quantize(prune(nn.Conv2d(16, 32, 3), sparsity=0.5, start=20, interval=5, repetition=4), bits=8, timeout=10)
+
+    conv = make_conv()
+    conv.train()
+    for s in range(45):
+        with quiet():
+            conv(torch.rand(4, 16, 7, 7, generator=gen(5000 + s)))
+    sd = conv.state_dict()
+    store = {}
+    schema = {}
+    for kname, v in sd.items():
+        put(store, "sd_" + kname, v)
+        schema[kname] = dict(dtype=str(v.dtype).replace("torch.", ""), shape=list(v.shape))
+    xt = torch.rand(4, 16, 7, 7, generator=gen(9999))
+    conv.eval()
+    conv3 = make_conv()
+    preload_qsparse_state_dict(conv3, sd)
+    conv3.load_state_dict(sd)
+    conv3.eval()
+    with quiet():
+        put(store, "eval_x", xt)
+        put(store, "eval_y_trained", conv(xt))
+        put(store, "eval_y_reloaded", conv3(xt))  # NOTE: _quantized is not restored by the reference (quirk B7)
+    save("f8_f9_convert_state", store, dict(cases=[dict(trees=trees, state_schema=schema)]))
+
+
+# --------------------------------------------------------------------------------------------
+# F10: the headline pair at a small shape: ReLU -> prune(0.75,{1}) -> quantize(4-bit, tensor-wise)
+# --------------------------------------------------------------------------------------------
+def f10():
+    store, cases = {}, []
+    idx = 0
+    for dt, shape, bits, sp in ((torch.bfloat16, (4, 16, 4, 4), 4, 0.75), (torch.float32, (4, 16, 4, 4), 8, 0.5),
+                                (torch.bfloat16, (8, 32, 6, 6), 4, 0.75)):
+        with quiet():
+            pl = prune(sparsity=sp, dimensions={1}, start=1, interval=2, repetition=3)
+            ql = quantize(bits=bits, channelwise=-1, timeout=2)
+        pl.train(), ql.train()
+        steps = 10
+        k = f"c{idx}_"
+        C = shape[1]
+        for s in range(steps + 1):
+            if s == steps:
+                pl.eval(), ql.eval()
+            x = (torch.randn(shape, generator=gen(7000 + 13 * idx + s)).relu() * torch.linspace(0.25, 4, C).view(1, -1, 1, 1)).to(dt)
+            x.requires_grad_(True)
+            with quiet():
+                h = pl(x)
+                y = ql(h)
+            gout = torch.randn(shape, generator=gen(8000 + 13 * idx + s)).to(y.dtype)
+            y.backward(gout.clone())
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_gout", gout)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_gx", x.grad)
+            put(store, k + f"s{s}_mask", pl.mask)
+            if hasattr(pl.callback, "magnitude"):
+                put(store, k + f"s{s}_magnitude", pl.callback.magnitude)
+            put(store, k + f"s{s}_cur_sparsity", pl._cur_sparsity)
+            put(store, k + f"s{s}_scale", ql.weight)
+        cases.append(dict(id=idx, dtype=str(dt).replace("torch.", ""), shape=list(shape), bits=bits, sparsity=sp,
+                          start=1, interval=2, repetition=3, timeout=2, total_steps=steps + 1))
+        idx += 1
+    save("f10_prune_quant_pair", store, dict(cases=cases))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    f1_f2()
+    f3()
+    f4()
+    f5()
+    f6()
+    f7()
+    f8_f9()
+    f10()

@@ -1,0 +1,43 @@
+"""loader for the fixtures written by tests/golden/generate.py (data only; see its docstring)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.meta = json.loads(str(self.z["meta"]))
+        self.cases = self.meta["cases"]
+
+    def has(self, key):
+        return any(k in self.z for k in (key, key + "__bf16", key + "__f16"))
+
+    def get(self, key):
+        """tensor stored under `key` (bf16 restored from its bit pattern)."""
+        if key + "__bf16" in self.z:
+            a = self.z[key + "__bf16"].view(np.int16)
+            return torch.from_numpy(a.copy()).view(torch.bfloat16)
+        if key + "__f16" in self.z:
+            return torch.from_numpy(self.z[key + "__f16"].copy())
+        a = self.z[key]
+        if a.ndim == 0:
+            return a.item()
+        return torch.from_numpy(a.copy())
+
+
+def tdtype(name):
+    return getattr(torch, name)
+
+
+def same(a, b):
+    """bit-for-bit equality of two tensors (same dtype, same shape, NaNs compare by payload)."""
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if a.dtype == torch.bool:
+        return bool((a == b).all())
+    return bool(torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)))
