@@ -1,0 +1,184 @@
+/*
+ * qsparse_hip.h -- C ABI of libqsparse_hip.so: the MI355X (gfx950) implementation of the tensor math
+ * behind mlzxy/qsparse's QuantizeLayer / PruneLayer forward + backward.
+ *
+ * This is the drop-in boundary.  The reference has no native layer (its "kernels" are chains of eager
+ * ATen operators inside qsparse/quantize.py, qsparse/sparse.py and qsparse/util.py); every entry point
+ * below names the reference lines whose arithmetic it replaces.  A binding needs nothing but a dlopen:
+ * plain pointers, sizes and enums, no torch types.
+ *
+ * Conventions
+ *   - Every tensor is CONTIGUOUS and described as a 3-d view [outer, C, inner]: `C` is the extent of the
+ *     reference's `channel_index` dimension, `outer`/`inner` the products of the extents before/after it.
+ *     Tensor-wise operation: pass nparam == 1 (C and inner may then be any factorisation of numel).
+ *   - Per-channel parameters are DEVICE float arrays of length nparam (1 or C).  A NULL parameter
+ *     pointer selects the by-value host scalar that follows it in the argument list.
+ *   - dtypes: QS_F32 / QS_BF16 / QS_F16.  Arithmetic is IEEE binary32, one rounding per operator of the
+ *     reference chain (built with -ffp-contract=off; division is correctly rounded).
+ *   - All work is enqueued on `stream` (a hipStream_t); no call allocates, frees or synchronises, so
+ *     every call is hipGraph-capturable.  Scratch memory is caller-provided (qs_workspace_bytes).
+ *   - Return value: 0 on success, a positive hipError_t from the runtime, or a negative QS_ERR_* for a
+ *     rejected argument (nothing is enqueued in that case).  qs_status_string() explains either kind.
+ *   - Data pointers of x / y / g must be 16-byte aligned (QS_ERR_ALIGN otherwise).
+ */
+#ifndef QSPARSE_HIP_H
+#define QSPARSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_ABI_VERSION 1
+
+enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
+
+enum qs_error {
+    QS_OK = 0,
+    QS_ERR_DTYPE = -1,     /* unsupported dtype combination              */
+    QS_ERR_ARG = -2,       /* inconsistent sizes / NULL where not allowed */
+    QS_ERR_ALIGN = -3,     /* data pointer not 16-byte aligned           */
+    QS_ERR_WORKSPACE = -4, /* workspace too small                        */
+    QS_ERR_RANK = -5       /* broadcast pattern needs more than QS_MAX_DIMS collapsed dims */
+};
+
+enum qs_workspace_op { QS_WS_KTH_VALUE = 1, QS_WS_PQ_STATS = 2 };
+
+#define QS_MAX_DIMS 6
+
+typedef void* qs_stream_t; /* hipStream_t */
+
+int qs_version(void);
+const char* qs_status_string(int status);
+size_t qs_workspace_bytes(int op, int64_t n);
+
+/* ---- quantizers: forward ------------------------------------------------------------------------ */
+
+/* ScalerQuantization.forward, qsparse/quantize.py:100-117.
+ *   q = int32(rint(round_to(qdt, f32(x) / s_c)));  y = f32(q) * s_c
+ * qdt is the dtype the reference's quotient tensor has (f32 when the scaler is a >=1-d tensor, the input
+ * dtype when it is a Python float / 0-d tensor).  `codes` (nullable) receives q.  `chan_mask` (nullable,
+ * nparam-independent, length C, one byte per channel) fuses a preceding channel PruneLayer
+ * (x * mask, qsparse/sparse.py:116): masked channels are quantised as x*0.  The reference never
+ * saturates (its clamp at :110-116 acts on a temporary); saturate != 0 enables q = clamp(q, lo, hi) as
+ * an explicit opt-in. */
+int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
+                        const float* scale, int64_t nscale, float scale_host,
+                        const uint8_t* chan_mask,
+                        int64_t outer, int64_t C, int64_t inner,
+                        int xdt, int ydt, int qdt,
+                        int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
+
+/* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
+int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
+                         const float* decimal, int64_t ndecimal, float decimal_host,
+                         const uint8_t* chan_mask,
+                         int64_t outer, int64_t C, int64_t inner,
+                         int xdt, int ydt, int qdt,
+                         int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
+
+/* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
+ * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
+ * float_zero_point == 0: (clamp(rint(xc/step)-rint(start/step),0,N-1)+rint(start/step))*step  (:161-166) */
+int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines, int bits,
+                      int float_zero_point, int64_t outer, int64_t C, int64_t inner,
+                      int xdt, int ydt, qs_stream_t stream);
+
+/* ---- quantizers: straight-through backward ------------------------------------------------------ */
+
+/* ScalerQuantization.backward / DecimalQuantization.backward, qsparse/quantize.py:66-77,120-131:
+ *   gx = cast(gxdt, min(max(g, lo_mul*step_c), hi_mul*step_c))     (passthrough != 0: gx = cast(g))
+ * step_c = scale (step_is_decimal == 0) or 2^-d (step_is_decimal != 0);  lo_mul = -2^(bits-1)+notch,
+ * hi_mul = 2^(bits-1)-1+notch.  chan_mask (nullable) fuses the PruneLayer backward g*mask
+ * (autograd MulBackward0 of qsparse/sparse.py:116).  g and gx may alias. */
+int qs_quant_ste_bwd(const void* g, void* gx,
+                     const float* step, int64_t nstep, float step_host, int step_is_decimal,
+                     float lo_mul, float hi_mul, int passthrough,
+                     const uint8_t* chan_mask,
+                     int64_t outer, int64_t C, int64_t inner,
+                     int gdt, int gxdt, qs_stream_t stream);
+
+/* ---- statistics ---------------------------------------------------------------------------------- */
+
+/* max |x| over the tensor (per_channel == 0 -> out[1]) or per channel (out[C]);
+ * DecimalQuantizer.optimize, qsparse/quantize.py:329-340.  Order-independent, hence bit-exact. */
+int qs_absmax(const void* x, float* out, int per_channel,
+              int64_t outer, int64_t C, int64_t inner, int xdt, qs_stream_t stream);
+
+/* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
+ * (min over the batch of per-sample minima == global per-channel minimum). */
+int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
+              int64_t outer, int64_t C, int64_t inner, int xdt, qs_stream_t stream);
+
+/* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1)
+ * (quantize.py:340,344-348). */
+int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, int bits, qs_stream_t stream);
+
+/* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430) */
+int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after,
+                    qs_stream_t stream);
+
+/* d[i] = rint(log2(nan_to_num(1/scale[i], posinf=1, neginf=1)))  (quantize.py:316) */
+int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stream_t stream);
+
+/* One stage of squeeze_tensor_to_shape (qsparse/util.py:92-99): mean over the middle dim of a contiguous
+ * [pre, n, post] tensor -> [pre, 1, post], fp32 accumulation in ATen's CPU summation order (cascade /
+ * 4-way interleave), one fp32 division by n, one rounding to odt.
+ * flags: QS_MEAN_ABS takes |x| first (sparse.py:87);  QS_MEAN_L0 maps x -> (x != 0) when *l0_flag != 0
+ * (sparse.py:85-86; l0_flag is a device int written by qs_l0_flag).
+ * absmax_out (nullable, device float[C]) additionally receives per-channel max|x| where channel =
+ * (column / chan_div) % C  -- the statistics of a following tensor-wise QuantizeLayer fused into the
+ * same read of x. */
+#define QS_MEAN_ABS 1
+#define QS_MEAN_L0 2
+int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
+                int xdt, int odt, int flags, const int32_t* l0_flag,
+                float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream);
+
+/* *flag = (min(x) == 0), qsparse/sparse.py:85 */
+int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scratch2, qs_stream_t stream);
+
+/* state[i] <- (t*state[i] + f32(new[i])) / (t+1)   (MagnitudePruningCallback.update_magnitude,
+ * qsparse/sparse.py:88-89) */
+int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, qs_stream_t stream);
+
+/* ---- mask construction --------------------------------------------------------------------------- */
+
+/* thr = sort_ascending(imp)[k]  (calculate_mask_given_importance, qsparse/util.py:113-116; the caller
+ * computes k = max(int(s*n-1),0)+1 on the host exactly as the reference does).  NaNs order last.
+ * ws: qs_workspace_bytes(QS_WS_KTH_VALUE, n) bytes. */
+int qs_kth_value(const float* imp, int64_t n, int64_t k, float* thr, void* ws, size_t ws_bytes,
+                 qs_stream_t stream);
+
+/* mask[i] = imp[i] >= *thr   (util.py:117) */
+int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_stream_t stream);
+
+/* ---- mask apply ------------------------------------------------------------------------------------ */
+
+/* y = x * mask with a broadcast bool mask (qsparse/sparse.py:66,116,122,263) and, with g in place of x,
+ * its backward g * mask.  The tensor is described by `ndim` collapsed extents `sizes`; `mask_strides[d]`
+ * is the mask's element stride along d (0 where the mask has extent 1). */
+int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes,
+                  const int64_t* mask_strides, int dt, qs_stream_t stream);
+
+/* ---- fused channel-prune -> tensor-wise-quantize statistics (the headline pair) -------------------- */
+
+/* One launch over C-sized state, replacing (per training step of the pair
+ * Sequential(PruneLayer(dims={1}), QuantizeLayer(channelwise=-1)) built by convert(), convert.py:214-218):
+ *   magnitude  <- (t_mag*magnitude + f32(stage_mean))/(t_mag+1)       if update_magnitude   (sparse.py:89)
+ *   mask       <- magnitude >= sort(magnitude)[k]                      if refresh_mask       (util.py:113-117)
+ *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340)
+ *   scale      <- t_q == 0 ? new : (t_q*scale + new)/(t_q+1), new = absmax_all/2^(bits-1)  if update_scale
+ * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536. */
+int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
+                 int update_magnitude, int64_t t_mag,
+                 int refresh_mask, int64_t k, uint8_t* mask,
+                 const float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
+                 void* ws, size_t ws_bytes, qs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSPARSE_HIP_H */

@@ -1,0 +1,332 @@
+"""ctypes binding of ``libqsparse_hip.so`` (C ABI: ``include/qsparse_hip.h``).
+
+PyTorch is used here only as the owner of device memory and streams: every call passes raw
+``data_ptr()`` values and the current HIP stream.  There is no fallback: a CUDA/HIP tensor reaching
+this module without the library present raises ``QsparseHipError``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+MEAN_ABS, MEAN_L0 = 1, 2
+WS_KTH_VALUE = 1
+MAX_DIMS = 6
+
+_LIB_NAME = "libqsparse_hip.so"
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class QsparseHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("QSPARSE_HIP_LIB", os.path.join(_PKG_DIR, _LIB_NAME))
+
+
+# name -> (restype, argtypes); mirrors include/qsparse_hip.h one to one
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+SIGNATURES = {
+    "qs_version": (c_int, []),
+    "qs_status_string": (c_char_p, [_I]),
+    "qs_workspace_bytes": (c_size_t, [_I, _L]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _P]),
+    "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
+    "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
+    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _P]),
+    "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
+    "qs_scale_update": (c_int, [_P, _P, _L, _L, _I, _P]),
+    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P]),
+    "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
+    "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _P]),
+    "qs_l0_flag": (c_int, [_P, _L, _I, _P, _P, _P]),
+    "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P]),
+    "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
+    "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
+    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load(path: Optional[str] = None):
+    """dlopen the library and declare every prototype (no GPU needed for this)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise QsparseHipError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). GPU tensors cannot be processed without it.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI mismatch
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def available() -> bool:
+    try:
+        load()
+        return True
+    except (QsparseHipError, OSError, AttributeError):
+        return False
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        msg = load().qs_status_string(status)
+        raise QsparseHipError(f"{what}: {msg.decode() if msg else status} (status {status})")
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise QsparseHipError(f"dtype {t.dtype} is not supported by the HIP path (float32/bfloat16/float16 only)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def dense(t: torch.Tensor) -> torch.Tensor:
+    """contiguous and 16-byte aligned (the ABI's requirement for data tensors)."""
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def split3(shape, channel_index: int):
+    """[outer, C, inner] factorisation around `channel_index` (negative: tensor-wise)."""
+    numel = 1
+    for s in shape:
+        numel *= s
+    if channel_index < 0:
+        return 1, 1, max(numel, 1) if numel else 1, numel
+    outer = 1
+    for s in shape[:channel_index]:
+        outer *= s
+    inner = 1
+    for s in shape[channel_index + 1:]:
+        inner *= s
+    return outer, shape[channel_index], inner, numel
+
+
+def _f32param(p, device):
+    """device fp32 array or (None, host float) for scalars given as Python numbers."""
+    if isinstance(p, torch.Tensor):
+        q = p.detach().to(device=device, dtype=torch.float32).contiguous().view(-1)
+        return q, q.numel(), 0.0
+    return None, 1, float(p)
+
+
+# ----------------------------------------------------------------------------------------------
+# quantizers
+# ----------------------------------------------------------------------------------------------
+def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
+              chan_mask: Optional[torch.Tensor] = None, mask_channel_index: Optional[int] = None,
+              want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None):
+    """kind in {'scaler','decimal'}; returns (y, codes|None)."""
+    lib = load()
+    x = dense(x)
+    pt, n, host = _f32param(param, x.device)
+    ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
+    outer, C, inner, numel = split3(x.shape, ci if ci is not None else -1)
+    if numel == 0:
+        return torch.empty(x.shape, dtype=out_dtype, device=x.device), None
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
+    cm = None
+    if chan_mask is not None:
+        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
+        assert cm.numel() == C
+    sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
+    fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
+    st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
+            _DT[qdtype], sat, lo, hi, _stream(x))
+    _check(st, f"qs_quant_{kind}_fwd")
+    return y, codes
+
+
+def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_index: int, float_zero_point: bool):
+    lib = load()
+    x = dense(x)
+    ln = lines.detach().to(device=x.device, dtype=torch.float32).contiguous().view(-1, 2)
+    n = ln.shape[0]
+    outer, C, inner, numel = split3(x.shape, channel_index if n > 1 else -1)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if numel == 0:
+        return y
+    st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C, inner,
+                               dt(x), F32, _stream(x))
+    _check(st, "qs_quant_line_fwd")
+    return y
+
+
+def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo_mul: float, hi_mul: float,
+            passthrough: bool, out_dtype: torch.dtype, chan_mask: Optional[torch.Tensor] = None,
+            mask_channel_index: Optional[int] = None):
+    lib = load()
+    g = dense(g)
+    pt, n, host = _f32param(step, g.device)
+    ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
+    outer, C, inner, numel = split3(g.shape, ci if ci is not None else -1)
+    gx = torch.empty(g.shape, dtype=out_dtype, device=g.device)
+    if numel == 0:
+        return gx
+    cm = None
+    if chan_mask is not None:
+        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
+        assert cm.numel() == C
+    st = lib.qs_quant_ste_bwd(_ptr(g), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)), float(lo_mul),
+                              float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g), _DT[out_dtype],
+                              _stream(g))
+    _check(st, "qs_quant_ste_bwd")
+    return gx
+
+
+# ----------------------------------------------------------------------------------------------
+# statistics
+# ----------------------------------------------------------------------------------------------
+def absmax(x: torch.Tensor, channel_index: int) -> torch.Tensor:
+    lib = load()
+    x = dense(x)
+    outer, C, inner, numel = split3(x.shape, channel_index)
+    n = C if channel_index >= 0 else 1
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
+    _check(st, "qs_absmax")
+    return out
+
+
+def minmax(x: torch.Tensor, channel_index: int):
+    lib = load()
+    x = dense(x)
+    outer, C, inner, numel = split3(x.shape, channel_index)
+    n = C if channel_index >= 0 else 1
+    mn = torch.empty(n, dtype=torch.float32, device=x.device)
+    mx = torch.empty(n, dtype=torch.float32, device=x.device)
+    st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
+    _check(st, "qs_minmax")
+    return mn, mx
+
+
+def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int):
+    """in place on `weight` (fp32, contiguous)."""
+    assert weight.dtype == torch.float32 and weight.is_contiguous()
+    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), int(bits), _stream(weight))
+    _check(st, "qs_scale_update")
+
+
+def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int):
+    assert lines.dtype == torch.float32 and lines.is_contiguous()
+    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _stream(lines))
+    _check(st, "qs_lines_update")
+
+
+def decimal_from_scale(scale: torch.Tensor) -> torch.Tensor:
+    s = scale.detach().to(torch.float32).contiguous()
+    d = torch.empty_like(s)
+    st = load().qs_decimal_from_scale(_ptr(s), _ptr(d), s.numel(), _stream(s))
+    _check(st, "qs_decimal_from_scale")
+    return d
+
+
+def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtype, flags: int = 0,
+             l0_flag: Optional[torch.Tensor] = None, absmax_out: Optional[torch.Tensor] = None, chan_div: int = 1,
+             C: int = 1) -> torch.Tensor:
+    """x: contiguous storage viewed as [pre, n, post]; returns a flat [pre*post] tensor."""
+    x = dense(x)
+    out = torch.empty(pre * post, dtype=out_dtype, device=x.device)
+    st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
+                            _ptr(absmax_out), int(chan_div), int(C), _stream(x))
+    _check(st, "qs_mean_dim")
+    return out
+
+
+def l0_flag(x: torch.Tensor) -> torch.Tensor:
+    x = dense(x)
+    flag = torch.empty(1, dtype=torch.int32, device=x.device)
+    scratch = torch.empty(2, dtype=torch.float32, device=x.device)
+    st = load().qs_l0_flag(_ptr(x), x.numel(), dt(x), _ptr(flag), _ptr(scratch), _stream(x))
+    _check(st, "qs_l0_flag")
+    return flag
+
+
+def running_mean(state: torch.Tensor, new: torch.Tensor, t: int):
+    assert state.dtype == torch.float32 and state.is_contiguous() and new.numel() == state.numel()
+    new = new.contiguous()
+    st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _stream(state))
+    _check(st, "qs_running_mean")
+
+
+# ----------------------------------------------------------------------------------------------
+# masks
+# ----------------------------------------------------------------------------------------------
+def kth_value(imp: torch.Tensor, k: int) -> torch.Tensor:
+    lib = load()
+    imp = imp.detach().to(torch.float32).contiguous().view(-1)
+    n = imp.numel()
+    thr = torch.empty(1, dtype=torch.float32, device=imp.device)
+    nbytes = lib.qs_workspace_bytes(WS_KTH_VALUE, n)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=imp.device)
+    st = lib.qs_kth_value(_ptr(imp), n, int(k), _ptr(thr), _ptr(ws), ws.numel(), _stream(imp))
+    _check(st, "qs_kth_value")
+    return thr
+
+
+def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
+    """out_mask (bool, contiguous, same numel) <- imp >= thr, in place."""
+    imp = imp.detach().to(torch.float32).contiguous()
+    assert out_mask.dtype == torch.bool and out_mask.is_contiguous() and out_mask.numel() == imp.numel()
+    st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(out_mask), imp.numel(), _stream(imp))
+    _check(st, "qs_mask_ge")
+
+
+def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x * mask for a bool mask broadcastable to x (same rank, extents 1 or equal)."""
+    lib = load()
+    x = dense(x)
+    if mask.dim() != x.dim():
+        raise RuntimeError(f"mask rank {mask.dim()} does not match input rank {x.dim()}")
+    for sm, sx in zip(mask.shape, x.shape):
+        if sm != 1 and sm != sx:
+            raise RuntimeError(
+                f"The size of tensor a ({sx}) must match the size of tensor b ({sm}) at non-singleton dimension")
+    m = mask.detach().contiguous()
+    y = torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    nd = x.dim()
+    sizes = (c_int64 * nd)(*x.shape)
+    mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
+    st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), _stream(x))
+    _check(st, "qs_mask_apply")
+    return y
+
+
+def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], update_magnitude: bool, t_mag: int,
+              refresh_mask: bool, k: int, mask: torch.Tensor, chan_absmax: Optional[torch.Tensor], update_scale: bool,
+              t_q: int, bits: int, scale: Optional[torch.Tensor]):
+    C = magnitude.numel()
+    sdt = dt(stage_mean) if stage_mean is not None else F32
+    st = load().qs_pq_select(_ptr(magnitude), _ptr(stage_mean), sdt, C, int(update_magnitude), int(t_mag),
+                             int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
+                             int(bits), _ptr(scale), None, 0, _stream(magnitude))
+    _check(st, "qs_pq_select")

@@ -1,0 +1,183 @@
+"""Model rewriting: inject prune/quantize operators into an existing network -- API of the reference's
+qsparse/convert.py:21-245 (same arguments, same resulting module tree and names).
+
+Weights of the listed layer types are wrapped through ``prune(layer)`` / ``quantize(layer)`` (class
+substitution, see ``imitation.py``); activations are wrapped as ``nn.Sequential(layer, operator)`` (or
+``Sequential(operator, layer)`` for ``order="pre"``) tagged ``_qsparse_conversion`` so that a second
+``convert`` nests around the first.  With ``fuse=True`` (default) every
+``Sequential(Sequential(act, PruneLayer{dims={1}}), QuantizeLayer{tensor-wise})`` produced this way is
+re-classed to ``FusedPruneQuantize`` -- same children, same ``state_dict`` keys -- which runs the pair
+as the fused HIP path on GPU tensors (see ``fused.py``).
+"""
+import copy
+import warnings
+from collections import defaultdict
+from typing import List, Mapping, Optional, Sequence, Tuple, Type, Union
+
+import torch.nn as nn
+
+from qsparse_amd.quantize import QuantizeLayer, quantize
+from qsparse_amd.sparse import PruneLayer, prune
+from qsparse_amd.util import auto_name_prune_quantize_layers, logging, nn_module
+
+_INJECTED = ("quantize", "prune", "quantize_bias")
+
+
+def _fresh_kwargs(kwargs: Mapping) -> Mapping:
+    """every converted layer gets its own copy of module-valued arguments (the callbacks)."""
+    return {k: (copy.deepcopy(v) if isinstance(v, nn.Module) else v) for k, v in kwargs.items()}
+
+
+def _type_name(m) -> str:
+    """class name used to match a module against ``weight_layers`` / ``activation_layers``; a wrapper
+    ``Sequential`` produced by an earlier conversion is named after the layer it wraps."""
+    if isinstance(m, nn.Sequential):
+        for child in m.children():
+            if not isinstance(child, (QuantizeLayer, PruneLayer)):
+                return _type_name(child)
+        return None
+    if isinstance(m, nn.Module):
+        return type(m).__name__
+    return m.__name__
+
+
+def _is_container(m: nn.Module) -> bool:
+    """has children that are not merely injected operators"""
+    return len(m._modules) > 0 and not any(hasattr(m, k) for k in _INJECTED)
+
+
+def convert(model: nn.Module, operator: Union[PruneLayer, QuantizeLayer], inplace: bool = True,
+            weight_layers: Sequence[Type[nn.Module]] = [], activation_layers: Sequence[Type[nn.Module]] = [],
+            input: bool = False, log: bool = True,
+            excluded_weight_layer_indexes: Sequence[Tuple[Type[nn.Module], Sequence[int]]] = [],
+            excluded_activation_layer_indexes: Sequence[Tuple[Type[nn.Module], Sequence[int]]] = [],
+            include: Optional[Union[str, List[str]]] = None, exclude: Optional[Union[str, List[str]]] = None,
+            order: str = "post", fuse: bool = True) -> nn.Module:
+    """apply ``operator`` (a layer made by ``prune(...)`` or ``quantize(...)``) across ``model``.
+
+    Args:
+        model: network to convert (``nn.DataParallel``-style wrappers are looked through).
+        operator: prototype ``PruneLayer`` / ``QuantizeLayer``; each site gets a fresh copy.
+        inplace: mutate ``model`` (default) or work on a deep copy.
+        weight_layers: layer types whose weights are transformed.
+        activation_layers: layer types whose outputs (``order="post"``) or inputs (``"pre"``) are transformed.
+        input: also transform the network input.
+        log: print one line per visited site.
+        excluded_*_layer_indexes: ``[(Type, [i, ...])]`` occurrence indexes (negative from the end) to skip.
+        include / exclude: substrings a module path must all contain / must not contain.
+        order: ``"post"`` or ``"pre"``.
+        fuse: (extension) run convert-built prune->quantize pairs through the fused GPU path.
+    """
+    assert isinstance(operator, (PruneLayer, QuantizeLayer)), "`operator` does not belong to (PruneLayer, QuantizeLayer)"
+    assert order in ["pre", "post"], "`order` must be either 'pre' or 'post'"
+    must_have = [include] if isinstance(include, str) else list(include or [])
+    must_not = [exclude] if isinstance(exclude, str) else list(exclude or [])
+
+    def skipped(path: str) -> bool:
+        return any(s in path for s in must_not)
+
+    def selected(path: str) -> bool:
+        return all(s in path for s in must_have)
+
+    if len(weight_layers) + len(activation_layers) == 0:
+        warnings.warn("No weight or activation layers specified, nothing will be converted.")
+
+    def say(msg):
+        if log:
+            logging.info(msg)
+
+    def instantiate(layer: Optional[nn.Module] = None) -> nn.Module:
+        if layer is None:
+            return copy.deepcopy(operator)
+        factory = quantize if isinstance(operator, QuantizeLayer) else prune
+        return factory(layer, **_fresh_kwargs(operator._kwargs))
+
+    if not inplace:
+        model = copy.deepcopy(model)
+
+    def occurrences(root: nn.Module, layer_types) -> Mapping[str, int]:
+        def count(m: nn.Module, wanted: str, scope: str) -> int:
+            total = 0
+            for child_name, child in m.named_children():
+                path = f"{scope}.{child_name}"
+                if skipped(path):
+                    continue
+                if _is_container(child):
+                    total += count(child, wanted, path)
+                elif _type_name(child) == wanted and selected(path):
+                    total += 1
+            return total
+
+        return {_type_name(t): count(root, _type_name(t), "") for t in layer_types}
+
+    def resolve_exclusions(spec, totals):
+        table = defaultdict(list)
+        for cls, idxs in spec:
+            key = _type_name(cls)
+            table[key] = [i if i >= 0 else i + totals[key] for i in idxs]
+        return table
+
+    root = nn_module(model)
+    w_seen = {_type_name(c): 0 for c in weight_layers}
+    w_excluded = resolve_exclusions(excluded_weight_layer_indexes, occurrences(root, weight_layers))
+    a_seen = {_type_name(c): 0 for c in activation_layers}
+    a_excluded = resolve_exclusions(excluded_activation_layer_indexes, occurrences(root, activation_layers))
+
+    label = str(operator).lower()
+    for token in ("(", ")", "layer"):
+        label = label.replace(token, "")
+    label = f"`{label}`"
+
+    def convert_weights(mod: nn.Module, scope: str = ""):
+        for child_name, child in list(mod.named_children()):
+            path = f"{scope}.{child_name}"
+            if skipped(path):
+                continue
+            if _is_container(child):
+                convert_weights(child, path)
+                continue
+            kind = _type_name(child)
+            if kind not in w_seen:
+                continue
+            if w_seen[kind] not in w_excluded[kind] and selected(path):
+                say(f"Apply {label} on the {path} weight")
+                mod._modules[child_name] = instantiate(child)
+            else:
+                say(f"Exclude {path} weight")
+            w_seen[kind] += 1
+
+    def convert_activations(mod: nn.Module, scope: str = ""):
+        for child_name, child in list(mod.named_children()):
+            path = f"{scope}.{child_name}"
+            if skipped(path):
+                continue
+            if _is_container(child) and not hasattr(child, "_qsparse_conversion"):
+                convert_activations(child, path)
+                continue
+            kind = _type_name(child)
+            if kind not in a_seen:
+                continue
+            if a_seen[kind] not in a_excluded[kind] and selected(path):
+                say(f"Apply {label} on the {path} activation")
+                pair = (child, instantiate()) if order == "post" else (instantiate(), child)
+                wrapped = nn.Sequential(*pair)
+                wrapped._qsparse_conversion = True
+                mod._modules[child_name] = wrapped
+            else:
+                say(f"Exclude {path} activation")
+            a_seen[kind] += 1
+
+    convert_weights(root)
+    convert_activations(root)
+    if input:
+        root = nn.Sequential(instantiate(), root)
+    if root is not nn_module(model):
+        if model is nn_module(model):
+            model = root
+        else:
+            model.module = root
+    auto_name_prune_quantize_layers(nn_module(model))
+    if fuse:
+        from qsparse_amd.fused import fuse_prune_quantize_pairs
+        fuse_prune_quantize_pairs(nn_module(model))
+    return model

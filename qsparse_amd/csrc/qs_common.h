@@ -1,0 +1,201 @@
+// Device-side helpers shared by the kernels of libqsparse_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qsparse_hip.h"
+
+namespace qs {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;        // 4 waves of 64 lanes
+constexpr int kElemsPerThread = 8; // one 16-byte load of a 2-byte dtype, two of fp32
+
+// ---- scalar dtype conversions (round-to-nearest-even, as ATen's CPU casts) ---------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;  // c10::BFloat16 maps every NaN to 0x7FC0
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+template <int DT>
+__device__ __forceinline__ float round_through(float v) {  // value after one rounding to DT
+    if constexpr (DT == QS_BF16) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+    if constexpr (DT == QS_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+    return v;
+}
+
+template <int DT>
+struct ElemBytes {
+    static constexpr int value = (DT == QS_F32) ? 4 : 2;
+};
+
+// ---- scalar element access ---------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ float load1(const void* p, int64_t i) {
+    if constexpr (DT == QS_F32) return ((const float*)p)[i];
+    if constexpr (DT == QS_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    return f16_bits_to_f32(((const uint16_t*)p)[i]);
+}
+template <int DT>
+__device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    if constexpr (DT == QS_F32) ((float*)p)[i] = v;
+    else if constexpr (DT == QS_BF16) ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16_bits(v);
+    else ((uint16_t*)p)[i] = (uint16_t)f32_to_f16_bits(v);
+}
+
+// ---- 8-element vector access: 16 B/lane for 2-byte dtypes, 2 x 16 B/lane for fp32 ----------------
+// `g` indexes groups of 8 elements.  NT selects non-temporal (streaming) accesses.
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int DT>
+struct Raw8 {  // the raw registers of one 8-element group
+    u32x4 a;
+    u32x4 b;  // only used for fp32
+};
+
+template <int DT, bool NT>
+__device__ __forceinline__ Raw8<DT> load8_raw(const void* base, int64_t g) {
+    Raw8<DT> r;
+    if constexpr (DT == QS_F32) {
+        const u32x4* p = (const u32x4*)base + 2 * g;
+        r.a = ld16<NT>(p);
+        r.b = ld16<NT>(p + 1);
+    } else {
+        r.a = ld16<NT>((const u32x4*)base + g);
+    }
+    return r;
+}
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const Raw8<DT>& r, float (&v)[8]) {
+    if constexpr (DT == QS_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = __uint_as_float(r.a[j]);
+            v[4 + j] = __uint_as_float(r.b[j]);
+        }
+    } else if constexpr (DT == QS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = __uint_as_float(r.a[j] << 16);
+            v[2 * j + 1] = __uint_as_float(r.a[j] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = f16_bits_to_f32(r.a[j] & 0xffffu);
+            v[2 * j + 1] = f16_bits_to_f32(r.a[j] >> 16);
+        }
+    }
+}
+
+template <int DT, bool NT>
+__device__ __forceinline__ void store8(void* base, int64_t g, const float (&v)[8]) {
+    if constexpr (DT == QS_F32) {
+        u32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = __float_as_uint(v[j]);
+            b[j] = __float_as_uint(v[4 + j]);
+        }
+        u32x4* p = (u32x4*)base + 2 * g;
+        st16<NT>(p, a);
+        st16<NT>(p + 1, b);
+    } else {
+        u32x4 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t lo, hi;
+            if constexpr (DT == QS_BF16) {
+                lo = f32_to_bf16_bits(v[2 * j]);
+                hi = f32_to_bf16_bits(v[2 * j + 1]);
+            } else {
+                lo = f32_to_f16_bits(v[2 * j]);
+                hi = f32_to_f16_bits(v[2 * j + 1]);
+            }
+            a[j] = lo | (hi << 16);
+        }
+        st16<NT>((u32x4*)base + g, a);
+    }
+}
+
+__device__ __forceinline__ void store8_i32(int32_t* base, int64_t g, const int32_t (&q)[8]) {
+    u32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = (uint32_t)q[j];
+        b[j] = (uint32_t)q[4 + j];
+    }
+    u32x4* p = (u32x4*)base + 2 * g;
+    *p = a;
+    *(p + 1) = b;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// order-preserving map float -> uint32 (NaN of either sign maps to the top, like torch.sort)
+__device__ __forceinline__ uint32_t f32_to_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_f32(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(u);
+}
+
+// channel of a flat element index for an [outer, C, inner] view
+struct ChanIter {
+    uint32_t c, r, C, inner;
+    __device__ __forceinline__ void seek(uint64_t e) {
+        uint64_t row = e / inner;
+        r = (uint32_t)(e - row * inner);
+        c = (uint32_t)(row % C);
+    }
+    __device__ __forceinline__ void next() {
+        if (++r == inner) {
+            r = 0;
+            if (++c == C) c = 0;
+        }
+    }
+};
+
+}  // namespace qs

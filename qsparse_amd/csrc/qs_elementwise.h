@@ -1,0 +1,313 @@
+// Element-wise kernels: quantizer forward (scaler / decimal / line), STE backward, mask apply.
+// All of them are HBM-bound streams: 16-byte loads and stores per lane, several loads in flight per
+// lane, grid-stride over at most kMaxBlocks workgroups.
+#pragma once
+#include "qs_common.h"
+
+namespace qs {
+
+enum ChanMode { CM_SCALAR = 0, CM_ROW = 1, CM_ELEM = 2 };
+
+struct EwGeom {
+    int64_t numel;
+    int64_t ngroups;          // numel / 8
+    uint32_t C;               // channel extent
+    uint32_t inner;           // elements after the channel dim
+    uint32_t groups_per_row;  // inner / 8 (CM_ROW only)
+};
+
+// ------------------------------------------------------------------------------------------------
+// Ops.  Each op exposes
+//   struct P                      per-channel parameters held in registers
+//   P channel(uint32_t c) const   fetch them (c == 0 in scalar mode)
+//   float apply(float v, const P&, int32_t& code) const
+// ------------------------------------------------------------------------------------------------
+
+// ScalerQuantization.forward  (reference qsparse/quantize.py:100-117)
+template <int QDT>
+struct ScalerFwdOp {
+    const float* scale;     // device, nullable
+    float scale_host;
+    const uint8_t* cmask;   // device, nullable: fused channel prune
+    int saturate;
+    int32_t lo, hi;
+    struct P {
+        float s;
+        float keep;
+    };
+    __device__ __forceinline__ P channel(uint32_t c) const {
+        P p;
+        p.s = scale ? scale[c] : scale_host;
+        p.keep = 1.0f;
+        return p;
+    }
+    __device__ __forceinline__ P channel_masked(uint32_t c_scale, uint32_t c_mask) const {
+        P p = channel(c_scale);
+        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        return p;
+    }
+    __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
+        float q = round_through<QDT>(v / p.s);   // correctly rounded fp32 division (:109)
+        int32_t qi = (int32_t)rintf(q);          // half-to-even, then .int()
+        if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
+        code = qi;
+        return (float)qi * p.s;                  // q.float() * scaler (:117)
+    }
+};
+
+// DecimalQuantization.forward  (reference qsparse/quantize.py:44-63)
+template <int QDT>
+struct DecimalFwdOp {
+    const float* decimal;
+    float decimal_host;
+    const uint8_t* cmask;
+    int saturate;
+    int32_t lo, hi;
+    struct P {
+        float toi, tof, keep;
+    };
+    __device__ __forceinline__ static float pow2(float d) {
+        // 2.0 ** d: exact for integral d (what DecimalQuantizer produces)
+        return (d == rintf(d) && fabsf(d) < 150.0f) ? ldexpf(1.0f, (int)d) : exp2f(d);
+    }
+    __device__ __forceinline__ P channel(uint32_t c) const {
+        P p;
+        float d = decimal ? decimal[c] : decimal_host;
+        p.toi = pow2(d);
+        p.tof = pow2(-d);
+        p.keep = 1.0f;
+        return p;
+    }
+    __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
+        P p = channel(c_par);
+        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        return p;
+    }
+    __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        v = v * p.keep;
+        float q = round_through<QDT>(v * p.toi);
+        int32_t qi = (int32_t)q;                 // .int(): truncation toward zero (:55)
+        if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
+        code = qi;
+        return (float)qi * p.tof;
+    }
+};
+
+// LineQuantization.forward  (reference qsparse/quantize.py:148-181)
+template <bool FLOAT_ZP>
+struct LineFwdOp {
+    const float* lines;  // device [nlines, 2]
+    float nlevels;       // 2^bits
+    struct P {
+        float start, end, step, qstart;
+    };
+    __device__ __forceinline__ P channel(uint32_t c) const {
+        P p;
+        p.start = lines[2 * c];
+        p.end = lines[2 * c + 1];
+        float st = (p.end - p.start) / nlevels;          // :159
+        p.step = (st == 0.0f) ? 0.0001f : st;            // :160
+        p.qstart = FLOAT_ZP ? 0.0f : rintf(p.start / p.step);
+        return p;
+    }
+    __device__ __forceinline__ P channel_masked(uint32_t c, uint32_t) const { return channel(c); }
+    __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        float xc = fminf(fmaxf(v, p.start), p.end);      // torch.clamp(x, start, end) (:158)
+        if (v != v) xc = v;
+        const float top = nlevels - 1.0f;
+        if constexpr (FLOAT_ZP) {                        // :175-181
+            float t = xc - p.start;
+            t = t / p.step;
+            t = rintf(t);
+            t = fminf(fmaxf(t, 0.0f), top);
+            code = (int32_t)t;
+            t = t * p.step;
+            return t + p.start;
+        } else {                                         // :161-166
+            float qa = rintf(xc / p.step);
+            qa = fminf(fmaxf(qa - p.qstart, 0.0f), top);
+            code = (int32_t)qa;
+            return (qa + p.qstart) * p.step;
+        }
+    }
+};
+
+// Scaler/DecimalQuantization.backward (reference qsparse/quantize.py:66-77, 120-131), optionally fused
+// with the PruneLayer backward g * mask.
+struct SteBwdOp {
+    const float* step;
+    float step_host;
+    int step_is_decimal;
+    float lo_mul, hi_mul;
+    int passthrough;
+    const uint8_t* cmask;
+    struct P {
+        float lo, hi, keep;
+    };
+    __device__ __forceinline__ P channel(uint32_t c) const {
+        P p;
+        float s = step ? step[c] : step_host;
+        if (step_is_decimal) s = DecimalFwdOp<QS_F32>::pow2(-s);
+        p.lo = lo_mul * s;
+        p.hi = hi_mul * s;
+        p.keep = 1.0f;
+        return p;
+    }
+    __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
+        P p = channel(c_par);
+        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        return p;
+    }
+    __device__ __forceinline__ float apply(float g, const P& p, int32_t& code) const {
+        float v = g;
+        if (!passthrough) {
+            v = fminf(fmaxf(g, p.lo), p.hi);             // clamp_(lo, hi) == min(max(g, lo), hi)
+            if (g != g) v = g;
+        }
+        code = 0;
+        return v * p.keep;                               // g * mask keeps the sign of zero
+    }
+};
+
+// x * mask with a per-channel mask (reference qsparse/sparse.py:66,116,122,263)
+struct ChanMaskOp {
+    const uint8_t* cmask;
+    struct P {
+        float keep;
+    };
+    __device__ __forceinline__ P channel(uint32_t c) const {
+        P p;
+        p.keep = cmask[c] ? 1.0f : 0.0f;
+        return p;
+    }
+    __device__ __forceinline__ P channel_masked(uint32_t, uint32_t c_mask) const { return channel(c_mask); }
+    __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        code = 0;
+        return v * p.keep;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The streaming kernel.  PARAM_PER_CHANNEL tells whether the op's parameter array is indexed by the
+// channel (nparam == C) or is a single value; the channel mask, when present, is always per channel.
+// ------------------------------------------------------------------------------------------------
+template <typename Op, int XDT, int YDT, int CM, bool PARAM_PER_CHANNEL, bool NT, int UNROLL>
+__global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const void* __restrict__ x,
+                                                     void* __restrict__ y, int32_t* __restrict__ codes) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t g0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+
+    typename Op::P p_scalar = op.channel(0);  // used as is in CM_SCALAR
+
+    for (; g0 < geo.ngroups; g0 += stride * UNROLL) {
+        Raw8<XDT> raw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t g = g0 + u * stride;
+            if (g < geo.ngroups) raw[u] = load8_raw<XDT, NT>(x, g);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t g = g0 + u * stride;
+            if (g >= geo.ngroups) break;
+            float v[8];
+            int32_t q[8];
+            unpack8<XDT>(raw[u], v);
+            if constexpr (CM == CM_SCALAR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
+            } else if constexpr (CM == CM_ROW) {
+                const uint32_t row = (uint32_t)((uint64_t)g / geo.groups_per_row);
+                const uint32_t c = row % geo.C;
+                typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, q[j]);
+            } else {
+                ChanIter it;
+                it.C = geo.C;
+                it.inner = geo.inner;
+                it.seek((uint64_t)g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
+                    v[j] = op.apply(v[j], p, q[j]);
+                    it.next();
+                }
+            }
+            store8<YDT, NT>(y, g, v);
+            if (codes) store8_i32(codes, g, q);
+        }
+    }
+
+    // ragged tail (numel % 8 elements), scalar accesses
+    const int64_t tail0 = geo.ngroups * 8;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < geo.numel) {
+        const int64_t e = tail0 + threadIdx.x;
+        ChanIter it;
+        it.C = geo.C;
+        it.inner = geo.inner;
+        it.seek((uint64_t)e);
+        typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
+        int32_t qi;
+        float r = op.apply(load1<XDT>(x, e), p, qi);
+        store1<YDT>(y, e, r);
+        if (codes) codes[e] = qi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mask apply with a full-shape (element-wise) mask, and the general broadcast case.
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool NT>
+__global__ __launch_bounds__(kBlock) void mask_full_kernel(const void* __restrict__ x, const uint8_t* __restrict__ m,
+                                                            void* __restrict__ y, int64_t numel) {
+    const int64_t ngroups = numel / 8;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const bool m_aligned = (((uintptr_t)m) & 7) == 0;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += stride) {
+        Raw8<DT> raw = load8_raw<DT, NT>(x, g);
+        uint8_t mb[8];
+        if (m_aligned) {
+            u32x2 mm = *((const u32x2*)m + g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mb[j] = (mm[0] >> (8 * j)) & 0xff;
+                mb[4 + j] = (mm[1] >> (8 * j)) & 0xff;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mb[j] = m[g * 8 + j];
+        }
+        float v[8];
+        unpack8<DT>(raw, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * (mb[j] ? 1.0f : 0.0f);
+        store8<DT, NT>(y, g, v);
+    }
+    const int64_t e = ngroups * 8 + threadIdx.x;
+    if (blockIdx.x == 0 && e < numel) store1<DT>(y, e, load1<DT>(x, e) * (m[e] ? 1.0f : 0.0f));
+}
+
+struct BcastGeom {
+    int ndim;
+    int64_t sizes[QS_MAX_DIMS];
+    int64_t mstrides[QS_MAX_DIMS];
+};
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mask_bcast_kernel(const void* __restrict__ x, const uint8_t* __restrict__ m,
+                                                             void* __restrict__ y, int64_t numel, BcastGeom geo) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < numel; e += stride) {
+        int64_t rem = e, moff = 0;
+        for (int d = geo.ndim - 1; d >= 0; --d) {
+            const int64_t q = rem / geo.sizes[d];
+            moff += (rem - q * geo.sizes[d]) * geo.mstrides[d];
+            rem = q;
+        }
+        store1<DT>(y, e, load1<DT>(x, e) * (m[moff] ? 1.0f : 0.0f));
+    }
+}
+
+}  // namespace qs

@@ -1,0 +1,500 @@
+// Reductions: abs-max / min-max statistics, staged means in ATen's CPU summation order, k-th order
+// statistic (radix select) and the C-sized "select" step of the fused prune->quantize pair.
+#pragma once
+#include "qs_common.h"
+
+namespace qs {
+
+// =================================================================================================
+// abs-max / min-max.  Results are accumulated with integer atomics on order-preserving keys, so they
+// are independent of the order of arrival (bit-exact on any device).
+//   kind 0: key = bits of |x|  (non-negative floats order like their bit patterns; NaN sorts on top)
+//   kind 1: min and max of x through f32_to_key
+// =================================================================================================
+template <int DT, bool MINMAX>
+struct RedAcc {
+    uint32_t mx = 0u, mn = 0xffffffffu;
+    __device__ __forceinline__ void add(float v) {
+        if constexpr (MINMAX) {
+            uint32_t k = f32_to_key(v);
+            mx = k > mx ? k : mx;
+            mn = k < mn ? k : mn;
+        } else {
+            uint32_t k = __float_as_uint(v) & 0x7fffffffu;
+            mx = k > mx ? k : mx;
+        }
+    }
+    __device__ __forceinline__ void wave_reduce() {
+        mx = wave_max_u32(mx);
+        if constexpr (MINMAX) mn = wave_min_u32(mn);
+    }
+    __device__ __forceinline__ void flush(uint32_t* out_max, uint32_t* out_min, uint32_t idx) const {
+        atomicMax(out_max + idx, mx);
+        if constexpr (MINMAX) atomicMin(out_min + idx, mn);
+    }
+};
+
+// whole tensor -> out[0]
+template <int DT, bool MINMAX>
+__global__ __launch_bounds__(kBlock) void reduce_all_kernel(const void* __restrict__ x, int64_t numel,
+                                                             uint32_t* out_max, uint32_t* out_min) {
+    RedAcc<DT, MINMAX> acc;
+    const int64_t ngroups = numel / 8;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; g + stride < ngroups; g += 2 * stride) {   // two loads in flight per lane
+        Raw8<DT> r0 = load8_raw<DT, false>(x, g);
+        Raw8<DT> r1 = load8_raw<DT, false>(x, g + stride);
+        float v[8];
+        unpack8<DT>(r0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+        unpack8<DT>(r1, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+    }
+    for (; g < ngroups; g += stride) {
+        Raw8<DT> r0 = load8_raw<DT, false>(x, g);
+        float v[8];
+        unpack8<DT>(r0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+    }
+    const int64_t e = ngroups * 8 + threadIdx.x;
+    if (blockIdx.x == 0 && e < numel) acc.add(load1<DT>(x, e));
+
+    __shared__ uint32_t smx[kBlock / 64], smn[kBlock / 64];
+    acc.wave_reduce();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        smx[w] = acc.mx;
+        smn[w] = acc.mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; ++i) {
+            acc.mx = smx[i] > acc.mx ? smx[i] : acc.mx;
+            acc.mn = smn[i] < acc.mn ? smn[i] : acc.mn;
+        }
+        acc.flush(out_max, out_min, 0);
+    }
+}
+
+// per channel, rows of `inner` contiguous elements: one wave per (outer, c) row
+template <int DT, bool MINMAX>
+__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restrict__ x, int64_t rows, uint32_t C,
+                                                              int64_t inner, int vec_ok, uint32_t* out_max,
+                                                              uint32_t* out_min) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        RedAcc<DT, MINMAX> acc;
+        const int64_t base = row * inner;
+        if (vec_ok) {  // inner % 8 == 0 and base pointer aligned: rows start on 16-byte boundaries
+            const int64_t g0 = base / 8, ng = inner / 8;
+            for (int64_t g = lane; g < ng; g += 64) {
+                Raw8<DT> r = load8_raw<DT, false>(x, g0 + g);
+                float v[8];
+                unpack8<DT>(r, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc.add(v[j]);
+            }
+        } else {
+            for (int64_t i = lane; i < inner; i += 64) acc.add(load1<DT>(x, base + i));
+        }
+        acc.wave_reduce();
+        if (lane == 0) acc.flush(out_max, out_min, (uint32_t)(row % C));
+    }
+}
+
+// per channel with a short inner extent (< 64): one thread per (c, inner) column, loop over outer
+template <int DT, bool MINMAX>
+__global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
+                                                              int64_t inner, int64_t outer_per_block,
+                                                              uint32_t* out_max, uint32_t* out_min) {
+    const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= cols) return;
+    const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
+    const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
+    RedAcc<DT, MINMAX> acc;
+    for (int64_t o = o0; o < o1; ++o) acc.add(load1<DT>(x, o * cols + col));
+    if (o1 > o0) acc.flush(out_max, out_min, (uint32_t)(col / inner));
+}
+
+__global__ void keys_init_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        mx[i] = 0u;
+        if (mn) mn[i] = 0xffffffffu;
+    }
+}
+__global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        ((float*)mx)[i] = key_to_f32(mx[i]);
+        ((float*)mn)[i] = key_to_f32(mn[i]);
+    }
+}
+
+// =================================================================================================
+// C-sized state updates
+// =================================================================================================
+__global__ void scale_update_kernel(const float* absmax, float* weight, int64_t n, float t, float tp1, float denom) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float nw = absmax[i] / denom;                       // max / 2**(bits-1)   (quantize.py:340)
+        weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
+    }
+}
+__global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        lines[2 * i] = (lines[2 * i] * tm1 + mn[i]) / t;          // (quantize.py:430)
+        lines[2 * i + 1] = (lines[2 * i + 1] * tm1 + mx[i]) / t;
+    }
+}
+__global__ void decimal_from_scale_kernel(const float* scale, float* d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float r = 1.0f / scale[i];
+        if (r == __builtin_inff() || r == -__builtin_inff()) r = 1.0f;   // nan_to_num(posinf=1, neginf=1)
+        if (r != r) r = 0.0f;                                             // nan -> 0
+        d[i] = rintf(log2f(r));
+    }
+}
+template <int DT>
+__global__ void running_mean_kernel(float* state, const void* nv, int64_t n, float t, float tp1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) state[i] = (t * state[i] + load1<DT>(nv, i)) / tp1;       // sparse.py:89
+}
+__global__ void l0_flag_kernel(const float* mn, int32_t* flag) { *flag = (mn[0] == 0.0f) ? 1 : 0; }
+
+// =================================================================================================
+// Staged mean in ATen's CPU order.  at::mean on CPU (ReduceOps.cpp, mean_out) is
+//     sum(x.to(float32)) -> div_(n) -> to(dtype)
+// and the fp32 sum kernel (cpu/SumKernel.cpp, AVX2 build also on AVX-512 hosts: Vectorized<float> has 8
+// lanes) adds in one of two per-column orders:
+//   "multi-row":  sequential over rows in chunks of 2^p (p = max(4, ceil_log2(n)/4)), chunk sums
+//                 cascaded through 4 levels, levels added at the end;
+//   "row-sum":    rows split 4-way (i mod 4), each part summed in multi-row order over n/4 items, the
+//                 n%4 leftover rows added to part 0, then parts 0+1+2+3.
+// Outer reduction ([n, post], post contiguous): columns below 32*floor(post/32) use multi-row when
+// post >= 8, columns below 4*floor(post/4) when post < 8; all other columns use row-sum.
+// Inner reduction (post == 1, n >= 8): 8 lane accumulators over n/8 vectors in row-sum order, then the
+// n%8 tail summed sequentially from zero, then the 8 lanes added one by one.  n < 8: row-sum over elements.
+// =================================================================================================
+__device__ __forceinline__ int ceil_log2_i64(int64_t x) { return x <= 1 ? 0 : 64 - __builtin_clzll((uint64_t)(x - 1)); }
+
+struct Cascade {  // 4-level cascade accumulator for ONE column
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    __device__ __forceinline__ void add(float v) { a0 += v; }
+    // called after `i` rows have been consumed, i a multiple of the level step
+    __device__ __forceinline__ void carry(int64_t i, int lp, int64_t lmask) {
+        a1 += a0;
+        a0 = 0.f;
+        if ((i & (lmask << lp)) != 0) return;
+        a2 += a1;
+        a1 = 0.f;
+        if ((i & (lmask << (2 * lp))) != 0) return;
+        a3 += a2;
+        a2 = 0.f;
+    }
+    __device__ __forceinline__ float total() const { return ((a0 + a1) + a2) + a3; }
+};
+
+template <int DT>
+__device__ __forceinline__ float mean_prep(float v, int flags, int l0) {
+    if (l0) return (v != 0.0f) ? 1.0f : 0.0f;       // (x != 0).float()  (sparse.py:86)
+    return (flags & QS_MEAN_ABS) ? fabsf(v) : v;    // x.abs()           (sparse.py:87)
+}
+
+// multi-row order of element sequence get(0..n-1)
+template <typename F>
+__device__ __forceinline__ float sum_multi_row(int64_t n, F get) {
+    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    Cascade c;
+    int64_t i = 0;
+    while (i + step <= n) {
+        for (int64_t j = 0; j < step; ++j, ++i) c.add(get(i));
+        c.carry(i, lp, lmask);
+    }
+    for (; i < n; ++i) c.add(get(i));
+    return c.total();
+}
+// row-sum order
+template <typename F>
+__device__ __forceinline__ float sum_row_sum(int64_t n, F get) {
+    const int64_t n4 = n / 4;
+    float p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = sum_multi_row(n4, [&](int64_t i) { return get(4 * i + k); });
+    for (int64_t i = n4 * 4; i < n; ++i) p[0] += get(i);
+    return ((p[0] + p[1]) + p[2]) + p[3];
+}
+
+// ---- hot stage: outer reduction, 8 adjacent columns per lane, multi-row order ---------------------
+// x: [pre, n, post] contiguous; handles columns [0, vcols) of every `pre` slice (vcols % 8 == 0).
+// Optionally accumulates per-channel max|x| (channel = (col / chan_div) % C) for a fused abs-max.
+template <int DT, int ODT, int ROWS_IN_FLIGHT>
+__global__ __launch_bounds__(kBlock) void mean_outer_vec_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                                 int64_t pre, int64_t n, int64_t post, int64_t vcols,
+                                                                 int flags, const int32_t* __restrict__ l0_flag,
+                                                                 uint32_t* __restrict__ absmax, int64_t chan_div,
+                                                                 uint32_t C) {
+    const int64_t gcols = vcols / 8;                 // column groups per slice
+    const int64_t total = pre * gcols;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    const float fn = (float)n;
+    if (t >= total) return;
+
+    const int64_t p = t / gcols, gc = t - p * gcols;
+    const int64_t row_groups = post / 8;             // 16-byte groups per row (post % 8 == 0 guaranteed)
+    const int64_t g_base = p * n * row_groups + gc;
+    Cascade acc[8];
+    uint32_t amax = 0u;
+
+    auto consume = [&](const Raw8<DT>& r) {
+        float v[8];
+        unpack8<DT>(r, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (absmax) {
+                const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
+                amax = k > amax ? k : amax;
+            }
+            acc[j].add(mean_prep<DT>(v[j], flags, l0));
+        }
+    };
+
+    int64_t i = 0;
+    while (i + step <= n) {
+        // step is a power of two >= 16, so it is a multiple of ROWS_IN_FLIGHT (8 or 16)
+        for (int64_t j = 0; j < step; j += ROWS_IN_FLIGHT) {
+            Raw8<DT> r[ROWS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) r[u] = load8_raw<DT, false>(x, g_base + (i + j + u) * row_groups);
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) consume(r[u]);
+        }
+        i += step;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+    }
+    for (; i < n; ++i) consume(load8_raw<DT, false>(x, g_base + i * row_groups));
+
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;     // .div_(n) in fp32, then one rounding to ODT
+    store8<ODT, false>(out, p * row_groups + gc, m);
+
+    if (absmax) {
+        // all 8 columns of a lane share a channel when chan_div % 8 == 0 (checked on the host)
+        const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
+        const uint32_t c0 = __shfl((int)c, 0, 64);
+        if (__all(c == c0)) {
+            amax = wave_max_u32(amax);
+            if ((threadIdx.x & 63) == 0) atomicMax(absmax + c0, amax);
+        } else {
+            atomicMax(absmax + c, amax);
+        }
+    }
+}
+
+// ---- generic stage: one thread per output element, either order -------------------------------------
+template <int DT, int ODT>
+__global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                               int64_t pre, int64_t n, int64_t post, int64_t col0,
+                                                               int flags, const int32_t* __restrict__ l0_flag,
+                                                               uint32_t* __restrict__ absmax, int64_t chan_div,
+                                                               uint32_t C) {
+    const int64_t ncols = post - col0;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= pre * ncols) return;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int64_t p = t / ncols, col = col0 + (t - p * ncols);
+    const int64_t base = p * n * post + col;
+    uint32_t amax = 0u;
+    auto get = [&](int64_t i) {
+        const float v = load1<DT>(x, base + i * post);
+        if (absmax) {
+            const uint32_t k = __float_as_uint(v) & 0x7fffffffu;
+            amax = k > amax ? k : amax;
+        }
+        return mean_prep<DT>(v, flags, l0);
+    };
+    float s;
+    if (post == 1) {
+        if (n >= 8) {  // vectorized inner sum: 8 lanes, row-sum order over n/8 vectors
+            const int64_t nv = n / 8;
+            float lanes[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lanes[k] = sum_row_sum(nv, [&](int64_t i) { return get(8 * i + k); });
+            float fin = 0.f;
+            for (int64_t i = nv * 8; i < n; ++i) fin += get(i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fin += lanes[k];
+            s = fin;
+        } else {
+            s = sum_row_sum(n, get);
+        }
+    } else {
+        const int64_t mr_cols = (post >= 8) ? (post / 32) * 32 : (post / 4) * 4;
+        s = (col < mr_cols) ? sum_multi_row(n, get) : sum_row_sum(n, get);
+    }
+    store1<ODT>(out, p * post + col, s / (float)n);
+    if (absmax) atomicMax(absmax + (uint32_t)((col / chan_div) % C), amax);
+}
+
+// =================================================================================================
+// k-th order statistic by 4-pass radix select on order-preserving keys.
+// =================================================================================================
+struct SelectState {
+    uint32_t prefix;   // key bits fixed so far
+    uint32_t k;        // rank still to find inside the surviving set
+    uint32_t hist[256];
+};
+
+// multi-block pass: histogram of byte `pass` (3 = most significant) among keys matching the prefix
+__global__ __launch_bounds__(kBlock) void select_hist_kernel(const float* __restrict__ imp, int64_t n, int pass,
+                                                              SelectState* st) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = st->prefix;
+    const int shift = 8 * pass;
+    const uint32_t himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = f32_to_key(imp[i]);
+        if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+// single-thread-block scan: pick the bin holding rank k, descend
+__global__ void select_scan_kernel(SelectState* st, int pass, float* thr) {
+    if (threadIdx.x == 0) {
+        uint32_t k = st->k, cum = 0;
+        int b = 0;
+        for (; b < 256; ++b) {
+            const uint32_t c = st->hist[b];
+            if (cum + c > k) break;
+            cum += c;
+        }
+        if (b == 256) b = 255;
+        st->k = k - cum;
+        st->prefix |= ((uint32_t)b) << (8 * pass);
+        if (pass == 0 && thr) *thr = key_to_f32(st->prefix);
+    }
+    __syncthreads();
+    st->hist[threadIdx.x] = 0;   // blockDim.x == 256
+}
+__global__ void select_init_kernel(SelectState* st, uint32_t k) {
+    st->hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        st->prefix = 0;
+        st->k = k;
+    }
+}
+
+// in-block radix select over a global array small enough for one workgroup; returns the key of rank k
+template <int THREADS>
+__device__ uint32_t block_select_key(const float* v, int64_t n, uint32_t k, uint32_t* sh_hist /*256*/,
+                                     uint32_t* sh_state /*2*/) {
+    uint32_t prefix = 0;
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int i = threadIdx.x; i < 256; i += THREADS) sh_hist[i] = 0;
+        __syncthreads();
+        const int shift = 8 * pass;
+        const uint32_t himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
+        for (int64_t i = threadIdx.x; i < n; i += THREADS) {
+            const uint32_t key = f32_to_key(v[i]);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&sh_hist[(key >> shift) & 0xff], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cum = 0;
+            int b = 0;
+            for (; b < 256; ++b) {
+                const uint32_t c = sh_hist[b];
+                if (cum + c > k) break;
+                cum += c;
+            }
+            if (b == 256) b = 255;
+            sh_state[0] = prefix | (((uint32_t)b) << shift);
+            sh_state[1] = k - cum;
+        }
+        __syncthreads();
+        prefix = sh_state[0];
+        k = sh_state[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+constexpr int kSelectThreads = 1024;
+
+__global__ __launch_bounds__(kSelectThreads) void kth_small_kernel(const float* __restrict__ imp, int64_t n, uint32_t k,
+                                                                    float* thr) {
+    __shared__ uint32_t sh_hist[256];
+    __shared__ uint32_t sh_state[2];
+    const uint32_t key = block_select_key<kSelectThreads>(imp, n, k, sh_hist, sh_state);
+    if (threadIdx.x == 0) *thr = key_to_f32(key);
+}
+
+__global__ __launch_bounds__(kBlock) void mask_ge_kernel(const float* __restrict__ imp, const float* __restrict__ thr,
+                                                          uint8_t* __restrict__ mask, int64_t n) {
+    const float t = *thr;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) mask[i] = imp[i] >= t ? 1 : 0;
+}
+
+// =================================================================================================
+// fused C-sized step of the channel-prune -> tensor-wise-quantize pair (see qsparse_hip.h)
+// =================================================================================================
+template <int SDT>
+__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __restrict__ magnitude,
+                                                                    const void* __restrict__ stage, int64_t C,
+                                                                    int update_magnitude, float t_mag, float t_mag1,
+                                                                    int refresh_mask, uint32_t k,
+                                                                    uint8_t* __restrict__ mask,
+                                                                    const uint32_t* __restrict__ chan_absmax,
+                                                                    int update_scale, float t_q, float t_q1,
+                                                                    float denom, float* __restrict__ scale) {
+    __shared__ uint32_t sh_hist[256];
+    __shared__ uint32_t sh_state[2];
+    __shared__ uint32_t sh_max[kSelectThreads / 64];
+    if (update_magnitude) {
+        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads)
+            magnitude[i] = (t_mag * magnitude[i] + load1<SDT>(stage, i)) / t_mag1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (refresh_mask) {
+        const uint32_t key = block_select_key<kSelectThreads>(magnitude, C, k, sh_hist, sh_state);
+        const float thr = key_to_f32(key);
+        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads) mask[i] = magnitude[i] >= thr ? 1 : 0;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (update_scale) {
+        uint32_t m = 0u;
+        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads)
+            if (mask[i]) m = chan_absmax[i] > m ? chan_absmax[i] : m;
+        m = wave_max_u32(m);
+        if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < kSelectThreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
+            const float nw = __uint_as_float(m) / denom;
+            scale[0] = (t_q == 0.0f) ? nw : (t_q * scale[0] + nw) / t_q1;
+        }
+    }
+}
+
+}  // namespace qs

@@ -1,0 +1,518 @@
+// libqsparse_hip.so -- C ABI (include/qsparse_hip.h) over the gfx950 kernels in qs_elementwise.h and
+// qs_reduce.h.  Host side: argument checks, geometry, launch configuration.  No allocation, no
+// synchronisation: every entry point only enqueues work on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "qs_elementwise.h"
+#include "qs_reduce.h"
+
+#ifndef QS_EW_UNROLL
+#define QS_EW_UNROLL 2
+#endif
+#ifndef QS_EW_NT
+#define QS_EW_NT 1
+#endif
+#ifndef QS_MEAN_ROWS_IN_FLIGHT
+#define QS_MEAN_ROWS_IN_FLIGHT 8
+#endif
+
+using namespace qs;
+
+namespace {
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+// streaming kernels: grid-stride over at most this many workgroups (256 CUs x 8)
+inline int max_blocks() {
+    static int v = env_int("QS_MAX_BLOCKS", 2048);
+    return v;
+}
+inline int mean_block() {
+    static int v = env_int("QS_MEAN_BLOCK", 64);
+    return v;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+inline int dt_ok(int dt) { return dt == QS_F32 || dt == QS_BF16 || dt == QS_F16; }
+inline int elem_bytes(int dt) { return dt == QS_F32 ? 4 : 2; }
+inline int hip_status(hipError_t e) { return (int)e; }
+inline int launch_status() { return hip_status(hipGetLastError()); }
+
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+template <typename F>
+int with_dtype(int dt, F&& f) {
+    switch (dt) {
+        case QS_F32: return f(IC<QS_F32>{});
+        case QS_BF16: return f(IC<QS_BF16>{});
+        case QS_F16: return f(IC<QS_F16>{});
+    }
+    return QS_ERR_DTYPE;
+}
+
+int grid_for(int64_t ngroups, int unroll) {
+    int64_t b = (ngroups + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
+    if (b < 1) b = 1;
+    if (b > max_blocks()) b = max_blocks();
+    return (int)b;
+}
+
+// geometry + channel mode of an element-wise launch over [outer, C, inner]
+struct EwPlan {
+    EwGeom geo;
+    int cm;
+};
+int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* plan) {
+    if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
+    const int64_t numel = outer * C * inner;
+    if (numel / 8 >= ((int64_t)1 << 32) || C >= ((int64_t)1 << 32) || inner >= ((int64_t)1 << 32)) return QS_ERR_ARG;
+    plan->geo.numel = numel;
+    plan->geo.ngroups = numel / 8;
+    plan->geo.C = (uint32_t)C;
+    plan->geo.inner = (uint32_t)inner;
+    plan->geo.groups_per_row = (uint32_t)(inner / 8);
+    if (!per_channel) plan->cm = CM_SCALAR;
+    else if (inner % 8 == 0) plan->cm = CM_ROW;
+    else plan->cm = CM_ELEM;
+    return QS_OK;
+}
+
+template <typename Op, int XDT, int YDT>
+int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
+              hipStream_t s) {
+    if (plan.geo.numel == 0) return QS_OK;
+    constexpr bool NT = QS_EW_NT != 0;
+    constexpr int U = QS_EW_UNROLL;
+    const int grid = grid_for(plan.geo.ngroups, U);
+    switch (plan.cm) {
+        case CM_SCALAR:
+            hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                               plan.geo, x, y, codes);
+            break;
+        case CM_ROW:
+            if (param_per_channel)
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, true, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, y, codes);
+            else
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, y, codes);
+            break;
+        default:
+            if (param_per_channel)
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, true, NT, 1>), dim3(grid_for(plan.geo.ngroups, 1)),
+                                   dim3(kBlock), 0, s, op, plan.geo, x, y, codes);
+            else
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, false, NT, 1>), dim3(grid_for(plan.geo.ngroups, 1)),
+                                   dim3(kBlock), 0, s, op, plan.geo, x, y, codes);
+            break;
+    }
+    return launch_status();
+}
+
+int check_param(const float* p, int64_t nparam, int64_t C) {
+    if (p == nullptr) return nparam == 1 ? QS_OK : QS_ERR_ARG;
+    if (nparam != 1 && nparam != C) return QS_ERR_ARG;
+    return QS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qs_version(void) { return QS_ABI_VERSION; }
+
+const char* qs_status_string(int status) {
+    switch (status) {
+        case QS_OK: return "ok";
+        case QS_ERR_DTYPE: return "qsparse_hip: unsupported dtype combination";
+        case QS_ERR_ARG: return "qsparse_hip: inconsistent arguments";
+        case QS_ERR_ALIGN: return "qsparse_hip: data pointer is not 16-byte aligned";
+        case QS_ERR_WORKSPACE: return "qsparse_hip: workspace too small";
+        case QS_ERR_RANK: return "qsparse_hip: broadcast pattern has too many dimensions";
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "qsparse_hip: unknown status";
+}
+
+size_t qs_workspace_bytes(int op, int64_t n) {
+    (void)n;
+    switch (op) {
+        case QS_WS_KTH_VALUE: return sizeof(SelectState);
+        case QS_WS_PQ_STATS: return 0;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
+                        const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
+                        int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
+    if (!x || !y) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
+    if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
+    if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
+    int st = check_param(scale, nscale, C);
+    if (st) return st;
+    const bool ppc = nscale > 1;
+    EwPlan plan;
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto go = [&](auto Y, auto Q) {
+            constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
+            ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi};
+            return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
+        };
+        if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
+        return (qdt == QS_F32) ? go(X, IC<QS_F32>{}) : go(X, X);
+    });
+}
+
+int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
+                         float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
+                         int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
+    if (!x || !y) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
+    if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
+    if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
+    int st = check_param(decimal, ndecimal, C);
+    if (st) return st;
+    const bool ppc = ndecimal > 1;
+    EwPlan plan;
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto go = [&](auto Y, auto Q) {
+            constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
+            DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi};
+            return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
+        };
+        if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
+        return (qdt == QS_F32) ? go(X, IC<QS_F32>{}) : go(X, X);
+    });
+}
+
+int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines, int bits, int float_zero_point,
+                      int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, qs_stream_t stream) {
+    if (!x || !y || !lines) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || ydt != QS_F32) return QS_ERR_DTYPE;
+    if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
+    if (bits < 1 || bits > 24) return QS_ERR_ARG;
+    int st = check_param(lines, nlines, C);
+    if (st) return st;
+    const bool ppc = nlines > 1;
+    EwPlan plan;
+    st = plan_ew(outer, C, inner, ppc, &plan);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    const float nlevels = (float)(1 << bits);
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        if (float_zero_point) {
+            LineFwdOp<true> op{lines, nlevels};
+            return launch_ew<LineFwdOp<true>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
+        }
+        LineFwdOp<false> op{lines, nlevels};
+        return launch_ew<LineFwdOp<false>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
+    });
+}
+
+int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, float step_host, int step_is_decimal,
+                     float lo_mul, float hi_mul, int passthrough, const uint8_t* chan_mask, int64_t outer, int64_t C,
+                     int64_t inner, int gdt, int gxdt, qs_stream_t stream) {
+    if (!g || !gx) return QS_ERR_ARG;
+    if (!dt_ok(gdt) || !dt_ok(gxdt)) return QS_ERR_DTYPE;
+    if (!(gdt == QS_F32 || gdt == gxdt)) return QS_ERR_DTYPE;
+    if (!aligned16(g) || !aligned16(gx)) return QS_ERR_ALIGN;
+    int st = check_param(step, nstep, C);
+    if (st) return st;
+    const bool ppc = nstep > 1;
+    EwPlan plan;
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, passthrough, chan_mask};
+    return with_dtype(gxdt, [&](auto GX) {
+        constexpr int GXD = decltype(GX)::value;
+        if (gdt == QS_F32) return launch_ew<SteBwdOp, QS_F32, GXD>(op, plan, ppc, g, gx, nullptr, s);
+        return launch_ew<SteBwdOp, GXD, GXD>(op, plan, ppc, g, gx, nullptr, s);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
+                       int64_t inner, int xdt, hipStream_t s) {
+    if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
+    if (!dt_ok(xdt)) return QS_ERR_DTYPE;
+    if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
+    const int64_t numel = outer * C * inner;
+    const int64_t nout = per_channel ? C : 1;
+    uint32_t* omax = (uint32_t*)(minmax ? out_b : out_a);
+    uint32_t* omin = minmax ? (uint32_t*)out_a : nullptr;
+    const int ib = (int)((nout + 255) / 256);
+    hipLaunchKernelGGL(keys_init_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    if (numel > 0) {
+        const bool vec_ptr = aligned16(x);
+        int st = with_dtype(xdt, [&](auto X) {
+            constexpr int XD = decltype(X)::value;
+            auto run = [&](auto MM) {
+                constexpr bool M = decltype(MM)::value != 0;
+                if (!per_channel) {
+                    if (!vec_ptr) return (int)QS_ERR_ALIGN;
+                    const int grid = grid_for(numel / 8, 2);
+                    hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin);
+                } else if (inner >= 64) {
+                    const int64_t rows = outer * C;
+                    int64_t blocks = (rows + 3) / 4;
+                    if (blocks > max_blocks()) blocks = max_blocks();
+                    const int vec_ok = vec_ptr && (inner % 8 == 0);
+                    hipLaunchKernelGGL((reduce_rows_kernel<XD, M>), dim3((int)blocks), dim3(kBlock), 0, s, x, rows,
+                                       (uint32_t)C, inner, vec_ok, omax, omin);
+                } else {
+                    const int64_t cols = C * inner;
+                    const int gx = (int)((cols + kBlock - 1) / kBlock);
+                    int64_t gy = 1;
+                    if (gx < 512) gy = (512 + gx - 1) / gx;
+                    if (gy > outer) gy = outer;
+                    if (gy < 1) gy = 1;
+                    const int64_t opb = (outer + gy - 1) / gy;
+                    hipLaunchKernelGGL((reduce_cols_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer, cols,
+                                       inner, opb, omax, omin);
+                }
+                return launch_status();
+            };
+            return minmax ? run(IC<1>{}) : run(IC<0>{});
+        });
+        if (st) return st;
+    }
+    if (minmax) hipLaunchKernelGGL(keys_to_float_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    return launch_status();
+}
+
+int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt,
+              qs_stream_t stream) {
+    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
+}
+
+int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
+              int xdt, qs_stream_t stream) {
+    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
+}
+
+int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, int bits, qs_stream_t stream) {
+    if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    hipLaunchKernelGGL(scale_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, absmax,
+                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)));
+    return launch_status();
+}
+
+int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, qs_stream_t stream) {
+    if (!mn || !mx || !lines || n < 0 || t_after < 1) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    hipLaunchKernelGGL(lines_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn, mx,
+                       lines, n, (float)(t_after - 1), (float)t_after);
+    return launch_status();
+}
+
+int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stream_t stream) {
+    if (!scale || !decimal || n < 0) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    hipLaunchKernelGGL(decimal_from_scale_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scale,
+                       decimal, n);
+    return launch_status();
+}
+
+int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
+                const int32_t* l0_flag, float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream) {
+    if (!x || !out || pre < 1 || n < 1 || post < 1) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
+    if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    if (absmax_out && (chan_div < 1 || C < 1)) return QS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (absmax_out) {
+        hipError_t e = hipMemsetAsync(absmax_out, 0, sizeof(float) * (size_t)C, s);
+        if (e != hipSuccess) return hip_status(e);
+    }
+    int64_t vcols = 0;
+    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!absmax_out || chan_div % 8 == 0))
+        vcols = (post / 32) * 32;
+    uint32_t* am = (uint32_t*)absmax_out;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto run = [&](auto O) {
+            constexpr int OD = decltype(O)::value;
+            if (vcols > 0) {
+                const int64_t total = pre * (vcols / 8);
+                const int bs = mean_block();
+                hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT>),
+                                   dim3((int)((total + bs - 1) / bs)), dim3(bs), 0, s, x, out, pre, n, post, vcols, flags,
+                                   l0_flag, am, chan_div, (uint32_t)(C > 0 ? C : 1));
+            }
+            if (vcols < post) {
+                const int64_t total = pre * (post - vcols);
+                hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
+                                   0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1,
+                                   (uint32_t)(C > 0 ? C : 1));
+            }
+            return launch_status();
+        };
+        return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
+    });
+}
+
+int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scratch2, qs_stream_t stream) {
+    if (!flag || !scratch2) return QS_ERR_ARG;
+    int st = reduce_impl(x, scratch2, scratch2 + 1, true, 0, 1, 1, numel > 0 ? numel : 1, xdt, (hipStream_t)stream);
+    if (st) return st;
+    hipLaunchKernelGGL(l0_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scratch2, flag);
+    return launch_status();
+}
+
+int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, qs_stream_t stream) {
+    if (!state || !newv || n < 0 || t < 0) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    return with_dtype(newdt, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((running_mean_kernel<DD>), dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           state, newv, n, (float)t, (float)(t + 1));
+        return launch_status();
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+int qs_kth_value(const float* imp, int64_t n, int64_t k, float* thr, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    if (!imp || !thr || n < 1 || k < 0 || k >= n || n >= ((int64_t)1 << 32)) return QS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 32768) {
+        hipLaunchKernelGGL(kth_small_kernel, dim3(1), dim3(kSelectThreads), 0, s, imp, n, (uint32_t)k, thr);
+        return launch_status();
+    }
+    if (!ws || ws_bytes < sizeof(SelectState)) return QS_ERR_WORKSPACE;
+    SelectState* st = (SelectState*)ws;
+    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, st, (uint32_t)k);
+    int64_t blocks = (n + kBlock * 8 - 1) / (kBlock * 8);
+    if (blocks > 1024) blocks = 1024;
+    for (int pass = 3; pass >= 0; --pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3((int)blocks), dim3(kBlock), 0, s, imp, n, pass, st);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(256), 0, s, st, pass, thr);
+    }
+    return launch_status();
+}
+
+int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_stream_t stream) {
+    if (!imp || !thr || !mask || n < 0) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > max_blocks()) blocks = max_blocks();
+    hipLaunchKernelGGL(mask_ge_kernel, dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, imp, thr, mask, n);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes, const int64_t* mask_strides,
+                  int dt, qs_stream_t stream) {
+    if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1) return QS_ERR_ARG;
+    if (!dt_ok(dt)) return QS_ERR_DTYPE;
+    if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    // collapse: drop extent-1 dims, merge neighbours that are both broadcast or contiguous in the mask
+    int64_t cs[64], cm[64];
+    int nd = 0;
+    int64_t numel = 1;
+    if (ndim > 64) return QS_ERR_RANK;
+    for (int d = 0; d < ndim; ++d) {
+        if (sizes[d] < 0) return QS_ERR_ARG;
+        numel *= sizes[d];
+        if (sizes[d] == 1) continue;
+        const int64_t ms = mask_strides[d];
+        if (nd > 0 && ((cm[nd - 1] == 0 && ms == 0) || (ms != 0 && cm[nd - 1] == ms * sizes[d]))) {
+            cs[nd - 1] *= sizes[d];
+            cm[nd - 1] = ms;
+        } else {
+            cs[nd] = sizes[d];
+            cm[nd] = ms;
+            ++nd;
+        }
+    }
+    if (numel == 0) return QS_OK;
+    if (nd == 0) {  // single element
+        cs[0] = 1;
+        cm[0] = 0;
+        nd = 1;
+    }
+    // pattern A: [outer bcast][C dense, unit stride][inner bcast]
+    int64_t outer = 1, C = 1, inner = 1;
+    bool pattern_a = false, full = false;
+    if (nd == 1 && cm[0] == 1) full = true;
+    else if (nd == 1 && cm[0] == 0) { pattern_a = true; outer = cs[0]; }
+    else if (nd == 2 && cm[0] == 0 && cm[1] == 1) { pattern_a = true; outer = cs[0]; C = cs[1]; }
+    else if (nd == 2 && cm[0] == 1 && cm[1] == 0) { pattern_a = true; C = cs[0]; inner = cs[1]; }
+    else if (nd == 3 && cm[0] == 0 && cm[1] == 1 && cm[2] == 0) { pattern_a = true; outer = cs[0]; C = cs[1]; inner = cs[2]; }
+
+    if (pattern_a) {
+        EwPlan plan;
+        int st = plan_ew(outer, C, inner, true, &plan);
+        if (st) return st;
+        ChanMaskOp op{mask};
+        return with_dtype(dt, [&](auto D) {
+            constexpr int DD = decltype(D)::value;
+            return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s);
+        });
+    }
+    if (full) {
+        const int grid = grid_for(numel / 8, 1);
+        return with_dtype(dt, [&](auto D) {
+            constexpr int DD = decltype(D)::value;
+            hipLaunchKernelGGL((mask_full_kernel<DD, (QS_EW_NT != 0)>), dim3(grid), dim3(kBlock), 0, s, x, mask, y, numel);
+            return launch_status();
+        });
+    }
+    if (nd > QS_MAX_DIMS) return QS_ERR_RANK;
+    BcastGeom geo;
+    geo.ndim = nd;
+    for (int d = 0; d < nd; ++d) {
+        geo.sizes[d] = cs[d];
+        geo.mstrides[d] = cm[d];
+    }
+    int64_t blocks = (numel + kBlock - 1) / kBlock;
+    if (blocks > max_blocks() * 4) blocks = max_blocks() * 4;
+    return with_dtype(dt, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((mask_bcast_kernel<DD>), dim3((int)blocks), dim3(kBlock), 0, s, x, mask, y, numel, geo);
+        return launch_status();
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
+                 int refresh_mask, int64_t k, uint8_t* mask, const float* chan_absmax, int update_scale, int64_t t_q,
+                 int bits, float* scale, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    (void)ws;
+    (void)ws_bytes;
+    if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
+    if (update_magnitude && (!stage_mean || t_mag < 0)) return QS_ERR_ARG;
+    if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
+    if (update_scale && (!chan_absmax || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
+    if (!dt_ok(sdt)) return QS_ERR_DTYPE;
+    return with_dtype(sdt, [&](auto S) {
+        constexpr int SD = decltype(S)::value;
+        hipLaunchKernelGGL((pq_select_kernel<SD>), dim3(1), dim3(kSelectThreads), 0, (hipStream_t)stream, magnitude,
+                           stage_mean, C, update_magnitude, (float)t_mag, (float)(t_mag + 1), refresh_mask, (uint32_t)k,
+                           mask, (const uint32_t*)chan_absmax, update_scale, (float)t_q, (float)(t_q + 1),
+                           (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0)), scale);
+        return launch_status();
+    });
+}
+
+}  // extern "C"

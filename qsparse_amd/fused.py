@@ -1,0 +1,196 @@
+"""Fused channel-prune -> tensor-wise-quantize pair (kernels K9/K10 of SURVEY.md section 2).
+
+``convert`` builds, for every activation site that is first pruned and then quantized,
+``Sequential(Sequential(act, PruneLayer), QuantizeLayer)`` (reference qsparse/convert.py:214-218).  Run
+module by module that is, per training step, 2 statistics reads + 2 element-wise passes forward and
+2 passes backward.  ``FusedPruneQuantize`` keeps the very same children (and therefore the same
+``state_dict`` keys, names and ``str()``) but executes the pair as
+
+    stats   one read of x:  staged mean|x| per channel  +  per-channel max|x|          (qs_mean_dim)
+    select  C-sized:        running magnitude, k-th value, mask, max over kept channels,
+                            running scale                                               (qs_pq_select)
+    apply   one read of x, one write of y:  y = dequant(quant(x * mask[c]))             (qs_quant_*_fwd)
+    bwd     one read of g, one write of gx: gx = clamp(g) * mask[c]                      (qs_quant_ste_bwd)
+
+The state machines of both layers (schedules, counters, refresh policy: reference sparse.py:215-273,
+99-122 and quantize.py:473-518, 327-349) advance exactly as if the layers had run one after the other;
+``tests/test_fused_gpu.py`` checks the trajectories against the unfused path and the oracle.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from qsparse_amd import _hip
+from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
+from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer
+from qsparse_amd.util import _reduction_plan, _staged_mean_hip, get_option, logging, threshold_rank
+from qsparse_amd import distributed as qdist
+
+
+def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
+    if not h.is_cuda or h.dim() < 2 or h.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return False
+    cb, qc = p.callback, q.callback
+    if type(cb) is not MagnitudePruningCallback or cb.use_gradient or not cb.running_average or cb.l0:
+        return False
+    if p.dimensions != {1} or h.shape[1] > 65536 or h.shape[1] < 2:
+        return False
+    if type(qc) not in (ScalerQuantizer, DecimalQuantizer) or qc.group_num > 0 or q.channelwise != -1:
+        return False
+    if qc.backward_passthrough:
+        return False
+    inner = 1
+    for s in h.shape[2:]:
+        inner *= s
+    return inner % 8 == 0 or h.dim() == 2
+
+
+class _FusedApply(torch.autograd.Function):
+    """y = Q(x * mask) forward, gx = clamp(g) * mask backward, each one pass over the tensor."""
+
+    @staticmethod
+    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on):
+        ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
+        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale)
+        ctx.has_mask = mask_c is not None
+        if not quant_on:
+            return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
+        if kind == "scaler":
+            y, _ = _hip.quant_fwd("scaler", h, scale, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1)
+        else:
+            y, _ = _hip.quant_fwd("decimal", h, _hip.decimal_from_scale(scale), -1, torch.float32, chan_mask=mask_c,
+                                  mask_channel_index=1)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        mask_c, scale = ctx.saved_tensors
+        mask_c = mask_c if ctx.has_mask else None
+        if not ctx.quant_on:
+            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 6
+        limit = 2.0 ** (ctx.bits - 1)
+        step = scale if ctx.kind == "scaler" else _hip.decimal_from_scale(scale)
+        out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
+        gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
+                          out_dtype, chan_mask=mask_c, mask_channel_index=1)
+        return (gx,) + (None,) * 6
+
+
+def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> torch.Tensor:
+    """one training / evaluation step of ``q(p(h))`` on a GPU tensor."""
+    cb, qc = p.callback, q.callback
+    C = h.shape[1]
+
+    # ---- PruneLayer.forward bookkeeping (reference sparse.py:228-273) ----
+    if not p.initted:
+        p._lazy_init(h)
+    n = p.advance_schedule()
+    prune_on = True
+    update_mag = refresh = False
+    t_mag = 0
+    k = 0
+    if p.training and p.mask.numel() != 1:
+        if n >= p.start:
+            if n == p.start and get_option("log_during_train"):
+                logging.warning(f"Start pruning at {p.name} @ {n}")
+            sparsity = p.current_sparsity()
+            t_mag = cb.begin_step(p.mask)
+            update_mag = t_mag < cb.stop_mask_refresh
+            refresh = cb.refresh_due(t_mag, sparsity)
+            if refresh:
+                k = threshold_rank(sparsity, C)
+                if k >= C:
+                    raise IndexError(f"index {k} is out of bounds for dimension 0 with size {C}")
+        else:
+            prune_on = False
+
+    # ---- QuantizeLayer.forward bookkeeping (reference quantize.py:482-517) ----
+    if not q.initted:
+        q._lazy_init(h)
+    quant_on = update_scale = False
+    t_q = 0
+    if q.timeout > 0:
+        tq = q._steps.read(q._n_updates)
+        if tq >= q.timeout:
+            if q.training:
+                if tq == q.timeout and get_option("log_during_train"):
+                    logging.warn(f"quantizing {q.name} with {q.bits} bits")
+                update_scale = True
+                t_q = qc.t
+                q._quantized = True
+            quant_on = q._quantized
+
+    # ---- statistics: one read of h ----
+    with torch.no_grad():
+        hd = h.detach()
+        stage = chan_absmax = None
+        world = qdist.stats_world_size()
+        if update_scale and not prune_on:
+            # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
+            am = qdist.allreduce_max_(_hip.absmax(hd, -1), world)
+            _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits)
+        else:
+            if update_mag:
+                if update_scale:
+                    chan_absmax = torch.empty(C, dtype=torch.float32, device=h.device)
+                dims = _reduction_plan(hd.shape, p.mask.shape)
+                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax,
+                                         absmax_channel_dim=1).view(-1)
+            elif update_scale:
+                chan_absmax = _hip.absmax(hd, 1)
+            if world > 1:
+                stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
+            if update_mag or refresh or update_scale:
+                mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)
+                _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1),
+                               chan_absmax, update_scale, t_q, q.bits, q.weight.data)
+        if update_scale:
+            qc.t += 1
+
+    # ---- counters (same order as the unfused layers) ----
+    if p.training and p.mask.numel() != 1:
+        if n >= p.start:
+            cb.end_step(p.mask, p.name)
+        p._steps.add(p._n_updates, 1)
+    if q.timeout > 0 and q.training:
+        q._steps.add(q._n_updates, 1)
+
+    # ---- apply: one read of h, one write ----
+    if not prune_on and not quant_on:
+        return h
+    kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
+    return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0,
+                             quant_on)
+
+
+class FusedPruneQuantize(nn.Sequential):
+    """``Sequential(Sequential(act, PruneLayer), QuantizeLayer)`` with a fused GPU forward/backward.
+    Children, parameter names and ``str()`` are those of the plain ``Sequential`` it replaces."""
+
+    def forward(self, x):
+        inner, q = self[0], self[1]
+        act, p = inner[0], inner[1]
+        h = act(x)
+        if _eligible(p, q, h):
+            return fused_prune_quantize(p, q, h)
+        return q(p(h))
+
+
+FusedPruneQuantize.__name__ = "Sequential"   # keep str(model) identical to the reference's tree
+
+
+def _is_pair(m: nn.Module) -> bool:
+    if type(m) is not nn.Sequential or len(m) != 2 or not isinstance(m[1], QuantizeLayer):
+        return False
+    inner = m[0]
+    return (type(inner) is nn.Sequential and len(inner) == 2 and isinstance(inner[1], PruneLayer)
+            and not isinstance(inner[0], (PruneLayer, QuantizeLayer)))
+
+
+def fuse_prune_quantize_pairs(model: nn.Module) -> nn.Module:
+    """re-class every convert-built prune->quantize pair in ``model`` (in place)."""
+    for m in model.modules():
+        if _is_pair(m):
+            m.__class__ = FusedPruneQuantize
+    return model

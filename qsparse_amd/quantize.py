@@ -1,0 +1,441 @@
+"""Quantization operators with straight-through gradients -- API of the reference's qsparse/quantize.py.
+
+Same public names, arguments, state (``weight``, ``_n_updates``, optional ``callback.groups``) and
+numerics as mlzxy/qsparse v2.0.1, but the tensor math runs as hand-written HIP kernels whenever the
+tensor lives on the GPU (``libqsparse_hip.so``: qs_quant_*_fwd, qs_quant_ste_bwd, qs_absmax, qs_minmax,
+qs_scale_update, qs_lines_update); CPU tensors take the equivalent ATen expression so that the host
+logic can be exercised without a device.  GPU tensors never take the ATen route: if the library is
+missing they raise ``QsparseHipError``.
+
+Numerical contract (reference file:line in comments): forward never saturates (the clamp at
+quantize.py:56-62/110-116 acts on a temporary), scaler rounds half-to-even after a true division,
+decimal truncates, the backward clamps gradient *values* into ``[(-L+notch)*s, (L-1+notch)*s]``.
+"""
+import math
+from typing import List, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from qsparse_amd import _hip
+from qsparse_amd.common import HostMirror, TensorOrFloat, TensorOrInt, ensure_tensor
+from qsparse_amd.imitation import imitate
+from qsparse_amd.util import get_option, logging
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------
+def _on_channel(p, ndim: int, channel_index: int, length: int):
+    """reshape a multi-element parameter so that it broadcasts along ``channel_index``."""
+    if isinstance(p, torch.Tensor) and p.numel() > 1:
+        assert len(p) == length, "channel of input and decimal must be equal in channel-wise quantization"
+        view = [1] * ndim
+        view[channel_index] = -1
+        return p.view(*view)
+    return p
+
+
+def _quotient_dtype(x: torch.Tensor, param) -> torch.dtype:
+    """dtype ATen gives ``x / param`` -- the precision the reference rounds the quotient to."""
+    return torch.result_type(x, param)
+
+
+def _gpu_dtype_guard(x: torch.Tensor, qd: torch.dtype):
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or qd not in (torch.float32, x.dtype):
+        raise _hip.QsparseHipError(
+            f"HIP quantizers support float32/bfloat16/float16 inputs with float32 parameters, got {x.dtype} -> {qd}")
+
+
+class _SteFunction(torch.autograd.Function):
+    """shared backward of the scaler and decimal quantizers (reference quantize.py:66-77, 120-131)."""
+
+    @staticmethod
+    def _backward(ctx, grad_output, step_is_decimal: bool):
+        if ctx.backward_passthrough:
+            return (grad_output,) + (None,) * 6
+        limit = 2.0 ** (ctx.bits - 1)
+        lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
+        (step,) = ctx.saved_tensors
+        if grad_output.is_cuda:
+            out_dtype = ctx.x_dtype if grad_output.dtype == torch.float32 else grad_output.dtype
+            gx = _hip.ste_bwd(grad_output, step, step_is_decimal, ctx.channel_index, lo_mul, hi_mul, False, out_dtype)
+            return (gx,) + (None,) * 6
+        s = torch.pow(2.0, -step) if step_is_decimal else step
+        if s.numel() > 1:
+            s = _on_channel(s, grad_output.dim(), ctx.channel_index, grad_output.shape[ctx.channel_index])
+        # values are clamped; nothing is zeroed (the reference's masked assignment is a no-op)
+        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 6
+
+
+class ScalerQuantization(_SteFunction):
+    """``q = int(round(x / s)); y = float(q) * s`` with STE backward (reference quantize.py:80-131)."""
+
+    @staticmethod
+    def forward(ctx, input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = 1,
+                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False):
+        ctx.backward_passthrough = backward_passthrough
+        ctx.notch = 1 if flip_axis else 0
+        ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
+        ctx.save_for_backward(ensure_tensor(scaler).detach())
+        if input.is_cuda:
+            qd = _quotient_dtype(input, scaler)
+            _gpu_dtype_guard(input, qd)
+            if isinstance(scaler, torch.Tensor) and scaler.numel() > 1:
+                assert len(scaler) == input.shape[channel_index], \
+                    "channel of input and decimal must be equal in channel-wise quantization"
+            y, _ = _hip.quant_fwd("scaler", input, scaler, channel_index, qd)
+            return y
+        s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
+        codes = torch.round(input / s).int()
+        return codes.float() * s  # no saturation: see module docstring
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return _SteFunction._backward(ctx, grad_output, step_is_decimal=False)
+
+
+class DecimalQuantization(_SteFunction):
+    """``q = int(x * 2^d); y = float(q) * 2^-d`` with STE backward (reference quantize.py:24-77)."""
+
+    @staticmethod
+    def forward(ctx, input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = 1,
+                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False):
+        ctx.backward_passthrough = backward_passthrough
+        ctx.notch = 1 if flip_axis else 0
+        ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
+        ctx.save_for_backward(ensure_tensor(decimal).detach().float())
+        if input.is_cuda:
+            qd = _quotient_dtype(input, decimal.float() if isinstance(decimal, torch.Tensor) else 1.0)
+            _gpu_dtype_guard(input, qd)
+            if isinstance(decimal, torch.Tensor) and decimal.numel() > 1:
+                assert len(decimal) == input.shape[channel_index], \
+                    "channel of input and decimal must be equal in channel-wise quantization"
+            y, _ = _hip.quant_fwd("decimal", input, decimal, channel_index, qd)
+            return y
+        to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
+        to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
+        return (input * to_int).int().float() * to_float
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return _SteFunction._backward(ctx, grad_output, step_is_decimal=True)
+
+
+class LineQuantization(torch.autograd.Function):
+    """asymmetric uniform quantization between per-channel ``(start, end)`` lines, identity backward
+    (reference quantize.py:134-185)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, bits: int = 8, lines=(-0.1, 0.9), channel_index=-1, inplace=False,
+                float_zero_point=True):
+        if not isinstance(lines, torch.Tensor):
+            lines = torch.tensor(lines).view(-1, 2).to(x.device)
+        if channel_index >= 0:
+            assert x.shape[channel_index] == lines.shape[0]
+        assert lines.shape[1] == 2
+        if x.is_cuda:
+            if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or lines.dtype != torch.float32:
+                raise _hip.QsparseHipError(f"HIP line quantizer: unsupported dtypes {x.dtype} / {lines.dtype}")
+            return _hip.quant_line_fwd(x, lines, bits, channel_index, float_zero_point)
+        levels = 2 ** bits
+        view = [1] * x.dim()
+        if channel_index >= 0:
+            view[channel_index] = -1
+        lo, hi = lines[:, 0].view(view), lines[:, 1].view(view)
+        xc = torch.clamp(x, lo, hi)
+        step = (hi - lo) / levels
+        step = torch.where(step == 0, torch.full_like(step, 0.0001), step)
+        if float_zero_point:   # training form (:168-181): separate multiply and add
+            idx = ((xc - lo) / step).round().clamp(0, levels - 1)
+            return idx * step + lo
+        zero_point = (lo / step).round()   # evaluation form (:161-166): integer zero point
+        idx = ((xc / step).round() - zero_point).clamp(0, levels - 1)
+        return (idx + zero_point) * step
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (grad_output,) + (None,) * 5
+
+
+def quantize_with_decimal(input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = -1,
+                          use_uint: bool = False, backward_passthrough: bool = False,
+                          flip_axis: bool = False) -> torch.Tensor:
+    """power-of-two uniform quantization (reference quantize.py:188-208).
+
+    Args mirror the reference: ``decimal`` is the number of fractional bits (int, or per-channel
+    tensor viewed along ``channel_index``); ``use_uint`` is accepted and, as in the reference, has no
+    effect; ``backward_passthrough`` skips the gradient clamp; ``flip_axis`` shifts the clamp
+    interval by one step."""
+    return DecimalQuantization.apply(input, bits, decimal, channel_index, use_uint, backward_passthrough, flip_axis)
+
+
+def quantize_with_scaler(input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = -1,
+                         use_uint: bool = False, backward_passthrough: bool = False,
+                         flip_axis: bool = False) -> torch.Tensor:
+    """scaling-factor based uniform quantization (reference quantize.py:210-230)."""
+    return ScalerQuantization.apply(input, bits, scaler, channel_index, use_uint, backward_passthrough, flip_axis)
+
+
+def quantize_with_line(x: torch.Tensor, bits: int = 8,
+                       lines: Union[Tuple[float, float], List[Tuple[float, float]]] = (-0.1, 0.9),
+                       channel_index: int = -1, inplace: bool = False, float_zero_point: bool = True) -> torch.Tensor:
+    """asymmetric uniform quantization (reference quantize.py:232-255)."""
+    return LineQuantization.apply(x, bits, lines, channel_index, inplace, float_zero_point)
+
+
+# ----------------------------------------------------------------------------------------------
+# quantizer callbacks (policy + running statistics)
+# ----------------------------------------------------------------------------------------------
+class BaseQuantizer(nn.Module):
+    """callback protocol of ``quantize`` (reference quantize.py:258-272)."""
+
+    weight_size = 1
+
+    def optimize(self, tensor, bits, weight=None, batched=False, channel_index=-1) -> torch.Tensor:
+        """return the updated weight for this step"""
+        raise NotImplementedError
+
+    def forward(self, tensor, bits, weight=None, batched=False, channel_index=-1) -> torch.Tensor:
+        """return the quantized tensor"""
+        raise NotImplementedError
+
+    def get_weight_shape(self, x, channelwise):
+        return (1 if channelwise < 0 else x.shape[channelwise], self.weight_size)
+
+
+def _absmax_rows_cpu(x: torch.Tensor, channel_index: int) -> torch.Tensor:
+    a = x.abs()
+    if channel_index == -1:
+        rows = a.reshape(1, -1)
+    elif channel_index == 0:
+        rows = a.reshape(a.shape[0], -1)
+    else:
+        rows = a.transpose(0, channel_index).contiguous().view(a.shape[channel_index], -1)
+    return rows.max(dim=1).values
+
+
+class DecimalQuantizer(BaseQuantizer):
+    """abs-max statistics + power-of-two scales (algorithm 3 of the MDPI paper; reference
+    quantize.py:275-367).  ``optimize`` updates the running scale, ``forward`` quantizes."""
+
+    weight_size = 1
+
+    def __init__(self, use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
+                 group_num=-1, group_timeout=512):
+        super().__init__()
+        self.use_uint = use_uint
+        self.backward_passthrough = backward_passthrough
+        self.flip_axis = flip_axis
+        self.use_float_scaler = False
+        self.function = DecimalQuantization.apply
+        self.t = 0
+        self.group_timeout = group_timeout
+        self.groups = None
+        self.group_num = group_num
+
+    def quantize(self, tensor, bits, scaler, channel_index=-1, **kwargs):
+        if self.use_float_scaler:
+            param = scaler
+        elif scaler.is_cuda:
+            param = _hip.decimal_from_scale(scaler).view(scaler.shape)
+        else:
+            param = (1 / scaler).nan_to_num(posinf=1, neginf=1).log2().round()   # quantize.py:316
+        return self.function(tensor, bits, param, channel_index, self.use_uint, self.backward_passthrough,
+                             self.flip_axis)
+
+    def optimize(self, x, bits, weight=None, batched=False, channel_index=-1, **kwargs):
+        """running mean of ``max|x| / 2^(bits-1)`` (reference quantize.py:327-349)."""
+        with torch.no_grad():
+            wshape = self.get_weight_shape(x, channel_index)
+            if batched and channel_index >= 0 and x.shape[0] != 1:
+                # the reference computes the per-channel maximum over (batch, spatial) and then fails in
+                # `.view(-1, batch_size)` (quantize.py:341-343); keep the failure, with a clearer message
+                raise RuntimeError(
+                    "channel-wise Scaler/Decimal quantization of a batched activation is not supported by the "
+                    f"reference (shape {tuple(x.shape)}, channelwise={channel_index}); use channelwise=-1 or "
+                    "AdaptiveQuantizer")
+            if x.is_cuda:
+                stat = _hip.absmax(x, channel_index)
+                if weight is None:
+                    weight = torch.zeros(wshape, device=x.device)
+                _hip.scale_update(stat, weight.data, self.t, bits)   # t == 0 overwrites, else running mean
+            else:
+                new_weight = (_absmax_rows_cpu(x, channel_index) / (2 ** (bits - 1))).view(wshape)
+                if self.t == 0:
+                    weight = new_weight
+                else:
+                    weight.data[:] = (self.t * weight + new_weight) / (self.t + 1)
+        self.t += 1
+        return weight
+
+    def _group_scales(self, scaler):
+        """optional group-wise quantization: cluster channels once with sklearn (host), then share the
+        mean scale inside each group (reference quantize.py:352-366)."""
+        if self.groups is None:
+            from sklearn.cluster import AgglomerativeClustering
+
+            logging.danger(f"clustering {len(scaler)} channels into {self.group_num} groups")
+            labels = AgglomerativeClustering(n_clusters=self.group_num).fit(scaler.detach().cpu().numpy()).labels_
+            self.groups = nn.Parameter(torch.from_numpy(labels).to(scaler.device), requires_grad=False)
+        shared = torch.clone(scaler)
+        for gi in range(self.group_num):
+            member = self.groups == gi
+            shared[member] = shared[member].mean(dim=0)
+        return shared
+
+    def forward(self, tensor, bits, scaler, channel_index=-1, **kwargs):
+        if self.t >= self.group_timeout and self.group_num > 0 and scaler.numel() > self.group_num:
+            scaler = self._group_scales(scaler)
+        return self.quantize(tensor, bits, scaler, channel_index, **kwargs)
+
+
+class ScalerQuantizer(DecimalQuantizer):
+    """abs-max statistics with free (non power-of-two) scales (reference quantize.py:370-378)."""
+
+    weight_size = 1
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_float_scaler = True
+        self.function = ScalerQuantization.apply
+
+
+class AdaptiveQuantizer(DecimalQuantizer):
+    """min/max statistics + asymmetric lines (algorithm 2 of the MDPI paper; reference
+    quantize.py:381-430)."""
+
+    weight_size = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.function = LineQuantization.apply
+
+    def quantize(self, tensor, bits, lines, channel_index=-1, **kwargs):
+        return self.function(tensor, bits, lines, channel_index, kwargs.get("inplace", False), self.training)
+
+    @staticmethod
+    def _bounds_cpu(x, channel_index, batched):
+        batch = x.shape[0]
+        if channel_index >= 0:
+            if batched:
+                xt = x if channel_index == 1 else x.transpose(1, channel_index)
+                rows = xt.reshape(-1, math.prod(xt.shape[2:]))
+            else:
+                xt = x if channel_index == 0 else x.transpose(0, channel_index)
+                rows = xt.contiguous().view(-1, math.prod(xt.shape[1:]))
+        else:
+            rows = x.reshape(len(x) if batched else 1, -1)
+        lo, hi = rows.min(dim=1).values, rows.max(dim=1).values
+        if batched:   # min of per-sample minima, max of per-sample maxima (:415-418)
+            lo, hi = lo.view(batch, -1).min(dim=0).values, hi.view(batch, -1).max(dim=0).values
+        return torch.stack([lo, hi], dim=1).view(-1, 2)
+
+    def optimize(self, x, bits, weight=None, channel_index=-1, batched=False, **kwargs):
+        with torch.no_grad():
+            if x.is_cuda:
+                lo, hi = _hip.minmax(x, channel_index)
+                if weight is None:
+                    self.t += 1
+                    return torch.stack([lo, hi], dim=1)
+                assert weight.shape == (lo.numel(), 2)
+                self.t += 1
+                _hip.lines_update(lo, hi, weight.data, self.t)
+                return weight
+            bounds = self._bounds_cpu(x, channel_index, batched)
+            self.t += 1
+            if weight is None:
+                return bounds
+            assert bounds.shape == weight.shape
+            return (weight * (self.t - 1) + bounds) / self.t
+
+
+# ----------------------------------------------------------------------------------------------
+# the layer
+# ----------------------------------------------------------------------------------------------
+class QuantizeLayer(nn.Module):
+    """stateful quantization operator (reference quantize.py:434-518): identity for the first
+    ``timeout`` training steps, then statistics update (training) + quantization."""
+
+    def __str__(self):
+        return (f"QuantizeLayer(bits={self.bits}, timeout={self.timeout}, "
+                f"callback={self.callback.__class__.__name__}, channelwise={self.channelwise})")
+
+    __repr__ = __str__
+
+    def __init__(self, bits: int = 8, channelwise: int = 1, timeout: int = 1000, callback: BaseQuantizer = None,
+                 batch_dimension: int = 0, name: str = ""):
+        super().__init__()
+        if get_option("log_on_created"):
+            logging.info(f"[Quantize{name if name == '' else f' @ {name}'}] bits={bits} channelwise={channelwise} "
+                         f"timeout={timeout}")
+        self.name = name
+        self.channelwise = channelwise
+        self.timeout = timeout
+        self.bits = bits
+        self.callback = callback
+        self.batch_dimension = batch_dimension   # 0: activation, -1: weight/bias
+        self._quantized = False
+        self._steps = HostMirror()
+
+    @property
+    def initted(self) -> bool:
+        return hasattr(self, "_n_updates")
+
+    def _lazy_init(self, x):
+        rows = 1 if self.channelwise < 0 else x.shape[self.channelwise]
+        self.weight = nn.Parameter(torch.zeros(rows, self.callback.weight_size, device=x.device), requires_grad=False)
+        self._n_updates = nn.Parameter(torch.zeros(1, dtype=torch.int, device=x.device), requires_grad=False)
+
+    def is_active(self) -> bool:
+        """whether the next forward quantizes (used by the fused prune->quantize path)."""
+        if self.timeout <= 0 or not self.initted:
+            return False
+        t = self._steps.read(self._n_updates)
+        return t >= self.timeout and (self.training or self._quantized)
+
+    def forward(self, x):
+        if not self.initted:
+            self._lazy_init(x)
+        if self.timeout <= 0:   # timeout=0 disables the operator for good (reference :496)
+            return x
+        t = self._steps.read(self._n_updates)
+        out = x
+        if t >= self.timeout:
+            if self.training:
+                if t == self.timeout and get_option("log_during_train"):
+                    logging.warn(f"quantizing {self.name} with {self.bits} bits")
+                new_weight = self.callback.optimize(x, self.bits, self.weight, batched=self.batch_dimension == 0,
+                                                    channel_index=self.channelwise)
+                if new_weight is not None and new_weight is not self.weight:
+                    self.weight.data[:] = new_weight
+                self._quantized = True
+            if self._quantized:
+                out = self.callback(x, self.bits, self.weight, channel_index=self.channelwise,
+                                    inplace=self.batch_dimension == 0)
+        if self.training:
+            self._steps.add(self._n_updates, 1)
+        return out
+
+
+def quantize(inp: nn.Module = None, bits: int = 8, channelwise: int = 1, timeout: int = 1000,
+             callback: BaseQuantizer = None, bias_bits: int = -1, name: str = "") -> nn.Module:
+    """build a ``QuantizeLayer`` (no ``inp``) or wrap ``inp`` so that its weight (and, with
+    ``bias_bits``, its bias) is read through one (reference quantize.py:521-585)."""
+    callback = callback or ScalerQuantizer()
+    kwargs = dict(bits=bits, channelwise=channelwise, timeout=timeout, callback=callback, bias_bits=bias_bits, name=name)
+
+    def make(batch_dimension=0, is_bias=False):
+        if is_bias and bias_bits == -1:
+            return lambda a: a
+        return QuantizeLayer(bits=bias_bits if is_bias else bits,
+                             channelwise=(0 if channelwise >= 0 else -1) if is_bias else channelwise,
+                             timeout=int(timeout), callback=callback, name=name, batch_dimension=batch_dimension)
+
+    if inp is None:
+        layer = make()
+        layer._kwargs = kwargs
+        return layer
+    if isinstance(inp, nn.Module):
+        return imitate(inp, "quantize", make(-1), make(-1, is_bias=True))
+    raise ValueError(f"{inp} is not a valid argument for quantize")

@@ -1,0 +1,309 @@
+"""Magnitude pruning operators -- API of the reference's qsparse/sparse.py.
+
+Same public names, arguments and state (``mask``, ``_n_updates``, ``_cur_sparsity``, ``callback.t``,
+``callback.magnitude``) as mlzxy/qsparse v2.0.1.  For GPU tensors the tensor math is HIP: staged
+mean-|x| (``qs_mean_dim``), running mean (``qs_running_mean``), k-th value + compare
+(``qs_kth_value`` / ``qs_mask_ge``) and mask apply forward/backward (``qs_mask_apply``).  The step
+counters are mirrored on the host (``HostMirror``) so a forward issues no ``.item()`` sync.
+"""
+import copy
+from typing import Callable, Iterable
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from qsparse_amd import _hip
+from qsparse_amd.common import HostMirror, f32_round
+from qsparse_amd.imitation import imitate
+from qsparse_amd.util import (_reduction_plan, _staged_mean_hip, calculate_mask_given_importance, get_option, logging,
+                              squeeze_tensor_to_shape, threshold_rank)
+
+
+class _MaskApply(torch.autograd.Function):
+    """``x * mask`` for a GPU tensor; backward ``g * mask`` (autograd's MulBackward0 in the reference,
+    qsparse/sparse.py:66,116,122,263)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return _hip.mask_apply(x, mask)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (mask,) = ctx.saved_tensors
+        return _hip.mask_apply(grad, mask), None
+
+
+def apply_mask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    if x.is_cuda:
+        return _MaskApply.apply(x, mask.detach())
+    return x * mask
+
+
+def _importance(x: torch.Tensor, shape, l0: bool = False) -> torch.Tensor:
+    """``squeeze_tensor_to_shape(x.abs(), shape)`` -- with the optional L0 substitution -- in one pass
+    over ``x`` on the GPU (reference sparse.py:85-87)."""
+    if x.is_cuda:
+        dims = _reduction_plan(x.shape, shape)
+        flag = _hip.l0_flag(x) if l0 else None
+        if l0 and not dims:   # nothing to reduce: materialise (x != 0).float() or |x| via the flag
+            return torch.where(flag.bool(), (x != 0).float(), x.abs().float())
+        return _staged_mean_hip(x, dims, take_abs=True, l0_flag=flag)
+    if l0 and x.min().item() == 0:
+        x = (x != 0).float()
+    return squeeze_tensor_to_shape(x.abs(), shape)
+
+
+class MagnitudePruningCallback(nn.Module):
+    def __init__(self, mask_refresh_interval: int = -1, stop_mask_refresh: int = float("inf"),
+                 use_gradient: bool = False, running_average: bool = True, l0: bool = False,
+                 forward_hook: Callable[[torch.Tensor, str], None] = None):
+        """magnitude-based mask construction, the callback of ``prune`` (reference sparse.py:18-56).
+
+        Args:
+            mask_refresh_interval: steps between mask rebuilds (<=0 means every step).
+            stop_mask_refresh: step after which the mask is frozen.
+            use_gradient: rank by gradient magnitude (collected through a tensor hook) instead.
+            running_average: rank by the running mean of the magnitude rather than the current input.
+            l0: count non-zeros instead of averaging magnitudes when the input has exact zeros.
+            forward_hook: called as ``hook(mask, name)`` after every training forward.
+        """
+        super().__init__()
+        if use_gradient and not running_average:
+            raise ValueError("the combination of `use_gradient=True` and `running_average=False` is not supported")
+        self.mask_refresh_interval = mask_refresh_interval
+        self.stop_mask_refresh = stop_mask_refresh
+        self.use_gradient = use_gradient
+        self.running_average = running_average
+        self.l0 = l0
+        self.forward_hook = forward_hook
+        self.prev_grad_hook = None
+        self.t = nn.Parameter(torch.full((1,), -1), requires_grad=False)
+        self._t_host = HostMirror()
+
+    @property
+    def initted(self) -> bool:
+        return self._t_host.read(self.t) != -1
+
+    def initialize(self, mask: torch.Tensor):
+        if self.running_average:
+            self.magnitude = nn.Parameter(torch.zeros(*mask.shape, device=mask.device, dtype=torch.float),
+                                          requires_grad=False)
+
+    def update_magnitude(self, x):
+        """magnitude <- (t*magnitude + mean|x|) / (t+1)   (reference sparse.py:82-89)"""
+        if not self.running_average:
+            return
+        with torch.no_grad():
+            t = self._t_host.read(self.t)
+            imp = _importance(x.detach(), self.magnitude.shape, self.l0)
+            if x.is_cuda:
+                _hip.running_mean(self.magnitude.data, imp, t)
+            else:
+                self.magnitude.data[:] = (t * self.magnitude + imp) / (t + 1)
+
+    def receive_input(self, x: torch.Tensor):
+        if not self.use_gradient:
+            self.update_magnitude(x)
+            return
+        if self.prev_grad_hook is not None:
+            self.prev_grad_hook.remove()
+            self.prev_grad_hook = None
+        if x.requires_grad:
+            self.prev_grad_hook = x.register_hook(lambda grad: self.update_magnitude(grad))
+        else:
+            logging.error("meeting no-grad tensor")
+
+    def prune_and_update_mask(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            importance = self.magnitude if self.running_average else _importance(x.detach(), mask.shape)
+            if x.is_cuda:
+                imp = importance.detach().to(torch.float32).contiguous()
+                n = imp.numel()
+                k = threshold_rank(sparsity, n)
+                if k >= n:
+                    raise IndexError(f"index {k} is out of bounds for dimension 0 with size {n}")
+                _hip.mask_ge(imp, _hip.kth_value(imp, k), mask.data)
+            else:
+                mask.data[:] = calculate_mask_given_importance(importance, sparsity)
+        return apply_mask(x, mask)
+
+    def refresh_due(self, t: int, sparsity: float) -> bool:
+        """whether step ``t`` rebuilds the mask (reference sparse.py:110-113)."""
+        return (sparsity >= 0 and t % self.mask_refresh_interval == 0 and t <= self.stop_mask_refresh
+                and (t > 0 or not self.running_average))
+
+    def begin_step(self, mask: torch.Tensor) -> int:
+        """first-use initialisation; returns the step index ``t`` of this call."""
+        if not self.initted:
+            self.initialize(mask)
+            self._t_host.write(self.t, 0)
+            if self.mask_refresh_interval <= 0:
+                self.mask_refresh_interval = 1
+        return self._t_host.read(self.t)
+
+    def end_step(self, mask: torch.Tensor, name: str):
+        self._t_host.add(self.t, 1)
+        if self.forward_hook is not None:
+            self.forward_hook(mask, name)
+
+    def forward(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor, name=""):
+        if not self.training:
+            return apply_mask(x, mask)
+        t = self.begin_step(mask)
+        if t < self.stop_mask_refresh:
+            self.receive_input(x)
+        if self.refresh_due(t, sparsity):
+            out = self.prune_and_update_mask(x, sparsity, mask)
+        else:
+            out = apply_mask(x, mask)
+        self.end_step(mask, name)
+        return out
+
+
+class UniformPruningCallback(MagnitudePruningCallback):
+    """unstructured random pruning that ignores magnitudes; positions already pruned stay pruned
+    (reference sparse.py:125-152).  Uses numpy's global RNG on the host, like the reference."""
+
+    def initialize(self, mask: torch.Tensor):
+        pass
+
+    def receive_input(self, x: torch.Tensor):
+        pass
+
+    def prune_and_update_mask(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor) -> torch.Tensor:
+        cur_sparsity = (~mask).sum().item() / mask.numel()
+        if cur_sparsity > sparsity:
+            logging.warning("sparsity is decreasing, which shall not happen")
+        budget = int(round((sparsity - cur_sparsity) * np.prod(mask.shape)))
+        alive = mask.nonzero(as_tuple=True)
+        chosen = torch.from_numpy(np.random.choice(len(alive[0]), size=budget, replace=False)).to(mask.device)
+        mask.data[tuple(idx[chosen] for idx in alive)] = False
+        return apply_mask(x, mask)
+
+
+class PruneLayer(nn.Module):
+    """stateful pruning operator with the cubic sparsity schedule (reference sparse.py:157-273)."""
+
+    def __str__(self):
+        return (f"PruneLayer(sparsity={self.sparsity}, start={self.start}, interval={self.interval}, "
+                f"repetition={self.repetition}, dimensions={self.dimensions})")
+
+    __repr__ = __str__
+
+    def __init__(self, sparsity: float = 0.5, dimensions: Iterable[int] = {1},
+                 callback: MagnitudePruningCallback = MagnitudePruningCallback(), start: int = 1000,
+                 interval: int = 1000, repetition: int = 4, rampup: bool = False, name=""):
+        super().__init__()
+        if get_option("log_on_created"):
+            logging.warning(f"[Prune{name if name == '' else f' @ {name}'}] start = {start} interval = {interval} "
+                            f"repetition = {repetition} sparsity = {sparsity} dimensions = {dimensions}")
+        first = 1 if rampup else 0
+        self.schedules = [start + interval * (first + i) for i in range(repetition)]
+        self.start = start
+        self.interval = interval
+        self.repetition = repetition
+        self.sparsity = sparsity
+        self.name = name
+        self.callback = callback
+        self.rampup_interval = 0 if rampup else interval
+        self.dimensions = set(dimensions)
+        for key in ("mask", "_n_updates", "_cur_sparsity"):   # shape-less placeholders until the first forward
+            self.register_parameter(key, nn.Parameter(torch.tensor(-1, dtype=torch.int), requires_grad=False))
+        self._steps = HostMirror()
+        self._sparsity_host = HostMirror()
+
+    @property
+    def initted(self) -> bool:
+        return self._steps.read(self._n_updates) != -1
+
+    def _lazy_init(self, x: torch.Tensor):
+        assert len(x.shape) > 1
+        mask_shape = [s if i in self.dimensions else 1 for i, s in enumerate(x.shape)]
+        self.mask = nn.Parameter(torch.ones(*mask_shape, dtype=torch.bool, device=x.device), requires_grad=False)
+        if self.mask.numel() == 1:
+            logging.warn(f"the mask shape of {self.name} is {tuple(self.mask.shape)}, which is not prunable")
+        self._n_updates = nn.Parameter(torch.zeros(1, dtype=torch.int, device=x.device), requires_grad=False)
+        self._cur_sparsity = nn.Parameter(torch.zeros(1, device=x.device), requires_grad=False)
+
+    def scheduled_sparsity(self, n: int) -> float:
+        """cubic ramp evaluated in Python doubles, stored as fp32 (reference sparse.py:252-257)."""
+        ratio = (1.0 - (n - self.start + self.rampup_interval) / (self.interval * self.repetition)) ** 3
+        return self.sparsity * (1 - ratio)
+
+    def advance_schedule(self) -> int:
+        """apply the sparsity schedule for the current step; returns the step index."""
+        n = self._steps.read(self._n_updates)
+        if self.training and n in self.schedules:
+            self._sparsity_host.write(self._cur_sparsity, self.scheduled_sparsity(n))
+            if get_option("log_during_train"):
+                tag = self.name if self.name == "" else f" @ {self.name}"
+                logging.warning(f"[Prune{tag}] [Step {n}] pruned {self._sparsity_host.read(self._cur_sparsity):.02f}")
+        return n
+
+    def current_sparsity(self) -> float:
+        return self._sparsity_host.read(self._cur_sparsity)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """prune ``x`` according to the schedule; raises ``RuntimeError`` when a full-shape mask meets a
+        different input shape in evaluation mode."""
+        if not self.initted:
+            self._lazy_init(x)
+        n = self.advance_schedule()
+        if not self.training or self.mask.numel() == 1:
+            return apply_mask(x, self.mask)
+        if n >= self.start:
+            if n == self.start and get_option("log_during_train"):
+                logging.warning(f"Start pruning at {self.name} @ {n}")
+            out = self.callback(x, self.current_sparsity(), mask=self.mask, name=self.name)
+        else:
+            out = x
+        self._steps.add(self._n_updates, 1)
+        return out
+
+
+def prune(inp: nn.Module = None, sparsity: float = 0.5, dimensions: Iterable[int] = {1},
+          callback: MagnitudePruningCallback = None, start: int = 1000, interval: int = 1000, repetition: int = 4,
+          rampup: bool = False, name="") -> nn.Module:
+    """build a ``PruneLayer`` (no ``inp``) for activations, or wrap ``inp`` so that its weight is read
+    through one (reference sparse.py:276-339).
+
+    Args:
+        inp: module whose weight is to be pruned, or None for an activation operator.
+        sparsity: target sparsity reached at the end of the schedule.
+        dimensions: dims along which the mask varies ({1}: channel pruning of NCHW activations).
+        callback: mask construction policy, default ``MagnitudePruningCallback()``.
+        start / interval / repetition / rampup: the cubic sparsity schedule.
+        name: used in log lines.
+    """
+    callback = callback or MagnitudePruningCallback()
+    kwargs = dict(start=int(start), sparsity=sparsity, interval=int(interval), repetition=repetition, rampup=rampup,
+                  name=name, callback=callback, dimensions=dimensions)
+    if inp is None:
+        layer = PruneLayer(**kwargs)
+        layer._kwargs = kwargs
+        return layer
+    if isinstance(inp, nn.Module):
+        return imitate(inp, "prune", PruneLayer(**kwargs))
+    raise ValueError(f"{inp} is not a valid argument for prune")
+
+
+def devise_layerwise_pruning_schedule(net: nn.Module, start: int = 1, interval: int = 10,
+                                      mask_refresh_interval: int = 1, inplace=False):
+    """stagger the prune layers of ``net`` one after another (reference sparse.py:343-359).  Like the
+    reference it leaves ``rampup_interval`` untouched."""
+    if not inplace:
+        net = copy.deepcopy(net)
+    layers = [m for m in net.modules() if isinstance(m, PruneLayer)]
+    weight_only = all(layer.name.endswith(".prune") for layer in layers)
+    for layer in layers:
+        layer.start, layer.interval, layer.repetition = start, interval, 1
+        layer.schedules = [start]
+        layer.callback.mask_refresh_interval = mask_refresh_interval
+        layer.callback.stop_mask_refresh = interval
+        if weight_only:
+            layer.callback.running_average = False
+        start += interval + 1
+    logging.danger(f"Pruning stops at iteration - {start}")
+    return net

@@ -1,0 +1,181 @@
+"""Options, naming, reductions-to-mask-shape, mask construction, checkpoint preload, logging.
+
+API-compatible with the reference's qsparse/util.py; the two tensor functions
+(``squeeze_tensor_to_shape`` util.py:79-99, ``calculate_mask_given_importance`` util.py:103-117) run as
+HIP kernels for GPU tensors (``qs_mean_dim``, ``qs_kth_value`` + ``qs_mask_ge``).
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from qsparse_amd import _hip
+
+_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None}
+
+
+def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
+                sync_statistics: Optional[bool] = None):
+    """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
+    Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
+    cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py)."""
+    for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
+                     ("sync_statistics", sync_statistics)):
+        if val is not None:
+            _options_[key] = val
+
+
+def get_option(key: str):
+    """exported as ``get_qsparse_option`` (reference util.py:29-40)."""
+    assert key in _options_, f"unknown qsparse option {key!r}"
+    return _options_[key]
+
+
+def nn_module(mod: nn.Module) -> nn.Module:
+    """unwrap ``nn.DataParallel`` / DDP style wrappers (reference util.py:64-76)."""
+    return mod.module if hasattr(mod, "module") else mod
+
+
+def auto_name_prune_quantize_layers(net: nn.Module) -> nn.Module:
+    """name every Prune/Quantize layer after its module path (reference util.py:43-60)."""
+    from qsparse_amd.quantize import QuantizeLayer
+    from qsparse_amd.sparse import PruneLayer
+
+    for path, mod in net.named_modules():
+        if isinstance(mod, (PruneLayer, QuantizeLayer)):
+            mod.name = path
+    return net
+
+
+# ----------------------------------------------------------------------------------------------
+# staged mean to the mask shape
+# ----------------------------------------------------------------------------------------------
+def _reduction_plan(xshape: Sequence[int], shape: Sequence[int]) -> List[int]:
+    """dims to average, ascending; same error behaviour as the reference (util.py:92-98)."""
+    assert len(xshape) == len(shape), "mismatch between the input tensor and mask"
+    dims = []
+    for i, (sx, sm) in enumerate(zip(xshape, shape)):
+        if sx != sm:
+            if sm != 1:
+                raise ValueError("mismatch between the input tensor and mask")
+            dims.append(i)
+    return dims
+
+
+def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=None, absmax_out=None,
+                     absmax_channel_dim: Optional[int] = None) -> torch.Tensor:
+    """successive keepdim means on the GPU, one ``qs_mean_dim`` launch per reduced dim."""
+    cur = _hip.dense(x)
+    shape = list(cur.shape)
+    out_dtype = torch.float32 if l0_flag is not None else cur.dtype
+    first = True
+    for d in dims:
+        pre = 1
+        for s in shape[:d]:
+            pre *= s
+        post = 1
+        for s in shape[d + 1:]:
+            post *= s
+        flags = 0
+        kw = {}
+        if first:
+            if take_abs:
+                flags |= _hip.MEAN_ABS
+            if l0_flag is not None:
+                flags |= _hip.MEAN_L0
+                kw["l0_flag"] = l0_flag
+            if absmax_out is not None:
+                cd = absmax_channel_dim
+                assert cd is not None and cd > d, "fused abs-max needs the channel dim inside the kept columns"
+                chan_div = 1
+                for s in shape[cd + 1:]:
+                    chan_div *= s
+                kw.update(absmax_out=absmax_out, chan_div=chan_div, C=shape[cd])
+        cur = _hip.mean_dim(cur, pre, shape[d], post, out_dtype if first else cur.dtype, flags, **kw)
+        shape[d] = 1
+        cur = cur.view(shape)
+        first = False
+    if first and take_abs:  # nothing to reduce: importance is |x| itself
+        cur = cur.abs()
+    return cur
+
+
+def squeeze_tensor_to_shape(x: torch.Tensor, shape: List[int]) -> torch.Tensor:
+    """average ``x`` down to ``shape`` one dim at a time (reference util.py:79-99): every stage
+    accumulates in fp32 and rounds to ``x``'s dtype, exactly like ``Tensor.mean`` on CPU."""
+    dims = _reduction_plan(x.shape, shape)
+    if x.is_cuda:
+        return _staged_mean_hip(x, dims, take_abs=False)
+    for i in dims:
+        x = x.mean(i, keepdim=True)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# mask from importance
+# ----------------------------------------------------------------------------------------------
+def threshold_rank(sparsity: float, n: int) -> int:
+    """position, in ascending order, of the threshold element (reference util.py:115-116)."""
+    return max(int(sparsity * n - 1), 0) + 1
+
+
+def calculate_mask_given_importance(importance: torch.Tensor, sparsity: float) -> torch.Tensor:
+    """binary mask keeping everything ``>=`` the ``threshold_rank``-th smallest importance
+    (reference util.py:103-117).  Ties at the threshold are all kept."""
+    n = importance.numel()
+    k = threshold_rank(sparsity, n)
+    if k >= n:
+        raise IndexError(f"index {k} is out of bounds for dimension 0 with size {n}")
+    if importance.is_cuda:
+        imp = importance.detach().to(torch.float32).contiguous()
+        thr = _hip.kth_value(imp, k)
+        mask = torch.empty(importance.shape, dtype=torch.bool, device=importance.device)
+        _hip.mask_ge(imp, thr, mask)
+        return mask
+    ordered = importance.flatten().sort()[0]
+    return importance >= ordered[k]
+
+
+# ----------------------------------------------------------------------------------------------
+# checkpoint preload
+# ----------------------------------------------------------------------------------------------
+def preload_qsparse_state_dict(model: nn.Module, state_dict: Dict[str, torch.Tensor]) -> nn.Module:
+    """install checkpoint tensors into the (shape-less until first forward) parameters of every
+    Prune/Quantize layer so that a following ``load_state_dict`` succeeds (reference util.py:120-145)."""
+    from qsparse_amd.quantize import QuantizeLayer
+    from qsparse_amd.sparse import PruneLayer
+
+    device = next(iter(model.parameters())).device
+    for path, layer in model.named_modules():
+        if not isinstance(layer, (PruneLayer, QuantizeLayer)):
+            continue
+        for subpath, sub in layer.named_modules():
+            prefix = "".join(p + "." for p in (path, subpath) if p)
+            for key, value in state_dict.items():
+                leaf = key[len(prefix):]
+                if key.startswith(prefix) and "." not in leaf:
+                    sub._parameters[leaf] = nn.Parameter(value.to(device), requires_grad=False)
+    return model
+
+
+# ----------------------------------------------------------------------------------------------
+# print-based logger (reference util.py:150-182)
+# ----------------------------------------------------------------------------------------------
+class style:
+    RED, GREEN, YELLOW, RESET = "\033[31m", "\033[32m", "\033[33m", "\033[0m"
+
+
+def _printer(color: str = ""):
+    def emit(msg: str):
+        print(f"{color}{msg}{style.RESET}" if color else msg)
+
+    return emit
+
+
+class logging:
+    """console logger with the reference's method names."""
+
+    info = _printer()
+    debug = _printer(style.GREEN)
+    warn = warning = _printer(style.YELLOW)
+    error = danger = exception = _printer(style.RED)

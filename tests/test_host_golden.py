@@ -1,0 +1,432 @@
+"""qsparse_amd host logic (layers, callbacks, convert, checkpoint) on CPU tensors against the golden
+vectors recorded from the real reference.  These mirror the reference's own property tests
+(tests/test_quantize.py, tests/test_sparse.py, tests/test_convert.py, tests/test_util.py) but compare
+with recorded reference outputs bit for bit.  The same trajectories run on the GPU in test_gpu_*.py.
+"""
+import json
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import qsparse_amd as qs
+from golden_io import Golden, same
+from qsparse_amd.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer, quantize_with_decimal,
+                                  quantize_with_line, quantize_with_scaler)
+from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer, UniformPruningCallback
+from qsparse_amd.util import squeeze_tensor_to_shape
+
+qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+MK = dict(scaler=ScalerQuantizer, decimal=DecimalQuantizer, adaptive=AdaptiveQuantizer)
+DEV = "cpu"
+
+
+def _param(g, k, c, dev=DEV):
+    p = g.get(k + "param")
+    if c["pkind"] == "pyfloat":
+        return float(p)
+    if not isinstance(p, torch.Tensor):
+        p = torch.tensor(p, dtype=torch.float32)
+    return p.to(dev)
+
+
+def run_f1_f2(dev):
+    for name, fn in (("f1_scaler", quantize_with_scaler), ("f2_decimal", quantize_with_decimal)):
+        g = Golden(name)
+        for c in g.cases:
+            k = f"c{c['id']}_"
+            p = _param(g, k, c, dev)
+            if name == "f2_decimal" and c["pkind"] == "pyfloat":
+                p = int(p)
+            x = g.get(k + "x").to(dev).requires_grad_(True)
+            y = fn(x, c["bits"], p, c["channel_index"], False, c["backward_passthrough"], c["flip_axis"])
+            assert same(y.detach().cpu(), g.get(k + "y")), (name, c)
+            y.backward(g.get(k + "gout").to(dev).clone())
+            assert same(x.grad.cpu(), g.get(k + "gx")), (name, c)
+
+
+def test_f1_f2_functional():
+    run_f1_f2(DEV)
+
+
+def run_f3(dev):
+    g = Golden("f3_line")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        lines = g.get(k + "lines").to(dev)
+        if c["lkind"] == "tuple":
+            lines = tuple(float(v) for v in g.get(k + "lines").view(-1))
+        y = quantize_with_line(g.get(k + "x").to(dev), c["bits"], lines, c["channel_index"], False, c["float_zero_point"])
+        assert same(y.cpu(), g.get(k + "y")), c
+
+
+def test_f3_line():
+    run_f3(DEV)
+
+
+def run_f4(dev):
+    g = Golden("f4_quantize_layer")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        if c.get("kind") == "conv_weight":
+            conv = nn.Conv2d(4, 6, 3)
+            with torch.no_grad():
+                conv.weight.copy_(g.get(k + "w0"))
+                conv.bias.copy_(g.get(k + "b0"))
+            conv = conv.to(dev)
+            qconv = qs.quantize(conv, bits=8, bias_bits=8, timeout=c["timeout"], channelwise=0, callback=MK[c["cb"]]())
+            qconv.train()
+            for s in range(c["steps"]):
+                y = qconv(g.get(k + f"s{s}_x").to(dev))
+                if dev == "cpu":
+                    assert same(y.detach(), g.get(k + f"s{s}_y")), (c, s)
+                assert same(qconv.weight.detach().cpu(), g.get(k + f"s{s}_qweight")), (c, s)
+                assert same(qconv.bias.detach().cpu(), g.get(k + f"s{s}_qbias")), (c, s)
+                assert same(qconv.quantize.weight.detach().cpu(), g.get(k + f"s{s}_wscale")), (c, s)
+                assert same(qconv.quantize_bias.weight.detach().cpu(), g.get(k + f"s{s}_bscale")), (c, s)
+            continue
+        layer = qs.quantize(bits=c["bits"], channelwise=c["channelwise"], timeout=c["timeout"], callback=MK[c["cb"]]())
+        layer.train()
+        for s in range(c["total_steps"]):
+            if s == c["steps"]:
+                layer.eval()
+            y = layer(g.get(k + f"s{s}_x").to(dev))
+            assert same(y.cpu(), g.get(k + f"s{s}_y")), (c, s)
+            assert same(layer.weight.detach().cpu(), g.get(k + f"s{s}_weight")), (c, s)
+            assert same(layer._n_updates.detach().cpu(), g.get(k + f"s{s}_n_updates")), (c, s)
+
+
+def test_f4_quantize_layer():
+    run_f4(DEV)
+
+
+def run_f5(dev):
+    g = Golden("f5_squeeze")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        out = squeeze_tensor_to_shape(g.get(k + "x").to(dev).abs(), c["mask_shape"])
+        assert same(out.cpu(), g.get(k + "out")), c
+
+
+def test_f5_squeeze():
+    run_f5(DEV)
+
+
+def run_f6(dev):
+    g = Golden("f6_mask")
+    for c in g.cases:
+        imp = g.get(c["imp_key"])
+        want = np.unpackbits(g.z[f"c{c['id']}_mask"])[: imp.numel()].astype(bool).reshape(tuple(imp.shape))
+        got = qs.calculate_mask_given_importance(imp.to(dev), c["sparsity"])
+        assert got.dtype == torch.bool and (got.cpu().numpy() == want).all(), c
+
+
+def test_f6_mask():
+    run_f6(DEV)
+
+
+def run_f7(dev):
+    g = Golden("f7_prune_layer")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        if c.get("kind") == "conv_weight":
+            torch.manual_seed(11)
+            conv = nn.Conv2d(10, 12, 3)
+            with torch.no_grad():
+                conv.weight.copy_(g.get(k + "w0"))
+            conv = conv.to(dev)
+            pconv = qs.prune(conv, sparsity=c["sparsity"], dimensions=set(c["dims"]), start=c["start"],
+                             interval=c["interval"], repetition=c["repetition"],
+                             callback=MagnitudePruningCallback(**c["cb"]))
+            pconv.train()
+            x = g.get(k + "x").to(dev)
+            for s in range(c["steps"]):
+                y = pconv(x)
+                if dev == "cpu":
+                    assert same(y.detach(), g.get(k + f"s{s}_y")), (c, s)
+                assert same(pconv.prune.mask.detach().cpu(), g.get(k + f"s{s}_mask")), (c, s)
+            continue
+        layer = qs.prune(sparsity=c["sparsity"], dimensions=set(c["dims"]), start=c["start"], interval=c["interval"],
+                         repetition=c["repetition"], rampup=c["rampup"], callback=MagnitudePruningCallback(**c["cb"]))
+        layer.train()
+        for s in range(c["total_steps"]):
+            if s == c["steps"]:
+                layer.eval()
+            x = g.get(k + f"s{s}_x").to(dev).requires_grad_(True)
+            y = layer(x)
+            y.backward(g.get(k + f"s{s}_gout").to(dev))
+            assert same(y.detach().cpu(), g.get(k + f"s{s}_y")), (c, s)
+            assert same(x.grad.cpu(), g.get(k + f"s{s}_gx")), (c, s)
+            assert same(layer.mask.detach().cpu(), g.get(k + f"s{s}_mask")), (c, s)
+            assert same(layer._n_updates.detach().cpu(), g.get(k + f"s{s}_n_updates")), (c, s)
+            assert same(layer._cur_sparsity.detach().cpu(), g.get(k + f"s{s}_cur_sparsity")), (c, s)
+            assert same(layer.callback.t.detach().cpu(), g.get(k + f"s{s}_t")), (c, s)
+            if g.has(k + f"s{s}_magnitude"):
+                assert same(layer.callback.magnitude.detach().cpu(), g.get(k + f"s{s}_magnitude")), (c, s)
+
+
+def test_f7_prune_layer():
+    run_f7(DEV)
+
+
+def run_f10(dev, fused):
+    g = Golden("f10_prune_quant_pair")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        pl = qs.prune(sparsity=c["sparsity"], dimensions={1}, start=c["start"], interval=c["interval"],
+                      repetition=c["repetition"])
+        ql = qs.quantize(bits=c["bits"], channelwise=-1, timeout=c["timeout"])
+        pair = nn.Sequential(nn.Sequential(nn.Identity(), pl), ql)
+        if fused:
+            from qsparse_amd.fused import fuse_prune_quantize_pairs
+            fuse_prune_quantize_pairs(pair)
+            assert type(pair).__name__ == "Sequential" and type(pair) is not nn.Sequential
+        pair.train()
+        for s in range(c["total_steps"]):
+            if s == c["total_steps"] - 1:
+                pair.eval()
+            x = g.get(k + f"s{s}_x").to(dev).requires_grad_(True)
+            y = pair(x)
+            y.backward(g.get(k + f"s{s}_gout").to(dev).clone())
+            assert same(y.detach().cpu(), g.get(k + f"s{s}_y")), (c, s)
+            assert same(x.grad.cpu(), g.get(k + f"s{s}_gx")), (c, s)
+            assert same(pl.mask.detach().cpu(), g.get(k + f"s{s}_mask")), (c, s)
+            assert same(ql.weight.detach().cpu(), g.get(k + f"s{s}_scale")), (c, s)
+            assert same(pl._cur_sparsity.detach().cpu(), g.get(k + f"s{s}_cur_sparsity")), (c, s)
+            if g.has(k + f"s{s}_magnitude"):
+                assert same(pl.callback.magnitude.detach().cpu(), g.get(k + f"s{s}_magnitude")), (c, s)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_f10_pair(fused):
+    run_f10(DEV, fused)
+
+
+# ---------------------------------------------------------------------------------------------
+# convert / state dict  (F8, F9)
+# ---------------------------------------------------------------------------------------------
+class LeNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 6, kernel_size=5)
+        self.conv2 = nn.Conv2d(6, 16, kernel_size=5)
+        self.fc1 = nn.Linear(16 * 5 * 5, 120)
+        self.fc2 = nn.Linear(120, 84)
+        self.fc3 = nn.Linear(84, 10)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.conv1(x)), 2)
+        x = F.max_pool2d(F.relu(self.conv2(x)), 2)
+        x = x.view(x.size(0), -1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+
+
+class MnistNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv_part = nn.Sequential(nn.Conv2d(1, 32, 3, 1), nn.BatchNorm2d(32), nn.ReLU(), nn.Conv2d(32, 64, 3, 1),
+                                       nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2), nn.Dropout(0.25))
+        self.linear_part = nn.Sequential(nn.Flatten(), nn.Linear(9216, 128), nn.BatchNorm1d(128), nn.ReLU(),
+                                         nn.Dropout(0.5), nn.Linear(128, 10))
+
+    def forward(self, x):
+        return F.log_softmax(self.linear_part(self.conv_part(x)), dim=1)
+
+
+def _trees():
+    g = Golden("f8_f9_convert_state")
+    return g, g.cases[0]["trees"], g.cases[0]["state_schema"]
+
+
+def test_f8_convert_trees():
+    g, trees, _ = _trees()
+    excl = [(nn.Conv2d, [0]), (nn.Linear, [-1])]
+    m = qs.convert(LeNet(), qs.prune(sparsity=0.5, callback=MagnitudePruningCallback()),
+                   weight_layers=[nn.Conv2d, nn.Linear], activation_layers=[nn.Conv2d, nn.Linear],
+                   excluded_weight_layer_indexes=excl, excluded_activation_layer_indexes=excl, log=False)
+    m = qs.convert(m, qs.quantize(bits=8), weight_layers=[nn.Conv2d, nn.Linear],
+                   activation_layers=[nn.Conv2d, nn.Linear], input=True, log=False)
+    assert {k: v.__class__.__name__ for k, v in m.named_modules()} == trees["lenet_pq"]
+    assert str(m) == trees["lenet_pq_str"]
+
+    m = qs.convert(MnistNet(), qs.prune(sparsity=0.75, dimensions={1}), activation_layers=[nn.ReLU],
+                   excluded_activation_layer_indexes=[(nn.ReLU, [-1])], log=False)
+    m = qs.convert(m, qs.quantize(bits=4, channelwise=-1, timeout=50), activation_layers=[nn.ReLU],
+                   weight_layers=[nn.Conv2d, nn.Linear], input=True, log=False)
+    assert {k: v.__class__.__name__ for k, v in m.named_modules()} == trees["mnist_pq"]
+    assert str(m) == trees["mnist_pq_str"]
+    from qsparse_amd.fused import FusedPruneQuantize
+    assert sum(isinstance(x, FusedPruneQuantize) for x in m.modules()) == 2   # the two pruned+quantized ReLUs
+
+    net = nn.Sequential(OrderedDict([("conv1", nn.Conv2d(3, 6, kernel_size=5)), ("fc1", nn.Linear(84, 10))]))
+    c = qs.convert(net, qs.quantize(bits=8), activation_layers=[nn.Conv2d, nn.Linear], order="pre", log=False)
+    assert str(c) == trees["order_pre_str"]
+    c = qs.convert(c, qs.prune(sparsity=0.5), activation_layers=[nn.Conv2d, nn.Linear], log=False)
+    assert str(c) == trees["order_pre_nested_str"]
+
+
+def _make_conv():
+    torch.manual_seed(3)
+    return qs.quantize(qs.prune(nn.Conv2d(16, 32, 3), sparsity=0.5, start=20, interval=5, repetition=4), bits=8,
+                       timeout=10)
+
+
+def test_f9_state_dict_and_preload():
+    g, _, schema = _trees()
+    conv = _make_conv()
+    conv.train()
+    for s in range(45):
+        gen = torch.Generator()
+        gen.manual_seed(5000 + s)
+        conv(torch.rand(4, 16, 7, 7, generator=gen))
+    sd = conv.state_dict()
+    assert {k: dict(dtype=str(v.dtype).replace("torch.", ""), shape=list(v.shape)) for k, v in sd.items()} == schema
+    for key, v in sd.items():
+        assert same(v.cpu(), g.get("sd_" + key)), key
+    conv.eval()
+    xt = g.get("eval_x")
+    assert same(conv(xt).detach(), g.get("eval_y_trained"))
+
+    # a reference checkpoint loads into a fresh model (keys, dtypes and shapes are the reference's)
+    ref_sd = {key: g.get("sd_" + key) for key in schema}
+    conv3 = _make_conv()
+    with pytest.raises(RuntimeError):
+        _make_conv().load_state_dict(ref_sd)   # shape-less placeholders: plain load fails, as in the reference
+    qs.preload_qsparse_state_dict(conv3, ref_sd)
+    conv3.load_state_dict(ref_sd)
+    conv3.eval()
+    assert same(conv3(xt).detach(), g.get("eval_y_reloaded"))
+    # counters were re-read from the loaded tensors, not from stale host mirrors
+    before = int(g.get("sd_prune._n_updates")[0])   # (preload aliases the checkpoint tensors, as the reference does)
+    conv3.train()
+    conv3(xt)
+    assert conv3.prune._n_updates.item() == before + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# behaviours the reference's tests pin (tests/test_sparse.py:43-202, tests/test_quantize.py:30-70,
+# tests/test_convert.py:75-137, tests/test_util.py:12-84)
+# ---------------------------------------------------------------------------------------------
+def _sparsity(t):
+    return 1 - t.count_nonzero().item() / t.numel()
+
+
+def test_prune_feature_properties():
+    start, interval, repetition = 5, 2, 3
+    data, data2x = torch.rand((1, 10, 32, 32)), torch.rand((1, 10, 64, 64))
+    layer = qs.prune(sparsity=0.5, start=start, interval=interval, repetition=repetition)
+    for _ in range(start + interval * (repetition + 1)):
+        out = layer(data)
+    assert np.isclose(_sparsity(out), 0.5, atol=1 / out.numel())
+    assert ((out == 0).numpy() == (layer.mask.numpy() == 0)).all()
+
+    np.random.seed(0)
+    layer = qs.prune(sparsity=0.5, start=start, interval=interval, repetition=repetition, dimensions={0, 1, 2, 3},
+                     callback=UniformPruningCallback())
+    total = start + interval * (repetition + 2)
+    for i in range(total):
+        if i == total - 1:
+            layer.eval()
+        out = layer(data)
+    assert np.isclose(_sparsity(out), 0.5, atol=1 / out.numel())
+    with pytest.raises(RuntimeError):
+        layer.eval()
+        layer(data2x)   # full-shape mask: input shape must not change
+
+    layer = qs.prune(sparsity=0.5, start=start, interval=interval, repetition=repetition, dimensions={1})
+    for _ in range(start + interval * (repetition + 1)):
+        layer(data)
+    layer.eval()
+    out = layer(data2x)   # channel mask broadcasts to a new spatial size
+    assert out.shape == data2x.shape and np.isclose(_sparsity(out), 0.5, atol=4 / out.numel())
+
+
+def test_weight_injection_properties():
+    data = torch.rand((1, 10, 32, 32))
+    pconv = qs.prune(nn.Conv2d(10, 30, 3), sparsity=0.5, start=5, interval=2, repetition=3,
+                     callback=MagnitudePruningCallback(running_average=False))
+    pconv.train()
+    for _ in range(13):
+        pconv(data)
+    assert np.isclose(_sparsity(pconv.weight), 0.5, atol=1 / pconv.weight.numel())
+    assert not np.isclose(_sparsity(dict(pconv.named_parameters())["weight"]), 0.5, atol=0.1)
+    pconv = qs.prune(nn.Conv2d(10, 30, 3), sparsity=0.5, start=5, interval=2, repetition=3)
+    pconv.eval()
+    for _ in range(13):
+        pconv(data)
+    assert not np.isclose(_sparsity(pconv.weight), 0.5, atol=0.1)   # schedule only advances in training
+    with pytest.raises(ValueError):
+        qs.prune(torch.rand((10,)))
+    with pytest.raises(ValueError):
+        qs.quantize(torch.rand((10,)))
+
+    qconv = qs.quantize(nn.Conv2d(10, 30, 3), bits=8, bias_bits=8, timeout=5, callback=ScalerQuantizer(), channelwise=0)
+    qconv.train()
+    for _ in range(6):
+        qconv(data)
+    assert (qconv.weight - quantize_with_scaler(qconv._parameters["weight"], 8, qconv.quantize.weight, 0)).sum() == 0
+    assert (qconv.bias - quantize_with_scaler(qconv._parameters["bias"], 8, qconv.quantize_bias.weight, 0)).sum() == 0
+    assert (qconv._parameters["weight"] - qconv.weight).sum().item() != 0
+
+
+def test_batched_channelwise_scaler_raises_like_reference():
+    layer = qs.quantize(bits=8, timeout=1, channelwise=1)
+    layer(torch.rand(4, 3, 5, 5))
+    with pytest.raises(RuntimeError):
+        layer(torch.rand(4, 3, 5, 5))
+
+
+def test_gradient_and_l0_magnitude_options():
+    shape = (3, 12, 12)
+    torch.manual_seed(0)
+    mean = torch.rand(*shape)
+    mask = torch.ones((1,) + shape, dtype=torch.bool)
+    cb = MagnitudePruningCallback(use_gradient=True)
+    for _ in range(300):
+        inp = torch.normal(mean, 1).view(1, *shape).requires_grad_(True)
+        cb(inp, 0.5, mask).backward(torch.rand((1,) + shape) / 10)
+    assert np.isclose(_sparsity(mask), 0.5, atol=2 / mask.numel())
+    mask = torch.ones(shape, dtype=torch.bool)
+    cb = MagnitudePruningCallback(l0=True)
+    for _ in range(300):
+        cb((torch.rand(*shape) > 0.5).float(), 0.5, mask)
+    assert np.isclose(_sparsity(mask), 0.5, atol=2 / mask.numel())
+
+
+def test_layerwise_schedule_and_naming_and_options():
+    net = qs.convert(LeNet(), qs.prune(sparsity=0.5, callback=MagnitudePruningCallback()),
+                     activation_layers=[nn.Conv2d, nn.Linear], log=False)
+    net = qs.devise_layerwise_pruning_schedule(net, start=10, interval=100, mask_refresh_interval=10)
+    starts = [m.start for m in net.modules() if isinstance(m, PruneLayer)]
+    assert starts == sorted(starts) and len(starts) == 5
+
+    class Two(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear1 = qs.quantize(qs.prune(nn.Linear(10, 30)))
+            self.linear2 = qs.quantize(qs.prune(nn.Linear(30, 1)))
+
+    net = qs.auto_name_prune_quantize_layers(Two())
+    assert net.linear1.prune.name == "linear1.prune" and net.linear2.quantize.name == "linear2.quantize"
+    assert qs.get_qsparse_option("log_on_created") is False
+    lenet = LeNet()
+    with pytest.warns(UserWarning):
+        assert str(qs.convert(lenet, qs.prune(sparsity=0.5))) == str(lenet)
+    dp = qs.convert(nn.DataParallel(LeNet()), qs.quantize(bits=8), weight_layers=[nn.Conv2d, nn.Linear],
+                    activation_layers=[nn.Conv2d, nn.Linear], log=False)
+    assert "quantize" in str(dp).lower()
+    seq = nn.Sequential(OrderedDict([("conv1", nn.Conv2d(3, 6, 5)), ("special", nn.Sequential(nn.Conv2d(6, 16, 5)))]))
+    res = str(qs.convert(seq, qs.quantize(bits=8), weight_layers=[nn.Conv2d], include=["special"], log=False))
+    assert res.count("quantize") == 1 and res.index("special") < res.index("quantize")
+
+
+def test_exact_sparsity_and_squeeze_shape():
+    t = torch.rand(10, 30, 7, 8)
+    mask = qs.calculate_mask_given_importance(t, 0.47)
+    assert 1 - mask.sum().item() / mask.numel() == 0.47
+    assert tuple(squeeze_tensor_to_shape(t, (1, 30, 7, 1)).shape) == (1, 30, 7, 1)
+    with pytest.raises(ValueError):
+        squeeze_tensor_to_shape(t, (1, 30, 3, 1))
