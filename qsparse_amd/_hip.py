@@ -55,6 +55,43 @@ SIGNATURES = {
 
 _lib = None
 
+# ---- optional per-kernel timing with HIP events (bench.py) -----------------------------------------
+# torch.cuda.Event records on torch's current stream, which is the stream every kernel here is
+# launched on, so (start, end) pairs bracket exactly one launch.
+_event_log = None
+
+
+def start_event_log():
+    global _event_log
+    _event_log = {}
+
+
+def stop_event_log():
+    """returns {kernel name: [ms, ...]} (synchronises)."""
+    global _event_log
+    log, _event_log = _event_log, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (log or {}).items()}
+
+
+class _timed:
+    __slots__ = ("name", "a")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _event_log is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _event_log is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _event_log.setdefault(self.name, []).append((self.a, b))
+        return False
+
 
 def load(path: Optional[str] = None):
     """dlopen the library and declare every prototype (no GPU needed for this)."""
@@ -118,7 +155,7 @@ def split3(shape, channel_index: int):
     for s in shape:
         numel *= s
     if channel_index < 0:
-        return 1, 1, max(numel, 1) if numel else 1, numel
+        return 1, 1, max(numel, 1), numel
     outer = 1
     for s in shape[:channel_index]:
         outer *= s
@@ -158,8 +195,9 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
         assert cm.numel() == C
     sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
-    st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-            _DT[qdtype], sat, lo, hi, _stream(x))
+    with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else "")):
+        st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
+                _DT[qdtype], sat, lo, hi, _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     return y, codes
 
@@ -194,9 +232,10 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
     if chan_mask is not None:
         cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
         assert cm.numel() == C
-    st = lib.qs_quant_ste_bwd(_ptr(g), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)), float(lo_mul),
-                              float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g), _DT[out_dtype],
-                              _stream(g))
+    with _timed("quant_ste_bwd" + ("+mask" if cm is not None else "")):
+        st = lib.qs_quant_ste_bwd(_ptr(g), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)), float(lo_mul),
+                                  float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g),
+                                  _DT[out_dtype], _stream(g))
     _check(st, "qs_quant_ste_bwd")
     return gx
 
@@ -210,7 +249,8 @@ def absmax(x: torch.Tensor, channel_index: int) -> torch.Tensor:
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
+    with _timed("absmax"):
+        st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
     _check(st, "qs_absmax")
     return out
 
@@ -254,8 +294,9 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     """x: contiguous storage viewed as [pre, n, post]; returns a flat [pre*post] tensor."""
     x = dense(x)
     out = torch.empty(pre * post, dtype=out_dtype, device=x.device)
-    st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
-                            _ptr(absmax_out), int(chan_div), int(C), _stream(x))
+    with _timed("mean_dim" + ("+absmax" if absmax_out is not None else "")):
+        st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
+                                _ptr(absmax_out), int(chan_div), int(C), _stream(x))
     _check(st, "qs_mean_dim")
     return out
 
@@ -316,7 +357,8 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     nd = x.dim()
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
-    st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), _stream(x))
+    with _timed("mask_apply"):
+        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), _stream(x))
     _check(st, "qs_mask_apply")
     return y
 

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void mean_outer_vec_kernel(const void* __re
                                                                  uint32_t C) {
     const int64_t gcols = vcols / 8;                 // column groups per slice
     const int64_t total = pre * gcols;
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // block size is a launch-time tunable
     const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
     const int lp = max(4, ceil_log2_i64(n) / 4);
     const int64_t step = (int64_t)1 << lp, lmask = step - 1;

@@ -1,0 +1,344 @@
+"""GPU parity: the HIP path (through the C ABI of libqsparse_hip.so) against
+  (1) the golden vectors recorded from the real reference,
+  (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds,
+  (3) size-independent properties at the BASELINE.json shapes (256x64x56x56 and 256x256x56x56).
+
+Bars (north_star): integer codes, masks, indices and counters bit-exact; floating-point values within
+1e-6 relative -- and in fact every float comparison below is asserted bit-exact too, because each
+kernel performs the reference's fp32 operator chain with one rounding per operator.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import qsparse_amd as qs
+from golden_io import same
+from oracle import qs_oracle as O
+from qsparse_amd import _hip
+from qsparse_amd.quantize import quantize_with_decimal, quantize_with_line, quantize_with_scaler
+from qsparse_amd.sparse import apply_mask
+from qsparse_amd.util import squeeze_tensor_to_shape
+
+import test_host_golden as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REL_TOL = 1e-6   # north_star: floating-point quantized values within 1e-6 relative
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def close(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return bool(((a - b).abs() <= REL_TOL * b.abs()).all())
+
+
+def test_library_is_loaded_and_versioned():
+    lib = _hip.load()
+    assert lib.qs_version() == 1
+    assert torch.cuda.is_available()
+
+
+# ---- (1) golden fixtures on the GPU ------------------------------------------------------------
+def test_golden_f1_f2_functional():
+    H.run_f1_f2(DEV)
+
+
+def test_golden_f3_line():
+    H.run_f3(DEV)
+
+
+def test_golden_f4_quantize_layer():
+    H.run_f4(DEV)
+
+
+def test_golden_f5_squeeze():
+    H.run_f5(DEV)
+
+
+def test_golden_f6_mask():
+    H.run_f6(DEV)
+
+
+def test_golden_f7_prune_layer():
+    H.run_f7(DEV)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_golden_f10_pair(fused):
+    H.run_f10(DEV, fused)
+
+
+# ---- (2) oracle parity on seeded inputs -----------------------------------------------------------
+SHAPES = [(8, 64, 28, 28), (3, 7, 5, 3), (2, 5, 7, 7), (64, 40), (1, 16, 56, 56), (4099,)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_scaler_fwd_bwd_vs_oracle(dtype, shape):
+    x = (torch.randn(shape, generator=gen(1)) * 3).to(dtype)
+    gout = torch.randn(shape, generator=gen(2)) * 2
+    cases = [(-1, torch.tensor([[0.0371]]) if len(shape) > 1 else torch.tensor([0.0371]))]
+    if len(shape) > 1:
+        for ci in (0, 1, len(shape) - 1):
+            cases.append((ci, torch.rand(shape[ci], 1, generator=gen(3 + ci)) * 0.2 + 0.003))
+    for ci, s in cases:
+        for bits, flip in ((8, False), (4, True)):
+            y_ref = O.scaler_fwd(x, bits, s, ci)
+            codes_ref = O.scaler_codes(x, s, ci)
+            gx_ref = O.ste_bwd(gout, bits, s, ci, flip, False, dtype)
+            xg = x.to(DEV).requires_grad_(True)
+            y = quantize_with_scaler(xg, bits, s.to(DEV), ci, False, False, flip)
+            y.backward(gout.to(DEV))
+            _, codes = _hip.quant_fwd("scaler", x.to(DEV), s.to(DEV), ci, torch.float32, want_codes=True)
+            assert same(codes.cpu(), codes_ref), (shape, ci)          # integer class: bit-exact
+            assert close(y, y_ref) and same(y.detach().cpu(), y_ref), (shape, ci)
+            assert same(xg.grad.cpu(), gx_ref), (shape, ci, bits)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decimal_and_line_vs_oracle(dtype):
+    shape = (4, 24, 14, 14)
+    x = (torch.randn(shape, generator=gen(5)) * 2).to(dtype)
+    for ci, d in ((-1, torch.tensor([[5.0]])), (1, torch.randint(0, 9, (24, 1), generator=gen(6)).float())):
+        y = quantize_with_decimal(x.to(DEV), 8, d.to(DEV), ci)
+        assert same(y.cpu(), O.decimal_fwd(x, 8, d, ci))
+        _, codes = _hip.quant_fwd("decimal", x.to(DEV), d.to(DEV), ci, torch.float32, want_codes=True)
+        assert same(codes.cpu(), O.decimal_codes(x, d, ci))
+    lo = -torch.rand(24, 1, generator=gen(7)) * 2
+    hi = torch.rand(24, 1, generator=gen(8)) * 2 + 0.05
+    lines = torch.cat([lo, hi], 1)
+    for ci, ln in ((-1, lines[:1]), (1, lines)):
+        for fzp in (True, False):
+            y = quantize_with_line(x.to(DEV), 4, ln.to(DEV), ci, False, fzp)
+            assert same(y.cpu(), O.line_fwd(x, 4, ln, ci, fzp)), (ci, fzp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_statistics_vs_oracle(dtype):
+    for shape, ci in (((16, 32, 28, 28), -1), ((16, 32, 28, 28), 1), ((1, 32, 28, 28), 1), ((48, 20, 3, 3), 0),
+                      ((40, 33), 1), ((7,), 0), ((16, 32, 5, 5), 1)):
+        x = (torch.randn(shape, generator=gen(11)) * 5).to(dtype)
+        am = _hip.absmax(x.to(DEV), ci).cpu()
+        ref = x.abs().float().amax() if ci < 0 else x.abs().float().transpose(0, ci).reshape(shape[ci], -1).amax(1)
+        assert same(am.view(-1), ref.reshape(-1).float()), (shape, ci)
+        mn, mx = _hip.minmax(x.to(DEV), ci)
+        xr = x.float().reshape(1, -1) if ci < 0 else x.float().transpose(0, ci).reshape(shape[ci], -1)
+        assert same(mn.cpu(), xr.amin(1)) and same(mx.cpu(), xr.amax(1)), (shape, ci)
+
+
+def test_quantize_layer_running_scale_vs_oracle():
+    for kind, cw, shape in (("scaler", -1, (8, 16, 14, 14)), ("decimal", -1, (8, 16, 14, 14)),
+                            ("adaptive", 1, (8, 16, 14, 14)), ("adaptive", -1, (8, 16, 14, 14)),
+                            ("scaler", 1, (1, 16, 14, 14))):
+        layer = qs.quantize(bits=4, channelwise=cw, timeout=2, callback=H.MK[kind]()).to(DEV)
+        sim = O.QuantizeSim(kind, 4, cw, 2)
+        layer.train()
+        for s in range(7):
+            if s == 6:
+                layer.eval()
+            x = ((torch.rand(shape, generator=gen(100 + s)) - 0.4) * (3 + s)).bfloat16()
+            y = layer(x.to(DEV))
+            y_ref = sim.step(x, training=s < 6)
+            assert same(y.cpu(), y_ref), (kind, cw, s)
+            assert same(layer.weight.detach().cpu(), sim.weight), (kind, cw, s)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_staged_mean_vs_oracle(dtype):
+    """staged means reproduce ATen's CPU summation order: exact equality, all shapes / paths."""
+    for shape, mshape in (((32, 24, 28, 28), (1, 24, 1, 1)), ((256, 8, 8, 8), (1, 8, 1, 1)),
+                          ((5, 6, 7, 9), (1, 6, 1, 1)), ((5, 6, 7, 9), (5, 6, 1, 1)), ((5, 6, 7, 9), (1, 1, 7, 9)),
+                          ((12, 6, 7, 56), (1, 6, 1, 1)), ((300, 70), (1, 70)), ((20, 3, 40, 100), (1, 3, 40, 1)),
+                          ((4, 10, 3, 3), (1, 10, 3, 3)), ((6, 16, 12, 12), (6, 16, 12, 12)), ((1030, 16), (1, 16))):
+        x = (torch.randn(shape, generator=gen(21)).abs() * torch.linspace(0.25, 4, shape[1]).view(
+            [1, -1] + [1] * (len(shape) - 2))).to(dtype)
+        out = squeeze_tensor_to_shape(x.to(DEV), mshape)
+        assert same(out.cpu(), O.squeeze_mean(x, mshape)), (shape, mshape)
+
+
+def test_kth_value_and_mask_vs_oracle():
+    for n, tie in ((256, False), (2048, True), (40000, False), (600000, True), (2359296, False)):
+        imp = torch.rand(n, generator=gen(31))
+        if tie:
+            imp = (imp * 50).floor() / 50
+        imp[::7] *= -1
+        for s in (0.0, 0.31, 0.5, 0.75, 0.97):
+            m = qs.calculate_mask_given_importance(imp.to(DEV), s)
+            assert bool((m.cpu() == O.mask_from_importance(imp, s)).all()), (n, tie, s)
+    nanimp = torch.rand(1000, generator=gen(32))
+    nanimp[5] = float("nan")
+    assert bool((qs.calculate_mask_given_importance(nanimp.to(DEV), 0.5).cpu() == O.mask_from_importance(nanimp, 0.5)).all())
+    with pytest.raises(IndexError):
+        qs.calculate_mask_given_importance(torch.rand(10, device=DEV), 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mask_apply_patterns_vs_oracle(dtype):
+    shape = (6, 10, 7, 8)
+    x = torch.randn(shape, generator=gen(41)).to(dtype)
+    gout = torch.randn(shape, generator=gen(42)).to(dtype)
+    for mshape in ((1, 10, 1, 1), (6, 10, 1, 1), (1, 10, 7, 1), (6, 1, 7, 1), (1, 1, 1, 8), (6, 10, 7, 8), (1, 1, 1, 1),
+                   (6, 1, 1, 8)):
+        mask = torch.rand(mshape, generator=gen(43)) > 0.4
+        xg = x.to(DEV).requires_grad_(True)
+        y = apply_mask(xg, mask.to(DEV))
+        y.backward(gout.to(DEV))
+        assert same(y.detach().cpu(), x * mask), mshape
+        assert same(xg.grad.cpu(), gout * mask), mshape
+    with pytest.raises(RuntimeError):
+        apply_mask(x.to(DEV), torch.ones(6, 10, 7, 9, dtype=torch.bool, device=DEV))
+
+
+def test_prune_and_pair_trajectories_vs_oracle():
+    """whole-layer trajectories (schedule, running magnitude, refresh, fused pair) on a mid-size
+    activation: unfused GPU == fused GPU == oracle, step by step, bit for bit."""
+    shape, C = (16, 48, 14, 14), 48
+    for dtype in (torch.bfloat16, torch.float32):
+        mods, sims = [], (O.PruneSim(0.75, [1], 2, 2, 3, False), O.QuantizeSim("scaler", 4, -1, 3))
+        for fused in (False, True):
+            pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.75, dimensions={1}, start=2, interval=2,
+                                                                        repetition=3)),
+                                 qs.quantize(bits=4, channelwise=-1, timeout=3)).to(DEV)
+            if fused:
+                from qsparse_amd.fused import fuse_prune_quantize_pairs
+                fuse_prune_quantize_pairs(pair)
+            mods.append(pair.train())
+        for s in range(12):
+            training = s < 11
+            x = (torch.randn(shape, generator=gen(200 + s)).relu() * torch.linspace(0.25, 4, C).view(1, -1, 1, 1)).to(dtype)
+            gout = torch.randn(shape, generator=gen(300 + s))
+            n_before = sims[0].n_updates
+            h_ref = sims[0].step(x, training)
+            y_ref = sims[1].step(h_ref, training)
+            gx_ref = sims[0].grad(sims[1].grad(gout, dtype), (not training) or n_before >= 2)
+            for pair in mods:
+                if not training:
+                    pair.eval()
+                xg = x.to(DEV).requires_grad_(True)
+                y = pair(xg)
+                y.backward(gout.to(DEV).to(y.dtype))
+                pl, ql = pair[0][1], pair[1]
+                assert same(y.detach().cpu(), y_ref), (dtype, s)
+                assert same(xg.grad.cpu(), gx_ref), (dtype, s)
+                assert same(pl.mask.detach().cpu(), sims[0].mask), (dtype, s)
+                assert same(ql.weight.detach().cpu(), sims[1].weight), (dtype, s)
+                if sims[0].magnitude is not None:
+                    assert same(pl.callback.magnitude.detach().cpu(), sims[0].magnitude), (dtype, s)
+                assert pl._n_updates.item() == sims[0].n_updates and ql._n_updates.item() == sims[1].n_updates
+
+
+def test_l0_and_unstructured_and_2d_vs_oracle():
+    sim = O.PruneSim(0.5, [1], 1, 1, 2, False, l0=True)
+    layer = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2,
+                     callback=qs.MagnitudePruningCallback(l0=True)).to(DEV).train()
+    for s in range(6):
+        x = (torch.randn(4, 12, 6, 6, generator=gen(400 + s)) * torch.linspace(0.1, 2, 12).view(1, -1, 1, 1)).relu()
+        assert same(layer(x.to(DEV)).cpu(), sim.step(x))
+        assert same(layer.mask.cpu(), sim.mask)
+    sim = O.PruneSim(0.6, [0, 1, 2, 3], 1, 1, 2, False)
+    layer = qs.prune(sparsity=0.6, dimensions={0, 1, 2, 3}, start=1, interval=1, repetition=2).to(DEV).train()
+    for s in range(6):
+        x = torch.randn(3, 8, 6, 6, generator=gen(500 + s)).bfloat16()
+        assert same(layer(x.to(DEV)).cpu(), sim.step(x))
+    sim = O.PruneSim(0.5, [1], 1, 1, 2, False)
+    layer = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2).to(DEV).train()
+    for s in range(6):
+        x = torch.randn(32, 40, generator=gen(600 + s)).bfloat16()
+        assert same(layer(x.to(DEV)).cpu(), sim.step(x))
+
+
+def test_abi_rejects_bad_arguments_loudly():
+    x = torch.randn(64, device=DEV, dtype=torch.float64)
+    with pytest.raises(_hip.QsparseHipError):
+        quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
+    lib = _hip.load()
+    y = torch.empty(64, device=DEV)
+    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, None)
+    assert st == -3 and b"aligned" in lib.qs_status_string(st)
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, None) == -1
+    # odd storage offsets are re-packed by the binding instead of failing
+    base = torch.randn(1001, device=DEV)
+    assert same(quantize_with_scaler(base[1:], 8, 0.1).cpu(), O.scaler_fwd(base[1:].cpu(), 8, 0.1))
+    assert quantize_with_scaler(torch.empty(0, 4, device=DEV), 8, 0.1).shape == (0, 4)
+
+
+# ---- (3) BASELINE.json shapes: size-independent properties -----------------------------------------
+def _headline_input(n, c, dtype=torch.bfloat16):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(0)
+    x = torch.randn((n, c, 56, 56), generator=g, device=DEV).relu_()
+    x *= torch.linspace(0.25, 4.0, c, device=DEV).view(1, c, 1, 1)
+    return x.to(dtype)
+
+
+@pytest.mark.parametrize("n,c,bits", [(256, 64, 8), (256, 256, 4)])
+def test_full_size_properties(n, c, bits):
+    x = _headline_input(n, c)
+    s = (x.abs().amax().float() / 2 ** (bits - 1)).view(1, 1)
+    xg = x.clone().requires_grad_(True)
+    y = quantize_with_scaler(xg, bits, s)
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    # (a) every output is an integer multiple of the scale, with |code| <= 2^(bits-1)
+    codes = (y / s).round()
+    assert torch.equal(codes * s, y) and codes.abs().max().item() <= 2 ** (bits - 1)
+    # (b) idempotence: quantizing the quantized tensor changes nothing
+    assert torch.equal(quantize_with_scaler(y, bits, s), y)
+    # (c) error bound: |y - x| <= s/2 (+ 1 ulp of the product)
+    assert ((y - x.float()).abs() <= s * 0.5 * (1 + 1e-6)).all()
+    # (d) a slice of the big launch equals the oracle on that slice (same kernel, same arithmetic)
+    sl = (slice(n - 2, n), slice(None), slice(None), slice(None))
+    assert same(y[sl].detach().cpu(), O.scaler_fwd(x[sl].cpu(), bits, s.cpu(), -1))
+    # (e) STE backward: values clamped into the interval, untouched inside; checksum against torch
+    g = torch.randn(x.shape, device=DEV)
+    y.backward(g)
+    lo, hi = O.ste_bounds(bits, s)
+    assert xg.grad.dtype == torch.bfloat16
+    assert torch.equal(xg.grad, torch.clamp(g, lo.item(), hi.item()).to(torch.bfloat16))
+    del y, g, codes
+    # (f) channel mask apply: exact zeros on pruned channels, bit-identical elsewhere, backward too
+    mask = (torch.arange(c, device=DEV) % 4 == 1).view(1, c, 1, 1)
+    xm = x.clone().requires_grad_(True)
+    ym = apply_mask(xm, mask)
+    assert torch.equal(ym[:, ~mask.view(-1)], torch.zeros_like(ym[:, ~mask.view(-1)]))
+    assert torch.equal(ym[:, mask.view(-1)], x[:, mask.view(-1)])
+    # (g) per-channel abs-max / tensor abs-max agree with torch reductions (order independent)
+    assert torch.equal(_hip.absmax(x, 1), x.abs().amax(dim=(0, 2, 3)).float())
+    assert torch.equal(_hip.absmax(x, -1), x.abs().amax().float().view(1))
+
+
+def test_full_size_fused_pair_step_matches_unfused():
+    """headline shape: one live training step of the fused pair == the two layers run separately."""
+    x = _headline_input(256, 256)
+    g = torch.randn(x.shape, device=DEV)
+    outs = []
+    for fused in (False, True):
+        pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.75, dimensions={1}, start=0, interval=1,
+                                                                    repetition=1)),
+                             qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train()
+        if fused:
+            from qsparse_amd.fused import fuse_prune_quantize_pairs
+            fuse_prune_quantize_pairs(pair)
+        for step in range(3):
+            xg = x.clone().requires_grad_(True)
+            y = pair(xg)
+            y.backward(g)
+        outs.append((y.detach(), xg.grad, pair[0][1].mask.clone(), pair[1].weight.clone(),
+                     pair[0][1].callback.magnitude.clone()))
+        del y, xg
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    mask = outs[0][2].view(-1)
+    assert mask.sum().item() == 64                      # 75 % of 256 channels pruned
+    # magnitude against the oracle's staged mean on the same data (CPU, one channel block at a time is too slow:
+    # compare the first 4 channels only)
+    m = O.squeeze_mean(x[:, :4].cpu().abs(), (1, 4, 1, 1)).view(-1)
+    ref = torch.zeros(4)
+    for t in range(3):
+        ref = (t * ref + m) / (t + 1)          # sparse.py:89 with the same input three times
+    assert torch.equal(outs[0][4].view(-1)[:4].cpu(), ref)
