@@ -128,14 +128,20 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
  * 4-way interleave), one fp32 division by n, one rounding to odt.
  * flags: QS_MEAN_ABS takes |x| first (sparse.py:87);  QS_MEAN_L0 maps x -> (x != 0) when *l0_flag != 0
  * (sparse.py:85-86; l0_flag is a device int written by qs_l0_flag).
- * absmax_out (nullable, device float[C]) additionally receives per-channel max|x| where channel =
- * (column / chan_div) % C  -- the statistics of a following tensor-wise QuantizeLayer fused into the
- * same read of x. */
+ * absmax_out (nullable, device float[C]) is additionally max-ACCUMULATED with per-channel max|x|, where
+ * channel = (column / chan_div) % C  -- the statistics of a following tensor-wise QuantizeLayer fused
+ * into the same read of x.  The caller provides it zeroed (qs_pq_select re-zeroes it after use). */
 #define QS_MEAN_ABS 1
 #define QS_MEAN_L0 2
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream);
+
+/* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
+ * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].
+ * Same summation order and rounding points as two qs_mean_dim calls.  (H*W + W)*4 bytes of LDS <= 48 KiB,
+ * otherwise QS_ERR_ARG (use two qs_mean_dim calls). */
+int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, qs_stream_t stream);
 
 /* *flag = (min(x) == 0), qsparse/sparse.py:85 */
 int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scratch2, qs_stream_t stream);
@@ -171,12 +177,15 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  *   mask       <- magnitude >= sort(magnitude)[k]                      if refresh_mask       (util.py:113-117)
  *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340)
  *   scale      <- t_q == 0 ? new : (t_q*scale + new)/(t_q+1), new = absmax_all/2^(bits-1)  if update_scale
- * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536. */
+ * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536.
+ * chan_absmax is zeroed after use when update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64 (each
+ * nullable) are one-element device counters incremented by one: the layers' `_n_updates` and the
+ * callback's `t` (sparse.py:117,272; quantize.py:515), so that a step needs no separate counter kernels. */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
-                 const float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
-                 void* ws, size_t ws_bytes, qs_stream_t stream);
+                 float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
+                 int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

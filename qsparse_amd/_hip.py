@@ -50,7 +50,8 @@ SIGNATURES = {
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, c_size_t, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
+    "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
 }
 
 _lib = None
@@ -59,11 +60,21 @@ _lib = None
 # torch.cuda.Event records on torch's current stream, which is the stream every kernel here is
 # launched on, so (start, end) pairs bracket exactly one launch.
 _event_log = None
+_event_filter = None
 
 
-def start_event_log():
-    global _event_log
+def start_event_log(only=None):
+    """only: optional collection of kernel names to time (every event pair costs a few us of stream time)."""
+    global _event_log, _event_filter
     _event_log = {}
+    _event_filter = set(only) if only else None
+
+
+def take_event_pairs():
+    """hand over the recorded (start, end) event pairs without synchronising; stops logging."""
+    global _event_log
+    log, _event_log = _event_log, None
+    return log or {}
 
 
 def stop_event_log():
@@ -81,12 +92,13 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if _event_log is not None:
+        self.a = None
+        if _event_log is not None and (_event_filter is None or self.name in _event_filter):
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if _event_log is not None:
+        if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _event_log.setdefault(self.name, []).append((self.a, b))
@@ -134,7 +146,13 @@ def dt(t: torch.Tensor) -> int:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    """raw device address; a host tensor here would fault the GPU, so refuse it loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise QsparseHipError(f"tensor of shape {tuple(t.shape)} lives on {t.device}, expected a GPU tensor: move the "
+                              "module / argument to the input's device")
+    return t.data_ptr()
 
 
 def _stream(t: torch.Tensor):
@@ -301,6 +319,16 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     return out
 
 
+def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """x viewed as [pre, H, W] -> [pre]: mean over H then over W, each rounded like ``Tensor.mean``."""
+    x = dense(x)
+    out = torch.empty(pre, dtype=out_dtype, device=x.device)
+    with _timed("mean_last2"):
+        st = load().qs_mean_last2(_ptr(x), _ptr(out), pre, H, W, dt(x), _DT[out_dtype], _stream(x))
+    _check(st, "qs_mean_last2")
+    return out
+
+
 def l0_flag(x: torch.Tensor) -> torch.Tensor:
     x = dense(x)
     flag = torch.empty(1, dtype=torch.int32, device=x.device)
@@ -350,7 +378,7 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         if sm != 1 and sm != sx:
             raise RuntimeError(
                 f"The size of tensor a ({sx}) must match the size of tensor b ({sm}) at non-singleton dimension")
-    m = mask.detach().contiguous()
+    m = mask.detach().to(x.device).contiguous()
     y = torch.empty_like(x)
     if x.numel() == 0:
         return y
@@ -365,10 +393,16 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 
 def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], update_magnitude: bool, t_mag: int,
               refresh_mask: bool, k: int, mask: torch.Tensor, chan_absmax: Optional[torch.Tensor], update_scale: bool,
-              t_q: int, bits: int, scale: Optional[torch.Tensor]):
+              t_q: int, bits: int, scale: Optional[torch.Tensor], bump_a: Optional[torch.Tensor] = None,
+              bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None):
+    """bump_a / bump_b: int32 one-element counters, bump_c: int64 one-element counter (each optional)."""
     C = magnitude.numel()
     sdt = dt(stage_mean) if stage_mean is not None else F32
-    st = load().qs_pq_select(_ptr(magnitude), _ptr(stage_mean), sdt, C, int(update_magnitude), int(t_mag),
-                             int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
-                             int(bits), _ptr(scale), None, 0, _stream(magnitude))
+    assert bump_a is None or bump_a.dtype == torch.int32
+    assert bump_b is None or bump_b.dtype == torch.int32
+    assert bump_c is None or bump_c.dtype == torch.int64
+    with _timed("pq_select"):
+        st = load().qs_pq_select(_ptr(magnitude), _ptr(stage_mean), sdt, C, int(update_magnitude), int(t_mag),
+                                 int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
+                                 int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _stream(magnitude))
     _check(st, "qs_pq_select")

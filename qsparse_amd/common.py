@@ -40,6 +40,11 @@ class HostMirror:
             p.add_(delta)
         self._value, self._version = cur + delta, p._version
 
+    def note_device_add(self, p: torch.Tensor, delta: int = 1):
+        """the tensor was (or will be, in stream order) incremented by a kernel through its raw pointer:
+        only the host copy needs updating."""
+        self._value = self.read(p) + delta
+
     def write(self, p: torch.Tensor, value):
         with torch.no_grad():
             p.fill_(value)

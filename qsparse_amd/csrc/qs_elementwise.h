@@ -14,6 +14,7 @@ struct EwGeom {
     uint32_t C;               // channel extent
     uint32_t inner;           // elements after the channel dim
     uint32_t groups_per_row;  // inner / 8 (CM_ROW only)
+    uint32_t reverse;         // walk the tensor from its end (cache-reuse hint, see launch_ew)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -33,11 +34,14 @@ struct ScalerFwdOp {
     int32_t lo, hi;
     struct P {
         float s;
+        float r;      // RN(1/s)
         float keep;
     };
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         p.s = scale ? scale[c] : scale_host;
+        p.r = 1.0f / p.s;
+        if (fabsf(p.r) < 1.17549435e-38f) p.r = __builtin_nanf("");   // subnormal reciprocal: always divide
         p.keep = 1.0f;
         return p;
     }
@@ -46,10 +50,24 @@ struct ScalerFwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
+    // rint(RN(v / s)) without dividing in the common case.  t = RN(v * RN(1/s)) differs from RN(v/s) by at
+    // most 1.5 * 2^-23 relative, so both round to the same integer unless t lies within |t| * 2^-21 of a
+    // half-way point k + 0.5; only then (probability ~2^-18..2^-14 per element for 4..8-bit codes) is the
+    // correctly rounded division evaluated.  NaN / inf / huge t fall through to the division as well.
+    __device__ __forceinline__ float quotient_rint(float v, const P& p) const {
+        if constexpr (QDT != QS_F32) {
+            return rintf(round_through<QDT>(v / p.s));   // quotient rounded to the input dtype first
+        } else {
+            const float t = v * p.r;
+            const float n = rintf(t);
+            const float off = fabsf(fabsf(t - n) - 0.5f);      // distance of t from the nearest k + 0.5
+            if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return n;   // 2^-21
+            return rintf(v / p.s);
+        }
+    }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
-        float q = round_through<QDT>(v / p.s);   // correctly rounded fp32 division (:109)
-        int32_t qi = (int32_t)rintf(q);          // half-to-even, then .int()
+        int32_t qi = (int32_t)quotient_rint(v, p);   // round(x / s).int(): half-to-even (:109)
         if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
         code = qi;
         return (float)qi * p.s;                  // q.float() * scaler (:117)
@@ -196,7 +214,8 @@ template <typename Op, int XDT, int YDT, int CM, bool PARAM_PER_CHANNEL, bool NT
 __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                      void* __restrict__ y, int32_t* __restrict__ codes) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t g0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
+    int64_t g0 = blk * kBlock + threadIdx.x;
 
     typename Op::P p_scalar = op.channel(0);  // used as is in CM_SCALAR
 

@@ -237,69 +237,78 @@ __device__ __forceinline__ float sum_row_sum(int64_t n, F get) {
 // ---- hot stage: outer reduction, 8 adjacent columns per lane, multi-row order ---------------------
 // x: [pre, n, post] contiguous; handles columns [0, vcols) of every `pre` slice (vcols % 8 == 0).
 // Optionally accumulates per-channel max|x| (channel = (col / chan_div) % C) for a fused abs-max.
+// Launch geometry: ONE wave per workgroup, of which only the first `lanes` (<= 64) lanes own a column group.
+// A CU sustains ~10 B/clk from HBM whatever runs on it, so the kernel is only as fast as its busiest CU:
+// the host picks `lanes` such that the number of waves is (close to) a multiple of the 256 CUs -- e.g.
+// 100352 column groups -> 56 lanes x 1792 waves = exactly 7 waves per CU instead of 64 x 1568 (6.1, i.e.
+// 7 on some CUs and 6 on others).
 template <int DT, int ODT, int ROWS_IN_FLIGHT>
-__global__ __launch_bounds__(kBlock) void mean_outer_vec_kernel(const void* __restrict__ x, void* __restrict__ out,
-                                                                 int64_t pre, int64_t n, int64_t post, int64_t vcols,
-                                                                 int flags, const int32_t* __restrict__ l0_flag,
-                                                                 uint32_t* __restrict__ absmax, int64_t chan_div,
-                                                                 uint32_t C) {
+__global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                             int64_t pre, int64_t n, int64_t post, int64_t vcols,
+                                                             int flags, const int32_t* __restrict__ l0_flag,
+                                                             uint32_t* __restrict__ absmax, int64_t chan_div,
+                                                             uint32_t C, int lanes) {
     const int64_t gcols = vcols / 8;                 // column groups per slice
     const int64_t total = pre * gcols;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // block size is a launch-time tunable
+    const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
+    const bool active = (int)threadIdx.x < lanes && t < total;
     const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
     const int lp = max(4, ceil_log2_i64(n) / 4);
     const int64_t step = (int64_t)1 << lp, lmask = step - 1;
     const float fn = (float)n;
-    if (t >= total) return;
 
-    const int64_t p = t / gcols, gc = t - p * gcols;
+    const int64_t tt = active ? t : 0;
+    const int64_t p = tt / gcols, gc = tt - p * gcols;
     const int64_t row_groups = post / 8;             // 16-byte groups per row (post % 8 == 0 guaranteed)
     const int64_t g_base = p * n * row_groups + gc;
-    Cascade acc[8];
     uint32_t amax = 0u;
 
-    auto consume = [&](const Raw8<DT>& r) {
-        float v[8];
-        unpack8<DT>(r, v);
+    if (active) {
+        Cascade acc[8];
+        auto consume = [&](const Raw8<DT>& r) {
+            float v[8];
+            unpack8<DT>(r, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (absmax) {
-                const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
-                amax = k > amax ? k : amax;
+            for (int j = 0; j < 8; ++j) {
+                if (absmax) {
+                    const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
+                    amax = k > amax ? k : amax;
+                }
+                acc[j].add(mean_prep<DT>(v[j], flags, l0));
             }
-            acc[j].add(mean_prep<DT>(v[j], flags, l0));
-        }
-    };
+        };
 
-    int64_t i = 0;
-    while (i + step <= n) {
-        // step is a power of two >= 16, so it is a multiple of ROWS_IN_FLIGHT (8 or 16)
-        for (int64_t j = 0; j < step; j += ROWS_IN_FLIGHT) {
-            Raw8<DT> r[ROWS_IN_FLIGHT];
+        int64_t i = 0;
+        while (i + step <= n) {
+            // step is a power of two >= 16, so it is a multiple of ROWS_IN_FLIGHT (8 or 16)
+            for (int64_t j = 0; j < step; j += ROWS_IN_FLIGHT) {
+                Raw8<DT> r[ROWS_IN_FLIGHT];
 #pragma unroll
-            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) r[u] = load8_raw<DT, false>(x, g_base + (i + j + u) * row_groups);
+                for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+                    r[u] = load8_raw<DT, false>(x, g_base + (i + j + u) * row_groups);
 #pragma unroll
-            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) consume(r[u]);
+                for (int u = 0; u < ROWS_IN_FLIGHT; ++u) consume(r[u]);
+            }
+            i += step;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
         }
-        i += step;
+        for (; i < n; ++i) consume(load8_raw<DT, false>(x, g_base + i * row_groups));
+
+        float m[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+        for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;   // .div_(n) in fp32, then one rounding to ODT
+        store8<ODT, false>(out, p * row_groups + gc, m);
     }
-    for (; i < n; ++i) consume(load8_raw<DT, false>(x, g_base + i * row_groups));
 
-    float m[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;     // .div_(n) in fp32, then one rounding to ODT
-    store8<ODT, false>(out, p * row_groups + gc, m);
-
-    if (absmax) {
+    if (absmax) {   // whole wave takes part: idle lanes contribute 0
         // all 8 columns of a lane share a channel when chan_div % 8 == 0 (checked on the host)
         const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
-        const uint32_t c0 = __shfl((int)c, 0, 64);
-        if (__all(c == c0)) {
+        const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
+        if (__all(!active || c == c0)) {
             amax = wave_max_u32(amax);
-            if ((threadIdx.x & 63) == 0) atomicMax(absmax + c0, amax);
-        } else {
+            if (threadIdx.x == 0) atomicMax(absmax + c0, amax);
+        } else if (active) {
             atomicMax(absmax + c, amax);
         }
     }
@@ -402,48 +411,82 @@ __global__ void select_init_kernel(SelectState* st, uint32_t k) {
     }
 }
 
-// in-block radix select over a global array small enough for one workgroup; returns the key of rank k
-template <int THREADS>
-__device__ uint32_t block_select_key(const float* v, int64_t n, uint32_t k, uint32_t* sh_hist /*256*/,
-                                     uint32_t* sh_state /*2*/) {
+// in-block selection of the key of rank k (0-based, ascending) among v[0..n):
+//   n <= kRankMax: every thread ranks one element against all others held in LDS (ties broken by index, so
+//                  ranks are a permutation) -- ~n broadcast LDS reads, no atomics;
+//   larger n:      4-pass radix select, bins scanned in parallel (one bin per thread, wave prefix sums).
+constexpr int kSelectThreads = 1024;
+constexpr int kRankMax = 1024;
+
+struct SelectShared {
+    uint32_t keys[kRankMax];
+    uint32_t hist[256];
+    uint32_t wsum[4];
+    uint32_t state[2];
+};
+
+__device__ __forceinline__ uint32_t block_select_key(const float* v, int64_t n, uint32_t k, SelectShared& sh) {
+    const int tid = threadIdx.x;
+    if (n <= kRankMax) {
+        if (tid < n) sh.keys[tid] = f32_to_key(v[tid]);
+        __syncthreads();
+        if (tid < n) {
+            const uint32_t mine = sh.keys[tid];
+            uint32_t rank = 0;
+            for (int j = 0; j < (int)n; ++j) {
+                const uint32_t kj = sh.keys[j];
+                rank += (kj < mine || (kj == mine && j < tid)) ? 1u : 0u;
+            }
+            if (rank == k) sh.state[0] = mine;
+        }
+        __syncthreads();
+        const uint32_t r = sh.state[0];
+        __syncthreads();
+        return r;
+    }
     uint32_t prefix = 0;
     for (int pass = 3; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += THREADS) sh_hist[i] = 0;
+        if (tid < 256) sh.hist[tid] = 0;
         __syncthreads();
         const int shift = 8 * pass;
         const uint32_t himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
-        for (int64_t i = threadIdx.x; i < n; i += THREADS) {
+        for (int64_t i = tid; i < n; i += kSelectThreads) {
             const uint32_t key = f32_to_key(v[i]);
-            if ((key & himask) == (prefix & himask)) atomicAdd(&sh_hist[(key >> shift) & 0xff], 1u);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&sh.hist[(key >> shift) & 0xff], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t cum = 0;
-            int b = 0;
-            for (; b < 256; ++b) {
-                const uint32_t c = sh_hist[b];
-                if (cum + c > k) break;
-                cum += c;
+        uint32_t c = 0, incl = 0;
+        if (tid < 256) {   // inclusive prefix sum over the 256 bins: 4 waves x 64 lanes
+            c = sh.hist[tid];
+            incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+                if ((tid & 63) >= off) incl += o;
             }
-            if (b == 256) b = 255;
-            sh_state[0] = prefix | (((uint32_t)b) << shift);
-            sh_state[1] = k - cum;
+            if ((tid & 63) == 63) sh.wsum[tid >> 6] = incl;
         }
         __syncthreads();
-        prefix = sh_state[0];
-        k = sh_state[1];
+        if (tid < 256) {
+            for (int w = 0; w < (tid >> 6); ++w) incl += sh.wsum[w];
+            const uint32_t excl = incl - c;
+            if (c > 0 && excl <= k && k < incl) {
+                sh.state[0] = prefix | (((uint32_t)tid) << shift);
+                sh.state[1] = k - excl;
+            }
+        }
+        __syncthreads();
+        prefix = sh.state[0];
+        k = sh.state[1];
         __syncthreads();
     }
     return prefix;
 }
 
-constexpr int kSelectThreads = 1024;
-
 __global__ __launch_bounds__(kSelectThreads) void kth_small_kernel(const float* __restrict__ imp, int64_t n, uint32_t k,
                                                                     float* thr) {
-    __shared__ uint32_t sh_hist[256];
-    __shared__ uint32_t sh_state[2];
-    const uint32_t key = block_select_key<kSelectThreads>(imp, n, k, sh_hist, sh_state);
+    __shared__ SelectShared sh;
+    const uint32_t key = block_select_key(imp, n, k, sh);
     if (threadIdx.x == 0) *thr = key_to_f32(key);
 }
 
@@ -463,11 +506,11 @@ __global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __rest
                                                                     int update_magnitude, float t_mag, float t_mag1,
                                                                     int refresh_mask, uint32_t k,
                                                                     uint8_t* __restrict__ mask,
-                                                                    const uint32_t* __restrict__ chan_absmax,
+                                                                    uint32_t* __restrict__ chan_absmax,
                                                                     int update_scale, float t_q, float t_q1,
-                                                                    float denom, float* __restrict__ scale) {
-    __shared__ uint32_t sh_hist[256];
-    __shared__ uint32_t sh_state[2];
+                                                                    float denom, float* __restrict__ scale,
+                                                                    int32_t* bump_a, int32_t* bump_b, int64_t* bump_c) {
+    __shared__ SelectShared sh;
     __shared__ uint32_t sh_max[kSelectThreads / 64];
     if (update_magnitude) {
         for (int64_t i = threadIdx.x; i < C; i += kSelectThreads)
@@ -476,7 +519,7 @@ __global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __rest
         __syncthreads();
     }
     if (refresh_mask) {
-        const uint32_t key = block_select_key<kSelectThreads>(magnitude, C, k, sh_hist, sh_state);
+        const uint32_t key = block_select_key(magnitude, C, k, sh);
         const float thr = key_to_f32(key);
         for (int64_t i = threadIdx.x; i < C; i += kSelectThreads) mask[i] = magnitude[i] >= thr ? 1 : 0;
         __threadfence_block();
@@ -484,8 +527,10 @@ __global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __rest
     }
     if (update_scale) {
         uint32_t m = 0u;
-        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads)
+        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads) {
             if (mask[i]) m = chan_absmax[i] > m ? chan_absmax[i] : m;
+            chan_absmax[i] = 0u;   // leave the accumulator clean for the next statistics pass
+        }
         m = wave_max_u32(m);
         if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = m;
         __syncthreads();
@@ -494,6 +539,52 @@ __global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __rest
             const float nw = __uint_as_float(m) / denom;
             scale[0] = (t_q == 0.0f) ? nw : (t_q * scale[0] + nw) / t_q1;
         }
+    }
+    if (threadIdx.x == 0) {   // step counters of the two layers / the callback (state_dict tensors)
+        if (bump_a) *bump_a += 1;
+        if (bump_b) *bump_b += 1;
+        if (bump_c) *bump_c += 1;
+    }
+}
+
+// =================================================================================================
+// Last two stages of the staged mean fused: x [pre, H, W] -> mean over H (rounded to DT) -> mean over W
+// (rounded to ODT) -> out [pre].  One workgroup per `pre` slice, tile held in LDS as fp32; both stages
+// add in ATen's order (outer rule over H, inner rule over W; see the block comment above).
+// =================================================================================================
+template <int DT, int ODT>
+__global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                             int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // H*W + W floats
+    float* colmean = tile + (size_t)H * W;
+    const int64_t p = blockIdx.x;
+    const int hw = H * W;
+    for (int i = threadIdx.x; i < hw; i += kBlock) tile[i] = load1<DT>(x, p * hw + i);
+    __syncthreads();
+    const int mr_cols = (W >= 8) ? (W / 32) * 32 : (W / 4) * 4;
+    for (int col = threadIdx.x; col < W; col += kBlock) {
+        auto get = [&](int64_t i) { return tile[i * W + col]; };
+        const float s = (col < mr_cols) ? sum_multi_row(H, get) : sum_row_sum(H, get);
+        colmean[col] = round_through<DT>(s / (float)H);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        auto get = [&](int64_t i) { return colmean[i]; };
+        float s;
+        if (W >= 8) {
+            const int64_t nv = W / 8;
+            float lanes[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lanes[k] = sum_row_sum(nv, [&](int64_t i) { return get(8 * i + k); });
+            float fin = 0.f;
+            for (int64_t i = nv * 8; i < W; ++i) fin += get(i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fin += lanes[k];
+            s = fin;
+        } else {
+            s = sum_row_sum(W, get);
+        }
+        store1<ODT>(out, p, s / (float)W);
     }
 }
 

@@ -10,7 +10,7 @@
 #include "qs_reduce.h"
 
 #ifndef QS_EW_UNROLL
-#define QS_EW_UNROLL 2
+#define QS_EW_UNROLL 1
 #endif
 #ifndef QS_EW_NT
 #define QS_EW_NT 1
@@ -27,14 +27,36 @@ inline int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-// streaming kernels: grid-stride over at most this many workgroups (256 CUs x 8)
+// streaming kernels: one workgroup per kBlock*UNROLL groups (measured best on MI355X: exact grids beat a
+// capped grid-stride loop by 8-10 %); QS_MAX_BLOCKS caps the grid for experiments
 inline int max_blocks() {
-    static int v = env_int("QS_MAX_BLOCKS", 2048);
+    static int v = env_int("QS_MAX_BLOCKS", 1 << 30);
     return v;
 }
-inline int mean_block() {
-    static int v = env_int("QS_MEAN_BLOCK", 64);
+// Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
+// the same tensor front to back) leaves the tail of the tensor in the 256 MiB Infinity Cache, and an LRU
+// cache serves a reverse walk from it where a forward walk would evict it before use.  QS_EW_REVERSE=0 disables.
+inline int ew_reverse() {
+    static int v = env_int("QS_EW_REVERSE", 1);
     return v;
+}
+// active lanes per wave of the column-parallel mean kernel: the busiest CU carries ceil(waves / 256) * lanes
+// column groups; pick the widest wave that minimises it (QS_MEAN_LANES overrides)
+inline int mean_lanes(int64_t total) {
+    static int forced = env_int("QS_MEAN_LANES", 0);
+    if (forced >= 1 && forced <= 64) return forced;
+    const int64_t kCUs = 256;
+    int best = 64;
+    int64_t best_cost = -1;
+    for (int l = 64; l >= 40; --l) {
+        const int64_t waves = (total + l - 1) / l;
+        const int64_t cost = ((waves + kCUs - 1) / kCUs) * l;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = l;
+        }
+    }
+    return best;
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
@@ -77,6 +99,7 @@ int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* p
     plan->geo.C = (uint32_t)C;
     plan->geo.inner = (uint32_t)inner;
     plan->geo.groups_per_row = (uint32_t)(inner / 8);
+    plan->geo.reverse = ew_reverse() ? 1u : 0u;
     if (!per_channel) plan->cm = CM_SCALAR;
     else if (inner % 8 == 0) plan->cm = CM_ROW;
     else plan->cm = CM_ELEM;
@@ -269,7 +292,8 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                 constexpr bool M = decltype(MM)::value != 0;
                 if (!per_channel) {
                     if (!vec_ptr) return (int)QS_ERR_ALIGN;
-                    const int grid = grid_for(numel / 8, 2);
+                    int grid = grid_for(numel / 8, 2);
+                    if (grid > 4096) grid = 4096;   // every block ends with one atomic on the same word
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin);
                 } else if (inner >= 64) {
                     const int64_t rows = outer * C;
@@ -340,10 +364,6 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
     if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     if (absmax_out && (chan_div < 1 || C < 1)) return QS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (absmax_out) {
-        hipError_t e = hipMemsetAsync(absmax_out, 0, sizeof(float) * (size_t)C, s);
-        if (e != hipSuccess) return hip_status(e);
-    }
     int64_t vcols = 0;
     if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!absmax_out || chan_div % 8 == 0))
         vcols = (post / 32) * 32;
@@ -354,10 +374,10 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
             constexpr int OD = decltype(O)::value;
             if (vcols > 0) {
                 const int64_t total = pre * (vcols / 8);
-                const int bs = mean_block();
+                const int lanes = mean_lanes(total);
                 hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT>),
-                                   dim3((int)((total + bs - 1) / bs)), dim3(bs), 0, s, x, out, pre, n, post, vcols, flags,
-                                   l0_flag, am, chan_div, (uint32_t)(C > 0 ? C : 1));
+                                   dim3((int)((total + lanes - 1) / lanes)), dim3(64), 0, s, x, out, pre, n, post, vcols,
+                                   flags, l0_flag, am, chan_div, (uint32_t)(C > 0 ? C : 1), lanes);
             }
             if (vcols < post) {
                 const int64_t total = pre * (post - vcols);
@@ -368,6 +388,23 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
             return launch_status();
         };
         return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
+    });
+}
+
+int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, qs_stream_t stream) {
+    if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    const size_t lds = (size_t)(H * W + W) * sizeof(float);
+    if (lds > 48 * 1024 || pre > 0x7fffffff) return QS_ERR_ARG;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        if (odt == QS_F32)
+            hipLaunchKernelGGL((mean_last2_kernel<XD, QS_F32>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x,
+                               out, (int)H, (int)W);
+        else
+            hipLaunchKernelGGL((mean_last2_kernel<XD, XD>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x, out,
+                               (int)H, (int)W);
+        return launch_status();
     });
 }
 
@@ -486,7 +523,7 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         geo.mstrides[d] = cm[d];
     }
     int64_t blocks = (numel + kBlock - 1) / kBlock;
-    if (blocks > max_blocks() * 4) blocks = max_blocks() * 4;
+    if (blocks > 16384) blocks = 16384;   // grid-stride
     return with_dtype(dt, [&](auto D) {
         constexpr int DD = decltype(D)::value;
         hipLaunchKernelGGL((mask_bcast_kernel<DD>), dim3((int)blocks), dim3(kBlock), 0, s, x, mask, y, numel, geo);
@@ -496,10 +533,8 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 
 // ------------------------------------------------------------------------------------------------
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
-                 int refresh_mask, int64_t k, uint8_t* mask, const float* chan_absmax, int update_scale, int64_t t_q,
-                 int bits, float* scale, void* ws, size_t ws_bytes, qs_stream_t stream) {
-    (void)ws;
-    (void)ws_bytes;
+                 int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits,
+                 float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64, qs_stream_t stream) {
     if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
     if (update_magnitude && (!stage_mean || t_mag < 0)) return QS_ERR_ARG;
     if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
@@ -509,8 +544,8 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
         constexpr int SD = decltype(S)::value;
         hipLaunchKernelGGL((pq_select_kernel<SD>), dim3(1), dim3(kSelectThreads), 0, (hipStream_t)stream, magnitude,
                            stage_mean, C, update_magnitude, (float)t_mag, (float)(t_mag + 1), refresh_mask, (uint32_t)k,
-                           mask, (const uint32_t*)chan_absmax, update_scale, (float)t_q, (float)(t_q + 1),
-                           (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0)), scale);
+                           mask, (uint32_t*)chan_absmax, update_scale, (float)t_q, (float)(t_q + 1),
+                           (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0)), scale, bump_i32_a, bump_i32_b, bump_i64);
         return launch_status();
     });
 }

@@ -46,6 +46,15 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
     return inner % 8 == 0 or h.dim() == 2
 
 
+def _absmax_accumulator(q: QuantizeLayer, C: int, device) -> torch.Tensor:
+    """persistent per-layer scratch for the per-channel abs-max (not a parameter, not in state_dict)."""
+    buf = getattr(q, "_chan_absmax", None)
+    if buf is None or buf.numel() != C or buf.device != device:
+        buf = torch.zeros(C, dtype=torch.float32, device=device)
+        q._chan_absmax = buf
+    return buf
+
+
 class _FusedApply(torch.autograd.Function):
     """y = Q(x * mask) forward, gx = clamp(g) * mask backward, each one pass over the tensor."""
 
@@ -122,6 +131,9 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
             quant_on = q._quantized
 
     # ---- statistics: one read of h ----
+    p_counts = p.training and p.mask.numel() != 1
+    q_counts = q.timeout > 0 and q.training
+    bump_p = bump_q = bump_t = None
     with torch.no_grad():
         hd = h.detach()
         stage = chan_absmax = None
@@ -133,7 +145,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
         else:
             if update_mag:
                 if update_scale:
-                    chan_absmax = torch.empty(C, dtype=torch.float32, device=h.device)
+                    chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by pq_select
                 dims = _reduction_plan(hd.shape, p.mask.shape)
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax,
                                          absmax_channel_dim=1).view(-1)
@@ -143,18 +155,37 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
                 mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)
-                _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1),
-                               chan_absmax, update_scale, t_q, q.bits, q.weight.data)
+                # step counters that live on this GPU ride along in the same launch (callback.t stays on the
+                # CPU when the module was never moved with .to(device): that one is then bumped on the host)
+                def on_dev(t):
+                    return t.data if (t.is_cuda and t.device == h.device) else None
+
+                bump_p = on_dev(p._n_updates) if p_counts else None
+                bump_q = on_dev(q._n_updates) if q_counts else None
+                bump_t = on_dev(cb.t) if (p_counts and n >= p.start) else None
+                _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
+                               update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t)
         if update_scale:
             qc.t += 1
 
     # ---- counters (same order as the unfused layers) ----
-    if p.training and p.mask.numel() != 1:
+    if p_counts:
         if n >= p.start:
-            cb.end_step(p.mask, p.name)
-        p._steps.add(p._n_updates, 1)
-    if q.timeout > 0 and q.training:
-        q._steps.add(q._n_updates, 1)
+            if bump_t is not None:
+                cb._t_host.note_device_add(cb.t, 1)
+                if cb.forward_hook is not None:
+                    cb.forward_hook(p.mask, p.name)
+            else:
+                cb.end_step(p.mask, p.name)
+        if bump_p is not None:
+            p._steps.note_device_add(p._n_updates, 1)
+        else:
+            p._steps.add(p._n_updates, 1)
+    if q_counts:
+        if bump_q is not None:
+            q._steps.note_device_add(q._n_updates, 1)
+        else:
+            q._steps.add(q._n_updates, 1)
 
     # ---- apply: one read of h, one write ----
     if not prune_on and not quant_on:

@@ -69,7 +69,17 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
     shape = list(cur.shape)
     out_dtype = torch.float32 if l0_flag is not None else cur.dtype
     first = True
-    for d in dims:
+    for pos, d in enumerate(dims):
+        nd = len(shape)
+        if (not first and len(dims) - pos == 2 and d == nd - 2 and dims[pos + 1] == nd - 1
+                and (shape[d] * shape[d + 1] + shape[d + 1]) * 4 <= 48 * 1024):
+            # the two trailing dims are what is left: one fused launch (same order, same rounding points)
+            pre = 1
+            for s in shape[:d]:
+                pre *= s
+            cur = _hip.mean_last2(cur, pre, shape[d], shape[d + 1], cur.dtype)
+            shape[d] = shape[d + 1] = 1
+            return cur.view(shape)
         pre = 1
         for s in shape[:d]:
             pre *= s

@@ -101,6 +101,32 @@ def test_scaler_fwd_bwd_vs_oracle(dtype, shape):
             assert same(xg.grad.cpu(), gx_ref), (shape, ci, bits)
 
 
+def test_scaler_codes_around_halfway_points():
+    """the forward avoids the division when x*RN(1/s) is provably on the same side of every k+0.5 as
+    RN(x/s); hammer the neighbourhood of the half-way points (+-3 ulp) where that proof does not hold and
+    the kernel must fall back to the correctly rounded division: codes stay bit-exact."""
+    ks = torch.arange(-300, 300, dtype=torch.float64) + 0.5
+    for seed in range(6):
+        s64 = torch.rand(1, generator=gen(50 + seed), dtype=torch.float64) * (10.0 ** (seed - 3)) + 1e-4
+        s = s64.float()
+        centre = (ks * s.double()).float()
+        xs = [centre]
+        up, dn = centre.clone(), centre.clone()
+        for _ in range(3):
+            up = torch.nextafter(up, torch.full_like(up, float("inf")))
+            dn = torch.nextafter(dn, torch.full_like(dn, float("-inf")))
+            xs += [up.clone(), dn.clone()]
+        x = torch.cat(xs + [torch.randn(4096, generator=gen(60 + seed)) * 50 * s])
+        x = torch.cat([x, x.new_zeros((-x.numel()) % 8)])
+        _, codes = _hip.quant_fwd("scaler", x.to(DEV), s.view(1, 1).to(DEV), -1, torch.float32, want_codes=True)
+        assert same(codes.cpu(), O.scaler_codes(x, s.view(1), -1)), seed
+        # per-channel scales take the same route
+        xc = x.view(1, 8, -1)
+        sc = (torch.rand(8, 1, generator=gen(70 + seed)) + 0.5) * s
+        _, codes = _hip.quant_fwd("scaler", xc.to(DEV), sc.to(DEV), 1, torch.float32, want_codes=True)
+        assert same(codes.cpu(), O.scaler_codes(xc, sc, 1)), seed
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_decimal_and_line_vs_oracle(dtype):
     shape = (4, 24, 14, 14)
