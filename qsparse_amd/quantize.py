@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from qsparse_amd import _hip
+from qsparse_amd import distributed as qdist
 from qsparse_amd.common import HostMirror, TensorOrFloat, TensorOrInt, ensure_tensor
 from qsparse_amd.imitation import imitate
 from qsparse_amd.util import get_option, logging
@@ -256,12 +257,12 @@ class DecimalQuantizer(BaseQuantizer):
                     f"reference (shape {tuple(x.shape)}, channelwise={channel_index}); use channelwise=-1 or "
                     "AdaptiveQuantizer")
             if x.is_cuda:
-                stat = _hip.absmax(x, channel_index)
+                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index))
                 if weight is None:
                     weight = torch.zeros(wshape, device=x.device)
                 _hip.scale_update(stat, weight.data, self.t, bits)   # t == 0 overwrites, else running mean
             else:
-                new_weight = (_absmax_rows_cpu(x, channel_index) / (2 ** (bits - 1))).view(wshape)
+                new_weight = (qdist.allreduce_max_(_absmax_rows_cpu(x, channel_index)) / (2 ** (bits - 1))).view(wshape)
                 if self.t == 0:
                     weight = new_weight
                 else:
@@ -335,6 +336,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
         with torch.no_grad():
             if x.is_cuda:
                 lo, hi = _hip.minmax(x, channel_index)
+                qdist.allreduce_min_(lo), qdist.allreduce_max_(hi)
                 if weight is None:
                     self.t += 1
                     return torch.stack([lo, hi], dim=1)
@@ -343,6 +345,9 @@ class AdaptiveQuantizer(DecimalQuantizer):
                 _hip.lines_update(lo, hi, weight.data, self.t)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)
+            if qdist.stats_world_size() > 1:
+                bounds = torch.stack([qdist.allreduce_min_(bounds[:, 0].contiguous()),
+                                      qdist.allreduce_max_(bounds[:, 1].contiguous())], dim=1)
             self.t += 1
             if weight is None:
                 return bounds

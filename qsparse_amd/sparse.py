@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from qsparse_amd import _hip
+from qsparse_amd import distributed as qdist
 from qsparse_amd.common import HostMirror, f32_round
 from qsparse_amd.imitation import imitate
 from qsparse_amd.util import (_reduction_plan, _staged_mean_hip, calculate_mask_given_importance, get_option, logging,
@@ -97,7 +98,7 @@ class MagnitudePruningCallback(nn.Module):
             return
         with torch.no_grad():
             t = self._t_host.read(self.t)
-            imp = _importance(x.detach(), self.magnitude.shape, self.l0)
+            imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0))
             if x.is_cuda:
                 _hip.running_mean(self.magnitude.data, imp, t)
             else:
@@ -117,7 +118,8 @@ class MagnitudePruningCallback(nn.Module):
 
     def prune_and_update_mask(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
-            importance = self.magnitude if self.running_average else _importance(x.detach(), mask.shape)
+            importance = self.magnitude if self.running_average else qdist.allreduce_mean(
+                _importance(x.detach(), mask.shape))
             if x.is_cuda:
                 imp = importance.detach().to(torch.float32).contiguous()
                 n = imp.numel()
