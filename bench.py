@@ -43,6 +43,23 @@ def make_input(shape, device, seed=0):
     return x, gout
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of a headline kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic.json: FETCH_SIZE*1024*2 + WRITE_SIZE*1024, see the file for the correction).
+    PMC counters need their own profiler passes, so they are collected with the same command line
+    under rocprofv3 and read back here; null if no such profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"][kernel_key]
+        return k["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def make_pair(device):
     import qsparse_amd as qs
     from qsparse_amd.fused import fuse_prune_quantize_pairs
@@ -156,6 +173,7 @@ def main():
         # dominant kernel: the fused apply forward (bf16 in, fp32 out: 6 B/elem); backward is its mirror image
         dom_name, dom_ms = ("quant_scaler_fwd+mask", fwd_ms) if (fwd_ms or 0) >= (bwd_ms or 0) else ("quant_ste_bwd+mask", bwd_ms)
         achieved = 6 * numel / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+        traffic, traffic_src = pmc_traffic("apply_fwd" if dom_name.startswith("quant_scaler_fwd") else "apply_bwd")
         kern = {}
         for name, ms, bpe in (("apply_fwd", fwd_ms, 6), ("apply_bwd", bwd_ms, 6), ("stats", stats_ms, 2)):
             if ms:
@@ -173,7 +191,8 @@ def main():
                        "step_frac_of_hbm_peak": round(14 * numel / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 6 * numel, "kernels": kern},
         }
         if world == 1 and not args.no_cpu_baseline:
