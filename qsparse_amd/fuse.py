@@ -1,0 +1,122 @@
+"""Fold BatchNorm layers into the preceding Conv2d / Linear / ConvTranspose2d for inference -- API of the
+reference's qsparse/fuse.py:76-163 (same arguments, same resulting module tree).
+
+Run once after training; pure C-sized weight algebra (no kernel): with ``g = gamma / sqrt(var + 1e-5)``,
+``W' = W * g`` broadcast along the layer's output-channel axis and ``b' = (b - mean) * g + beta``
+(reference fuse.py:26-68; note the fixed 1e-5, the BatchNorm's own ``eps`` is not consulted there either).
+The raw parameters in ``_parameters`` are rewritten, so injected prune/quantize operators keep working on
+the folded weights.
+"""
+from copy import deepcopy
+from typing import Callable, Dict, Iterable, Mapping, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from qsparse_amd.util import logging, nn_module
+
+BNFuser = Callable[[nn.Module, nn.Module], nn.Module]
+
+
+def _fold(layer: nn.Module, bn: nn.Module, out_axis: int) -> nn.Module:
+    weight = layer._parameters["weight"].detach()
+    bias = layer._parameters["bias"].detach() if layer.bias is not None else 0
+    gain = bn.weight.detach() / torch.sqrt(bn.running_var.detach().add(1e-5))
+    view = [1] * weight.dim()
+    view[out_axis] = -1
+    layer._parameters["weight"].data = weight * gain.view(view)
+    layer._parameters["bias"] = nn.Parameter((bias - bn.running_mean.detach()) * gain + bn.bias.detach())
+    return layer
+
+
+def conv2d_bn_fuser(conv: nn.Module, bn: nn.Module) -> nn.Module:
+    """BNFuser for Conv2d (output channels on axis 0)"""
+    return _fold(conv, bn, 0)
+
+
+def linear_bn_fuser(linear: nn.Module, bn: nn.Module) -> nn.Module:
+    """BNFuser for Linear (output features on axis 0)"""
+    return _fold(linear, bn, 0)
+
+
+def deconv2d_bn_fuser(deconv: nn.Module, bn: nn.Module) -> nn.Module:
+    """BNFuser for ConvTranspose2d (output channels on axis 1)"""
+    return _fold(deconv, bn, 1)
+
+
+default_handlers: Dict[str, BNFuser] = dict(Conv2d=conv2d_bn_fuser, Linear=linear_bn_fuser,
+                                            ConvTranspose2d=deconv2d_bn_fuser)
+
+
+def _is_batchnorm(m: nn.Module) -> bool:
+    return type(m).__name__.lower().startswith("batchnorm")
+
+
+def fuse_bn(model: nn.Module, layers: Iterable[str] = ["Conv2d", "Linear", "ConvTranspose2d"],
+            handlers: Optional[Mapping[str, BNFuser]] = None, log: bool = True, inplace: bool = True) -> nn.Module:
+    """fold every BatchNorm that directly follows a layer whose class name is in ``layers`` -- also across
+    the boundary of nested ``nn.Sequential`` containers -- and drop it from the tree.
+
+    Args:
+        model: network; ``nn.Sequential`` models are processed as a whole, for any other module each
+            direct ``nn.Sequential`` child is processed.
+        layers: class names eligible for folding.
+        handlers: class name -> ``fuser(layer, bn)`` overrides / additions.
+        log: print one line per folded BatchNorm.
+        inplace: mutate ``model`` (default) or a deep copy.
+    """
+    table = {**default_handlers, **(handlers or {})}
+    wanted = set(layers)
+    for name in wanted:
+        assert name in table, f"layer {name} is not in handlers"
+    if not inplace:
+        model = deepcopy(model)
+
+    def walk(seq: nn.Sequential, carried: Optional[nn.Module] = None) -> Tuple[Optional[nn.Module], Optional[nn.Module]]:
+        """returns (rewritten container or None when emptied, the possibly-updated layer that preceded it)"""
+        kept = []
+
+        def previous():
+            return kept[-1] if kept else carried
+
+        def replace_previous(m):
+            nonlocal carried
+            if kept:
+                kept[-1] = m
+            else:
+                carried = m
+
+        for child in seq.children():
+            if _is_batchnorm(child):
+                target = previous()
+                kind = type(target).__name__ if target is not None else ""
+                if kind in wanted:
+                    if log:
+                        logging.info(f"Fuse {child} into {target}")
+                    replace_previous(table[kind](target, child))
+                else:
+                    kept.append(child)
+            elif isinstance(child, nn.Sequential):
+                inner, before = walk(child, previous())
+                if before is not None:
+                    replace_previous(before)
+                if inner is not None:
+                    kept.append(inner)
+            else:
+                kept.append(child)
+        if not kept:
+            return None, carried
+        return (kept[0] if len(kept) == 1 else nn.Sequential(*kept)), carried
+
+    root = nn_module(model)
+    if isinstance(root, nn.Sequential):
+        rewritten = walk(root)[0]
+        if model is root:
+            model = rewritten
+        else:
+            model.module = rewritten
+    else:
+        for name, child in list(root.named_children()):
+            if isinstance(child, nn.Sequential):
+                root._modules[name] = walk(child)[0]
+    return model

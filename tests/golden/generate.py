@@ -527,6 +527,50 @@ def f10():
     save("f10_prune_quant_pair", store, dict(cases=cases))
 
 
+# --------------------------------------------------------------------------------------------
+# F11: fuse_bn (qsparse/fuse.py:76-163)
+# --------------------------------------------------------------------------------------------
+def make_bn_nets():
+    """deterministic conv/linear/deconv + BatchNorm stacks with non-trivial running statistics"""
+    from collections import OrderedDict
+    torch.manual_seed(21)
+    nets = OrderedDict()
+    nets["conv"] = (nn.Sequential(nn.Conv2d(3, 5, 3), nn.BatchNorm2d(5)), (4, 3, 8, 8))
+    nets["linear"] = (nn.Sequential(nn.Linear(12, 7, bias=False), nn.BatchNorm1d(7)), (6, 12))
+    nets["deconv"] = (nn.Sequential(nn.ConvTranspose2d(3, 5, 3), nn.BatchNorm2d(5)), (4, 3, 6, 6))
+    nets["nested"] = (nn.Sequential(nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4)), nn.ReLU(),
+                                    nn.Sequential(nn.Conv2d(4, 4, 3)), nn.BatchNorm2d(4), nn.ReLU(),
+                                    nn.Sequential(nn.BatchNorm2d(4), nn.ConvTranspose2d(4, 2, 3), nn.BatchNorm2d(2))),
+                       (3, 3, 12, 12))
+    for net, shape in nets.values():
+        for m in net.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                nn.init.uniform_(m.weight, 0.5, 1.5)
+                nn.init.uniform_(m.bias, -0.5, 0.5)
+        net.train()
+        for i in range(3):
+            net(torch.randn(shape, generator=gen(600 + i)))
+        net.eval()
+    return nets
+
+
+def f11():
+    from qsparse import fuse_bn
+    store, cases = {}, []
+    for name, (net, shape) in make_bn_nets().items():
+        x = torch.randn(shape, generator=gen(700))
+        for kname, v in net.state_dict().items():
+            put(store, f"{name}_in_{kname}", v)
+        with quiet():
+            fused = fuse_bn(net, log=False)
+        for kname, v in fused.state_dict().items():
+            put(store, f"{name}_out_{kname}", v)
+        put(store, name + "_x", x)
+        put(store, name + "_y", fused(x))
+        cases.append(dict(name=name, shape=list(shape), tree=str(fused), in_keys=None, out_keys=list(fused.state_dict().keys())))
+    save("f11_fuse_bn", store, dict(cases=cases))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     f1_f2()
@@ -537,3 +581,4 @@ if __name__ == "__main__":
     f7()
     f8_f9()
     f10()
+    f11()
