@@ -2,7 +2,7 @@
 reference's qsparse/fuse.py:76-163 (same arguments, same resulting module tree).
 
 Run once after training; pure C-sized weight algebra (no kernel): with ``g = gamma / sqrt(var + 1e-5)``,
-``W' = W * g`` broadcast along the layer's output-channel axis and ``b' = (b - mean) * g + beta``
+``W' = W * g`` broadcast along the layer's output-channel axis and ``b' = (b - mean) * gamma / std + beta``
 (reference fuse.py:26-68; note the fixed 1e-5, the BatchNorm's own ``eps`` is not consulted there either).
 The raw parameters in ``_parameters`` are rewritten, so injected prune/quantize operators keep working on
 the folded weights.
@@ -21,11 +21,12 @@ BNFuser = Callable[[nn.Module, nn.Module], nn.Module]
 def _fold(layer: nn.Module, bn: nn.Module, out_axis: int) -> nn.Module:
     weight = layer._parameters["weight"].detach()
     bias = layer._parameters["bias"].detach() if layer.bias is not None else 0
-    gain = bn.weight.detach() / torch.sqrt(bn.running_var.detach().add(1e-5))
+    gamma, std = bn.weight.detach(), torch.sqrt(bn.running_var.detach().add(1e-5))
     view = [1] * weight.dim()
     view[out_axis] = -1
-    layer._parameters["weight"].data = weight * gain.view(view)
-    layer._parameters["bias"] = nn.Parameter((bias - bn.running_mean.detach()) * gain + bn.bias.detach())
+    layer._parameters["weight"].data = weight * (gamma / std).view(view)
+    # operator order of the reference (fuse.py:35): ((b - mean) * gamma) / std + beta
+    layer._parameters["bias"] = nn.Parameter((bias - bn.running_mean.detach()) * gamma / std + bn.bias.detach())
     return layer
 
 
