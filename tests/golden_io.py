@@ -40,4 +40,4 @@ def same(a, b):
         return False
     if a.dtype == torch.bool:
         return bool((a == b).all())
-    return bool(torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)))
+    return bool(torch.equal(a.contiguous().reshape(-1).view(torch.uint8), b.contiguous().reshape(-1).view(torch.uint8)))

@@ -32,7 +32,7 @@ def test_f11_fuse_bn():
         sd = fused.state_dict()
         assert list(sd.keys()) == c["out_keys"], name
         for k, v in sd.items():
-            assert same(v, g.get(f"{name}_out_{k}")), (name, k)
+            assert same(v, torch.as_tensor(g.get(f"{name}_out_{k}"))), (name, k)
         y = fused(x)
         assert same(y.detach(), g.get(name + "_y")), name
         assert torch.allclose(y, before, atol=1e-5)   # the reference's own criterion (tests/test_fuse.py)
