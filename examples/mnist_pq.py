@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""MNIST-shaped counterpart of the reference's examples/mnist.py --pq recipe (BASELINE.json config 0) on
+synthetic data: there is no dataset access here, so images are random digits-like tensors and the run only
+exercises the plumbing (convert -> train -> evaluate -> checkpoint round trip).
+
+    python examples/mnist_pq.py [--device cuda] [--steps 60] [--batch 64]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+import qsparse_amd as qs
+from examples.models import MnistNet, convert_pq
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-pq", action="store_true")
+    args = ap.parse_args(argv)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    torch.manual_seed(1)
+    model = MnistNet()
+    if not args.no_pq:
+        model = convert_pq(model, sparsity=0.75, bits=4, prune_start=args.steps // 4, prune_interval=max(args.steps // 8, 1),
+                           repetition=3, quant_timeout=args.steps // 2)
+    model = model.to(args.device)
+    opt = optim.Adadelta(model.parameters(), lr=1.0)
+    g = torch.Generator().manual_seed(0)
+    protos = torch.randn(10, 1, 28, 28, generator=g)          # ten class prototypes + noise
+    losses = []
+    model.train()
+    for step in range(args.steps):
+        y = torch.randint(0, 10, (args.batch,), generator=g)
+        x = (protos[y] + 0.5 * torch.randn(args.batch, 1, 28, 28, generator=g)).to(args.device)
+        opt.zero_grad()
+        loss = F.nll_loss(model(x), y.to(args.device))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    model.eval()
+    y = torch.randint(0, 10, (256,), generator=g)
+    x = (protos[y] + 0.5 * torch.randn(256, 1, 28, 28, generator=g)).to(args.device)
+    acc = (model(x).argmax(1).cpu() == y).float().mean().item()
+    print(f"device={args.device} first loss {losses[0]:.3f} last loss {losses[-1]:.3f} eval accuracy {acc:.3f}")
+    return model, losses, acc
+
+
+if __name__ == "__main__":
+    main()

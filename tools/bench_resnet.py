@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""End-to-end step time of the BASELINE.json model configurations on one GPU (development tool, not the
+headline): ResNet-18 (CIFAR shape) / ResNet-50 (ImageNet shape), synthetic data, --pq conversion.
+Reports ms/step for: plain model, converted with the fused pair path, converted unfused."""
+import argparse
+import copy
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+import qsparse_amd as qs
+from examples.models import convert_pq, resnet18, resnet50
+
+
+def run(model, shape, classes, steps, warmup, dtype):
+    model = model.cuda().train()   # fp32 master weights; bf16 compute through autocast (activations are bf16)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    x = torch.randn(shape, device="cuda")
+    y = torch.randint(0, classes, (shape[0],), device="cuda")
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            loss = F.cross_entropy(model(x).float(), y)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--dtype", default="bfloat16")
+    args = ap.parse_args()
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    dtype = getattr(torch, args.dtype)
+    if args.arch == "resnet18":
+        base, shape, classes, sp = resnet18(10, True), (args.batch, 3, 32, 32), 10, 0.5
+    else:
+        base, shape, classes, sp = resnet50(1000, False), (args.batch, 3, 224, 224), 1000, 0.75
+    res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 3, dtype)}
+    for name, fuse in (("pq_fused", True), ("pq_unfused", False)):
+        m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
+                       quant_timeout=1, fuse=fuse)
+        res[name] = run(m, shape, classes, args.steps, 4, dtype)
+    print(args.arch, shape, args.dtype, {k: round(v, 2) for k, v in res.items()}, flush=True)
+
+
+if __name__ == "__main__":
+    main()
