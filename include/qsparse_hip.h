@@ -44,7 +44,7 @@ enum qs_error {
     QS_ERR_RANK = -5       /* broadcast pattern needs more than QS_MAX_DIMS collapsed dims */
 };
 
-enum qs_workspace_op { QS_WS_KTH_VALUE = 1, QS_WS_PQ_STATS = 2 };
+enum qs_workspace_op { QS_WS_KTH_VALUE = 1 };
 
 #define QS_MAX_DIMS 6
 

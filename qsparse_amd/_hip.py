@@ -406,3 +406,4 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
                                  int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _stream(magnitude))
     _check(st, "qs_pq_select")
+

@@ -216,9 +216,24 @@ __device__ __forceinline__ float sum_multi_row(int64_t n, F get) {
     const int64_t step = (int64_t)1 << lp, lmask = step - 1;
     Cascade c;
     int64_t i = 0;
+    // operands are fetched in batches (16 / 8 / 1) ahead of the strictly ordered adds, so that their
+    // latencies (global or LDS) overlap; the order of the additions is untouched
     while (i + step <= n) {
-        for (int64_t j = 0; j < step; ++j, ++i) c.add(get(i));
+        for (int64_t j = 0; j < step; j += 16, i += 16) {   // step is a power of two >= 16
+            float b[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) b[u] = get(i + u);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c.add(b[u]);
+        }
         c.carry(i, lp, lmask);
+    }
+    for (; i + 8 <= n; i += 8) {
+        float b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = get(i + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c.add(b[u]);
     }
     for (; i < n; ++i) c.add(get(i));
     return c.total();
@@ -232,6 +247,44 @@ __device__ __forceinline__ float sum_row_sum(int64_t n, F get) {
     for (int k = 0; k < 4; ++k) p[k] = sum_multi_row(n4, [&](int64_t i) { return get(4 * i + k); });
     for (int64_t i = n4 * 4; i < n; ++i) p[0] += get(i);
     return ((p[0] + p[1]) + p[2]) + p[3];
+}
+
+// copy tile p (hw elements of dtype DT) into LDS as fp32: 16-byte global loads when the tile is 8-element aligned
+template <int DT>
+__device__ __forceinline__ void load_tile_f32(const void* src, int64_t p, int hw, float* tile) {
+    if ((hw & 7) == 0 && (((uintptr_t)src) & 15) == 0) {
+        const int64_t g0 = p * (hw / 8);
+        for (int g = threadIdx.x; g < hw / 8; g += blockDim.x) {
+            float v[8];
+            unpack8<DT>(load8_raw<DT, false>(src, g0 + g), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[g * 8 + j] = v[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = load1<DT>(src, p * hw + i);
+    }
+}
+
+// inner-sum order over `W` values held in LDS, evaluated by lanes 0..7 of one wave: lane k owns the k-th
+// vector lane (row-sum order over W/8 items), lane 0 then adds the W%8 tail and the 8 lane sums in order.
+__device__ __forceinline__ float inner_sum_lds(const float* v, int W, float* lane_out /* 8 floats, LDS */) {
+    if (W >= 8) {
+        const int nv = W / 8;
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            lane_out[k] = sum_row_sum(nv, [&](int64_t i) { return v[8 * i + k]; });
+        }
+        __syncthreads();
+        float fin = 0.f;
+        if (threadIdx.x == 0) {
+            for (int i = nv * 8; i < W; ++i) fin += v[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fin += lane_out[k];
+        }
+        return fin;
+    }
+    __syncthreads();
+    return threadIdx.x == 0 ? sum_row_sum(W, [&](int64_t i) { return v[i]; }) : 0.f;
 }
 
 // ---- hot stage: outer reduction, 8 adjacent columns per lane, multi-row order ---------------------
@@ -419,25 +472,34 @@ constexpr int kSelectThreads = 1024;
 constexpr int kRankMax = 1024;
 
 struct SelectShared {
-    uint32_t keys[kRankMax];
+    alignas(16) uint32_t keys[kRankMax];
     uint32_t hist[256];
     uint32_t wsum[4];
     uint32_t state[2];
 };
 
+// rank of (key `mine` at index i) among keys[0..npad): #smaller + #equal-with-lower-index.  npad is n rounded up
+// to a multiple of 4 with the padding slots holding 0xffffffff; 16-byte LDS reads, 4 keys per read.
+__device__ __forceinline__ uint32_t rank_of(const uint32_t* keys, int npad, uint32_t mine, int i) {
+    uint32_t rank = 0;
+#pragma unroll 4
+    for (int j = 0; j < npad; j += 4) {
+        const u32x4 kk = *(const u32x4*)(keys + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank += (kk[u] < mine || (kk[u] == mine && j + u < i)) ? 1u : 0u;
+    }
+    return rank;
+}
+
 __device__ __forceinline__ uint32_t block_select_key(const float* v, int64_t n, uint32_t k, SelectShared& sh) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthreads = blockDim.x;   // nthreads >= 256
     if (n <= kRankMax) {
-        if (tid < n) sh.keys[tid] = f32_to_key(v[tid]);
+        const int npad = ((int)n + 3) & ~3;
+        for (int i = tid; i < npad; i += nthreads) sh.keys[i] = i < (int)n ? f32_to_key(v[i]) : 0xffffffffu;
         __syncthreads();
-        if (tid < n) {
-            const uint32_t mine = sh.keys[tid];
-            uint32_t rank = 0;
-            for (int j = 0; j < (int)n; ++j) {
-                const uint32_t kj = sh.keys[j];
-                rank += (kj < mine || (kj == mine && j < tid)) ? 1u : 0u;
-            }
-            if (rank == k) sh.state[0] = mine;
+        for (int i = tid; i < (int)n; i += nthreads) {
+            const uint32_t mine = sh.keys[i];
+            if (rank_of(sh.keys, npad, mine, i) == k) sh.state[0] = mine;
         }
         __syncthreads();
         const uint32_t r = sh.state[0];
@@ -450,7 +512,7 @@ __device__ __forceinline__ uint32_t block_select_key(const float* v, int64_t n, 
         __syncthreads();
         const int shift = 8 * pass;
         const uint32_t himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
-        for (int64_t i = tid; i < n; i += kSelectThreads) {
+        for (int64_t i = tid; i < n; i += nthreads) {
             const uint32_t key = f32_to_key(v[i]);
             if ((key & himask) == (prefix & himask)) atomicAdd(&sh.hist[(key >> shift) & 0xff], 1u);
         }
@@ -500,51 +562,137 @@ __global__ __launch_bounds__(kBlock) void mask_ge_kernel(const float* __restrict
 // =================================================================================================
 // fused C-sized step of the channel-prune -> tensor-wise-quantize pair (see qsparse_hip.h)
 // =================================================================================================
+struct PqArgs {
+    float* magnitude;
+    int64_t C;
+    int update_magnitude;
+    float t_mag, t_mag1;
+    int refresh_mask;
+    uint32_t k;
+    uint8_t* mask;
+    uint32_t* chan_absmax;
+    int update_scale;
+    float t_q, t_q1, denom;
+    float* scale;
+    int32_t* bump_a;
+    int32_t* bump_b;
+    int64_t* bump_c;
+};
+
+// the C-sized step, run by ONE workgroup of >= 256 threads; `stage` holds the last squeeze stage ([C], dtype SDT)
 template <int SDT>
-__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(float* __restrict__ magnitude,
-                                                                    const void* __restrict__ stage, int64_t C,
-                                                                    int update_magnitude, float t_mag, float t_mag1,
-                                                                    int refresh_mask, uint32_t k,
-                                                                    uint8_t* __restrict__ mask,
-                                                                    uint32_t* __restrict__ chan_absmax,
-                                                                    int update_scale, float t_q, float t_q1,
-                                                                    float denom, float* __restrict__ scale,
-                                                                    int32_t* bump_a, int32_t* bump_b, int64_t* bump_c) {
-    __shared__ SelectShared sh;
-    __shared__ uint32_t sh_max[kSelectThreads / 64];
-    if (update_magnitude) {
-        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads)
-            magnitude[i] = (t_mag * magnitude[i] + load1<SDT>(stage, i)) / t_mag1;
+__device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stage, SelectShared& sh, uint32_t* sh_max) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    if (a.update_magnitude) {
+        for (int64_t i = tid; i < a.C; i += nthreads)
+            a.magnitude[i] = (a.t_mag * a.magnitude[i] + load1<SDT>(stage, i)) / a.t_mag1;   // sparse.py:89
         __threadfence_block();
         __syncthreads();
     }
-    if (refresh_mask) {
-        const uint32_t key = block_select_key(magnitude, C, k, sh);
+    if (a.refresh_mask) {
+        const uint32_t key = block_select_key(a.magnitude, a.C, a.k, sh);
         const float thr = key_to_f32(key);
-        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads) mask[i] = magnitude[i] >= thr ? 1 : 0;
+        for (int64_t i = tid; i < a.C; i += nthreads) a.mask[i] = a.magnitude[i] >= thr ? 1 : 0;   // util.py:117
         __threadfence_block();
         __syncthreads();
     }
-    if (update_scale) {
+    if (a.update_scale) {
         uint32_t m = 0u;
-        for (int64_t i = threadIdx.x; i < C; i += kSelectThreads) {
-            if (mask[i]) m = chan_absmax[i] > m ? chan_absmax[i] : m;
-            chan_absmax[i] = 0u;   // leave the accumulator clean for the next statistics pass
+        for (int64_t i = tid; i < a.C; i += nthreads) {
+            if (a.mask[i]) m = a.chan_absmax[i] > m ? a.chan_absmax[i] : m;
+            a.chan_absmax[i] = 0u;   // leave the accumulator clean for the next statistics pass
         }
         m = wave_max_u32(m);
-        if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = m;
+        if ((tid & 63) == 0) sh_max[tid >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 1; i < kSelectThreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
-            const float nw = __uint_as_float(m) / denom;
-            scale[0] = (t_q == 0.0f) ? nw : (t_q * scale[0] + nw) / t_q1;
+        if (tid == 0) {
+            for (int i = 1; i < nthreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
+            const float nw = __uint_as_float(m) / a.denom;                                      // quantize.py:340
+            a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * a.scale[0] + nw) / a.t_q1;             // :344-347
         }
     }
-    if (threadIdx.x == 0) {   // step counters of the two layers / the callback (state_dict tensors)
-        if (bump_a) *bump_a += 1;
-        if (bump_b) *bump_b += 1;
-        if (bump_c) *bump_c += 1;
+    if (tid == 0) {   // step counters of the two layers / the callback (state_dict tensors)
+        if (a.bump_a) *a.bump_a += 1;
+        if (a.bump_b) *a.bump_b += 1;
+        if (a.bump_c) *a.bump_c += 1;
     }
+}
+
+// C <= kRankMax: the whole select step with every per-channel value held in registers / LDS (one global
+// round trip in, one out).  Same arithmetic and order as pq_select_body.
+template <int SDT, int ITEMS>
+__device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* stage, SelectShared& sh, uint32_t* sh_max) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    float mag[ITEMS];
+    uint32_t amax[ITEMS];
+    uint8_t keep[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * nthreads;
+        mag[it] = 0.f;
+        amax[it] = 0u;
+        keep[it] = 0;
+        if (i < a.C) {
+            mag[it] = a.magnitude[i];
+            if (a.update_magnitude) mag[it] = (a.t_mag * mag[it] + load1<SDT>(stage, i)) / a.t_mag1;   // sparse.py:89
+            if (a.update_scale) amax[it] = a.chan_absmax[i];
+            keep[it] = a.mask[i];
+            sh.keys[i] = f32_to_key(mag[it]);
+        } else if (i < kRankMax) {
+            sh.keys[i] = 0xffffffffu;   // padding for the 4-wide rank loop
+        }
+    }
+    __syncthreads();
+    if (a.refresh_mask) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = tid + it * nthreads;
+            if (i < a.C) {
+                const uint32_t mine = sh.keys[i];
+                if (rank_of(sh.keys, ((int)a.C + 3) & ~3, mine, i) == a.k) sh.state[0] = mine;
+            }
+        }
+        __syncthreads();
+        const float thr = key_to_f32(sh.state[0]);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) keep[it] = mag[it] >= thr ? 1 : 0;      // util.py:117
+    }
+    uint32_t m = 0u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * nthreads;
+        if (i < a.C) {
+            if (a.update_magnitude) a.magnitude[i] = mag[it];
+            if (a.refresh_mask) a.mask[i] = keep[it];
+            if (a.update_scale) {
+                if (keep[it]) m = amax[it] > m ? amax[it] : m;
+                a.chan_absmax[i] = 0u;
+            }
+        }
+    }
+    if (a.update_scale) {
+        m = wave_max_u32(m);
+        if ((tid & 63) == 0) sh_max[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < nthreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
+            const float nw = __uint_as_float(m) / a.denom;
+            a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * a.scale[0] + nw) / a.t_q1;
+        }
+    }
+    if (tid == 0) {
+        if (a.bump_a) *a.bump_a += 1;
+        if (a.bump_b) *a.bump_b += 1;
+        if (a.bump_c) *a.bump_c += 1;
+    }
+}
+
+template <int SDT>
+__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(PqArgs a, const void* __restrict__ stage) {
+    __shared__ SelectShared sh;
+    __shared__ uint32_t sh_max[kSelectThreads / 64];
+    if (a.C <= kRankMax) pq_select_small<SDT, 1>(a, stage, sh, sh_max);
+    else pq_select_body<SDT>(a, stage, sh, sh_max);
 }
 
 // =================================================================================================
@@ -559,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restri
     float* colmean = tile + (size_t)H * W;
     const int64_t p = blockIdx.x;
     const int hw = H * W;
-    for (int i = threadIdx.x; i < hw; i += kBlock) tile[i] = load1<DT>(x, p * hw + i);
+    load_tile_f32<DT>(x, p, hw, tile);
     __syncthreads();
     const int mr_cols = (W >= 8) ? (W / 32) * 32 : (W / 4) * 4;
     for (int col = threadIdx.x; col < W; col += kBlock) {
@@ -568,22 +716,8 @@ __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restri
         colmean[col] = round_through<DT>(s / (float)H);
     }
     __syncthreads();
+    const float s = inner_sum_lds(colmean, W, colmean + W);
     if (threadIdx.x == 0) {
-        auto get = [&](int64_t i) { return colmean[i]; };
-        float s;
-        if (W >= 8) {
-            const int64_t nv = W / 8;
-            float lanes[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lanes[k] = sum_row_sum(nv, [&](int64_t i) { return get(8 * i + k); });
-            float fin = 0.f;
-            for (int64_t i = nv * 8; i < W; ++i) fin += get(i);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) fin += lanes[k];
-            s = fin;
-        } else {
-            s = sum_row_sum(W, get);
-        }
         store1<ODT>(out, p, s / (float)W);
     }
 }

@@ -167,7 +167,6 @@ size_t qs_workspace_bytes(int op, int64_t n) {
     (void)n;
     switch (op) {
         case QS_WS_KTH_VALUE: return sizeof(SelectState);
-        case QS_WS_PQ_STATS: return 0;
     }
     return 0;
 }
@@ -394,8 +393,8 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
 int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, qs_stream_t stream) {
     if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
-    const size_t lds = (size_t)(H * W + W) * sizeof(float);
-    if (lds > 48 * 1024 || pre > 0x7fffffff) return QS_ERR_ARG;
+    const size_t lds = (size_t)(H * W + W + 8) * sizeof(float);
+    if (lds > 48 * 1024 + 32 || pre > 0x7fffffff) return QS_ERR_ARG;
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         if (odt == QS_F32)
@@ -532,20 +531,45 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 }
 
 // ------------------------------------------------------------------------------------------------
+static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude, int64_t t_mag, int refresh_mask,
+                   int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
+                   int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64) {
+    if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
+    if (update_magnitude && t_mag < 0) return QS_ERR_ARG;
+    if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
+    if (update_scale && (!chan_absmax || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
+    a->magnitude = magnitude;
+    a->C = C;
+    a->update_magnitude = update_magnitude;
+    a->t_mag = (float)t_mag;
+    a->t_mag1 = (float)(t_mag + 1);
+    a->refresh_mask = refresh_mask;
+    a->k = (uint32_t)k;
+    a->mask = mask;
+    a->chan_absmax = (uint32_t*)chan_absmax;
+    a->update_scale = update_scale;
+    a->t_q = (float)t_q;
+    a->t_q1 = (float)(t_q + 1);
+    a->denom = (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0));
+    a->scale = scale;
+    a->bump_a = bump_i32_a;
+    a->bump_b = bump_i32_b;
+    a->bump_c = bump_i64;
+    return QS_OK;
+}
+
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits,
                  float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64, qs_stream_t stream) {
-    if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
-    if (update_magnitude && (!stage_mean || t_mag < 0)) return QS_ERR_ARG;
-    if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
-    if (update_scale && (!chan_absmax || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
+    PqArgs a;
+    int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, update_scale, t_q, bits,
+                     scale, bump_i32_a, bump_i32_b, bump_i64);
+    if (st) return st;
+    if (update_magnitude && !stage_mean) return QS_ERR_ARG;
     if (!dt_ok(sdt)) return QS_ERR_DTYPE;
     return with_dtype(sdt, [&](auto S) {
         constexpr int SD = decltype(S)::value;
-        hipLaunchKernelGGL((pq_select_kernel<SD>), dim3(1), dim3(kSelectThreads), 0, (hipStream_t)stream, magnitude,
-                           stage_mean, C, update_magnitude, (float)t_mag, (float)(t_mag + 1), refresh_mask, (uint32_t)k,
-                           mask, (uint32_t*)chan_absmax, update_scale, (float)t_q, (float)(t_q + 1),
-                           (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0)), scale, bump_i32_a, bump_i32_b, bump_i64);
+        hipLaunchKernelGGL((pq_select_kernel<SD>), dim3(1), dim3(kSelectThreads), 0, (hipStream_t)stream, a, stage_mean);
         return launch_status();
     });
 }

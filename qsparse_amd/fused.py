@@ -143,26 +143,26 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
             am = qdist.allreduce_max_(_hip.absmax(hd, -1), world)
             _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits)
         else:
+            # step counters that live on this GPU ride along in the select launch (callback.t stays on the CPU
+            # when the module was never moved with .to(device): that one is then bumped on the host)
+            def on_dev(t):
+                return t.data if (t.is_cuda and t.device == h.device) else None
+
+            if update_mag or refresh or update_scale:
+                bump_p = on_dev(p._n_updates) if p_counts else None
+                bump_q = on_dev(q._n_updates) if q_counts else None
+                bump_t = on_dev(cb.t) if (p_counts and n >= p.start) else None
             if update_mag:
                 if update_scale:
-                    chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by pq_select
+                    chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 dims = _reduction_plan(hd.shape, p.mask.shape)
-                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax,
-                                         absmax_channel_dim=1).view(-1)
+                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax, absmax_channel_dim=1).view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1)
             if world > 1:
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
                 mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)
-                # step counters that live on this GPU ride along in the same launch (callback.t stays on the
-                # CPU when the module was never moved with .to(device): that one is then bumped on the host)
-                def on_dev(t):
-                    return t.data if (t.is_cuda and t.device == h.device) else None
-
-                bump_p = on_dev(p._n_updates) if p_counts else None
-                bump_q = on_dev(q._n_updates) if q_counts else None
-                bump_t = on_dev(cb.t) if (p_counts and n >= p.start) else None
                 _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
                                update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t)
         if update_scale:
