@@ -27,6 +27,10 @@ __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
     return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
 }
 __device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+    // The empty asm pins `f` as a materialised binary32 value.  Without it hipcc folds a preceding multiply
+    // into v_fma_mixlo_f16 (a*b+0 rounded once to f16): that drops the sign of a zero product ((-0)+(+0) = +0)
+    // and rounds once where the reference rounds twice (fp32 op, then the cast).
+    asm volatile("" : "+v"(f));
     return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
@@ -63,6 +67,9 @@ __device__ __forceinline__ u32x4 ld16(const u32x4* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     return *p;
 }
+// Streaming stores are non-temporal.  Measured alternatives on MI355X (tools/probe_order.py): plain stores
+// are equal within noise; sc1 / sc0 sc1 (write-through) stores make the bf16->fp32 apply kernel 2.4x slower
+// and do not relieve the following kernel of the Infinity-Cache write-back.
 template <bool NT>
 __device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
     if constexpr (NT) __builtin_nontemporal_store(v, p);

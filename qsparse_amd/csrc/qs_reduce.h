@@ -42,16 +42,17 @@ __global__ __launch_bounds__(kBlock) void reduce_all_kernel(const void* __restri
     const int64_t ngroups = numel / 8;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    for (; g + stride < ngroups; g += 2 * stride) {   // two loads in flight per lane
-        Raw8<DT> r0 = load8_raw<DT, false>(x, g);
-        Raw8<DT> r1 = load8_raw<DT, false>(x, g + stride);
-        float v[8];
-        unpack8<DT>(r0, v);
+    for (; g + 3 * stride < ngroups; g += 4 * stride) {   // four 16-byte loads in flight per lane
+        Raw8<DT> r[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc.add(v[j]);
-        unpack8<DT>(r1, v);
+        for (int u = 0; u < 4; ++u) r[u] = load8_raw<DT, false>(x, g + u * stride);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+        for (int u = 0; u < 4; ++u) {
+            float v[8];
+            unpack8<DT>(r[u], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc.add(v[j]);
+        }
     }
     for (; g < ngroups; g += stride) {
         Raw8<DT> r0 = load8_raw<DT, false>(x, g);
@@ -93,7 +94,20 @@ __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restr
         const int64_t base = row * inner;
         if (vec_ok) {  // inner % 8 == 0 and base pointer aligned: rows start on 16-byte boundaries
             const int64_t g0 = base / 8, ng = inner / 8;
-            for (int64_t g = lane; g < ng; g += 64) {
+            int64_t g = lane;
+            for (; g + 3 * 64 < ng; g += 4 * 64) {   // four 16-byte loads in flight per lane
+                Raw8<DT> r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = load8_raw<DT, false>(x, g0 + g + u * 64);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[8];
+                    unpack8<DT>(r[u], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.add(v[j]);
+                }
+            }
+            for (; g < ng; g += 64) {
                 Raw8<DT> r = load8_raw<DT, false>(x, g0 + g);
                 float v[8];
                 unpack8<DT>(r, v);

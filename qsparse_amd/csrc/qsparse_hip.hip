@@ -33,6 +33,10 @@ inline int max_blocks() {
     static int v = env_int("QS_MAX_BLOCKS", 1 << 30);
     return v;
 }
+inline int reduce_blocks() {
+    static int v = env_int("QS_REDUCE_BLOCKS", 4096);
+    return v;
+}
 // Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
 // the same tensor front to back) leaves the tail of the tensor in the 256 MiB Infinity Cache, and an LRU
 // cache serves a reverse walk from it where a forward walk would evict it before use.  QS_EW_REVERSE=0 disables.
@@ -291,8 +295,8 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                 constexpr bool M = decltype(MM)::value != 0;
                 if (!per_channel) {
                     if (!vec_ptr) return (int)QS_ERR_ALIGN;
-                    int grid = grid_for(numel / 8, 2);
-                    if (grid > 4096) grid = 4096;   // every block ends with one atomic on the same word
+                    int grid = grid_for(numel / 8, 4);
+                    if (grid > reduce_blocks()) grid = reduce_blocks();   // every block ends with one atomic on the same word
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin);
                 } else if (inner >= 64) {
                     const int64_t rows = outer * C;

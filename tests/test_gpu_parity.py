@@ -368,3 +368,82 @@ def test_full_size_fused_pair_step_matches_unfused():
     for t in range(3):
         ref = (t * ref + m) / (t + 1)          # sparse.py:89 with the same input three times
     assert torch.equal(outs[0][4].view(-1)[:4].cpu(), ref)
+
+
+# ---- more shapes / dtypes through the fused pair, and graph capture of the C ABI -----------------------
+@pytest.mark.parametrize("shape,dtype", [((6, 24, 7, 7), torch.bfloat16), ((32, 40), torch.float32),
+                                         ((5, 16, 4, 8), torch.float16), ((3, 8, 2, 4, 4), torch.bfloat16)])
+def test_fused_pair_on_ragged_and_nd_shapes(shape, dtype):
+    """7x7 maps (inner not a multiple of 8 -> unfused route), 2-d activations, fp16, 5-d: convert-built pair
+    (fused where eligible) against the oracle, state included."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    C = shape[1]
+    pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
+                                                                repetition=2)),
+                         qs.quantize(bits=8, channelwise=-1, timeout=1)).to(DEV).train()
+    fuse_prune_quantize_pairs(pair)
+    ps, qsim = O.PruneSim(0.5, [1], 1, 1, 2, False), O.QuantizeSim("scaler", 8, -1, 1)
+    for s in range(6):
+        x = (torch.randn(shape, generator=gen(900 + s)) * torch.linspace(0.3, 3, C).view([1, C] + [1] * (len(shape) - 2))).to(dtype)
+        gout = torch.randn(shape, generator=gen(950 + s))
+        n_before = ps.n_updates
+        y_ref = qsim.step(ps.step(x, True), True)
+        gx_ref = ps.grad(qsim.grad(gout, dtype), n_before >= 1)
+        xg = x.to(DEV).requires_grad_(True)
+        y = pair(xg)
+        y.backward(gout.to(DEV))
+        assert same(y.detach().cpu(), y_ref), (shape, s)
+        assert same(xg.grad.cpu(), gx_ref), (shape, s)
+        assert same(pair[0][1].mask.cpu(), ps.mask) and same(pair[1].weight.detach().cpu(), qsim.weight), (shape, s)
+
+
+def test_channels_last_and_sliced_inputs():
+    x = torch.randn(4, 16, 8, 8, generator=gen(77))
+    s = torch.tensor([[0.05]])
+    xcl = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    assert same(quantize_with_scaler(xcl, 8, s.to(DEV)).cpu().contiguous(), O.scaler_fwd(x, 8, s))
+    view = x.to(DEV)[:, 3:11, ::2]
+    assert same(quantize_with_scaler(view, 8, s.to(DEV)).cpu(), O.scaler_fwd(x[:, 3:11, ::2], 8, s))
+    mask = torch.rand(1, 8, 1, 1, generator=gen(78)) > 0.5
+    assert same(apply_mask(view, mask.to(DEV)).cpu(), x[:, 3:11, ::2] * mask)
+
+
+def test_abi_calls_are_graph_capturable():
+    """the header promises: no allocation, no synchronisation, everything on the caller's stream -- so a
+    statistics -> select -> apply -> backward sequence can be captured into a hipGraph and replayed."""
+    lib = _hip.load()
+    N, C, H, W = 8, 32, 8, 8
+    x = (torch.randn(N, C, H, W, generator=gen(5)) * torch.linspace(0.3, 3, C).view(1, C, 1, 1)).bfloat16().to(DEV)
+    g = torch.randn(N, C, H, W, generator=gen(6)).to(DEV)
+    y, gx = torch.empty(N, C, H, W, device=DEV), torch.empty(N, C, H, W, device=DEV, dtype=torch.bfloat16)
+    stage1 = torch.empty(C * H * W, device=DEV, dtype=torch.bfloat16)
+    imp = torch.empty(C, device=DEV, dtype=torch.bfloat16)
+    amax, mag = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    mask, scale = torch.ones(C, device=DEV, dtype=torch.uint8), torch.zeros(1, device=DEV)
+
+    def sequence(stream):
+        assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), H * W, C, stream) == 0
+        assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, stream) == 0
+        assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 0, 4,
+                                scale.data_ptr(), None, None, None, stream) == 0
+        assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
+                                       1, 0, 0, 0, 0, 0, stream) == 0
+        assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
+                                    N, C, H * W, 0, 1, stream) == 0
+
+    sequence(None)
+    torch.cuda.synchronize()
+    want = (y.clone(), gx.clone(), mask.clone(), scale.clone())
+    y.zero_(), gx.zero_(), mask.fill_(1), scale.zero_(), mag.zero_(), amax.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequence(torch.cuda.current_stream().cuda_stream)
+    y.zero_(), gx.zero_(), mask.fill_(1), scale.zero_(), mag.zero_(), amax.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(want, (y, gx, mask, scale)):
+        assert torch.equal(a, b)
+    ps = O.PruneSim(0.5, [1], 0, 1, 1, False)
+    ps.cur_sparsity, ps.t, ps.mask = 0.5, 0, torch.ones(1, C, 1, 1, dtype=torch.bool)
+    ps.magnitude = O.magnitude_update(torch.zeros(1, C, 1, 1), x.cpu(), 0)
+    assert torch.equal(mask.bool().cpu(), O.mask_from_importance(ps.magnitude, 0.5).view(-1))

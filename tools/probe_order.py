@@ -38,6 +38,10 @@ def timed(pre, fn, iters=15):
     ts.sort()
     return ts[len(ts) // 2]
 
+if os.environ.get("QS_PROBE_SHORT"):
+    a = timed([bwd], stats); b = timed([stats], fwd); c = timed([fwd], bwd)
+    print(f"{os.environ.get('QSPARSE_HIP_LIB','default')[-16:]}: stats|bwd {a*1e3:6.1f}  fwd|stats {b*1e3:6.1f}  bwd|fwd {c*1e3:6.1f}  sum {(a+b+c)*1e3:6.1f} us", flush=True)
+    sys.exit(0)
 for name, pre in (("stats after stats", [stats]), ("stats after fwd", [fwd]), ("stats after bwd", [bwd]),
                   ("stats after fwd,bwd", [fwd, bwd]), ("stats after read-only pass over g", [readg]),
                   ("stats after 300MB memset", [fill])):
