@@ -113,13 +113,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid for 1-GPU boxes: QS_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, which
+    # exercises the whole N>1 code path (rendezvous, statistics exchange, max-over-ranks timing) without RCCL
+    share_gpu = os.environ.get("QS_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from qsparse_amd import _hip

@@ -53,9 +53,17 @@ def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
 
 def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor],
                          world: int) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """the two exchanges of the fused prune->quantize step."""
+    """the two exchanges of the fused prune->quantize step, issued back to back (asynchronously) so that
+    their latencies overlap; both are C-sized (<= 8 KB)."""
+    works = []
+    buf = None
     if stage is not None:
-        stage = allreduce_mean(stage, world)
+        buf = stage.detach().to(torch.float32).contiguous().clone()
+        works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
     if chan_absmax is not None:
-        allreduce_max_(chan_absmax, world)
+        works.append(dist.all_reduce(chan_absmax, op=dist.ReduceOp.MAX, async_op=True))
+    for w in works:
+        w.wait()
+    if buf is not None:
+        stage = buf / world
     return stage, chan_absmax

@@ -47,11 +47,11 @@ def main():
         base, shape, classes, sp = resnet18(10, True), (args.batch, 3, 32, 32), 10, 0.5
     else:
         base, shape, classes, sp = resnet50(1000, False), (args.batch, 3, 224, 224), 1000, 0.75
-    res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 3, dtype)}
+    res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype)}
     for name, fuse in (("pq_fused", True), ("pq_unfused", False)):
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
-        res[name] = run(m, shape, classes, args.steps, 4, dtype)
+        res[name] = run(m, shape, classes, args.steps, 10, dtype)
     print(args.arch, shape, args.dtype, {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
