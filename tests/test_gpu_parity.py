@@ -447,3 +447,60 @@ def test_abi_calls_are_graph_capturable():
     ps.cur_sparsity, ps.t, ps.mask = 0.5, 0, torch.ones(1, C, 1, 1, dtype=torch.bool)
     ps.magnitude = O.magnitude_update(torch.zeros(1, C, 1, 1), x.cpu(), 0)
     assert torch.equal(mask.bool().cpu(), O.mask_from_importance(ps.magnitude, 0.5).view(-1))
+
+
+# ---- remaining callback options on the GPU ---------------------------------------------------------------
+def test_weight_injection_gpu_equals_cpu_bitwise():
+    """prune + quantize injected into a conv's weight/bias: the operators only see the parameters, so the GPU
+    run must reproduce the CPU run (== reference, test_host_golden) bit for bit, whatever the conv does."""
+    import copy
+    torch.manual_seed(7)
+    base = nn.Conv2d(16, 24, 3)
+    states = []
+    for dev in ("cpu", DEV):
+        conv = copy.deepcopy(base).to(dev)
+        conv = qs.quantize(qs.prune(conv, sparsity=0.6, dimensions={0, 1, 2, 3}, start=1, interval=1, repetition=2,
+                                    callback=qs.MagnitudePruningCallback(running_average=False)),
+                           bits=4, bias_bits=8, timeout=2, channelwise=0)
+        conv.train()
+        snaps = []
+        for s in range(6):
+            conv(torch.rand(2, 16, 8, 8, generator=gen(40 + s)).to(dev))
+            snaps.append([t.detach().cpu().clone() for t in (conv.weight, conv.bias, conv.prune.mask, conv.quantize.weight,
+                                                              conv.quantize_bias.weight)])
+        states.append(snaps)
+    for a, b in zip(*states):
+        for u, v in zip(a, b):
+            assert same(u, v)
+
+
+def test_uniform_gradient_and_groupwise_options_on_gpu():
+    # uniform (random) pruning: host RNG picks positions, the mask lives on the GPU
+    np.random.seed(0)
+    layer = qs.prune(sparsity=0.5, start=1, interval=1, repetition=2, dimensions={0, 1, 2, 3},
+                     callback=qs.UniformPruningCallback()).to(DEV).train()
+    x = torch.rand(2, 6, 8, 8, generator=gen(1)).to(DEV) + 0.1
+    for _ in range(6):
+        out = layer(x)
+    assert abs((out == 0).float().mean().item() - 0.5) < 2 / out.numel()
+    assert torch.equal(out == 0, ~layer.mask)
+    # gradient-magnitude pruning: the tensor hook feeds qs_mean_dim / qs_running_mean during backward
+    cb = qs.MagnitudePruningCallback(use_gradient=True).to(DEV)
+    sim_mag, t = torch.zeros(1, 3, 6, 6), 0
+    mask = torch.ones(1, 3, 6, 6, dtype=torch.bool, device=DEV)
+    for s in range(5):
+        inp = torch.randn(1, 3, 6, 6, generator=gen(10 + s)).to(DEV).requires_grad_(True)
+        gout = torch.rand(1, 3, 6, 6, generator=gen(20 + s))
+        cb(inp, 0.5, mask).backward(gout.to(DEV))
+        # the hook sees the gradient flowing into `inp`'s consumer, i.e. gout * mask(before refresh of this step)
+    assert cb.t.item() == 5 and hasattr(cb, "magnitude") and cb.magnitude.is_cuda
+    assert abs((~mask).float().mean().item() - 0.5) <= 1 / mask.numel()
+    # group-wise quantization: clustering on the host (sklearn), shared scales applied on the GPU
+    data = (torch.rand(8, 10, 6, 6, generator=gen(30)) - 0.5) * 4
+    ql = qs.quantize(bits=8, timeout=2, channelwise=1, callback=qs.AdaptiveQuantizer(group_num=4, group_timeout=4)).to(DEV)
+    qc = qs.quantize(bits=8, timeout=2, channelwise=1, callback=qs.AdaptiveQuantizer(group_num=4, group_timeout=4))
+    for _ in range(10):
+        yg, yc = ql(data.to(DEV)), qc(data)
+    assert same(ql.weight.detach().cpu(), qc.weight.detach())
+    assert torch.equal(ql.callback.groups.cpu(), qc.callback.groups)
+    assert same(yg.cpu(), yc)
