@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 1
+#define QS_ABI_VERSION 2
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -112,13 +112,21 @@ int qs_absmax(const void* x, float* out, int per_channel,
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
               int64_t outer, int64_t C, int64_t inner, int xdt, qs_stream_t stream);
 
+/* Step counters.  The reference keeps them on the host (Python ints / `.item()` reads) and they enter the
+ * arithmetic of every running mean.  A by-value kernel argument is frozen when a launch is captured into a
+ * hipGraph, so every entry point that takes a counter `t` also takes `t_dev` (nullable): a device-resident
+ * int64 holding the same counter, read by the kernel INSTEAD of `t` when non-NULL.  Counters are advanced
+ * either by the caller (any stream-ordered increment) or, for qs_pq_select, by its bump_* arguments. */
+
 /* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1)
  * (quantize.py:340,344-348). */
-int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, int bits, qs_stream_t stream);
-
-/* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430) */
-int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after,
+int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
                     qs_stream_t stream);
+
+/* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
+ * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */
+int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after,
+                    const int64_t* t_dev, qs_stream_t stream);
 
 /* d[i] = rint(log2(nan_to_num(1/scale[i], posinf=1, neginf=1)))  (quantize.py:316) */
 int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stream_t stream);
@@ -148,7 +156,8 @@ int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scra
 
 /* state[i] <- (t*state[i] + f32(new[i])) / (t+1)   (MagnitudePruningCallback.update_magnitude,
  * qsparse/sparse.py:88-89) */
-int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, qs_stream_t stream);
+int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, const int64_t* t_dev,
+                    qs_stream_t stream);
 
 /* ---- mask construction --------------------------------------------------------------------------- */
 
@@ -178,14 +187,16 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340)
  *   scale      <- t_q == 0 ? new : (t_q*scale + new)/(t_q+1), new = absmax_all/2^(bits-1)  if update_scale
  * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536.
- * chan_absmax is zeroed after use when update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64 (each
- * nullable) are one-element device counters incremented by one: the layers' `_n_updates` and the
- * callback's `t` (sparse.py:117,272; quantize.py:515), so that a step needs no separate counter kernels. */
+ * chan_absmax is zeroed after use when update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64_a / bump_i64_b
+ * (each nullable) are one-element device counters incremented by one at the end: the layers' `_n_updates`,
+ * the pruning callback's `t` and the quantizer's device-side `t` (sparse.py:117,272; quantize.py:348,515), so
+ * that a step needs no separate counter kernels.  t_mag_dev / t_q_dev: see "Step counters" above. */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
                  float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
-                 int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64, qs_stream_t stream);
+                 int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

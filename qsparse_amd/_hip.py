@@ -41,16 +41,16 @@ SIGNATURES = {
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
-    "qs_scale_update": (c_int, [_P, _P, _L, _L, _I, _P]),
-    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P]),
+    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _P]),
+    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _P]),
     "qs_l0_flag": (c_int, [_P, _L, _I, _P, _P, _P]),
-    "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P]),
+    "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P, _P]),
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
 }
 
@@ -155,7 +155,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+try:   # raw hipStream_t of torch's current stream without building a Stream object (20x cheaper per call)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:   # pragma: no cover
+    _raw_stream = None
+
+
 def _stream(t: torch.Tensor):
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -285,16 +293,18 @@ def minmax(x: torch.Tensor, channel_index: int):
     return mn, mx
 
 
-def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int):
-    """in place on `weight` (fp32, contiguous)."""
+def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None):
+    """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t`."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
-    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), int(bits), _stream(weight))
+    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(bits),
+                                _stream(weight))
     _check(st, "qs_scale_update")
 
 
-def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int):
+def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int,
+                 t_dev: Optional[torch.Tensor] = None):
     assert lines.dtype == torch.float32 and lines.is_contiguous()
-    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _stream(lines))
+    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), _stream(lines))
     _check(st, "qs_lines_update")
 
 
@@ -338,10 +348,10 @@ def l0_flag(x: torch.Tensor) -> torch.Tensor:
     return flag
 
 
-def running_mean(state: torch.Tensor, new: torch.Tensor, t: int):
+def running_mean(state: torch.Tensor, new: torch.Tensor, t: int, t_dev: Optional[torch.Tensor] = None):
     assert state.dtype == torch.float32 and state.is_contiguous() and new.numel() == state.numel()
     new = new.contiguous()
-    st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _stream(state))
+    st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _ptr(t_dev), _stream(state))
     _check(st, "qs_running_mean")
 
 
@@ -394,16 +404,20 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], update_magnitude: bool, t_mag: int,
               refresh_mask: bool, k: int, mask: torch.Tensor, chan_absmax: Optional[torch.Tensor], update_scale: bool,
               t_q: int, bits: int, scale: Optional[torch.Tensor], bump_a: Optional[torch.Tensor] = None,
-              bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None):
-    """bump_a / bump_b: int32 one-element counters, bump_c: int64 one-element counter (each optional)."""
+              bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None,
+              bump_d: Optional[torch.Tensor] = None, t_mag_dev: Optional[torch.Tensor] = None,
+              t_q_dev: Optional[torch.Tensor] = None):
+    """bump_a / bump_b: int32 one-element counters; bump_c / bump_d: int64 one-element counters; t_*_dev: device
+    int64 counters read instead of the by-value t_mag / t_q (each optional)."""
     C = magnitude.numel()
     sdt = dt(stage_mean) if stage_mean is not None else F32
-    assert bump_a is None or bump_a.dtype == torch.int32
-    assert bump_b is None or bump_b.dtype == torch.int32
-    assert bump_c is None or bump_c.dtype == torch.int64
+    for b32 in (bump_a, bump_b):
+        assert b32 is None or b32.dtype == torch.int32
+    for b64 in (bump_c, bump_d, t_mag_dev, t_q_dev):
+        assert b64 is None or b64.dtype == torch.int64
     with _timed("pq_select"):
         st = load().qs_pq_select(_ptr(magnitude), _ptr(stage_mean), sdt, C, int(update_magnitude), int(t_mag),
                                  int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
-                                 int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _stream(magnitude))
+                                 int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
+                                 _ptr(t_mag_dev), _ptr(t_q_dev), _stream(magnitude))
     _check(st, "qs_pq_select")
-

@@ -51,6 +51,10 @@ class HostMirror:
         self._obj, self._version = p, p._version
         self._value = f32_round(float(value)) if p.dtype == torch.float32 else value
 
+    def invalidate(self):
+        """forget the host copy (the tensor was advanced behind our back, e.g. by hipGraph replays)"""
+        self._obj, self._version, self._value = None, -1, None
+
     def __deepcopy__(self, memo):
         return HostMirror()  # a copied layer re-reads its own (copied) tensor on first use
 

@@ -154,15 +154,27 @@ __global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
 // =================================================================================================
 // C-sized state updates
 // =================================================================================================
-__global__ void scale_update_kernel(const float* absmax, float* weight, int64_t n, float t, float tp1, float denom) {
+// `t_dev` (nullable): device-resident step counter read instead of the by-value `t`, so that a captured hipGraph
+// replays with the live counter (by-value kernel arguments are frozen at capture time)
+__global__ void scale_update_kernel(const float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
+                                    const int64_t* t_dev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_dev) {
+        t = (float)*t_dev;
+        tp1 = (float)(*t_dev + 1);
+    }
     if (i < n) {
         const float nw = absmax[i] / denom;                       // max / 2**(bits-1)   (quantize.py:340)
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
     }
 }
-__global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t) {
+__global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t,
+                                    const int64_t* t_dev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_dev) {   // counter BEFORE this step's increment
+        tm1 = (float)*t_dev;
+        t = (float)(*t_dev + 1);
+    }
     if (i < n) {
         lines[2 * i] = (lines[2 * i] * tm1 + mn[i]) / t;          // (quantize.py:430)
         lines[2 * i + 1] = (lines[2 * i + 1] * tm1 + mx[i]) / t;
@@ -178,8 +190,12 @@ __global__ void decimal_from_scale_kernel(const float* scale, float* d, int64_t 
     }
 }
 template <int DT>
-__global__ void running_mean_kernel(float* state, const void* nv, int64_t n, float t, float tp1) {
+__global__ void running_mean_kernel(float* state, const void* nv, int64_t n, float t, float tp1, const int64_t* t_dev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t_dev) {
+        t = (float)*t_dev;
+        tp1 = (float)(*t_dev + 1);
+    }
     if (i < n) state[i] = (t * state[i] + load1<DT>(nv, i)) / tp1;       // sparse.py:89
 }
 __global__ void l0_flag_kernel(const float* mn, int32_t* flag) { *flag = (mn[0] == 0.0f) ? 1 : 0; }
@@ -591,7 +607,22 @@ struct PqArgs {
     int32_t* bump_a;
     int32_t* bump_b;
     int64_t* bump_c;
+    int64_t* bump_d;
+    const int64_t* t_mag_dev;   // nullable device counters overriding t_mag / t_q (graph replay)
+    const int64_t* t_q_dev;
 };
+
+__device__ __forceinline__ PqArgs pq_live_counters(PqArgs a) {
+    if (a.t_mag_dev) {
+        a.t_mag = (float)*a.t_mag_dev;
+        a.t_mag1 = (float)(*a.t_mag_dev + 1);
+    }
+    if (a.t_q_dev) {
+        a.t_q = (float)*a.t_q_dev;
+        a.t_q1 = (float)(*a.t_q_dev + 1);
+    }
+    return a;
+}
 
 // the C-sized step, run by ONE workgroup of >= 256 threads; `stage` holds the last squeeze stage ([C], dtype SDT)
 template <int SDT>
@@ -629,6 +660,7 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
         if (a.bump_a) *a.bump_a += 1;
         if (a.bump_b) *a.bump_b += 1;
         if (a.bump_c) *a.bump_c += 1;
+        if (a.bump_d) *a.bump_d += 1;
     }
 }
 
@@ -698,11 +730,13 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
         if (a.bump_a) *a.bump_a += 1;
         if (a.bump_b) *a.bump_b += 1;
         if (a.bump_c) *a.bump_c += 1;
+        if (a.bump_d) *a.bump_d += 1;
     }
 }
 
 template <int SDT>
-__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(PqArgs a, const void* __restrict__ stage) {
+__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(PqArgs a0, const void* __restrict__ stage) {
+    const PqArgs a = pq_live_counters(a0);   // every thread reads the counters before thread 0 bumps them (barriers in between)
     __shared__ SelectShared sh;
     __shared__ uint32_t sh_max[kSelectThreads / 64];
     if (a.C <= kRankMax) pq_select_small<SDT, 1>(a, stage, sh, sh_max);

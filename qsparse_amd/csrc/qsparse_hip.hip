@@ -336,19 +336,21 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, in
     return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
 }
 
-int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, int bits, qs_stream_t stream) {
+int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
+                    qs_stream_t stream) {
     if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
     hipLaunchKernelGGL(scale_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, absmax,
-                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)));
+                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev);
     return launch_status();
 }
 
-int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, qs_stream_t stream) {
+int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, const int64_t* t_dev,
+                    qs_stream_t stream) {
     if (!mn || !mx || !lines || n < 0 || t_after < 1) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
     hipLaunchKernelGGL(lines_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn, mx,
-                       lines, n, (float)(t_after - 1), (float)t_after);
+                       lines, n, (float)(t_after - 1), (float)t_after, t_dev);
     return launch_status();
 }
 
@@ -419,13 +421,14 @@ int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scra
     return launch_status();
 }
 
-int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, qs_stream_t stream) {
+int qs_running_mean(float* state, const void* newv, int newdt, int64_t n, int64_t t, const int64_t* t_dev,
+                    qs_stream_t stream) {
     if (!state || !newv || n < 0 || t < 0) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
     return with_dtype(newdt, [&](auto D) {
         constexpr int DD = decltype(D)::value;
         hipLaunchKernelGGL((running_mean_kernel<DD>), dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           state, newv, n, (float)t, (float)(t + 1));
+                           state, newv, n, (float)t, (float)(t + 1), t_dev);
         return launch_status();
     });
 }
@@ -537,7 +540,8 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 // ------------------------------------------------------------------------------------------------
 static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude, int64_t t_mag, int refresh_mask,
                    int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
-                   int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64) {
+                   int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
+                   const int64_t* t_mag_dev, const int64_t* t_q_dev) {
     if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
     if (update_magnitude && t_mag < 0) return QS_ERR_ARG;
     if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
@@ -558,16 +562,20 @@ static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude,
     a->scale = scale;
     a->bump_a = bump_i32_a;
     a->bump_b = bump_i32_b;
-    a->bump_c = bump_i64;
+    a->bump_c = bump_i64_a;
+    a->bump_d = bump_i64_b;
+    a->t_mag_dev = t_mag_dev;
+    a->t_q_dev = t_q_dev;
     return QS_OK;
 }
 
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits,
-                 float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64, qs_stream_t stream) {
+                 float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream) {
     PqArgs a;
     int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, update_scale, t_q, bits,
-                     scale, bump_i32_a, bump_i32_b, bump_i64);
+                     scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev);
     if (st) return st;
     if (update_magnitude && !stage_mean) return QS_ERR_ARG;
     if (!dt_ok(sdt)) return QS_ERR_DTYPE;

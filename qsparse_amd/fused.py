@@ -134,6 +134,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
     p_counts = p.training and p.mask.numel() != 1
     q_counts = q.timeout > 0 and q.training
     bump_p = bump_q = bump_t = None
+    select_bumped_tq = False
     with torch.no_grad():
         hd = h.detach()
         stage = chan_absmax = None
@@ -141,7 +142,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
         if update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1), world)
-            _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits)
+            _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits,
+                              t_dev=qc.device_t(h.device) if get_option("graph_safe") else None)
         else:
             # step counters that live on this GPU ride along in the select launch (callback.t stays on the CPU
             # when the module was never moved with .to(device): that one is then bumped on the host)
@@ -163,10 +165,19 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
                 mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)
+                t_mag_dev = t_q_dev = None
+                if get_option("graph_safe"):   # running-mean counters come from device memory (hipGraph replay)
+                    t_mag_dev = on_dev(cb.t) if update_mag else None
+                    t_q_dev = qc.device_t(h.device) if update_scale else None
                 _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
-                               update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t)
+                               update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t,
+                               bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev)
+                select_bumped_tq = t_q_dev is not None
         if update_scale:
-            qc.t += 1
+            if select_bumped_tq:
+                qc._advance_t(qc.__dict__["_t_dev"], bumped_by_kernel=True)
+            else:
+                qc._advance_t(qc.device_t(h.device) if (get_option("graph_safe") and not prune_on) else None)
 
     # ---- counters (same order as the unfused layers) ----
     if p_counts:

@@ -235,6 +235,23 @@ class DecimalQuantizer(BaseQuantizer):
         self.groups = None
         self.group_num = group_num
 
+    def device_t(self, device) -> torch.Tensor:
+        """device-resident copy of ``self.t`` (int64, one element) for graph-safe kernels; recreated whenever the
+        host value was changed by anyone but the step itself"""
+        buf = self.__dict__.get("_t_dev")
+        if buf is None or buf.device != device or self.__dict__.get("_t_dev_value") != self.t:
+            buf = torch.full((1,), int(self.t), dtype=torch.int64, device=device)
+            self.__dict__["_t_dev"] = buf
+            self.__dict__["_t_dev_value"] = self.t
+        return buf
+
+    def _advance_t(self, t_dev: torch.Tensor = None, bumped_by_kernel: bool = False):
+        self.t += 1
+        if t_dev is not None:
+            if not bumped_by_kernel:
+                t_dev.add_(1)
+            self.__dict__["_t_dev_value"] = self.t
+
     def quantize(self, tensor, bits, scaler, channel_index=-1, **kwargs):
         if self.use_float_scaler:
             param = scaler
@@ -260,7 +277,10 @@ class DecimalQuantizer(BaseQuantizer):
                 stat = qdist.allreduce_max_(_hip.absmax(x, channel_index))
                 if weight is None:
                     weight = torch.zeros(wshape, device=x.device)
-                _hip.scale_update(stat, weight.data, self.t, bits)   # t == 0 overwrites, else running mean
+                t_dev = self.device_t(x.device) if get_option("graph_safe") else None
+                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev)   # t == 0 overwrites, else running mean
+                self._advance_t(t_dev)
+                return weight
             else:
                 new_weight = (qdist.allreduce_max_(_absmax_rows_cpu(x, channel_index)) / (2 ** (bits - 1))).view(wshape)
                 if self.t == 0:
@@ -341,8 +361,9 @@ class AdaptiveQuantizer(DecimalQuantizer):
                     self.t += 1
                     return torch.stack([lo, hi], dim=1)
                 assert weight.shape == (lo.numel(), 2)
-                self.t += 1
-                _hip.lines_update(lo, hi, weight.data, self.t)
+                t_dev = self.device_t(x.device) if get_option("graph_safe") else None
+                _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev)
+                self._advance_t(t_dev)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)
             if qdist.stats_world_size() > 1:

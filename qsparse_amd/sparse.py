@@ -100,7 +100,8 @@ class MagnitudePruningCallback(nn.Module):
             t = self._t_host.read(self.t)
             imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0))
             if x.is_cuda:
-                _hip.running_mean(self.magnitude.data, imp, t)
+                t_dev = self.t.data if (get_option("graph_safe") and self.t.is_cuda) else None
+                _hip.running_mean(self.magnitude.data, imp, t, t_dev=t_dev)
             else:
                 self.magnitude.data[:] = (t * self.magnitude + imp) / (t + 1)
 
