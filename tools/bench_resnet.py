@@ -16,20 +16,33 @@ import qsparse_amd as qs
 from examples.models import convert_pq, resnet18, resnet50
 
 
-def run(model, shape, classes, steps, warmup, dtype):
+def run(model, shape, classes, steps, warmup, dtype, graph=False):
     model = model.cuda().train()   # fp32 master weights; bf16 compute through autocast (activations are bf16)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     x = torch.randn(shape, device="cuda")
     y = torch.randint(0, classes, (shape[0],), device="cuda")
-    for i in range(warmup + steps):
-        if i == warmup:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
         with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
             loss = F.cross_entropy(model(x).float(), y)
         loss.backward()
         opt.step()
+
+    for i in range(warmup):
+        step()
+    if graph:
+        from qsparse_amd import graphs
+        assert graphs.steady_state(model) or not any(True for _ in model.modules() if hasattr(_, "_kwargs") or type(_).__name__ in ("PruneLayer", "QuantizeLayer"))
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            step()
+        step = g.replay
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -47,11 +60,13 @@ def main():
         base, shape, classes, sp = resnet18(10, True), (args.batch, 3, 32, 32), 10, 0.5
     else:
         base, shape, classes, sp = resnet50(1000, False), (args.batch, 3, 224, 224), 1000, 0.75
-    res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype)}
-    for name, fuse in (("pq_fused", True), ("pq_unfused", False)):
+    res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype),
+           "plain_graph": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype, graph=True)}
+    qs.set_qsparse_options(graph_safe=True)
+    for name, fuse, graph in (("pq_fused", True, False), ("pq_unfused", False, False), ("pq_fused_graph", True, True)):
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
-        res[name] = run(m, shape, classes, args.steps, 10, dtype)
+        res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph)
     print(args.arch, shape, args.dtype, {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
