@@ -81,44 +81,55 @@ __global__ __launch_bounds__(kBlock) void reduce_all_kernel(const void* __restri
     }
 }
 
-// per channel, rows of `inner` contiguous elements: one wave per (outer, c) row
+// per channel, rows of `inner` contiguous elements.  Workgroup (c, s) owns channel c and the s-th slice of the
+// outer range; its waves walk rows o*C + c and keep their running extrema in registers, so each workgroup
+// ends with ONE atomic: same-address device-scope atomics cost ~0.3 us each once hundreds of workgroups
+// contend (65 k per-row atomics on 256 words took 80 us), a few per word are free.
 template <int DT, bool MINMAX>
-__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restrict__ x, int64_t rows, uint32_t C,
-                                                              int64_t inner, int vec_ok, uint32_t* out_max,
-                                                              uint32_t* out_min) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    for (int64_t row = wave; row < rows; row += nwaves) {
-        RedAcc<DT, MINMAX> acc;
-        const int64_t base = row * inner;
+__global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restrict__ x, int64_t outer, uint32_t C,
+                                                              int64_t inner, int vec_ok, int64_t outer_per_block,
+                                                              uint32_t* out_max, uint32_t* out_min) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
+    const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
+    RedAcc<DT, MINMAX> acc;
+    for (int64_t o = o0 + wave; o < o1; o += kBlock / 64) {
+        const int64_t base = (o * C + c) * inner;
         if (vec_ok) {  // inner % 8 == 0 and base pointer aligned: rows start on 16-byte boundaries
             const int64_t g0 = base / 8, ng = inner / 8;
-            int64_t g = lane;
-            for (; g + 3 * 64 < ng; g += 4 * 64) {   // four 16-byte loads in flight per lane
-                Raw8<DT> r[4];
+            for (int64_t g = lane; g < ng; g += 8 * 64) {   // up to eight 16-byte loads in flight per lane
+                Raw8<DT> r[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = load8_raw<DT, false>(x, g0 + g + u * 64);
+                for (int u = 0; u < 8; ++u)
+                    if (g + u * 64 < ng) r[u] = load8_raw<DT, false>(x, g0 + g + u * 64);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float v[8];
-                    unpack8<DT>(r[u], v);
+                for (int u = 0; u < 8; ++u) {
+                    if (g + u * 64 < ng) {
+                        float v[8];
+                        unpack8<DT>(r[u], v);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc.add(v[j]);
+                        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+                    }
                 }
-            }
-            for (; g < ng; g += 64) {
-                Raw8<DT> r = load8_raw<DT, false>(x, g0 + g);
-                float v[8];
-                unpack8<DT>(r, v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc.add(v[j]);
             }
         } else {
             for (int64_t i = lane; i < inner; i += 64) acc.add(load1<DT>(x, base + i));
         }
-        acc.wave_reduce();
-        if (lane == 0) acc.flush(out_max, out_min, (uint32_t)(row % C));
+    }
+    __shared__ uint32_t smx[kBlock / 64], smn[kBlock / 64];
+    acc.wave_reduce();
+    if (lane == 0) {
+        smx[wave] = acc.mx;
+        smn[wave] = acc.mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && o1 > o0) {
+        for (int i = 1; i < kBlock / 64; ++i) {
+            acc.mx = smx[i] > acc.mx ? smx[i] : acc.mx;
+            acc.mn = smn[i] < acc.mn ? smn[i] : acc.mn;
+        }
+        acc.flush(out_max, out_min, c);
     }
 }
 
@@ -134,6 +145,62 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restr
     RedAcc<DT, MINMAX> acc;
     for (int64_t o = o0; o < o1; ++o) acc.add(load1<DT>(x, o * cols + col));
     if (o1 > o0) acc.flush(out_max, out_min, (uint32_t)(col / inner));
+}
+
+// same, 8 adjacent columns per thread with 16-byte loads (cols % 8 == 0, aligned base), 8 rows in flight
+template <int DT, bool MINMAX>
+__global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
+                                                                  int64_t inner, int64_t outer_per_block,
+                                                                  uint32_t* out_max, uint32_t* out_min) {
+    const int64_t gcols = cols / 8;
+    const int64_t gc = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
+    const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
+    RedAcc<DT, MINMAX> acc[8];
+    for (int64_t o = o0; o < o1 && gc < gcols; o += 8) {
+        Raw8<DT> r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (o + u < o1) r[u] = load8_raw<DT, false>(x, (o + u) * gcols + gc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (o + u < o1) {
+                float v[8];
+                unpack8<DT>(r[u], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j].add(v[j]);
+            }
+        }
+    }
+    // combine inside the workgroup first (LDS atomics, indexed by channel relative to the block's first one), then
+    // one global atomic per (workgroup, channel): global same-address atomics are what limits this kernel
+    constexpr int kLocal = kBlock * 8 + 2;
+    __shared__ uint32_t lmx[kLocal], lmn[kLocal];
+    const int64_t col_first = (int64_t)blockIdx.x * kBlock * 8;
+    const uint32_t c_block = (uint32_t)(col_first / inner);
+    int64_t col_last = col_first + (int64_t)kBlock * 8 - 1;
+    if (col_last >= cols) col_last = cols - 1;
+    const int nlocal = (int)(col_last / inner - c_block) + 1;
+    for (int i = threadIdx.x; i < nlocal; i += kBlock) {
+        lmx[i] = 0u;
+        lmn[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    if (gc < gcols && o1 > o0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int li = (int)((gc * 8 + j) / inner - c_block);
+            atomicMax(&lmx[li], acc[j].mx);
+            if constexpr (MINMAX) atomicMin(&lmn[li], acc[j].mn);
+        }
+    }
+    __syncthreads();
+    if (o1 > o0) {
+        for (int i = threadIdx.x; i < nlocal; i += kBlock) {
+            atomicMax(out_max + c_block + i, lmx[i]);
+            if constexpr (MINMAX) atomicMin(out_min + c_block + i, lmn[i]);
+        }
+    }
 }
 
 __global__ void keys_init_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
@@ -385,14 +452,117 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
     }
 
     if (absmax) {   // whole wave takes part: idle lanes contribute 0
-        // all 8 columns of a lane share a channel when chan_div % 8 == 0 (checked on the host)
-        const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
-        const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
-        if (__all(!active || c == c0)) {
-            amax = wave_max_u32(amax);
-            if (threadIdx.x == 0) atomicMax(absmax + c0, amax);
+        if (chan_div % 8 == 0) {   // all 8 columns of a lane share a channel
+            const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
+            const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
+            if (__all(!active || c == c0)) {
+                amax = wave_max_u32(amax);
+                if (threadIdx.x == 0) atomicMax(absmax + c0, amax);
+            } else if (active) {
+                atomicMax(absmax + c, amax);
+            }
+        } else if (active) {       // ragged rows (e.g. 7x7 maps): handled per column by the caller's generic kernel
+            atomicMax(absmax + (uint32_t)(((gc * 8) / chan_div) % C), amax);
+        }
+    }
+}
+
+// ---- the same stage for tensors with FEW columns: rows split over R waves of one workgroup -------------------
+// With C*H*W small (late ResNet stages, small batches of small maps) one wave per 512 columns leaves most CUs
+// with one or two waves and the kernel becomes latency-bound.  Here the R waves of a workgroup own the SAME
+// column groups and share the rows chunk-wise: wave w sums chunks w, w+R, ... (a chunk = 2^p consecutive rows,
+// summed sequentially from zero -- exactly what ATen's level-0 accumulator holds when it is dumped into level
+// 1), parks the chunk sums in LDS, and wave 0 then feeds them IN ORDER through the level-1..3 cascade, adds the
+// n % 2^p tail rows and finishes.  Bit-identical to the single-wave kernel; needs n / 2^p <= kMaxSplitChunks.
+constexpr int kMaxSplitChunks = 32;
+
+template <int DT, int ODT, int R>
+__global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                                   int64_t pre, int64_t n, int64_t post, int64_t vcols,
+                                                                   int flags, const int32_t* __restrict__ l0_flag,
+                                                                   uint32_t* __restrict__ absmax, int64_t chan_div,
+                                                                   uint32_t C, int lanes) {
+    extern __shared__ __attribute__((aligned(16))) float chunk_sums[];   // [nchunks][8][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gcols = vcols / 8, total = pre * gcols;
+    const int64_t t = (int64_t)blockIdx.x * lanes + lane;
+    const bool active = lane < lanes && t < total;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    const int nchunks = (int)(n / step);
+    const int64_t tt = active ? t : 0;
+    const int64_t p = tt / gcols, gc = tt - p * gcols;
+    const int64_t row_groups = post / 8;
+    const int64_t g_base = p * n * row_groups + gc;
+    uint32_t amax0 = 0u, amax1 = 0u;
+    // channels of the first / last of this lane's 8 columns (they differ when chan_div is not a multiple of 8)
+    const uint32_t c_first = absmax ? (uint32_t)(((gc * 8) / chan_div) % C) : 0u;
+    const int64_t first_col_next = absmax ? ((gc * 8) / chan_div + 1) * chan_div - gc * 8 : 8;   // #cols in c_first
+
+    auto track = [&](const float (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
+            if (j < first_col_next) amax0 = k > amax0 ? k : amax0;
+            else amax1 = k > amax1 ? k : amax1;
+        }
+    };
+
+    if (active) {
+        for (int ch = wave; ch < nchunks; ch += R) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            const int64_t r0 = (int64_t)ch * step;
+            for (int64_t j = 0; j < step; j += 16) {
+                Raw8<DT> r[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, false>(x, g_base + (r0 + j + u) * row_groups);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    float v[8];
+                    unpack8<DT>(r[u], v);
+                    if (absmax) track(v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += mean_prep<DT>(v[k], flags, l0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) chunk_sums[(ch * 8 + j) * 64 + lane] = acc[j];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        Cascade c[8];
+        for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                c[j].a0 = chunk_sums[(ch * 8 + j) * 64 + lane];   // level 0 as ATen holds it after this chunk
+                c[j].carry((int64_t)(ch + 1) * step, lp, lmask);
+            }
+        }
+        for (int64_t i = (int64_t)nchunks * step; i < n; ++i) {       // n % step tail rows, sequential into level 0
+            float v[8];
+            unpack8<DT>(load8_raw<DT, false>(x, g_base + i * row_groups), v);
+            if (absmax) track(v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j].add(mean_prep<DT>(v[j], flags, l0));
+        }
+        float m[8];
+        const float fn = (float)n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = c[j].total() / fn;
+        store8<ODT, false>(out, p * row_groups + gc, m);
+    }
+    if (absmax) {   // one atomic per wave when the whole wave sits inside one channel, else per lane
+        const uint32_t c0 = (uint32_t)__shfl((int)c_first, 0, 64);
+        if (__all(!active || (c_first == c0 && first_col_next >= 8))) {
+            const uint32_t m = wave_max_u32(active ? amax0 : 0u);
+            if (lane == 0) atomicMax(absmax + c0, m);
         } else if (active) {
-            atomicMax(absmax + c, amax);
+            atomicMax(absmax + c_first, amax0);
+            if (first_col_next < 8) atomicMax(absmax + (c_first + 1 == C ? 0u : c_first + 1), amax1);
         }
     }
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "qs_elementwise.h"
@@ -34,7 +35,7 @@ inline int max_blocks() {
     return v;
 }
 inline int reduce_blocks() {
-    static int v = env_int("QS_REDUCE_BLOCKS", 4096);
+    static int v = env_int("QS_REDUCE_BLOCKS", 512);
     return v;
 }
 // Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
@@ -298,23 +299,30 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     int grid = grid_for(numel / 8, 4);
                     if (grid > reduce_blocks()) grid = reduce_blocks();   // every block ends with one atomic on the same word
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin);
-                } else if (inner >= 64) {
-                    const int64_t rows = outer * C;
-                    int64_t blocks = (rows + 3) / 4;
-                    if (blocks > max_blocks()) blocks = max_blocks();
+                } else if (inner >= 64 && C < 65536) {
+                    int64_t slices = (2048 + C - 1) / C;              // ~2048 workgroups, one atomic each
+                    if (slices > (outer + 3) / 4) slices = (outer + 3) / 4;
+                    if (slices < 1) slices = 1;
+                    const int64_t opb = (outer + slices - 1) / slices;
                     const int vec_ok = vec_ptr && (inner % 8 == 0);
-                    hipLaunchKernelGGL((reduce_rows_kernel<XD, M>), dim3((int)blocks), dim3(kBlock), 0, s, x, rows,
-                                       (uint32_t)C, inner, vec_ok, omax, omin);
+                    hipLaunchKernelGGL((reduce_rows_kernel<XD, M>), dim3((int)C, (int)((outer + opb - 1) / opb)), dim3(kBlock),
+                                       0, s, x, outer, (uint32_t)C, inner, vec_ok, opb, omax, omin);
                 } else {
                     const int64_t cols = C * inner;
-                    const int gx = (int)((cols + kBlock - 1) / kBlock);
+                    const bool vec = vec_ptr && (cols % 8 == 0);
+                    const int64_t per_block = vec ? (int64_t)kBlock * 8 : kBlock;
+                    const int gx = (int)((cols + per_block - 1) / per_block);
                     int64_t gy = 1;
-                    if (gx < 512) gy = (512 + gx - 1) / gx;
-                    if (gy > outer) gy = outer;
+                    if (gx < 1024) gy = (1024 + gx - 1) / gx;     // enough workgroups to fill the chip
+                    if (gy > (outer + 7) / 8) gy = (outer + 7) / 8;
                     if (gy < 1) gy = 1;
                     const int64_t opb = (outer + gy - 1) / gy;
-                    hipLaunchKernelGGL((reduce_cols_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer, cols,
-                                       inner, opb, omax, omin);
+                    if (vec)
+                        hipLaunchKernelGGL((reduce_cols_vec_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer,
+                                           cols, inner, opb, omax, omin);
+                    else
+                        hipLaunchKernelGGL((reduce_cols_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer, cols,
+                                           inner, opb, omax, omin);
                 }
                 return launch_status();
             };
@@ -370,9 +378,24 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
     if (absmax_out && (chan_div < 1 || C < 1)) return QS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int64_t vcols = 0;
-    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!absmax_out || chan_div % 8 == 0))
+    const bool ragged_absmax = absmax_out && (chan_div % 8 != 0);
+    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!ragged_absmax || chan_div >= 8))
         vcols = (post / 32) * 32;
     uint32_t* am = (uint32_t*)absmax_out;
+    // rows are split over R waves per workgroup when there are too few column groups to fill the chip
+    const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
+    const int64_t nchunks = n >> lp;
+    int R = 1;
+    if (vcols > 0) {
+        const int64_t waves = (pre * (vcols / 8) + 63) / 64;
+        const int want = env_int("QS_MEAN_SPLIT", 0);
+        if (want > 0) R = want;
+        else if (waves < 1024 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = waves >= 512 ? 2 : (waves >= 256 ? 4 : 8);
+        while (R > 1 && R > nchunks) R >>= 1;
+        if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
+        if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
+        if (R == 0) vcols = 0;
+    }
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         auto run = [&](auto O) {
@@ -380,9 +403,21 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
             if (vcols > 0) {
                 const int64_t total = pre * (vcols / 8);
                 const int lanes = mean_lanes(total);
-                hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT>),
-                                   dim3((int)((total + lanes - 1) / lanes)), dim3(64), 0, s, x, out, pre, n, post, vcols,
-                                   flags, l0_flag, am, chan_div, (uint32_t)(C > 0 ? C : 1), lanes);
+                const int blocks = (int)((total + lanes - 1) / lanes);
+                const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
+                const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
+                if (R == 1)
+                    hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT>), dim3(blocks), dim3(64), 0, s,
+                                       x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                else if (R == 2)
+                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 2>), dim3(blocks), dim3(128), lds, s, x, out, pre, n,
+                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                else if (R == 4)
+                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 4>), dim3(blocks), dim3(256), lds, s, x, out, pre, n,
+                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                else
+                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 8>), dim3(blocks), dim3(512), lds, s, x, out, pre, n,
+                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
             }
             if (vcols < post) {
                 const int64_t total = pre * (post - vcols);

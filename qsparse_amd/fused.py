@@ -40,10 +40,7 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
         return False
     if qc.backward_passthrough:
         return False
-    inner = 1
-    for s in h.shape[2:]:
-        inner *= s
-    return inner % 8 == 0 or h.dim() == 2
+    return True
 
 
 def _absmax_accumulator(q: QuantizeLayer, C: int, device) -> torch.Tensor:
