@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from qsparse_amd import _hip
-from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
+from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer, _out_dtype
 from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer
 from qsparse_amd.util import _reduction_plan, _staged_mean_hip, get_option, logging, threshold_rank
 from qsparse_amd import distributed as qdist
@@ -62,11 +62,13 @@ class _FusedApply(torch.autograd.Function):
         ctx.has_mask = mask_c is not None
         if not quant_on:
             return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
+        out_dtype = _out_dtype(h)
         if kind == "scaler":
-            y, _ = _hip.quant_fwd("scaler", h, scale, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1)
+            y, _ = _hip.quant_fwd("scaler", h, scale, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1,
+                                  out_dtype=out_dtype)
         else:
             y, _ = _hip.quant_fwd("decimal", h, _hip.decimal_from_scale(scale), -1, torch.float32, chan_mask=mask_c,
-                                  mask_channel_index=1)
+                                  mask_channel_index=1, out_dtype=out_dtype)
         return y
 
     @staticmethod

@@ -42,6 +42,13 @@ def _quotient_dtype(x: torch.Tensor, param) -> torch.dtype:
     return torch.result_type(x, param)
 
 
+def _out_dtype(x: torch.Tensor) -> torch.dtype:
+    """float32 like the reference (type promotion), or the input dtype with the ``preserve_dtype`` extension"""
+    if get_option("preserve_dtype") and x.dtype in (torch.bfloat16, torch.float16):
+        return x.dtype
+    return torch.float32
+
+
 def _gpu_dtype_guard(x: torch.Tensor, qd: torch.dtype):
     if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or qd not in (torch.float32, x.dtype):
         raise _hip.QsparseHipError(
@@ -85,11 +92,11 @@ class ScalerQuantization(_SteFunction):
             if isinstance(scaler, torch.Tensor) and scaler.numel() > 1:
                 assert len(scaler) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
-            y, _ = _hip.quant_fwd("scaler", input, scaler, channel_index, qd)
+            y, _ = _hip.quant_fwd("scaler", input, scaler, channel_index, qd, out_dtype=_out_dtype(input))
             return y
         s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
         codes = torch.round(input / s).int()
-        return codes.float() * s  # no saturation: see module docstring
+        return (codes.float() * s).to(_out_dtype(input))  # no saturation: see module docstring
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -112,11 +119,11 @@ class DecimalQuantization(_SteFunction):
             if isinstance(decimal, torch.Tensor) and decimal.numel() > 1:
                 assert len(decimal) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
-            y, _ = _hip.quant_fwd("decimal", input, decimal, channel_index, qd)
+            y, _ = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input))
             return y
         to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
         to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
-        return (input * to_int).int().float() * to_float
+        return ((input * to_int).int().float() * to_float).to(_out_dtype(input))
 
     @staticmethod
     def backward(ctx, grad_output):

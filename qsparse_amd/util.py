@@ -11,18 +11,23 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 
-_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False}
+_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
-                sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None):
+                sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
+                preserve_dtype: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
     ``graph_safe`` (extension, default False) makes GPU layers feed their running-mean counters to the kernels
-    from device memory so that a training step can be captured into a hipGraph and replayed (see graphs.py)."""
+    from device memory so that a training step can be captured into a hipGraph and replayed (see graphs.py);
+    ``preserve_dtype`` (extension, default False) makes the Scaler/Decimal quantizers return the input's dtype
+    instead of the reference's float32 promotion: the value is the float32 result rounded once, i.e. exactly
+    what a following autocast convolution would consume, at 4 instead of 6 B/elem and without the cast pass."""
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
-                     ("sync_statistics", sync_statistics), ("graph_safe", graph_safe)):
+                     ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
+                     ("preserve_dtype", preserve_dtype)):
         if val is not None:
             _options_[key] = val
 

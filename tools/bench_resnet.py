@@ -63,7 +63,9 @@ def main():
     res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype),
            "plain_graph": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype, graph=True)}
     qs.set_qsparse_options(graph_safe=True)
-    for name, fuse, graph in (("pq_fused", True, False), ("pq_unfused", False, False), ("pq_fused_graph", True, True)):
+    for name, fuse, graph in (("pq_fused", True, False), ("pq_unfused", False, False), ("pq_fused_graph", True, True),
+                              ("pq_fused_graph_preserve_dtype", True, True)):
+        qs.set_qsparse_options(preserve_dtype=name.endswith("preserve_dtype"))
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
         res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph)
