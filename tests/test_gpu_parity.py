@@ -533,3 +533,45 @@ def test_preserve_dtype_extension():
                 assert y.dtype == dtype and same(y.cpu(), qsim.step(ps.step(x, True), True).to(dtype)), step
     finally:
         qs.set_qsparse_options(preserve_dtype=False)
+
+
+def test_row_split_statistics_kernel_all_widths(monkeypatch):
+    """the row-split stage (R = 2/4/8 waves sharing the rows, chunk sums combined in order) must equal ATen's
+    order exactly for every split width, including a ragged channel abs-max riding along."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+        from oracle import qs_oracle as O
+        from qsparse_amd import _hip
+        from qsparse_amd.util import _staged_mean_hip
+        g = torch.Generator().manual_seed(1)
+        for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7)):
+            for dt in (torch.bfloat16, torch.float32):
+                x = (torch.randn(shape, generator=g) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dt)
+                am = torch.zeros(shape[1], device='cuda')
+                out = _staged_mean_hip(x.cuda(), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
+                ref = O.squeeze_mean(x.abs(), (1, shape[1], 1, 1))
+                assert torch.equal(out.cpu(), ref), (shape, dt)
+                assert torch.equal(am.cpu(), x.abs().float().amax(dim=(0, 2, 3))), (shape, dt)
+        print('ok')
+    """)
+    for split in ("0", "2", "4", "8"):
+        env = dict(os.environ, QS_MEAN_SPLIT=split)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "ok" in r.stdout, (split, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reduction_kernels_all_layouts(dtype):
+    """abs-max / min-max: tensor-wise, rows (inner >= 64, sliced over the outer range), columns (inner < 64,
+    vector and scalar variants), ragged sizes, single rows -- all order independent, hence exact."""
+    for shape, ci in (((64, 48, 9, 9), 1), ((200, 8, 16, 16), 1), ((3, 5, 64), 1), ((1000, 16), 1), ((33, 7), 1),
+                      ((16, 2048, 7, 7), 1), ((5, 3, 2, 2), 1), ((4, 6, 10, 10), 2), ((512, 512, 3, 3), 0), ((1, 8, 1, 1), 1),
+                      ((9, 4, 130), 0), ((70000,), -1), ((3, 1, 5), -1)):
+        x = (torch.randn(shape, generator=gen(sum(shape))) * 3).to(dtype)
+        xr = x.float().reshape(1, -1) if ci < 0 else x.float().transpose(0, ci).reshape(shape[ci], -1)
+        assert same(_hip.absmax(x.to(DEV), ci).cpu(), xr.abs().amax(1)), (shape, ci)
+        mn, mx = _hip.minmax(x.to(DEV), ci)
+        assert same(mn.cpu(), xr.amin(1)) and same(mx.cpu(), xr.amax(1)), (shape, ci)
