@@ -198,6 +198,17 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream);
 
+/* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
+
+/* record[0..C) = f32(stage[i]) (0 when stage == NULL), record[C..2C) = absmax[i] (0 when NULL): the per-rank
+ * record of the fused pair's statistics, to be all-gathered by the caller (RCCL / any transport). */
+int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t C, float* record, qs_stream_t stream);
+
+/* gathered = `world` records of 2C floats in rank order.  stage_out[i] = (sum over ranks, in rank order) / world;
+ * absmax_out[i] = max over ranks.  Either output may be NULL. */
+int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
+                     qs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,8 @@ SIGNATURES = {
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
+    "qs_stats_pack": (c_int, [_P, _I, _P, _L, _P, _P]),
+    "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _P]),
 }
 
 _lib = None
@@ -421,3 +423,18 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
                                  _ptr(t_mag_dev), _ptr(t_q_dev), _stream(magnitude))
     _check(st, "qs_pq_select")
+
+
+def stats_pack(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], C: int, device) -> torch.Tensor:
+    rec = torch.empty(2 * C, dtype=torch.float32, device=device)
+    st = load().qs_stats_pack(_ptr(stage), dt(stage) if stage is not None else F32, _ptr(chan_absmax), C, _ptr(rec),
+                              _stream(rec))
+    _check(st, "qs_stats_pack")
+    return rec
+
+
+def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, absmax_out: Optional[torch.Tensor]):
+    stage = torch.empty(C, dtype=torch.float32, device=gathered.device) if want_stage else None
+    st = load().qs_stats_combine(_ptr(gathered), int(world), C, _ptr(stage), _ptr(absmax_out), _stream(gathered))
+    _check(st, "qs_stats_combine")
+    return stage

@@ -940,4 +940,31 @@ __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restri
     }
 }
 
+// =================================================================================================
+// data-parallel statistics exchange: pack (importance, abs-max) into one fp32 record per rank, all-gather,
+// combine in rank order (mean of the importances, max of the abs-max) -- one collective per step
+// =================================================================================================
+template <int SDT>
+__global__ void stats_pack_kernel(const void* stage, const uint32_t* absmax, int64_t C, float* rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        rec[i] = stage ? load1<SDT>(stage, i) : 0.f;
+        rec[C + i] = absmax ? __uint_as_float(absmax[i]) : 0.f;
+    }
+}
+__global__ void stats_combine_kernel(const float* gathered, int world, int64_t C, float* stage_out, uint32_t* absmax_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        float sum = 0.f;
+        uint32_t mx = 0u;
+        for (int r = 0; r < world; ++r) {        // fixed rank order: every rank computes the same bits
+            sum += gathered[(int64_t)r * 2 * C + i];
+            const uint32_t a = __float_as_uint(gathered[(int64_t)r * 2 * C + C + i]);
+            mx = a > mx ? a : mx;
+        }
+        if (stage_out) stage_out[i] = sum / (float)world;
+        if (absmax_out) absmax_out[i] = mx;
+    }
+}
+
 }  // namespace qs

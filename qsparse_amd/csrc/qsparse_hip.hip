@@ -621,4 +621,22 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
     });
 }
 
+int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t C, float* record, qs_stream_t stream) {
+    if (!record || C < 1) return QS_ERR_ARG;
+    if (stage && !dt_ok(sdt)) return QS_ERR_DTYPE;
+    return with_dtype(stage ? sdt : QS_F32, [&](auto S) {
+        constexpr int SD = decltype(S)::value;
+        hipLaunchKernelGGL((stats_pack_kernel<SD>), dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stage,
+                           (const uint32_t*)absmax, C, record);
+        return launch_status();
+    });
+}
+
+int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out, qs_stream_t stream) {
+    if (!gathered || world < 1 || C < 1) return QS_ERR_ARG;
+    hipLaunchKernelGGL(stats_combine_kernel, dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
+                       C, stage_out, (uint32_t*)absmax_out);
+    return launch_status();
+}
+
 }  // extern "C"

@@ -53,17 +53,30 @@ def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
 
 def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor],
                          world: int) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """the two exchanges of the fused prune->quantize step, issued back to back (asynchronously) so that
-    their latencies overlap; both are C-sized (<= 8 KB)."""
-    works = []
-    buf = None
+    """the exchange of the fused prune->quantize step as ONE collective: every rank packs (importance, abs-max)
+    into a 2C-float record, the records are all-gathered and combined in rank order on every rank (mean / max),
+    so all ranks end with bit-identical statistics.  GPU tensors: pack/combine are HIP kernels."""
+    ref = stage if stage is not None else chan_absmax
+    if ref is None or world <= 1:
+        return stage, chan_absmax
+    C = ref.numel()
+    if ref.is_cuda:
+        from qsparse_amd import _hip
+        rec = _hip.stats_pack(stage, chan_absmax, C, ref.device)
+        gathered = torch.empty(world * 2 * C, dtype=torch.float32, device=ref.device)
+        dist.all_gather_into_tensor(gathered, rec)
+        new_stage = _hip.stats_combine(gathered, world, C, stage is not None, chan_absmax)
+        return new_stage, chan_absmax
+    rec = torch.cat([stage.detach().float().view(-1) if stage is not None else torch.zeros(C),
+                     chan_absmax.view(-1) if chan_absmax is not None else torch.zeros(C)])
+    parts = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(parts, rec)
+    g = torch.stack(parts)
     if stage is not None:
-        buf = stage.detach().to(torch.float32).contiguous().clone()
-        works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        acc = torch.zeros(C)
+        for r in range(world):
+            acc = acc + g[r, :C]
+        stage = acc / world
     if chan_absmax is not None:
-        works.append(dist.all_reduce(chan_absmax, op=dist.ReduceOp.MAX, async_op=True))
-    for w in works:
-        w.wait()
-    if buf is not None:
-        stage = buf / world
+        chan_absmax.copy_(g[:, C:].amax(0))
     return stage, chan_absmax
