@@ -103,9 +103,11 @@ int qs_quant_ste_bwd(const void* g, void* gx,
 /* ---- statistics ---------------------------------------------------------------------------------- */
 
 /* max |x| over the tensor (per_channel == 0 -> out[1]) or per channel (out[C]);
- * DecimalQuantizer.optimize, qsparse/quantize.py:329-340.  Order-independent, hence bit-exact. */
+ * DecimalQuantizer.optimize, qsparse/quantize.py:329-340.  Order-independent, hence bit-exact.
+ * accumulate != 0: out is max-accumulated instead of overwritten (the caller keeps it zeroed between steps, e.g.
+ * through qs_scale_update's clear_absmax), which saves the initialisation launch. */
 int qs_absmax(const void* x, float* out, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, qs_stream_t stream);
+              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, qs_stream_t stream);
 
 /* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
  * (min over the batch of per-sample minima == global per-channel minimum). */
@@ -119,9 +121,10 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
  * either by the caller (any stream-ordered increment) or, for qs_pq_select, by its bump_* arguments. */
 
 /* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1)
- * (quantize.py:340,344-348). */
-int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
-                    qs_stream_t stream);
+ * (quantize.py:340,344-348).  clear_absmax != 0 zeroes absmax[i] after use; bump_i32 (nullable) is a one-element
+ * device counter incremented once (QuantizeLayer._n_updates, quantize.py:515). */
+int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
+                    int clear_absmax, int32_t* bump_i32, qs_stream_t stream);
 
 /* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
  * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */

@@ -39,9 +39,9 @@ SIGNATURES = {
     "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
-    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _P]),
+    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
-    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _P]),
+    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _P]),
@@ -271,14 +271,18 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
 # ----------------------------------------------------------------------------------------------
 # statistics
 # ----------------------------------------------------------------------------------------------
-def absmax(x: torch.Tensor, channel_index: int) -> torch.Tensor:
+def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max|x| per channel / over the tensor.  `accumulate_into`: zeroed persistent fp32 buffer that is
+    max-accumulated instead of allocating + initialising a fresh one (one launch instead of two)."""
     lib = load()
     x = dense(x)
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
-    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    out = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x.device)
+    assert out.numel() == n and out.dtype == torch.float32
     with _timed("absmax"):
-        st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
+        st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
+                           int(accumulate_into is not None), _stream(x))
     _check(st, "qs_absmax")
     return out
 
@@ -295,11 +299,14 @@ def minmax(x: torch.Tensor, channel_index: int):
     return mn, mx
 
 
-def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None):
-    """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t`."""
+def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None,
+                 clear_absmax: bool = False, bump: Optional[torch.Tensor] = None):
+    """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t`;
+    `clear_absmax`: zero the statistics buffer after use; `bump`: int32 one-element counter to increment."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
+    assert bump is None or bump.dtype == torch.int32
     st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(bits),
-                                _stream(weight))
+                                int(clear_absmax), _ptr(bump), _stream(weight))
     _check(st, "qs_scale_update")
 
 

@@ -223,8 +223,10 @@ __global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
 // =================================================================================================
 // `t_dev` (nullable): device-resident step counter read instead of the by-value `t`, so that a captured hipGraph
 // replays with the live counter (by-value kernel arguments are frozen at capture time)
-__global__ void scale_update_kernel(const float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
-                                    const int64_t* t_dev) {
+// `clear` != 0 zeroes absmax[i] after use (accumulate-mode abs-max buffers); `bump` (nullable) is a one-element
+// int32 step counter incremented once (the layer's `_n_updates`, quantize.py:515)
+__global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
+                                    const int64_t* t_dev, int clear, int32_t* bump) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t_dev) {
         t = (float)*t_dev;
@@ -233,7 +235,9 @@ __global__ void scale_update_kernel(const float* absmax, float* weight, int64_t 
     if (i < n) {
         const float nw = absmax[i] / denom;                       // max / 2**(bits-1)   (quantize.py:340)
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
+        if (clear) absmax[i] = 0.0f;
     }
+    if (bump && i == 0) *bump += 1;
 }
 __global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t,
                                     const int64_t* t_dev) {
@@ -669,7 +673,7 @@ __global__ void select_init_kernel(SelectState* st, uint32_t k) {
 //                  ranks are a permutation) -- ~n broadcast LDS reads, no atomics;
 //   larger n:      4-pass radix select, bins scanned in parallel (one bin per thread, wave prefix sums).
 constexpr int kSelectThreads = 1024;
-constexpr int kRankMax = 1024;
+constexpr int kRankMax = 2048;
 
 struct SelectShared {
     alignas(16) uint32_t keys[kRankMax];

@@ -278,7 +278,7 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
 
 // ------------------------------------------------------------------------------------------------
 static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
-                       int64_t inner, int xdt, hipStream_t s) {
+                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false) {
     if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
     if (!dt_ok(xdt)) return QS_ERR_DTYPE;
     if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
@@ -287,7 +287,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
     uint32_t* omax = (uint32_t*)(minmax ? out_b : out_a);
     uint32_t* omin = minmax ? (uint32_t*)out_a : nullptr;
     const int ib = (int)((nout + 255) / 256);
-    hipLaunchKernelGGL(keys_init_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    if (!accumulate) hipLaunchKernelGGL(keys_init_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
     if (numel > 0) {
         const bool vec_ptr = aligned16(x);
         int st = with_dtype(xdt, [&](auto X) {
@@ -334,9 +334,9 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
     return launch_status();
 }
 
-int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt,
+int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate,
               qs_stream_t stream) {
-    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
+    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0);
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
@@ -344,12 +344,12 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, in
     return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
 }
 
-int qs_scale_update(const float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
-                    qs_stream_t stream) {
+int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits, int clear_absmax,
+                    int32_t* bump_i32, qs_stream_t stream) {
     if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
     hipLaunchKernelGGL(scale_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, absmax,
-                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev);
+                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, clear_absmax, bump_i32);
     return launch_status();
 }
 

@@ -281,11 +281,21 @@ class DecimalQuantizer(BaseQuantizer):
                     f"reference (shape {tuple(x.shape)}, channelwise={channel_index}); use channelwise=-1 or "
                     "AdaptiveQuantizer")
             if x.is_cuda:
-                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index))
+                # three launches per step: abs-max accumulated into a persistent zeroed buffer, running-mean update
+                # (which also clears that buffer and bumps the layer's step counter), quantization
+                n_stat = wshape[0]
+                bufs = self.__dict__.setdefault("_absmax_bufs", {})
+                buf = bufs.get((n_stat, x.device))
+                if buf is None:
+                    buf = bufs[(n_stat, x.device)] = torch.zeros(n_stat, dtype=torch.float32, device=x.device)
+                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index, accumulate_into=buf))
                 if weight is None:
                     weight = torch.zeros(wshape, device=x.device)
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None
-                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev)   # t == 0 overwrites, else running mean
+                counter = kwargs.get("step_counter")
+                bump = counter.data if (counter is not None and counter.is_cuda and counter.device == x.device) else None
+                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump)
+                self.__dict__["_bumped_step_counter"] = bump is not None
                 self._advance_t(t_dev)
                 return weight
             else:
@@ -434,12 +444,18 @@ class QuantizeLayer(nn.Module):
             return x
         t = self._steps.read(self._n_updates)
         out = x
+        counter_on_device = False
         if t >= self.timeout:
             if self.training:
                 if t == self.timeout and get_option("log_during_train"):
                     logging.warn(f"quantizing {self.name} with {self.bits} bits")
+                extra = {}
+                if x.is_cuda and type(self.callback) in (DecimalQuantizer, ScalerQuantizer):
+                    self.callback.__dict__["_bumped_step_counter"] = False
+                    extra["step_counter"] = self._n_updates   # bumped inside the running-mean kernel
                 new_weight = self.callback.optimize(x, self.bits, self.weight, batched=self.batch_dimension == 0,
-                                                    channel_index=self.channelwise)
+                                                    channel_index=self.channelwise, **extra)
+                counter_on_device = bool(extra) and self.callback.__dict__.get("_bumped_step_counter", False)
                 if new_weight is not None and new_weight is not self.weight:
                     self.weight.data[:] = new_weight
                 self._quantized = True
@@ -447,7 +463,10 @@ class QuantizeLayer(nn.Module):
                 out = self.callback(x, self.bits, self.weight, channel_index=self.channelwise,
                                     inplace=self.batch_dimension == 0)
         if self.training:
-            self._steps.add(self._n_updates, 1)
+            if counter_on_device:
+                self._steps.note_device_add(self._n_updates, 1)
+            else:
+                self._steps.add(self._n_updates, 1)
         return out
 
 
