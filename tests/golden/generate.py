@@ -571,6 +571,56 @@ def f11():
     save("f11_fuse_bn", store, dict(cases=cases))
 
 
+# --------------------------------------------------------------------------------------------
+# F12: public API surface (names, parameter names/defaults/order) -- data about signatures only
+# --------------------------------------------------------------------------------------------
+def f12():
+    import inspect
+    # `qsparse.quantize` / `qsparse.convert` the ATTRIBUTES are functions (the package re-exports them), so the
+    # modules have to be fetched from sys.modules
+    Q, S, U, FU, IM = (sys.modules["qsparse." + m] for m in ("quantize", "sparse", "util", "fuse", "imitation"))
+
+    def sig(obj):
+        target = obj.__init__ if inspect.isclass(obj) else obj
+        out = []
+        for name, prm in inspect.signature(target).parameters.items():
+            if name == "self":
+                continue
+            d = prm.default
+            if d is inspect.Parameter.empty:
+                dflt = "<required>"
+            elif isinstance(d, (int, float, str, bool, type(None))):
+                dflt = repr(d)
+            elif isinstance(d, (list, tuple, set)):
+                dflt = repr(sorted(d) if isinstance(d, set) else list(d))
+            else:
+                dflt = "<" + type(d).__name__ + ">"
+            out.append([name, str(prm.kind), dflt])
+        return out
+
+    api = {}
+    for modname, mod, names in (
+            ("", qsparse, ["convert", "fuse_bn", "quantize", "DecimalQuantizer", "ScalerQuantizer", "AdaptiveQuantizer",
+                           "MagnitudePruningCallback", "UniformPruningCallback", "prune", "devise_layerwise_pruning_schedule",
+                           "auto_name_prune_quantize_layers", "calculate_mask_given_importance", "get_qsparse_option",
+                           "set_qsparse_options"]),
+            ("quantize.", Q, ["quantize_with_decimal", "quantize_with_scaler", "quantize_with_line", "QuantizeLayer",
+                              "BaseQuantizer"]),
+            ("sparse.", S, ["PruneLayer"]),
+            ("util.", U, ["squeeze_tensor_to_shape", "preload_qsparse_state_dict", "nn_module"]),
+            ("imitation.", IM, ["imitate"]),
+            ("fuse.", FU, ["conv2d_bn_fuser", "linear_bn_fuser", "deconv2d_bn_fuser"])):
+        for n in names:
+            api[modname + n] = sig(getattr(mod, n))
+    methods = {}
+    for cls in (Q.DecimalQuantizer, Q.AdaptiveQuantizer, Q.BaseQuantizer, S.MagnitudePruningCallback):
+        for m in ("optimize", "forward", "quantize", "get_weight_shape", "prune_and_update_mask", "receive_input",
+                  "update_magnitude", "initialize"):
+            if hasattr(cls, m):
+                methods[cls.__name__ + "." + m] = sig(getattr(cls, m))
+    save("f12_api_surface", {}, dict(cases=[dict(api=api, methods=methods, version=qsparse.__version__)]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     f1_f2()
@@ -582,3 +632,4 @@ if __name__ == "__main__":
     f8_f9()
     f10()
     f11()
+    f12()
