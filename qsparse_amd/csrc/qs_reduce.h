@@ -388,6 +388,14 @@ __device__ __forceinline__ float inner_sum_lds(const float* v, int W, float* lan
     return threadIdx.x == 0 ? sum_row_sum(W, [&](int64_t i) { return v[i]; }) : 0.f;
 }
 
+// The big statistics pass reads x with NON-TEMPORAL loads: it streams the tensor once in a row-strided pattern
+// and, when it allocates in the Infinity Cache, it is the kernel that has to push out the previous kernel's dirty
+// lines -- which it does badly (0.138 ms in-step vs 0.084 ms alone).  Without allocation the next streaming
+// kernel pays instead and does it better: step 0.554 -> 0.538 ms (apply forward 0.189 -> 0.215 ms, statistics
+// 0.138 -> 0.098 ms).  QS_MEAN_NT_LOADS=false restores cached loads.
+#ifndef QS_MEAN_NT_LOADS
+#define QS_MEAN_NT_LOADS true
+#endif
 // ---- hot stage: outer reduction, 8 adjacent columns per lane, multi-row order ---------------------
 // x: [pre, n, post] contiguous; handles columns [0, vcols) of every `pre` slice (vcols % 8 == 0).
 // Optionally accumulates per-channel max|x| (channel = (col / chan_div) % C) for a fused abs-max.
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                 Raw8<DT> r[ROWS_IN_FLIGHT];
 #pragma unroll
                 for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
-                    r[u] = load8_raw<DT, false>(x, g_base + (i + j + u) * row_groups);
+                    r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, g_base + (i + j + u) * row_groups);
 #pragma unroll
                 for (int u = 0; u < ROWS_IN_FLIGHT; ++u) consume(r[u]);
             }
