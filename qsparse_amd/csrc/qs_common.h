@@ -11,7 +11,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;        // 4 waves of 64 lanes
-constexpr int kElemsPerThread = 8; // one 16-byte load of a 2-byte dtype, two of fp32
 
 // ---- scalar dtype conversions (round-to-nearest-even, as ATen's CPU casts) ---------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
@@ -40,11 +39,6 @@ __device__ __forceinline__ float round_through(float v) {  // value after one ro
     if constexpr (DT == QS_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
     return v;
 }
-
-template <int DT>
-struct ElemBytes {
-    static constexpr int value = (DT == QS_F32) ? 4 : 2;
-};
 
 // ---- scalar element access ---------------------------------------------------------------------
 template <int DT>

@@ -1,6 +1,6 @@
 // Element-wise kernels: quantizer forward (scaler / decimal / line), STE backward, mask apply.
-// All of them are HBM-bound streams: 16-byte loads and stores per lane, several loads in flight per
-// lane, grid-stride over at most kMaxBlocks workgroups.
+// All of them are HBM-bound streams: 16-byte non-temporal loads and stores per lane, one 256-thread workgroup
+// per 2048 elements (exact grids measured faster than capped grid-stride loops on MI355X).
 #pragma once
 #include "qs_common.h"
 

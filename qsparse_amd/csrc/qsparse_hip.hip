@@ -66,7 +66,6 @@ inline int mean_lanes(int64_t total) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 inline int dt_ok(int dt) { return dt == QS_F32 || dt == QS_BF16 || dt == QS_F16; }
-inline int elem_bytes(int dt) { return dt == QS_F32 ? 4 : 2; }
 inline int hip_status(hipError_t e) { return (int)e; }
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -6,7 +6,8 @@ times the three headline kernels of each through the C ABI with HIP events:
     apply fwd  : qs_quant_scaler_fwd  bf16 -> fp32 with channel mask      (6 B/elem)
     apply bwd  : qs_quant_ste_bwd     fp32 -> bf16 with channel mask      (6 B/elem)
     stats      : qs_mean_dim          bf16 read, per-channel absmax fused (2 B/elem)
-on the 256x256x56x56 headline tensor, for several QS_MAX_BLOCKS / QS_MEAN_BLOCK settings.
+on the 256x256x56x56 headline tensor, for a few QS_MEAN_LANES settings (further knobs: QS_MAX_BLOCKS,
+QS_REDUCE_BLOCKS, QS_MEAN_SPLIT, QS_EW_REVERSE).
 """
 import ctypes
 import glob
