@@ -71,13 +71,10 @@ def make_pair(device):
     return fuse_prune_quantize_pairs(pair)
 
 
-def cpu_baseline(batch=32, reps=3, threads=None):
-    """the oracle (a port of the reference's ATen op chain) timed on this host's cores on a bounded
-    sample of the same workload: the same tensor restricted to `batch` samples."""
+def _cpu_steps(batch, reps, threads):
     from oracle import qs_oracle as O
 
-    cores = threads or int(os.environ.get("QS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     shape = (batch,) + SHAPE[1:]
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(shape, generator=g).relu_() * torch.linspace(0.25, 4.0, shape[1]).view(1, -1, 1, 1)).bfloat16()
@@ -92,9 +89,21 @@ def cpu_baseline(batch=32, reps=3, threads=None):
         if i >= 2:
             best = min(best, dt)
     del y, gx
-    return {"value": round(x.numel() / best / 1e9, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
+    return x.numel() / best / 1e9
+
+
+def cpu_baseline(batch=64, reps=8, threads=None):
+    """the oracle (a port of the reference's ATen op chain) timed on this host's cores on a bounded sample of the
+    same workload: the same tensor restricted to `batch` samples (about 10 s of CPU work in total), with the
+    best thread count found on the GPU box's EPYC (32; 8/16/64/128 threads were slower) and with one thread."""
+    cores = threads or int(os.environ.get("QS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+    multi = _cpu_steps(batch, reps, cores)
+    single = _cpu_steps(max(batch // 2, 1), 2, 1)
+    return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "value_1thread": round(single, 4),
             "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on "
-                      f"{batch}x256x56x56 bf16, best of {reps}, torch {torch.__version__} CPU threads={cores}"}
+                      f"{batch}x256x56x56 bf16, best of {reps} ({cores} threads); {max(batch // 2, 1)}x256x56x56, best of 2 "
+                      f"(1 thread); torch {torch.__version__} CPU"}
 
 
 def main():
