@@ -164,8 +164,16 @@ except AttributeError:   # pragma: no cover
 
 
 def _stream(t: torch.Tensor):
+    """hipStream_t to launch on.  Kernels are launched in the CURRENT device context, so the tensor must live on
+    the current device (one process per GPU is the supported topology); anything else fails loudly here instead
+    of faulting on the device."""
+    cur = torch.cuda.current_device()
+    idx = t.device.index if t.device.index is not None else cur
+    if idx != cur:
+        raise QsparseHipError(f"tensor on cuda:{idx} but the current device is cuda:{cur}: call "
+                              "torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)")
     if _raw_stream is not None:
-        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+        return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -17,7 +17,7 @@
 #define QS_EW_NT 1
 #endif
 #ifndef QS_MEAN_ROWS_IN_FLIGHT
-#define QS_MEAN_ROWS_IN_FLIGHT 8
+#define QS_MEAN_ROWS_IN_FLIGHT 16   // 16 KiB per wave outstanding; 8 was 8 % slower once the loads bypass the Infinity Cache, 32 no faster
 #endif
 
 using namespace qs;
