@@ -916,12 +916,15 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
     }
 }
 
-template <int SDT>
-__global__ __launch_bounds__(kSelectThreads) void pq_select_kernel(PqArgs a0, const void* __restrict__ stage) {
+// THREADS = 256 for C <= 256 (4 waves synchronise faster than 16), 1024 otherwise
+template <int SDT, int THREADS>
+__global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const void* __restrict__ stage) {
     const PqArgs a = pq_live_counters(a0);   // every thread reads the counters before thread 0 bumps them (barriers in between)
     __shared__ SelectShared sh;
-    __shared__ uint32_t sh_max[kSelectThreads / 64];
-    if (a.C <= kRankMax) pq_select_small<SDT, 1>(a, stage, sh, sh_max);
+    __shared__ uint32_t sh_max[THREADS / 64];
+    static_assert(THREADS == 256 || kRankMax % THREADS == 0, "items per thread must cover kRankMax");
+    if (THREADS == 256) pq_select_small<SDT, 1>(a, stage, sh, sh_max);                       // host guarantees C <= 256
+    else if (a.C <= kRankMax) pq_select_small<SDT, kRankMax / THREADS>(a, stage, sh, sh_max);
     else pq_select_body<SDT>(a, stage, sh, sh_max);
 }
 

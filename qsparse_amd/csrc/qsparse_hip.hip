@@ -615,7 +615,11 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
     if (!dt_ok(sdt)) return QS_ERR_DTYPE;
     return with_dtype(sdt, [&](auto S) {
         constexpr int SD = decltype(S)::value;
-        hipLaunchKernelGGL((pq_select_kernel<SD>), dim3(1), dim3(kSelectThreads), 0, (hipStream_t)stream, a, stage_mean);
+        if (C <= 256)
+            hipLaunchKernelGGL((pq_select_kernel<SD, 256>), dim3(1), dim3(256), 0, (hipStream_t)stream, a, stage_mean);
+        else
+            hipLaunchKernelGGL((pq_select_kernel<SD, kSelectThreads>), dim3(1), dim3(kSelectThreads), 0,
+                               (hipStream_t)stream, a, stage_mean);
         return launch_status();
     });
 }

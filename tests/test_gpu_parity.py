@@ -575,3 +575,22 @@ def test_reduction_kernels_all_layouts(dtype):
         assert same(_hip.absmax(x.to(DEV), ci).cpu(), xr.abs().amax(1)), (shape, ci)
         mn, mx = _hip.minmax(x.to(DEV), ci)
         assert same(mn.cpu(), xr.amin(1)) and same(mx.cpu(), xr.amax(1)), (shape, ci)
+
+
+@pytest.mark.parametrize("C", [200, 256, 257, 1000, 1024, 1536, 2048, 2049, 4096])
+def test_fused_select_all_channel_counts(C):
+    """the C-sized select step has three code paths (256-thread, rank select up to 2048 channels, radix select
+    beyond): the fused pair must match the oracle for channel counts on both sides of every boundary."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    shape = (4, C, 2, 4)
+    pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.7, dimensions={1}, start=0, interval=1,
+                                                                repetition=1)),
+                         qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train()
+    fuse_prune_quantize_pairs(pair)
+    ps, qsim = O.PruneSim(0.7, [1], 0, 1, 1, False), O.QuantizeSim("scaler", 4, -1, 1)
+    for s in range(4):
+        x = (torch.randn(shape, generator=gen(C + s)) * (torch.rand(C, generator=gen(7 * C + s)) + 0.1).view(1, C, 1, 1)).bfloat16()
+        y = pair(x.to(DEV))
+        assert same(y.cpu(), qsim.step(ps.step(x, True), True)), (C, s)
+        assert same(pair[0][1].mask.cpu(), ps.mask) and same(pair[1].weight.detach().cpu(), qsim.weight), (C, s)
+        assert same(pair[0][1].callback.magnitude.cpu(), ps.magnitude), (C, s)
