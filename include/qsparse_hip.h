@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 2
+#define QS_ABI_VERSION 3
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -63,13 +63,14 @@ size_t qs_workspace_bytes(int op, int64_t n);
  * nparam-independent, length C, one byte per channel) fuses a preceding channel PruneLayer
  * (x * mask, qsparse/sparse.py:116): masked channels are quantised as x*0.  The reference never
  * saturates (its clamp at :110-116 acts on a temporary); saturate != 0 enables q = clamp(q, lo, hi) as
- * an explicit opt-in. */
+ * an explicit opt-in.  pre_relu != 0 quantises max(x, 0): the nn.ReLU that convert() finds in front of the pair
+ * (qsparse/convert.py:214-218) folded into the same pass. */
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
                         const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask,
                         int64_t outer, int64_t C, int64_t inner,
                         int xdt, int ydt, int qdt,
-                        int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
+                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream);
 
 /* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
@@ -77,7 +78,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          const uint8_t* chan_mask,
                          int64_t outer, int64_t C, int64_t inner,
                          int xdt, int ydt, int qdt,
-                         int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
+                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream);
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
@@ -99,6 +100,14 @@ int qs_quant_ste_bwd(const void* g, void* gx,
                      const uint8_t* chan_mask,
                      int64_t outer, int64_t C, int64_t inner,
                      int gdt, int gxdt, qs_stream_t stream);
+
+/* The same backward with the gate of a folded nn.ReLU (threshold_backward: 0 where x <= 0):
+ *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)
+ * x is the ReLU's INPUT (dtype xdt); gx has x's dtype. */
+int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
+                          const float* step, int64_t nstep, float step_host, int step_is_decimal,
+                          float lo_mul, float hi_mul, const uint8_t* chan_mask,
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, qs_stream_t stream);
 
 /* ---- statistics ---------------------------------------------------------------------------------- */
 
@@ -144,6 +153,7 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
  * into the same read of x.  The caller provides it zeroed (qs_pq_select re-zeroes it after use). */
 #define QS_MEAN_ABS 1
 #define QS_MEAN_L0 2
+#define QS_MEAN_RELU 4 /* statistics of max(x, 0): a folded preceding nn.ReLU (abs-max included) */
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream);

@@ -13,7 +13,7 @@ import torch
 
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
-MEAN_ABS, MEAN_L0 = 1, 2
+MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
@@ -35,8 +35,9 @@ SIGNATURES = {
     "qs_version": (c_int, []),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
-    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _P]),
-    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _P]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _P]),
+    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _P]),
@@ -214,8 +215,8 @@ def _f32param(p, device):
 # ----------------------------------------------------------------------------------------------
 def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
               chan_mask: Optional[torch.Tensor] = None, mask_channel_index: Optional[int] = None,
-              want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None):
-    """kind in {'scaler','decimal'}; returns (y, codes|None)."""
+              want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False):
+    """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU)."""
     lib = load()
     x = dense(x)
     pt, n, host = _f32param(param, x.device)
@@ -233,7 +234,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else "")):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, _stream(x))
+                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     return y, codes
 
@@ -273,6 +274,29 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
                                   float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g),
                                   _DT[out_dtype], _stream(g))
     _check(st, "qs_quant_ste_bwd")
+    return gx
+
+
+def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
+                 chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1):
+    """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate."""
+    lib = load()
+    g, x = dense(g), dense(x)
+    assert g.shape == x.shape
+    pt, n, host = _f32param(step, g.device)
+    ci = mask_channel_index if chan_mask is not None else -1
+    outer, C, inner, numel = split3(g.shape, ci)
+    gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if numel == 0:
+        return gx
+    cm = None
+    if chan_mask is not None:
+        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
+        assert cm.numel() == C
+    with _timed("quant_ste_relu_bwd"):
+        st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
+                                       float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x), _stream(g))
+    _check(st, "qs_quant_ste_relu_bwd")
     return gx
 
 

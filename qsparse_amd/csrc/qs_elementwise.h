@@ -32,6 +32,7 @@ struct ScalerFwdOp {
     const uint8_t* cmask;   // device, nullable: fused channel prune
     int saturate;
     int32_t lo, hi;
+    int pre_relu;           // folded preceding nn.ReLU: quantise max(x, 0)
     struct P {
         float s;
         float r;      // RN(1/s)
@@ -66,6 +67,7 @@ struct ScalerFwdOp {
         }
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        if (pre_relu) v = fmaxf(v, 0.0f);
         v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
         int32_t qi = (int32_t)quotient_rint(v, p);   // round(x / s).int(): half-to-even (:109)
         if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
@@ -82,6 +84,7 @@ struct DecimalFwdOp {
     const uint8_t* cmask;
     int saturate;
     int32_t lo, hi;
+    int pre_relu;
     struct P {
         float toi, tof, keep;
     };
@@ -103,6 +106,7 @@ struct DecimalFwdOp {
         return p;
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        if (pre_relu) v = fmaxf(v, 0.0f);
         v = v * p.keep;
         float q = round_through<QDT>(v * p.toi);
         int32_t qi = (int32_t)q;                 // .int(): truncation toward zero (:55)
@@ -272,6 +276,60 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
         float r = op.apply(load1<XDT>(x, e), p, qi);
         store1<YDT>(y, e, r);
         if (codes) codes[e] = qi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STE backward with the folded ReLU's gate: gx = (x <= 0) ? 0 : clamp(g) * mask.  Two streamed inputs (the
+// gradient and the ReLU's input), one output in x's dtype.  Same geometry as ew_kernel, CM_ROW / CM_ELEM only
+// (a channel mask is what makes the fold worthwhile) plus CM_SCALAR for completeness.
+// ------------------------------------------------------------------------------------------------
+template <int GDT, int XDT, int CM, bool NT>
+__global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
+                                                              const void* __restrict__ g, const void* __restrict__ x,
+                                                              void* __restrict__ gx) {
+    const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
+    const int64_t grp = blk * kBlock + threadIdx.x;
+    if (grp < geo.ngroups) {
+        const Raw8<GDT> rg = load8_raw<GDT, NT>(g, grp);
+        const Raw8<XDT> rx = load8_raw<XDT, NT>(x, grp);
+        float vg[8], vx[8];
+        unpack8<GDT>(rg, vg);
+        unpack8<XDT>(rx, vx);
+        int32_t dummy;
+        if constexpr (CM == CM_SCALAR) {
+            const SteBwdOp::P p = op.channel(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+        } else if constexpr (CM == CM_ROW) {
+            const uint32_t c = (uint32_t)((uint64_t)grp / geo.groups_per_row) % geo.C;
+            const SteBwdOp::P p = op.channel_masked(param_per_channel ? c : 0u, c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+        } else {
+            ChanIter it;
+            it.C = geo.C;
+            it.inner = geo.inner;
+            it.seek((uint64_t)grp * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
+                vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+                it.next();
+            }
+        }
+        store8<XDT, NT>(gx, grp, vg);
+    }
+    const int64_t e = geo.ngroups * 8 + threadIdx.x;
+    if (blockIdx.x == 0 && e < geo.numel) {
+        ChanIter it;
+        it.C = geo.C;
+        it.inner = geo.inner;
+        it.seek((uint64_t)e);
+        const SteBwdOp::P p = (CM == CM_SCALAR) ? op.channel(0) : op.channel_masked(param_per_channel ? it.c : 0u, it.c);
+        int32_t dummy;
+        const float r = (load1<XDT>(x, e) <= 0.0f) ? 0.0f : op.apply(load1<GDT>(g, e), p, dummy);
+        store1<XDT>(gx, e, r);
     }
 }
 

@@ -306,6 +306,7 @@ struct Cascade {  // 4-level cascade accumulator for ONE column
 
 template <int DT>
 __device__ __forceinline__ float mean_prep(float v, int flags, int l0) {
+    if (flags & QS_MEAN_RELU) v = fmaxf(v, 0.0f);   // folded preceding nn.ReLU
     if (l0) return (v != 0.0f) ? 1.0f : 0.0f;       // (x != 0).float()  (sparse.py:86)
     return (flags & QS_MEAN_ABS) ? fabsf(v) : v;    // x.abs()           (sparse.py:87)
 }
@@ -404,7 +405,7 @@ __device__ __forceinline__ float inner_sum_lds(const float* v, int W, float* lan
 // the host picks `lanes` such that the number of waves is (close to) a multiple of the 256 CUs -- e.g.
 // 100352 column groups -> 56 lanes x 1792 waves = exactly 7 waves per CU instead of 64 x 1568 (6.1, i.e.
 // 7 on some CUs and 6 on others).
-template <int DT, int ODT, int ROWS_IN_FLIGHT>
+template <int DT, int ODT, int ROWS_IN_FLIGHT, int MODE>
 __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                              int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                              int flags, const int32_t* __restrict__ l0_flag,
@@ -427,16 +428,27 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 
     if (active) {
         Cascade acc[8];
+        // MODE 1 (|x|) and 2 (max(x,0)) are the hot configurations: the mean operand and the abs-max key are the
+        // same non-negative value, 3-5 VALU ops per element (the wave count per CU is low, so VALU time is not
+        // hidden); MODE 0 handles every other flag combination
         auto consume = [&](const Raw8<DT>& r) {
             float v[8];
             unpack8<DT>(r, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (absmax) {
-                    const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
+                if constexpr (MODE == 0) {
+                    if (absmax) {
+                        const float av = (flags & QS_MEAN_RELU) ? fmaxf(v[j], 0.0f) : v[j];
+                        const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
+                        amax = k > amax ? k : amax;
+                    }
+                    acc[j].add(mean_prep<DT>(v[j], flags, l0));
+                } else {
+                    const float w = (MODE == 2) ? fmaxf(v[j], 0.0f) : v[j];
+                    const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
                     amax = k > amax ? k : amax;
+                    acc[j].add(__uint_as_float(k));
                 }
-                acc[j].add(mean_prep<DT>(v[j], flags, l0));
             }
         };
 
@@ -515,7 +527,8 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
     auto track = [&](const float (&v)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t k = __float_as_uint(v[j]) & 0x7fffffffu;
+            const float av = (flags & QS_MEAN_RELU) ? fmaxf(v[j], 0.0f) : v[j];
+            const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             if (j < first_col_next) amax0 = k > amax0 ? k : amax0;
             else amax1 = k > amax1 ? k : amax1;
         }
@@ -596,7 +609,8 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, base + i * post);
         if (absmax) {
-            const uint32_t k = __float_as_uint(v) & 0x7fffffffu;
+            const float av = (flags & QS_MEAN_RELU) ? fmaxf(v, 0.0f) : v;
+            const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }
         return mean_prep<DT>(v, flags, l0);

@@ -178,7 +178,7 @@ size_t qs_workspace_bytes(int op, int64_t n) {
 // ------------------------------------------------------------------------------------------------
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
-                        int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
+                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream) {
     if (!x || !y) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
@@ -194,7 +194,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
-            ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi};
+            ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
             return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
@@ -204,7 +204,8 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
 
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
                          float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
-                         int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
+                         int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, int pre_relu,
+                         qs_stream_t stream) {
     if (!x || !y) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
@@ -220,7 +221,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
-            DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi};
+            DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
             return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
@@ -272,6 +273,47 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
         constexpr int GXD = decltype(GX)::value;
         if (gdt == QS_F32) return launch_ew<SteBwdOp, QS_F32, GXD>(op, plan, ppc, g, gx, nullptr, s);
         return launch_ew<SteBwdOp, GXD, GXD>(op, plan, ppc, g, gx, nullptr, s);
+    });
+}
+
+int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* step, int64_t nstep, float step_host,
+                          int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask, int64_t outer,
+                          int64_t C, int64_t inner, int gdt, int xdt, qs_stream_t stream) {
+    if (!g || !x || !gx) return QS_ERR_ARG;
+    if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
+    if (!aligned16(g) || !aligned16(x) || !aligned16(gx)) return QS_ERR_ALIGN;
+    int st = check_param(step, nstep, C);
+    if (st) return st;
+    const bool ppc = nstep > 1;
+    EwPlan plan;
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    if (st) return st;
+    if (plan.geo.numel == 0) return QS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, 0, chan_mask};
+    const int grid = grid_for(plan.geo.ngroups, 1);
+    constexpr bool NT = QS_EW_NT != 0;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto go = [&](auto G) {
+            constexpr int GD = decltype(G)::value;
+            switch (plan.cm) {
+                case CM_SCALAR:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                       plan.geo, (int)ppc, g, x, gx);
+                    break;
+                case CM_ROW:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                       plan.geo, (int)ppc, g, x, gx);
+                    break;
+                default:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                       plan.geo, (int)ppc, g, x, gx);
+                    break;
+            }
+            return launch_status();
+        };
+        return gdt == QS_F32 ? go(IC<QS_F32>{}) : go(X);
     });
 }
 
@@ -405,9 +447,18 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 const int blocks = (int)((total + lanes - 1) / lanes);
                 const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
                 const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
-                if (R == 1)
-                    hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT>), dim3(blocks), dim3(64), 0, s,
-                                       x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                if (R == 1) {
+                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
+                    if (mode == 1)
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 1>), dim3(blocks), dim3(64), 0,
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                    else if (mode == 2)
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 2>), dim3(blocks), dim3(64), 0,
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                    else
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 0>), dim3(blocks), dim3(64), 0,
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                }
                 else if (R == 2)
                     hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 2>), dim3(blocks), dim3(128), lds, s, x, out, pre, n,
                                        post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);

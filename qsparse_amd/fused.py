@@ -53,40 +53,46 @@ def _absmax_accumulator(q: QuantizeLayer, C: int, device) -> torch.Tensor:
 
 
 class _FusedApply(torch.autograd.Function):
-    """y = Q(x * mask) forward, gx = clamp(g) * mask backward, each one pass over the tensor."""
+    """y = Q(relu?(x) * mask) forward, gx = gate * clamp(g) * mask backward, each one pass over the tensor."""
 
     @staticmethod
-    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on):
+    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False):
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
-        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale)
+        ctx.pre_relu = pre_relu
+        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
+                              h if pre_relu else h.new_empty(0))
         ctx.has_mask = mask_c is not None
         if not quant_on:
             return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
         out_dtype = _out_dtype(h)
         if kind == "scaler":
             y, _ = _hip.quant_fwd("scaler", h, scale, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1,
-                                  out_dtype=out_dtype)
+                                  out_dtype=out_dtype, pre_relu=pre_relu)
         else:
             y, _ = _hip.quant_fwd("decimal", h, _hip.decimal_from_scale(scale), -1, torch.float32, chan_mask=mask_c,
-                                  mask_channel_index=1, out_dtype=out_dtype)
+                                  mask_channel_index=1, out_dtype=out_dtype, pre_relu=pre_relu)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        mask_c, scale = ctx.saved_tensors
+        mask_c, scale, x = ctx.saved_tensors
         mask_c = mask_c if ctx.has_mask else None
         if not ctx.quant_on:
-            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 6
+            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 7
         limit = 2.0 ** (ctx.bits - 1)
         step = scale if ctx.kind == "scaler" else _hip.decimal_from_scale(scale)
+        if ctx.pre_relu:
+            gx = _hip.ste_relu_bwd(g, x, step, ctx.kind == "decimal", -limit + ctx.notch, limit - 1 + ctx.notch, mask_c)
+            return (gx,) + (None,) * 7
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
                           out_dtype, chan_mask=mask_c, mask_channel_index=1)
-        return (gx,) + (None,) * 6
+        return (gx,) + (None,) * 7
 
 
-def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> torch.Tensor:
-    """one training / evaluation step of ``q(p(h))`` on a GPU tensor."""
+def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
+    """one training / evaluation step of ``q(p(h))`` on a GPU tensor -- or of ``q(p(relu(h)))`` with ``pre_relu``
+    (the caller guarantees that the quantizer is active this step, so the ReLU is applied inside the kernels)."""
     cb, qc = p.callback, q.callback
     C = h.shape[1]
 
@@ -140,7 +146,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
         world = qdist.stats_world_size()
         if update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
-            am = qdist.allreduce_max_(_hip.absmax(hd, -1), world)
+            am = qdist.allreduce_max_(_hip.absmax(torch.relu(hd) if pre_relu else hd, -1), world)
             _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits,
                               t_dev=qc.device_t(h.device) if get_option("graph_safe") else None)
         else:
@@ -157,9 +163,10 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
                 if update_scale:
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 dims = _reduction_plan(hd.shape, p.mask.shape)
-                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax, absmax_channel_dim=1).view(-1)
+                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax, absmax_channel_dim=1,
+                                         pre_relu=pre_relu).view(-1)
             elif update_scale:
-                chan_absmax = _hip.absmax(hd, 1)
+                chan_absmax = _hip.absmax(torch.relu(hd) if pre_relu else hd, 1)
             if world > 1:
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
@@ -199,10 +206,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> to
 
     # ---- apply: one read of h, one write ----
     if not prune_on and not quant_on:
-        return h
+        return torch.relu(h) if pre_relu else h
+    if pre_relu and not quant_on:      # cannot happen when the caller checked q.is_active(); stay correct anyway
+        h, pre_relu = torch.relu(h), False
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
-    return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0,
-                             quant_on)
+    return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
+                             1 if qc.flip_axis else 0, quant_on, pre_relu)
 
 
 class FusedPruneQuantize(nn.Sequential):
@@ -212,6 +221,12 @@ class FusedPruneQuantize(nn.Sequential):
     def forward(self, x):
         inner, q = self[0], self[1]
         act, p = inner[0], inner[1]
+        # a plain, out-of-place nn.ReLU in front of an active quantizer is folded into the kernels: relu(x) is
+        # never materialised (statistics, apply and backward read x itself); the gate of its backward rides in
+        # the fused backward kernel
+        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and q.is_active()
+                and isinstance(x, torch.Tensor) and _eligible(p, q, x)):
+            return fused_prune_quantize(p, q, x, pre_relu=True)
         h = act(x)
         if _eligible(p, q, h):
             return fused_prune_quantize(p, q, h)

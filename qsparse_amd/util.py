@@ -11,12 +11,12 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 
-_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False}
+_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
-                preserve_dtype: Optional[bool] = None):
+                preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
@@ -24,10 +24,12 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     from device memory so that a training step can be captured into a hipGraph and replayed (see graphs.py);
     ``preserve_dtype`` (extension, default False) makes the Scaler/Decimal quantizers return the input's dtype
     instead of the reference's float32 promotion: the value is the float32 result rounded once, i.e. exactly
-    what a following autocast convolution would consume, at 4 instead of 6 B/elem and without the cast pass."""
+    what a following autocast convolution would consume, at 4 instead of 6 B/elem and without the cast pass;
+    ``fold_relu`` (default True, bit-identical) lets a convert-built ``ReLU -> prune -> quantize`` site apply the
+    ReLU inside the fused kernels instead of materialising its output."""
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
-                     ("preserve_dtype", preserve_dtype)):
+                     ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu)):
         if val is not None:
             _options_[key] = val
 
@@ -70,7 +72,7 @@ def _reduction_plan(xshape: Sequence[int], shape: Sequence[int]) -> List[int]:
 
 
 def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=None, absmax_out=None,
-                     absmax_channel_dim: Optional[int] = None) -> torch.Tensor:
+                     absmax_channel_dim: Optional[int] = None, pre_relu: bool = False) -> torch.Tensor:
     """successive keepdim means on the GPU, one ``qs_mean_dim`` launch per reduced dim."""
     cur = _hip.dense(x)
     shape = list(cur.shape)
@@ -98,6 +100,8 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         if first:
             if take_abs:
                 flags |= _hip.MEAN_ABS
+            if pre_relu:
+                flags |= _hip.MEAN_RELU
             if l0_flag is not None:
                 flags |= _hip.MEAN_L0
                 kw["l0_flag"] = l0_flag

@@ -40,7 +40,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 2
+    assert lib.qs_version() == 3
     assert torch.cuda.is_available()
 
 
@@ -285,9 +285,9 @@ def test_abi_rejects_bad_arguments_loudly():
         quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
     lib = _hip.load()
     y = torch.empty(64, device=DEV)
-    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, None)
+    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, None)
     assert st == -3 and b"aligned" in lib.qs_status_string(st)
-    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, None) == -1
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, None) == -1
     # odd storage offsets are re-packed by the binding instead of failing
     base = torch.randn(1001, device=DEV)
     assert same(quantize_with_scaler(base[1:], 8, 0.1).cpu(), O.scaler_fwd(base[1:].cpu(), 8, 0.1))
@@ -427,7 +427,7 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
-                                       1, 0, 0, 0, 0, 0, stream) == 0
+                                       1, 0, 0, 0, 0, 0, 0, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
                                     N, C, H * W, 0, 1, stream) == 0
 
@@ -594,3 +594,43 @@ def test_fused_select_all_channel_counts(C):
         assert same(y.cpu(), qsim.step(ps.step(x, True), True)), (C, s)
         assert same(pair[0][1].mask.cpu(), ps.mask) and same(pair[1].weight.detach().cpu(), qsim.weight), (C, s)
         assert same(pair[0][1].callback.magnitude.cpu(), ps.magnitude), (C, s)
+
+
+def test_relu_fold_is_bit_identical_to_materialised_relu():
+    """convert() finds ReLU -> prune -> quantize; with the fold the ReLU is applied inside the kernels.  Outputs,
+    input gradients (incl. the threshold_backward gate and signed zeros) and all state must equal the unfolded
+    run and the oracle, for the pruning-only phase, the active phase and evaluation."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (6, 24, 4, 8))):
+        runs = []
+        for fold in (True, False):
+            qs.set_qsparse_options(fold_relu=fold)
+            pair = nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
+                                                                    repetition=2)),
+                                 qs.quantize(bits=4, channelwise=-1, timeout=2)).to(DEV).train()
+            fuse_prune_quantize_pairs(pair)
+            ps, qsim = O.PruneSim(0.5, [1], 1, 1, 2, False), O.QuantizeSim("scaler", 4, -1, 2)
+            outs = []
+            for s in range(7):
+                training = s < 6
+                if not training:
+                    pair.eval()
+                x = (torch.randn(shape, generator=gen(1000 + s)) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dtype)
+                x.view(-1)[:4] = torch.tensor([0.0, -1e-3, 1.0, -1.0]).to(dtype)   # (torch's own CPU and GPU ReLU disagree on relu(-0.0))
+                gout = torch.randn(shape, generator=gen(1100 + s))
+                xg = x.to(DEV).requires_grad_(True)
+                y = pair(xg)
+                y.backward(gout.to(DEV).to(y.dtype))
+                n_before = ps.n_updates
+                h = torch.relu(x)
+                y_ref = qsim.step(ps.step(h, training), training)
+                gh = ps.grad(qsim.grad(gout.to(y_ref.dtype), dtype), (not training) or n_before >= 1)
+                gx_ref = torch.where(x <= 0, torch.zeros_like(gh), gh)
+                assert same(y.detach().cpu(), y_ref), (dtype, fold, s)
+                assert same(xg.grad.cpu(), gx_ref), (dtype, fold, s)
+                assert same(pair[0][1].mask.cpu(), ps.mask) and same(pair[1].weight.detach().cpu(), qsim.weight)
+                outs.append((y.detach().clone(), xg.grad.clone()))
+            runs.append(outs)
+        for (ya, ga), (yb, gb) in zip(*runs):
+            assert torch.equal(ya, yb) and same(ga.cpu(), gb.cpu())
+    qs.set_qsparse_options(fold_relu=True)
