@@ -61,6 +61,7 @@ struct ScalerFwdOp {
         } else {
             const float t = v * p.r;
             const float n = rintf(t);
+
             const float off = fabsf(fabsf(t - n) - 0.5f);      // distance of t from the nearest k + 0.5
             if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return n;   // 2^-21
             return rintf(v / p.s);
@@ -276,6 +277,66 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
         float r = op.apply(load1<XDT>(x, e), p, qi);
         store1<YDT>(y, e, r);
         if (codes) codes[e] = qi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Widening variant (2-byte input -> fp32 output): every store instruction of a wave covers ONE contiguous
+// 1 KiB span (lane l writes 16 B at l*16), instead of 16 B at a 32-B stride; paid for with 8-byte loads.
+// A wave owns 512 consecutive elements: lane l handles elements [4l, 4l+4) and [256+4l, 256+4l+4).
+// Measured on the headline tensor: 0.2165 -> 0.2025 ms (5.7 -> 6.1 TB/s).  The mirror image for the narrowing
+// backward (contiguous 1 KiB loads, 8-byte stores) changed nothing (0.2045 vs 0.2042 ms) and was dropped:
+// it is the stores whose per-instruction footprint matters.
+// ------------------------------------------------------------------------------------------------
+template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT>
+__global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, const void* __restrict__ x,
+                                                           float* __restrict__ y) {
+    static_assert(XDT != QS_F32, "widening variant is for 2-byte inputs");
+    const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e_wave = (blk * (kBlock / 64) + wave) * 512;          // first element of this wave
+    typename Op::P p_scalar = op.channel(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int64_t e = e_wave + half * 256 + lane * 4;
+        if (e + 4 <= geo.ngroups * 8) {
+            const u32x2 raw = NT ? __builtin_nontemporal_load((const u32x2*)((const uint16_t*)x + e))
+                                 : *(const u32x2*)((const uint16_t*)x + e);
+            float v[4];
+            if constexpr (XDT == QS_BF16) {
+                v[0] = __uint_as_float(raw[0] << 16);
+                v[1] = __uint_as_float(raw[0] & 0xffff0000u);
+                v[2] = __uint_as_float(raw[1] << 16);
+                v[3] = __uint_as_float(raw[1] & 0xffff0000u);
+            } else {
+                v[0] = f16_bits_to_f32(raw[0] & 0xffffu);
+                v[1] = f16_bits_to_f32(raw[0] >> 16);
+                v[2] = f16_bits_to_f32(raw[1] & 0xffffu);
+                v[3] = f16_bits_to_f32(raw[1] >> 16);
+            }
+            typename Op::P p = p_scalar;
+            if constexpr (CM == CM_ROW) {
+                const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 8 == 0: 4 elements share a row
+                p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+            }
+            int32_t q;
+            u32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(op.apply(v[j], p, q));
+            st16<NT>((u32x4*)(y + e), out);
+        }
+    }
+    // ragged tail (numel % 8 elements)
+    const int64_t tail0 = geo.ngroups * 8;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < geo.numel) {
+        const int64_t e = tail0 + threadIdx.x;
+        ChanIter it;
+        it.C = geo.C;
+        it.inner = geo.inner;
+        it.seek((uint64_t)e);
+        typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
+        int32_t qi;
+        y[e] = op.apply(load1<XDT>(x, e), p, qi);
     }
 }
 

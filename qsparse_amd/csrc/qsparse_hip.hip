@@ -110,12 +110,33 @@ int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* p
     return QS_OK;
 }
 
+inline int ew_widen() {
+    static int v = env_int("QS_EW_WIDEN", 1);
+    return v;
+}
+
 template <typename Op, int XDT, int YDT>
 int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
               hipStream_t s) {
     if (plan.geo.numel == 0) return QS_OK;
     constexpr bool NT = QS_EW_NT != 0;
     constexpr int U = QS_EW_UNROLL;
+    if constexpr (XDT != QS_F32 && YDT == QS_F32) {
+        if (ew_widen() && !codes && plan.cm != CM_ELEM) {
+            const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
+            const int gridw = (int)((waves + kBlock / 64 - 1) / (kBlock / 64));
+            if (plan.cm == CM_SCALAR)
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, (float*)y);
+            else if (param_per_channel)
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, (float*)y);
+            else
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, (float*)y);
+            return launch_status();
+        }
+    }
     const int grid = grid_for(plan.geo.ngroups, U);
     switch (plan.cm) {
         case CM_SCALAR:
