@@ -109,7 +109,7 @@ def cpu_baseline(batch=64, reps=8, threads=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS",
@@ -151,7 +151,11 @@ def main():
         (gx,) = torch.autograd.grad(y, x, gout)
         return gx
 
-    for _ in range(max(args.warmup, 3)):   # >= 3 so that mask refresh and running scale are live
+    # setup: bring the operators to their steady state (schedule finished, mask refresh and running scale live,
+    # allocator pools and clocks settled); not part of the W warm-up steps or the K timed steps
+    for _ in range(20):
+        step()
+    for _ in range(args.warmup):
         step()
 
     def fence():
@@ -160,14 +164,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events bracket the dominant kernel (apply forward) on every timed step; the other kernels are
-    # bracketed on every 8th step only, because each event pair costs a few microseconds of stream time
-    dom = ("quant_scaler_fwd+mask",)
+    # HIP events (torch.cuda.Event on the stream the kernels are launched on) bracket single launches inside the
+    # timed region: the two apply kernels on every 4th step, every kernel on every 16th.  Each event pair costs
+    # ~5 us of stream time, so bracketing every launch of every step would inflate the step by ~5 %.
+    dom = ("quant_scaler_fwd+mask", "quant_ste_bwd+mask")
     fence()
     events = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
-        _hip.start_event_log(only=None if i % 8 == 7 else dom)
+        if i % 16 == 15:
+            _hip.start_event_log(only=None)
+        elif i % 4 == 3:
+            _hip.start_event_log(only=dom)
         step()
         for kname, pairs in _hip.take_event_pairs().items():
             events.setdefault(kname, []).extend(pairs)
