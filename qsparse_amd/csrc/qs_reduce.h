@@ -237,7 +237,7 @@ __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, flo
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
         if (clear) absmax[i] = 0.0f;
     }
-    if (bump && i == 0) *bump += 1;
+    if (bump && i == 0) atomicAdd(bump, 1);
 }
 __global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t,
                                     const int64_t* t_dev) {
@@ -853,10 +853,11 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
         }
     }
     if (tid == 0) {   // step counters of the two layers / the callback (state_dict tensors)
-        if (a.bump_a) *a.bump_a += 1;
-        if (a.bump_b) *a.bump_b += 1;
-        if (a.bump_c) *a.bump_c += 1;
-        if (a.bump_d) *a.bump_d += 1;
+        // fire-and-forget atomics: a plain `*p += 1` is a dependent load -> store round trip per counter
+        if (a.bump_a) atomicAdd(a.bump_a, 1);
+        if (a.bump_b) atomicAdd(a.bump_b, 1);
+        if (a.bump_c) atomicAdd((unsigned long long*)a.bump_c, 1ull);
+        if (a.bump_d) atomicAdd((unsigned long long*)a.bump_d, 1ull);
     }
 }
 
@@ -923,10 +924,11 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
         }
     }
     if (tid == 0) {
-        if (a.bump_a) *a.bump_a += 1;
-        if (a.bump_b) *a.bump_b += 1;
-        if (a.bump_c) *a.bump_c += 1;
-        if (a.bump_d) *a.bump_d += 1;
+        // fire-and-forget atomics: a plain `*p += 1` is a dependent load -> store round trip per counter
+        if (a.bump_a) atomicAdd(a.bump_a, 1);
+        if (a.bump_b) atomicAdd(a.bump_b, 1);
+        if (a.bump_c) atomicAdd((unsigned long long*)a.bump_c, 1ull);
+        if (a.bump_d) atomicAdd((unsigned long long*)a.bump_d, 1ull);
     }
 }
 
