@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 3
+#define QS_ABI_VERSION 4
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -148,15 +148,20 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
  * 4-way interleave), one fp32 division by n, one rounding to odt.
  * flags: QS_MEAN_ABS takes |x| first (sparse.py:87);  QS_MEAN_L0 maps x -> (x != 0) when *l0_flag != 0
  * (sparse.py:85-86; l0_flag is a device int written by qs_l0_flag).
- * absmax_out (nullable, device float[C]) is additionally max-ACCUMULATED with per-channel max|x|, where
- * channel = (column / chan_div) % C  -- the statistics of a following tensor-wise QuantizeLayer fused
- * into the same read of x.  The caller provides it zeroed (qs_pq_select re-zeroes it after use). */
+ * absmax_out (nullable, device float[C * absmax_stride]) is additionally max-ACCUMULATED with per-channel
+ * max|x| at absmax_out[channel * absmax_stride], where channel = (column / chan_div) % C  -- the statistics of
+ * a following tensor-wise QuantizeLayer fused into the same read of x.  The caller provides it zeroed
+ * (qs_pq_select re-zeroes it after use).  The accumulation is one device atomic per wave and channel, and
+ * MI355X serialises atomics that fall into the same 128-byte line (~10 ns each, exposed at the end of a short
+ * kernel): absmax_stride = QS_AMAX_LINE_STRIDE gives every channel its own line (measured, batch-64 ResNet
+ * activations: 33.9 -> 10.3 us on 256x14x14 maps, 87.9 -> 18.4 us on 128 x 64x32x32); 1 is a dense float[C]. */
+#define QS_AMAX_LINE_STRIDE 32
 #define QS_MEAN_ABS 1
 #define QS_MEAN_L0 2
 #define QS_MEAN_RELU 4 /* statistics of max(x, 0): a folded preceding nn.ReLU (abs-max included) */
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
-                float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream);
+                float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C, qs_stream_t stream);
 
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].
@@ -200,27 +205,29 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340)
  *   scale      <- t_q == 0 ? new : (t_q*scale + new)/(t_q+1), new = absmax_all/2^(bits-1)  if update_scale
  * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536.
- * chan_absmax is zeroed after use when update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64_a / bump_i64_b
+ * chan_absmax[c * chan_absmax_stride] (stride as for qs_mean_dim's absmax_out, >= 1) is zeroed after use when
+ * update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64_a / bump_i64_b
  * (each nullable) are one-element device counters incremented by one at the end: the layers' `_n_updates`,
  * the pruning callback's `t` and the quantizer's device-side `t` (sparse.py:117,272; quantize.py:348,515), so
  * that a step needs no separate counter kernels.  t_mag_dev / t_q_dev: see "Step counters" above. */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
-                 float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
+                 float* chan_absmax, int64_t chan_absmax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                  int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream);
 
 /* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
 
-/* record[0..C) = f32(stage[i]) (0 when stage == NULL), record[C..2C) = absmax[i] (0 when NULL): the per-rank
- * record of the fused pair's statistics, to be all-gathered by the caller (RCCL / any transport). */
-int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t C, float* record, qs_stream_t stream);
+/* record[0..C) = f32(stage[i]) (0 when stage == NULL), record[C..2C) = absmax[i * absmax_stride] (0 when NULL):
+ * the per-rank record of the fused pair's statistics, to be all-gathered by the caller (RCCL / any transport). */
+int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t absmax_stride, int64_t C, float* record,
+                  qs_stream_t stream);
 
 /* gathered = `world` records of 2C floats in rank order.  stage_out[i] = (sum over ranks, in rank order) / world;
- * absmax_out[i] = max over ranks.  Either output may be NULL. */
+ * absmax_out[i * absmax_stride] = max over ranks.  Either output may be NULL. */
 int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
-                     qs_stream_t stream);
+                     int64_t absmax_stride, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

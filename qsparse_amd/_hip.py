@@ -45,16 +45,16 @@ SIGNATURES = {
     "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
-    "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _P]),
+    "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _L, _P]),
     "qs_l0_flag": (c_int, [_P, _L, _I, _P, _P, _P]),
     "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P, _P]),
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
-    "qs_stats_pack": (c_int, [_P, _I, _P, _L, _P, _P]),
-    "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _P]),
+    "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
+    "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
 
 _lib = None
@@ -357,6 +357,28 @@ def decimal_from_scale(scale: torch.Tensor) -> torch.Tensor:
     return d
 
 
+AMAX_LINE_STRIDE = 32   # QS_AMAX_LINE_STRIDE: floats per 128-byte line
+
+
+def amax_accumulator(C: int, device) -> torch.Tensor:
+    """zeroed per-channel abs-max accumulator with one 128-byte line per channel ([C, 32]; channel c lives in
+    [c, 0]): atomics into one line serialise on MI355X, see qs_mean_dim in the header."""
+    return torch.zeros(C, AMAX_LINE_STRIDE, dtype=torch.float32, device=device)
+
+
+def amax_stride(t: Optional[torch.Tensor]) -> int:
+    """element stride between channels of an abs-max tensor: [C] (dense) or [C, stride] (padded)."""
+    if t is None or t.dim() < 2:
+        return 1
+    assert t.is_contiguous()
+    return t.shape[1]
+
+
+def amax_values(t: torch.Tensor) -> torch.Tensor:
+    """the [C] view of a dense or padded abs-max tensor."""
+    return t[:, 0] if t.dim() == 2 else t.view(-1)
+
+
 def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtype, flags: int = 0,
              l0_flag: Optional[torch.Tensor] = None, absmax_out: Optional[torch.Tensor] = None, chan_div: int = 1,
              C: int = 1) -> torch.Tensor:
@@ -365,7 +387,7 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     out = torch.empty(pre * post, dtype=out_dtype, device=x.device)
     with _timed("mean_dim" + ("+absmax" if absmax_out is not None else "")):
         st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
-                                _ptr(absmax_out), int(chan_div), int(C), _stream(x))
+                                _ptr(absmax_out), amax_stride(absmax_out), int(chan_div), int(C), _stream(x))
     _check(st, "qs_mean_dim")
     return out
 
@@ -458,7 +480,8 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
         assert b64 is None or b64.dtype == torch.int64
     with _timed("pq_select"):
         st = load().qs_pq_select(_ptr(magnitude), _ptr(stage_mean), sdt, C, int(update_magnitude), int(t_mag),
-                                 int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), int(update_scale), int(t_q),
+                                 int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), amax_stride(chan_absmax),
+                                 int(update_scale), int(t_q),
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
                                  _ptr(t_mag_dev), _ptr(t_q_dev), _stream(magnitude))
     _check(st, "qs_pq_select")
@@ -466,14 +489,15 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
 
 def stats_pack(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], C: int, device) -> torch.Tensor:
     rec = torch.empty(2 * C, dtype=torch.float32, device=device)
-    st = load().qs_stats_pack(_ptr(stage), dt(stage) if stage is not None else F32, _ptr(chan_absmax), C, _ptr(rec),
-                              _stream(rec))
+    st = load().qs_stats_pack(_ptr(stage), dt(stage) if stage is not None else F32, _ptr(chan_absmax),
+                              amax_stride(chan_absmax), C, _ptr(rec), _stream(rec))
     _check(st, "qs_stats_pack")
     return rec
 
 
 def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, absmax_out: Optional[torch.Tensor]):
     stage = torch.empty(C, dtype=torch.float32, device=gathered.device) if want_stage else None
-    st = load().qs_stats_combine(_ptr(gathered), int(world), C, _ptr(stage), _ptr(absmax_out), _stream(gathered))
+    st = load().qs_stats_combine(_ptr(gathered), int(world), C, _ptr(stage), _ptr(absmax_out),
+                                 amax_stride(absmax_out), _stream(gathered))
     _check(st, "qs_stats_combine")
     return stage

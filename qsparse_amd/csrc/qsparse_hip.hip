@@ -111,7 +111,7 @@ int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* p
 }
 
 inline int ew_widen() {
-    static int v = env_int("QS_EW_WIDEN", 1);
+    static int v = env_int("QS_EW_WIDEN", 2);
     return v;
 }
 
@@ -121,8 +121,8 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
     if (plan.geo.numel == 0) return QS_OK;
     constexpr bool NT = QS_EW_NT != 0;
     constexpr int U = QS_EW_UNROLL;
-    if constexpr (XDT != QS_F32 && YDT == QS_F32) {
-        if (ew_widen() && !codes && plan.cm != CM_ELEM) {
+    if constexpr (YDT == QS_F32) {   // QS_EW_WIDEN: 0 off, 1 two-byte inputs only, 2 (default) fp32 inputs as well
+        if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && plan.cm != CM_ELEM) {
             const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
             const int gridw = (int)((waves + kBlock / 64 - 1) / (kBlock / 64));
             if (plan.cm == CM_SCALAR)
@@ -433,11 +433,13 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
 }
 
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
-                const int32_t* l0_flag, float* absmax_out, int64_t chan_div, int64_t C, qs_stream_t stream) {
+                const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
+                qs_stream_t stream) {
     if (!x || !out || pre < 1 || n < 1 || post < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
     if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
-    if (absmax_out && (chan_div < 1 || C < 1)) return QS_ERR_ARG;
+    if (absmax_out && (chan_div < 1 || C < 1 || absmax_stride < 1)) return QS_ERR_ARG;
+    const int64_t as = absmax_out ? absmax_stride : 1;
     hipStream_t s = (hipStream_t)stream;
     int64_t vcols = 0;
     const bool ragged_absmax = absmax_out && (chan_div % 8 != 0);
@@ -452,7 +454,7 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
         const int64_t waves = (pre * (vcols / 8) + 63) / 64;
         const int want = env_int("QS_MEAN_SPLIT", 0);
         if (want > 0) R = want;
-        else if (waves < 1024 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = waves >= 512 ? 2 : (waves >= 256 ? 4 : 8);
+        else if (waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
         while (R > 1 && R > nchunks) R >>= 1;
         if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
         if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
@@ -472,28 +474,28 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                     const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
                     if (mode == 1)
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 1>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
                     else if (mode == 2)
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 2>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
                     else
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 0>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div, Cc, lanes);
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
                 }
                 else if (R == 2)
                     hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 2>), dim3(blocks), dim3(128), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
                 else if (R == 4)
                     hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 4>), dim3(blocks), dim3(256), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
                 else
                     hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 8>), dim3(blocks), dim3(512), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
             }
             if (vcols < post) {
                 const int64_t total = pre * (post - vcols);
                 hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
-                                   0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, chan_div > 0 ? chan_div : 1,
+                                   0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1,
                                    (uint32_t)(C > 0 ? C : 1));
             }
             return launch_status();
@@ -645,13 +647,13 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 
 // ------------------------------------------------------------------------------------------------
 static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude, int64_t t_mag, int refresh_mask,
-                   int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits, float* scale,
+                   int64_t k, uint8_t* mask, float* chan_absmax, int64_t amax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                    int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                    const int64_t* t_mag_dev, const int64_t* t_q_dev) {
     if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
     if (update_magnitude && t_mag < 0) return QS_ERR_ARG;
     if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
-    if (update_scale && (!chan_absmax || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
+    if (update_scale && (!chan_absmax || amax_stride < 1 || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
     a->magnitude = magnitude;
     a->C = C;
     a->update_magnitude = update_magnitude;
@@ -661,6 +663,7 @@ static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude,
     a->k = (uint32_t)k;
     a->mask = mask;
     a->chan_absmax = (uint32_t*)chan_absmax;
+    a->amax_stride = amax_stride;
     a->update_scale = update_scale;
     a->t_q = (float)t_q;
     a->t_q1 = (float)(t_q + 1);
@@ -672,15 +675,18 @@ static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude,
     a->bump_d = bump_i64_b;
     a->t_mag_dev = t_mag_dev;
     a->t_q_dev = t_q_dev;
+    static const int rank_small = env_int("QS_RANK_SMALL", kRankSmall);
+    a->rank_small = rank_small;
     return QS_OK;
 }
 
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
-                 int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int update_scale, int64_t t_q, int bits,
+                 int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int64_t chan_absmax_stride, int update_scale,
+                 int64_t t_q, int bits,
                  float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream) {
     PqArgs a;
-    int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, update_scale, t_q, bits,
+    int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, chan_absmax_stride, update_scale, t_q, bits,
                      scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev);
     if (st) return st;
     if (update_magnitude && !stage_mean) return QS_ERR_ARG;
@@ -696,21 +702,23 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
     });
 }
 
-int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t C, float* record, qs_stream_t stream) {
+int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t absmax_stride, int64_t C, float* record,
+                  qs_stream_t stream) {
     if (!record || C < 1) return QS_ERR_ARG;
     if (stage && !dt_ok(sdt)) return QS_ERR_DTYPE;
     return with_dtype(stage ? sdt : QS_F32, [&](auto S) {
         constexpr int SD = decltype(S)::value;
         hipLaunchKernelGGL((stats_pack_kernel<SD>), dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stage,
-                           (const uint32_t*)absmax, C, record);
+                           (const uint32_t*)absmax, absmax_stride > 0 ? absmax_stride : 1, C, record);
         return launch_status();
     });
 }
 
-int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out, qs_stream_t stream) {
+int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
+                     int64_t absmax_stride, qs_stream_t stream) {
     if (!gathered || world < 1 || C < 1) return QS_ERR_ARG;
     hipLaunchKernelGGL(stats_combine_kernel, dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
-                       C, stage_out, (uint32_t*)absmax_out);
+                       C, stage_out, (uint32_t*)absmax_out, absmax_stride > 0 ? absmax_stride : 1);
     return launch_status();
 }
 

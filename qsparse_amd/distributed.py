@@ -59,7 +59,7 @@ def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[to
     ref = stage if stage is not None else chan_absmax
     if ref is None or world <= 1:
         return stage, chan_absmax
-    C = ref.numel()
+    C = stage.numel() if stage is not None else chan_absmax.shape[0]   # chan_absmax: [C] or line-padded [C, 32]
     if ref.is_cuda:
         from qsparse_amd import _hip
         rec = _hip.stats_pack(stage, chan_absmax, C, ref.device)
@@ -67,8 +67,9 @@ def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[to
         dist.all_gather_into_tensor(gathered, rec)
         new_stage = _hip.stats_combine(gathered, world, C, stage is not None, chan_absmax)
         return new_stage, chan_absmax
+    from qsparse_amd._hip import amax_values
     rec = torch.cat([stage.detach().float().view(-1) if stage is not None else torch.zeros(C),
-                     chan_absmax.view(-1) if chan_absmax is not None else torch.zeros(C)])
+                     amax_values(chan_absmax) if chan_absmax is not None else torch.zeros(C)])
     parts = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(parts, rec)
     g = torch.stack(parts)
@@ -78,5 +79,5 @@ def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[to
             acc = acc + g[r, :C]
         stage = acc / world
     if chan_absmax is not None:
-        chan_absmax.copy_(g[:, C:].amax(0))
+        amax_values(chan_absmax).copy_(g[:, C:].amax(0))
     return stage, chan_absmax

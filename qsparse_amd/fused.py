@@ -46,8 +46,8 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
 def _absmax_accumulator(q: QuantizeLayer, C: int, device) -> torch.Tensor:
     """persistent per-layer scratch for the per-channel abs-max (not a parameter, not in state_dict)."""
     buf = getattr(q, "_chan_absmax", None)
-    if buf is None or buf.numel() != C or buf.device != device:
-        buf = torch.zeros(C, dtype=torch.float32, device=device)
+    if buf is None or buf.shape[0] != C or buf.device != device:
+        buf = _hip.amax_accumulator(C, device)   # [C, 32]: one 128-byte line per channel
         q._chan_absmax = buf
     return buf
 

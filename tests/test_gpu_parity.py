@@ -40,7 +40,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 3
+    assert lib.qs_version() == 4
     assert torch.cuda.is_available()
 
 
@@ -422,9 +422,9 @@ def test_abi_calls_are_graph_capturable():
     mask, scale = torch.ones(C, device=DEV, dtype=torch.uint8), torch.zeros(1, device=DEV)
 
     def sequence(stream):
-        assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), H * W, C, stream) == 0
+        assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, stream) == 0
         assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, stream) == 0
-        assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 0, 4,
+        assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
                                        1, 0, 0, 0, 0, 0, 0, stream) == 0
@@ -549,11 +549,13 @@ def test_row_split_statistics_kernel_all_widths(monkeypatch):
         for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7)):
             for dt in (torch.bfloat16, torch.float32):
                 x = (torch.randn(shape, generator=g) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dt)
-                am = torch.zeros(shape[1], device='cuda')
-                out = _staged_mean_hip(x.cuda(), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
                 ref = O.squeeze_mean(x.abs(), (1, shape[1], 1, 1))
-                assert torch.equal(out.cpu(), ref), (shape, dt)
-                assert torch.equal(am.cpu(), x.abs().float().amax(dim=(0, 2, 3))), (shape, dt)
+                for am in (torch.zeros(shape[1], device='cuda'), _hip.amax_accumulator(shape[1], 'cuda')):   # dense / one line per channel
+                    out = _staged_mean_hip(x.cuda(), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
+                    assert torch.equal(out.cpu(), ref), (shape, dt)
+                    assert torch.equal(_hip.amax_values(am).cpu(), x.abs().float().amax(dim=(0, 2, 3))), (shape, dt)
+                    if am.dim() == 2:
+                        assert not am[:, 1:].any()
         print('ok')
     """)
     for split in ("0", "2", "4", "8"):

@@ -64,6 +64,10 @@ def main():
         report("line fwd (eval form) bf16->f32 per-channel", lambda: quantize_with_line(xb, 8, lc, 1, False, False), 6 * n)
         report("ste bwd f32->bf16 tensor-wise", lambda: _hip.ste_bwd(g, s1, False, -1, -128.0, 127.0, False, torch.bfloat16), 6 * n)
         report("ste bwd f32->bf16 per-channel", lambda: _hip.ste_bwd(g, sc, False, 1, -128.0, 127.0, False, torch.bfloat16), 6 * n)
+        xf = g
+        report("scaler fwd f32->f32 tensor-wise", lambda: quantize_with_scaler(xf, 8, s1), 8 * n)
+        report("scaler fwd f32->f32 per-channel", lambda: quantize_with_scaler(xf, 8, sc, 1), 8 * n)
+        report("ste bwd f32->f32 per-channel", lambda: _hip.ste_bwd(g, sc, False, 1, -128.0, 127.0, False, torch.float32), 8 * n)
         report("mask apply bf16 channel mask", lambda: _hip.mask_apply(xb, mask_c), 4 * n)
         report("mask apply bf16 full-shape mask", lambda: _hip.mask_apply(xb, mask_full), 5 * n)
         report("mask apply bf16 general broadcast (N,1,H,1)", lambda: _hip.mask_apply(xb, mask_odd), 4 * n)

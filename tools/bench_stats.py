@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Statistics pass (qs_mean_dim over the batch dim with the fused per-channel abs-max) on the activation shapes
+of a ResNet-50 step at batch 64, for every row-split width (QS_MEAN_SPLIT; 0 = the host's own choice).
+Development tool: shows where the kernel is latency- rather than bandwidth-bound."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from qsparse_amd import _hip
+
+SHAPES = [(64, 64, 56, 56), (64, 256, 56, 56), (64, 128, 28, 28), (64, 512, 28, 28), (64, 256, 14, 14), (64, 1024, 14, 14),
+          (64, 512, 7, 7), (64, 2048, 7, 7), (128, 64, 32, 32), (128, 512, 4, 4)]
+
+
+def t_us(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e3
+
+
+def main():
+    lib = _hip.load()
+    dev = "cuda"
+    noabs = "--noabs" in sys.argv
+    stride = 1 if "--dense" in sys.argv else 32     # abs-max accumulator: dense float[C] or one 128-byte line per channel
+    splits = [int(s) for s in sys.argv[1:] if s.isdigit()] or [0, 1, 2, 4, 8]
+    print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{'R=' + str(r):>14s}" for r in splits))
+    for shp in SHAPES:
+        N, C, H, W = shp
+        for dtype, code, nbytes in ((torch.bfloat16, 1, 2), (torch.float32, 0, 4)):
+            x = torch.randn(shp, device=dev).to(dtype)
+            stage = torch.empty(C * H * W, device=dev, dtype=dtype)
+            amax = torch.zeros(C * 32, device=dev)
+            cells = []
+            for r in splits:
+                os.environ["QS_MEAN_SPLIT"] = str(r)
+
+                def stats():
+                    assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, code, code, 1 | 4, None,
+                                           None if noabs else amax.data_ptr(), stride, H * W, C, None) == 0
+
+                us = t_us(stats)
+                cells.append(f"{us:6.1f}us {x.numel() * nbytes / us / 1e3:5.0f}GB/s"[:14].rjust(14))
+            print(f"{str(shp):24s} {str(dtype)[6:]:6s} " + " ".join(cells), flush=True)
+    os.environ["QS_MEAN_SPLIT"] = "0"
+
+
+if __name__ == "__main__":
+    main()

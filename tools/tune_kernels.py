@@ -70,7 +70,7 @@ def run_variant(path):
                                     mask.data_ptr(), N, C, H * W, 0, 1, None) == 0
 
     def stats():
-        assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), H * W, C,
+        assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C,
                                None) == 0
 
     am1 = torch.empty(1, device=dev)
@@ -91,7 +91,7 @@ def run_variant(path):
     sc = torch.ones(1, device=dev)
 
     def select():
-        assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 3, 1, 191, mk.data_ptr(), amax.data_ptr(), 1, 3, 4,
+        assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 3, 1, 191, mk.data_ptr(), amax.data_ptr(), 1, 1, 3, 4,
                                 sc.data_ptr(), None, None, None, None, None, None, None) == 0
 
     out = {}
