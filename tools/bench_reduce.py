@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""abs-max / min-max reductions (qs_absmax, qs_minmax) straight through the C ABI: tensor-wise and per-channel, on
+the BASELINE shapes and batch-64 ResNet activations.  Development tool; QS_REDUCE_BLOCKS is read once per process."""
+import json
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [(256, 256, 56, 56), (256, 64, 56, 56), (64, 256, 56, 56), (64, 64, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14),
+          (64, 2048, 7, 7), (512, 512, 3, 3), (64, 64, 1, 1)]
+
+
+def one():
+    import torch
+
+    from qsparse_amd import _hip
+
+    lib = _hip.load()
+    out = {}
+    for shp in SHAPES:
+        N, C, H, W = shp
+        x = torch.randn(shp, device="cuda").bfloat16()
+        a1, ac = torch.zeros(1, device="cuda"), torch.zeros(C, device="cuda")
+        mn, mx = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+
+        def t_us(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            evs = []
+            for _ in range(30):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in evs)
+            return round(ts[len(ts) // 2] * 1e3, 1)
+
+        r = {}
+        r["all"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), a1.data_ptr(), 0, 1, 1, x.numel(), 1, 1, None))
+        r["chan"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N, C, H * W, 1, 1, None))
+        r["chan_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N, C, H * W, 1, None))
+        r["ideal@6TB/s"] = round(x.numel() * 2 / 6e6, 1)
+        out[str(shp)] = r
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--one":
+        one()
+    else:
+        for rb in sys.argv[1:] or ["512"]:
+            r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, QS_REDUCE_BLOCKS=rb), capture_output=True,
+                               text=True)
+            print(f"QS_REDUCE_BLOCKS={rb}")
+            if not r.stdout.strip():
+                print(r.stderr[-600:])
+                continue
+            for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items():
+                print(f"  {k:22s} {v}")
