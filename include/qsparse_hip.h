@@ -114,9 +114,10 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
 /* max |x| over the tensor (per_channel == 0 -> out[1]) or per channel (out[C]);
  * DecimalQuantizer.optimize, qsparse/quantize.py:329-340.  Order-independent, hence bit-exact.
  * accumulate != 0: out is max-accumulated instead of overwritten (the caller keeps it zeroed between steps, e.g.
- * through qs_scale_update's clear_absmax), which saves the initialisation launch. */
+ * through qs_scale_update's clear_absmax), which saves the initialisation launch.
+ * pre_relu != 0: the statistic of max(x, 0) -- a preceding nn.ReLU folded into the quantizer's kernels. */
 int qs_absmax(const void* x, float* out, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, qs_stream_t stream);
+              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, int pre_relu, qs_stream_t stream);
 
 /* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
  * (min over the batch of per-sample minima == global per-channel minimum). */

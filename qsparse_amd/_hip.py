@@ -40,7 +40,7 @@ SIGNATURES = {
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
-    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _P]),
+    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
     "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
@@ -303,9 +303,11 @@ def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, 
 # ----------------------------------------------------------------------------------------------
 # statistics
 # ----------------------------------------------------------------------------------------------
-def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.Tensor] = None,
+           pre_relu: bool = False) -> torch.Tensor:
     """max|x| per channel / over the tensor.  `accumulate_into`: zeroed persistent fp32 buffer that is
-    max-accumulated instead of allocating + initialising a fresh one (one launch instead of two)."""
+    max-accumulated instead of allocating + initialising a fresh one (one launch instead of two).
+    `pre_relu`: the statistic of max(x, 0) (folded nn.ReLU)."""
     lib = load()
     x = dense(x)
     outer, C, inner, numel = split3(x.shape, channel_index)
@@ -314,7 +316,7 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
     assert out.numel() == n and out.dtype == torch.float32
     with _timed("absmax"):
         st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
-                           int(accumulate_into is not None), _stream(x))
+                           int(accumulate_into is not None), int(bool(pre_relu)), _stream(x))
     _check(st, "qs_absmax")
     return out
 

@@ -14,7 +14,9 @@ namespace qs {
 template <int DT, bool MINMAX>
 struct RedAcc {
     uint32_t mx = 0u, mn = 0xffffffffu;
+    int relu = 0;   // abs-max of max(x, 0): the statistics of a folded nn.ReLU
     __device__ __forceinline__ void add(float v) {
+        if (relu) v = fmaxf(v, 0.0f);
         if constexpr (MINMAX) {
             uint32_t k = f32_to_key(v);
             mx = k > mx ? k : mx;
@@ -37,8 +39,9 @@ struct RedAcc {
 // whole tensor -> out[0]
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_all_kernel(const void* __restrict__ x, int64_t numel,
-                                                             uint32_t* out_max, uint32_t* out_min) {
+                                                             uint32_t* out_max, uint32_t* out_min, int relu) {
     RedAcc<DT, MINMAX> acc;
+    acc.relu = relu;
     const int64_t ngroups = numel / 8;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -88,12 +91,13 @@ __global__ __launch_bounds__(kBlock) void reduce_all_kernel(const void* __restri
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restrict__ x, int64_t outer, uint32_t C,
                                                               int64_t inner, int vec_ok, int64_t outer_per_block,
-                                                              uint32_t* out_max, uint32_t* out_min) {
+                                                              uint32_t* out_max, uint32_t* out_min, int relu) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc;
+    acc.relu = relu;
     for (int64_t o = o0 + wave; o < o1; o += kBlock / 64) {
         const int64_t base = (o * C + c) * inner;
         if (vec_ok) {  // inner % 8 == 0 and base pointer aligned: rows start on 16-byte boundaries
@@ -137,12 +141,13 @@ __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restr
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
                                                               int64_t inner, int64_t outer_per_block,
-                                                              uint32_t* out_max, uint32_t* out_min) {
+                                                              uint32_t* out_max, uint32_t* out_min, int relu) {
     const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (col >= cols) return;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc;
+    acc.relu = relu;
     for (int64_t o = o0; o < o1; ++o) acc.add(load1<DT>(x, o * cols + col));
     if (o1 > o0) acc.flush(out_max, out_min, (uint32_t)(col / inner));
 }
@@ -151,12 +156,14 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restr
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
                                                                   int64_t inner, int64_t outer_per_block,
-                                                                  uint32_t* out_max, uint32_t* out_min) {
+                                                                  uint32_t* out_max, uint32_t* out_min, int relu) {
     const int64_t gcols = cols / 8;
     const int64_t gc = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j].relu = relu;
     for (int64_t o = o0; o < o1 && gc < gcols; o += 8) {
         Raw8<DT> r[8];
 #pragma unroll

@@ -340,7 +340,7 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
 
 // ------------------------------------------------------------------------------------------------
 static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
-                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false) {
+                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false, int relu = 0) {
     if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
     if (!dt_ok(xdt)) return QS_ERR_DTYPE;
     if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
@@ -360,7 +360,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     if (!vec_ptr) return (int)QS_ERR_ALIGN;
                     int grid = grid_for(numel / 8, 4);
                     if (grid > reduce_blocks()) grid = reduce_blocks();   // every block ends with one atomic on the same word
-                    hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin);
+                    hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin, relu);
                 } else if (inner >= 64 && C < 65536) {
                     int64_t slices = (2048 + C - 1) / C;              // ~2048 workgroups, one atomic each
                     if (slices > (outer + 3) / 4) slices = (outer + 3) / 4;
@@ -368,7 +368,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     const int64_t opb = (outer + slices - 1) / slices;
                     const int vec_ok = vec_ptr && (inner % 8 == 0);
                     hipLaunchKernelGGL((reduce_rows_kernel<XD, M>), dim3((int)C, (int)((outer + opb - 1) / opb)), dim3(kBlock),
-                                       0, s, x, outer, (uint32_t)C, inner, vec_ok, opb, omax, omin);
+                                       0, s, x, outer, (uint32_t)C, inner, vec_ok, opb, omax, omin, relu);
                 } else {
                     const int64_t cols = C * inner;
                     const bool vec = vec_ptr && (cols % 8 == 0);
@@ -381,10 +381,10 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     const int64_t opb = (outer + gy - 1) / gy;
                     if (vec)
                         hipLaunchKernelGGL((reduce_cols_vec_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer,
-                                           cols, inner, opb, omax, omin);
+                                           cols, inner, opb, omax, omin, relu);
                     else
                         hipLaunchKernelGGL((reduce_cols_kernel<XD, M>), dim3(gx, (int)gy), dim3(kBlock), 0, s, x, outer, cols,
-                                           inner, opb, omax, omin);
+                                           inner, opb, omax, omin, relu);
                 }
                 return launch_status();
             };
@@ -397,8 +397,9 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
 }
 
 int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate,
-              qs_stream_t stream) {
-    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0);
+              int pre_relu, qs_stream_t stream) {
+    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0,
+                       pre_relu != 0);
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,

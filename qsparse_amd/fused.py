@@ -146,7 +146,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         world = qdist.stats_world_size()
         if update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
-            am = qdist.allreduce_max_(_hip.absmax(torch.relu(hd) if pre_relu else hd, -1), world)
+            am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)
             _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits,
                               t_dev=qc.device_t(h.device) if get_option("graph_safe") else None)
         else:
@@ -166,7 +166,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax, absmax_channel_dim=1,
                                          pre_relu=pre_relu).view(-1)
             elif update_scale:
-                chan_absmax = _hip.absmax(torch.relu(hd) if pre_relu else hd, 1)
+                chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
             if world > 1:
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
@@ -236,17 +236,78 @@ class FusedPruneQuantize(nn.Sequential):
 FusedPruneQuantize.__name__ = "Sequential"   # keep str(model) identical to the reference's tree
 
 
+def _quantizer_foldable(q: QuantizeLayer, x) -> bool:
+    qc = q.callback
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() >= 1
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and type(qc) in (ScalerQuantizer, DecimalQuantizer) and qc.group_num <= 0 and q.channelwise == -1
+            and not qc.backward_passthrough and q.batch_dimension == 0)
+
+
+def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
+    """one step of ``q(relu(x))`` for an ACTIVE tensor-wise Scaler/Decimal quantizer without materialising
+    relu(x): abs-max of max(x, 0) (qs_absmax pre_relu), running scale, y = Q(max(x, 0)), and a backward that
+    applies the ReLU gate and the STE clamp in one pass.  Bookkeeping as QuantizeLayer.forward
+    (reference quantize.py:482-517)."""
+    qc = q.callback
+    if q.training:
+        t = q._steps.read(q._n_updates)
+        if t == q.timeout and get_option("log_during_train"):
+            logging.warn(f"quantizing {q.name} with {q.bits} bits")
+        qc.__dict__["_bumped_step_counter"] = False
+        new_weight = qc.optimize(x.detach(), q.bits, q.weight, batched=True, channel_index=-1, step_counter=q._n_updates,
+                                 pre_relu=True)
+        if new_weight is not None and new_weight is not q.weight:
+            q.weight.data[:] = new_weight
+        q._quantized = True
+        if qc.__dict__.get("_bumped_step_counter", False):
+            q._steps.note_device_add(q._n_updates, 1)
+        else:
+            q._steps.add(q._n_updates, 1)
+    kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
+    return _FusedApply.apply(x, None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0, True, True)
+
+
+class FusedActQuantize(nn.Sequential):
+    """``Sequential(act, QuantizeLayer)`` as convert builds it for a quantize-only activation site
+    (reference convert.py:214-218): a plain out-of-place nn.ReLU in front of an active tensor-wise quantizer is
+    folded into the quantizer's kernels (24 -> 16 B/elem per training step for bf16 activations); anything else runs
+    module by module.  Children, parameter names and ``str()`` are those of the plain ``Sequential``."""
+
+    def forward(self, x):
+        act, q = self[0], self[1]
+        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and q.is_active()
+                and _quantizer_foldable(q, x)):
+            return fused_relu_quantize(q, x)
+        return q(act(x))
+
+
+FusedActQuantize.__name__ = "Sequential"
+
+
 def _is_pair(m: nn.Module) -> bool:
-    if type(m) is not nn.Sequential or len(m) != 2 or not isinstance(m[1], QuantizeLayer):
+    if len(m) != 2 or not isinstance(m[1], QuantizeLayer):
         return False
     inner = m[0]
     return (type(inner) is nn.Sequential and len(inner) == 2 and isinstance(inner[1], PruneLayer)
             and not isinstance(inner[0], (PruneLayer, QuantizeLayer)))
 
 
+def _is_act_quantize(m: nn.Module) -> bool:
+    return len(m) == 2 and type(m[0]) is nn.ReLU and isinstance(m[1], QuantizeLayer)
+
+
 def fuse_prune_quantize_pairs(model: nn.Module) -> nn.Module:
-    """re-class every convert-built prune->quantize pair in ``model`` (in place)."""
+    """re-class every convert-built prune->quantize pair and ReLU->quantize site in ``model`` (in place).
+    Idempotent, and safe to call again after a further ``convert`` changed the tree (a site whose structure no
+    longer matches goes back to a plain ``Sequential``)."""
     for m in model.modules():
+        if type(m) not in (nn.Sequential, FusedPruneQuantize, FusedActQuantize):
+            continue
         if _is_pair(m):
             m.__class__ = FusedPruneQuantize
+        elif _is_act_quantize(m):
+            m.__class__ = FusedActQuantize
+        elif type(m) is not nn.Sequential:
+            m.__class__ = nn.Sequential
     return model

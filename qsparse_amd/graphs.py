@@ -74,3 +74,59 @@ def resync_host_state(model: nn.Module) -> nn.Module:
                 qc.t = int(buf.item())
                 qc.__dict__["_t_dev_value"] = qc.t
     return model
+
+
+class GraphedStep:
+    """runs ``step_fn(*tensors)`` eagerly until the network is in steady state, then captures it once into a
+    hipGraph and replays it from there on:
+
+        step = graphs.GraphedStep(model, train_step)      # train_step(x, y) -> loss (fwd + bwd + optimizer)
+        for x, y in loader:
+            loss = step(x, y)                              # eager first, graph replay later; same results
+        step.finish()                                      # host mirrors back in sync (checkpoints, eval)
+
+    Inputs are copied into static buffers (shapes and dtypes must not change once captured); tensors returned by
+    ``step_fn`` are static too and are overwritten by the next call.  ``settle`` extra eager steps are run in
+    steady state before capturing so that allocations (optimizer state, layer scratch) exist.  Sets the
+    ``graph_safe`` option (required for the counters to stay live under replay)."""
+
+    def __init__(self, model: nn.Module, step_fn, settle: int = 2):
+        from qsparse_amd.util import set_options
+
+        set_options(graph_safe=True)
+        self.model, self.step_fn, self.settle = model, step_fn, settle
+        self.graph = None
+        self._steady_steps = 0
+        self._static_in = None
+        self._static_out = None
+
+    @property
+    def captured(self) -> bool:
+        return self.graph is not None
+
+    def __call__(self, *tensors):
+        if self.graph is not None:
+            for s, t in zip(self._static_in, tensors):
+                s.copy_(t, non_blocking=True)
+            self.graph.replay()
+            return self._static_out
+        if not (tensors and all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors)) or not steady_state(self.model):
+            return self.step_fn(*tensors)
+        if self._steady_steps < self.settle:
+            self._steady_steps += 1
+            return self.step_fn(*tensors)
+        self._static_in = [t.detach().clone() for t in tensors]
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_out = self.step_fn(*self._static_in)
+        self.graph = graph
+        graph.replay()                     # the capture records the step without running it
+        return self._static_out
+
+    def finish(self) -> nn.Module:
+        """drop the graph and re-read the host mirrors of every counter."""
+        self.graph = None
+        self._static_in = self._static_out = None
+        self._steady_steps = 0
+        return resync_host_state(self.model)

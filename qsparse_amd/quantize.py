@@ -288,7 +288,8 @@ class DecimalQuantizer(BaseQuantizer):
                 buf = bufs.get((n_stat, x.device))
                 if buf is None:
                     buf = bufs[(n_stat, x.device)] = torch.zeros(n_stat, dtype=torch.float32, device=x.device)
-                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index, accumulate_into=buf))
+                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index, accumulate_into=buf,
+                                                        pre_relu=bool(kwargs.get("pre_relu", False))))
                 if weight is None:
                     weight = torch.zeros(wshape, device=x.device)
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None

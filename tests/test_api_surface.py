@@ -56,3 +56,34 @@ def test_callback_protocol_methods_match_reference():
         cls, meth = name.split(".")
         obj = getattr(getattr(Q, cls, None) or getattr(S, cls), meth)
         _compatible(_sig(obj), ref, name)
+
+
+def test_site_fusion_follows_the_tree():
+    """a second convert nests around the first one's site (reference convert.py:214-218): prune-then-quantize gives
+    Sequential(Sequential(act, prune), quantize) -> the fused pair; quantize-then-prune gives
+    Sequential(Sequential(act, quantize), prune) -> a plain Sequential around the ReLU->quantize site; a
+    quantize-only net gets the ReLU->quantize site.  str(model) shows none of it."""
+    import torch.nn as nn
+    import qsparse_amd as qs
+    from qsparse_amd.fused import FusedActQuantize, FusedPruneQuantize, fuse_prune_quantize_pairs
+
+    before = qs.get_qsparse_option("log_on_created")
+    qs.set_qsparse_options(log_on_created=False)
+
+    def net():
+        return nn.Sequential(nn.Conv2d(3, 8, 3), nn.ReLU(), nn.Conv2d(8, 8, 3), nn.ReLU())
+
+    q_only = qs.convert(net(), qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU])
+    assert type(q_only[1]) is FusedActQuantize and "Fused" not in str(q_only)
+    q_then_p = qs.convert(q_only, qs.prune(sparsity=0.5, dimensions={1}), activation_layers=[nn.ReLU])
+    assert type(q_then_p[1]) is nn.Sequential and type(q_then_p[1][0]) is FusedActQuantize
+    p_then_q = qs.convert(qs.convert(net(), qs.prune(sparsity=0.5, dimensions={1}), activation_layers=[nn.ReLU]),
+                          qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU])
+    assert type(p_then_q[1]) is FusedPruneQuantize and type(p_then_q[3]) is FusedPruneQuantize and "Fused" not in str(p_then_q)
+    # re-classing is idempotent and follows later edits of the tree
+    p_then_q[1][0][1] = nn.Identity()
+    fuse_prune_quantize_pairs(p_then_q)
+    assert type(p_then_q[1]) is nn.Sequential and type(p_then_q[3]) is FusedPruneQuantize
+    unfused = qs.convert(net(), qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU], fuse=False)
+    assert type(unfused[1]) is nn.Sequential
+    qs.set_qsparse_options(log_on_created=before)

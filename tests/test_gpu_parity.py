@@ -636,3 +636,56 @@ def test_relu_fold_is_bit_identical_to_materialised_relu():
         for (ya, ga), (yb, gb) in zip(*runs):
             assert torch.equal(ya, yb) and same(ga.cpu(), gb.cpu())
     qs.set_qsparse_options(fold_relu=True)
+
+
+@pytest.mark.parametrize("kind", ["scaler", "decimal"])
+def test_relu_quantize_site_fold_is_bit_identical(kind):
+    """convert() builds Sequential(ReLU, QuantizeLayer) for a quantize-only activation site; with the fold relu(x)
+    is never materialised (abs-max of max(x,0), y = Q(max(x,0)), gated STE backward).  Outputs, gradients and state
+    equal the module-by-module run and the oracle: identity phase, active phase, evaluation."""
+    from qsparse_amd.fused import FusedActQuantize, fuse_prune_quantize_pairs
+    cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (3, 50))):
+        runs = []
+        for fold in (True, False):
+            qs.set_qsparse_options(fold_relu=fold)
+            site = nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=2, callback=cbs[kind]())).to(DEV).train()
+            fuse_prune_quantize_pairs(site)
+            assert type(site) is FusedActQuantize and str(site).startswith("Sequential(")
+            qsim = O.QuantizeSim(kind, 4, -1, 2)
+            outs = []
+            for s in range(7):
+                training = s < 6
+                if not training:
+                    site.eval()
+                x = (torch.randn(shape, generator=gen(2000 + s)) * 2).to(dtype)
+                x.view(-1)[:4] = torch.tensor([0.0, -1e-3, 1.0, -1.0]).to(dtype)
+                gout = torch.randn(shape, generator=gen(2100 + s))
+                xg = x.to(DEV).requires_grad_(True)
+                y = site(xg)
+                y.backward(gout.to(DEV).to(y.dtype))
+                y_ref = qsim.step(torch.relu(x), training)
+                gh = qsim.grad(gout.to(y_ref.dtype), dtype)
+                gx_ref = torch.where(x <= 0, torch.zeros_like(gh), gh)
+                assert same(y.detach().cpu(), y_ref), (dtype, fold, s)
+                assert same(xg.grad.cpu(), gx_ref), (dtype, fold, s)
+                assert same(site[1].weight.detach().cpu(), qsim.weight) and int(site[1]._n_updates) == qsim.n_updates
+                outs.append((y.detach().clone(), xg.grad.clone()))
+            runs.append(outs)
+        for (ya, ga), (yb, gb) in zip(*runs):
+            assert torch.equal(ya, yb) and same(ga.cpu(), gb.cpu())
+    qs.set_qsparse_options(fold_relu=True)
+
+
+def test_absmax_of_folded_relu():
+    """qs_absmax(pre_relu=1) == max|relu(x)| for every reduction layout (tensor-wise, rows, columns)."""
+    for dtype in (torch.bfloat16, torch.float32):
+        for shape, ci in (((64, 48, 9, 9), -1), ((64, 48, 9, 9), 1), ((200, 8, 16, 16), 1), ((1000, 16), 1), ((33, 7), 1),
+                          ((5, 4096), -1)):
+            x = torch.randn(shape, generator=gen(77)).to(dtype)
+            got = _hip.absmax(x.to(DEV), ci, pre_relu=True).cpu()
+            r = torch.relu(x).float()
+            ref = r.amax().view(1) if ci < 0 else r.transpose(0, ci).reshape(shape[ci], -1).amax(1)
+            assert torch.equal(got, ref), (dtype, shape, ci)
+        neg = -torch.rand(4, 8, 8, 8).to(dtype) - 0.1
+        assert float(_hip.absmax(neg.to(DEV), -1, pre_relu=True)) == 0.0

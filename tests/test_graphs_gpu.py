@@ -103,3 +103,38 @@ def test_steady_state_detection():
         assert graphs.steady_state(pair) is False
     finally:
         qs.set_qsparse_options(graph_safe=False)
+
+
+def test_graphed_step_wrapper_switches_to_replay_and_matches_eager():
+    """graphs.GraphedStep: eager until steady state, then capture + replay; the trajectory equals plain eager."""
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, graph_safe=True)
+    torch.backends.cudnn.deterministic = True
+    try:
+        shape, K = (8, 3, 32, 32), 10
+        data = _batches(K, shape)
+        results = []
+        for wrapped in (False, True):
+            model = _make(True)
+            opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+
+            def train_step(x, y):
+                opt.zero_grad(set_to_none=False)
+                loss = F.cross_entropy(model(x), y)
+                loss.backward()
+                opt.step()
+                return loss.detach()
+
+            step = graphs.GraphedStep(model, train_step) if wrapped else train_step
+            losses = [float(step(x, y)) for x, y in data]
+            if wrapped:
+                assert step.captured, "the wrapper never reached graph replay"
+                step.finish()
+            results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        (le, se), (lg, sg) = results
+        if le[:3] != lg[:3]:
+            pytest.skip("backend not run-to-run deterministic")
+        assert le == lg
+        for k in se:
+            assert torch.equal(se[k], sg[k]), k
+    finally:
+        qs.set_qsparse_options(graph_safe=False)
