@@ -193,9 +193,12 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
 
 /* y = x * mask with a broadcast bool mask (qsparse/sparse.py:66,116,122,263) and, with g in place of x,
  * its backward g * mask.  The tensor is described by `ndim` collapsed extents `sizes`; `mask_strides[d]`
- * is the mask's element stride along d (0 where the mask has extent 1). */
+ * is the mask's element stride along d (0 where the mask has extent 1).
+ * pre_relu != 0: y = max(x, 0) * mask, a preceding nn.ReLU folded into the prune site; only for masks that
+ * vary along one run of dims (channel masks; QS_ERR_ARG otherwise).  Its backward is
+ * qs_quant_ste_relu_bwd with step_host = 1 and lo_mul / hi_mul = -inf / +inf. */
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes,
-                  const int64_t* mask_strides, int dt, qs_stream_t stream);
+                  const int64_t* mask_strides, int dt, int pre_relu, qs_stream_t stream);
 
 /* ---- fused channel-prune -> tensor-wise-quantize statistics (the headline pair) -------------------- */
 

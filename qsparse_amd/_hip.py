@@ -50,7 +50,7 @@ SIGNATURES = {
     "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P, _P]),
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
-    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _P]),
+    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -443,8 +443,9 @@ def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
     _check(st, "qs_mask_ge")
 
 
-def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-    """x * mask for a bool mask broadcastable to x (same rank, extents 1 or equal)."""
+def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
+    """x * mask for a bool mask broadcastable to x (same rank, extents 1 or equal); `pre_relu`: max(x, 0) * mask
+    (channel-type masks only)."""
     lib = load()
     x = dense(x)
     if mask.dim() != x.dim():
@@ -461,7 +462,7 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
     with _timed("mask_apply"):
-        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), _stream(x))
+        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _stream(x))
     _check(st, "qs_mask_apply")
     return y
 

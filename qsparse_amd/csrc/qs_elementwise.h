@@ -196,6 +196,7 @@ struct SteBwdOp {
 // x * mask with a per-channel mask (reference qsparse/sparse.py:66,116,122,263)
 struct ChanMaskOp {
     const uint8_t* cmask;
+    int relu;   // max(x, 0) * mask: a preceding nn.ReLU folded into the prune site
     struct P {
         float keep;
     };
@@ -207,6 +208,7 @@ struct ChanMaskOp {
     __device__ __forceinline__ P channel_masked(uint32_t, uint32_t c_mask) const { return channel(c_mask); }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         code = 0;
+        if (relu) v = fmaxf(v, 0.0f);
         return v * p.keep;
     }
 };

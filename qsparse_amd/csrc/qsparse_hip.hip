@@ -573,7 +573,7 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
 
 // ------------------------------------------------------------------------------------------------
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes, const int64_t* mask_strides,
-                  int dt, qs_stream_t stream) {
+                  int dt, int pre_relu, qs_stream_t stream) {
     if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1) return QS_ERR_ARG;
     if (!dt_ok(dt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
@@ -616,12 +616,13 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         EwPlan plan;
         int st = plan_ew(outer, C, inner, true, &plan);
         if (st) return st;
-        ChanMaskOp op{mask};
+        ChanMaskOp op{mask, pre_relu != 0};
         return with_dtype(dt, [&](auto D) {
             constexpr int DD = decltype(D)::value;
             return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s);
         });
     }
+    if (pre_relu) return QS_ERR_ARG;   // the ReLU fold exists for channel-type masks only
     if (full) {
         const int grid = grid_for(numel / 8, 1);
         return with_dtype(dt, [&](auto D) {

@@ -285,11 +285,34 @@ class FusedActQuantize(nn.Sequential):
 FusedActQuantize.__name__ = "Sequential"
 
 
+class FusedActPrune(nn.Sequential):
+    """``Sequential(act, PruneLayer)`` as convert builds it for a prune-only activation site: a plain out-of-place
+    nn.ReLU in front of an active channel-pruning layer is folded into its kernels -- importance of max(x, 0),
+    y = max(x, 0) * mask, backward gate(x) * g * mask -- 20 -> 12 B/elem per training step for bf16
+    activations.  Children, parameter names and ``str()`` are those of the plain ``Sequential``."""
+
+    def forward(self, x):
+        act, p = self[0], self[1]
+        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and isinstance(x, torch.Tensor)
+                and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and p.is_active()
+                and type(p.callback) is MagnitudePruningCallback and not p.callback.l0
+                and not p.callback.use_gradient and len(p.dimensions) == 1):
+            return p(x, pre_relu=True)
+        return p(act(x))
+
+
+FusedActPrune.__name__ = "Sequential"
+
+
+def _is_act_prune(m: nn.Module) -> bool:
+    return len(m) == 2 and type(m[0]) is nn.ReLU and isinstance(m[1], PruneLayer)
+
+
 def _is_pair(m: nn.Module) -> bool:
     if len(m) != 2 or not isinstance(m[1], QuantizeLayer):
         return False
     inner = m[0]
-    return (type(inner) is nn.Sequential and len(inner) == 2 and isinstance(inner[1], PruneLayer)
+    return (type(inner) in (nn.Sequential, FusedActPrune) and len(inner) == 2 and isinstance(inner[1], PruneLayer)
             and not isinstance(inner[0], (PruneLayer, QuantizeLayer)))
 
 
@@ -301,13 +324,20 @@ def fuse_prune_quantize_pairs(model: nn.Module) -> nn.Module:
     """re-class every convert-built prune->quantize pair and ReLU->quantize site in ``model`` (in place).
     Idempotent, and safe to call again after a further ``convert`` changed the tree (a site whose structure no
     longer matches goes back to a plain ``Sequential``)."""
+    inner_of_pair = set()
     for m in model.modules():
-        if type(m) not in (nn.Sequential, FusedPruneQuantize, FusedActQuantize):
+        if type(m) not in (nn.Sequential, FusedPruneQuantize, FusedActQuantize, FusedActPrune):
             continue
         if _is_pair(m):
             m.__class__ = FusedPruneQuantize
+            m[0].__class__ = nn.Sequential        # the pair runs its inner (act, prune) itself
+            inner_of_pair.add(id(m[0]))
+        elif id(m) in inner_of_pair:
+            continue
         elif _is_act_quantize(m):
             m.__class__ = FusedActQuantize
+        elif _is_act_prune(m):
+            m.__class__ = FusedActPrune
         elif type(m) is not nn.Sequential:
             m.__class__ = nn.Sequential
     return model

@@ -23,28 +23,53 @@ from qsparse_amd.util import (_reduction_plan, _staged_mean_hip, calculate_mask_
 
 class _MaskApply(torch.autograd.Function):
     """``x * mask`` for a GPU tensor; backward ``g * mask`` (autograd's MulBackward0 in the reference,
-    qsparse/sparse.py:66,116,122,263)."""
+    qsparse/sparse.py:66,116,122,263).  ``relu_dim >= 0``: ``max(x, 0) * mask`` for a mask that varies along that
+    dim only, with the ReLU's gate in the backward (a folded nn.ReLU; relu(x) is never materialised)."""
 
     @staticmethod
-    def forward(ctx, x, mask):
+    def forward(ctx, x, mask, relu_dim=-1):
+        ctx.relu_dim = relu_dim
+        if relu_dim >= 0:
+            ctx.save_for_backward(mask, x)
+            return _hip.mask_apply(x, mask, pre_relu=True)
         ctx.save_for_backward(mask)
         return _hip.mask_apply(x, mask)
 
     @staticmethod
     def backward(ctx, grad):
+        if ctx.relu_dim >= 0:
+            mask, x = ctx.saved_tensors
+            inf = float("inf")   # no clamp: qs_quant_ste_relu_bwd reduces to gate(x) * g * mask
+            return _hip.ste_relu_bwd(grad, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim), None, None
         (mask,) = ctx.saved_tensors
-        return _hip.mask_apply(grad, mask), None
+        return _hip.mask_apply(grad, mask), None, None
 
 
-def apply_mask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+def _channel_dim(mask: torch.Tensor) -> int:
+    """the single dim along which ``mask`` varies, or -1"""
+    dims = [d for d, s in enumerate(mask.shape) if s != 1]
+    return dims[0] if len(dims) == 1 else -1
+
+
+def apply_mask(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
     if x.is_cuda:
+        if pre_relu:
+            d = _channel_dim(mask)
+            if d < 0 or mask.shape[d] != x.shape[d]:
+                return _MaskApply.apply(torch.relu(x), mask.detach())
+            return _MaskApply.apply(x, mask.detach(), d)
         return _MaskApply.apply(x, mask.detach())
-    return x * mask
+    return (torch.relu(x) if pre_relu else x) * mask
 
 
-def _importance(x: torch.Tensor, shape, l0: bool = False) -> torch.Tensor:
+def _importance(x: torch.Tensor, shape, l0: bool = False, pre_relu: bool = False) -> torch.Tensor:
     """``squeeze_tensor_to_shape(x.abs(), shape)`` -- with the optional L0 substitution -- in one pass
-    over ``x`` on the GPU (reference sparse.py:85-87)."""
+    over ``x`` on the GPU (reference sparse.py:85-87).  ``pre_relu``: the importance of max(x, 0)."""
+    if pre_relu:
+        dims = _reduction_plan(x.shape, shape)
+        if x.is_cuda and dims and not l0:
+            return _staged_mean_hip(x, dims, take_abs=True, pre_relu=True)
+        x = torch.relu(x)
     if x.is_cuda:
         dims = _reduction_plan(x.shape, shape)
         flag = _hip.l0_flag(x) if l0 else None
@@ -151,10 +176,60 @@ class MagnitudePruningCallback(nn.Module):
         if self.forward_hook is not None:
             self.forward_hook(mask, name)
 
-    def forward(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor, name=""):
+    def _single_launch_select(self, x: torch.Tensor, mask: torch.Tensor) -> bool:
+        """GPU tensors, running-average magnitudes of at most 65536 mask entries, no overridden policy methods:
+        running mean + k-th value + mask (+ step counters) are then ONE launch (qs_pq_select)."""
+        cls = type(self)
+        return (x.is_cuda and self.running_average and not self.use_gradient and 2 <= mask.numel() <= 65536
+                and mask.is_cuda and mask.is_contiguous() and hasattr(self, "magnitude")
+                and cls.update_magnitude is MagnitudePruningCallback.update_magnitude
+                and cls.receive_input is MagnitudePruningCallback.receive_input
+                and cls.prune_and_update_mask is MagnitudePruningCallback.prune_and_update_mask)
+
+    def _forward_single_launch(self, x, sparsity, mask, name, t, step_counter, pre_relu=False):
+        update = t < self.stop_mask_refresh
+        refresh = self.refresh_due(t, sparsity)
+        self.__dict__["_bumped_step_counter"] = False
+        t_on_dev = self.t.is_cuda and self.t.device == x.device
+        if update or refresh:
+            with torch.no_grad():
+                imp = k = None
+                if update:
+                    imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0, pre_relu)).view(-1)
+                if refresh:
+                    n = mask.numel()
+                    k = threshold_rank(sparsity, n)
+                    if k >= n:
+                        raise IndexError(f"index {k} is out of bounds for dimension 0 with size {n}")
+                bump = None
+                if step_counter is not None and step_counter.is_cuda and step_counter.device == x.device:
+                    bump = step_counter.data
+                _hip.pq_select(self.magnitude.data.view(-1), imp, update, t, refresh, k or 0, mask.data.view(-1), None, False,
+                               0, 8, None, bump_a=bump, bump_c=self.t.data if t_on_dev else None,
+                               t_mag_dev=self.t.data if (update and t_on_dev and get_option("graph_safe")) else None)
+                self.__dict__["_bumped_step_counter"] = bump is not None
+            out = apply_mask(x, mask, pre_relu)
+            if t_on_dev:
+                self._t_host.note_device_add(self.t, 1)
+                if self.forward_hook is not None:
+                    self.forward_hook(mask, name)
+                return out
+        else:
+            out = apply_mask(x, mask, pre_relu)
+        self.end_step(mask, name)
+        return out
+
+    def forward(self, x: torch.Tensor, sparsity: float, mask: torch.Tensor, name="", step_counter=None,
+                pre_relu: bool = False):
+        """``pre_relu`` (used by the fused ReLU->prune site only): treat ``x`` as the input of a ReLU that has not
+        been applied yet -- statistics, mask apply and backward then work on max(x, 0)."""
         if not self.training:
-            return apply_mask(x, mask)
+            return apply_mask(x, mask, pre_relu)
         t = self.begin_step(mask)
+        if self._single_launch_select(x, mask):
+            return self._forward_single_launch(x, sparsity, mask, name, t, step_counter, pre_relu)
+        if pre_relu:
+            x = torch.relu(x)
         if t < self.stop_mask_refresh:
             self.receive_input(x)
         if self.refresh_due(t, sparsity):
@@ -248,18 +323,37 @@ class PruneLayer(nn.Module):
     def current_sparsity(self) -> float:
         return self._sparsity_host.read(self._cur_sparsity)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def is_active(self) -> bool:
+        """whether the next forward multiplies by the mask (used by the fused ReLU->prune site)."""
+        if not self.initted:
+            return False
+        return (not self.training) or self.mask.numel() == 1 or self._steps.read(self._n_updates) >= self.start
+
+    def forward(self, x: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
         """prune ``x`` according to the schedule; raises ``RuntimeError`` when a full-shape mask meets a
-        different input shape in evaluation mode."""
+        different input shape in evaluation mode.  ``pre_relu``: see MagnitudePruningCallback.forward."""
         if not self.initted:
             self._lazy_init(x)
         n = self.advance_schedule()
         if not self.training or self.mask.numel() == 1:
-            return apply_mask(x, self.mask)
+            return apply_mask(x, self.mask, pre_relu)
+        if pre_relu and not (n >= self.start and x.is_cuda and type(self.callback) is MagnitudePruningCallback):
+            x, pre_relu = torch.relu(x), False
         if n >= self.start:
             if n == self.start and get_option("log_during_train"):
                 logging.warning(f"Start pruning at {self.name} @ {n}")
-            out = self.callback(x, self.current_sparsity(), mask=self.mask, name=self.name)
+            cb = self.callback
+            if x.is_cuda and type(cb) is MagnitudePruningCallback:
+                # the layer's step counter rides along in the callback's select launch when there is one
+                cb.__dict__["_bumped_step_counter"] = False
+                out = cb(x, self.current_sparsity(), mask=self.mask, name=self.name, step_counter=self._n_updates,
+                         pre_relu=pre_relu)
+                if cb.__dict__.get("_bumped_step_counter", False):
+                    cb.__dict__["_bumped_step_counter"] = False
+                    self._steps.note_device_add(self._n_updates, 1)
+                    return out
+            else:
+                out = cb(x, self.current_sparsity(), mask=self.mask, name=self.name)
         else:
             out = x
         self._steps.add(self._n_updates, 1)

@@ -84,6 +84,10 @@ def test_site_fusion_follows_the_tree():
     p_then_q[1][0][1] = nn.Identity()
     fuse_prune_quantize_pairs(p_then_q)
     assert type(p_then_q[1]) is nn.Sequential and type(p_then_q[3]) is FusedPruneQuantize
+    assert type(p_then_q[3][0]) is nn.Sequential          # the inner (act, prune) of a pair stays plain
+    from qsparse_amd.fused import FusedActPrune
+    p_only = qs.convert(net(), qs.prune(sparsity=0.5, dimensions={1}), activation_layers=[nn.ReLU])
+    assert type(p_only[1]) is FusedActPrune and "Fused" not in str(p_only)
     unfused = qs.convert(net(), qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU], fuse=False)
     assert type(unfused[1]) is nn.Sequential
     qs.set_qsparse_options(log_on_created=before)

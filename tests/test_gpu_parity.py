@@ -689,3 +689,44 @@ def test_absmax_of_folded_relu():
             assert torch.equal(got, ref), (dtype, shape, ci)
         neg = -torch.rand(4, 8, 8, 8).to(dtype) - 0.1
         assert float(_hip.absmax(neg.to(DEV), -1, pre_relu=True)) == 0.0
+
+
+def test_relu_prune_site_fold_is_bit_identical():
+    """convert() builds Sequential(ReLU, PruneLayer) for a prune-only activation site; with the fold relu(x) is never
+    materialised (importance of max(x,0), y = max(x,0)*mask, backward gate*g*mask).  Outputs, gradients, masks,
+    magnitudes and counters equal the module-by-module run and the oracle, before the start step, while the schedule
+    ramps, in steady state and in evaluation."""
+    from qsparse_amd.fused import FusedActPrune, fuse_prune_quantize_pairs
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (6, 24, 4, 8))):
+        runs = []
+        for fold in (True, False):
+            qs.set_qsparse_options(fold_relu=fold)
+            site = nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=2, interval=1, repetition=2)).to(DEV).train()
+            fuse_prune_quantize_pairs(site)
+            assert type(site) is FusedActPrune and str(site).startswith("Sequential(")
+            ps = O.PruneSim(0.5, [1], 2, 1, 2, False)
+            outs = []
+            for s in range(8):
+                training = s < 7
+                if not training:
+                    site.eval()
+                x = (torch.randn(shape, generator=gen(3000 + s)) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dtype)
+                x.view(-1)[:4] = torch.tensor([0.0, -1e-3, 1.0, -1.0]).to(dtype)
+                gout = torch.randn(shape, generator=gen(3100 + s)).to(dtype)
+                xg = x.to(DEV).requires_grad_(True)
+                y = site(xg)
+                y.backward(gout.to(DEV))
+                n_before = ps.n_updates
+                y_ref = ps.step(torch.relu(x), training)
+                gh = ps.grad(gout, (not training) or n_before >= 2)
+                gx_ref = torch.where(x <= 0, torch.zeros_like(gh), gh)
+                assert same(y.detach().cpu(), y_ref), (dtype, fold, s)
+                assert same(xg.grad.cpu(), gx_ref), (dtype, fold, s)
+                assert same(site[1].mask.cpu(), ps.mask) and int(site[1]._n_updates) == ps.n_updates, (dtype, fold, s)
+                if ps.magnitude is not None:
+                    assert same(site[1].callback.magnitude.cpu(), ps.magnitude) and int(site[1].callback.t) == ps.t
+                outs.append((y.detach().clone(), xg.grad.clone()))
+            runs.append(outs)
+        for (ya, ga), (yb, gb) in zip(*runs):
+            assert torch.equal(ya, yb) and same(ga.cpu(), gb.cpu())
+    qs.set_qsparse_options(fold_relu=True)

@@ -57,6 +57,12 @@ def main():
         run(pair, shape, nbuf, 14, "pair: prune(0.75,{1}) -> quantize(4)")
         p = qs.prune(sparsity=0.75, dimensions={1}, start=1, interval=1, repetition=1).to(DEV).train()
         run(p, shape, nbuf, 10, "PruneLayer(0.75,{1}) alone (bf16 in/out)")
+        for fold in (True, False):
+            qs.set_qsparse_options(fold_relu=fold)
+            site = fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.75, dimensions={1}, start=1, interval=1,
+                                                                               repetition=1))).to(DEV).train()
+            run(site, shape, nbuf, 12 if fold else 20, f"ReLU -> PruneLayer(0.75,{{1}}), fold_relu={fold}")
+        qs.set_qsparse_options(fold_relu=True)
 
 
 if __name__ == "__main__":
