@@ -119,6 +119,13 @@ def main():
         print(json.dumps(cpu_baseline(threads=args.cpu_baseline_only)))
         return
 
+    # stdout must carry exactly ONE line, the JSON record of rank 0.  RCCL / MIOpen / the HIP runtime print banners
+    # through C stdio (flushed at exit, i.e. after anything Python printed), so from here on file descriptor 1 is
+    # pointed at stderr for every rank and rank 0 writes its record to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,12 +138,20 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # development aid: QS_BENCH_FORCE_EXCHANGE=1 runs the N=1 bench inside a one-rank RCCL group with the statistics
+    # exchange live, i.e. with the collective's launch + kernel latency on the step's critical path (what every
+    # rank pays at N>1, minus the xGMI hop); the JSON line then says so in config.exchange
+    force_exchange = world == 1 and os.environ.get("QS_BENCH_FORCE_EXCHANGE", "0") == "1"
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if force_exchange:
+            import qsparse_amd as qs
+            qs.set_qsparse_options(sync_statistics="always")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from qsparse_amd import _hip
@@ -220,11 +235,18 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 6 * numel, "kernels": kern},
         }
+        if world > 1 or force_exchange:
+            out["config"]["exchange"] = ("one all-gather of a 2C-float record per step over " +
+                                         ("gloo (shared GPU, development)" if share_gpu else "RCCL") +
+                                         (" in a ONE-rank group (QS_BENCH_FORCE_EXCHANGE)" if force_exchange else ""))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_exchange:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ reduces nor broadcasts); with one process this module is a no-op, so single-GPU 
 
 Collectives go through ``torch.distributed`` (backend "nccl" == RCCL over xGMI on MI355X, "gloo" on
 CPU).  Enabled automatically when a process group with world size > 1 exists; switch off with
-``set_qsparse_options(sync_statistics=False)``.
+``set_qsparse_options(sync_statistics=False)``.  ``sync_statistics="always"`` runs the collectives even in a
+process group of one rank -- the way to exercise the RCCL path on a single-GPU machine.
 """
 from typing import Optional, Tuple
 
@@ -27,10 +28,15 @@ def stats_world_size() -> int:
     return dist.get_world_size()
 
 
+def exchange_active(world: Optional[int] = None) -> bool:
+    world = world or stats_world_size()
+    return world > 1 or (get_option("sync_statistics") == "always" and dist.is_available() and dist.is_initialized())
+
+
 def allreduce_mean(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
     """mean over ranks of a small statistics tensor, in fp32 (returns a new fp32 tensor)."""
     world = world or stats_world_size()
-    if world <= 1:
+    if not exchange_active(world):
         return t
     buf = t.detach().to(torch.float32).contiguous().clone()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
@@ -39,14 +45,14 @@ def allreduce_mean(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
 
 def allreduce_max_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
     world = world or stats_world_size()
-    if world > 1:
+    if exchange_active(world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
 
 def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
     world = world or stats_world_size()
-    if world > 1:
+    if exchange_active(world):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return t
 
@@ -57,7 +63,7 @@ def sync_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[to
     into a 2C-float record, the records are all-gathered and combined in rank order on every rank (mean / max),
     so all ranks end with bit-identical statistics.  GPU tensors: pack/combine are HIP kernels."""
     ref = stage if stage is not None else chan_absmax
-    if ref is None or world <= 1:
+    if ref is None or not exchange_active(world):
         return stage, chan_absmax
     C = stage.numel() if stage is not None else chan_absmax.shape[0]   # chan_absmax: [C] or line-padded [C, 32]
     if ref.is_cuda:

@@ -167,7 +167,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                                          pre_relu=pre_relu).view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
-            if world > 1:
+            if qdist.exchange_active(world):
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
                 mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)

@@ -384,7 +384,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
                 self._advance_t(t_dev)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)
-            if qdist.stats_world_size() > 1:
+            if qdist.exchange_active():
                 bounds = torch.stack([qdist.allreduce_min_(bounds[:, 0].contiguous()),
                                       qdist.allreduce_max_(bounds[:, 1].contiguous())], dim=1)
             self.t += 1

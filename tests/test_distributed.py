@@ -105,3 +105,111 @@ def test_fused_pair_exchange_on_gpu_two_ranks():
             assert torch.equal(a, b), fused                      # ranks agree
     for a, b in zip(res[0][False], res[0][True]):
         assert torch.equal(a, b)                                  # fused exchange == unfused exchange
+
+
+def _ddp_worker(rank, world, port, out):
+    """BASELINE config 5 in miniature: a converted network under DistributedDataParallel (gloo, CPU)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import qsparse_amd as qs
+    from examples.models import MnistNet, convert_pq
+    from qsparse_amd.quantize import QuantizeLayer
+    from qsparse_amd.sparse import PruneLayer
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    torch.manual_seed(0)
+    net = convert_pq(MnistNet(), sparsity=0.5, bits=4, prune_start=2, prune_interval=1, repetition=2, quant_timeout=2, log=False)
+    ddp = DDP(net)
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.05)
+    for step in range(7):
+        g = torch.Generator().manual_seed(500 + step)
+        x, y = torch.randn(8, 1, 28, 28, generator=g), torch.randint(0, 10, (8,), generator=g)
+        xs, ys = x[rank * 4:(rank + 1) * 4] * (1.0 + 0.3 * rank), y[rank * 4:(rank + 1) * 4]
+        opt.zero_grad()
+        F.nll_loss(ddp(xs), ys).backward()
+        opt.step()
+    state = {}
+    for name, m in qs.util.nn_module(ddp).named_modules():
+        if isinstance(m, PruneLayer):
+            state[name + ".mask"] = m.mask.detach().clone()
+        elif isinstance(m, QuantizeLayer) and m.initted:
+            state[name + ".weight"] = m.weight.detach().clone()
+    state.update({"param." + k: v.detach().clone() for k, v in net.named_parameters() if v.requires_grad})
+    out.put((rank, {k: v.numpy().copy() for k, v in state.items()}))    # by value: the worker may exit before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_converted_network_under_ddp_keeps_ranks_identical():
+    """weights follow DDP's gradient all-reduce; masks and scales (requires_grad=False parameters DDP neither
+    reduces nor re-broadcasts) follow the statistics exchange: after training on different shards every rank
+    holds the same network."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(out.get(timeout=300) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert res[0].keys() == res[1].keys() and any(k.endswith(".mask") for k in res[0]) and any(k.endswith(".weight") for k in res[0])
+    import numpy as np
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert any((~v).any() for k, v in res[0].items() if k.endswith(".mask"))     # something was pruned
+
+
+def _rccl_worker(port, out):
+    """one rank, backend nccl (= RCCL): the collectives really run, on the stream the kernels run on."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.nn as nn
+    import qsparse_amd as qs
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    torch.cuda.set_device(0)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+
+    def run(tag):
+        pair = nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2)),
+                             qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train()
+        fuse_prune_quantize_pairs(pair)
+        lone_q = qs.quantize(bits=8, channelwise=-1, timeout=1).cuda().train()
+        lone_a = qs.quantize(bits=8, channelwise=1, timeout=1, callback=qs.AdaptiveQuantizer()).cuda().train()
+        lone_p = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1).cuda().train()
+        outs = []
+        for step in range(5):
+            g = torch.Generator().manual_seed(900 + step)
+            x = (torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().cuda().requires_grad_(True)
+            y = pair(x)
+            y.backward(torch.ones_like(y))
+            outs += [y.detach().float().cpu().numpy(), x.grad.float().cpu().numpy(), lone_q(x.detach()).float().cpu().numpy(),
+                     lone_a(x.detach()).float().cpu().numpy(), lone_p(x.detach()).float().cpu().numpy()]
+        outs += [pair[0][1].mask.cpu().numpy(), pair[1].weight.detach().cpu().numpy(), lone_a.weight.detach().cpu().numpy()]
+        return outs
+
+    plain = run("no process group")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    qs.set_qsparse_options(sync_statistics="always")
+    with_rccl = run("rccl, one rank")
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    out.put((plain, with_rccl))
+
+
+@pytest.mark.gpu
+def test_statistics_exchange_through_rccl_with_one_rank():
+    """the exchange with backend nccl (RCCL) in a one-rank group -- all-gather of the packed record, all-reduces of
+    the stand-alone layers -- leaves every output and state bit-identical to the run without a process group."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    pr = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    pr.start()
+    plain, with_rccl = out.get(timeout=600)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    assert len(plain) == len(with_rccl) > 0
+    for a, b in zip(plain, with_rccl):
+        assert np.array_equal(a, b)
