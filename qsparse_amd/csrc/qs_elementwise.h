@@ -24,6 +24,21 @@ struct EwGeom {
 //   float apply(float v, const P&, int32_t& code) const
 // ------------------------------------------------------------------------------------------------
 
+// rint(RN(v / s)) given r = RN(1/s), without dividing in the common case (see ScalerFwdOp::quotient_rint for the
+// error argument); r = NaN forces the division.
+__device__ __forceinline__ float rint_of_quotient(float v, float s, float r) {
+    const float t = v * r;
+    const float n = rintf(t);
+    const float off = fabsf(fabsf(t - n) - 0.5f);      // distance of t from the nearest k + 0.5
+    if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return n;   // 2^-21
+    return rintf(v / s);
+}
+__device__ __forceinline__ float guarded_reciprocal(float s) {
+    float r = 1.0f / s;
+    if (fabsf(r) < 1.17549435e-38f) r = __builtin_nanf("");   // subnormal reciprocal: always divide
+    return r;
+}
+
 // ScalerQuantization.forward  (reference qsparse/quantize.py:100-117)
 template <int QDT>
 struct ScalerFwdOp {
@@ -41,8 +56,7 @@ struct ScalerFwdOp {
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         p.s = scale ? scale[c] : scale_host;
-        p.r = 1.0f / p.s;
-        if (fabsf(p.r) < 1.17549435e-38f) p.r = __builtin_nanf("");   // subnormal reciprocal: always divide
+        p.r = guarded_reciprocal(p.s);
         p.keep = 1.0f;
         return p;
     }
@@ -59,12 +73,7 @@ struct ScalerFwdOp {
         if constexpr (QDT != QS_F32) {
             return rintf(round_through<QDT>(v / p.s));   // quotient rounded to the input dtype first
         } else {
-            const float t = v * p.r;
-            const float n = rintf(t);
-
-            const float off = fabsf(fabsf(t - n) - 0.5f);      // distance of t from the nearest k + 0.5
-            if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return n;   // 2^-21
-            return rintf(v / p.s);
+            return rint_of_quotient(v, p.s, p.r);
         }
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
@@ -122,16 +131,18 @@ template <bool FLOAT_ZP>
 struct LineFwdOp {
     const float* lines;  // device [nlines, 2]
     float nlevels;       // 2^bits
+    float inv_levels;    // 2^-bits (exact)
     struct P {
-        float start, end, step, qstart;
+        float start, end, step, qstart, r;
     };
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         p.start = lines[2 * c];
         p.end = lines[2 * c + 1];
-        float st = (p.end - p.start) / nlevels;          // :159
+        float st = (p.end - p.start) * inv_levels;       // :159; nlevels = 2^bits, so the product IS the correctly rounded quotient
         p.step = (st == 0.0f) ? 0.0001f : st;            // :160
-        p.qstart = FLOAT_ZP ? 0.0f : rintf(p.start / p.step);
+        p.r = guarded_reciprocal(p.step);                // every quotient below goes through rint_of_quotient
+        p.qstart = FLOAT_ZP ? 0.0f : rint_of_quotient(p.start, p.step, p.r);
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c, uint32_t) const { return channel(c); }
@@ -141,14 +152,13 @@ struct LineFwdOp {
         const float top = nlevels - 1.0f;
         if constexpr (FLOAT_ZP) {                        // :175-181
             float t = xc - p.start;
-            t = t / p.step;
-            t = rintf(t);
+            t = rint_of_quotient(t, p.step, p.r);        // ((x - start) / step).round()
             t = fminf(fmaxf(t, 0.0f), top);
             code = (int32_t)t;
             t = t * p.step;
             return t + p.start;
         } else {                                         // :161-166
-            float qa = rintf(xc / p.step);
+            float qa = rint_of_quotient(xc, p.step, p.r);  // (x / step).round()
             qa = fminf(fmaxf(qa - p.qstart, 0.0f), top);
             code = (int32_t)qa;
             return (qa + p.qstart) * p.step;

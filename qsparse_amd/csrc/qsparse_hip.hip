@@ -267,10 +267,10 @@ int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         if (float_zero_point) {
-            LineFwdOp<true> op{lines, nlevels};
+            LineFwdOp<true> op{lines, nlevels, 1.0f / nlevels};
             return launch_ew<LineFwdOp<true>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
         }
-        LineFwdOp<false> op{lines, nlevels};
+        LineFwdOp<false> op{lines, nlevels, 1.0f / nlevels};
         return launch_ew<LineFwdOp<false>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
     });
 }

@@ -127,6 +127,39 @@ def test_scaler_codes_around_halfway_points():
         assert same(codes.cpu(), O.scaler_codes(xc, sc, 1)), seed
 
 
+def test_line_levels_around_halfway_points():
+    """LineQuantization goes through the same division-free quotient: hammer +-3 ulp around every level boundary
+    start + (k + 0.5) * step (training form) and (k + 0.5) * step (evaluation form), tensor-wise and per-channel."""
+    for seed in range(5):
+        bits = (4, 8, 6, 3, 8)[seed]
+        n = 2 ** bits
+        lo = -torch.rand(8, 1, generator=gen(80 + seed)) * (10.0 ** (seed - 2)) - 1e-3
+        hi = torch.rand(8, 1, generator=gen(90 + seed)) * (10.0 ** (seed - 2)) + 1e-3
+        lines = torch.cat([lo, hi], 1)
+        step = (hi - lo) / n
+        ks = torch.arange(-2, n + 2, dtype=torch.float32) + 0.5
+        cols = []
+        for base in (lo + ks.view(1, -1) * step, ks.view(1, -1) * step + torch.zeros_like(lo)):
+            up, dn = base.clone(), base.clone()
+            cols.append(base)
+            for _ in range(3):
+                up = torch.nextafter(up, torch.full_like(up, float("inf")))
+                dn = torch.nextafter(dn, torch.full_like(dn, float("-inf")))
+                cols += [up.clone(), dn.clone()]
+        x = torch.cat(cols + [torch.randn(8, 512, generator=gen(95 + seed)) * (hi - lo)], 1)
+        x = torch.cat([x, x.new_zeros(8, (-x.shape[1]) % 8)], 1).view(1, 8, -1).contiguous()
+        for fzp in (True, False):
+            y = quantize_with_line(x.to(DEV), bits, lines.to(DEV), 1, False, fzp)
+            assert same(y.cpu(), O.line_fwd(x, bits, lines, 1, fzp)), (seed, fzp, "per-channel")
+            y = quantize_with_line(x[:, :1].contiguous().to(DEV), bits, lines[:1].to(DEV), -1, False, fzp)
+            assert same(y.cpu(), O.line_fwd(x[:, :1].contiguous(), bits, lines[:1], -1, fzp)), (seed, fzp, "tensor-wise")
+    # degenerate rows: step == 0 is replaced by 1e-4 (quantize.py:160)
+    flat = torch.tensor([[0.5, 0.5], [-1.0, 1.0]])
+    xz = torch.randn(1, 2, 64, generator=gen(99))
+    for fzp in (True, False):
+        assert same(quantize_with_line(xz.to(DEV), 4, flat.to(DEV), 1, False, fzp).cpu(), O.line_fwd(xz, 4, flat, 1, fzp))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_decimal_and_line_vs_oracle(dtype):
     shape = (4, 24, 14, 14)
