@@ -437,13 +437,15 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
         Cascade acc[8];
         // MODE 1 (|x|) and 2 (max(x,0)) are the hot configurations: the mean operand and the abs-max key are the
         // same non-negative value, 3-5 VALU ops per element (the wave count per CU is low, so VALU time is not
-        // hidden); MODE 0 handles every other flag combination
+        // hidden); MODE 3 is the plain mean without abs-max; MODE 0 handles every other flag combination
         auto consume = [&](const Raw8<DT>& r) {
             float v[8];
             unpack8<DT>(r, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if constexpr (MODE == 0) {
+                if constexpr (MODE == 3) {          // plain mean (squeeze_tensor_to_shape on its own): no abs, no abs-max
+                    acc[j].add(v[j]);
+                } else if constexpr (MODE == 0) {
                     if (absmax) {
                         const float av = (flags & QS_MEAN_RELU) ? fmaxf(v[j], 0.0f) : v[j];
                         const uint32_t k = __float_as_uint(av) & 0x7fffffffu;

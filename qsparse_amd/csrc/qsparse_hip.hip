@@ -472,8 +472,12 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
                 const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
                 if (R == 1) {
-                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
-                    if (mode == 1)
+                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                                    (flags == 0 && !am ? 3 : 0)));
+                    if (mode == 3)
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 3>), dim3(blocks), dim3(64), 0,
+                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
+                    else if (mode == 1)
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 1>), dim3(blocks), dim3(64), 0,
                                            s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
                     else if (mode == 2)

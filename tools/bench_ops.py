@@ -74,7 +74,7 @@ def main():
         report("abs-max tensor-wise bf16", lambda: _hip.absmax(xb, -1), 2 * n)
         report("abs-max per-channel bf16", lambda: _hip.absmax(xb, 1), 2 * n)
         report("min/max per-channel bf16 (Adaptive)", lambda: _hip.minmax(xb, 1), 2 * n)
-        report("staged mean |x| -> (1,C,1,1) bf16", lambda: squeeze_tensor_to_shape(xb, (1, C, 1, 1)), 2 * n)
+        report("staged mean x -> (1,C,1,1) bf16 (squeeze_tensor_to_shape)", lambda: squeeze_tensor_to_shape(xb, (1, C, 1, 1)), 2 * n)
         del xb, g, mask_full
         torch.cuda.empty_cache()
     # ragged inner (7x7) and 2-d
@@ -83,7 +83,8 @@ def main():
     m7 = torch.rand(1, 2048, 1, 1, device=dev) > 0.5
     sc7 = torch.rand(2048, 1, device=dev) * 0.1 + 0.01
     print(f"--- shape {tuple(x7.shape)} ({n/1e6:.1f} M elements, inner=49)")
-    report("scaler fwd bf16->f32 tensor-wise", lambda: quantize_with_scaler(x7, 8, torch.tensor([[0.05]], device=dev)), 6 * n)
+    s7 = torch.tensor([[0.05]], device=dev)
+    report("scaler fwd bf16->f32 tensor-wise", lambda: quantize_with_scaler(x7, 8, s7), 6 * n)
     report("scaler fwd bf16->f32 per-channel (element-wise channel walk)", lambda: quantize_with_scaler(x7, 8, sc7, 1), 6 * n)
     report("mask apply bf16 channel mask (element-wise channel walk)", lambda: _hip.mask_apply(x7, m7), 4 * n)
     report("abs-max per-channel bf16 (rows of 49)", lambda: _hip.absmax(x7, 1), 2 * n)
