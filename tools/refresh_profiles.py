@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Regenerates the evidence under profiles/ on an MI355X box (writes to gpurun_out/profiles/, to be copied):
+
+  rNN_bench_default.json                 the JSON record of a plain `python3 bench.py`
+  rNN_bench_kernel_stats.csv             rocprofv3 --kernel-trace --stats summary of the same command
+  rNN_bench_step_timeline.txt            the last three steps of that trace, kernel by kernel
+  rNN_pmc_<COUNTER>_counter_collection.csv   rocprofv3 --pmc <COUNTER> rows of the library's kernels (one pass per counter)
+  rNN_pmc_traffic.json                   HBM bytes per launch of the three streaming kernels, corrected as
+                                         /opt/skills/guides/MI355X_MICROARCH.md prescribes, next to the algorithmic bytes
+
+usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r01]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+OUT = os.path.join(ROOT, "gpurun_out", "profiles")
+BENCH = os.path.join(ROOT, "bench.py")
+ENV = dict(os.environ, TMPDIR="/tmp")
+NUMEL = 256 * 256 * 56 * 56
+
+
+def sh(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    return subprocess.run(cmd, cwd="/tmp", env=ENV, text=True, **kw)
+
+
+def find(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    assert hits, f"nothing matches {pattern}"
+    return hits[-1]
+
+
+def main():
+    shutil.rmtree(OUT, ignore_errors=True)
+    os.makedirs(OUT)
+
+    # 1. the plain command
+    r = sh(["python3", BENCH], stdout=subprocess.PIPE)
+    assert r.returncode == 0
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    with open(os.path.join(OUT, f"{TAG}_bench_default.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+
+    # 2. kernel stats of the same command
+    d = os.path.join(OUT, "stats")
+    assert sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+               "python3", BENCH]).returncode == 0
+    shutil.copy(find(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(OUT, f"{TAG}_bench_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(find(os.path.join(d, "**", "*kernel_trace.csv")))))
+    rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+    qs_rows = [x for x in rows if "qs::" in x["Kernel_Name"]]
+    tail = qs_rows[-15:]
+    with open(os.path.join(OUT, f"{TAG}_bench_step_timeline.txt"), "w") as f:
+        f.write("rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py\n")
+        f.write("last 3 steps of the timed region (durations under the profiler; a gap holds a HIP event pair on sampled steps)\n\n")
+        prev_end = None
+        for x in tail:
+            s, e = int(x["Start_Timestamp"]), int(x["End_Timestamp"])
+            gap = 0.0 if prev_end is None else (s - prev_end) / 1e3
+            name = x["Kernel_Name"].split("(")[0]
+            f.write(f"{name:72s} dur={(e - s) / 1e3:8.1f}us gap={gap:6.1f}us grid={x.get('Grid_Size_X', x.get('Grid_Size', '?')):>10s} wg={x.get('Workgroup_Size_X', x.get('Workgroup_Size', '?')):>4s} "
+                    f"vgpr={x.get('VGPR_Count', '?')}\n")
+            prev_end = e
+    shutil.rmtree(d)
+
+    # 3. PMC passes, one counter each (never combined with other trace domains)
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(OUT, "pmc_" + counter)
+        assert sh(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+                   "python3", BENCH, "--steps", "8", "--warmup", "3", "--no-cpu-baseline"]).returncode == 0
+        src = find(os.path.join(d, "**", "*counter_collection.csv"))
+        rows = [x for x in csv.DictReader(open(src)) if "qs::" in x["Kernel_Name"]]
+        rows = rows[-8 * 5:]                                     # the 8 timed steps, 5 launches each
+        with open(os.path.join(OUT, f"{TAG}_pmc_{counter}_counter_collection.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+            w.writeheader()
+            w.writerows(rows)
+        for x in rows:
+            per.setdefault(x["Kernel_Name"].split("(")[0], {}).setdefault(counter, []).append(float(x["Counter_Value"]))
+        shutil.rmtree(d)
+
+    def pick(sub):
+        names = [k for k in per if sub in k]
+        assert len(names) == 1, (sub, list(per))
+        return names[0]
+
+    kernels = {"apply_fwd": (pick("ew_widen_kernel<qs::ScalerFwdOp"), 6 * NUMEL), "apply_bwd": (pick("SteBwdOp"), 6 * NUMEL),
+               "stats": (pick("mean_outer_vec_kernel"), 2 * NUMEL)}
+    traffic = {
+        "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 8 --warmup 3 "
+                   "--no-cpu-baseline  (one pass per counter; tools/refresh_profiles.py)",
+        "unit": "bytes per launch",
+        "correction": "FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts a wide coalesced streaming "
+                      "read at exactly half its bytes (MI355X_MICROARCH.md, HBM section), so fetch bytes = FETCH_SIZE*1024*2.  "
+                      "That section calibrates 16-byte/lane loads (apply backward, statistics); the apply-forward kernel reads "
+                      "8 bytes/lane, which it leaves uncalibrated, so it is calibrated here on its known input: "
+                      "FETCH_SIZE*1024*2 reproduces the 411,041,792-byte bf16 tensor, i.e. the same factor holds.  "
+                      "WRITE_SIZE is used as reported.",
+        "kernels": {},
+    }
+    for key, (name, algo) in kernels.items():
+        fk = sum(per[name]["FETCH_SIZE"]) / len(per[name]["FETCH_SIZE"])
+        wk = sum(per[name]["WRITE_SIZE"]) / len(per[name]["WRITE_SIZE"])
+        hbm = int(fk * 1024 * 2 + wk * 1024)
+        traffic["kernels"][key] = {"kernel": name, "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
+                                   "hbm_bytes": hbm, "algorithmic_bytes": algo, "ratio": round(hbm / algo, 4)}
+    with open(os.path.join(OUT, f"{TAG}_pmc_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print(json.dumps({k: v["ratio"] for k, v in traffic["kernels"].items()}))
+    print("value", rec["value"], "ms/step", rec["ms_per_step"], "frac", rec["roofline"]["frac"])
+
+
+if __name__ == "__main__":
+    main()
