@@ -14,7 +14,10 @@ module by module that is, per training step, 2 statistics reads + 2 element-wise
 
 The state machines of both layers (schedules, counters, refresh policy: reference sparse.py:215-273,
 99-122 and quantize.py:473-518, 327-349) advance exactly as if the layers had run one after the other;
-``tests/test_fused_gpu.py`` checks the trajectories against the unfused path and the oracle.
+``tests/test_gpu_parity.py`` checks the trajectories against the unfused path and the oracle.
+
+The same idea one operator at a time: ``FusedActQuantize`` and ``FusedActPrune`` fold a plain ``nn.ReLU`` into a lone
+quantize / prune site (``Sequential(act, op)``), see the classes below.
 """
 from typing import Optional
 
