@@ -24,6 +24,20 @@ struct EwGeom {
 //   float apply(float v, const P&, int32_t& code) const
 // ------------------------------------------------------------------------------------------------
 
+// float -> int32 as ATen's CPU kernels do it (cvttps2dq): NaN and everything outside [-2^31, 2^31) give INT_MIN, the
+// x86 "integer indefinite".  Only reachable with a zero / denormal scale (an all-zero tensor), where the reference's
+// output is -0.0 everywhere; v_cvt_i32_f32 alone would saturate and give +0.0 for NaN and +inf.
+#ifndef QS_X86_CVT
+#define QS_X86_CVT 1
+#endif
+__device__ __forceinline__ int32_t f32_to_i32_x86(float q) {
+#if QS_X86_CVT
+    return (fabsf(q) < 2147483648.0f) ? (int32_t)q : (int32_t)0x80000000;
+#else
+    return (int32_t)q;
+#endif
+}
+
 // rint(RN(v / s)) given r = RN(1/s), without dividing in the common case (see ScalerFwdOp::quotient_rint for the
 // error argument); r = NaN forces the division.
 __device__ __forceinline__ float rint_of_quotient(float v, float s, float r) {
@@ -32,6 +46,15 @@ __device__ __forceinline__ float rint_of_quotient(float v, float s, float r) {
     const float off = fabsf(fabsf(t - n) - 0.5f);      // distance of t from the nearest k + 0.5
     if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return n;   // 2^-21
     return rintf(v / s);
+}
+// the same as an int32 code.  The fast path only sees |t| < 2^22 (beyond that `off` is 0.5 or 0 and the test fails),
+// so the x86 conversion rule for NaN / out-of-range values costs nothing there.
+__device__ __forceinline__ int32_t rint_of_quotient_i32(float v, float s, float r) {
+    const float t = v * r;
+    const float n = rintf(t);
+    const float off = fabsf(fabsf(t - n) - 0.5f);
+    if (__builtin_expect(off > fabsf(t) * 4.76837158203125e-07f, 1)) return (int32_t)n;
+    return f32_to_i32_x86(rintf(v / s));
 }
 __device__ __forceinline__ float guarded_reciprocal(float s) {
     float r = 1.0f / s;
@@ -79,7 +102,9 @@ struct ScalerFwdOp {
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         if (pre_relu) v = fmaxf(v, 0.0f);
         v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
-        int32_t qi = (int32_t)quotient_rint(v, p);   // round(x / s).int(): half-to-even (:109)
+        int32_t qi;                                   // round(x / s).int(): half-to-even (:109)
+        if constexpr (QDT != QS_F32) qi = f32_to_i32_x86(quotient_rint(v, p));
+        else qi = rint_of_quotient_i32(v, p.s, p.r);
         if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
         code = qi;
         return (float)qi * p.s;                  // q.float() * scaler (:117)
@@ -119,7 +144,7 @@ struct DecimalFwdOp {
         if (pre_relu) v = fmaxf(v, 0.0f);
         v = v * p.keep;
         float q = round_through<QDT>(v * p.toi);
-        int32_t qi = (int32_t)q;                 // .int(): truncation toward zero (:55)
+        int32_t qi = f32_to_i32_x86(q);          // .int(): truncation toward zero (:55)
         if (saturate) qi = qi < lo ? lo : (qi > hi ? hi : qi);
         code = qi;
         return (float)qi * p.tof;

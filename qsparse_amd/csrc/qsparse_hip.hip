@@ -124,7 +124,7 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
     if constexpr (YDT == QS_F32) {   // QS_EW_WIDEN: 0 off, 1 two-byte inputs only, 2 (default) fp32 inputs as well
         if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && plan.cm != CM_ELEM) {
             const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
-            const int gridw = (int)((waves + kBlock / 64 - 1) / (kBlock / 64));
+            const int gridw = (int)std::max<int64_t>(1, (waves + kBlock / 64 - 1) / (kBlock / 64));   // < 8 elements: tail only
             if (plan.cm == CM_SCALAR)
                 hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
@@ -610,7 +610,10 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
     // pattern A: [outer bcast][C dense, unit stride][inner bcast]
     int64_t outer = 1, C = 1, inner = 1;
     bool pattern_a = false, full = false;
-    if (nd == 1 && cm[0] == 1) full = true;
+    if (nd == 1 && cm[0] == 1) {
+        if (pre_relu) { pattern_a = true; C = cs[0]; }   // every element has its own mask entry: a channel mask with inner = 1
+        else full = true;
+    }
     else if (nd == 1 && cm[0] == 0) { pattern_a = true; outer = cs[0]; }
     else if (nd == 2 && cm[0] == 0 && cm[1] == 1) { pattern_a = true; outer = cs[0]; C = cs[1]; }
     else if (nd == 2 && cm[0] == 1 && cm[1] == 0) { pattern_a = true; C = cs[0]; inner = cs[1]; }

@@ -163,11 +163,17 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 bump_q = on_dev(q._n_updates) if q_counts else None
                 bump_t = on_dev(cb.t) if (p_counts and n >= p.start) else None
             if update_mag:
-                if update_scale:
-                    chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 dims = _reduction_plan(hd.shape, p.mask.shape)
-                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax, absmax_channel_dim=1,
-                                         pre_relu=pre_relu).view(-1)
+                # the per-channel abs-max rides along in the first statistics stage when that stage reduces a dim
+                # in front of the channel dim (the batch); with a batch of one there is no such stage and the
+                # abs-max is a pass of its own
+                rides = update_scale and bool(dims) and dims[0] < 1
+                if rides:
+                    chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
+                elif update_scale:
+                    chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
+                stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax if rides else None,
+                                         absmax_channel_dim=1, pre_relu=pre_relu).view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
             if qdist.exchange_active(world):

@@ -116,8 +116,8 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         shape[d] = 1
         cur = cur.view(shape)
         first = False
-    if first and take_abs:  # nothing to reduce: importance is |x| itself
-        cur = cur.abs()
+    if first and take_abs:  # nothing to reduce: importance is |x| itself (|max(x, 0)| under a folded ReLU)
+        cur = torch.relu(cur) if pre_relu else cur.abs()
     return cur
 
 

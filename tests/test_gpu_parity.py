@@ -763,3 +763,27 @@ def test_relu_prune_site_fold_is_bit_identical():
         for (ya, ga), (yb, gb) in zip(*runs):
             assert torch.equal(ya, yb) and same(ga.cpu(), gb.cpu())
     qs.set_qsparse_options(fold_relu=True)
+
+
+def test_out_of_range_codes_follow_the_cpu_conversion():
+    """a zero scale (all-zero tensor) or a huge quotient leaves the int32 range; ATen's CPU cast then yields INT_MIN
+    (x86 integer indefinite) and the reference's output is float(INT_MIN) * s -- e.g. -0.0 everywhere for s == 0.
+    The kernels reproduce that instead of the GPU's saturating conversion."""
+    x = torch.tensor([0.0, -0.0, 1.0, -1.0, 3e38, -3e38, float("inf"), float("-inf"), float("nan"), 5.0, 1e-30, 7.5] + [0.25] * 20)
+    for s in (0.0, 1e-38, 1e-30, 0.5):
+        sc = torch.tensor([[s]])
+        y, codes = _hip.quant_fwd("scaler", x.to(DEV), sc.to(DEV), -1, torch.float32, want_codes=True)
+        assert same(codes.cpu(), O.scaler_codes(x, sc.view(1), -1)), s
+        assert same(y.cpu(), O.scaler_fwd(x, 8, sc.view(1))), s
+    for d in (0.0, 100.0, 127.0, -3.0):
+        dc = torch.tensor([[d]])
+        y, codes = _hip.quant_fwd("decimal", x.to(DEV), dc.to(DEV), -1, torch.float32, want_codes=True)
+        assert same(codes.cpu(), O.decimal_codes(x, dc.view(1), -1).view(-1)), d
+        assert same(y.cpu(), O.decimal_fwd(x, 8, dc.view(1)).view(-1)), d
+    # an activation that is zero everywhere: the layer's scale becomes 0 and stays usable
+    q_gpu, q_cpu = (qs.quantize(bits=4, channelwise=-1, timeout=1) for _ in range(2))
+    q_gpu.to(DEV)
+    z = torch.zeros(2, 4, 3, 3)
+    for step in range(3):
+        xin = z if step < 2 else z + torch.randn(2, 4, 3, 3, generator=gen(7))
+        assert same(q_gpu(xin.to(DEV)).cpu(), q_cpu(xin)), step

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Randomised differential test: convert-style activation sites on the GPU against the CPU oracle's state machines
+(oracle/qs_oracle.py: PruneSim, QuantizeSim), bit for bit, over random shapes, dtypes, schedules, site kinds and
+training/evaluation switches.  Development tool (the fixed cases live in tests/); usage:
+    python3 tools/fuzz_parity.py [cases=200] [seed=0]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.nn as nn
+
+import qsparse_amd as qs
+from golden_io import same
+from oracle import qs_oracle as O
+from qsparse_amd.fused import fuse_prune_quantize_pairs
+
+DEV = os.environ.get("QS_FUZZ_DEVICE", "cuda")
+LAST = None
+VERBOSE = bool(os.environ.get("QS_FUZZ_ONLY"))
+
+
+def rand_shape(rng):
+    kind = rng.choice(["nchw", "nchw", "nchw", "nc", "ncl", "ncdhw"])
+    n = rng.choice([1, 2, 3, 4, 8, 16, 17, 32, 33, 64, 100])
+    c = rng.choice([2, 3, 8, 16, 24, 31, 64, 130, 256, 300])
+    if kind == "nc":
+        return (n, c)
+    if kind == "ncl":
+        return (n, c, rng.choice([1, 5, 8, 49, 64, 100]))
+    if kind == "ncdhw":
+        return (min(n, 8), min(c, 32), rng.choice([1, 2, 3]), rng.choice([2, 4, 7]), rng.choice([2, 4, 8]))
+    hw = rng.choice([(1, 1), (2, 2), (4, 4), (7, 7), (8, 8), (14, 14), (5, 9), (16, 16), (3, 32)])
+    if n * c * hw[0] * hw[1] > 2_000_000:
+        n = max(1, 2_000_000 // (c * hw[0] * hw[1]))
+    return (n, c) + hw
+
+
+def one_case(rng, idx):
+    shape = rand_shape(rng)
+    dtype = rng.choice([torch.bfloat16, torch.float32, torch.float16])
+    site_kind = rng.choice(["pair", "pair", "relu_pair", "relu_pair", "q", "relu_q", "p", "relu_p"])
+    kind = rng.choice(["scaler", "scaler", "decimal"])
+    bits = rng.choice([2, 4, 8])
+    sparsity = rng.choice([0.25, 0.5, 0.75, 0.9])
+    start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2, 3])
+    timeout = rng.choice([1, 2, 3])
+    fold = rng.random() < 0.7
+    steps = rng.choice([4, 6, 8])
+    eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
+    global LAST
+    desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
+                interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from)
+    if DRY or len(shape) < 2 or shape[1] < 2:
+        return None
+    if VERBOSE:
+        print(desc, flush=True)
+    k = max(int(sparsity * shape[1] - 1), 0) + 1
+    if k >= shape[1]:
+        return None
+    qs.set_qsparse_options(fold_relu=fold)
+    cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
+    has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
+    has_p = has_p or "pair" in site_kind
+    act = nn.ReLU() if has_relu else nn.Identity()
+    p = qs.prune(sparsity=sparsity, dimensions={1}, start=start, interval=interval, repetition=rep) if has_p else None
+    q = qs.quantize(bits=bits, channelwise=-1, timeout=timeout, callback=cbs[kind]()) if has_q else None
+    if has_p and has_q:
+        site = nn.Sequential(nn.Sequential(act, p), q)
+    else:
+        site = nn.Sequential(act, p if has_p else q)
+    site = fuse_prune_quantize_pairs(site.to(DEV).train())
+    ps = O.PruneSim(sparsity, [1], start, interval, rep, False) if has_p else None
+    qsim = O.QuantizeSim(kind, bits, -1, timeout) if has_q else None
+    g = torch.Generator().manual_seed(1000 + idx)
+    C = shape[1]
+    chan = torch.linspace(0.3, 3, C).view([1, C] + [1] * (len(shape) - 2))
+    for s in range(steps):
+        training = s < eval_from
+        site.train(training)
+        x = (torch.randn(shape, generator=g) * chan).to(dtype)
+        x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
+        xg = x.to(DEV).requires_grad_(True)
+        y = site(xg)
+        gout = torch.randn(shape, generator=g).to(y.dtype)
+        y.backward(gout.to(DEV))
+        h = torch.relu(x) if has_relu else x
+        n_before = ps.n_updates if ps else 0
+        r = ps.step(h, training) if ps else h
+        y_ref = qsim.step(r, training) if qsim else r
+        gr = gout
+        if qsim:
+            gr = qsim.grad(gr.to(y_ref.dtype), dtype)
+        if ps:
+            gr = ps.grad(gr, (not training) or n_before >= start)
+        if has_relu:
+            gr = torch.where(x <= 0, torch.zeros_like(gr), gr)
+        ok = same(y.detach().cpu(), y_ref) and same(xg.grad.cpu(), gr.to(dtype))
+        if VERBOSE:
+            print(s, "y", same(y.detach().cpu(), y_ref), "gx", same(xg.grad.cpu(), gr.to(dtype)),
+                  "mask", (same((site[0][1] if has_q else site[1]).mask.cpu(), ps.mask) if ps else None),
+                  "scale", (site[1].weight.detach().cpu().flatten().tolist(), None if qsim.weight is None else qsim.weight.flatten().tolist())
+                  if qsim else None, flush=True)
+        if ps:
+            pl = site[0][1] if has_q else site[1]
+            ok = ok and same(pl.mask.cpu(), ps.mask) and int(pl._n_updates) == ps.n_updates
+            if ps.magnitude is not None:
+                ok = ok and same(pl.callback.magnitude.cpu(), ps.magnitude) and int(pl.callback.t) == ps.t
+        if qsim:
+            ql = site[1]
+            ok = ok and int(ql._n_updates) == qsim.n_updates and (qsim.weight is None or same(ql.weight.detach().cpu(), qsim.weight))
+        if not ok:
+            return dict(desc, failed_step=s)
+    return "ok"
+
+
+def _skip(rng, idx):
+    """consume exactly the random draws of one_case without running it"""
+    global DRY
+    DRY = True
+    try:
+        return one_case(rng, idx)
+    finally:
+        DRY = False
+
+
+DRY = False
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = random.Random(seed)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    ran = fails = 0
+    only = os.environ.get("QS_FUZZ_ONLY")
+    for i in range(cases):
+        try:
+            if only is not None and i != int(only):
+                r = one_case.__wrapped__(rng, i) if False else _skip(rng, i)
+                continue
+            r = one_case(rng, i)
+        except Exception as e:      # noqa: BLE001 -- a fuzz driver reports and goes on
+            r = dict(LAST or {}, i=i, exception=repr(e)[:300])
+        if r is None:
+            continue
+        ran += 1
+        if r != "ok":
+            fails += 1
+            print("FAIL", r, flush=True)
+    print(f"fuzz: {ran} cases, {fails} failures (seed {seed})")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
