@@ -55,6 +55,15 @@ def _gpu_dtype_guard(x: torch.Tensor, qd: torch.dtype):
             f"HIP quantizers support float32/bfloat16/float16 inputs with float32 parameters, got {x.dtype} -> {qd}")
 
 
+def _reference_shape(y: torch.Tensor, x: torch.Tensor, param) -> torch.Tensor:
+    """the reference broadcasts the input against the parameter tensor (``input / scaler``): a tensor-wise parameter of
+    shape (1, 1) -- what QuantizeLayer holds -- turns a 1-d input such as a bias into a (1, C) output (which nn.Linear
+    accepts and nn.Conv2d rejects, in the reference as here).  The kernels work on x's shape; restore that quirk."""
+    if isinstance(param, torch.Tensor) and param.numel() == 1 and param.dim() > x.dim():
+        return y.view(torch.broadcast_shapes(tuple(x.shape), tuple(param.shape)))
+    return y
+
+
 class _SteFunction(torch.autograd.Function):
     """shared backward of the scaler and decimal quantizers (reference quantize.py:66-77, 120-131)."""
 
@@ -93,7 +102,7 @@ class ScalerQuantization(_SteFunction):
                 assert len(scaler) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
             y, _ = _hip.quant_fwd("scaler", input, scaler, channel_index, qd, out_dtype=_out_dtype(input))
-            return y
+            return _reference_shape(y, input, scaler)
         s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
         codes = torch.round(input / s).int()
         return (codes.float() * s).to(_out_dtype(input))  # no saturation: see module docstring
@@ -120,7 +129,7 @@ class DecimalQuantization(_SteFunction):
                 assert len(decimal) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
             y, _ = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input))
-            return y
+            return _reference_shape(y, input, decimal)
         to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
         to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
         return ((input * to_int).int().float() * to_float).to(_out_dtype(input))

@@ -75,6 +75,12 @@ def _importance(x: torch.Tensor, shape, l0: bool = False, pre_relu: bool = False
         flag = _hip.l0_flag(x) if l0 else None
         if l0 and not dims:   # nothing to reduce: materialise (x != 0).float() or |x| via the flag
             return torch.where(flag.bool(), (x != 0).float(), x.abs().float())
+        if l0 and x.dtype != torch.float32:
+            # the L0 substitute is a float32 tensor, |x| stays in x's dtype, and the staged means round to whichever
+            # it is: for 2-byte inputs the choice changes the arithmetic, so it is taken on the host like the
+            # reference's own `x.min().item()` (sparse.py:85)
+            if not bool(flag.item()):
+                flag = None
         return _staged_mean_hip(x, dims, take_abs=True, l0_flag=flag)
     if l0 and x.min().item() == 0:
         x = (x != 0).float()

@@ -7,6 +7,8 @@ Bars (north_star): integer codes, masks, indices and counters bit-exact; floatin
 1e-6 relative -- and in fact every float comparison below is asserted bit-exact too, because each
 kernel performs the reference's fp32 operator chain with one rounding per operator.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -787,3 +789,48 @@ def test_out_of_range_codes_follow_the_cpu_conversion():
     for step in range(3):
         xin = z if step < 2 else z + torch.randn(2, 4, 3, 3, generator=gen(7))
         assert same(q_gpu(xin.to(DEV)).cpu(), q_cpu(xin)), step
+
+
+@pytest.mark.parametrize("shape,dtype,site,fold", [
+    ((1, 16), torch.bfloat16, "relu_pair", False), ((1, 64), torch.float16, "pair", True), ((1, 24), torch.float32, "relu_pair", True),
+    ((1, 16, 1, 1), torch.float16, "relu_pair", True), ((1, 130, 1), torch.float16, "relu_pair", False),
+    ((1, 32, 7, 7), torch.bfloat16, "pair", True), ((1, 32, 8, 8), torch.bfloat16, "relu_pair", True),
+    ((1, 3), torch.float16, "relu_p", True), ((1, 6), torch.float32, "relu_q", True), ((2, 3), torch.bfloat16, "q", True),
+    ((3, 2, 1, 1), torch.float32, "pair", True), ((1, 5), torch.float32, "relu_p", True)])
+def test_sites_with_a_batch_of_one_and_tiny_tensors(shape, dtype, site, fold):
+    """regressions found by tools/fuzz_parity.py: a batch of one leaves the fused pair without a statistics stage in
+    front of the channel dim (the abs-max must not ride along), tensors of fewer than 8 elements, masks that cover
+    every element under the ReLU fold."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    try:
+        for kind, bits, sparsity, start, timeout in (("scaler", 4, 0.25, 0, 2), ("decimal", 8, 0.5, 1, 1), ("scaler", 2, 0.5, 2, 3)):
+            r = fz.run_site(shape, dtype, site, kind, bits, sparsity, start, 1, 2, timeout, fold, 6, 5)
+            assert r in ("ok", None), r
+    finally:
+        qs.set_qsparse_options(fold_relu=True)
+
+
+def test_tensor_wise_bias_keeps_the_reference_output_shape():
+    """a (1,1) tensor-wise parameter broadcasts a 1-d input (a bias) to (1, C) in the reference; nn.Linear accepts that
+    bias, nn.Conv2d raises -- on the GPU exactly as on the CPU."""
+    x = torch.randn(12, generator=gen(3))
+    for fn, p in ((quantize_with_scaler, torch.tensor([[0.05]])), (quantize_with_decimal, torch.tensor([[5.0]]))):
+        y_cpu, y_gpu = fn(x, 8, p, -1), fn(x.to(DEV), 8, p.to(DEV), -1)
+        assert y_cpu.shape == (1, 12) and same(y_gpu.cpu(), y_cpu)
+        xg = x.to(DEV).requires_grad_(True)
+        fn(xg, 8, p.to(DEV), -1).backward(torch.ones(1, 12, device=DEV))
+        assert xg.grad.shape == (12,)
+    assert quantize_with_line(x.to(DEV), 8, torch.tensor([[-1.0, 1.0]], device=DEV), -1).shape == (12,)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    lin = qs.quantize(nn.Linear(16, 12), bits=4, channelwise=-1, timeout=1, bias_bits=8).to(DEV).train()
+    conv = qs.quantize(nn.Conv2d(3, 8, 3), bits=4, channelwise=-1, timeout=1, bias_bits=8).to(DEV).train()
+    for _ in range(3):
+        assert lin(torch.randn(4, 16, device=DEV)).shape == (4, 12)
+    assert lin.bias.shape == (1, 12)
+    conv(torch.randn(2, 3, 8, 8, device=DEV))               # identity phase: the raw 1-d bias
+    with pytest.raises(RuntimeError):
+        conv(torch.randn(2, 3, 8, 8, device=DEV))           # (1, 8) bias, as in the reference

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Randomised differential test, CPU path vs HIP path of the SAME modules: random operator configurations (quantizer
+kinds, channel-wise modes, mask dimension sets, pruning policies, schedules, wrapped Conv/Linear layers with weight and
+bias operators) run a few training + evaluation steps on CPU tensors (the reference's own op sequence, pinned by the
+golden fixtures) and on GPU tensors (the kernels); outputs, input/parameter gradients and the whole state_dict must
+agree bit for bit.  Development tool; usage:  python3 tools/fuzz_cpu_gpu.py [cases=150] [seed=0]"""
+import copy
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import torch.nn as nn
+
+import qsparse_amd as qs
+from golden_io import same
+
+VERBOSE = bool(os.environ.get("QS_FUZZ_ONLY"))
+
+
+def make_quantizer(rng):
+    kind = rng.choice(["scaler", "decimal", "adaptive"])
+    kw = dict(flip_axis=rng.random() < 0.2, backward_passthrough=rng.random() < 0.15)
+    cb = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer, "adaptive": qs.AdaptiveQuantizer}[kind](**kw)
+    return kind, cb
+
+
+def build(rng):
+    """returns (description, module factory, input shape, dtype)"""
+    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear"])
+    dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16])
+    if what in ("conv", "linear"):
+        dtype = torch.float32
+    n = rng.choice([1, 2, 4, 8])
+    c = rng.choice([2, 4, 6, 16, 33])
+    hw = rng.choice([(1, 1), (3, 3), (7, 7), (8, 8), (5, 6)])
+    shape = (n, c) + hw
+    bits = rng.choice([2, 4, 8])
+    timeout = rng.choice([0, 1, 2])
+    kind, qcb = make_quantizer(rng)
+    start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2])
+    sparsity = rng.choice([0.3, 0.5, 0.75])
+    desc = dict(what=what, dtype=str(dtype)[6:], shape=shape, bits=bits, timeout=timeout, quantizer=kind, start=start,
+                interval=interval, rep=rep, sparsity=sparsity)
+
+    def pcb():
+        policy = rng.choice(["default", "default", "no_avg", "l0", "grad", "uniform", "refresh"])
+        desc["policy"] = policy
+        if policy == "no_avg":
+            return qs.MagnitudePruningCallback(running_average=False)
+        if policy == "l0":
+            return qs.MagnitudePruningCallback(l0=True)
+        if policy == "grad":
+            return qs.MagnitudePruningCallback(use_gradient=True)
+        if policy == "uniform":
+            return qs.UniformPruningCallback()
+        if policy == "refresh":
+            return qs.MagnitudePruningCallback(mask_refresh_interval=2, stop_mask_refresh=4)
+        return qs.MagnitudePruningCallback()
+
+    if what == "act_q":
+        cw = rng.choice([-1, -1, 1])
+        if cw == 1 and kind != "adaptive":
+            shape = (1,) + shape[1:]          # batched channel-wise Scaler/Decimal raises in the reference
+        desc.update(channelwise=cw, shape=shape)
+        return desc, (lambda: qs.quantize(bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb))), shape, dtype
+    if what == "act_p":
+        dims = rng.choice([{1}, {1}, {0, 1}, {2, 3}, {1, 2, 3}, {0, 1, 2, 3}, {0}])
+        desc.update(dimensions=sorted(dims))
+        cb = pcb()
+        return desc, (lambda: qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
+                                       callback=copy.deepcopy(cb))), shape, dtype
+    if what == "act_pq":
+        cb = pcb()
+        return desc, (lambda: nn.Sequential(qs.prune(sparsity=sparsity, dimensions={1}, start=start, interval=interval, repetition=rep,
+                                                     callback=copy.deepcopy(cb)),
+                                            qs.quantize(bits=bits, channelwise=-1, timeout=timeout, callback=copy.deepcopy(qcb)))), shape, dtype
+    cw = rng.choice([-1, 0, 0])
+    bias_bits = rng.choice([-1, 8, 12])
+    dims = rng.choice([{0, 1, 2, 3}, {1}, {0}, {0, 1}]) if what == "conv" else rng.choice([{0, 1}, {1}, {0}])
+    desc.update(channelwise=cw, bias_bits=bias_bits, dimensions=sorted(dims))
+    cb = pcb()
+    cout = rng.choice([4, 8, 12])
+
+    def factory():
+        torch.manual_seed(1234)
+        base = nn.Conv2d(c, cout, 3, padding=1) if what == "conv" else nn.Linear(c, cout)
+        m = qs.prune(base, sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep, callback=copy.deepcopy(cb))
+        return qs.quantize(m, bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb), bias_bits=bias_bits)
+
+    if what == "linear":
+        shape = (n, c)
+        desc["shape"] = shape
+    return desc, factory, shape, dtype
+
+
+def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    m = factory().to(device)
+    g = torch.Generator().manual_seed(seed)
+    outs = []
+    for s in range(steps):
+        m.train(s < eval_from)
+        if weight_mode:
+            # read the layer's weight (and bias) through its operators, as its forward does, without the convolution
+            # itself (whose CPU and GPU algorithms round differently)
+            for p in m.parameters():
+                p.grad = None
+            w = m.weight
+            gw = torch.randn(w.shape, generator=g)
+            outs.append(("w", w.detach().cpu()))
+            b = m.bias
+            if b is not None and b.requires_grad:
+                (w * 1.0).backward(gw.to(device), retain_graph=True)
+                gb = torch.randn(b.shape, generator=g)
+                outs.append(("b", b.detach().cpu()))
+                b.backward(gb.to(device))
+            else:
+                w.backward(gw.to(device))
+            for name, p in m.named_parameters():
+                if p.grad is not None:
+                    outs.append(("grad:" + name, p.grad.cpu()))
+            continue
+        x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
+        x.view(-1)[:2] = torch.tensor([0.0, -0.5]).to(dtype)
+        xd = x.to(device).requires_grad_(True)
+        y = m(xd)
+        gout = torch.randn(y.shape, generator=g).to(y.dtype)
+        for p in m.parameters():
+            p.grad = None
+        y.backward(gout.to(device))
+        outs.append(("y", y.detach().cpu()))
+        outs.append(("gx", xd.grad.cpu()))
+        for name, p in m.named_parameters():
+            if p.grad is not None:
+                outs.append(("grad:" + name, p.grad.cpu()))
+    for k, v in m.state_dict().items():
+        outs.append(("state:" + k, v.detach().cpu()))
+    return outs
+
+
+def one_case(rng, idx, dry=False):
+    desc, factory, shape, dtype = build(rng)
+    steps = rng.choice([3, 5, 6])
+    eval_from = rng.choice([steps, steps - 1])
+    desc.update(i=idx, steps=steps, eval_from=eval_from)
+    if dry:
+        return None
+    if VERBOSE:
+        print(desc, flush=True)
+    results = {}
+    for device in ("cpu", "cuda"):
+        try:
+            results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'))
+        except Exception as e:      # noqa: BLE001 -- both paths must fail alike
+            results[device] = ("raised", type(e).__name__)
+    a, b = results["cpu"], results["cuda"]
+    if isinstance(a, tuple) or isinstance(b, tuple):
+        if isinstance(a, tuple) and isinstance(b, tuple) and a[1] == b[1]:
+            return "ok"
+        return dict(desc, cpu=a if isinstance(a, tuple) else "ran", gpu=b if isinstance(b, tuple) else "ran")
+    if len(a) != len(b):
+        return dict(desc, mismatch="number of outputs")
+    for (ka, va), (kb, vb) in zip(a, b):
+        if ka != kb or not same(va, vb):
+            return dict(desc, mismatch=(ka, kb), cpu=(tuple(va.shape), str(va.dtype)), gpu=(tuple(vb.shape), str(vb.dtype)),
+                        max_abs=float((va.float() - vb.float()).abs().max()) if va.shape == vb.shape and va.numel() else None)
+    return "ok"
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = random.Random(seed)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    only = os.environ.get("QS_FUZZ_ONLY")
+    ran = fails = 0
+    for i in range(cases):
+        r = one_case(rng, i, dry=only is not None and i != int(only))
+        if r is None:
+            continue
+        ran += 1
+        if r != "ok":
+            fails += 1
+            print("FAIL", r, flush=True)
+    print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed})")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

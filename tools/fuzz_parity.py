@@ -51,10 +51,18 @@ def one_case(rng, idx):
     fold = rng.random() < 0.7
     steps = rng.choice([4, 6, 8])
     eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
+    if DRY:
+        return None
+    return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx)
+
+
+def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0):
+    """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
+    describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
-                interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from)
-    if DRY or len(shape) < 2 or shape[1] < 2:
+                       interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from)
+    if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
         print(desc, flush=True)
