@@ -1,0 +1,49 @@
+"""Fixed-seed runs of the randomised differential tests under tools/ (site state machines against the oracle, CPU path
+against HIP path of whole modules and of the functional API).  A few hundred random configurations per run; the tools
+themselves take a case count and a seed for longer campaigns."""
+import importlib.util
+import os
+import random
+
+import pytest
+
+import qsparse_amd as qs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(autouse=True)
+def _quiet_and_restore():
+    before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu")}
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    yield
+    qs.set_qsparse_options(**before)
+
+
+def test_sites_against_oracle_state_machines():
+    fz = _load("fuzz_parity")
+    rng = random.Random(2024)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(120)) if r not in ("ok", None)]
+    assert not bad, bad[:3]
+
+
+def test_modules_cpu_path_against_hip_path():
+    fz = _load("fuzz_cpu_gpu")
+    rng = random.Random(2025)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(80)) if r not in ("ok", None)]
+    assert not bad, bad[:3]
+
+
+def test_functional_api_cpu_path_against_hip_path():
+    fz = _load("fuzz_cpu_gpu")
+    rng = random.Random(2026)
+    bad = [r for r in (fz.one_functional(rng, i) for i in range(250)) if r not in ("ok", None)]
+    assert not bad, bad[:3]

@@ -32,12 +32,16 @@ def make_quantizer(rng):
 def build(rng):
     """returns (description, module factory, input shape, dtype)"""
     what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear"])
-    dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16])
+    dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
     if what in ("conv", "linear"):
         dtype = torch.float32
-    n = rng.choice([1, 2, 4, 8])
-    c = rng.choice([2, 4, 6, 16, 33])
-    hw = rng.choice([(1, 1), (3, 3), (7, 7), (8, 8), (5, 6)])
+    n = rng.choice([1, 2, 4, 8, 16, 17, 48, 64, 130])
+    c = rng.choice([2, 4, 6, 16, 33, 64, 96, 256])
+    hw = rng.choice([(1, 1), (3, 3), (7, 7), (8, 8), (5, 6), (14, 14), (16, 16), (28, 28)])
+    if what in ("conv", "linear"):
+        n, c, hw = min(n, 8), min(c, 33), hw if hw[0] <= 8 else (8, 8)
+    while n * c * hw[0] * hw[1] > 1_500_000 and n > 1:
+        n = max(1, n // 2)
     shape = (n, c) + hw
     bits = rng.choice([2, 4, 8])
     timeout = rng.choice([0, 1, 2])
@@ -96,6 +100,102 @@ def build(rng):
         shape = (n, c)
         desc["shape"] = shape
     return desc, factory, shape, dtype
+
+
+def functional_case(rng, idx):
+    """one random call of the functional API on both devices: (description, callable(device) -> list of tensors)"""
+    from qsparse_amd.quantize import quantize_with_decimal, quantize_with_line, quantize_with_scaler
+    from qsparse_amd.sparse import apply_mask
+    from qsparse_amd.util import calculate_mask_given_importance, squeeze_tensor_to_shape
+
+    g = torch.Generator().manual_seed(9000 + idx)
+    nd = rng.choice([1, 2, 3, 4, 4, 5])
+    shape = tuple(rng.choice([1, 2, 3, 5, 8, 16, 31, 64]) for _ in range(nd))
+    while int(np.prod(shape)) > 600_000:
+        shape = tuple(max(1, d // 2) for d in shape)
+    dtype = rng.choice([torch.float32, torch.bfloat16, torch.float16])
+    x = (torch.randn(shape, generator=g) * rng.choice([0.01, 1.0, 30.0])).to(dtype)
+    fn = rng.choice(["scaler", "decimal", "line", "squeeze", "mask", "apply_mask"])
+    ci = rng.choice([-1] + list(range(nd)))
+    bits = rng.choice([2, 4, 8])
+    desc = dict(i=idx, fn=fn, shape=shape, dtype=str(dtype)[6:], ci=ci, bits=bits)
+    C = shape[ci] if ci >= 0 else 1
+
+    if fn in ("scaler", "decimal"):
+        form = rng.choice(["tensor", "tensor", "float", "zerodim"]) if ci < 0 else "tensor"
+        desc["param"] = form
+        if fn == "scaler":
+            p = torch.rand(C, 1, generator=g) * 0.2 + 0.01
+        else:
+            p = torch.randint(0, 9, (C, 1), generator=g).float()
+        if form == "float":
+            p = float(p.view(-1)[0]) if fn == "scaler" else int(p.view(-1)[0])
+        elif form == "zerodim":
+            p = p.view(-1)[0].clone()
+        f = quantize_with_scaler if fn == "scaler" else quantize_with_decimal
+        gout = torch.randn(shape, generator=g)
+        flip, passthrough = rng.random() < 0.2, rng.random() < 0.2
+
+        def call(dev):
+            xd = x.detach().clone().to(dev).requires_grad_(True)
+            pd = p.to(dev) if isinstance(p, torch.Tensor) else p
+            y = f(xd, bits, pd, ci, False, passthrough, flip)
+            y.backward(gout.to(dev).to(y.dtype).view(y.shape) if y.numel() == gout.numel() else torch.ones_like(y))
+            return [y.detach().cpu(), xd.grad.cpu()]
+        return desc, call
+    if fn == "line":
+        lo = -torch.rand(C, 1, generator=g) * 2
+        hi = torch.rand(C, 1, generator=g) * 2 + rng.choice([0.0, 0.05])
+        lines = torch.cat([lo, hi], 1)
+        fzp = rng.random() < 0.5
+        desc["fzp"] = fzp
+        return desc, (lambda dev: [quantize_with_line(x.to(dev), bits, lines.to(dev), ci, False, fzp).cpu()])
+    if fn == "squeeze":
+        tgt = [d if rng.random() < 0.5 else 1 for d in shape]
+        desc["target"] = tgt
+        return desc, (lambda dev: [squeeze_tensor_to_shape(x.to(dev), tgt).cpu()])
+    if fn == "mask":
+        imp = x.float().flatten()
+        if rng.random() < 0.5:
+            imp = (imp * 4).round() / 4          # ties
+        sp = rng.choice([0.0, 0.3, 0.5, 0.75, 0.95])
+        desc["sparsity"] = sp
+        return desc, (lambda dev: [calculate_mask_given_importance(imp.to(dev), sp).cpu()])
+    mshape = [d if rng.random() < 0.5 else 1 for d in shape]
+    mask = torch.rand(mshape, generator=g) > 0.4
+    gout = torch.randn(shape, generator=g).to(dtype)
+    desc["mask_shape"] = mshape
+
+    def call(dev):
+        xd = x.detach().clone().to(dev).requires_grad_(True)
+        y = apply_mask(xd, mask.to(dev))
+        y.backward(gout.to(dev))
+        return [y.detach().cpu(), xd.grad.cpu()]
+    return desc, call
+
+
+def one_functional(rng, idx, dry=False):
+    desc, call = functional_case(rng, idx)
+    if dry:
+        return None
+    if VERBOSE:
+        print(desc, flush=True)
+    res = {}
+    for dev in ("cpu", "cuda"):
+        try:
+            res[dev] = call(dev)
+        except Exception as e:      # noqa: BLE001
+            res[dev] = ("raised", type(e).__name__, str(e)[:120])
+    a, b = res["cpu"], res["cuda"]
+    if isinstance(a, tuple) or isinstance(b, tuple):
+        if isinstance(a, tuple) and isinstance(b, tuple) and a[1] == b[1]:
+            return "ok"
+        return dict(desc, cpu=a if isinstance(a, tuple) else "ran", gpu=b if isinstance(b, tuple) else "ran")
+    for k, (va, vb) in enumerate(zip(a, b)):
+        if not same(va, vb):
+            return dict(desc, mismatch=k, cpu=(tuple(va.shape), str(va.dtype)), gpu=(tuple(vb.shape), str(vb.dtype)),
+                        max_abs=float((va.float() - vb.float()).abs().max()) if va.shape == vb.shape and va.numel() else None)
+    return "ok"
 
 
 def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False):
@@ -180,8 +280,9 @@ def main():
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     only = os.environ.get("QS_FUZZ_ONLY")
     ran = fails = 0
+    mode = os.environ.get("QS_FUZZ_MODE", "modules")
     for i in range(cases):
-        r = one_case(rng, i, dry=only is not None and i != int(only))
+        r = (one_functional if mode == "functional" else one_case)(rng, i, dry=only is not None and i != int(only))
         if r is None:
             continue
         ran += 1
