@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""kernel-time breakdown of one converted ResNet-50 training step (development tool; run under rocprofv3)"""
-import copy, os, sys
+"""kernel-time breakdown of one converted ResNet training step (development tool; run under rocprofv3, then
+tools/summarize_profile.py):  profile_resnet.py [pq|plain] [resnet50|resnet18] [batch]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 import qsparse_amd as qs
-from examples.models import convert_pq, resnet50
+from examples.models import convert_pq, resnet18, resnet50
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
 mode = sys.argv[1] if len(sys.argv) > 1 else "pq"
-base = resnet50(1000, False)
-m = base if mode == "plain" else convert_pq(base, sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+arch = sys.argv[2] if len(sys.argv) > 2 else "resnet50"
+if arch == "resnet18":
+    base, shape, classes, sp = resnet18(10, True), (int(sys.argv[3]) if len(sys.argv) > 3 else 128, 3, 32, 32), 10, 0.5
+else:
+    base, shape, classes, sp = resnet50(1000, False), (int(sys.argv[3]) if len(sys.argv) > 3 else 64, 3, 224, 224), 1000, 0.75
+m = base if mode == "plain" else convert_pq(base, sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
 m = m.cuda().train()
 opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
-x = torch.randn(64, 3, 224, 224, device="cuda"); y = torch.randint(0, 1000, (64,), device="cuda")
+x = torch.randn(shape, device="cuda"); y = torch.randint(0, classes, (shape[0],), device="cuda")
 def step():
     opt.zero_grad(set_to_none=False)
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -19,6 +24,5 @@ def step():
     loss.backward(); opt.step()
 for _ in range(12): step()
 torch.cuda.synchronize()
-torch.cuda.cudart().cudaProfilerStart() if hasattr(torch.cuda, "cudart") else None
 for _ in range(10): step()
 torch.cuda.synchronize()
