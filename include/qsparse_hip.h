@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 4
+#define QS_ABI_VERSION 5
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -164,11 +164,24 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C, qs_stream_t stream);
 
+/* The first stage for a channels_last (NHWC in memory) activation x[n][hw][C], C % 8 == 0: mean over n ->
+ * out[C][hw], NCHW-contiguous like the result of Tensor.mean(0, keepdim=True) on a channels_last tensor, in the
+ * summation order ATen uses for that layout (per channel, positions hw < 4*floor(hw/4) in cascade order, the rest
+ * 4-way interleaved; the later stages are the NCHW ones: qs_mean_last2 / qs_mean_dim).  flags: 0, QS_MEAN_ABS or
+ * QS_MEAN_ABS|QS_MEAN_RELU.  amax_part (nullable, device float[C*hw], not with flags == 0) receives the maximum over
+ * n of the mean's operand per output element; hand it to qs_mean_last2, which reduces it to the per-channel
+ * abs-max without atomics. */
+int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
+                   float* amax_part, qs_stream_t stream);
+
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].
  * Same summation order and rounding points as two qs_mean_dim calls.  (H*W + W)*4 bytes of LDS <= 48 KiB,
- * otherwise QS_ERR_ARG (use two qs_mean_dim calls). */
-int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, qs_stream_t stream);
+ * otherwise QS_ERR_ARG (use two qs_mean_dim calls).
+ * amax_part (nullable, [pre, H, W] from qs_mean_dim_cl): absmax_out[p * absmax_stride] is max-accumulated with the
+ * maximum of slice p. */
+int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt,
+                  const float* amax_part, float* absmax_out, int64_t absmax_stride, qs_stream_t stream);
 
 /* *flag = (min(x) == 0), qsparse/sparse.py:85 */
 int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scratch2, qs_stream_t stream);

@@ -52,7 +52,8 @@ SIGNATURES = {
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P]),
+    "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P]),
+    "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
@@ -186,6 +187,20 @@ def dense(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def mem_view(x: torch.Tensor, channel_index: int):
+    """(xm, channel index in xm, like): the tensor the kernels address.  A dense channels_last activation (4-d NHWC or
+    5-d NDHWC in memory) whose channel index is 1 (or absent) is used in place through its memory-order view -- channel
+    dim innermost, no copy -- and outputs are allocated ``empty_like(like)``, i.e. channels_last again, as the reference's
+    element-wise torch ops would return them.  Everything else goes through a contiguous copy, as before."""
+    if x.dim() in (4, 5) and channel_index in (-1, 1) and not x.is_contiguous() and x.data_ptr() % 16 == 0:
+        fmt = torch.channels_last if x.dim() == 4 else torch.channels_last_3d
+        if x.is_contiguous(memory_format=fmt):
+            perm = (0, 2, 3, 1) if x.dim() == 4 else (0, 2, 3, 4, 1)
+            return x.permute(perm), (-1 if channel_index < 0 else x.dim() - 1), x
+    xd = dense(x)
+    return xd, channel_index, xd
+
+
 def split3(shape, channel_index: int):
     """[outer, C, inner] factorisation around `channel_index` (negative: tensor-wise)."""
     numel = 1
@@ -218,14 +233,14 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
               want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False):
     """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU)."""
     lib = load()
-    x = dense(x)
     pt, n, host = _f32param(param, x.device)
     ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
-    outer, C, inner, numel = split3(x.shape, ci if ci is not None else -1)
+    x, ci, like = mem_view(x, ci if ci is not None else -1)
+    outer, C, inner, numel = split3(x.shape, ci)
     if numel == 0:
-        return torch.empty(x.shape, dtype=out_dtype, device=x.device), None
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
+        return torch.empty_like(like, dtype=out_dtype), None
+    y = torch.empty_like(like, dtype=out_dtype)
+    codes = torch.empty_like(like, dtype=torch.int32) if want_codes else None
     cm = None
     if chan_mask is not None:
         cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
@@ -241,11 +256,11 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
 
 def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_index: int, float_zero_point: bool):
     lib = load()
-    x = dense(x)
     ln = lines.detach().to(device=x.device, dtype=torch.float32).contiguous().view(-1, 2)
     n = ln.shape[0]
-    outer, C, inner, numel = split3(x.shape, channel_index if n > 1 else -1)
-    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    x, ci, like = mem_view(x, channel_index if n > 1 else -1)
+    outer, C, inner, numel = split3(x.shape, ci)
+    y = torch.empty_like(like, dtype=torch.float32)
     if numel == 0:
         return y
     st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C, inner,
@@ -258,11 +273,11 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
             passthrough: bool, out_dtype: torch.dtype, chan_mask: Optional[torch.Tensor] = None,
             mask_channel_index: Optional[int] = None):
     lib = load()
-    g = dense(g)
     pt, n, host = _f32param(step, g.device)
     ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
-    outer, C, inner, numel = split3(g.shape, ci if ci is not None else -1)
-    gx = torch.empty(g.shape, dtype=out_dtype, device=g.device)
+    g, ci, like = mem_view(g, ci if ci is not None else -1)
+    outer, C, inner, numel = split3(g.shape, ci)
+    gx = torch.empty_like(like, dtype=out_dtype)
     if numel == 0:
         return gx
     cm = None
@@ -281,12 +296,22 @@ def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, 
                  chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1):
     """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate."""
     lib = load()
-    g, x = dense(g), dense(x)
     assert g.shape == x.shape
     pt, n, host = _f32param(step, g.device)
     ci = mask_channel_index if chan_mask is not None else -1
+    xm, ci_mem, like = mem_view(x, ci)
+    gm = None
+    if like is x and xm is not x:        # x is addressed in place as channels_last: the gradient must share that layout
+        gcl = g.contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+        gv, _, glike = mem_view(gcl, ci)
+        if glike is gcl and gv is not gcl:
+            gm = gv
+    if gm is None:                        # the ordinary case, and the fallback for a misaligned gradient
+        xm = dense(x)
+        ci_mem, like, gm = ci, xm, dense(g)
+    g, x, ci = gm, xm, ci_mem
     outer, C, inner, numel = split3(g.shape, ci)
-    gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    gx = torch.empty_like(like, dtype=like.dtype)
     if numel == 0:
         return gx
     cm = None
@@ -309,7 +334,7 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
     max-accumulated instead of allocating + initialising a fresh one (one launch instead of two).
     `pre_relu`: the statistic of max(x, 0) (folded nn.ReLU)."""
     lib = load()
-    x = dense(x)
+    x, channel_index, _ = mem_view(x, channel_index)
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
     out = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x.device)
@@ -323,7 +348,7 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
 
 def minmax(x: torch.Tensor, channel_index: int):
     lib = load()
-    x = dense(x)
+    x, channel_index, _ = mem_view(x, channel_index)
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
     mn = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -394,14 +419,31 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     return out
 
 
-def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype) -> torch.Tensor:
-    """x viewed as [pre, H, W] -> [pre]: mean over H then over W, each rounded like ``Tensor.mean``."""
+def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype, amax_part: Optional[torch.Tensor] = None,
+               absmax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x viewed as [pre, H, W] -> [pre]: mean over H then over W, each rounded like ``Tensor.mean``.  `amax_part`
+    ([pre, H, W] from mean_dim_cl) is reduced per slice into `absmax_out` on the way."""
     x = dense(x)
     out = torch.empty(pre, dtype=out_dtype, device=x.device)
     with _timed("mean_last2"):
-        st = load().qs_mean_last2(_ptr(x), _ptr(out), pre, H, W, dt(x), _DT[out_dtype], _stream(x))
+        st = load().qs_mean_last2(_ptr(x), _ptr(out), pre, H, W, dt(x), _DT[out_dtype], _ptr(amax_part), _ptr(absmax_out),
+                                  amax_stride(absmax_out), _stream(x))
     _check(st, "qs_mean_last2")
     return out
+
+
+def mean_dim_cl(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, want_amax: bool):
+    """first squeeze stage of a channels_last activation given as its contiguous [N, H, W, C] view: mean over N ->
+    ([C*H*W] in NCHW order, per-element maxima or None)."""
+    N, C = x_nhwc.shape[0], x_nhwc.shape[-1]
+    hw = x_nhwc.numel() // (N * C)
+    out = torch.empty(C * hw, dtype=out_dtype, device=x_nhwc.device)
+    part = torch.empty(C * hw, dtype=torch.float32, device=x_nhwc.device) if want_amax else None
+    with _timed("mean_dim" + ("+absmax" if want_amax else "")):
+        st = load().qs_mean_dim_cl(_ptr(x_nhwc), _ptr(out), N, hw, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(part),
+                                   _stream(x_nhwc))
+    _check(st, "qs_mean_dim_cl")
+    return out, part
 
 
 def l0_flag(x: torch.Tensor) -> torch.Tensor:
@@ -447,7 +489,6 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> t
     """x * mask for a bool mask broadcastable to x (same rank, extents 1 or equal); `pre_relu`: max(x, 0) * mask
     (channel-type masks only)."""
     lib = load()
-    x = dense(x)
     if mask.dim() != x.dim():
         raise RuntimeError(f"mask rank {mask.dim()} does not match input rank {x.dim()}")
     for sm, sx in zip(mask.shape, x.shape):
@@ -455,7 +496,11 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> t
             raise RuntimeError(
                 f"The size of tensor a ({sx}) must match the size of tensor b ({sm}) at non-singleton dimension")
     m = mask.detach().to(x.device).contiguous()
-    y = torch.empty_like(x)
+    xm, _, like = mem_view(x, 1 if x.dim() in (4, 5) else -1)
+    if xm is not like:                    # dense channels_last x, addressed in memory order; the mask dims follow
+        m = m.permute((0, 2, 3, 1) if x.dim() == 4 else (0, 2, 3, 4, 1))
+    x = xm
+    y = torch.empty_like(like)
     if x.numel() == 0:
         return y
     nd = x.dim()

@@ -6,7 +6,10 @@
 
 namespace qs {
 
-enum ChanMode { CM_SCALAR = 0, CM_ROW = 1, CM_ELEM = 2 };
+// CM_LAST: the channel dim is the innermost one (channels_last activations viewed as [N*H*W, C]), C % 8 == 0, the
+// parameter is tensor-wise and only the channel mask varies: the 8 (4) elements of a lane are 8 (4) consecutive
+// channels, whose mask bytes come with one aligned load.
+enum ChanMode { CM_SCALAR = 0, CM_ROW = 1, CM_ELEM = 2, CM_LAST = 3 };
 
 struct EwGeom {
     int64_t numel;
@@ -88,6 +91,11 @@ struct ScalerFwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
+    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
+        p.keep = m ? 1.0f : 0.0f;
+        return p;
+    }
     // rint(RN(v / s)) without dividing in the common case.  t = RN(v * RN(1/s)) differs from RN(v/s) by at
     // most 1.5 * 2^-23 relative, so both round to the same integer unless t lies within |t| * 2^-21 of a
     // half-way point k + 0.5; only then (probability ~2^-18..2^-14 per element for 4..8-bit codes) is the
@@ -140,6 +148,11 @@ struct DecimalFwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
+    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
+        p.keep = m ? 1.0f : 0.0f;
+        return p;
+    }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         if (pre_relu) v = fmaxf(v, 0.0f);
         v = v * p.keep;
@@ -171,6 +184,8 @@ struct LineFwdOp {
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c, uint32_t) const { return channel(c); }
+    __device__ __forceinline__ const uint8_t* mask_ptr() const { return nullptr; }
+    __device__ __forceinline__ static P keep_of(P p, uint32_t) { return p; }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         float xc = fminf(fmaxf(v, p.start), p.end);      // torch.clamp(x, start, end) (:158)
         if (v != v) xc = v;
@@ -217,6 +232,11 @@ struct SteBwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
+    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
+        p.keep = m ? 1.0f : 0.0f;
+        return p;
+    }
     __device__ __forceinline__ float apply(float g, const P& p, int32_t& code) const {
         float v = g;
         if (!passthrough) {
@@ -241,6 +261,11 @@ struct ChanMaskOp {
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t, uint32_t c_mask) const { return channel(c_mask); }
+    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
+        p.keep = m ? 1.0f : 0.0f;
+        return p;
+    }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         code = 0;
         if (relu) v = fmaxf(v, 0.0f);
@@ -284,6 +309,14 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                 typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, q[j]);
+            } else if constexpr (CM == CM_LAST) {
+                const uint32_t c0 = (uint32_t)(((uint64_t)g * 8) % geo.C);
+                const uint8_t* mp = op.mask_ptr();
+                u32x2 mm = {0x01010101u, 0x01010101u};
+                if (mp) mm = *(const u32x2*)(mp + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = op.apply(v[j], Op::keep_of(p_scalar, (mm[j >> 2] >> (8 * (j & 3))) & 0xffu), q[j]);
             } else {
                 ChanIter it;
                 it.C = geo.C;
@@ -363,10 +396,18 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                 const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 8 == 0: 4 elements share a row
                 p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
             }
+            uint32_t mm = 0x01010101u;
+            if constexpr (CM == CM_LAST) {
+                const uint8_t* mp = op.mask_ptr();
+                if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+            }
             int32_t q;
             u32x4 out;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(op.apply(v[j], p, q));
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (CM == CM_LAST) out[j] = __float_as_uint(op.apply(v[j], Op::keep_of(p_scalar, (mm >> (8 * j)) & 0xffu), q));
+                else out[j] = __float_as_uint(op.apply(v[j], p, q));
+            }
             st16<NT>((u32x4*)(y + e), out);
         }
     }
@@ -386,8 +427,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
 
 // ------------------------------------------------------------------------------------------------
 // STE backward with the folded ReLU's gate: gx = (x <= 0) ? 0 : clamp(g) * mask.  Two streamed inputs (the
-// gradient and the ReLU's input), one output in x's dtype.  Same geometry as ew_kernel, CM_ROW / CM_ELEM only
-// (a channel mask is what makes the fold worthwhile) plus CM_SCALAR for completeness.
+// gradient and the ReLU's input), one output in x's dtype.  Same geometry and channel modes as ew_kernel.
 // ------------------------------------------------------------------------------------------------
 template <int GDT, int XDT, int CM, bool NT>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
@@ -411,6 +451,14 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
             const SteBwdOp::P p = op.channel_masked(param_per_channel ? c : 0u, c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+        } else if constexpr (CM == CM_LAST) {
+            const SteBwdOp::P p0 = op.channel(0);
+            const uint32_t c0 = (uint32_t)(((uint64_t)grp * 8) % geo.C);
+            u32x2 mm = {0x01010101u, 0x01010101u};
+            if (op.cmask) mm = *(const u32x2*)(op.cmask + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], SteBwdOp::keep_of(p0, (mm[j >> 2] >> (8 * (j & 3))) & 0xffu), dummy);
         } else {
             ChanIter it;
             it.C = geo.C;

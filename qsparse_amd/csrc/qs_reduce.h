@@ -500,6 +500,75 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
     }
 }
 
+// ---- the same stage for channels_last activations ---------------------------------------------------------
+// x: [n][hw][C] in memory (NHWC), C % 8 == 0; out: [C][hw], i.e. NCHW-contiguous -- which is what ATen's reduction of
+// a channels_last input returns, so the later stages are the ordinary NCHW ones.  ATen sums such an input over N with
+// its scalar outer loop (SumKernel.cpp, scalar_outer_sum over the coalesced H*W dim): per channel, positions
+// hw < 4*floor(HW/4) in multi-row order, the remaining HW % 4 positions in row-sum order.  A lane owns 8 consecutive
+// channels of one position (one 16-byte load per row).  amax_part (nullable) receives, per output element, the
+// maximum over n of the mean's operand (|x| or max(x, 0)) as a uint32 key; the following qs_mean_last2 launch, which
+// runs one workgroup per channel anyway, reduces it to the per-channel abs-max -- no atomics at all.
+// MODE 1: |x|, 2: max(x, 0), 3: x as it is (no abs-max).
+template <int DT, int ODT, int MODE>
+__global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
+                                                      int64_t hw, int64_t C, uint32_t* __restrict__ amax_part, int lanes) {
+    const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
+    const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
+    if ((int)threadIdx.x >= lanes || t >= groups) return;
+    const int64_t col0 = t * 8;
+    const int64_t pos = col0 / C, c0 = col0 - pos * C;
+    const int64_t hw_multi = (hw / 4) * 4;
+    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    uint32_t amax[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax[j] = 0u;
+    auto prep = [&](float v, uint32_t& am) -> float {
+        if constexpr (MODE == 3) return v;
+        const float w = (MODE == 2) ? fmaxf(v, 0.0f) : v;
+        const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
+        am = k > am ? k : am;
+        return __uint_as_float(k);
+    };
+    float m[8];
+    if (pos < hw_multi) {
+        Cascade acc[8];
+        auto consume = [&](const Raw8<DT>& r) {
+            float v[8];
+            unpack8<DT>(r, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j].add(prep(v[j], amax[j]));
+        };
+        int64_t i = 0;
+        while (i + step <= n) {
+            for (int64_t j = 0; j < step; j += 16) {
+                Raw8<DT> r[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (i + j + u) * groups);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) consume(r[u]);
+            }
+            i += step;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+        }
+        for (; i < n; ++i) consume(load8_raw<DT, false>(x, t + i * groups));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = acc[j].total();
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            m[j] = sum_row_sum(n, [&](int64_t i) { return prep(load1<DT>(x, (i * groups + t) * 8 + j), amax[j]); });
+    }
+    const float fn = (float)n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t o = (c0 + j) * hw + pos;
+        store1<ODT>(out, o, m[j] / fn);              // .div_(n) in fp32, then one rounding to ODT
+        if (MODE != 3 && amax_part) amax_part[o] = amax[j];
+    }
+}
+
 // ---- the same stage for tensors with FEW columns: rows split over R waves of one workgroup -------------------
 // With C*H*W small (late ResNet stages, small batches of small maps) one wave per 512 columns leaves most CUs
 // with one or two waves and the kernel becomes latency-bound.  Here the R waves of a workgroup own the SAME
@@ -978,11 +1047,28 @@ __global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const voi
 // =================================================================================================
 template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restrict__ x, void* __restrict__ out,
-                                                             int H, int W) {
+                                                             int H, int W, const uint32_t* __restrict__ amax_part,
+                                                             uint32_t* __restrict__ chan_absmax, int64_t astride) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // H*W + W floats
     float* colmean = tile + (size_t)H * W;
     const int64_t p = blockIdx.x;
     const int hw = H * W;
+    if (amax_part) {   // per-element maxima left by mean_cl_kernel -> per-channel abs-max (this workgroup owns channel p)
+        __shared__ uint32_t wmax[kBlock / 64];
+        uint32_t m = 0u;
+        for (int i = threadIdx.x; i < hw; i += kBlock) {
+            const uint32_t k = amax_part[p * hw + i];
+            m = k > m ? k : m;
+        }
+        m = wave_max_u32(m);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+            const uint32_t old = chan_absmax[p * astride];
+            chan_absmax[p * astride] = m > old ? m : old;   // max-accumulate, single writer per channel
+        }
+    }
     load_tile_f32<DT>(x, p, hw, tile);
     __syncthreads();
     const int mr_cols = (W >= 8) ? (W / 32) * 32 : (W / 4) * 4;

@@ -94,7 +94,11 @@ struct EwPlan {
     EwGeom geo;
     int cm;
 };
-int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* plan) {
+inline bool aligned8(const void* p) { return (((uintptr_t)p) & 7u) == 0; }
+
+// `last_ok`: the caller's parameter is tensor-wise and its channel mask (if any) is 8-byte aligned, so that a tensor
+// whose channel dim is the innermost one (channels_last activations: outer = N*H*W, inner = 1) may take CM_LAST
+int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* plan, bool last_ok = false) {
     if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
     const int64_t numel = outer * C * inner;
     if (numel / 8 >= ((int64_t)1 << 32) || C >= ((int64_t)1 << 32) || inner >= ((int64_t)1 << 32)) return QS_ERR_ARG;
@@ -106,6 +110,7 @@ int plan_ew(int64_t outer, int64_t C, int64_t inner, bool per_channel, EwPlan* p
     plan->geo.reverse = ew_reverse() ? 1u : 0u;
     if (!per_channel) plan->cm = CM_SCALAR;
     else if (inner % 8 == 0) plan->cm = CM_ROW;
+    else if (last_ok && inner == 1 && C % 8 == 0) plan->cm = CM_LAST;
     else plan->cm = CM_ELEM;
     return QS_OK;
 }
@@ -127,6 +132,9 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
             const int gridw = (int)std::max<int64_t>(1, (waves + kBlock / 64 - 1) / (kBlock / 64));   // < 8 elements: tail only
             if (plan.cm == CM_SCALAR)
                 hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, (float*)y);
+            else if (plan.cm == CM_LAST)
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else if (param_per_channel)
                 hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
@@ -150,6 +158,10 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
             else
                 hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
+            break;
+        case CM_LAST:
+            hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_LAST, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                               plan.geo, x, y, codes);
             break;
         default:
             if (param_per_channel)
@@ -208,7 +220,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
     if (st) return st;
     const bool ppc = nscale > 1;
     EwPlan plan;
-    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
     if (st) return st;
     hipStream_t s = (hipStream_t)stream;
     return with_dtype(xdt, [&](auto X) {
@@ -235,7 +247,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
     if (st) return st;
     const bool ppc = ndecimal > 1;
     EwPlan plan;
-    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
     if (st) return st;
     hipStream_t s = (hipStream_t)stream;
     return with_dtype(xdt, [&](auto X) {
@@ -286,7 +298,7 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
     if (st) return st;
     const bool ppc = nstep > 1;
     EwPlan plan;
-    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
     if (st) return st;
     hipStream_t s = (hipStream_t)stream;
     SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, passthrough, chan_mask};
@@ -307,7 +319,7 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
     if (st) return st;
     const bool ppc = nstep > 1;
     EwPlan plan;
-    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan);
+    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
     if (st) return st;
     if (plan.geo.numel == 0) return QS_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -325,6 +337,10 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
                     break;
                 case CM_ROW:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                       plan.geo, (int)ppc, g, x, gx);
+                    break;
+                case CM_LAST:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT>), dim3(grid), dim3(kBlock), 0, s, op,
                                        plan.geo, (int)ppc, g, x, gx);
                     break;
                 default:
@@ -509,8 +525,38 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
     });
 }
 
-int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, qs_stream_t stream) {
+int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
+                   float* amax_part, qs_stream_t stream) {
+    if (!x || !out || n < 1 || hw < 1 || C < 8 || C % 8 != 0) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    if (!aligned16(x)) return QS_ERR_ALIGN;
+    const int mode = flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : (flags == 0 ? 3 : 0));
+    if (mode == 0 || (mode == 3 && amax_part)) return QS_ERR_ARG;
+    const int64_t groups = hw * C / 8;
+    const int lanes = mean_lanes(groups);
+    const int blocks = (int)((groups + lanes - 1) / lanes);
+    hipStream_t s = (hipStream_t)stream;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto run = [&](auto O) {
+            constexpr int OD = decltype(O)::value;
+            uint32_t* am = (uint32_t*)amax_part;
+            if (mode == 1)
+                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 1>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
+            else if (mode == 2)
+                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 2>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
+            else
+                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 3>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
+            return launch_status();
+        };
+        return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
+    });
+}
+
+int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, const float* amax_part,
+                  float* absmax_out, int64_t absmax_stride, qs_stream_t stream) {
     if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;
+    if (amax_part && (!absmax_out || absmax_stride < 1)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     const size_t lds = (size_t)(H * W + W + 8) * sizeof(float);
     if (lds > 48 * 1024 + 32 || pre > 0x7fffffff) return QS_ERR_ARG;
@@ -518,10 +564,10 @@ int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, i
         constexpr int XD = decltype(X)::value;
         if (odt == QS_F32)
             hipLaunchKernelGGL((mean_last2_kernel<XD, QS_F32>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x,
-                               out, (int)H, (int)W);
+                               out, (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride);
         else
             hipLaunchKernelGGL((mean_last2_kernel<XD, XD>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x, out,
-                               (int)H, (int)W);
+                               (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride);
         return launch_status();
     });
 }
@@ -621,7 +667,7 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 
     if (pattern_a) {
         EwPlan plan;
-        int st = plan_ew(outer, C, inner, true, &plan);
+        int st = plan_ew(outer, C, inner, true, &plan, aligned8(mask));
         if (st) return st;
         ChanMaskOp op{mask, pre_relu != 0};
         return with_dtype(dt, [&](auto D) {

@@ -173,7 +173,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 elif update_scale:
                     chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax if rides else None,
-                                         absmax_channel_dim=1, pre_relu=pre_relu).view(-1)
+                                         absmax_channel_dim=1, pre_relu=pre_relu).contiguous().view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
             if qdist.exchange_active(world):

@@ -201,7 +201,7 @@ class MagnitudePruningCallback(nn.Module):
             with torch.no_grad():
                 imp = k = None
                 if update:
-                    imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0, pre_relu)).view(-1)
+                    imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0, pre_relu)).contiguous().view(-1)
                 if refresh:
                     n = mask.numel()
                     k = threshold_rank(sparsity, n)

@@ -74,6 +74,17 @@ def _reduction_plan(xshape: Sequence[int], shape: Sequence[int]) -> List[int]:
 def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=None, absmax_out=None,
                      absmax_channel_dim: Optional[int] = None, pre_relu: bool = False) -> torch.Tensor:
     """successive keepdim means on the GPU, one ``qs_mean_dim`` launch per reduced dim."""
+    if (x.dim() == 4 and dims == [0, 2, 3] and l0_flag is None and x.shape[1] % 8 == 0
+            and (x.shape[2] * x.shape[3] + x.shape[3]) * 4 <= 48 * 1024 and (absmax_out is None or absmax_channel_dim == 1)):
+        # channels_last activation reduced to its channels: no NCHW copy.  ATen's mean over N of such a tensor returns
+        # an NCHW-contiguous result (summed in the order qs_mean_dim_cl reproduces), so stages 2 and 3 are the usual ones
+        xm, _, like = _hip.mem_view(x, 1)
+        if xm is not like:
+            N, C, H, W = x.shape
+            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
+            if flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU) and not (flags == 0 and absmax_out is not None):
+                stage, part = _hip.mean_dim_cl(xm, x.dtype, flags, absmax_out is not None)
+                return _hip.mean_last2(stage, C, H, W, x.dtype, part, absmax_out).view(1, C, 1, 1)
     cur = _hip.dense(x)
     shape = list(cur.shape)
     out_dtype = torch.float32 if l0_flag is not None else cur.dtype

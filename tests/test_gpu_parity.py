@@ -42,7 +42,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 4
+    assert lib.qs_version() == 5
     assert torch.cuda.is_available()
 
 
@@ -458,7 +458,7 @@ def test_abi_calls_are_graph_capturable():
 
     def sequence(stream):
         assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, stream) == 0
-        assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, stream) == 0
+        assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, stream) == 0
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
@@ -834,3 +834,64 @@ def test_tensor_wise_bias_keeps_the_reference_output_shape():
     conv(torch.randn(2, 3, 8, 8, device=DEV))               # identity phase: the raw 1-d bias
     with pytest.raises(RuntimeError):
         conv(torch.randn(2, 3, 8, 8, device=DEV))           # (1, 8) bias, as in the reference
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_channels_last_activations_are_used_in_place(dtype):
+    """dense channels_last (NHWC) activations -- what MIOpen's convolutions prefer -- are addressed in memory order
+    without an NCHW copy: outputs and gradients come back channels_last, element-wise results equal the NCHW ones,
+    and the channel statistics follow ATen's summation order for that layout (reproduced for up to 32 CPU threads;
+    the reference's own 128-thread result differs from its 8-thread one)."""
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads))
+    try:
+        for shape in ((16, 32, 14, 14), (33, 64, 7, 7), (40, 8, 5, 6), (64, 16, 3, 9)):
+            N, C, H, W = shape
+            x = (torch.randn(shape, generator=gen(11)) * torch.linspace(0.3, 3, C).view(1, C, 1, 1)).to(dtype)
+            xcl = x.contiguous(memory_format=torch.channels_last)
+            # statistics: staged mean to the channels and the fused per-channel abs-max
+            am = _hip.amax_accumulator(C, DEV)
+            from qsparse_amd.util import _staged_mean_hip
+            imp = _staged_mean_hip(xcl.to(DEV), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
+            assert same(imp.cpu(), O.squeeze_mean(xcl.abs(), (1, C, 1, 1))), shape
+            assert same(_hip.amax_values(am).cpu(), x.abs().float().amax(dim=(0, 2, 3))), shape
+            assert same(squeeze_tensor_to_shape(xcl.to(DEV), (1, C, 1, 1)).cpu(), squeeze_tensor_to_shape(xcl, (1, C, 1, 1)))
+            # element-wise kernels: same values as NCHW, channels_last out, per-channel mask and tensor-wise scale
+            mask = torch.rand(C, generator=gen(12)) > 0.4
+            s = torch.tensor([[0.07]])
+            for relu in (False, True):
+                y_cl, _ = _hip.quant_fwd("scaler", xcl.to(DEV), s.to(DEV), -1, torch.float32, chan_mask=mask.to(DEV),
+                                         mask_channel_index=1, pre_relu=relu)
+                y_nc, _ = _hip.quant_fwd("scaler", x.to(DEV), s.to(DEV), -1, torch.float32, chan_mask=mask.to(DEV),
+                                         mask_channel_index=1, pre_relu=relu)
+                assert y_cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(y_cl, y_nc), (shape, relu)
+            g = torch.randn(shape, generator=gen(13)).contiguous(memory_format=torch.channels_last)
+            gx_cl = _hip.ste_relu_bwd(g.to(DEV), xcl.to(DEV), s.to(DEV), False, -8.0, 7.0, mask.to(DEV))
+            gx_nc = _hip.ste_relu_bwd(g.contiguous().to(DEV), x.to(DEV), s.to(DEV), False, -8.0, 7.0, mask.to(DEV))
+            assert gx_cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(gx_cl, gx_nc), shape
+            m4 = mask.view(1, C, 1, 1)
+            y = apply_mask(xcl.to(DEV), m4.to(DEV))
+            assert y.is_contiguous(memory_format=torch.channels_last) and same(y.cpu(), xcl * m4), shape
+            assert same(_hip.absmax(xcl.to(DEV), 1).cpu(), x.abs().float().amax(dim=(0, 2, 3)))
+        # a whole fused site: channels_last in, channels_last out and grad, same numbers as the NCHW run
+        from qsparse_amd.fused import fuse_prune_quantize_pairs
+        runs = []
+        for cl in (False, True):
+            pair = nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                                 qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train()
+            fuse_prune_quantize_pairs(pair)
+            outs = []
+            for step in range(4):
+                x = (torch.randn(16, 32, 8, 8, generator=gen(20 + step)) * torch.linspace(0.3, 3, 32).view(1, 32, 1, 1)).to(dtype)
+                xg = (x.contiguous(memory_format=torch.channels_last) if cl else x).to(DEV).requires_grad_(True)
+                y = pair(xg)
+                y.backward(torch.ones_like(y))
+                if cl:
+                    assert y.is_contiguous(memory_format=torch.channels_last) and xg.grad.is_contiguous(memory_format=torch.channels_last)
+                outs.append((y.detach().cpu().contiguous(), xg.grad.cpu().contiguous(), pair[0][1].mask.cpu().clone()))
+            runs.append(outs)
+        if dtype == torch.bfloat16:      # bf16 means absorb the 1-ulp order difference between the two layouts
+            for (ya, ga, ma), (yb, gb, mb) in zip(*runs):
+                assert torch.equal(ma, mb) and torch.equal(ya, yb) and torch.equal(ga, gb)
+    finally:
+        torch.set_num_threads(threads)

@@ -16,10 +16,16 @@ import qsparse_amd as qs
 from examples.models import convert_pq, resnet18, resnet50
 
 
+CHANNELS_LAST = False
+
+
 def run(model, shape, classes, steps, warmup, dtype, graph=False):
     model = model.cuda().train()   # fp32 master weights; bf16 compute through autocast (activations are bf16)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     x = torch.randn(shape, device="cuda")
+    if CHANNELS_LAST:              # NHWC activations and weights: MIOpen's native layout, no transposes around the convolutions
+        model = model.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, classes, (shape[0],), device="cuda")
 
     def step():
@@ -53,7 +59,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--channels-last", action="store_true")
     args = ap.parse_args()
+    global CHANNELS_LAST
+    CHANNELS_LAST = args.channels_last
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     dtype = getattr(torch, args.dtype)
     if args.arch == "resnet18":
@@ -69,7 +78,7 @@ def main():
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
         res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph)
-    print(args.arch, shape, args.dtype, {k: round(v, 2) for k, v in res.items()}, flush=True)
+    print(args.arch, shape, args.dtype, "channels_last" if CHANNELS_LAST else "nchw", {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
 if __name__ == "__main__":

@@ -116,9 +116,12 @@ def functional_case(rng, idx):
     dtype = rng.choice([torch.float32, torch.bfloat16, torch.float16])
     x = (torch.randn(shape, generator=g) * rng.choice([0.01, 1.0, 30.0])).to(dtype)
     fn = rng.choice(["scaler", "decimal", "line", "squeeze", "mask", "apply_mask"])
+    cl = nd == 4 and rng.random() < 0.5 and fn != "squeeze"
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
     ci = rng.choice([-1] + list(range(nd)))
     bits = rng.choice([2, 4, 8])
-    desc = dict(i=idx, fn=fn, shape=shape, dtype=str(dtype)[6:], ci=ci, bits=bits)
+    desc = dict(i=idx, fn=fn, shape=shape, dtype=str(dtype)[6:], ci=ci, bits=bits, channels_last=cl)
     C = shape[ci] if ci >= 0 else 1
 
     if fn in ("scaler", "decimal"):
@@ -198,7 +201,7 @@ def one_functional(rng, idx, dry=False):
     return "ok"
 
 
-def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False):
+def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -228,9 +231,14 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             continue
         x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -0.5]).to(dtype)
+        if channels_last and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
         xd = x.to(device).requires_grad_(True)
         y = m(xd)
         gout = torch.randn(y.shape, generator=g).to(y.dtype)
+        if channels_last and gout.dim() == 4:
+            gout = gout.contiguous(memory_format=torch.channels_last)
+        outs.append(("layout", torch.tensor(y.stride())))
         for p in m.parameters():
             p.grad = None
         y.backward(gout.to(device))
@@ -248,7 +256,11 @@ def one_case(rng, idx, dry=False):
     desc, factory, shape, dtype = build(rng)
     steps = rng.choice([3, 5, 6])
     eval_from = rng.choice([steps, steps - 1])
-    desc.update(i=idx, steps=steps, eval_from=eval_from)
+    channels_last = rng.random() < 0.4
+    if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact where a native kernel exists
+        channels_last = (channels_last and desc.get("dimensions", [1]) == [1] and shape[1] % 8 == 0 and shape[0] > 1
+                         and len(shape) == 4 and desc.get("policy") != "l0")
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last)
     if dry:
         return None
     if VERBOSE:
@@ -256,7 +268,8 @@ def one_case(rng, idx, dry=False):
     results = {}
     for device in ("cpu", "cuda"):
         try:
-            results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'))
+            results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
+                                  channels_last)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
     a, b = results["cpu"], results["cuda"]
@@ -274,6 +287,7 @@ def one_case(rng, idx, dry=False):
 
 
 def main():
+    torch.set_num_threads(min(8, torch.get_num_threads()))     # see tools/fuzz_parity.py
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)

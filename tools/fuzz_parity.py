@@ -51,17 +51,21 @@ def one_case(rng, idx):
     fold = rng.random() < 0.7
     steps = rng.choice([4, 6, 8])
     eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
+    channels_last = rng.random() < 0.35
     if DRY:
         return None
-    return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx)
+    return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
+                    channels_last)
 
 
-def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0):
+def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
+             channels_last=False):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
-                       interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from)
+                       interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
+                       channels_last=channels_last)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -91,14 +95,23 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         site.train(training)
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
+        # channels_last statistics are bit-exact for the configuration with a native kernel (C % 8 == 0, a batch to
+        # reduce); other channels_last inputs are summed in NCHW order, 1 ulp away from ATen's layout-dependent order
+        cl = channels_last and len(shape) == 4 and shape[1] % 8 == 0 and shape[0] > 1
+        if cl:                      # the oracle then sees ATen's channels_last behaviour (summation order included)
+            x = x.contiguous(memory_format=torch.channels_last)
         xg = x.to(DEV).requires_grad_(True)
         y = site(xg)
         gout = torch.randn(shape, generator=g).to(y.dtype)
+        if cl:
+            gout = gout.contiguous(memory_format=torch.channels_last)
         y.backward(gout.to(DEV))
         h = torch.relu(x) if has_relu else x
         n_before = ps.n_updates if ps else 0
         r = ps.step(h, training) if ps else h
-        y_ref = qsim.step(r, training) if qsim else r
+        # (the reference's quantizer statistics call .view on their input and raise for a channels_last tensor,
+        # quantize.py:333; abs-max and the element-wise math do not depend on the layout, so the oracle gets a copy)
+        y_ref = qsim.step(r.contiguous() if cl else r, training) if qsim else r
         gr = gout
         if qsim:
             gr = qsim.grad(gr.to(y_ref.dtype), dtype)
@@ -139,6 +152,9 @@ DRY = False
 
 
 def main():
+    # ATen's CPU reduction of a channels_last tensor depends on how its threads split the work (the 128-thread result
+    # differs from the 1..32-thread one in half of the elements); the kernels reproduce the few-thread order
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)
