@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """kernel-time breakdown of one converted ResNet training step (development tool; run under rocprofv3, then
-tools/summarize_profile.py):  profile_resnet.py [pq|plain] [resnet50|resnet18] [batch]"""
+tools/summarize_profile.py):  profile_resnet.py [pq|plain] [resnet50|resnet18] [batch] [channels_last]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
@@ -15,8 +15,10 @@ else:
     base, shape, classes, sp = resnet50(1000, False), (int(sys.argv[3]) if len(sys.argv) > 3 else 64, 3, 224, 224), 1000, 0.75
 m = base if mode == "plain" else convert_pq(base, sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
 m = m.cuda().train()
-opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
 x = torch.randn(shape, device="cuda"); y = torch.randint(0, classes, (shape[0],), device="cuda")
+if "channels_last" in sys.argv:
+    m = m.to(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
+opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
 def step():
     opt.zero_grad(set_to_none=False)
     with torch.autocast("cuda", dtype=torch.bfloat16):
