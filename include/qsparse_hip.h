@@ -130,11 +130,13 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
  * int64 holding the same counter, read by the kernel INSTEAD of `t` when non-NULL.  Counters are advanced
  * either by the caller (any stream-ordered increment) or, for qs_pq_select, by its bump_* arguments. */
 
-/* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1)
- * (quantize.py:340,344-348).  clear_absmax != 0 zeroes absmax[i] after use; bump_i32 (nullable) is a one-element
- * device counter incremented once (QuantizeLayer._n_updates, quantize.py:515). */
+/* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1) rounded to stat_dt, the
+ * dtype of the tensor the abs-max was taken from: the reference divides in that dtype, which matters for fp16,
+ * where small maxima underflow into subnormals (quantize.py:340,344-348).  clear_absmax != 0 zeroes absmax[i]
+ * after use; bump_i32 (nullable) is a one-element device counter incremented once (QuantizeLayer._n_updates,
+ * quantize.py:515). */
 int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
-                    int clear_absmax, int32_t* bump_i32, qs_stream_t stream);
+                    int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream);
 
 /* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
  * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */
@@ -226,13 +228,14 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  * update_scale != 0.  bump_i32_a / bump_i32_b / bump_i64_a / bump_i64_b
  * (each nullable) are one-element device counters incremented by one at the end: the layers' `_n_updates`,
  * the pruning callback's `t` and the quantizer's device-side `t` (sparse.py:117,272; quantize.py:348,515), so
- * that a step needs no separate counter kernels.  t_mag_dev / t_q_dev: see "Step counters" above. */
+ * that a step needs no separate counter kernels.  t_mag_dev / t_q_dev: see "Step counters" above.  stat_dt: dtype
+ * of the activation (the new scale's quotient is rounded to it, as in qs_scale_update). */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
                  float* chan_absmax, int64_t chan_absmax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                  int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
-                 const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream);
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, qs_stream_t stream);
 
 /* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
 

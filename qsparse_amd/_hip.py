@@ -42,7 +42,7 @@ SIGNATURES = {
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
-    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _P]),
+    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _I, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _L, _P]),
@@ -51,7 +51,7 @@ SIGNATURES = {
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -359,13 +359,14 @@ def minmax(x: torch.Tensor, channel_index: int):
 
 
 def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None,
-                 clear_absmax: bool = False, bump: Optional[torch.Tensor] = None):
+                 clear_absmax: bool = False, bump: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32):
     """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t`;
-    `clear_absmax`: zero the statistics buffer after use; `bump`: int32 one-element counter to increment."""
+    `clear_absmax`: zero the statistics buffer after use; `bump`: int32 one-element counter to increment;
+    `stat_dtype`: dtype of the tensor the abs-max came from (the reference divides in that dtype)."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
     assert bump is None or bump.dtype == torch.int32
     st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(bits),
-                                int(clear_absmax), _ptr(bump), _stream(weight))
+                                int(clear_absmax), _ptr(bump), _DT.get(stat_dtype, F32), _stream(weight))
     _check(st, "qs_scale_update")
 
 
@@ -517,7 +518,7 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
               t_q: int, bits: int, scale: Optional[torch.Tensor], bump_a: Optional[torch.Tensor] = None,
               bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None,
               bump_d: Optional[torch.Tensor] = None, t_mag_dev: Optional[torch.Tensor] = None,
-              t_q_dev: Optional[torch.Tensor] = None):
+              t_q_dev: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32):
     """bump_a / bump_b: int32 one-element counters; bump_c / bump_d: int64 one-element counters; t_*_dev: device
     int64 counters read instead of the by-value t_mag / t_q (each optional)."""
     C = magnitude.numel()
@@ -531,7 +532,7 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
                                  int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), amax_stride(chan_absmax),
                                  int(update_scale), int(t_q),
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
-                                 _ptr(t_mag_dev), _ptr(t_q_dev), _stream(magnitude))
+                                 _ptr(t_mag_dev), _ptr(t_q_dev), _DT.get(stat_dtype, F32), _stream(magnitude))
     _check(st, "qs_pq_select")
 
 

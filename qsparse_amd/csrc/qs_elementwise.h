@@ -268,7 +268,7 @@ struct ChanMaskOp {
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         code = 0;
-        if (relu) v = fmaxf(v, 0.0f);
+        if (relu) v = (v < 0.0f) ? 0.0f : v;   // ATen's CPU relu (clamp_min = max_ps(0, x)): -0.0 and NaN pass through
         return v * p.keep;
     }
 };

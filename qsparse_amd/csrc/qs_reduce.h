@@ -232,15 +232,23 @@ __global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
 // replays with the live counter (by-value kernel arguments are frozen at capture time)
 // `clear` != 0 zeroes absmax[i] after use (accumulate-mode abs-max buffers); `bump` (nullable) is a one-element
 // int32 step counter incremented once (the layer's `_n_updates`, quantize.py:515)
+// The reference divides in the dtype of the statistic (`x.abs().max() / 2**(bits-1)` on an fp16 / bf16 tensor): the
+// quotient is rounded to that dtype before it enters the float32 running mean.  Exact for bf16 (same exponent range as
+// fp32) but not for fp16, where small maxima underflow into subnormals (max|x| = 1e-3, 8 bits: 7.8082e-6, not 7.8157e-6).
+__device__ __forceinline__ float round_to_dtype(float v, int dt) {
+    if (dt == QS_F16) return round_through<QS_F16>(v);
+    if (dt == QS_BF16) return round_through<QS_BF16>(v);
+    return v;
+}
 __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
-                                    const int64_t* t_dev, int clear, int32_t* bump) {
+                                    const int64_t* t_dev, int clear, int32_t* bump, int stat_dt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t_dev) {
         t = (float)*t_dev;
         tp1 = (float)(*t_dev + 1);
     }
     if (i < n) {
-        const float nw = absmax[i] / denom;                       // max / 2**(bits-1)   (quantize.py:340)
+        const float nw = round_to_dtype(absmax[i] / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
         if (clear) absmax[i] = 0.0f;
     }
@@ -910,6 +918,7 @@ struct PqArgs {
     const int64_t* t_mag_dev;   // nullable device counters overriding t_mag / t_q (graph replay)
     const int64_t* t_q_dev;
     int rank_small;             // rank counting up to this many channels, radix select above (kRankSmall)
+    int stat_dt;                // dtype of the activation the abs-max was taken from (the quotient is rounded to it)
 };
 
 __device__ __forceinline__ PqArgs pq_live_counters(PqArgs a) {
@@ -953,7 +962,7 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
         __syncthreads();
         if (tid == 0) {
             for (int i = 1; i < nthreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
-            const float nw = __uint_as_float(m) / a.denom;                                      // quantize.py:340
+            const float nw = round_to_dtype(__uint_as_float(m) / a.denom, a.stat_dt);           // quantize.py:340
             a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * a.scale[0] + nw) / a.t_q1;             // :344-347
         }
     }
@@ -1015,7 +1024,7 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
         __syncthreads();
         if (tid == 0) {
             for (int i = 1; i < nthreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
-            const float nw = __uint_as_float(m) / a.denom;
+            const float nw = round_to_dtype(__uint_as_float(m) / a.denom, a.stat_dt);
             a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * a.scale[0] + nw) / a.t_q1;
         }
     }

@@ -424,11 +424,13 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, in
 }
 
 int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits, int clear_absmax,
-                    int32_t* bump_i32, qs_stream_t stream) {
+                    int32_t* bump_i32, int stat_dt, qs_stream_t stream) {
     if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
+    if (!dt_ok(stat_dt)) return QS_ERR_DTYPE;
     if (n == 0) return QS_OK;
     hipLaunchKernelGGL(scale_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, absmax,
-                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, clear_absmax, bump_i32);
+                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, clear_absmax, bump_i32,
+                       stat_dt);
     return launch_status();
 }
 
@@ -739,10 +741,12 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
                  int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int64_t chan_absmax_stride, int update_scale,
                  int64_t t_q, int bits,
                  float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
-                 const int64_t* t_mag_dev, const int64_t* t_q_dev, qs_stream_t stream) {
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, qs_stream_t stream) {
     PqArgs a;
     int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, chan_absmax_stride, update_scale, t_q, bits,
                      scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev);
+    if (st == QS_OK && update_scale && !dt_ok(stat_dt)) st = QS_ERR_DTYPE;
+    a.stat_dt = stat_dt;
     if (st) return st;
     if (update_magnitude && !stage_mean) return QS_ERR_ARG;
     if (!dt_ok(sdt)) return QS_ERR_DTYPE;

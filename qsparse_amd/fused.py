@@ -151,7 +151,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)
             _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits,
-                              t_dev=qc.device_t(h.device) if get_option("graph_safe") else None)
+                              t_dev=qc.device_t(h.device) if get_option("graph_safe") else None, stat_dtype=h.dtype)
         else:
             # step counters that live on this GPU ride along in the select launch (callback.t stays on the CPU
             # when the module was never moved with .to(device): that one is then bumped on the host)
@@ -186,7 +186,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                     t_q_dev = qc.device_t(h.device) if update_scale else None
                 _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
                                update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t,
-                               bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev)
+                               bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev, stat_dtype=h.dtype)
                 select_bumped_tq = t_q_dev is not None
         if update_scale:
             if select_bumped_tq:

@@ -297,19 +297,23 @@ class DecimalQuantizer(BaseQuantizer):
                 buf = bufs.get((n_stat, x.device))
                 if buf is None:
                     buf = bufs[(n_stat, x.device)] = torch.zeros(n_stat, dtype=torch.float32, device=x.device)
-                stat = qdist.allreduce_max_(_hip.absmax(x, channel_index, accumulate_into=buf,
-                                                        pre_relu=bool(kwargs.get("pre_relu", False))))
+                stat = _hip.absmax(x, channel_index, accumulate_into=buf, pre_relu=bool(kwargs.get("pre_relu", False)))
+                if batched:      # activations differ per rank; weights and biases (batched=False) are identical under DDP
+                    stat = qdist.allreduce_max_(stat)
                 if weight is None:
                     weight = torch.zeros(wshape, device=x.device)
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None
                 counter = kwargs.get("step_counter")
                 bump = counter.data if (counter is not None and counter.is_cuda and counter.device == x.device) else None
-                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump)
+                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump, stat_dtype=x.dtype)
                 self.__dict__["_bumped_step_counter"] = bump is not None
                 self._advance_t(t_dev)
                 return weight
             else:
-                new_weight = (qdist.allreduce_max_(_absmax_rows_cpu(x, channel_index)) / (2 ** (bits - 1))).view(wshape)
+                stat = _absmax_rows_cpu(x, channel_index)
+                if batched:
+                    stat = qdist.allreduce_max_(stat)
+                new_weight = (stat / (2 ** (bits - 1))).view(wshape)
                 if self.t == 0:
                     weight = new_weight
                 else:
@@ -383,7 +387,8 @@ class AdaptiveQuantizer(DecimalQuantizer):
         with torch.no_grad():
             if x.is_cuda:
                 lo, hi = _hip.minmax(x, channel_index)
-                qdist.allreduce_min_(lo), qdist.allreduce_max_(hi)
+                if batched:
+                    qdist.allreduce_min_(lo), qdist.allreduce_max_(hi)
                 if weight is None:
                     self.t += 1
                     return torch.stack([lo, hi], dim=1)
@@ -393,7 +398,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
                 self._advance_t(t_dev)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)
-            if qdist.exchange_active():
+            if batched and qdist.exchange_active():
                 bounds = torch.stack([qdist.allreduce_min_(bounds[:, 0].contiguous()),
                                       qdist.allreduce_max_(bounds[:, 1].contiguous())], dim=1)
             self.t += 1

@@ -460,7 +460,7 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, stream) == 0
         assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, stream) == 0
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
-                                scale.data_ptr(), None, None, None, None, None, None, stream) == 0
+                                scale.data_ptr(), None, None, None, None, None, None, 1, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
                                        1, 0, 0, 0, 0, 0, 0, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
@@ -895,3 +895,35 @@ def test_channels_last_activations_are_used_in_place(dtype):
                 assert torch.equal(ma, mb) and torch.equal(ya, yb) and torch.equal(ga, gb)
     finally:
         torch.set_num_threads(threads)
+
+
+def test_fp16_scale_quotient_is_rounded_to_fp16_and_relu_keeps_negative_zero():
+    """two fuzz finds: (1) the reference divides max|x| by 2^(bits-1) in x's dtype, so a small fp16 maximum lands on an
+    fp16 subnormal (1e-3 / 128 -> 7.8082e-6, not 7.8157e-6); (2) ATen's CPU relu returns -0.0 for -0.0, and so does
+    the ReLU folded into the prune site."""
+    x = torch.zeros(2, 8, 4, 4, dtype=torch.float16)
+    x[0, 1, 0, 0] = -1e-3
+    x[1, 3, 2, 1] = 7e-4
+    for fused in (False, True):
+        q_cpu, q_gpu = (qs.quantize(bits=8, channelwise=-1, timeout=1) for _ in range(2))
+        p_cpu, p_gpu = (qs.prune(sparsity=0.5, dimensions={1}, start=0, interval=1, repetition=1) for _ in range(2))
+        site_cpu = nn.Sequential(nn.Sequential(nn.Identity(), p_cpu), q_cpu) if fused else q_cpu
+        site_gpu = (nn.Sequential(nn.Sequential(nn.Identity(), p_gpu), q_gpu) if fused else q_gpu).to(DEV)
+        if fused:
+            from qsparse_amd.fused import fuse_prune_quantize_pairs
+            fuse_prune_quantize_pairs(site_gpu)
+        for _ in range(3):
+            y_cpu, y_gpu = site_cpu(x), site_gpu(x.to(DEV))
+            assert same(y_gpu.cpu(), y_cpu)
+        assert same(q_gpu.weight.detach().cpu(), q_cpu.weight.detach()) and float(q_cpu.weight) < 7.82e-6
+    from qsparse_amd.fused import FusedActPrune, fuse_prune_quantize_pairs
+    z = torch.tensor([[-0.0, 0.0, -1.0, 2.0]] * 2).view(2, 4, 1, 1).half()
+    sites = [fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=0, interval=1, repetition=1)))
+             for _ in range(2)]
+    sites[1].to(DEV)
+    assert type(sites[1]) is FusedActPrune
+    warm = torch.rand(2, 4, 1, 1).half() + 0.5      # the first call initialises the layer and runs module by module
+    sites[0](warm), sites[1](warm.to(DEV))            # (torch's own GPU ReLU returns +0.0 for -0.0, its CPU ReLU -0.0)
+    for _ in range(2):
+        y_cpu, y_gpu = sites[0](z), sites[1](z.to(DEV))
+        assert same(y_gpu.cpu(), y_cpu)

@@ -95,6 +95,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         site.train(training)
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
+        x[x == 0] = 0.0             # no -0.0 (fp16 underflow): torch's own CPU and GPU ReLU disagree on its sign
         # channels_last statistics are bit-exact for the configuration with a native kernel (C % 8 == 0, a batch to
         # reduce); other channels_last inputs are summed in NCHW order, 1 ulp away from ATen's layout-dependent order
         cl = channels_last and len(shape) == 4 and shape[1] % 8 == 0 and shape[0] > 1
@@ -120,6 +121,11 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         if has_relu:
             gr = torch.where(x <= 0, torch.zeros_like(gr), gr)
         ok = same(y.detach().cpu(), y_ref) and same(xg.grad.cpu(), gr.to(dtype))
+        if VERBOSE and not same(y.detach().cpu(), y_ref) and y.shape == y_ref.shape:
+            bad = (y.detach().cpu().view(-1).view(torch.int16 if y.element_size() == 2 else torch.int32)
+                   != y_ref.contiguous().view(-1).view(torch.int16 if y_ref.element_size() == 2 else torch.int32)).nonzero().view(-1)[:6]
+            print("   first mismatches (x, got, want):", [(float(x.reshape(-1)[i]), float(y.detach().cpu().reshape(-1)[i]),
+                                                            float(y_ref.reshape(-1)[i])) for i in bad.tolist()], flush=True)
         if VERBOSE:
             print(s, "y", same(y.detach().cpu(), y_ref), "gx", same(xg.grad.cpu(), gr.to(dtype)),
                   "mask", (same((site[0][1] if has_q else site[1]).mask.cpu(), ps.mask) if ps else None),
