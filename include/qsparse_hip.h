@@ -249,6 +249,26 @@ int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t absma
 int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
                      int64_t absmax_stride, qs_stream_t stream);
 
+/* ---- multi-tensor weight path ---------------------------------------------------------------------- */
+
+/* The weight-side operators of a converted network (quantize(conv) / quantize(linear), reference quantize.py:559-571
+ * through imitation.py) are the same three small kernels per layer and step.  These entry points run them for a LIST
+ * of n contiguous, 16-byte aligned float32 tensors in one launch each (per 48 tensors): tensor-wise Scaler / Decimal
+ * quantizers only.  All arrays are HOST arrays of length n holding device pointers / values.
+ *   qs_multi_absmax:        amax[i][0] = max(amax[i][0], max|x[i]|)            (keep the accumulators zero between steps;
+ *                           give every accumulator its own 128-byte line, see qs_mean_dim)
+ *   qs_multi_scale_update:  scale[i][0] <- t == 0 ? new : (t*scale + new)/(t+1), new = amax[i][0] / 2^(bits[i]-1);
+ *                           amax[i][0] <- 0; decimal[i][0] <- rint(log2(1/scale)) where decimal[i] != NULL;
+ *                           t from t_dev[i] (then incremented there) where non-NULL, else t[i]; bump[i] (nullable
+ *                           int32 counters) incremented
+ *   qs_multi_quant_fwd:     y[i] = Q(x[i]) with param[i][0] the scale (decimal == 0, qs_quant_scaler_fwd's
+ *                           arithmetic) or the decimal (decimal != 0, qs_quant_decimal_fwd's) */
+int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream);
+int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
+                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, qs_stream_t stream);
+int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
+                       int decimal, qs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@ callbacks and helpers they expose (reference qsparse/__init__.py:2-8).  GPU tens
 hand-written HIP kernels for gfx950 behind a C ABI (``include/qsparse_hip.h``,
 ``qsparse_amd/libqsparse_hip.so``); see DESIGN.md.
 """
+from qsparse_amd.batch import WeightBatcher
 from qsparse_amd.convert import convert
 from qsparse_amd.fuse import fuse_bn
 from qsparse_amd.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer, quantize,

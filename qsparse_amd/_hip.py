@@ -54,6 +54,9 @@ SIGNATURES = {
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
+    "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
@@ -550,3 +553,33 @@ def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, 
                                  amax_stride(absmax_out), _stream(gathered))
     _check(st, "qs_stats_combine")
     return stage
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-tensor weight path (host arrays of device pointers; see qs_multi_* in the header)
+# ----------------------------------------------------------------------------------------------
+def ptr_array(tensors):
+    """ctypes array of device addresses (None -> NULL)"""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else _ptr(t) for t in tensors])
+
+
+def i64_array(values):
+    return (c_int64 * len(values))(*[int(v) for v in values])
+
+
+def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
+    st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _raw_stream(device.index) if _raw_stream else
+                                torch.cuda.current_stream(device).cuda_stream)
+    _check(st, "qs_multi_absmax")
+
+
+def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device):
+    st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs,
+                                      _raw_stream(device.index) if _raw_stream else torch.cuda.current_stream(device).cuda_stream)
+    _check(st, "qs_multi_scale_update")
+
+
+def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device):
+    st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)),
+                                   _raw_stream(device.index) if _raw_stream else torch.cuda.current_stream(device).cuda_stream)
+    _check(st, "qs_multi_quant_fwd")

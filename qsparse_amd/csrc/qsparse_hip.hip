@@ -9,6 +9,7 @@
 
 #include "qs_elementwise.h"
 #include "qs_reduce.h"
+#include "qs_multi.h"
 
 #ifndef QS_EW_UNROLL
 #define QS_EW_UNROLL 1
@@ -778,6 +779,81 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
     if (!gathered || world < 1 || C < 1) return QS_ERR_ARG;
     hipLaunchKernelGGL(stats_combine_kernel, dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
                        C, stage_out, (uint32_t*)absmax_out, absmax_stride > 0 ? absmax_stride : 1);
+    return launch_status();
+}
+
+// ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
+int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !numel || !amax))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiTensors a{};
+        MultiUpdate u{};
+        a.n = u.n = std::min(kMultiMax, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int k = base + i;
+            if (!x[k] || !amax[k] || numel[k] < 0) return QS_ERR_ARG;
+            if (!aligned16(x[k])) return QS_ERR_ALIGN;
+            a.x[i] = x[k];
+            a.numel[i] = numel[k];
+            u.amax[i] = (uint32_t*)amax[k];
+            a.block0[i] = blocks;
+            const int64_t want = (numel[k] / 8 + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);   // ~4 groups per lane
+            blocks += (int)std::min<int64_t>(std::max<int64_t>(want, 1), 64);
+        }
+        a.block0[a.n] = blocks;
+        hipLaunchKernelGGL(multi_absmax_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, a, u);
+    }
+    return launch_status();
+}
+
+int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
+                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!amax || !scale || !t || !bits))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiUpdate u{};
+        u.n = std::min(kMultiMax, n - base);
+        for (int i = 0; i < u.n; ++i) {
+            const int k = base + i;
+            if (!amax[k] || !scale[k] || t[k] < 0 || bits[k] < 1 || bits[k] > 31) return QS_ERR_ARG;
+            u.amax[i] = (uint32_t*)amax[k];
+            u.scale[i] = scale[k];
+            u.decimal[i] = decimal ? decimal[k] : nullptr;
+            u.t_dev[i] = t_dev ? t_dev[k] : nullptr;
+            u.bump[i] = bump ? bump[k] : nullptr;
+            u.t[i] = (float)t[k];
+            u.denom[i] = (float)((int64_t)1 << (bits[k] - 1));
+        }
+        hipLaunchKernelGGL(multi_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
+    }
+    return launch_status();
+}
+
+int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
+                       int decimal, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !y || !param || !numel))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiTensors a{};
+        a.n = std::min(kMultiMax, n - base);
+        int64_t blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int k = base + i;
+            if (!x[k] || !y[k] || !param[k] || numel[k] < 0) return QS_ERR_ARG;
+            if (!aligned16(x[k]) || !aligned16(y[k])) return QS_ERR_ALIGN;
+            a.x[i] = x[k];
+            a.y[i] = y[k];
+            a.scale[i] = param[k];
+            a.numel[i] = numel[k];
+            a.block0[i] = (int32_t)blocks;
+            blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
+            if (blocks > 0x7fffffff) return QS_ERR_ARG;
+        }
+        a.block0[a.n] = (int32_t)blocks;
+        if (decimal)
+            hipLaunchKernelGGL((multi_quant_kernel<true>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((multi_quant_kernel<false>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+    }
     return launch_status();
 }
 

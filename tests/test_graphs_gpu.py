@@ -138,3 +138,59 @@ def test_graphed_step_wrapper_switches_to_replay_and_matches_eager():
             assert torch.equal(se[k], sg[k]), k
     finally:
         qs.set_qsparse_options(graph_safe=False)
+
+
+@pytest.mark.parametrize("graphed,quantizer", [(False, "scaler"), (True, "scaler"), (False, "decimal")])
+def test_weight_batcher_is_bit_identical(graphed, quantizer):
+    """qs.WeightBatcher evaluates the weight quantizers of all layers with three multi-tensor launches at the start of
+    the forward pass; eager and under whole-step graph capture the trajectory (losses, weights, scales, counters)
+    equals the per-layer one, training and evaluation."""
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, graph_safe=True)
+    torch.backends.cudnn.deterministic = True
+    try:
+        shape, K = (8, 3, 32, 32), 9
+        data = _batches(K, shape)
+        results = []
+        for batched in (False, True):
+            torch.manual_seed(0)
+            base = resnet18(num_classes=10, cifar_stem=True, width=16)
+            if quantizer == "scaler":
+                model = convert_pq(base, sparsity=0.5, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=2)
+            else:
+                model = qs.convert(base, qs.quantize(bits=6, channelwise=-1, timeout=2, callback=qs.DecimalQuantizer()),
+                                   weight_layers=[nn.Conv2d, nn.Linear], log=False)
+            model = model.cuda().train()
+            if batched:
+                wb = qs.WeightBatcher(model)
+                assert len(wb.layers) >= 10
+            opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+
+            def train_step(x, y):
+                opt.zero_grad(set_to_none=False)
+                loss = F.cross_entropy(model(x), y)
+                loss.backward()
+                opt.step()
+                return loss.detach()
+
+            step = graphs.GraphedStep(model, train_step) if graphed else train_step
+            losses = [float(step(x, y)) for x, y in data]
+            if graphed:
+                assert step.captured
+                step.finish()
+            model.eval()
+            with torch.no_grad():
+                ev = model(data[0][0]).float().cpu()
+            results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, ev))
+            if batched:
+                wb.remove()
+                with torch.no_grad():
+                    assert torch.equal(model(data[0][0]).float().cpu(), ev)      # inline again after remove()
+        (la, sa, ea), (lb, sb, eb) = results
+        if la[:2] != lb[:2] and quantizer == "scaler":
+            pytest.skip("backend not run-to-run deterministic")
+        assert la == lb
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(ea, eb)
+    finally:
+        qs.set_qsparse_options(graph_safe=False)

@@ -19,8 +19,10 @@ from examples.models import convert_pq, resnet18, resnet50
 CHANNELS_LAST = False
 
 
-def run(model, shape, classes, steps, warmup, dtype, graph=False):
+def run(model, shape, classes, steps, warmup, dtype, graph=False, batch_weights=False):
     model = model.cuda().train()   # fp32 master weights; bf16 compute through autocast (activations are bf16)
+    if batch_weights:
+        qs.WeightBatcher(model)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     x = torch.randn(shape, device="cuda")
     if CHANNELS_LAST:              # NHWC activations and weights: MIOpen's native layout, no transposes around the convolutions
@@ -72,12 +74,13 @@ def main():
     res = {"plain": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype),
            "plain_graph": run(copy.deepcopy(base), shape, classes, args.steps, 10, dtype, graph=True)}
     qs.set_qsparse_options(graph_safe=True)
-    for name, fuse, graph in (("pq_fused", True, False), ("pq_unfused", False, False), ("pq_fused_graph", True, True),
-                              ("pq_fused_graph_preserve_dtype", True, True)):
+    for name, fuse, graph in (("pq_fused", True, False), ("pq_unfused", False, False), ("pq_fused_batchw", True, False),
+                              ("pq_fused_graph", True, True), ("pq_fused_graph_batchw", True, True),
+                              ("pq_fused_graph_batchw_preserve_dtype", True, True)):
         qs.set_qsparse_options(preserve_dtype=name.endswith("preserve_dtype"))
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
-        res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph)
+        res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph, batch_weights="batchw" in name)
     print(args.arch, shape, args.dtype, "channels_last" if CHANNELS_LAST else "nchw", {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
