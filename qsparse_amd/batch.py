@@ -35,7 +35,7 @@ class _PrecomputedSte(torch.autograd.Function):
     def forward(ctx, w, y, step, is_decimal, bits, notch, passthrough):
         ctx.is_decimal, ctx.bits, ctx.notch, ctx.passthrough = is_decimal, bits, notch, passthrough
         ctx.save_for_backward(step)
-        return y.view(w.shape)
+        return y.view_as(y)
 
     @staticmethod
     def backward(ctx, g):
@@ -100,8 +100,9 @@ class WeightBatcher:
         train, frozen = [], []          # layers that update statistics this step / that only quantize
         for layer in self.layers:
             q, w = layer.quantize, layer._parameters["weight"]
-            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.data_ptr() % 16 == 0):
-                continue
+            dense = w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))
+            if not (w.is_cuda and w.dtype == torch.float32 and dense and w.data_ptr() % 16 == 0):
+                continue                # (tensor-wise quantization does not care about the order of a dense tensor's elements)
             if not q.initted:
                 q._lazy_init(w)
             if not (q.weight.is_cuda and q._n_updates.is_cuda):
@@ -156,7 +157,7 @@ class WeightBatcher:
                 offsets.append(total)
                 total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
             flat = torch.empty(total, dtype=torch.float32, device=dev)
-            outs = [flat[o:o + w.numel()] for o, w in zip(offsets, weights)]
+            outs = [flat[o:o + w.numel()].as_strided(w.shape, w.stride()) for o, w in zip(offsets, weights)]   # w's own layout
             numels = [w.numel() for w in weights]
             for decimal in (False, True):
                 idx = [i for i, l in enumerate(todo) if (not l.quantize.callback.use_float_scaler) == decimal]

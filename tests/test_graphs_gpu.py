@@ -140,8 +140,9 @@ def test_graphed_step_wrapper_switches_to_replay_and_matches_eager():
         qs.set_qsparse_options(graph_safe=False)
 
 
-@pytest.mark.parametrize("graphed,quantizer", [(False, "scaler"), (True, "scaler"), (False, "decimal")])
-def test_weight_batcher_is_bit_identical(graphed, quantizer):
+@pytest.mark.parametrize("graphed,quantizer,channels_last", [(False, "scaler", False), (True, "scaler", False),
+                                                             (False, "decimal", False), (False, "scaler", True)])
+def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
     """qs.WeightBatcher evaluates the weight quantizers of all layers with three multi-tensor launches at the start of
     the forward pass; eager and under whole-step graph capture the trajectory (losses, weights, scales, counters)
     equals the per-layer one, training and evaluation."""
@@ -160,6 +161,8 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer):
                 model = qs.convert(base, qs.quantize(bits=6, channelwise=-1, timeout=2, callback=qs.DecimalQuantizer()),
                                    weight_layers=[nn.Conv2d, nn.Linear], log=False)
             model = model.cuda().train()
+            if channels_last:
+                model = model.to(memory_format=torch.channels_last)
             if batched:
                 wb = qs.WeightBatcher(model)
                 assert len(wb.layers) >= 10
@@ -173,10 +176,13 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer):
                 return loss.detach()
 
             step = graphs.GraphedStep(model, train_step) if graphed else train_step
-            losses = [float(step(x, y)) for x, y in data]
+            fmt = torch.channels_last if channels_last else torch.contiguous_format
+            losses = [float(step(x.contiguous(memory_format=fmt), y)) for x, y in data]
             if graphed:
                 assert step.captured
                 step.finish()
+            if batched and channels_last:     # every layer took part, the 3x3 convolutions with their NHWC weights included
+                assert not wb._cache and all(l.quantize._quantized for l in wb.layers)
             model.eval()
             with torch.no_grad():
                 ev = model(data[0][0]).float().cpu()
