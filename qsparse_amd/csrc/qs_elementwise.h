@@ -187,8 +187,11 @@ struct LineFwdOp {
     __device__ __forceinline__ const uint8_t* mask_ptr() const { return nullptr; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t) { return p; }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
+        if (v != v) {                                    // torch.clamp and everything after it propagate NaN
+            code = (int32_t)0x80000000;
+            return v;
+        }
         float xc = fminf(fmaxf(v, p.start), p.end);      // torch.clamp(x, start, end) (:158)
-        if (v != v) xc = v;
         const float top = nlevels - 1.0f;
         if constexpr (FLOAT_ZP) {                        // :175-181
             float t = xc - p.start;

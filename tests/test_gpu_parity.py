@@ -155,6 +155,12 @@ def test_line_levels_around_halfway_points():
             assert same(y.cpu(), O.line_fwd(x, bits, lines, 1, fzp)), (seed, fzp, "per-channel")
             y = quantize_with_line(x[:, :1].contiguous().to(DEV), bits, lines[:1].to(DEV), -1, False, fzp)
             assert same(y.cpu(), O.line_fwd(x[:, :1].contiguous(), bits, lines[:1], -1, fzp)), (seed, fzp, "tensor-wise")
+    # non-finite inputs: NaN propagates (torch.clamp keeps it), +-inf clamp to the line's ends
+    xs = torch.tensor([float("nan"), float("inf"), float("-inf"), 3e38, -3e38, 0.3, -0.2, 0.0])
+    ln = torch.tensor([[-1.0, 1.5]])
+    for fzp in (True, False):
+        got, want = quantize_with_line(xs.to(DEV), 4, ln.to(DEV), -1, False, fzp).cpu(), O.line_fwd(xs, 4, ln, -1, fzp)
+        assert torch.isnan(got[0]) and torch.isnan(want[0]) and same(got[1:], want[1:]), fzp
     # degenerate rows: step == 0 is replaced by 1e-4 (quantize.py:160)
     flat = torch.tensor([[0.5, 0.5], [-1.0, 1.0]])
     xz = torch.randn(1, 2, 64, generator=gen(99))
