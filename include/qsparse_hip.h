@@ -44,7 +44,7 @@ enum qs_error {
     QS_ERR_RANK = -5       /* broadcast pattern needs more than QS_MAX_DIMS collapsed dims */
 };
 
-enum qs_workspace_op { QS_WS_KTH_VALUE = 1 };
+enum qs_workspace_op { QS_WS_KTH_VALUE = 1, QS_WS_REDUCE = 2 /* n = C * inner of a per-channel qs_absmax / qs_minmax */ };
 
 #define QS_MAX_DIMS 6
 
@@ -115,14 +115,17 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
  * DecimalQuantizer.optimize, qsparse/quantize.py:329-340.  Order-independent, hence bit-exact.
  * accumulate != 0: out is max-accumulated instead of overwritten (the caller keeps it zeroed between steps, e.g.
  * through qs_scale_update's clear_absmax), which saves the initialisation launch.
- * pre_relu != 0: the statistic of max(x, 0) -- a preceding nn.ReLU folded into the quantizer's kernels. */
+ * pre_relu != 0: the statistic of max(x, 0) -- a preceding nn.ReLU folded into the quantizer's kernels.
+ * ws (nullable): qs_workspace_bytes(QS_WS_REDUCE, C*inner) bytes of scratch; with it a per-channel reduction over few
+ * columns and many rows (channels_last activations: inner == 1, C <= 512) runs as two atomics-free stages; 0 bytes means the shape never takes that route. */
 int qs_absmax(const void* x, float* out, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, int pre_relu, qs_stream_t stream);
+              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, int pre_relu,
+              void* ws, size_t ws_bytes, qs_stream_t stream);
 
 /* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
  * (min over the batch of per-sample minima == global per-channel minimum). */
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, qs_stream_t stream);
+              int64_t outer, int64_t C, int64_t inner, int xdt, void* ws, size_t ws_bytes, qs_stream_t stream);
 
 /* Step counters.  The reference keeps them on the host (Python ints / `.item()` reads) and they enter the
  * arithmetic of every running mean.  A by-value kernel argument is frozen when a launch is captured into a

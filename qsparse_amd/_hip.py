@@ -40,8 +40,8 @@ SIGNATURES = {
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
-    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P]),
-    "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P]),
+    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P, c_size_t, _P]),
+    "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P, c_size_t, _P]),
     "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _I, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
@@ -331,6 +331,19 @@ def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, 
 # ----------------------------------------------------------------------------------------------
 # statistics
 # ----------------------------------------------------------------------------------------------
+WS_REDUCE = 2
+
+
+def _reduce_workspace(x: torch.Tensor, channel_index: int, outer: int, C: int, inner: int):
+    """scratch for the two-stage per-channel reduction over few columns (channels_last activations, 2-d inputs)"""
+    if channel_index < 0 or inner >= 64 or outer < 256:
+        return None, 0
+    nbytes = load().qs_workspace_bytes(WS_REDUCE, C * inner)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=x.device), nbytes
+
+
 def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.Tensor] = None,
            pre_relu: bool = False) -> torch.Tensor:
     """max|x| per channel / over the tensor.  `accumulate_into`: zeroed persistent fp32 buffer that is
@@ -342,9 +355,10 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
     n = C if channel_index >= 0 else 1
     out = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x.device)
     assert out.numel() == n and out.dtype == torch.float32
+    ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
     with _timed("absmax"):
         st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
-                           int(accumulate_into is not None), int(bool(pre_relu)), _stream(x))
+                           int(accumulate_into is not None), int(bool(pre_relu)), _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_absmax")
     return out
 
@@ -356,7 +370,9 @@ def minmax(x: torch.Tensor, channel_index: int):
     n = C if channel_index >= 0 else 1
     mn = torch.empty(n, dtype=torch.float32, device=x.device)
     mx = torch.empty(n, dtype=torch.float32, device=x.device)
-    st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _stream(x))
+    ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
+    st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _ptr(ws), ws_bytes,
+                       _stream(x))
     _check(st, "qs_minmax")
     return mn, mx
 

@@ -205,6 +205,7 @@ size_t qs_workspace_bytes(int op, int64_t n) {
     (void)n;
     switch (op) {
         case QS_WS_KTH_VALUE: return sizeof(SelectState);
+        case QS_WS_REDUCE: return n >= 8 && n <= kFewColsMaxCols ? (size_t)2 * kFewColsMaxBlocks * n * sizeof(uint32_t) : 0;
     }
     return 0;
 }
@@ -357,7 +358,8 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
 
 // ------------------------------------------------------------------------------------------------
 static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
-                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false, int relu = 0) {
+                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false, int relu = 0, void* ws = nullptr,
+                       size_t ws_bytes = 0) {
     if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
     if (!dt_ok(xdt)) return QS_ERR_DTYPE;
     if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
@@ -383,12 +385,27 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     if (slices > (outer + 3) / 4) slices = (outer + 3) / 4;
                     if (slices < 1) slices = 1;
                     const int64_t opb = (outer + slices - 1) / slices;
-                    const int vec_ok = vec_ptr && (inner % 8 == 0);
+                    const int vec_ok = vec_ptr ? (inner % 8 == 0 ? 1 : 2) : 0;
                     hipLaunchKernelGGL((reduce_rows_kernel<XD, M>), dim3((int)C, (int)((outer + opb - 1) / opb)), dim3(kBlock),
                                        0, s, x, outer, (uint32_t)C, inner, vec_ok, opb, omax, omin, relu);
                 } else {
                     const int64_t cols = C * inner;
                     const bool vec = vec_ptr && (cols % 8 == 0);
+                    if (vec && ws && cols <= kFewColsMaxCols && cols / 8 <= kBlock) {
+                        // few columns, many rows: two stages through the caller's workspace, no atomics
+                        const int64_t rows_per_iter = kBlock / (cols / 8);
+                        int64_t nblk = outer / (rows_per_iter * 32);     // >= 4 rounds of 8 loads per workgroup
+                        nblk = std::min<int64_t>(std::max<int64_t>(nblk, 1), kFewColsMaxBlocks);
+                        if (ws_bytes >= (size_t)(2 * nblk * cols) * sizeof(uint32_t) && outer >= 32 * rows_per_iter) {
+                            uint32_t* pmax = (uint32_t*)ws;
+                            uint32_t* pmin = pmax + nblk * cols;
+                            hipLaunchKernelGGL((reduce_fewcols_kernel<XD, M>), dim3((int)nblk), dim3(kBlock), 0, s, x, outer,
+                                               cols, pmax, pmin, relu);
+                            hipLaunchKernelGGL((reduce_fewcols_finish_kernel<M>), dim3((int)((C + 15) / 16)), dim3(kBlock), 0, s,
+                                               pmax, pmin, (int)nblk, cols, inner, omax, omin);
+                            return launch_status();
+                        }
+                    }
                     const int64_t per_block = vec ? (int64_t)kBlock * 8 : kBlock;
                     const int gx = (int)((cols + per_block - 1) / per_block);
                     int64_t gy = 1;
@@ -414,14 +431,15 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
 }
 
 int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate,
-              int pre_relu, qs_stream_t stream) {
+              int pre_relu, void* ws, size_t ws_bytes, qs_stream_t stream) {
     return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0,
-                       pre_relu != 0);
+                       pre_relu != 0, ws, ws_bytes);
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
-              int xdt, qs_stream_t stream) {
-    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream);
+              int xdt, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream, false, 0, ws,
+                       ws_bytes);
 }
 
 int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits, int clear_absmax,

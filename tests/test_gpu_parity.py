@@ -612,12 +612,24 @@ def test_reduction_kernels_all_layouts(dtype):
     vector and scalar variants), ragged sizes, single rows -- all order independent, hence exact."""
     for shape, ci in (((64, 48, 9, 9), 1), ((200, 8, 16, 16), 1), ((3, 5, 64), 1), ((1000, 16), 1), ((33, 7), 1),
                       ((16, 2048, 7, 7), 1), ((5, 3, 2, 2), 1), ((4, 6, 10, 10), 2), ((512, 512, 3, 3), 0), ((1, 8, 1, 1), 1),
-                      ((9, 4, 130), 0), ((70000,), -1), ((3, 1, 5), -1)):
+                      ((9, 4, 130), 0), ((70000,), -1), ((3, 1, 5), -1),
+                      # few columns, many rows: the two-stage path (2-d inputs, channels_last activations)
+                      ((5000, 2048), 1), ((4097, 24), 1), ((300, 8), 1), ((100000, 64), 1), ((1024, 2056), 1), ((9000, 512), 1), ((8192, 256), 1)):
         x = (torch.randn(shape, generator=gen(sum(shape))) * 3).to(dtype)
         xr = x.float().reshape(1, -1) if ci < 0 else x.float().transpose(0, ci).reshape(shape[ci], -1)
         assert same(_hip.absmax(x.to(DEV), ci).cpu(), xr.abs().amax(1)), (shape, ci)
         mn, mx = _hip.minmax(x.to(DEV), ci)
         assert same(mn.cpu(), xr.amin(1)) and same(mx.cpu(), xr.amax(1)), (shape, ci)
+    for shape in ((64, 64, 14, 14), (16, 40, 9, 9), (33, 256, 7, 7)):          # channels_last, per channel, accumulating
+        x = (torch.randn(shape, generator=gen(sum(shape))) * 3).to(dtype)
+        xcl = x.contiguous(memory_format=torch.channels_last).to(DEV)
+        want = x.float().abs().amax(dim=(0, 2, 3))
+        assert same(_hip.absmax(xcl, 1).cpu(), want), shape
+        buf = torch.full((shape[1],), 0.5, device=DEV)
+        assert same(_hip.absmax(xcl, 1, accumulate_into=buf).cpu(), torch.maximum(want, torch.tensor(0.5))), shape
+        assert same(_hip.absmax(xcl, 1, pre_relu=True).cpu(), torch.relu(x).float().amax(dim=(0, 2, 3))), shape
+        mn, mx = _hip.minmax(xcl, 1)
+        assert same(mn.cpu(), x.float().amin(dim=(0, 2, 3))) and same(mx.cpu(), x.float().amax(dim=(0, 2, 3))), shape
 
 
 @pytest.mark.parametrize("C", [200, 256, 257, 1000, 1024, 1536, 2048, 2049, 4096])
