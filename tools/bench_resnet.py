@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--frozen-masks", action="store_true",
+                    help="stop the mask refresh after 3 steps (the reference recipe's steady state: scales keep following the data)")
     args = ap.parse_args()
     global CHANNELS_LAST
     CHANNELS_LAST = args.channels_last
@@ -80,8 +82,12 @@ def main():
         qs.set_qsparse_options(preserve_dtype=name.endswith("preserve_dtype"))
         m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1,
                        quant_timeout=1, fuse=fuse)
+        if args.frozen_masks:
+            for mod in m.modules():
+                if isinstance(mod, qs.MagnitudePruningCallback):
+                    mod.stop_mask_refresh = 3
         res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph, batch_weights="batchw" in name)
-    print(args.arch, shape, args.dtype, "channels_last" if CHANNELS_LAST else "nchw", {k: round(v, 2) for k, v in res.items()}, flush=True)
+    print(args.arch, shape, args.dtype, ("channels_last" if CHANNELS_LAST else "nchw") + (" frozen-masks" if args.frozen_masks else ""), {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
 if __name__ == "__main__":
