@@ -945,3 +945,48 @@ def test_fp16_scale_quotient_is_rounded_to_fp16_and_relu_keeps_negative_zero():
     for _ in range(2):
         y_cpu, y_gpu = sites[0](z), sites[1](z.to(DEV))
         assert same(y_gpu.cpu(), y_cpu)
+
+
+def test_multi_tensor_weight_kernels_match_the_per_tensor_ones():
+    """qs_multi_absmax / qs_multi_scale_update / qs_multi_quant_fwd over 60 tensors (more than one launch's worth of 48,
+    ragged sizes included) against qs_absmax / qs_scale_update / qs_quant_*_fwd per tensor."""
+    sizes = [1, 5, 8, 9, 63, 64, 100, 1000, 4096, 36864, 147456, 65, 12345] * 5
+    sizes = sizes[:60]
+    ws = [(torch.randn(n, generator=gen(300 + i)) * (0.05 + 0.01 * i)) for i, n in enumerate(sizes)]
+    wd = [w.to(DEV) for w in ws]
+    n = len(wd)
+    bits = [2 + (i % 7) for i in range(n)]
+    ts = [i % 4 for i in range(n)]
+    scales0 = [torch.rand(1, 1, generator=gen(400 + i)) * 0.1 for i in range(n)]
+    for decimal in (False, True):
+        # reference: one tensor at a time
+        ref_scales, ref_y = [], []
+        for w, b, t, s0 in zip(wd, bits, ts, scales0):
+            s = s0.clone().to(DEV)
+            _hip.scale_update(_hip.absmax(w, -1), s.view(-1), t, b)
+            ref_scales.append(s)
+            if decimal:
+                y, _ = _hip.quant_fwd("decimal", w, _hip.decimal_from_scale(s.view(-1)).view(1, 1), -1, torch.float32)
+            else:
+                y, _ = _hip.quant_fwd("scaler", w, s, -1, torch.float32)
+            ref_y.append(y)
+        amax = torch.zeros(n, 32, device=DEV)
+        scales = [s0.clone().to(DEV) for s0 in scales0]
+        decs = torch.zeros(n, device=DEV)
+        bumps = torch.zeros(n, dtype=torch.int32, device=DEV)
+        numels = _hip.i64_array(sizes)
+        _hip.multi_absmax(n, _hip.ptr_array(wd), numels, _hip.ptr_array([amax[i] for i in range(n)]), wd[0].device)
+        _hip.multi_scale_update(n, _hip.ptr_array([amax[i] for i in range(n)]), _hip.ptr_array(scales),
+                                _hip.ptr_array([decs[i:i + 1] for i in range(n)]), _hip.i64_array(ts), _hip.ptr_array([None] * n),
+                                (_hip.c_int * n)(*bits), _hip.ptr_array([bumps[i:i + 1] for i in range(n)]), wd[0].device)
+        flat = torch.empty(sum((s + 63) // 64 * 64 for s in sizes), device=DEV)
+        outs, o = [], 0
+        for s in sizes:
+            outs.append(flat[o:o + s])
+            o += (s + 63) // 64 * 64
+        params = [decs[i:i + 1] for i in range(n)] if decimal else scales
+        _hip.multi_quant_fwd(n, _hip.ptr_array(wd), _hip.ptr_array(outs), _hip.ptr_array(params), numels, decimal, wd[0].device)
+        for i in range(n):
+            assert torch.equal(scales[i], ref_scales[i]), (decimal, i)
+            assert torch.equal(outs[i], ref_y[i]), (decimal, i, sizes[i])
+        assert not amax.any() and bool((bumps == 1).all())
