@@ -12,7 +12,9 @@ become ready one layer at a time).
     qs.WeightBatcher(model)        # once; .remove() undoes it
 
 Only layers whose weight is read through exactly one tensor-wise Scaler / Decimal ``QuantizeLayer`` (no weight pruning,
-no bias quantizer, float32 parameter on the GPU) take part; every other layer keeps its inline path.  A layer that the
+no bias quantizer, float32 parameter on the GPU) take part; every other layer keeps its inline path.  In evaluation
+mode the quantized weights are computed once and handed out again until a parameter or a scale changes (serving: no
+weight-side launch at all per request).  A layer that the
 forward pass never reaches has its statistics advanced all the same -- unlike the inline path; do not use the batcher
 for networks that skip layers data-dependently.
 """
@@ -73,6 +75,8 @@ class WeightBatcher:
         self._orig = {}
         self._amax = None
         self._decimals = None
+        self._eval_key = None
+        self._eval_outs = None
         for layer in self.layers:
             self._patch(layer)
         self._hook = model.register_forward_pre_hook(self._precompute)
@@ -87,6 +91,12 @@ class WeightBatcher:
             return y if y is not None else base.weight.__get__(self_)
 
         layer.__class__ = type(base.__name__, (base,), {"weight": property(read_weight)})
+
+    def invalidate(self):
+        """forget the quantized weights kept for evaluation.  They are reused while no parameter and no scale has been
+        written -- detected through ``Tensor._version``, which optimizers, ``load_state_dict`` and any in-place op bump;
+        writes through ``param.data`` do not, call this after such a write."""
+        self._eval_key = self._eval_outs = None
 
     def remove(self):
         self._hook.remove()
@@ -128,6 +138,17 @@ class WeightBatcher:
             self._decimals = torch.zeros(n_all, dtype=torch.float32, device=dev)
         slot = {id(l): i for i, l in enumerate(self.layers)}
         weights = [l._parameters["weight"] for l in todo]
+        # evaluation / serving: nothing changes between calls unless someone writes a parameter or a scale (both bump
+        # `_version`), so the quantized weights of the previous call are handed out again without a launch
+        eval_key = None
+        if not train:
+            eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
+                              tuple(w.stride())) for l, w in zip(todo, weights))
+            if eval_key == self._eval_key:
+                for l, w, y in zip(todo, weights, self._eval_outs):
+                    self._hand_out(l, w, y, slot)
+                return
+        self._eval_key = None
         with torch.no_grad():
             if train:
                 graph_safe = get_option("graph_safe")
@@ -167,9 +188,14 @@ class WeightBatcher:
                           for i in idx]
                 _hip.multi_quant_fwd(len(idx), _hip.ptr_array([weights[i] for i in idx]), _hip.ptr_array([outs[i] for i in idx]),
                                      _hip.ptr_array(params), _hip.i64_array([numels[i] for i in idx]), decimal, dev)
+        if eval_key is not None:
+            self._eval_key, self._eval_outs = eval_key, outs
         for l, w, y in zip(todo, weights, outs):
-            q, qc = l.quantize, l.quantize.callback
-            is_decimal = not qc.use_float_scaler
-            step = self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data
-            self._cache[id(l)] = _PrecomputedSte.apply(w, y, step, is_decimal, q.bits, 1 if qc.flip_axis else 0,
-                                                       bool(qc.backward_passthrough))
+            self._hand_out(l, w, y, slot)
+
+    def _hand_out(self, l, w, y, slot):
+        q, qc = l.quantize, l.quantize.callback
+        is_decimal = not qc.use_float_scaler
+        step = self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data
+        self._cache[id(l)] = _PrecomputedSte.apply(w, y, step, is_decimal, q.bits, 1 if qc.flip_axis else 0,
+                                                   bool(qc.backward_passthrough))

@@ -188,9 +188,16 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
                 ev = model(data[0][0]).float().cpu()
             results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, ev))
             if batched:
-                wb.remove()
                 with torch.no_grad():
-                    assert torch.equal(model(data[0][0]).float().cpu(), ev)      # inline again after remove()
+                    assert wb._eval_key is not None
+                    assert torch.equal(model(data[0][0]).float().cpu(), ev)      # second call: weights from the cache
+                    first = wb.layers[0]._parameters["weight"]
+                    first.add_(0.05)                                              # an in-place write invalidates it
+                    changed = model(data[0][0]).float().cpu()
+                    wb.remove()
+                    assert torch.equal(model(data[0][0]).float().cpu(), changed) and not torch.equal(changed, ev)
+                    first.sub_(0.05)
+                    model(data[0][0])
         (la, sa, ea), (lb, sb, eb) = results
         if la[:2] != lb[:2] and quantizer == "scaler":
             pytest.skip("backend not run-to-run deterministic")

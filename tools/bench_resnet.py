@@ -55,6 +55,30 @@ def run(model, shape, classes, steps, warmup, dtype, graph=False, batch_weights=
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def run_eval(model, shape, steps, dtype, batch_weights=False):
+    """inference: forward only, eval mode, no_grad"""
+    model = model.cuda().eval()
+    if batch_weights:
+        qs.WeightBatcher(model)
+    x = torch.randn(shape, device="cuda")
+    if CHANNELS_LAST:
+        model = model.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            return model(x)
+
+    for _ in range(8):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fwd()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--arch", default="resnet50")
@@ -62,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--eval", action="store_true", help="also time inference (forward only) of the trained network")
     ap.add_argument("--frozen-masks", action="store_true",
                     help="stop the mask refresh after 3 steps (the reference recipe's steady state: scales keep following the data)")
     args = ap.parse_args()
@@ -87,6 +112,13 @@ def main():
                 if isinstance(mod, qs.MagnitudePruningCallback):
                     mod.stop_mask_refresh = 3
         res[name] = run(m, shape, classes, args.steps, 10, dtype, graph=graph, batch_weights="batchw" in name)
+    if args.eval:
+        ev = {"plain": run_eval(copy.deepcopy(base), shape, args.steps, dtype)}
+        for name in ("pq_fused", "pq_fused_batchw"):
+            m = convert_pq(copy.deepcopy(base), sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+            run(m, shape, classes, 6, 6, dtype)            # a few training steps: masks and scales exist
+            ev[name] = run_eval(m, shape, args.steps, dtype, batch_weights="batchw" in name)
+        print(args.arch, shape, args.dtype, "inference", {k: round(v, 2) for k, v in ev.items()}, flush=True)
     print(args.arch, shape, args.dtype, ("channels_last" if CHANNELS_LAST else "nchw") + (" frozen-masks" if args.frozen_masks else ""), {k: round(v, 2) for k, v in res.items()}, flush=True)
 
 
