@@ -46,6 +46,16 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
     return True
 
 
+def _absmax_accumulator_dense(q: QuantizeLayer, C: int, device) -> torch.Tensor:
+    """persistent dense [C] accumulator for the abs-max passes that run on their own (no statistics stage to ride on):
+    zero on entry because the select re-zeroes it, so the reduction needs no initialisation launch."""
+    buf = getattr(q, "_chan_absmax_dense", None)
+    if buf is None or buf.shape[0] != C or buf.device != device:
+        buf = torch.zeros(C, dtype=torch.float32, device=device)
+        q._chan_absmax_dense = buf
+    return buf
+
+
 def _absmax_accumulator(q: QuantizeLayer, C: int, device) -> torch.Tensor:
     """persistent per-layer scratch for the per-channel abs-max (not a parameter, not in state_dict)."""
     buf = getattr(q, "_chan_absmax", None)
@@ -171,11 +181,11 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 if rides:
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 elif update_scale:
-                    chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
+                    chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax if rides else None,
                                          absmax_channel_dim=1, pre_relu=pre_relu).contiguous().view(-1)
             elif update_scale:
-                chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu)
+                chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
             if qdist.exchange_active(world):
                 stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:

@@ -18,6 +18,10 @@ m = m.cuda().train()
 x = torch.randn(shape, device="cuda"); y = torch.randint(0, classes, (shape[0],), device="cuda")
 if "channels_last" in sys.argv:
     m = m.to(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
+if "frozen" in sys.argv and mode != "plain":
+    for mod in m.modules():
+        if isinstance(mod, qs.MagnitudePruningCallback):
+            mod.stop_mask_refresh = 3
 if "batchw" in sys.argv and mode != "plain":
     qs.WeightBatcher(m)
 opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
