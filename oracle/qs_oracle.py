@@ -16,7 +16,7 @@ against this file in the same test module.
 Every function cites the reference lines it restates (paths relative to /root/reference).
 """
 import math
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Union
 
 import torch
 

@@ -19,8 +19,6 @@ The state machines of both layers (schedules, counters, refresh policy: referenc
 The same idea one operator at a time: ``FusedActQuantize`` and ``FusedActPrune`` fold a plain ``nn.ReLU`` into a lone
 quantize / prune site (``Sequential(act, op)``), see the classes below.
 """
-from typing import Optional
-
 import torch
 import torch.nn as nn
 

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 from qsparse_amd import distributed as qdist
-from qsparse_amd.common import HostMirror, f32_round
+from qsparse_amd.common import HostMirror
 from qsparse_amd.imitation import imitate
 from qsparse_amd.util import (_reduction_plan, _staged_mean_hip, calculate_mask_given_importance, get_option, logging,
                               squeeze_tensor_to_shape, threshold_rank)

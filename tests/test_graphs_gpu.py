@@ -1,8 +1,6 @@
 """hipGraph capture of whole training steps (forward + backward + optimizer) of networks converted with the
 --pq recipe: K replays must leave the network -- weights, masks, scales, magnitudes, counters -- exactly where
 K eager steps leave it."""
-import copy
-
 import pytest
 import torch
 import torch.nn as nn

@@ -3,7 +3,6 @@ vectors recorded from the real reference.  These mirror the reference's own prop
 (tests/test_quantize.py, tests/test_sparse.py, tests/test_convert.py, tests/test_util.py) but compare
 with recorded reference outputs bit for bit.  The same trajectories run on the GPU in test_gpu_*.py.
 """
-import json
 from collections import OrderedDict
 
 import numpy as np

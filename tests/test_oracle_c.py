@@ -2,7 +2,6 @@
 (oracle/qs_oracle.py, itself pinned to the reference's golden vectors).  CPU only."""
 import ctypes
 import os
-import subprocess
 
 import numpy as np
 import pytest
