@@ -187,7 +187,7 @@ def main():
     events = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i % 16 == 15:
+        if i % 16 == 15 or i == args.steps - 1:     # (the last step too, so that short runs carry a roofline as well)
             _hip.start_event_log(only=None)
         elif i % 4 == 3:
             _hip.start_event_log(only=dom)
