@@ -92,3 +92,18 @@ def test_mnist_pq_on_gpu_matches_cpu_state_machine():
         if k.endswith(("_n_updates", "_cur_sparsity", ".t")):
             assert torch.equal(sc[k], sg[k].cpu()), k
     assert lg[-1] < lg[0]
+
+
+@pytest.mark.gpu
+def test_resnet_recipe_example_runs(capsys):
+    """examples/resnet_pq_ddp.py (BASELINE configs 3-5 as a recipe): single process, channels_last, whole-step graph
+    replay and batched weight quantizers together."""
+    import qsparse_amd as qs
+    from examples import resnet_pq_ddp
+    try:
+        resnet_pq_ddp.main(["--arch", "resnet18", "--batch", "16", "--steps", "3", "--warmup", "14", "--channels-last", "--graph",
+                            "--batch-weights"])
+    finally:
+        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, log_on_created=True, log_during_train=True)
+    out = capsys.readouterr().out
+    assert "images/s" in out and "graphed" in out
