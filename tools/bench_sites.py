@@ -17,6 +17,9 @@ from qsparse_amd.fused import fuse_prune_quantize_pairs
 
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
 DEV = "cuda"
+GRAPH = "--graph" in sys.argv
+if GRAPH:
+    qs.set_qsparse_options(graph_safe=True)
 
 
 def run(site, shape, nbuf, bytes_per_elem, label, steps=200):
@@ -29,10 +32,24 @@ def run(site, shape, nbuf, bytes_per_elem, label, steps=200):
     for i in range(50):
         torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
     torch.cuda.synchronize()
+    graphs = None
+    if GRAPH:      # one captured step per buffer: what the kernels alone take, without the Python between them
+        graphs = []
+        for k in range(nbuf):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                torch.autograd.grad(site(xs[k]), xs[k], g)
+            graphs.append(gr)
+        for k in range(nbuf):
+            graphs[k].replay()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for i in range(steps):
-        torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
+        if graphs:
+            graphs[i % nbuf].replay()
+        else:
+            torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
