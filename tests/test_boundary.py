@@ -72,3 +72,23 @@ def test_gpu_tensors_fail_loudly_without_the_library(monkeypatch, tmp_path):
     # a host tensor can never be handed to a kernel
     with pytest.raises(_hip.QsparseHipError):
         _hip._ptr(torch.zeros(4))
+
+
+@pytest.mark.gpu
+def test_integration_md_binding_sketch_runs_as_written():
+    """the ctypes stub INTEGRATION.md shows a maintainer (reference-side binding of qs_quant_scaler_fwd) is executed
+    verbatim against the built library and checked against the oracle."""
+    import re
+    import torch
+    from oracle import qs_oracle as O
+    from qsparse_amd import _hip
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch\n.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libqsparse_hip.so")', f'ctypes.CDLL("{_hip.lib_path()}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    x = (torch.randn(4, 8, 7, 7, generator=torch.Generator().manual_seed(0)) * 2).bfloat16()
+    s = torch.rand(8, 1, generator=torch.Generator().manual_seed(1)) * 0.1 + 0.01
+    assert torch.equal(ns["scaler_fwd"](x.cuda(), s.cuda(), 1).cpu(), O.scaler_fwd(x, 8, s, 1))
