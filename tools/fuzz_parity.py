@@ -52,20 +52,21 @@ def one_case(rng, idx):
     steps = rng.choice([4, 6, 8])
     eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
     channels_last = rng.random() < 0.35
+    preserve = rng.random() < 0.2
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last)
+                    channels_last, preserve)
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False):
+             channels_last=False, preserve=False):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last)
+                       channels_last=channels_last, preserve=preserve)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -73,7 +74,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
     k = max(int(sparsity * shape[1] - 1), 0) + 1
     if k >= shape[1]:
         return None
-    qs.set_qsparse_options(fold_relu=fold)
+    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve)
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
     has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
     has_p = has_p or "pair" in site_kind
@@ -113,6 +114,8 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         # (the reference's quantizer statistics call .view on their input and raise for a channels_last tensor,
         # quantize.py:333; abs-max and the element-wise math do not depend on the layout, so the oracle gets a copy)
         y_ref = qsim.step(r.contiguous() if cl else r, training) if qsim else r
+        if preserve:                # the extension returns the float32 result rounded once to the input dtype
+            y_ref = y_ref.to(dtype)
         gr = gout
         if qsim:
             gr = qsim.grad(gr.to(y_ref.dtype), dtype)
