@@ -3,13 +3,13 @@
 kinds, channel-wise modes, mask dimension sets, pruning policies, schedules, wrapped Conv/Linear layers with weight and
 bias operators) run a few training + evaluation steps on CPU tensors (the reference's own op sequence, pinned by the
 golden fixtures) and on GPU tensors (the kernels); outputs, input/parameter gradients and the whole state_dict must
-agree bit for bit.  Development tool; usage:  python3 tools/fuzz_cpu_gpu.py [cases=150] [seed=0]"""
+agree bit for bit.  Development tool; usage:  python3 tests/fuzz/fuzz_cpu_gpu.py [cases=150] [seed=0]"""
 import copy
 import os
 import random
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -251,7 +251,7 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             continue
         x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -0.5]).to(dtype)
-        x[x == 0] = 0.0             # no -0.0 (see tools/fuzz_parity.py)
+        x[x == 0] = 0.0             # no -0.0 (see tests/fuzz/fuzz_parity.py)
         if channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         xd = x.to(device).requires_grad_(True)
@@ -310,7 +310,7 @@ def one_case(rng, idx, dry=False):
 
 
 def main():
-    torch.set_num_threads(min(8, torch.get_num_threads()))     # see tools/fuzz_parity.py
+    torch.set_num_threads(min(8, torch.get_num_threads()))     # see tests/fuzz/fuzz_parity.py
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)

@@ -2,12 +2,12 @@
 """Randomised differential test: convert-style activation sites on the GPU against the CPU oracle's state machines
 (oracle/qs_oracle.py: PruneSim, QuantizeSim), bit for bit, over random shapes, dtypes, schedules, site kinds and
 training/evaluation switches.  Development tool (the fixed cases live in tests/); usage:
-    python3 tools/fuzz_parity.py [cases=200] [seed=0]"""
+    python3 tests/fuzz/fuzz_parity.py [cases=200] [seed=0]"""
 import os
 import random
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

@@ -1,4 +1,4 @@
-"""Fixed-seed runs of the randomised differential tests under tools/ (site state machines against the oracle, CPU path
+"""Fixed-seed runs of the randomised differential tests under tests/fuzz/ (site state machines against the oracle, CPU path
 against HIP path of whole modules and of the functional API).  A few hundred random configurations per run; the tools
 themselves take a case count and a seed for longer campaigns."""
 import importlib.util
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load(name):
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", "fuzz", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -23,10 +23,10 @@ def _load(name):
 @pytest.fixture(autouse=True)
 def _quiet_and_restore():
     import torch
-    before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu")}
+    before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu", "preserve_dtype")}
     threads = torch.get_num_threads()
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
-    torch.set_num_threads(min(8, threads))      # ATen's channels_last reductions depend on the thread split (tools/fuzz_parity.py)
+    torch.set_num_threads(min(8, threads))      # ATen's channels_last reductions depend on the thread split (tests/fuzz/fuzz_parity.py)
     yield
     torch.set_num_threads(threads)
     qs.set_qsparse_options(**before)

@@ -816,12 +816,12 @@ def test_out_of_range_codes_follow_the_cpu_conversion():
     ((1, 3), torch.float16, "relu_p", True), ((1, 6), torch.float32, "relu_q", True), ((2, 3), torch.bfloat16, "q", True),
     ((3, 2, 1, 1), torch.float32, "pair", True), ((1, 5), torch.float32, "relu_p", True)])
 def test_sites_with_a_batch_of_one_and_tiny_tensors(shape, dtype, site, fold):
-    """regressions found by tools/fuzz_parity.py: a batch of one leaves the fused pair without a statistics stage in
+    """regressions found by tests/fuzz/fuzz_parity.py: a batch of one leaves the fused pair without a statistics stage in
     front of the channel dim (the abs-max must not ride along), tensors of fewer than 8 elements, masks that cover
     every element under the ReLU fold."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                             "tools", "fuzz_parity.py"))
+                                                                             "tests", "fuzz", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     try:
