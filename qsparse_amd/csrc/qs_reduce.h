@@ -597,15 +597,36 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
         };
 
         int64_t i = 0;
-        while (i + step <= n) {
-            // step is a power of two >= 16, so it is a multiple of ROWS_IN_FLIGHT (8 or 16)
-            for (int64_t j = 0; j < step; j += ROWS_IN_FLIGHT) {
-                Raw8<DT> r[ROWS_IN_FLIGHT];
+        if constexpr (ROWS_IN_FLIGHT > 16) {
+            // deep variant for launches with few waves per CU (the host picks it): several 16-row chunks are
+            // fetched ahead, the adds and carries keep their order.  step == 16 for every n < 2^20.
+            if (step == 16) {
+                while (i + ROWS_IN_FLIGHT <= n) {
+                    Raw8<DT> r[ROWS_IN_FLIGHT];
 #pragma unroll
-                for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+                    for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+                        r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, g_base + (i + u) * row_groups);
+#pragma unroll
+                    for (int c = 0; c < ROWS_IN_FLIGHT / 16; ++c) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) consume(r[c * 16 + u]);
+                        i += 16;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+                    }
+                }
+            }
+        }
+        constexpr int kBatch = ROWS_IN_FLIGHT > 16 ? 16 : ROWS_IN_FLIGHT;
+        while (i + step <= n) {
+            // step is a power of two >= 16, so it is a multiple of kBatch (8 or 16)
+            for (int64_t j = 0; j < step; j += kBatch) {
+                Raw8<DT> r[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u)
                     r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, g_base + (i + j + u) * row_groups);
 #pragma unroll
-                for (int u = 0; u < ROWS_IN_FLIGHT; ++u) consume(r[u]);
+                for (int u = 0; u < kBatch; ++u) consume(r[u]);
             }
             i += step;
 #pragma unroll
@@ -713,7 +734,9 @@ __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x,
 // n % 2^p tail rows and finishes.  Bit-identical to the single-wave kernel; needs n / 2^p <= kMaxSplitChunks.
 constexpr int kMaxSplitChunks = 32;
 
-template <int DT, int ODT, int R>
+// MODE 1 (|x|) / 2 (max(x, 0)) as in mean_outer_vec_kernel: mean operand == abs-max key, every lane inside one channel
+// (chan_div % 8 == 0); MODE 0 handles every other flag combination.
+template <int DT, int ODT, int R, int MODE>
 __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                    int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                                    int flags, const int32_t* __restrict__ l0_flag,
@@ -747,6 +770,24 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
         }
     };
 
+    auto consume = [&](const Raw8<DT>& r, auto add) {
+        float v[8];
+        unpack8<DT>(r, v);
+        if constexpr (MODE == 1 || MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = (MODE == 2) ? fmaxf(v[k], 0.0f) : v[k];
+                const uint32_t key = __float_as_uint(w) & 0x7fffffffu;
+                amax0 = key > amax0 ? key : amax0;
+                add(k, __uint_as_float(key));
+            }
+        } else {
+            if (absmax) track(v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) add(k, mean_prep<DT>(v[k], flags, l0));
+        }
+    };
+
     if (active) {
         for (int ch = wave; ch < nchunks; ch += R) {
             float acc[8];
@@ -756,15 +797,9 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
             for (int64_t j = 0; j < step; j += 16) {
                 Raw8<DT> r[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, false>(x, g_base + (r0 + j + u) * row_groups);
+                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, g_base + (r0 + j + u) * row_groups);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    float v[8];
-                    unpack8<DT>(r[u], v);
-                    if (absmax) track(v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += mean_prep<DT>(v[k], flags, l0);
-                }
+                for (int u = 0; u < 16; ++u) consume(r[u], [&](int k, float val) { acc[k] += val; });
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) chunk_sums[(ch * 8 + j) * 64 + lane] = acc[j];
@@ -781,11 +816,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
             }
         }
         for (int64_t i = (int64_t)nchunks * step; i < n; ++i) {       // n % step tail rows, sequential into level 0
-            float v[8];
-            unpack8<DT>(load8_raw<DT, false>(x, g_base + i * row_groups), v);
-            if (absmax) track(v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[j].add(mean_prep<DT>(v[j], flags, l0));
+            consume(load8_raw<DT, false>(x, g_base + i * row_groups), [&](int k, float val) { c[k].add(val); });
         }
         float m[8];
         const float fn = (float)n;

@@ -493,6 +493,7 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
         const int want = env_int("QS_MEAN_SPLIT", 0);
         if (want > 0) R = want;
         else if (waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
+        else if (waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
         while (R > 1 && R > nchunks) R >>= 1;
         if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
         if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
@@ -511,28 +512,46 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 if (R == 1) {
                     const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
                                                     (flags == 0 && !am ? 3 : 0)));
-                    if (mode == 3)
-                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 3>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
-                    else if (mode == 1)
-                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 1>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
-                    else if (mode == 2)
-                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 2>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
-                    else
-                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, QS_MEAN_ROWS_IN_FLIGHT, 0>), dim3(blocks), dim3(64), 0,
-                                           s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
+                    // few waves per CU: keep more rows in flight per wave instead (latency-, not bandwidth-bound)
+                    // (2-byte inputs only: 32 fp32 rows of 8 columns do not fit the register file)
+                    int depth = env_int("QS_MEAN_DEPTH", 0);
+                    if (depth == 0) depth = (blocks < 4 * 256 && n >= 32) ? 32 : QS_MEAN_ROWS_IN_FLIGHT;
+                    if (XD == QS_F32) depth = QS_MEAN_ROWS_IN_FLIGHT;
+                    auto launch = [&](auto D, auto M) {
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, decltype(D)::value, decltype(M)::value>), dim3(blocks),
+                                           dim3(64), 0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
+                    };
+                    auto by_mode = [&](auto D) {
+                        if (mode == 3) launch(D, IC<3>{});
+                        else if (mode == 1) launch(D, IC<1>{});
+                        else if (mode == 2) launch(D, IC<2>{});
+                        else launch(D, IC<0>{});
+                    };
+                    if constexpr (XD != QS_F32) {
+                        if (depth >= 32) by_mode(IC<32>{});
+                        else by_mode(IC<QS_MEAN_ROWS_IN_FLIGHT>{});
+                    } else {
+                        by_mode(IC<QS_MEAN_ROWS_IN_FLIGHT>{});
+                    }
                 }
-                else if (R == 2)
-                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 2>), dim3(blocks), dim3(128), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
-                else if (R == 4)
-                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 4>), dim3(blocks), dim3(256), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
-                else
-                    hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, 8>), dim3(blocks), dim3(512), lds, s, x, out, pre, n,
-                                       post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, Cc, lanes);
+                else {
+                    const int64_t cd = chan_div > 0 ? chan_div : 1;
+                    const int smode = (l0_flag || !am || cd % 8 != 0) ? 0 : (flags == QS_MEAN_ABS ? 1 :
+                                      (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
+                    auto launch = [&](auto RR, auto M) {
+                        constexpr int kR = decltype(RR)::value;
+                        hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value>), dim3(blocks), dim3(64 * kR),
+                                           lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes);
+                    };
+                    auto by_mode = [&](auto RR) {
+                        if (smode == 1) launch(RR, IC<1>{});
+                        else if (smode == 2) launch(RR, IC<2>{});
+                        else launch(RR, IC<0>{});
+                    };
+                    if (R == 2) by_mode(IC<2>{});
+                    else if (R == 4) by_mode(IC<4>{});
+                    else by_mode(IC<8>{});
+                }
             }
             if (vcols < post) {
                 const int64_t total = pre * (post - vcols);

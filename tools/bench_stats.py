@@ -11,7 +11,8 @@ import torch
 from qsparse_amd import _hip
 
 SHAPES = [(64, 64, 56, 56), (64, 256, 56, 56), (64, 128, 28, 28), (64, 512, 28, 28), (64, 256, 14, 14), (64, 1024, 14, 14),
-          (64, 512, 7, 7), (64, 2048, 7, 7), (128, 64, 32, 32), (128, 512, 4, 4)]
+          (64, 512, 7, 7), (64, 2048, 7, 7), (128, 64, 32, 32), (128, 512, 4, 4), (256, 64, 56, 56), (128, 64, 56, 56),
+          (256, 128, 28, 28), (256, 256, 56, 56)]
 
 
 def t_us(fn, iters=30, warm=5):
@@ -35,26 +36,34 @@ def main():
     dev = "cuda"
     noabs = "--noabs" in sys.argv
     stride = 1 if "--dense" in sys.argv else 32     # abs-max accumulator: dense float[C] or one 128-byte line per channel
-    splits = [int(s) for s in sys.argv[1:] if s.isdigit()] or [0, 1, 2, 4, 8]
-    print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{'R=' + str(r):>14s}" for r in splits))
+    depth_sweep = "--depth" in sys.argv          # sweep the rows in flight per wave (QS_MEAN_DEPTH) of the unsplit kernel instead
+    splits = [int(s) for s in sys.argv[1:] if s.isdigit()] or ([0, 16, 32] if depth_sweep else [0, 1, 2, 4, 8])
+    print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{('D=' if depth_sweep else 'R=') + str(r):>14s}" for r in splits))
     for shp in SHAPES:
         N, C, H, W = shp
         for dtype, code, nbytes in ((torch.bfloat16, 1, 2), (torch.float32, 0, 4)):
-            x = torch.randn(shp, device=dev).to(dtype)
+            nrot = max(1, min(6, int(6e8 // (N * C * H * W * nbytes))))     # rotate inputs past the 256 MiB Infinity Cache
+            xs = [torch.randn(shp, device=dev).to(dtype) for _ in range(nrot)]
+            x = xs[0]
+            turn = [0]
             stage = torch.empty(C * H * W, device=dev, dtype=dtype)
             amax = torch.zeros(C * 32, device=dev)
             cells = []
             for r in splits:
-                os.environ["QS_MEAN_SPLIT"] = str(r)
+                if depth_sweep:
+                    os.environ["QS_MEAN_SPLIT"], os.environ["QS_MEAN_DEPTH"] = ("1" if r else "0"), str(r)
+                else:
+                    os.environ["QS_MEAN_SPLIT"] = str(r)
 
                 def stats():
-                    assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, code, code, 1 | 4, None,
+                    turn[0] += 1
+                    assert lib.qs_mean_dim(xs[turn[0] % nrot].data_ptr(), stage.data_ptr(), 1, N, C * H * W, code, code, 1 | 4, None,
                                            None if noabs else amax.data_ptr(), stride, H * W, C, None) == 0
 
                 us = t_us(stats)
                 cells.append(f"{us:6.1f}us {x.numel() * nbytes / us / 1e3:5.0f}GB/s"[:14].rjust(14))
             print(f"{str(shp):24s} {str(dtype)[6:]:6s} " + " ".join(cells), flush=True)
-    os.environ["QS_MEAN_SPLIT"] = "0"
+    os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = "0"
 
 
 if __name__ == "__main__":
