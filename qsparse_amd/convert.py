@@ -28,6 +28,9 @@ def _fresh_kwargs(kwargs: Mapping) -> Mapping:
     return {k: (copy.deepcopy(v) if isinstance(v, nn.Module) else v) for k, v in kwargs.items()}
 
 
+copy_nn_module_on_demand = _fresh_kwargs      # the reference's name for it (convert.py:14)
+
+
 def _type_name(m) -> str:
     """class name used to match a module against ``weight_layers`` / ``activation_layers``; a wrapper
     ``Sequential`` produced by an earlier conversion is named after the layer it wraps."""

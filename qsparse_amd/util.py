@@ -204,6 +204,11 @@ def _printer(color: str = ""):
     return emit
 
 
+def log_functor(name: str, color: str = ""):
+    """the reference's factory for the methods below (util.py:163): `name` is unused there as well."""
+    return _printer(color)
+
+
 class logging:
     """console logger with the reference's method names."""
 
