@@ -606,6 +606,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 #pragma unroll
                     for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
                         r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, g_base + (i + u) * row_groups);
+                    __builtin_amdgcn_sched_barrier(0);      // all loads are issued before the first add (the scheduler would interleave)
 #pragma unroll
                     for (int c = 0; c < ROWS_IN_FLIGHT / 16; ++c) {
 #pragma unroll
@@ -665,62 +666,209 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 // maximum over n of the mean's operand (|x| or max(x, 0)) as a uint32 key; the following qs_mean_last2 launch, which
 // runs one workgroup per channel anyway, reduces it to the per-channel abs-max -- no atomics at all.
 // MODE 1: |x|, 2: max(x, 0), 3: x as it is (no abs-max).
+template <int MODE>
+__device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am) {
+    if constexpr (MODE == 3) return v;
+    const float w = (MODE == 2) ? fmaxf(v, 0.0f) : v;
+    const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
+    am = k > am ? k : am;
+    return __uint_as_float(k);
+}
+
+// positions hw < 4*floor(HW/4): multi-row order (the host launches it over those positions only)
 template <int DT, int ODT, int MODE>
 __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
-                                                      int64_t hw, int64_t C, uint32_t* __restrict__ amax_part, int lanes) {
+                                                      int64_t hw, int64_t C, uint32_t* __restrict__ amax_part, int lanes,
+                                                      int64_t ngroups) {
     const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
     const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
-    if ((int)threadIdx.x >= lanes || t >= groups) return;
+    if ((int)threadIdx.x >= lanes || t >= ngroups) return;
     const int64_t col0 = t * 8;
     const int64_t pos = col0 / C, c0 = col0 - pos * C;
-    const int64_t hw_multi = (hw / 4) * 4;
     const int lp = max(4, ceil_log2_i64(n) / 4);
     const int64_t step = (int64_t)1 << lp, lmask = step - 1;
     uint32_t amax[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax[j] = 0u;
-    auto prep = [&](float v, uint32_t& am) -> float {
-        if constexpr (MODE == 3) return v;
-        const float w = (MODE == 2) ? fmaxf(v, 0.0f) : v;
-        const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
-        am = k > am ? k : am;
-        return __uint_as_float(k);
-    };
-    float m[8];
-    if (pos < hw_multi) {
-        Cascade acc[8];
-        auto consume = [&](const Raw8<DT>& r) {
-            float v[8];
-            unpack8<DT>(r, v);
+    Cascade acc[8];
+    auto consume = [&](const Raw8<DT>& r) {
+        float v[8];
+        unpack8<DT>(r, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j].add(prep(v[j], amax[j]));
-        };
-        int64_t i = 0;
-        while (i + step <= n) {
+        for (int j = 0; j < 8; ++j) acc[j].add(mean_cl_prep<MODE>(v[j], amax[j]));
+    };
+    int64_t i = 0;
+    while (i + step <= n) {
+        for (int64_t j = 0; j < step; j += 16) {
+            Raw8<DT> r[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (i + j + u) * groups);
+            __builtin_amdgcn_sched_barrier(0);          // all 16 rows in flight before the first add
+#pragma unroll
+            for (int u = 0; u < 16; ++u) consume(r[u]);
+        }
+        i += step;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+    }
+    for (; i < n; ++i) consume(load8_raw<DT, false>(x, t + i * groups));
+    const float fn = (float)n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t o = (c0 + j) * hw + pos;
+        store1<ODT>(out, o, acc[j].total() / fn);     // .div_(n) in fp32, then one rounding to ODT
+        if (MODE != 3 && amax_part) amax_part[o] = amax[j];
+    }
+}
+
+// mean_cl_kernel for launches with few waves (small maps, small batches): the R waves of a workgroup own the same
+// column groups and share the rows chunk-wise exactly as mean_outer_split_kernel does -- chunk sums (what ATen's
+// level-0 accumulator holds when it is dumped into level 1) parked in LDS, wave 0 feeds them in order through levels
+// 1..3 and adds the n % 2^p last rows; the waves' abs-max keys are combined through LDS as well.
+// LDS: [n / 2^p][8][64] floats + [R][8][64] keys.
+template <int DT, int ODT, int R, int MODE>
+__global__ __launch_bounds__(64 * R) void mean_cl_split_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
+                                                                int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
+                                                                int lanes, int64_t ngroups) {
+    extern __shared__ __attribute__((aligned(16))) float cl_chunk_sums[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups = hw * C / 8;
+    const int64_t t = (int64_t)blockIdx.x * lanes + lane;
+    const bool active = lane < lanes && t < ngroups;
+    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    const int nchunks = (int)(n / step);
+    uint32_t* amax_lds = (uint32_t*)(cl_chunk_sums + (size_t)nchunks * 8 * 64);
+    uint32_t amax[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax[j] = 0u;
+    if (active) {
+        for (int ch = wave; ch < nchunks; ch += R) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            const int64_t r0 = (int64_t)ch * step;
             for (int64_t j = 0; j < step; j += 16) {
                 Raw8<DT> r[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (i + j + u) * groups);
+                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (r0 + j + u) * groups);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) consume(r[u]);
+                for (int u = 0; u < 16; ++u) {
+                    float v[8];
+                    unpack8<DT>(r[u], v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += mean_cl_prep<MODE>(v[k], amax[k]);
+                }
             }
-            i += step;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+            for (int k = 0; k < 8; ++k) cl_chunk_sums[(ch * 8 + k) * 64 + lane] = acc[k];
         }
-        for (; i < n; ++i) consume(load8_raw<DT, false>(x, t + i * groups));
+        if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = acc[j].total();
-    } else {
+            for (int k = 0; k < 8; ++k) amax_lds[(wave * 8 + k) * 64 + lane] = amax[k];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        Cascade c[8];
+        for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            m[j] = sum_row_sum(n, [&](int64_t i) { return prep(load1<DT>(x, (i * groups + t) * 8 + j), amax[j]); });
+            for (int k = 0; k < 8; ++k) {
+                c[k].a0 = cl_chunk_sums[(ch * 8 + k) * 64 + lane];
+                c[k].carry((int64_t)(ch + 1) * step, lp, lmask);
+            }
+        }
+        for (int64_t i = (int64_t)nchunks * step; i < n; ++i) {
+            float v[8];
+            unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k].add(mean_cl_prep<MODE>(v[k], amax[k]));
+        }
+        for (int w = 1; w < R; ++w) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t o = amax_lds[(w * 8 + k) * 64 + lane];
+                amax[k] = o > amax[k] ? o : amax[k];
+            }
+        }
+        const int64_t col0 = t * 8;
+        const int64_t pos = col0 / C, c0 = col0 - pos * C;
+        const float fn = (float)n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t o = (c0 + k) * hw + pos;
+            store1<ODT>(out, o, c[k].total() / fn);
+            if (MODE != 3 && amax_part) amax_part[o] = amax[k];
+        }
+    }
+}
+
+// the remaining HW % 4 positions: row-sum order, i.e. per column four interleaved multi-row sums over n/4 rows each
+// (row i feeds sum i % 4), the n % 4 last rows added to the first of them, then ((p0 + p1) + p2) + p3 -- sum_row_sum()
+// with the 8 columns of a lane fetched by one 16-byte load per row.  A lane owns group `first_group + t` of every row.
+template <int DT, int ODT, int MODE>
+__global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
+                                                           int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
+                                                           int64_t first_group, int64_t ngroups) {
+    const int64_t groups = hw * C / 8;
+    const int64_t tt = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tt >= ngroups) return;
+    const int64_t t = first_group + tt;
+    const int64_t col0 = t * 8;
+    const int64_t pos = col0 / C, c0 = col0 - pos * C;
+    const int64_t n4 = n / 4;
+    const int lp = max(4, ceil_log2_i64(n4) / 4);
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    uint32_t amax[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax[j] = 0u;
+    Cascade acc[4][8];
+    auto consume = [&](const Raw8<DT>& r, Cascade (&a)[8]) {
+        float v[8];
+        unpack8<DT>(r, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j].add(mean_cl_prep<MODE>(v[j], amax[j]));
+    };
+    int64_t e = 0;                                      // elements consumed per interleaved sum
+    while (e + step <= n4) {
+        for (int64_t j = 0; j < step; j += 4) {         // 16 rows = 4 elements of each of the four sums
+            Raw8<DT> r[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, false>(x, t + (4 * (e + j) + u) * groups);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) consume(r[u], acc[u & 3]);
+        }
+        e += step;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j].carry(e, lp, lmask);
+    }
+    for (; e < n4; ++e) {
+        Raw8<DT> r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = load8_raw<DT, false>(x, t + (4 * e + k) * groups);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) consume(r[k], acc[k]);
+    }
+    float p[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[k][j] = acc[k][j].total();
+    for (int64_t i = n4 * 4; i < n; ++i) {
+        float v[8];
+        unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[0][j] += mean_cl_prep<MODE>(v[j], amax[j]);
     }
     const float fn = (float)n;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t o = (c0 + j) * hw + pos;
-        store1<ODT>(out, o, m[j] / fn);              // .div_(n) in fp32, then one rounding to ODT
+        store1<ODT>(out, o, (((p[0][j] + p[1][j]) + p[2][j]) + p[3][j]) / fn);
         if (MODE != 3 && amax_part) amax_part[o] = amax[j];
     }
 }

@@ -572,21 +572,46 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
     if (!aligned16(x)) return QS_ERR_ALIGN;
     const int mode = flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : (flags == 0 ? 3 : 0));
     if (mode == 0 || (mode == 3 && amax_part)) return QS_ERR_ARG;
-    const int64_t groups = hw * C / 8;
-    const int lanes = mean_lanes(groups);
-    const int blocks = (int)((groups + lanes - 1) / lanes);
+    const int64_t main_groups = (hw / 4) * 4 * C / 8, tail_groups = hw * C / 8 - main_groups;   // ATen's split of H*W
+    const int lanes = mean_lanes(main_groups > 0 ? main_groups : 1);
+    const int blocks = (int)((main_groups + lanes - 1) / lanes);
+    const int tail_blocks = (int)((tail_groups + 63) / 64);
+    // few waves: split the rows over R waves per workgroup (measured: tools/bench_stats.py --cl)
+    const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
+    const int64_t nchunks = n >> lp;
+    int R = env_int("QS_MEAN_SPLIT", 0);
+    if (R == 0) {
+        const int64_t waves = (main_groups + 63) / 64;
+        R = waves < 512 ? 4 : (waves < 1024 ? 2 : 1);
+    }
+    R = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
+    while (R > 1 && R > nchunks) R >>= 1;
+    if (nchunks < 2 || nchunks + R > kMaxSplitChunks) R = 1;         // 64 KiB of LDS
+    const size_t lds = (size_t)(nchunks + R) * 8 * 64 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         auto run = [&](auto O) {
             constexpr int OD = decltype(O)::value;
             uint32_t* am = (uint32_t*)amax_part;
-            if (mode == 1)
-                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 1>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
-            else if (mode == 2)
-                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 2>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
-            else
-                hipLaunchKernelGGL((mean_cl_kernel<XD, OD, 3>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes);
+            auto launch = [&](auto M) {
+                constexpr int kM = decltype(M)::value;
+                if (blocks > 0 && R == 4)
+                    hipLaunchKernelGGL((mean_cl_split_kernel<XD, OD, 4, kM>), dim3(blocks), dim3(256), lds, s, x, out, n, hw, C,
+                                       am, lanes, main_groups);
+                else if (blocks > 0 && R == 2)
+                    hipLaunchKernelGGL((mean_cl_split_kernel<XD, OD, 2, kM>), dim3(blocks), dim3(128), lds, s, x, out, n, hw, C,
+                                       am, lanes, main_groups);
+                else if (blocks > 0)
+                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes,
+                                       main_groups);
+                if (tail_blocks > 0)
+                    hipLaunchKernelGGL((mean_cl_tail_kernel<XD, OD, kM>), dim3(tail_blocks), dim3(64), 0, s, x, out, n, hw, C,
+                                       am, main_groups, tail_groups);
+            };
+            if (mode == 1) launch(IC<1>{});
+            else if (mode == 2) launch(IC<2>{});
+            else launch(IC<3>{});
             return launch_status();
         };
         return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);

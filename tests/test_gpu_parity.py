@@ -863,7 +863,8 @@ def test_channels_last_activations_are_used_in_place(dtype):
     threads = torch.get_num_threads()
     torch.set_num_threads(min(8, threads))
     try:
-        for shape in ((16, 32, 14, 14), (33, 64, 7, 7), (40, 8, 5, 6), (64, 16, 3, 9)):
+        # (H*W % 4 positions go through the row-sum-order kernel: n / 4 >= 32 exercises its carries, n % 4 its last rows)
+        for shape in ((16, 32, 14, 14), (33, 64, 7, 7), (40, 8, 5, 6), (64, 16, 3, 9), (130, 16, 3, 3), (3, 8, 3, 3), (259, 8, 1, 3)):
             N, C, H, W = shape
             x = (torch.randn(shape, generator=gen(11)) * torch.linspace(0.3, 3, C).view(1, C, 1, 1)).to(dtype)
             xcl = x.contiguous(memory_format=torch.channels_last)

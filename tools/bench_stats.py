@@ -36,6 +36,7 @@ def main():
     dev = "cuda"
     noabs = "--noabs" in sys.argv
     stride = 1 if "--dense" in sys.argv else 32     # abs-max accumulator: dense float[C] or one 128-byte line per channel
+    channels_last = "--cl" in sys.argv
     depth_sweep = "--depth" in sys.argv          # sweep the rows in flight per wave (QS_MEAN_DEPTH) of the unsplit kernel instead
     splits = [int(s) for s in sys.argv[1:] if s.isdigit()] or ([0, 16, 32] if depth_sweep else [0, 1, 2, 4, 8])
     print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{('D=' if depth_sweep else 'R=') + str(r):>14s}" for r in splits))
@@ -48,6 +49,7 @@ def main():
             turn = [0]
             stage = torch.empty(C * H * W, device=dev, dtype=dtype)
             amax = torch.zeros(C * 32, device=dev)
+            part = torch.empty(C * H * W, device=dev)
             cells = []
             for r in splits:
                 if depth_sweep:
@@ -55,12 +57,17 @@ def main():
                 else:
                     os.environ["QS_MEAN_SPLIT"] = str(r)
 
+                def stats_cl():      # the same activation in NHWC memory order through qs_mean_dim_cl
+                    turn[0] += 1
+                    assert lib.qs_mean_dim_cl(xs[turn[0] % nrot].data_ptr(), stage.data_ptr(), N, H * W, C, code, code, 1 | 4,
+                                              None if noabs else part.data_ptr(), None) == 0
+
                 def stats():
                     turn[0] += 1
                     assert lib.qs_mean_dim(xs[turn[0] % nrot].data_ptr(), stage.data_ptr(), 1, N, C * H * W, code, code, 1 | 4, None,
                                            None if noabs else amax.data_ptr(), stride, H * W, C, None) == 0
 
-                us = t_us(stats)
+                us = t_us(stats_cl if channels_last else stats)
                 cells.append(f"{us:6.1f}us {x.numel() * nbytes / us / 1e3:5.0f}GB/s"[:14].rjust(14))
             print(f"{str(shp):24s} {str(dtype)[6:]:6s} " + " ".join(cells), flush=True)
     os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = "0"
