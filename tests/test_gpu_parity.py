@@ -612,7 +612,7 @@ def test_reduction_kernels_all_layouts(dtype):
     vector and scalar variants), ragged sizes, single rows -- all order independent, hence exact."""
     for shape, ci in (((64, 48, 9, 9), 1), ((200, 8, 16, 16), 1), ((3, 5, 64), 1), ((1000, 16), 1), ((33, 7), 1),
                       ((16, 2048, 7, 7), 1), ((5, 3, 2, 2), 1), ((4, 6, 10, 10), 2), ((512, 512, 3, 3), 0), ((1, 8, 1, 1), 1),
-                      ((9, 4, 130), 0), ((70000,), -1), ((3, 1, 5), -1),
+                      ((9, 4, 130), 0), ((70000,), -1), ((3, 1, 5), -1), ((37, 12, 14, 14), 1), ((50, 1024, 14, 14), 1), ((21, 5, 3, 5), 1),
                       # few columns, many rows: the two-stage path (2-d inputs, channels_last activations)
                       ((5000, 2048), 1), ((4097, 24), 1), ((300, 8), 1), ((100000, 64), 1), ((1024, 2056), 1), ((9000, 512), 1), ((8192, 256), 1)):
         x = (torch.randn(shape, generator=gen(sum(shape))) * 3).to(dtype)
