@@ -380,7 +380,9 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     int grid = grid_for(numel / 8, 4);
                     if (grid > reduce_blocks()) grid = reduce_blocks();   // every block ends with one atomic on the same word
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin, relu);
-                } else if (inner >= 64 && C < 65536) {
+                } else if (inner >= 64 && C < 65536 && !(inner < 512 && vec_ptr && (C * inner) % 8 == 0)) {
+                    // (rows of 64..511 elements -- 14x14 maps -- go to the column kernel below when it can use vector
+                    //  loads: a wave there reads 1 KiB of consecutive columns per row instead of one short ragged row)
                     int64_t slices = (2048 + C - 1) / C;              // ~2048 workgroups, one atomic each
                     if (slices > (outer + 3) / 4) slices = (outer + 3) / 4;
                     if (slices < 1) slices = 1;
