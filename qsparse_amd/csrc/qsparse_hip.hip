@@ -36,7 +36,7 @@ inline int max_blocks() {
     return v;
 }
 inline int reduce_blocks() {
-    static int v = env_int("QS_REDUCE_BLOCKS", 512);
+    static int v = env_int("QS_REDUCE_BLOCKS", 256);
     return v;
 }
 // Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
@@ -377,9 +377,12 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                 constexpr bool M = decltype(MM)::value != 0;
                 if (!per_channel) {
                     if (!vec_ptr) return (int)QS_ERR_ALIGN;
-                    int grid = grid_for(numel / 8, 4);
-                    if (grid > reduce_blocks()) grid = reduce_blocks();   // every block ends with one atomic on the same word
-                    hipLaunchKernelGGL((reduce_all_kernel<XD, M>), dim3(grid), dim3(kBlock), 0, s, x, numel, omax, omin, relu);
+                    // 512-thread workgroups, at most 256 of them: every one ends with an atomic on the same word, which
+                    // serialise at ~12 ns each (256x512 vs 512x256 threads: 256x64x56x56 bf16 23.6 -> 21.2 us,
+                    // 64x64x56x56 12.4 -> 9.8 us; tools/bench_reduce.py)
+                    int grid = (grid_for(numel / 8, 4) + 1) / 2;
+                    if (grid > reduce_blocks()) grid = reduce_blocks();
+                    hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu);
                 } else if (inner >= 64 && C < 65536 && !(inner < 512 && vec_ptr && (C * inner) % 8 == 0)) {
                     // (rows of 64..511 elements -- 14x14 maps -- go to the column kernel below when it can use vector
                     //  loads: a wave there reads 1 KiB of consecutive columns per row instead of one short ragged row)

@@ -64,7 +64,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--one":
         one()
     else:
-        for rb in sys.argv[1:] or ["512"]:
+        for rb in sys.argv[1:] or ["256"]:
             r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, QS_REDUCE_BLOCKS=rb), capture_output=True,
                                text=True)
             print(f"QS_REDUCE_BLOCKS={rb}")
