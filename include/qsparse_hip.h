@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 5
+#define QS_ABI_VERSION 6
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -131,20 +131,22 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
  * arithmetic of every running mean.  A by-value kernel argument is frozen when a launch is captured into a
  * hipGraph, so every entry point that takes a counter `t` also takes `t_dev` (nullable): a device-resident
  * int64 holding the same counter, read by the kernel INSTEAD of `t` when non-NULL.  Counters are advanced
- * either by the caller (any stream-ordered increment) or, for qs_pq_select, by its bump_* arguments. */
+ * either by the caller (any stream-ordered increment), by qs_pq_select's bump_* arguments, or -- qs_scale_update,
+ * qs_lines_update with advance_t_dev != 0 -- by the kernel itself after every thread has read them (the update then
+ * runs as a single workgroup). */
 
 /* weight[i] <- t == 0 ? new : (t*weight[i] + new)/(t+1),  new = absmax[i] / 2^(bits-1) rounded to stat_dt, the
  * dtype of the tensor the abs-max was taken from: the reference divides in that dtype, which matters for fp16,
  * where small maxima underflow into subnormals (quantize.py:340,344-348).  clear_absmax != 0 zeroes absmax[i]
  * after use; bump_i32 (nullable) is a one-element device counter incremented once (QuantizeLayer._n_updates,
  * quantize.py:515). */
-int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits,
+int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev, int bits,
                     int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream);
 
 /* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
  * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */
 int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after,
-                    const int64_t* t_dev, qs_stream_t stream);
+                    int64_t* t_dev, int advance_t_dev, qs_stream_t stream);
 
 /* d[i] = rint(log2(nan_to_num(1/scale[i], posinf=1, neginf=1)))  (quantize.py:316) */
 int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stream_t stream);

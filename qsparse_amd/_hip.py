@@ -42,8 +42,8 @@ SIGNATURES = {
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P, c_size_t, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P, c_size_t, _P]),
-    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _P, _I, _P]),
-    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _P]),
+    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _I, _P, _I, _P]),
+    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _I, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _L, _P]),
     "qs_l0_flag": (c_int, [_P, _L, _I, _P, _P, _P]),
@@ -378,21 +378,24 @@ def minmax(x: torch.Tensor, channel_index: int):
 
 
 def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None,
-                 clear_absmax: bool = False, bump: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32):
-    """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t`;
+                 clear_absmax: bool = False, bump: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32,
+                 advance_t_dev: bool = False):
+    """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t` (and
+    incremented by the kernel with `advance_t_dev`);
     `clear_absmax`: zero the statistics buffer after use; `bump`: int32 one-element counter to increment;
     `stat_dtype`: dtype of the tensor the abs-max came from (the reference divides in that dtype)."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
     assert bump is None or bump.dtype == torch.int32
-    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(bits),
-                                int(clear_absmax), _ptr(bump), _DT.get(stat_dtype, F32), _stream(weight))
+    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(advance_t_dev),
+                                int(bits), int(clear_absmax), _ptr(bump), _DT.get(stat_dtype, F32), _stream(weight))
     _check(st, "qs_scale_update")
 
 
 def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int,
-                 t_dev: Optional[torch.Tensor] = None):
+                 t_dev: Optional[torch.Tensor] = None, advance_t_dev: bool = False):
     assert lines.dtype == torch.float32 and lines.is_contiguous()
-    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), _stream(lines))
+    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), int(advance_t_dev),
+                                _stream(lines))
     _check(st, "qs_lines_update")
 
 

@@ -413,29 +413,35 @@ __device__ __forceinline__ float round_to_dtype(float v, int dt) {
     return v;
 }
 __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
-                                    const int64_t* t_dev, int clear, int32_t* bump, int stat_dt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                    int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt) {
     if (t_dev) {
         t = (float)*t_dev;
         tp1 = (float)(*t_dev + 1);
     }
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float nw = round_to_dtype(absmax[i] / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
         if (clear) absmax[i] = 0.0f;
     }
-    if (bump && i == 0) atomicAdd(bump, 1);
+    if (bump && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(bump, 1);
+    if (advance && t_dev) {      // single-workgroup launch: every thread has read the counter before it moves
+        __syncthreads();
+        if (threadIdx.x == 0) *t_dev += 1;
+    }
 }
 __global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t,
-                                    const int64_t* t_dev) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                    int64_t* t_dev, int advance) {
     if (t_dev) {   // counter BEFORE this step's increment
         tm1 = (float)*t_dev;
         t = (float)(*t_dev + 1);
     }
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         lines[2 * i] = (lines[2 * i] * tm1 + mn[i]) / t;          // (quantize.py:430)
         lines[2 * i + 1] = (lines[2 * i + 1] * tm1 + mx[i]) / t;
+    }
+    if (advance && t_dev) {
+        __syncthreads();
+        if (threadIdx.x == 0) *t_dev += 1;
     }
 }
 __global__ void decimal_from_scale_kernel(const float* scale, float* d, int64_t n) {

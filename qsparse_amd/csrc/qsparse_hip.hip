@@ -447,23 +447,26 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, in
                        ws_bytes);
 }
 
-int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, const int64_t* t_dev, int bits, int clear_absmax,
-                    int32_t* bump_i32, int stat_dt, qs_stream_t stream) {
+int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev, int bits,
+                    int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream) {
     if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
     if (!dt_ok(stat_dt)) return QS_ERR_DTYPE;
     if (n == 0) return QS_OK;
-    hipLaunchKernelGGL(scale_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, absmax,
-                       weight, n, (float)t, (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, clear_absmax, bump_i32,
-                       stat_dt);
+    const int advance = (advance_t_dev && t_dev) ? 1 : 0;
+    const int blocks = advance ? 1 : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(scale_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, absmax, weight, n, (float)t,
+                       (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, advance, clear_absmax, bump_i32, stat_dt);
     return launch_status();
 }
 
-int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, const int64_t* t_dev,
-                    qs_stream_t stream) {
+int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, int64_t* t_dev,
+                    int advance_t_dev, qs_stream_t stream) {
     if (!mn || !mx || !lines || n < 0 || t_after < 1) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
-    hipLaunchKernelGGL(lines_update_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn, mx,
-                       lines, n, (float)(t_after - 1), (float)t_after, t_dev);
+    const int advance = (advance_t_dev && t_dev) ? 1 : 0;
+    const int blocks = advance ? 1 : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(lines_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mn, mx, lines, n,
+                       (float)(t_after - 1), (float)t_after, t_dev, advance);
     return launch_status();
 }
 

@@ -305,9 +305,10 @@ class DecimalQuantizer(BaseQuantizer):
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None
                 counter = kwargs.get("step_counter")
                 bump = counter.data if (counter is not None and counter.is_cuda and counter.device == x.device) else None
-                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump, stat_dtype=x.dtype)
+                _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump, stat_dtype=x.dtype,
+                                  advance_t_dev=True)
                 self.__dict__["_bumped_step_counter"] = bump is not None
-                self._advance_t(t_dev)
+                self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight
             else:
                 stat = _absmax_rows_cpu(x, channel_index)
@@ -394,8 +395,8 @@ class AdaptiveQuantizer(DecimalQuantizer):
                     return torch.stack([lo, hi], dim=1)
                 assert weight.shape == (lo.numel(), 2)
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None
-                _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev)
-                self._advance_t(t_dev)
+                _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev, advance_t_dev=True)
+                self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)
             if batched and qdist.exchange_active():

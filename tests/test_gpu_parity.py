@@ -42,7 +42,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 5
+    assert lib.qs_version() == 6
     assert torch.cuda.is_available()
 
 

@@ -205,3 +205,46 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
         assert torch.equal(ea, eb)
     finally:
         qs.set_qsparse_options(graph_safe=False)
+
+
+@pytest.mark.parametrize("kind", ["scaler_300_channels", "adaptive"])
+def test_kernel_advanced_counter_matches_host_counter(kind):
+    """graph_safe mode: qs_scale_update / qs_lines_update read the running-mean counter from the device and advance it
+    themselves (one workgroup, also for more than 256 channels).  Eager steps with and without graph_safe, and graph
+    replays, must leave the same scales."""
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(6, 300, 5, generator=g).cuda() * (i + 1) for i in range(7)]
+    outs = []
+    try:
+        for graph_safe, replay in ((False, False), (True, False), (True, True)):
+            qs.set_qsparse_options(graph_safe=graph_safe)
+            if kind == "adaptive":
+                layer = qs.quantize(bits=8, channelwise=-1, timeout=1, callback=qs.AdaptiveQuantizer()).cuda().train()
+            else:
+                layer = qs.quantize(bits=8, channelwise=1, timeout=1).cuda().train()
+                layer.batch_dimension = -1          # a weight-like tensor: 300 per-channel scales
+            sx = torch.empty_like(xs[0])
+            ys = []
+            for x in xs[:3]:
+                sx.copy_(x)
+                ys.append(layer(sx).clone())
+            if replay:
+                gr = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(gr):
+                    y_static = layer(sx)
+            for x in xs[3:]:
+                sx.copy_(x)
+                if replay:
+                    gr.replay()
+                    ys.append(y_static.clone())
+                else:
+                    ys.append(layer(sx).clone())
+            outs.append((ys, layer.weight.detach().clone()))
+    finally:
+        qs.set_qsparse_options(graph_safe=False)
+    for ys, w in outs[1:]:
+        assert torch.equal(w, outs[0][1])
+        for a, b in zip(ys, outs[0][0]):
+            assert torch.equal(a, b)
