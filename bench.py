@@ -220,7 +220,7 @@ def main():
                 kern[name] = {"ms": round(ms, 4), "GB/s": round(bpe * numel / ms / 1e6, 1),
                               "frac": round(bpe * numel / ms / 1e6 / HBM_PEAK_GBS, 4)}
         out = {
-            "metric": "Gelem/s quantize+prune fwd+bwd, 256x256x56x56 bf16; % HBM roofline",
+            "metric": "Gelem/s quantize+prune fwd+bwd, 256\u00d7256\u00d756\u00d756 bf16; % HBM roofline",   # BASELINE.json's string
             "value": round(value, 3), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
