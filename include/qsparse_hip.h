@@ -234,13 +234,18 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  * (each nullable) are one-element device counters incremented by one at the end: the layers' `_n_updates`,
  * the pruning callback's `t` and the quantizer's device-side `t` (sparse.py:117,272; quantize.py:348,515), so
  * that a step needs no separate counter kernels.  t_mag_dev / t_q_dev: see "Step counters" above.  stat_dt: dtype
- * of the activation (the new scale's quotient is rounded to it, as in qs_scale_update). */
+ * of the activation (the new scale's quotient is rounded to it, as in qs_scale_update).
+ * gathered (nullable, device float[world][2*C]): the all-gathered qs_stats_pack records of a data-parallel run.  When
+ * given, channel c's importance is (sum over ranks, in rank order, of gathered[r][c]) / world and its abs-max the
+ * maximum over ranks of gathered[r][C + c] -- what qs_stats_combine computes -- read INSTEAD of stage_mean and
+ * chan_absmax (which, when non-NULL, is still zeroed). */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
                  float* chan_absmax, int64_t chan_absmax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                  int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
-                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, qs_stream_t stream);
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
+                 qs_stream_t stream);
 
 /* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
 

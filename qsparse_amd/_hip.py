@@ -51,7 +51,7 @@ SIGNATURES = {
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
@@ -540,11 +540,14 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
               t_q: int, bits: int, scale: Optional[torch.Tensor], bump_a: Optional[torch.Tensor] = None,
               bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None,
               bump_d: Optional[torch.Tensor] = None, t_mag_dev: Optional[torch.Tensor] = None,
-              t_q_dev: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32):
+              t_q_dev: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32,
+              gathered: Optional[torch.Tensor] = None, world: int = 1):
     """bump_a / bump_b: int32 one-element counters; bump_c / bump_d: int64 one-element counters; t_*_dev: device
-    int64 counters read instead of the by-value t_mag / t_q (each optional)."""
+    int64 counters read instead of the by-value t_mag / t_q (each optional).  `gathered`: the all-gathered
+    [world, 2C] float32 records of `stats_pack`, combined in rank order by the kernel itself."""
     C = magnitude.numel()
     sdt = dt(stage_mean) if stage_mean is not None else F32
+    assert gathered is None or (gathered.dtype == torch.float32 and gathered.numel() == world * 2 * C)
     for b32 in (bump_a, bump_b):
         assert b32 is None or b32.dtype == torch.int32
     for b64 in (bump_c, bump_d, t_mag_dev, t_q_dev):
@@ -554,7 +557,8 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
                                  int(refresh_mask), int(k), _ptr(mask), _ptr(chan_absmax), amax_stride(chan_absmax),
                                  int(update_scale), int(t_q),
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
-                                 _ptr(t_mag_dev), _ptr(t_q_dev), _DT.get(stat_dtype, F32), _stream(magnitude))
+                                 _ptr(t_mag_dev), _ptr(t_q_dev), _DT.get(stat_dtype, F32), _ptr(gathered), int(world),
+                                 _stream(magnitude))
     _check(st, "qs_pq_select")
 
 

@@ -1278,7 +1278,30 @@ struct PqArgs {
     const int64_t* t_q_dev;
     int rank_small;             // rank counting up to this many channels, radix select above (kRankSmall)
     int stat_dt;                // dtype of the activation the abs-max was taken from (the quotient is rounded to it)
+    // multi-rank run: the all-gathered [world][2C] records of qs_stats_pack (importance | abs-max) are combined here,
+    // in rank order, instead of reading `stage` / `chan_absmax` (which is then only re-zeroed)
+    const float* gathered;
+    int world;
 };
+
+// channel i's importance / abs-max key: the local statistics, or the rank-ordered combination of every rank's record
+// (same arithmetic as stats_combine_kernel: fp32 sum in rank order divided by the world size; maximum of the keys)
+template <int SDT>
+__device__ __forceinline__ float pq_stage_value(const PqArgs& a, const void* stage, int64_t i) {
+    if (!a.gathered) return load1<SDT>(stage, i);
+    float sum = 0.f;
+    for (int r = 0; r < a.world; ++r) sum += a.gathered[(int64_t)r * 2 * a.C + i];
+    return sum / (float)a.world;
+}
+__device__ __forceinline__ uint32_t pq_amax_key(const PqArgs& a, int64_t i) {
+    if (!a.gathered) return a.chan_absmax[i * a.amax_stride];
+    uint32_t mx = 0u;
+    for (int r = 0; r < a.world; ++r) {
+        const uint32_t k = __float_as_uint(a.gathered[(int64_t)r * 2 * a.C + a.C + i]);
+        mx = k > mx ? k : mx;
+    }
+    return mx;
+}
 
 __device__ __forceinline__ PqArgs pq_live_counters(PqArgs a) {
     if (a.t_mag_dev) {
@@ -1298,7 +1321,7 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
     const int tid = threadIdx.x, nthreads = blockDim.x;
     if (a.update_magnitude) {
         for (int64_t i = tid; i < a.C; i += nthreads)
-            a.magnitude[i] = (a.t_mag * a.magnitude[i] + load1<SDT>(stage, i)) / a.t_mag1;   // sparse.py:89
+            a.magnitude[i] = (a.t_mag * a.magnitude[i] + pq_stage_value<SDT>(a, stage, i)) / a.t_mag1;   // sparse.py:89
         __threadfence_block();
         __syncthreads();
     }
@@ -1312,9 +1335,9 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
     if (a.update_scale) {
         uint32_t m = 0u;
         for (int64_t i = tid; i < a.C; i += nthreads) {
-            const uint32_t am = a.chan_absmax[i * a.amax_stride];
+            const uint32_t am = pq_amax_key(a, i);
             if (a.mask[i]) m = am > m ? am : m;
-            a.chan_absmax[i * a.amax_stride] = 0u;   // leave the accumulator clean for the next statistics pass
+            if (a.chan_absmax) a.chan_absmax[i * a.amax_stride] = 0u;   // leave the accumulator clean for the next statistics pass
         }
         m = wave_max_u32(m);
         if ((tid & 63) == 0) sh_max[tid >> 6] = m;
@@ -1350,8 +1373,8 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
         keep[it] = 0;
         if (i < a.C) {
             mag[it] = a.magnitude[i];
-            if (a.update_magnitude) mag[it] = (a.t_mag * mag[it] + load1<SDT>(stage, i)) / a.t_mag1;   // sparse.py:89
-            if (a.update_scale) amax[it] = a.chan_absmax[i * a.amax_stride];
+            if (a.update_magnitude) mag[it] = (a.t_mag * mag[it] + pq_stage_value<SDT>(a, stage, i)) / a.t_mag1;   // sparse.py:89
+            if (a.update_scale) amax[it] = pq_amax_key(a, i);
             keep[it] = a.mask[i];
             sh.keys[i] = f32_to_key(mag[it]);
         } else if (i < kRankMax) {
@@ -1373,7 +1396,7 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
             if (a.refresh_mask) a.mask[i] = keep[it];
             if (a.update_scale) {
                 if (keep[it]) m = amax[it] > m ? amax[it] : m;
-                a.chan_absmax[i * a.amax_stride] = 0u;
+                if (a.chan_absmax) a.chan_absmax[i * a.amax_stride] = 0u;
             }
         }
     }

@@ -777,11 +777,15 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
 static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude, int64_t t_mag, int refresh_mask,
                    int64_t k, uint8_t* mask, float* chan_absmax, int64_t amax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                    int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
-                   const int64_t* t_mag_dev, const int64_t* t_q_dev) {
+                   const int64_t* t_mag_dev, const int64_t* t_q_dev, const float* gathered, int world) {
     if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
     if (update_magnitude && t_mag < 0) return QS_ERR_ARG;
     if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
-    if (update_scale && (!chan_absmax || amax_stride < 1 || !scale || bits < 1 || bits > 31 || t_q < 0)) return QS_ERR_ARG;
+    if (gathered && world < 1) return QS_ERR_ARG;
+    if (update_scale && ((!chan_absmax && !gathered) || amax_stride < 1 || !scale || bits < 1 || bits > 31 || t_q < 0))
+        return QS_ERR_ARG;
+    a->gathered = gathered;
+    a->world = gathered ? world : 1;
     a->magnitude = magnitude;
     a->C = C;
     a->update_magnitude = update_magnitude;
@@ -812,14 +816,16 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
                  int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int64_t chan_absmax_stride, int update_scale,
                  int64_t t_q, int bits,
                  float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
-                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, qs_stream_t stream) {
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
+                 qs_stream_t stream) {
     PqArgs a;
     int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, chan_absmax_stride, update_scale, t_q, bits,
-                     scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev);
+                     scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev, gathered, world);
     if (st == QS_OK && update_scale && !dt_ok(stat_dt)) st = QS_ERR_DTYPE;
     a.stat_dt = stat_dt;
     if (st) return st;
-    if (update_magnitude && !stage_mean) return QS_ERR_ARG;
+    if (update_magnitude && !stage_mean && !gathered) return QS_ERR_ARG;
+    if (gathered) sdt = QS_F32;      // the records are float32; `stage_mean` is not read
     if (!dt_ok(sdt)) return QS_ERR_DTYPE;
     return with_dtype(sdt, [&](auto S) {
         constexpr int SD = decltype(S)::value;

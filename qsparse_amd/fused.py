@@ -184,8 +184,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                                          absmax_channel_dim=1, pre_relu=pre_relu).contiguous().view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
-            if qdist.exchange_active(world):
-                stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
+            gathered = None
+            if qdist.exchange_active(world) and (stage is not None or chan_absmax is not None):
+                if h.is_cuda:     # one collective; the select kernel combines the ranks' records in rank order
+                    gathered = qdist.gather_pair_statistics(stage, chan_absmax, world)
+                else:
+                    stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:
                 mag = cb.magnitude.data.view(-1) if hasattr(cb, "magnitude") else torch.zeros(C, device=h.device)
                 t_mag_dev = t_q_dev = None
@@ -194,7 +198,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                     t_q_dev = qc.device_t(h.device) if update_scale else None
                 _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
                                update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t,
-                               bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev, stat_dtype=h.dtype)
+                               bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev, stat_dtype=h.dtype,
+                               gathered=gathered, world=world if gathered is not None else 1)
                 select_bumped_tq = t_q_dev is not None
         if update_scale:
             if select_bumped_tq:
