@@ -991,3 +991,43 @@ def test_multi_tensor_weight_kernels_match_the_per_tensor_ones():
             assert torch.equal(scales[i], ref_scales[i]), (decimal, i)
             assert torch.equal(outs[i], ref_y[i]), (decimal, i, sizes[i])
         assert not amax.any() and bool((bumps == 1).all())
+
+
+@pytest.mark.parametrize("C", [48, 300, 2500])
+def test_select_on_gathered_records_equals_combine_then_select(C):
+    """data-parallel exchange: qs_pq_select given the all-gathered [world, 2C] records must do exactly what
+    qs_stats_combine followed by qs_pq_select on the combined vectors does (and what the rank-ordered CPU formula says)."""
+    world, k = 3, C // 3
+    g = gen(900 + C)
+    stages = [torch.rand(C, generator=g) + 0.01 for _ in range(world)]
+    amaxes = [torch.rand(C, generator=g) * 4 for _ in range(world)]
+    gathered = torch.cat([torch.cat([s, a]) for s, a in zip(stages, amaxes)]).to(DEV)
+    acc = torch.zeros(C)
+    for s in stages:
+        acc = acc + s
+    want_stage, want_amax = acc / world, torch.stack(amaxes).amax(0)
+
+    def run(use_gathered):
+        mag = torch.linspace(0.1, 1.0, C).to(DEV)
+        mask = torch.ones(C, dtype=torch.bool, device=DEV)
+        scale = torch.full((1, 1), 0.25, device=DEV)
+        am = _hip.amax_accumulator(C, DEV)
+        if use_gathered:
+            _hip.pq_select(mag, None, True, 2, True, k, mask, am, True, 2, 4, scale, gathered=gathered, world=world)
+        else:
+            stage = _hip.stats_combine(gathered, world, C, True, am)
+            assert same(stage.cpu(), want_stage) and same(_hip.amax_values(am).cpu(), want_amax)
+            _hip.pq_select(mag, stage, True, 2, True, k, mask, am, True, 2, 4, scale)
+        assert float(_hip.amax_values(am).abs().max()) == 0.0          # accumulator left clean either way
+        return mag.cpu(), mask.cpu(), scale.cpu()
+
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    mag0 = torch.linspace(0.1, 1.0, C)
+    want_mag = (2 * mag0 + want_stage) / 3
+    assert same(a[0], want_mag)
+    want_mask = want_mag >= want_mag.sort().values[k]
+    assert torch.equal(a[1], want_mask)
+    new = want_amax[want_mask].max() / 8                       # 4 bits
+    assert same(a[2].view(-1), ((2 * torch.tensor(0.25) + new) / 3).view(-1))
