@@ -186,9 +186,12 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
  * Same summation order and rounding points as two qs_mean_dim calls.  (H*W + W)*4 bytes of LDS <= 48 KiB,
  * otherwise QS_ERR_ARG (use two qs_mean_dim calls).
  * amax_part (nullable, [pre, H, W] from qs_mean_dim_cl): absmax_out[p * absmax_stride] is max-accumulated with the
- * maximum of slice p. */
+ * maximum of slice p.
+ * record (nullable, device float[2 * pre]): this rank's exchange record in qs_stats_pack's layout, written on the way
+ * out -- record[p] = float(out[p]), record[pre + p] = absmax_out[p * absmax_stride] (0 when absmax_out is NULL; with
+ * amax_part NULL absmax_out is only read) -- which saves the qs_stats_pack launch of a data-parallel step. */
 int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt,
-                  const float* amax_part, float* absmax_out, int64_t absmax_stride, qs_stream_t stream);
+                  const float* amax_part, float* absmax_out, int64_t absmax_stride, float* record, qs_stream_t stream);
 
 /* *flag = (min(x) == 0), qsparse/sparse.py:85 */
 int qs_l0_flag(const void* x, int64_t numel, int xdt, int32_t* flag, float* scratch2, qs_stream_t stream);

@@ -52,7 +52,7 @@ SIGNATURES = {
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
-    "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P]),
+    "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -443,14 +443,16 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
 
 
 def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype, amax_part: Optional[torch.Tensor] = None,
-               absmax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               absmax_out: Optional[torch.Tensor] = None, record: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x viewed as [pre, H, W] -> [pre]: mean over H then over W, each rounded like ``Tensor.mean``.  `amax_part`
-    ([pre, H, W] from mean_dim_cl) is reduced per slice into `absmax_out` on the way."""
+    ([pre, H, W] from mean_dim_cl) is reduced per slice into `absmax_out` on the way.  `record` (float32 [2 * pre]):
+    receives the rank's exchange record (means | `absmax_out`'s values) -- what `stats_pack` would write."""
     x = dense(x)
     out = torch.empty(pre, dtype=out_dtype, device=x.device)
+    assert record is None or (record.dtype == torch.float32 and record.numel() == 2 * pre and record.is_contiguous())
     with _timed("mean_last2"):
         st = load().qs_mean_last2(_ptr(x), _ptr(out), pre, H, W, dt(x), _DT[out_dtype], _ptr(amax_part), _ptr(absmax_out),
-                                  amax_stride(absmax_out), _stream(x))
+                                  amax_stride(absmax_out), _ptr(record), _stream(x))
     _check(st, "qs_mean_last2")
     return out
 

@@ -1439,7 +1439,8 @@ __global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const voi
 template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                              int H, int W, const uint32_t* __restrict__ amax_part,
-                                                             uint32_t* __restrict__ chan_absmax, int64_t astride) {
+                                                             uint32_t* __restrict__ chan_absmax, int64_t astride,
+                                                             float* __restrict__ record) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // H*W + W floats
     float* colmean = tile + (size_t)H * W;
     const int64_t p = blockIdx.x;
@@ -1471,7 +1472,12 @@ __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restri
     __syncthreads();
     const float s = inner_sum_lds(colmean, W, colmean + W);
     if (threadIdx.x == 0) {
-        store1<ODT>(out, p, s / (float)W);
+        const float mean = s / (float)W;
+        store1<ODT>(out, p, mean);
+        if (record) {   // this rank's exchange record (qs_stats_pack's layout): importance | abs-max, as float32
+            record[p] = round_through<ODT>(mean);
+            record[gridDim.x + p] = chan_absmax ? __uint_as_float(chan_absmax[p * astride]) : 0.f;
+        }
     }
 }
 

@@ -627,9 +627,9 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
 }
 
 int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, const float* amax_part,
-                  float* absmax_out, int64_t absmax_stride, qs_stream_t stream) {
+                  float* absmax_out, int64_t absmax_stride, float* record, qs_stream_t stream) {
     if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;
-    if (amax_part && (!absmax_out || absmax_stride < 1)) return QS_ERR_ARG;
+    if ((amax_part || (record && absmax_out)) && (!absmax_out || absmax_stride < 1)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     const size_t lds = (size_t)(H * W + W + 8) * sizeof(float);
     if (lds > 48 * 1024 + 32 || pre > 0x7fffffff) return QS_ERR_ARG;
@@ -637,10 +637,10 @@ int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, i
         constexpr int XD = decltype(X)::value;
         if (odt == QS_F32)
             hipLaunchKernelGGL((mean_last2_kernel<XD, QS_F32>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x,
-                               out, (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride);
+                               out, (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride, record);
         else
             hipLaunchKernelGGL((mean_last2_kernel<XD, XD>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x, out,
-                               (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride);
+                               (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride, record);
         return launch_status();
     });
 }

@@ -57,13 +57,18 @@ def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
     return t
 
 
-def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int) -> torch.Tensor:
-    """GPU half of `sync_pair_statistics` without its last step: pack the rank's record, all-gather -- ONE collective --
-    and hand the [world, 2C] records to `qs_pq_select`, which combines them in rank order itself."""
+def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int,
+                           record: Optional[dict] = None) -> torch.Tensor:
+    """GPU half of `sync_pair_statistics` without its last step: pack the rank's record (unless the last statistics
+    launch has already written it, `record["filled"]`), all-gather -- ONE collective -- and hand the [world, 2C]
+    records to `qs_pq_select`, which combines them in rank order itself."""
     from qsparse_amd import _hip
     ref = stage if stage is not None else chan_absmax
     C = stage.numel() if stage is not None else chan_absmax.shape[0]
-    rec = _hip.stats_pack(stage, chan_absmax, C, ref.device)
+    if record is not None and record["filled"]:
+        rec = record["buf"]
+    else:
+        rec = _hip.stats_pack(stage, chan_absmax, C, ref.device)
     gathered = torch.empty(world * 2 * C, dtype=torch.float32, device=ref.device)
     dist.all_gather_into_tensor(gathered, rec)
     return gathered

@@ -153,7 +153,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     select_bumped_tq = False
     with torch.no_grad():
         hd = h.detach()
-        stage = chan_absmax = None
+        stage = chan_absmax = record = None
         world = qdist.stats_world_size()
         if update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
@@ -180,14 +180,17 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 elif update_scale:
                     chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
+                if qdist.exchange_active(world) and h.is_cuda:   # the last statistics launch writes the exchange record
+                    record = {"buf": torch.empty(2 * C, dtype=torch.float32, device=h.device), "filled": False}
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax if rides else None,
-                                         absmax_channel_dim=1, pre_relu=pre_relu).contiguous().view(-1)
+                                         absmax_channel_dim=1, pre_relu=pre_relu, record=record,
+                                         record_absmax=chan_absmax).contiguous().view(-1)
             elif update_scale:
                 chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
             gathered = None
             if qdist.exchange_active(world) and (stage is not None or chan_absmax is not None):
                 if h.is_cuda:     # one collective; the select kernel combines the ranks' records in rank order
-                    gathered = qdist.gather_pair_statistics(stage, chan_absmax, world)
+                    gathered = qdist.gather_pair_statistics(stage, chan_absmax, world, record)
                 else:
                     stage, chan_absmax = qdist.sync_pair_statistics(stage, chan_absmax, world)
             if update_mag or refresh or update_scale:

@@ -71,9 +71,22 @@ def _reduction_plan(xshape: Sequence[int], shape: Sequence[int]) -> List[int]:
     return dims
 
 
+def _record_for(record, slices: int):
+    """the exchange-record buffer if the fused last-two-dims launch can fill it (one slice per channel)"""
+    if record is None or record["buf"].numel() != 2 * slices:
+        return None
+    record["filled"] = True
+    return record["buf"]
+
+
 def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=None, absmax_out=None,
-                     absmax_channel_dim: Optional[int] = None, pre_relu: bool = False) -> torch.Tensor:
-    """successive keepdim means on the GPU, one ``qs_mean_dim`` launch per reduced dim."""
+                     absmax_channel_dim: Optional[int] = None, pre_relu: bool = False, record=None,
+                     record_absmax=None) -> torch.Tensor:
+    """successive keepdim means on the GPU, one ``qs_mean_dim`` launch per reduced dim.
+
+    ``record`` (a dict with a float32 ``buf`` of 2C elements): when the plan ends in the fused last-two-dims launch over
+    C slices, that launch also writes the rank's exchange record (means | values of ``record_absmax``, the per-channel
+    abs-max accumulator that is complete by then) and ``record["filled"]`` is set."""
     if (x.dim() == 4 and dims == [0, 2, 3] and l0_flag is None and x.shape[1] % 8 == 0
             and (x.shape[2] * x.shape[3] + x.shape[3]) * 4 <= 48 * 1024 and (absmax_out is None or absmax_channel_dim == 1)):
         # channels_last activation reduced to its channels: no NCHW copy.  ATen's mean over N of such a tensor returns
@@ -84,7 +97,10 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
             flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
             if flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU) and not (flags == 0 and absmax_out is not None):
                 stage, part = _hip.mean_dim_cl(xm, x.dtype, flags, absmax_out is not None)
-                return _hip.mean_last2(stage, C, H, W, x.dtype, part, absmax_out).view(1, C, 1, 1)
+                rec = _record_for(record, C)
+                # (with a record and no riding abs-max the accumulator is only read, for the record's second half)
+                acc = absmax_out if absmax_out is not None else (record_absmax if rec is not None else None)
+                return _hip.mean_last2(stage, C, H, W, x.dtype, part, acc, rec).view(1, C, 1, 1)
     cur = _hip.dense(x)
     shape = list(cur.shape)
     out_dtype = torch.float32 if l0_flag is not None else cur.dtype
@@ -97,7 +113,8 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
             pre = 1
             for s in shape[:d]:
                 pre *= s
-            cur = _hip.mean_last2(cur, pre, shape[d], shape[d + 1], cur.dtype)
+            rec = _record_for(record, pre)
+            cur = _hip.mean_last2(cur, pre, shape[d], shape[d + 1], cur.dtype, None, record_absmax if rec is not None else None, rec)
             shape[d] = shape[d + 1] = 1
             return cur.view(shape)
         pre = 1

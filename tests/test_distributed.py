@@ -5,6 +5,7 @@ import os
 import socket
 
 import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -70,19 +71,27 @@ def _gpu_worker(rank, world, port, out):
     from qsparse_amd.fused import fuse_prune_quantize_pairs
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     res = {}
-    for fused in (False, True):
-        pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
-                                                                    repetition=2)),
-                             qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train()
-        if fused:
-            fuse_prune_quantize_pairs(pair)
-        for step in range(6):
-            g = torch.Generator().manual_seed(100 + step)
-            full = (torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16()
-            shard = (full[rank * 4:(rank + 1) * 4].float() * (1.0 + 0.5 * rank)).bfloat16().cuda().requires_grad_(True)
-            y = pair(shard)
-            y.backward(torch.ones_like(y))
-        res[fused] = tuple(t.detach().cpu().clone() for t in (pair[0][1].mask, pair[0][1].callback.magnitude, pair[1].weight))
+    # nchw / channels_last: the last statistics launch writes the exchange record itself; 2-d: qs_stats_pack does
+    for layout in ("nchw", "channels_last", "2d"):
+        for fused in (False, True):
+            pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
+                                                                        repetition=2)),
+                                 qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train()
+            if fused:
+                fuse_prune_quantize_pairs(pair)
+            for step in range(6):
+                g = torch.Generator().manual_seed(100 + step)
+                full = (torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16()
+                shard = (full[rank * 4:(rank + 1) * 4].float() * (1.0 + 0.5 * rank)).bfloat16().cuda()
+                if layout == "channels_last":
+                    shard = shard.contiguous(memory_format=torch.channels_last)
+                elif layout == "2d":
+                    shard = shard[:, :, 0, 0].contiguous()
+                shard.requires_grad_(True)
+                y = pair(shard)
+                y.backward(torch.ones_like(y))
+            res[(layout, fused)] = tuple(t.detach().cpu().numpy().copy()     # numpy: no fd hand-over after the worker's exit
+                                         for t in (pair[0][1].mask, pair[0][1].callback.magnitude, pair[1].weight))
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -100,11 +109,14 @@ def test_fused_pair_exchange_on_gpu_two_ranks():
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    for fused in (False, True):
-        for a, b in zip(res[0][fused], res[1][fused]):
-            assert torch.equal(a, b), fused                      # ranks agree
-    for a, b in zip(res[0][False], res[0][True]):
-        assert torch.equal(a, b)                                  # fused exchange == unfused exchange
+    for layout in ("nchw", "channels_last", "2d"):
+        for fused in (False, True):
+            for a, b in zip(res[0][(layout, fused)], res[1][(layout, fused)]):
+                assert np.array_equal(a, b), (layout, fused)      # ranks agree
+        if layout == "channels_last":
+            continue    # (the unfused layers sum a channels_last shard in NCHW order after a copy: 1 ulp apart in bf16)
+        for a, b in zip(res[0][(layout, False)], res[0][(layout, True)]):
+            assert np.array_equal(a, b), layout                   # fused exchange == unfused exchange
 
 
 def _ddp_worker(rank, world, port, out):

@@ -464,7 +464,7 @@ def test_abi_calls_are_graph_capturable():
 
     def sequence(stream):
         assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, stream) == 0
-        assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, stream) == 0
+        assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, None, stream) == 0
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,

@@ -84,7 +84,7 @@ def run_variant(path):
     imp = torch.empty(C, device=dev, dtype=torch.bfloat16)
 
     def last2():
-        assert lib.qs_mean_last2(stage.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, None) == 0
+        assert lib.qs_mean_last2(stage.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, None, None) == 0
 
     mag = torch.rand(C, device=dev)
     mk = torch.ones(C, device=dev, dtype=torch.uint8)
