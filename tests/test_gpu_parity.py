@@ -587,20 +587,25 @@ def test_row_split_statistics_kernel_all_widths(monkeypatch):
         from qsparse_amd import _hip
         from qsparse_amd.util import _staged_mean_hip
         g = torch.Generator().manual_seed(1)
-        for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7)):
-            for dt in (torch.bfloat16, torch.float32):
-                x = (torch.randn(shape, generator=g) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dt)
-                ref = O.squeeze_mean(x.abs(), (1, shape[1], 1, 1))
-                for am in (torch.zeros(shape[1], device='cuda'), _hip.amax_accumulator(shape[1], 'cuda')):   # dense / one line per channel
-                    out = _staged_mean_hip(x.cuda(), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
-                    assert torch.equal(out.cpu(), ref), (shape, dt)
-                    assert torch.equal(_hip.amax_values(am).cpu(), x.abs().float().amax(dim=(0, 2, 3))), (shape, dt)
-                    if am.dim() == 2:
-                        assert not am[:, 1:].any()
+        torch.set_num_threads(min(8, torch.get_num_threads()))     # ATen's channels_last order depends on the thread split
+        for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7), (70, 16, 5, 5)):
+            for dt in (torch.bfloat16, torch.float32, torch.float16):
+                for cl in (False, True):      # NCHW: qs_mean_dim's kernels; channels_last: qs_mean_dim_cl's
+                    x = (torch.randn(shape, generator=g) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dt)
+                    if cl:
+                        x = x.contiguous(memory_format=torch.channels_last)
+                    ref = O.squeeze_mean(x.abs(), (1, shape[1], 1, 1))
+                    for am in (torch.zeros(shape[1], device='cuda'), _hip.amax_accumulator(shape[1], 'cuda')):   # dense / one line per channel
+                        out = _staged_mean_hip(x.cuda(), [0, 2, 3], take_abs=True, absmax_out=am, absmax_channel_dim=1)
+                        assert torch.equal(out.cpu(), ref), (shape, dt, cl)
+                        assert torch.equal(_hip.amax_values(am).cpu(), x.abs().float().amax(dim=(0, 2, 3))), (shape, dt, cl)
+                        if am.dim() == 2:
+                            assert not am[:, 1:].any()
         print('ok')
     """)
-    for split in ("0", "2", "4", "8"):
-        env = dict(os.environ, QS_MEAN_SPLIT=split)
+    # (split "1" + depth: the unsplit kernel with 16 / 32 rows in flight per wave)
+    for split, depth in (("0", "0"), ("2", "0"), ("4", "0"), ("8", "0"), ("1", "16"), ("1", "32")):
+        env = dict(os.environ, QS_MEAN_SPLIT=split, QS_MEAN_DEPTH=depth)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "ok" in r.stdout, (split, r.stdout[-500:], r.stderr[-1500:])
