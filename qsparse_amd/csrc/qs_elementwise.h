@@ -438,6 +438,54 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                                                               void* __restrict__ gx) {
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int64_t grp = blk * kBlock + threadIdx.x;
+    if constexpr (GDT == QS_F32 && XDT == QS_F32) {
+        // all three streams fp32 (the site behind a residual add): a lane's 8 elements would be 32 bytes, i.e. two
+        // 16-byte accesses per stream at a 32-byte stride across the wave.  As in ew_widen_kernel a wave owns 512
+        // consecutive elements and lane l takes [4l, 4l+4) and [256+4l, 256+4l+4): every load and store instruction
+        // covers one contiguous 1 KiB span (64x256x56x56: 113 -> 100 us, 5.4 -> 6.1 TB/s; tools/bench_relu_bwd.py).
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int64_t e_wave = (blk * (kBlock / 64) + wave) * 512;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t e = e_wave + half * 256 + lane * 4;
+            if (e + 4 <= geo.ngroups * 8) {
+                const u32x4 rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
+                const u32x4 rx4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                int32_t dummy;
+                u32x4 out;
+                if constexpr (CM == CM_LAST) {
+                    const SteBwdOp::P p0 = op.channel(0);
+                    uint32_t mm = 0x01010101u;
+                    if (op.cmask) mm = *(const uint32_t*)(op.cmask + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f
+                                 : op.apply(__uint_as_float(rg4[j]), SteBwdOp::keep_of(p0, (mm >> (8 * j)) & 0xffu), dummy));
+                } else if constexpr (CM == CM_ELEM) {
+                    ChanIter it;
+                    it.C = geo.C;
+                    it.inner = geo.inner;
+                    it.seek((uint64_t)e);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
+                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f : op.apply(__uint_as_float(rg4[j]), p, dummy));
+                        it.next();
+                    }
+                } else {
+                    SteBwdOp::P p = op.channel(0);
+                    if constexpr (CM == CM_ROW) {
+                        const uint32_t c = (uint32_t)(((uint64_t)e / 8) / geo.groups_per_row) % geo.C;   // rows are whole groups of 8
+                        p = op.channel_masked(param_per_channel ? c : 0u, c);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f : op.apply(__uint_as_float(rg4[j]), p, dummy));
+                }
+                st16<NT>((u32x4*)((float*)gx + e), out);
+            }
+        }
+    } else
     if (grp < geo.ngroups) {
         const Raw8<GDT> rg = load8_raw<GDT, NT>(g, grp);
         const Raw8<XDT> rx = load8_raw<XDT, NT>(x, grp);

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""STE backward with the folded ReLU gate (qs_quant_ste_relu_bwd) on the post-residual activation shapes of a ResNet-50
+step: fp32 gradient, fp32 ReLU input, fp32 out -- three fp32 streams, 12 B/elem (development tool)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from qsparse_amd import _hip
+
+
+def t_us(fn, iters=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e3
+
+
+for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7)):
+    for xdt in (torch.float32, torch.bfloat16):
+        for cl in (False, True):
+            C = shape[1]
+            nrot = 3
+            xs = [torch.randn(shape, device="cuda").to(xdt) for _ in range(nrot)]
+            gs = [torch.randn(shape, device="cuda") for _ in range(nrot)]
+            if cl:
+                xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+                gs = [g.contiguous(memory_format=torch.channels_last) for g in gs]
+            scale = torch.full((1, 1), 0.1, device="cuda")
+            mask = (torch.rand(C, device="cuda") > 0.5)
+            turn = [0]
+
+            def run():
+                turn[0] += 1
+                i = turn[0] % nrot
+                _hip.ste_relu_bwd(gs[i], xs[i], scale, False, -8.0, 7.0, mask, 1)
+
+            us = t_us(run)
+            nbytes = xs[0].numel() * (4 + xs[0].element_size() * 2)
+            print(f"{str(shape):20s} x {str(xdt)[6:]:8s} {'channels_last' if cl else 'nchw':13s} {us:7.1f} us  {nbytes / us / 1e3:6.0f} GB/s", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timeline of one activation site's training step (development tool).
-    rocprofv3 --kernel-trace -d out -- python3 tools/profile_site.py pair M [--graph]      # run
+    rocprofv3 --kernel-trace -d out -- python3 tools/profile_site.py pair M|H|N,C,H,W [--graph] [--cl]      # run
     python3 tools/profile_site.py --timeline out/.../results.db [kernels-per-step]            # print the last steps
 """
 import os
@@ -31,7 +31,9 @@ def main():
 
     import qsparse_amd as qs
     from qsparse_amd.fused import fuse_prune_quantize_pairs
-    kind, shape = sys.argv[1], {"M": (256, 64, 56, 56), "H": (256, 256, 56, 56)}[sys.argv[2]]
+    kind = sys.argv[1]
+    shape = {"M": (256, 64, 56, 56), "H": (256, 256, 56, 56)}.get(sys.argv[2]) or tuple(int(v) for v in sys.argv[2].split(","))
+    channels_last = "--cl" in sys.argv
     graph = "--graph" in sys.argv
     qs.set_qsparse_options(log_on_created=False, log_during_train=False, graph_safe=graph)
     if kind == "pair":
@@ -44,11 +46,15 @@ def main():
         site = qs.prune(sparsity=0.75, dimensions={1}, start=1, interval=1, repetition=1)
     site = site.to("cuda").train()
     C, nbuf = shape[1], 4
-    xs = [(torch.randn(shape, device="cuda") * torch.linspace(0.25, 4, C, device="cuda").view(1, C, 1, 1)).bfloat16().requires_grad_(True)
-          for _ in range(nbuf)]
+    xs = [(torch.randn(shape, device="cuda") * torch.linspace(0.25, 4, C, device="cuda").view(1, C, 1, 1)).bfloat16() for _ in range(nbuf)]
+    if channels_last:
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    xs = [x.requires_grad_(True) for x in xs]
     for i in range(20):
         site(xs[i % nbuf])
     g = torch.randn(shape, device="cuda", dtype=site(xs[0]).dtype)
+    if channels_last:
+        g = g.contiguous(memory_format=torch.channels_last)
     for i in range(20):
         torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
     torch.cuda.synchronize()
