@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""STE backward with the folded ReLU gate (qs_quant_ste_relu_bwd) on the post-residual activation shapes of a ResNet-50
+"""STE backward with the folded ReLU gate (qs_quant_ste_relu_bwd), and the matching forward, on the post-residual activation shapes of a ResNet-50
 step: fp32 gradient, fp32 ReLU input, fp32 out -- three fp32 streams, 12 B/elem (development tool)."""
 import os
 import sys
@@ -45,6 +45,14 @@ for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 204
                 i = turn[0] % nrot
                 _hip.ste_relu_bwd(gs[i], xs[i], scale, False, -8.0, 7.0, mask, 1)
 
+            def fwd():      # the forward of the same site: y = Q(max(x, 0) * mask), fp32 out
+                turn[0] += 1
+                _hip.quant_fwd("scaler", xs[turn[0] % nrot], scale, -1, torch.float32, chan_mask=mask, mask_channel_index=1,
+                               pre_relu=True)
+
             us = t_us(run)
             nbytes = xs[0].numel() * (4 + xs[0].element_size() * 2)
-            print(f"{str(shape):20s} x {str(xdt)[6:]:8s} {'channels_last' if cl else 'nchw':13s} {us:7.1f} us  {nbytes / us / 1e3:6.0f} GB/s", flush=True)
+            usf = t_us(fwd)
+            nbf = xs[0].numel() * (4 + xs[0].element_size())
+            print(f"{str(shape):20s} x {str(xdt)[6:]:8s} {'channels_last' if cl else 'nchw':13s} bwd {us:7.1f} us {nbytes / us / 1e3:6.0f} GB/s"
+                  f"   fwd {usf:7.1f} us {nbf / usf / 1e3:6.0f} GB/s", flush=True)

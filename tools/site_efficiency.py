@@ -2,7 +2,9 @@
 """Per-call efficiency of the library's streaming kernels inside a converted ResNet training step (development tool):
 every launch of the element-wise and statistics wrappers is bracketed with HIP events and listed per (kernel, shape,
 dtype) with its algorithmic bytes, GB/s and the time above a 6 TB/s stream.  Shows which activation shapes of a real
-network are far from the roofline.    site_efficiency.py [resnet50|resnet18] [batch] [channels_last]"""
+network are far from the roofline.  In eager mode the rows of SMALL launches (below ~30 us) are dominated by the host:
+the time between the two events includes waiting for the launch to be issued; trust them only for the large shapes and
+use tools/profile_site.py --graph for the small ones.    site_efficiency.py [resnet50|resnet18] [batch] [channels_last]"""
 import collections
 import os
 import sys
