@@ -53,20 +53,21 @@ def one_case(rng, idx):
     eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
     channels_last = rng.random() < 0.35
     preserve = rng.random() < 0.2
+    graph_safe = rng.random() < 0.25       # counters read from (and advanced in) device memory by the kernels
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last, preserve)
+                    channels_last, preserve, graph_safe)
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False, preserve=False):
+             channels_last=False, preserve=False, graph_safe=False):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last, preserve=preserve)
+                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -74,7 +75,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
     k = max(int(sparsity * shape[1] - 1), 0) + 1
     if k >= shape[1]:
         return None
-    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve)
+    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve, graph_safe=graph_safe and DEV != "cpu")
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
     has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
     has_p = has_p or "pair" in site_kind
