@@ -100,14 +100,19 @@ def build(rng):
     cw = rng.choice([-1, 0, 0])
     bias_bits = rng.choice([-1, 8, 12])
     dims = rng.choice([{0, 1, 2, 3}, {1}, {0}, {0, 1}]) if what == "conv" else rng.choice([{0, 1}, {1}, {0}])
-    desc.update(channelwise=cw, bias_bits=bias_bits, dimensions=sorted(dims))
+    with_prune = rng.random() < 0.65       # quantize-only layers are what the multi-tensor weight path takes
+    if not with_prune:                     # (tensor-wise, no bias quantizer: make those common among them)
+        cw, bias_bits = rng.choice([-1, -1, 0]), rng.choice([-1, -1, 8])
+    desc.update(channelwise=cw, bias_bits=bias_bits, dimensions=sorted(dims), with_prune=with_prune)
     cb = pcb()
     cout = rng.choice([4, 8, 12])
 
     def factory():
         torch.manual_seed(1234)
         base = nn.Conv2d(c, cout, 3, padding=1) if what == "conv" else nn.Linear(c, cout)
-        m = qs.prune(base, sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep, callback=copy.deepcopy(cb))
+        m = base
+        if with_prune:
+            m = qs.prune(base, sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep, callback=copy.deepcopy(cb))
         return qs.quantize(m, bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb), bias_bits=bias_bits)
 
     if what == "linear":
@@ -221,10 +226,17 @@ def one_functional(rng, idx, dry=False):
     return "ok"
 
 
-def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False):
+ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
+
+
+def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
+    # the multi-tensor weight path on the GPU side (a no-op for layers it does not take): same results as the inline one
+    wb = qs.WeightBatcher(m) if (batcher and weight_mode and device == "cuda") else None
+    if wb is not None and wb.layers:
+        ENGAGED[0] += 1
     g = torch.Generator().manual_seed(seed)
     outs = []
     for s in range(steps):
@@ -234,6 +246,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             # itself (whose CPU and GPU algorithms round differently)
             for p in m.parameters():
                 p.grad = None
+            if wb is not None:
+                wb._precompute(m, ())       # what the forward pre-hook does
             w = m.weight
             gw = torch.randn(w.shape, generator=g)
             outs.append(("w", w.detach().cpu()))
@@ -281,7 +295,8 @@ def one_case(rng, idx, dry=False):
     if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact where a native kernel exists
         channels_last = (channels_last and desc.get("dimensions", [1]) == [1] and shape[1] % 8 == 0 and shape[0] > 1
                          and len(shape) == 4 and desc.get("policy") != "l0")
-    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last)
+    batcher = rng.random() < 0.6
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher)
     if dry:
         return None
     if VERBOSE:
@@ -290,7 +305,7 @@ def one_case(rng, idx, dry=False):
     for device in ("cpu", "cuda"):
         try:
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last)
+                                  channels_last, batcher)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
     a, b = results["cpu"], results["cuda"]
@@ -326,7 +341,7 @@ def main():
         if r != "ok":
             fails += 1
             print("FAIL", r, flush=True)
-    print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed})")
+    print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed}); weight batcher engaged in {ENGAGED[0]}")
     sys.exit(1 if fails else 0)
 
 
