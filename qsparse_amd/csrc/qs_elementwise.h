@@ -325,11 +325,22 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                 it.C = geo.C;
                 it.inner = geo.inner;
                 it.seek((uint64_t)g * 8);
+                if (geo.inner >= 8) {
+                    // rows of at least 8 elements: a lane's 8 elements lie in at most two rows -- two parameter / mask
+                    // look-ups instead of eight (ragged maps such as 7x7 and 14x14)
+                    const uint32_t left = geo.inner - it.r;            // elements of the first row
+                    const uint32_t c1 = it.c + 1 == geo.C ? 0u : it.c + 1;
+                    const typename Op::P p0 = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
+                    const typename Op::P p1 = left < 8 ? op.channel_masked(PARAM_PER_CHANNEL ? c1 : 0u, c1) : p0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
-                    v[j] = op.apply(v[j], p, q[j]);
-                    it.next();
+                    for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], (uint32_t)j < left ? p0 : p1, q[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
+                        v[j] = op.apply(v[j], p, q[j]);
+                        it.next();
+                    }
                 }
             }
             store8<YDT, NT>(y, g, v);
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
             }
             typename Op::P p = p_scalar;
             if constexpr (CM == CM_ROW) {
-                const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 8 == 0: 4 elements share a row
+                const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
                 p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
             }
             uint32_t mm = 0x01010101u;
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 } else {
                     SteBwdOp::P p = op.channel(0);
                     if constexpr (CM == CM_ROW) {
-                        const uint32_t c = (uint32_t)(((uint64_t)e / 8) / geo.groups_per_row) % geo.C;   // rows are whole groups of 8
+                        const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
                         p = op.channel_masked(param_per_channel ? c : 0u, c);
                     }
 #pragma unroll
@@ -515,11 +526,20 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
             it.C = geo.C;
             it.inner = geo.inner;
             it.seek((uint64_t)grp * 8);
+            if (geo.inner >= 8) {       // at most two rows per lane: two look-ups instead of eight (see ew_kernel)
+                const uint32_t left = geo.inner - it.r;
+                const uint32_t c1 = it.c + 1 == geo.C ? 0u : it.c + 1;
+                const SteBwdOp::P p0 = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
+                const SteBwdOp::P p1 = left < 8 ? op.channel_masked(param_per_channel ? c1 : 0u, c1) : p0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
-                vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
-                it.next();
+                for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], (uint32_t)j < left ? p0 : p1, dummy);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
+                    vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+                    it.next();
+                }
             }
         }
         store8<XDT, NT>(gx, grp, vg);

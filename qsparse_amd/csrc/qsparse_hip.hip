@@ -128,13 +128,15 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
     constexpr bool NT = QS_EW_NT != 0;
     constexpr int U = QS_EW_UNROLL;
     if constexpr (YDT == QS_F32) {   // QS_EW_WIDEN: 0 off, 1 two-byte inputs only, 2 (default) fp32 inputs as well
-        if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && plan.cm != CM_ELEM) {
+        // (its lanes take 4 elements at a time, so rows of 4k elements -- 14x14 maps -- keep one channel per lane as well)
+        const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
+        if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && cm_w != CM_ELEM) {
             const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
             const int gridw = (int)std::max<int64_t>(1, (waves + kBlock / 64 - 1) / (kBlock / 64));   // < 8 elements: tail only
-            if (plan.cm == CM_SCALAR)
+            if (cm_w == CM_SCALAR)
                 hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
-            else if (plan.cm == CM_LAST)
+            else if (cm_w == CM_LAST)
                 hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else if (param_per_channel)
@@ -332,7 +334,9 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto G) {
             constexpr int GD = decltype(G)::value;
-            switch (plan.cm) {
+            int cm = plan.cm;
+            if (GD == QS_F32 && XD == QS_F32 && cm == CM_ELEM && plan.geo.inner % 4 == 0) cm = CM_ROW;   // 4 elements per lane
+            switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT>), dim3(grid), dim3(kBlock), 0, s, op,
                                        plan.geo, (int)ppc, g, x, gx);

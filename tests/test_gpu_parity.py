@@ -661,7 +661,7 @@ def test_relu_fold_is_bit_identical_to_materialised_relu():
     input gradients (incl. the threshold_backward gate and signed zeros) and all state must equal the unfolded
     run and the oracle, for the pruning-only phase, the active phase and evaluation."""
     from qsparse_amd.fused import fuse_prune_quantize_pairs
-    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (6, 24, 4, 8))):
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float32, (3, 8, 6, 6)), (torch.bfloat16, (5, 16, 14, 14)), (torch.float16, (6, 24, 4, 8))):
         runs = []
         for fold in (True, False):
             qs.set_qsparse_options(fold_relu=fold)
@@ -703,7 +703,7 @@ def test_relu_quantize_site_fold_is_bit_identical(kind):
     equal the module-by-module run and the oracle: identity phase, active phase, evaluation."""
     from qsparse_amd.fused import FusedActQuantize, fuse_prune_quantize_pairs
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
-    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (3, 50))):
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float32, (3, 8, 6, 6)), (torch.bfloat16, (5, 16, 14, 14)), (torch.float16, (3, 50))):
         runs = []
         for fold in (True, False):
             qs.set_qsparse_options(fold_relu=fold)
@@ -755,7 +755,7 @@ def test_relu_prune_site_fold_is_bit_identical():
     magnitudes and counters equal the module-by-module run and the oracle, before the start step, while the schedule
     ramps, in steady state and in evaluation."""
     from qsparse_amd.fused import FusedActPrune, fuse_prune_quantize_pairs
-    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float16, (6, 24, 4, 8))):
+    for dtype, shape in ((torch.bfloat16, (8, 32, 8, 8)), (torch.float32, (4, 16, 7, 7)), (torch.float32, (3, 8, 6, 6)), (torch.bfloat16, (5, 16, 14, 14)), (torch.float16, (6, 24, 4, 8))):
         runs = []
         for fold in (True, False):
             qs.set_qsparse_options(fold_relu=fold)
