@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                     const uint32_t left = geo.inner - it.r;            // elements of the first row
                     const uint32_t c1 = it.c + 1 == geo.C ? 0u : it.c + 1;
                     const typename Op::P p0 = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
-                    const typename Op::P p1 = left < 8 ? op.channel_masked(PARAM_PER_CHANNEL ? c1 : 0u, c1) : p0;
+                    const typename Op::P p1 = op.channel_masked(PARAM_PER_CHANNEL ? c1 : 0u, c1);      // unconditional: no divergent branch
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], (uint32_t)j < left ? p0 : p1, q[j]);
                 } else {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 const uint32_t left = geo.inner - it.r;
                 const uint32_t c1 = it.c + 1 == geo.C ? 0u : it.c + 1;
                 const SteBwdOp::P p0 = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
-                const SteBwdOp::P p1 = left < 8 ? op.channel_masked(param_per_channel ? c1 : 0u, c1) : p0;
+                const SteBwdOp::P p1 = op.channel_masked(param_per_channel ? c1 : 0u, c1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], (uint32_t)j < left ? p0 : p1, dummy);
             } else {
