@@ -379,8 +379,54 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t e_wave = (blk * (kBlock / 64) + wave) * 512;          // first element of this wave
     typename Op::P p_scalar = op.channel(0);
+    bool done = false;
+    if constexpr (XDT != QS_F32) {
+        // 2-byte inputs, whole wave inside the tensor: ONE 16-byte load per lane (1 KiB per wave in flight instead of
+        // two dependent 512-byte rounds) and the 8 results transposed through LDS, so that each of the lane's two
+        // 16-byte stores still covers one contiguous 1 KiB span per instruction.  The kernel is bound by the bytes its
+        // resident waves keep in flight (capping it at 4 / 2 waves per SIMD costs 1.55x / 2.3x): headline forward
+        // 0.2008 -> 0.1898 ms (6.1 -> 6.5 TB/s).
+        __shared__ __attribute__((aligned(16))) float stage[kBlock * 8];
+        if (e_wave + 512 <= (int64_t)geo.ngroups * 8 && (CM != CM_ROW || geo.inner % 8 == 0)) {
+            float* ws = stage + wave * 512;
+            const int64_t e = e_wave + lane * 8;
+            float v[8];
+            unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
+            int32_t q;
+            u32x4 a, b;
+            if constexpr (CM == CM_LAST) {
+                const uint8_t* mp = op.mask_ptr();
+                u32x2 mm = {0x01010101u, 0x01010101u};
+                if (mp) mm = *(const u32x2*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 8 consecutive channels
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = __float_as_uint(op.apply(v[j], Op::keep_of(p_scalar, (mm[0] >> (8 * j)) & 0xffu), q));
+                    b[j] = __float_as_uint(op.apply(v[4 + j], Op::keep_of(p_scalar, (mm[1] >> (8 * j)) & 0xffu), q));
+                }
+            } else {
+                typename Op::P p = p_scalar;
+                if constexpr (CM == CM_ROW) {
+                    const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 8 == 0: one row per lane
+                    p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = __float_as_uint(op.apply(v[j], p, q));
+                    b[j] = __float_as_uint(op.apply(v[4 + j], p, q));
+                }
+            }
+            *(u32x4*)(ws + lane * 8) = a;              // wave-private LDS region: no workgroup barrier
+            *(u32x4*)(ws + lane * 8 + 4) = b;
+            __builtin_amdgcn_wave_barrier();
+            const u32x4 o0 = *(const u32x4*)(ws + lane * 4);
+            const u32x4 o1 = *(const u32x4*)(ws + 256 + lane * 4);
+            st16<NT>((u32x4*)(y + e_wave + lane * 4), o0);
+            st16<NT>((u32x4*)(y + e_wave + 256 + lane * 4), o1);
+            done = true;
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2 && !done; ++half) {
         const int64_t e = e_wave + half * 256 + lane * 4;
         if (e + 4 <= geo.ngroups * 8) {
             float v[4];
