@@ -100,9 +100,9 @@ def main():
         "unit": "bytes per launch",
         "correction": "FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts a wide coalesced streaming "
                       "read at exactly half its bytes (MI355X_MICROARCH.md, HBM section), so fetch bytes = FETCH_SIZE*1024*2.  "
-                      "That section calibrates 16-byte/lane loads (apply backward, statistics); the apply-forward kernel reads "
-                      "8 bytes/lane, which it leaves uncalibrated, so it is calibrated here on its known input: "
-                      "FETCH_SIZE*1024*2 reproduces the 411,041,792-byte bf16 tensor, i.e. the same factor holds.  "
+                      "That section calibrates 16-byte/lane loads, which is what all three kernels issue (the apply forward as "
+                      "well since it takes one 16-byte load per lane); cross-check on the forward's known input: "
+                      "FETCH_SIZE*1024*2 reproduces the 411,041,792-byte bf16 tensor.  "
                       "WRITE_SIZE is used as reported.",
         "kernels": {},
     }
