@@ -366,8 +366,10 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 
 // ------------------------------------------------------------------------------------------------
 // fp32-output variant (2-byte or fp32 input -> fp32 output): every store instruction of a wave covers ONE contiguous
-// 1 KiB span (lane l writes 16 B at l*16), instead of 16 B at a 32-B stride; paid for with 8-byte loads.
-// A wave owns 512 consecutive elements: lane l handles elements [4l, 4l+4) and [256+4l, 256+4l+4).
+// 1 KiB span (lane l writes 16 B at l*16), instead of 16 B at a 32-B stride.
+// A wave owns 512 consecutive elements: lane l stores elements [4l, 4l+4) and [256+4l, 256+4l+4).  2-byte inputs are
+// LOADED 8 consecutive elements per lane (one 16-byte load) and transposed through LDS (below); fp32 inputs, partial
+// waves and ragged rows load what they store (8- / 16-byte loads per half).
 // Measured on the headline tensor: 0.2165 -> 0.2025 ms (5.7 -> 6.1 TB/s).  The mirror image for the narrowing
 // backward (contiguous 1 KiB loads, 8-byte stores) changed nothing (0.2045 vs 0.2042 ms) and was dropped:
 // it is the stores whose per-instruction footprint matters.
