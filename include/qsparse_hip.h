@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 6
+#define QS_ABI_VERSION 7
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -64,13 +64,17 @@ size_t qs_workspace_bytes(int op, int64_t n);
  * (x * mask, qsparse/sparse.py:116): masked channels are quantised as x*0.  The reference never
  * saturates (its clamp at :110-116 acts on a temporary); saturate != 0 enables q = clamp(q, lo, hi) as
  * an explicit opt-in.  pre_relu != 0 quantises max(x, 0): the nn.ReLU that convert() finds in front of the pair
- * (qsparse/convert.py:214-218) folded into the same pass. */
+ * (qsparse/convert.py:214-218) folded into the same pass.
+ * elide_masked != 0 (with chan_mask): the x of a pruned channel is not loaded at all -- it only ever meets `* 0`
+ * (sparse.py:116) -- and the quantizer is applied to +0.0 instead: bit-identical to the loading path for every finite
+ * x; a NaN / Inf on a pruned channel yields f32(0)*s instead of the reference's f32(INT_MIN)*s. */
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
                         const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask,
                         int64_t outer, int64_t C, int64_t inner,
                         int xdt, int ydt, int qdt,
-                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream);
+                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
+                        qs_stream_t stream);
 
 /* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
@@ -78,7 +82,8 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          const uint8_t* chan_mask,
                          int64_t outer, int64_t C, int64_t inner,
                          int xdt, int ydt, int qdt,
-                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream);
+                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
+                         qs_stream_t stream);
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
@@ -93,13 +98,15 @@ int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines
  *   gx = cast(gxdt, min(max(g, lo_mul*step_c), hi_mul*step_c))     (passthrough != 0: gx = cast(g))
  * step_c = scale (step_is_decimal == 0) or 2^-d (step_is_decimal != 0);  lo_mul = -2^(bits-1)+notch,
  * hi_mul = 2^(bits-1)-1+notch.  chan_mask (nullable) fuses the PruneLayer backward g*mask
- * (autograd MulBackward0 of qsparse/sparse.py:116).  g and gx may alias. */
+ * (autograd MulBackward0 of qsparse/sparse.py:116).  g and gx may alias.
+ * elide_masked != 0 (with chan_mask): the g of a pruned channel is not loaded and gx = +0.0 there; the reference's
+ * g*0 carries the sign of clamp(g), so this is numerically equal, not bit-identical (opt-in). */
 int qs_quant_ste_bwd(const void* g, void* gx,
                      const float* step, int64_t nstep, float step_host, int step_is_decimal,
                      float lo_mul, float hi_mul, int passthrough,
                      const uint8_t* chan_mask,
                      int64_t outer, int64_t C, int64_t inner,
-                     int gdt, int gxdt, qs_stream_t stream);
+                     int gdt, int gxdt, int elide_masked, qs_stream_t stream);
 
 /* The same backward with the gate of a folded nn.ReLU (threshold_backward: 0 where x <= 0):
  *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)
@@ -107,7 +114,8 @@ int qs_quant_ste_bwd(const void* g, void* gx,
 int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
                           const float* step, int64_t nstep, float step_host, int step_is_decimal,
                           float lo_mul, float hi_mul, const uint8_t* chan_mask,
-                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, qs_stream_t stream);
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked,
+                          qs_stream_t stream);
 
 /* ---- statistics ---------------------------------------------------------------------------------- */
 
@@ -219,9 +227,11 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
  * is the mask's element stride along d (0 where the mask has extent 1).
  * pre_relu != 0: y = max(x, 0) * mask, a preceding nn.ReLU folded into the prune site; only for masks that
  * vary along one run of dims (channel masks; QS_ERR_ARG otherwise).  Its backward is
- * qs_quant_ste_relu_bwd with step_host = 1 and lo_mul / hi_mul = -inf / +inf. */
+ * qs_quant_ste_relu_bwd with step_host = 1 and lo_mul / hi_mul = -inf / +inf.
+ * elide_masked != 0 (channel-type masks): pruned channels are not loaded and y = +0.0 there; the reference's x*0
+ * carries the sign of x, so this is numerically equal, not bit-identical (opt-in). */
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes,
-                  const int64_t* mask_strides, int dt, int pre_relu, qs_stream_t stream);
+                  const int64_t* mask_strides, int dt, int pre_relu, int elide_masked, qs_stream_t stream);
 
 /* ---- fused channel-prune -> tensor-wise-quantize statistics (the headline pair) -------------------- */
 

@@ -8,6 +8,7 @@ hand-written HIP kernels for gfx950 behind a C ABI (``include/qsparse_hip.h``,
 from qsparse_amd.batch import WeightBatcher
 from qsparse_amd.convert import convert
 from qsparse_amd.fuse import fuse_bn
+from qsparse_amd.graphs import resync_host_state
 from qsparse_amd.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer, quantize,
                                   quantize_with_decimal, quantize_with_line, quantize_with_scaler)
 from qsparse_amd.sparse import (MagnitudePruningCallback, UniformPruningCallback, devise_layerwise_pruning_schedule,

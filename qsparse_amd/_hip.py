@@ -35,11 +35,11 @@ SIGNATURES = {
     "qs_version": (c_int, []),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
-    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _P]),
-    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _P]),
-    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _P]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P]),
+    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
-    "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _P]),
+    "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P, c_size_t, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P, c_size_t, _P]),
     "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _I, _P, _I, _P]),
@@ -50,7 +50,7 @@ SIGNATURES = {
     "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P, _P]),
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
-    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
@@ -62,6 +62,22 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# Mask-aware traffic elision (set through set_qsparse_options(elide_pruned=...), see qs_elementwise.h):
+#   "forward" (default)  quantizer forward kernels that carry a channel mask skip the loads of pruned channels --
+#                        bit-identical for finite inputs
+#   "all"                the backward and mask-apply kernels as well: +0.0 where the reference has -0.0 (opt-in)
+#   "off"                every element is loaded (NaN / Inf on pruned channels behave as in the reference, quirk B15)
+elide_mode = "forward"
+
+
+def _elide_fwd() -> int:
+    return int(elide_mode != "off")
+
+
+def _elide_all() -> int:
+    return int(elide_mode == "all")
+
 
 # ---- optional per-kernel timing with HIP events (bench.py) -----------------------------------------
 # torch.cuda.Event records on torch's current stream, which is the stream every kernel here is
@@ -220,6 +236,18 @@ def split3(shape, channel_index: int):
     return outer, shape[channel_index], inner, numel
 
 
+def _chan_mask_bytes(chan_mask: Optional[torch.Tensor], C: int):
+    """flat uint8 view of a per-channel bool mask; a channel count that does not match the tensor raises the
+    RuntimeError the reference's ``x * mask`` broadcast raises (PruneLayer.forward docstring, sparse.py:222)"""
+    if chan_mask is None:
+        return None
+    cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
+    if cm.numel() != C:
+        raise RuntimeError(f"The size of tensor a ({C}) must match the size of tensor b ({cm.numel()}) at non-singleton "
+                           "dimension (channel mask vs input)")
+    return cm
+
+
 def _f32param(p, device):
     """device fp32 array or (None, host float) for scalars given as Python numbers."""
     if isinstance(p, torch.Tensor):
@@ -244,15 +272,12 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
         return torch.empty_like(like, dtype=out_dtype), None
     y = torch.empty_like(like, dtype=out_dtype)
     codes = torch.empty_like(like, dtype=torch.int32) if want_codes else None
-    cm = None
-    if chan_mask is not None:
-        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
-        assert cm.numel() == C
+    cm = _chan_mask_bytes(chan_mask, C)
     sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else "")):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _stream(x))
+                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0, _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     return y, codes
 
@@ -283,14 +308,11 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
     gx = torch.empty_like(like, dtype=out_dtype)
     if numel == 0:
         return gx
-    cm = None
-    if chan_mask is not None:
-        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
-        assert cm.numel() == C
+    cm = _chan_mask_bytes(chan_mask, C)
     with _timed("quant_ste_bwd" + ("+mask" if cm is not None else "")):
         st = lib.qs_quant_ste_bwd(_ptr(g), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)), float(lo_mul),
                                   float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g),
-                                  _DT[out_dtype], _stream(g))
+                                  _DT[out_dtype], _elide_all() if cm is not None else 0, _stream(g))
     _check(st, "qs_quant_ste_bwd")
     return gx
 
@@ -317,13 +339,11 @@ def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, 
     gx = torch.empty_like(like, dtype=like.dtype)
     if numel == 0:
         return gx
-    cm = None
-    if chan_mask is not None:
-        cm = chan_mask.detach().contiguous().view(torch.uint8).view(-1)
-        assert cm.numel() == C
+    cm = _chan_mask_bytes(chan_mask, C)
     with _timed("quant_ste_relu_bwd"):
         st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
-                                       float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x), _stream(g))
+                                       float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x),
+                                       _elide_all() if cm is not None else 0, _stream(g))
     _check(st, "qs_quant_ste_relu_bwd")
     return gx
 
@@ -532,7 +552,7 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> t
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
     with _timed("mask_apply"):
-        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _stream(x))
+        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _elide_all(), _stream(x))
     _check(st, "qs_mask_apply")
     return y
 
@@ -592,19 +612,27 @@ def i64_array(values):
     return (c_int64 * len(values))(*[int(v) for v in values])
 
 
+def _device_stream(device):
+    """hipStream_t for a multi-tensor launch: same rule as ``_stream`` -- the tensors' device must be the current one"""
+    cur = torch.cuda.current_device()
+    idx = device.index if device.index is not None else cur
+    if idx != cur:
+        raise QsparseHipError(f"tensors on cuda:{idx} but the current device is cuda:{cur}: call "
+                              "torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)")
+    return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+
+
 def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
-    st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _raw_stream(device.index) if _raw_stream else
-                                torch.cuda.current_stream(device).cuda_stream)
+    st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
     _check(st, "qs_multi_absmax")
 
 
 def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device):
     st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs,
-                                      _raw_stream(device.index) if _raw_stream else torch.cuda.current_stream(device).cuda_stream)
+                                      _device_stream(device))
     _check(st, "qs_multi_scale_update")
 
 
 def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device):
-    st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)),
-                                   _raw_stream(device.index) if _raw_stream else torch.cuda.current_stream(device).cuda_stream)
+    st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
     _check(st, "qs_multi_quant_fwd")

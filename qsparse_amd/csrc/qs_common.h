@@ -40,6 +40,10 @@ __device__ __forceinline__ float round_through(float v) {  // value after one ro
     return v;
 }
 
+// ATen's CPU relu is clamp_min(x, 0) = max_ps(0, x): NaN and -0.0 pass through.  fmaxf would turn NaN into 0 and hide
+// a diverged activation that the module-by-module path reports.
+__device__ __forceinline__ float relu_aten(float v) { return (v < 0.0f) ? 0.0f : v; }
+
 // ---- scalar element access ---------------------------------------------------------------------
 template <int DT>
 __device__ __forceinline__ float load1(const void* p, int64_t i) {

@@ -68,6 +68,7 @@ __device__ __forceinline__ float guarded_reciprocal(float s) {
 // ScalerQuantization.forward  (reference qsparse/quantize.py:100-117)
 template <int QDT>
 struct ScalerFwdOp {
+    static constexpr bool kHasMask = true;
     const float* scale;     // device, nullable
     float scale_host;
     const uint8_t* cmask;   // device, nullable: fused channel prune
@@ -91,7 +92,7 @@ struct ScalerFwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
-    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
         p.keep = m ? 1.0f : 0.0f;
         return p;
@@ -108,7 +109,7 @@ struct ScalerFwdOp {
         }
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
-        if (pre_relu) v = fmaxf(v, 0.0f);
+        if (pre_relu) v = relu_aten(v);
         v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
         int32_t qi;                                   // round(x / s).int(): half-to-even (:109)
         if constexpr (QDT != QS_F32) qi = f32_to_i32_x86(quotient_rint(v, p));
@@ -122,6 +123,7 @@ struct ScalerFwdOp {
 // DecimalQuantization.forward  (reference qsparse/quantize.py:44-63)
 template <int QDT>
 struct DecimalFwdOp {
+    static constexpr bool kHasMask = true;
     const float* decimal;
     float decimal_host;
     const uint8_t* cmask;
@@ -148,13 +150,13 @@ struct DecimalFwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
-    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
         p.keep = m ? 1.0f : 0.0f;
         return p;
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
-        if (pre_relu) v = fmaxf(v, 0.0f);
+        if (pre_relu) v = relu_aten(v);
         v = v * p.keep;
         float q = round_through<QDT>(v * p.toi);
         int32_t qi = f32_to_i32_x86(q);          // .int(): truncation toward zero (:55)
@@ -167,6 +169,7 @@ struct DecimalFwdOp {
 // LineQuantization.forward  (reference qsparse/quantize.py:148-181)
 template <bool FLOAT_ZP>
 struct LineFwdOp {
+    static constexpr bool kHasMask = false;
     const float* lines;  // device [nlines, 2]
     float nlevels;       // 2^bits
     float inv_levels;    // 2^-bits (exact)
@@ -184,7 +187,7 @@ struct LineFwdOp {
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c, uint32_t) const { return channel(c); }
-    __device__ __forceinline__ const uint8_t* mask_ptr() const { return nullptr; }
+    __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return nullptr; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t) { return p; }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         if (v != v) {                                    // torch.clamp and everything after it propagate NaN
@@ -212,6 +215,7 @@ struct LineFwdOp {
 // Scaler/DecimalQuantization.backward (reference qsparse/quantize.py:66-77, 120-131), optionally fused
 // with the PruneLayer backward g * mask.
 struct SteBwdOp {
+    static constexpr bool kHasMask = true;
     const float* step;
     float step_host;
     int step_is_decimal;
@@ -235,7 +239,7 @@ struct SteBwdOp {
         if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
         return p;
     }
-    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
         p.keep = m ? 1.0f : 0.0f;
         return p;
@@ -253,6 +257,7 @@ struct SteBwdOp {
 
 // x * mask with a per-channel mask (reference qsparse/sparse.py:66,116,122,263)
 struct ChanMaskOp {
+    static constexpr bool kHasMask = true;
     const uint8_t* cmask;
     int relu;   // max(x, 0) * mask: a preceding nn.ReLU folded into the prune site
     struct P {
@@ -264,25 +269,73 @@ struct ChanMaskOp {
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t, uint32_t c_mask) const { return channel(c_mask); }
-    __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
+    __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
         p.keep = m ? 1.0f : 0.0f;
         return p;
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         code = 0;
-        if (relu) v = (v < 0.0f) ? 0.0f : v;   // ATen's CPU relu (clamp_min = max_ps(0, x)): -0.0 and NaN pass through
+        if (relu) v = relu_aten(v);   // ATen's CPU relu (clamp_min = max_ps(0, x)): -0.0 and NaN pass through
         return v * p.keep;
     }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Mask-aware traffic elision (ELIDE).  With a channel mask the input of a pruned channel only ever meets
+// `* 0`: the mask byte is read FIRST and the load of x (or g) is skipped for lanes whose elements are all pruned; the
+// op is applied to +0.0 instead.  At 75 % channel sparsity the fused forward reads a quarter of x.  Exactness:
+//   * quantizer forward: bit-identical to the loading path for every finite x (x*0 = +-0 -> code 0 -> f32(0)*s),
+//     which is why it is the default; a NaN / Inf on a PRUNED channel gives f32(0)*s here and INT_MIN*s in the
+//     reference (quirk B15) -- the loading path stays available (elide_masked = 0).
+//   * mask apply and the backward kernels: the reference's g*0 / x*0 keeps the sign of its operand, the elided result
+//     is always +0.0 -- numerically equal, not bit-identical, hence opt-in.
+// Lanes decide individually (a divergent skip still saves the HBM lines no active lane touches); rows of at least
+// 8 elements are needed for a lane to be all-pruned in the [outer, C, inner] layout, 8 consecutive pruned channels
+// in the channels_last layout (CM_LAST), where the gain is accordingly small.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ Raw8<DT> zero_raw8() {
+    Raw8<DT> r;
+    r.a = u32x4{0u, 0u, 0u, 0u};
+    r.b = u32x4{0u, 0u, 0u, 0u};
+    return r;
+}
+
+// One mask byte through the SCALAR cache (s_load_dword of the aligned word that holds it): `c` must be wave-uniform.
+// The vector memory pipeline of a streaming kernel is full of non-temporal stores, and a per-lane mask load queued
+// behind them delays every wave by a memory round trip before it can even decide what to load (measured: elided
+// forward no faster than the dense one); the scalar path is separate and short.
+typedef const __attribute__((address_space(4))) uint32_t* qs_const_u32_ptr;
+__device__ __forceinline__ uint32_t sload_mask_byte(const uint8_t* m, uint32_t c_uniform) {
+    const uintptr_t a = (uintptr_t)m + c_uniform;
+    const uint32_t w = *(qs_const_u32_ptr)(a & ~(uintptr_t)3);
+    return (w >> (8u * (uint32_t)(a & 3u))) & 0xffu;
+}
+
+// The at most two rows a wave's 64 consecutive 8-element groups touch when a row has at least 64 groups, with their
+// mask bytes: wave-uniform values (SGPRs).  `gw` = first group of the wave (uniform).
+struct WaveRows {
+    uint32_t c0, c1, k0, k1, split;   // channels, mask bytes, number of the wave's groups that lie in the first row
+    __device__ __forceinline__ void seek(uint32_t gw, uint32_t groups_per_row, uint32_t C, const uint8_t* mask) {
+        const uint32_t row0 = gw / groups_per_row;
+        split = groups_per_row - (gw - row0 * groups_per_row);
+        c0 = row0 % C;
+        c1 = c0 + 1u == C ? 0u : c0 + 1u;
+        k0 = sload_mask_byte(mask, c0);
+        k1 = sload_mask_byte(mask, c1);
+    }
+    __device__ __forceinline__ bool all_pruned() const { return k0 == 0u && (split >= 64u || k1 == 0u); }
 };
 
 // ------------------------------------------------------------------------------------------------
 // The streaming kernel.  PARAM_PER_CHANNEL tells whether the op's parameter array is indexed by the
 // channel (nparam == C) or is a single value; the channel mask, when present, is always per channel.
 // ------------------------------------------------------------------------------------------------
-template <typename Op, int XDT, int YDT, int CM, bool PARAM_PER_CHANNEL, bool NT, int UNROLL>
+template <typename Op, int XDT, int YDT, int CM, bool PARAM_PER_CHANNEL, bool NT, int UNROLL, bool ELIDE = false>
 __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                      void* __restrict__ y, int32_t* __restrict__ codes) {
+    static_assert(!ELIDE || (Op::kHasMask && CM != CM_SCALAR), "elision needs a channel mask");
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     int64_t g0 = blk * kBlock + threadIdx.x;
@@ -291,10 +344,12 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 
     for (; g0 < geo.ngroups; g0 += stride * UNROLL) {
         Raw8<XDT> raw[UNROLL];
+        if constexpr (!ELIDE) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t g = g0 + u * stride;
-            if (g < geo.ngroups) raw[u] = load8_raw<XDT, NT>(x, g);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t g = g0 + u * stride;
+                if (g < geo.ngroups) raw[u] = load8_raw<XDT, NT>(x, g);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -302,14 +357,31 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
             if (g >= geo.ngroups) break;
             float v[8];
             int32_t q[8];
-            unpack8<XDT>(raw[u], v);
+            if constexpr (!ELIDE) unpack8<XDT>(raw[u], v);
             if constexpr (CM == CM_SCALAR) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
             } else if constexpr (CM == CM_ROW) {
-                const uint32_t row = (uint32_t)((uint64_t)g / geo.groups_per_row);
-                const uint32_t c = row % geo.C;
-                typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                typename Op::P p;
+                if constexpr (ELIDE) {      // mask first; pruned rows are never loaded
+                    if (geo.groups_per_row >= 64u) {    // rows of >= 512 elements: wave-uniform look-up through the scalar cache
+                        const uint32_t lane = threadIdx.x & 63u;
+                        WaveRows wr;
+                        wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)g - lane), geo.groups_per_row, geo.C, op.mask_ptr());
+                        const bool first = lane < wr.split;
+                        p = Op::keep_of(op.channel(PARAM_PER_CHANNEL ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
+                    } else {
+                        const uint32_t c = (uint32_t)((uint64_t)g / geo.groups_per_row) % geo.C;
+                        p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                    }
+                    raw[u] = zero_raw8<XDT>();
+                    if (p.keep != 0.0f) raw[u] = load8_raw<XDT, NT>(x, g);
+                    unpack8<XDT>(raw[u], v);
+                } else {
+                    const uint32_t row = (uint32_t)((uint64_t)g / geo.groups_per_row);
+                    const uint32_t c = row % geo.C;
+                    p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, q[j]);
             } else if constexpr (CM == CM_LAST) {
@@ -317,6 +389,11 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                 const uint8_t* mp = op.mask_ptr();
                 u32x2 mm = {0x01010101u, 0x01010101u};
                 if (mp) mm = *(const u32x2*)(mp + c0);
+                if constexpr (ELIDE) {      // 8 consecutive channels, all pruned
+                    raw[u] = zero_raw8<XDT>();
+                    if ((mm[0] | mm[1]) != 0u) raw[u] = load8_raw<XDT, NT>(x, g);
+                    unpack8<XDT>(raw[u], v);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     v[j] = op.apply(v[j], Op::keep_of(p_scalar, (mm[j >> 2] >> (8 * (j & 3))) & 0xffu), q[j]);
@@ -332,9 +409,15 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                     const uint32_t c1 = it.c + 1 == geo.C ? 0u : it.c + 1;
                     const typename Op::P p0 = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
                     const typename Op::P p1 = op.channel_masked(PARAM_PER_CHANNEL ? c1 : 0u, c1);      // unconditional: no divergent branch
+                    if constexpr (ELIDE) {
+                        raw[u] = zero_raw8<XDT>();
+                        if (p0.keep != 0.0f || (left < 8u && p1.keep != 0.0f)) raw[u] = load8_raw<XDT, NT>(x, g);
+                        unpack8<XDT>(raw[u], v);
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], (uint32_t)j < left ? p0 : p1, q[j]);
                 } else {
+                    if constexpr (ELIDE) unpack8<XDT>(load8_raw<XDT, NT>(x, g), v);   // rows shorter than a lane's 8 elements
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
@@ -374,9 +457,10 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 // backward (contiguous 1 KiB loads, 8-byte stores) changed nothing (0.2045 vs 0.2042 ms) and was dropped:
 // it is the stores whose per-instruction footprint matters.
 // ------------------------------------------------------------------------------------------------
-template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT>
+template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT, bool ELIDE = false>
 __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                            float* __restrict__ y) {
+    static_assert(!ELIDE || (Op::kHasMask && (CM == CM_ROW || CM == CM_LAST)), "elision needs a channel mask");
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t e_wave = (blk * (kBlock / 64) + wave) * 512;          // first element of this wave
@@ -393,13 +477,18 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
             float* ws = stage + wave * 512;
             const int64_t e = e_wave + lane * 8;
             float v[8];
-            unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
+            if constexpr (!ELIDE) unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
             int32_t q;
             u32x4 a, b;
             if constexpr (CM == CM_LAST) {
                 const uint8_t* mp = op.mask_ptr();
                 u32x2 mm = {0x01010101u, 0x01010101u};
                 if (mp) mm = *(const u32x2*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 8 consecutive channels
+                if constexpr (ELIDE) {
+                    Raw8<XDT> r = zero_raw8<XDT>();
+                    if ((mm[0] | mm[1]) != 0u) r = load8_raw<XDT, NT>(x, e / 8);
+                    unpack8<XDT>(r, v);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     a[j] = __float_as_uint(op.apply(v[j], Op::keep_of(p_scalar, (mm[0] >> (8 * j)) & 0xffu), q));
@@ -407,7 +496,32 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                 }
             } else {
                 typename Op::P p = p_scalar;
-                if constexpr (CM == CM_ROW) {
+                if constexpr (CM == CM_ROW && ELIDE) {      // the mask byte first; the x of a pruned row is never loaded
+                    if (geo.groups_per_row >= 64u) {        // rows of >= 512 elements: wave-uniform look-up through the scalar cache
+                        WaveRows wr;
+                        wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)(e_wave >> 3)), geo.groups_per_row, geo.C, op.mask_ptr());
+                        if (wr.all_pruned()) {
+                            // nothing of this wave is kept: no load, no LDS round trip -- store Q(+0.0) of each element's row.
+                            // Lane l stores elements [4l, 4l+4) and [256+4l, 256+4l+4); rows change at a multiple of 8 elements.
+                            const float z0 = op.apply(0.0f, Op::keep_of(op.channel(PARAM_PER_CHANNEL ? wr.c0 : 0u), 0u), q);
+                            const float z1 = op.apply(0.0f, Op::keep_of(op.channel(PARAM_PER_CHANNEL ? wr.c1 : 0u), 0u), q);
+                            const uint32_t split_e = wr.split >= 64u ? 512u : wr.split * 8u;
+                            const uint32_t za = __float_as_uint((uint32_t)lane * 4u < split_e ? z0 : z1);
+                            const uint32_t zb = __float_as_uint(256u + (uint32_t)lane * 4u < split_e ? z0 : z1);
+                            st16<NT>((u32x4*)(y + e_wave + lane * 4), u32x4{za, za, za, za});
+                            st16<NT>((u32x4*)(y + e_wave + 256 + lane * 4), u32x4{zb, zb, zb, zb});
+                            return;     // (inner % 8 == 0 here, so numel % 8 == 0: there is no ragged tail for this wave to serve)
+                        }
+                        const bool first = (uint32_t)lane < wr.split;
+                        p = Op::keep_of(op.channel(PARAM_PER_CHANNEL ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
+                    } else {
+                        const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;
+                        p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                    }
+                    Raw8<XDT> r = zero_raw8<XDT>();
+                    if (p.keep != 0.0f) r = load8_raw<XDT, NT>(x, e / 8);
+                    unpack8<XDT>(r, v);
+                } else if constexpr (CM == CM_ROW) {
                     const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 8 == 0: one row per lane
                     p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
                 }
@@ -433,11 +547,26 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
         if (e + 4 <= geo.ngroups * 8) {
             float v[4];
             u32x2 raw = {0u, 0u};
+            bool need = true;                // ELIDE: whether any of the lane's 4 elements is kept
+            typename Op::P p = p_scalar;
+            uint32_t mm = 0x01010101u;
+            if constexpr (ELIDE) {
+                if constexpr (CM == CM_ROW) {
+                    const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;
+                    p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                    need = p.keep != 0.0f;
+                } else {
+                    const uint8_t* mp = op.mask_ptr();
+                    if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));
+                    need = mm != 0u;
+                }
+            }
             if constexpr (XDT == QS_F32) {   // fp32 -> fp32: 16-byte loads and stores, both one contiguous 1 KiB span
-                const u32x4 r4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                u32x4 r4 = {0u, 0u, 0u, 0u};
+                if (need) r4 = ld16<NT>((const u32x4*)((const float*)x + e));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(r4[j]);
-            } else {
+            } else if (need) {
                 raw = NT ? __builtin_nontemporal_load((const u32x2*)((const uint16_t*)x + e))
                          : *(const u32x2*)((const uint16_t*)x + e);
             }
@@ -453,15 +582,15 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                 v[2] = f16_bits_to_f32(raw[1] & 0xffffu);
                 v[3] = f16_bits_to_f32(raw[1] >> 16);
             }
-            typename Op::P p = p_scalar;
-            if constexpr (CM == CM_ROW) {
-                const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
-                p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
-            }
-            uint32_t mm = 0x01010101u;
-            if constexpr (CM == CM_LAST) {
-                const uint8_t* mp = op.mask_ptr();
-                if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+            if constexpr (!ELIDE) {
+                if constexpr (CM == CM_ROW) {
+                    const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
+                    p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                }
+                if constexpr (CM == CM_LAST) {
+                    const uint8_t* mp = op.mask_ptr();
+                    if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+                }
             }
             int32_t q;
             u32x4 out;
@@ -491,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
 // STE backward with the folded ReLU's gate: gx = (x <= 0) ? 0 : clamp(g) * mask.  Two streamed inputs (the
 // gradient and the ReLU's input), one output in x's dtype.  Same geometry and channel modes as ew_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int GDT, int XDT, int CM, bool NT>
+template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
                                                               void* __restrict__ gx) {
@@ -508,8 +637,24 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         for (int half = 0; half < 2; ++half) {
             const int64_t e = e_wave + half * 256 + lane * 4;
             if (e + 4 <= geo.ngroups * 8) {
-                const u32x4 rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
-                const u32x4 rx4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                u32x4 rg4 = {0u, 0u, 0u, 0u}, rx4 = {0u, 0u, 0u, 0u};
+                bool need = true;            // ELIDE: pruned lanes load neither stream (x = +0 closes the gate: gx = +0)
+                if constexpr (ELIDE && CM == CM_ROW) {
+                    if (geo.groups_per_row >= 64u && geo.inner % 8u == 0u) {     // wave-uniform look-up, see WaveRows
+                        WaveRows wr;
+                        wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)(e_wave >> 3)), geo.groups_per_row, geo.C, op.cmask);
+                        need = ((uint32_t)(half * 256 + lane * 4) < wr.split * 8u ? wr.k0 : wr.k1) != 0u;
+                    } else {
+                        const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;
+                        need = op.cmask[c] != 0;
+                    }
+                } else if constexpr (ELIDE && CM == CM_LAST) {
+                    need = *(const uint32_t*)(op.cmask + (uint32_t)((uint64_t)e % geo.C)) != 0u;
+                }
+                if (need) {
+                    rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
+                    rx4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                }
                 int32_t dummy;
                 u32x4 out;
                 if constexpr (CM == CM_LAST) {
@@ -546,8 +691,27 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         }
     } else
     if (grp < geo.ngroups) {
-        const Raw8<GDT> rg = load8_raw<GDT, NT>(g, grp);
-        const Raw8<XDT> rx = load8_raw<XDT, NT>(x, grp);
+        Raw8<GDT> rg = zero_raw8<GDT>();
+        Raw8<XDT> rx = zero_raw8<XDT>();
+        bool need = true;
+        if constexpr (ELIDE && CM == CM_ROW) {
+            if (geo.groups_per_row >= 64u) {     // wave-uniform look-up, see WaveRows
+                const uint32_t lane = threadIdx.x & 63u;
+                WaveRows wr;
+                wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)grp - lane), geo.groups_per_row, geo.C, op.cmask);
+                need = (lane < wr.split ? wr.k0 : wr.k1) != 0u;
+            } else {
+                const uint32_t c = (uint32_t)((uint64_t)grp / geo.groups_per_row) % geo.C;
+                need = op.cmask[c] != 0;
+            }
+        } else if constexpr (ELIDE && CM == CM_LAST) {
+            const u32x2 m8 = *(const u32x2*)(op.cmask + (uint32_t)(((uint64_t)grp * 8) % geo.C));
+            need = (m8[0] | m8[1]) != 0u;
+        }
+        if (need) {
+            rg = load8_raw<GDT, NT>(g, grp);
+            rx = load8_raw<XDT, NT>(x, grp);
+        }
         float vg[8], vx[8];
         unpack8<GDT>(rg, vg);
         unpack8<XDT>(rx, vx);

@@ -16,7 +16,7 @@ struct RedAcc {
     uint32_t mx = 0u, mn = 0xffffffffu;
     int relu = 0;   // abs-max of max(x, 0): the statistics of a folded nn.ReLU
     __device__ __forceinline__ void add(float v) {
-        if (relu) v = fmaxf(v, 0.0f);
+        if (relu) v = relu_aten(v);
         if constexpr (MINMAX) {
             uint32_t k = f32_to_key(v);
             mx = k > mx ? k : mx;
@@ -499,7 +499,7 @@ struct Cascade {  // 4-level cascade accumulator for ONE column
 
 template <int DT>
 __device__ __forceinline__ float mean_prep(float v, int flags, int l0) {
-    if (flags & QS_MEAN_RELU) v = fmaxf(v, 0.0f);   // folded preceding nn.ReLU
+    if (flags & QS_MEAN_RELU) v = relu_aten(v);   // folded preceding nn.ReLU
     if (l0) return (v != 0.0f) ? 1.0f : 0.0f;       // (x != 0).float()  (sparse.py:86)
     return (flags & QS_MEAN_ABS) ? fabsf(v) : v;    // x.abs()           (sparse.py:87)
 }
@@ -633,13 +633,13 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                     acc[j].add(v[j]);
                 } else if constexpr (MODE == 0) {
                     if (absmax) {
-                        const float av = (flags & QS_MEAN_RELU) ? fmaxf(v[j], 0.0f) : v[j];
+                        const float av = (flags & QS_MEAN_RELU) ? relu_aten(v[j]) : v[j];
                         const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
                         amax = k > amax ? k : amax;
                     }
                     acc[j].add(mean_prep<DT>(v[j], flags, l0));
                 } else {
-                    const float w = (MODE == 2) ? fmaxf(v[j], 0.0f) : v[j];
+                    const float w = (MODE == 2) ? relu_aten(v[j]) : v[j];
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
                     amax = k > amax ? k : amax;
                     acc[j].add(__uint_as_float(k));
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 template <int MODE>
 __device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am) {
     if constexpr (MODE == 3) return v;
-    const float w = (MODE == 2) ? fmaxf(v, 0.0f) : v;
+    const float w = (MODE == 2) ? relu_aten(v) : v;
     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
     am = k > am ? k : am;
     return __uint_as_float(k);
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
     auto track = [&](const float (&v)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float av = (flags & QS_MEAN_RELU) ? fmaxf(v[j], 0.0f) : v[j];
+            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v[j]) : v[j];
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             if (j < first_col_next) amax0 = k > amax0 ? k : amax0;
             else amax1 = k > amax1 ? k : amax1;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
         if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float w = (MODE == 2) ? fmaxf(v[k], 0.0f) : v[k];
+                const float w = (MODE == 2) ? relu_aten(v[k]) : v[k];
                 const uint32_t key = __float_as_uint(w) & 0x7fffffffu;
                 amax0 = key > amax0 ? key : amax0;
                 add(k, __uint_as_float(key));
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, base + i * post);
         if (absmax) {
-            const float av = (flags & QS_MEAN_RELU) ? fmaxf(v, 0.0f) : v;
+            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v) : v;
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }

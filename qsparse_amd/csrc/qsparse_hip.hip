@@ -14,6 +14,9 @@
 #ifndef QS_EW_UNROLL
 #define QS_EW_UNROLL 1
 #endif
+#ifndef QS_EW_UNROLL_ELIDE
+#define QS_EW_UNROLL_ELIDE 1   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
+#endif
 #ifndef QS_EW_NT
 #define QS_EW_NT 1
 #endif
@@ -121,29 +124,31 @@ inline int ew_widen() {
     return v;
 }
 
-template <typename Op, int XDT, int YDT>
-int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
-              hipStream_t s) {
-    if (plan.geo.numel == 0) return QS_OK;
+// `elide`: skip the loads of lanes whose elements are all pruned (qs_elementwise.h, "Mask-aware traffic elision");
+// only meaningful for ops that carry a channel mask, in the per-channel modes
+template <typename Op, int XDT, int YDT, bool ELIDE>
+int launch_ew_impl(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
+                   hipStream_t s) {
     constexpr bool NT = QS_EW_NT != 0;
-    constexpr int U = QS_EW_UNROLL;
+    constexpr int U = ELIDE ? QS_EW_UNROLL_ELIDE : QS_EW_UNROLL;
     if constexpr (YDT == QS_F32) {   // QS_EW_WIDEN: 0 off, 1 two-byte inputs only, 2 (default) fp32 inputs as well
         // (its lanes take 4 elements at a time, so rows of 4k elements -- 14x14 maps -- keep one channel per lane as well)
         const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
         if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && cm_w != CM_ELEM) {
             const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
             const int gridw = (int)std::max<int64_t>(1, (waves + kBlock / 64 - 1) / (kBlock / 64));   // < 8 elements: tail only
-            if (cm_w == CM_SCALAR)
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
-                                   plan.geo, x, (float*)y);
-            else if (cm_w == CM_LAST)
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+            if (cm_w == CM_SCALAR) {
+                if constexpr (!ELIDE)
+                    hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                                       plan.geo, x, (float*)y);
+            } else if (cm_w == CM_LAST)
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else if (param_per_channel)
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, false, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             return launch_status();
         }
@@ -151,31 +156,43 @@ int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const vo
     const int grid = grid_for(plan.geo.ngroups, U);
     switch (plan.cm) {
         case CM_SCALAR:
-            hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
-                               plan.geo, x, y, codes);
+            if constexpr (!ELIDE)
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                                   plan.geo, x, y, codes);
             break;
         case CM_ROW:
             if (param_per_channel)
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, true, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, true, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
             else
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
             break;
         case CM_LAST:
-            hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_LAST, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
+            hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_LAST, false, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
                                plan.geo, x, y, codes);
             break;
         default:
             if (param_per_channel)
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, true, NT, 1>), dim3(grid_for(plan.geo.ngroups, 1)),
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, true, NT, 1, ELIDE>), dim3(grid_for(plan.geo.ngroups, 1)),
                                    dim3(kBlock), 0, s, op, plan.geo, x, y, codes);
             else
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, false, NT, 1>), dim3(grid_for(plan.geo.ngroups, 1)),
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ELEM, false, NT, 1, ELIDE>), dim3(grid_for(plan.geo.ngroups, 1)),
                                    dim3(kBlock), 0, s, op, plan.geo, x, y, codes);
             break;
     }
     return launch_status();
+}
+
+template <typename Op, int XDT, int YDT>
+int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
+              hipStream_t s, bool elide = false) {
+    if (plan.geo.numel == 0) return QS_OK;
+    if constexpr (Op::kHasMask) {
+        if (elide && plan.cm != CM_SCALAR && op.mask_ptr() != nullptr)
+            return launch_ew_impl<Op, XDT, YDT, true>(op, plan, param_per_channel, x, y, codes, s);
+    }
+    return launch_ew_impl<Op, XDT, YDT, false>(op, plan, param_per_channel, x, y, codes, s);
 }
 
 int check_param(const float* p, int64_t nparam, int64_t C) {
@@ -215,7 +232,7 @@ size_t qs_workspace_bytes(int op, int64_t n) {
 // ------------------------------------------------------------------------------------------------
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
-                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, qs_stream_t stream) {
+                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked, qs_stream_t stream) {
     if (!x || !y) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
@@ -232,7 +249,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
-            return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
+            return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
         return (qdt == QS_F32) ? go(X, IC<QS_F32>{}) : go(X, X);
@@ -242,7 +259,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
                          float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
                          int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, int pre_relu,
-                         qs_stream_t stream) {
+                         int elide_masked, qs_stream_t stream) {
     if (!x || !y) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
@@ -259,7 +276,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
-            return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s);
+            return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
         return (qdt == QS_F32) ? go(X, IC<QS_F32>{}) : go(X, X);
@@ -293,7 +310,7 @@ int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines
 
 int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, float step_host, int step_is_decimal,
                      float lo_mul, float hi_mul, int passthrough, const uint8_t* chan_mask, int64_t outer, int64_t C,
-                     int64_t inner, int gdt, int gxdt, qs_stream_t stream) {
+                     int64_t inner, int gdt, int gxdt, int elide_masked, qs_stream_t stream) {
     if (!g || !gx) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(gxdt)) return QS_ERR_DTYPE;
     if (!(gdt == QS_F32 || gdt == gxdt)) return QS_ERR_DTYPE;
@@ -308,14 +325,14 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
     SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, passthrough, chan_mask};
     return with_dtype(gxdt, [&](auto GX) {
         constexpr int GXD = decltype(GX)::value;
-        if (gdt == QS_F32) return launch_ew<SteBwdOp, QS_F32, GXD>(op, plan, ppc, g, gx, nullptr, s);
-        return launch_ew<SteBwdOp, GXD, GXD>(op, plan, ppc, g, gx, nullptr, s);
+        if (gdt == QS_F32) return launch_ew<SteBwdOp, QS_F32, GXD>(op, plan, ppc, g, gx, nullptr, s, elide_masked != 0);
+        return launch_ew<SteBwdOp, GXD, GXD>(op, plan, ppc, g, gx, nullptr, s, elide_masked != 0);
     });
 }
 
 int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* step, int64_t nstep, float step_host,
                           int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask, int64_t outer,
-                          int64_t C, int64_t inner, int gdt, int xdt, qs_stream_t stream) {
+                          int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, qs_stream_t stream) {
     if (!g || !x || !gx) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(g) || !aligned16(x) || !aligned16(gx)) return QS_ERR_ALIGN;
@@ -336,18 +353,27 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
             constexpr int GD = decltype(G)::value;
             int cm = plan.cm;
             if (GD == QS_F32 && XD == QS_F32 && cm == CM_ELEM && plan.geo.inner % 4 == 0) cm = CM_ROW;   // 4 elements per lane
+            const bool el = elide_masked != 0 && chan_mask != nullptr;
             switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT>), dim3(grid), dim3(kBlock), 0, s, op,
                                        plan.geo, (int)ppc, g, x, gx);
                     break;
                 case CM_ROW:
-                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                       plan.geo, (int)ppc, g, x, gx);
+                    if (el)
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, true>), dim3(grid), dim3(kBlock), 0, s, op,
+                                           plan.geo, (int)ppc, g, x, gx);
+                    else
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                           plan.geo, (int)ppc, g, x, gx);
                     break;
                 case CM_LAST:
-                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                       plan.geo, (int)ppc, g, x, gx);
+                    if (el)
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, true>), dim3(grid), dim3(kBlock), 0, s, op,
+                                           plan.geo, (int)ppc, g, x, gx);
+                    else
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT>), dim3(grid), dim3(kBlock), 0, s, op,
+                                           plan.geo, (int)ppc, g, x, gx);
                     break;
                 default:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT>), dim3(grid), dim3(kBlock), 0, s, op,
@@ -700,7 +726,7 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
 
 // ------------------------------------------------------------------------------------------------
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes, const int64_t* mask_strides,
-                  int dt, int pre_relu, qs_stream_t stream) {
+                  int dt, int pre_relu, int elide_masked, qs_stream_t stream) {
     if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1) return QS_ERR_ARG;
     if (!dt_ok(dt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
@@ -749,7 +775,7 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         ChanMaskOp op{mask, pre_relu != 0};
         return with_dtype(dt, [&](auto D) {
             constexpr int DD = decltype(D)::value;
-            return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s);
+            return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s, elide_masked != 0);
         });
     }
     if (pre_relu) return QS_ERR_ARG;   // the ReLU fold exists for channel-type masks only

@@ -239,6 +239,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                              1 if qc.flip_axis else 0, quant_on, pre_relu)
 
 
+def _hooked(*modules) -> bool:
+    """forward (pre-)hooks registered on a child: the fused forward never calls the child, so its hooks would not
+    fire -- such a site runs module by module, exactly as the plain ``Sequential`` it replaces"""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in modules)
+
+
 class FusedPruneQuantize(nn.Sequential):
     """``Sequential(Sequential(act, PruneLayer), QuantizeLayer)`` with a fused GPU forward/backward.
     Children, parameter names and ``str()`` are those of the plain ``Sequential`` it replaces."""
@@ -246,6 +252,8 @@ class FusedPruneQuantize(nn.Sequential):
     def forward(self, x):
         inner, q = self[0], self[1]
         act, p = inner[0], inner[1]
+        if _hooked(inner, act, p, q, p.callback, q.callback):
+            return q(inner(x))
         # a plain, out-of-place nn.ReLU in front of an active quantizer is folded into the kernels: relu(x) is
         # never materialised (statistics, apply and backward read x itself); the gate of its backward rides in
         # the fused backward kernel
@@ -302,7 +310,7 @@ class FusedActQuantize(nn.Sequential):
     def forward(self, x):
         act, q = self[0], self[1]
         if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and q.is_active()
-                and _quantizer_foldable(q, x)):
+                and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback)):
             return fused_relu_quantize(q, x)
         return q(act(x))
 
@@ -321,7 +329,7 @@ class FusedActPrune(nn.Sequential):
         if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and isinstance(x, torch.Tensor)
                 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and p.is_active()
                 and type(p.callback) is MagnitudePruningCallback and not p.callback.l0
-                and not p.callback.use_gradient and len(p.dimensions) == 1):
+                and not p.callback.use_gradient and len(p.dimensions) == 1 and not _hooked(act, p.callback)):
             return p(x, pre_relu=True)
         return p(act(x))
 

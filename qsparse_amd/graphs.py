@@ -42,6 +42,8 @@ def steady_state(model: nn.Module) -> bool:
             cb = m.callback
             if isinstance(cb, UniformPruningCallback) or not isinstance(cb, MagnitudePruningCallback):
                 return False
+            if cb.l0 and m.mask.numel() != 1 and not (cb._t_host.read(cb.t) > cb.stop_mask_refresh):
+                return False       # the L0 choice of 2-byte inputs is taken on the host each step (sparse._importance)
             if m.mask.numel() != 1:
                 t = cb._t_host.read(cb.t)
                 frozen = t > cb.stop_mask_refresh          # mask refresh has stopped for good

@@ -19,7 +19,8 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 from qsparse_amd import distributed as qdist
-from qsparse_amd.common import HostMirror, TensorOrFloat, TensorOrInt, ensure_tensor
+from qsparse_amd.common import (HostMirror, TensorOrFloat, TensorOrInt, adopt_state_parameters, ensure_tensor,
+                                state_parameter)
 from qsparse_amd.imitation import imitate
 from qsparse_amd.util import get_option, logging
 
@@ -444,7 +445,11 @@ class QuantizeLayer(nn.Module):
     def _lazy_init(self, x):
         rows = 1 if self.channelwise < 0 else x.shape[self.channelwise]
         self.weight = nn.Parameter(torch.zeros(rows, self.callback.weight_size, device=x.device), requires_grad=False)
-        self._n_updates = nn.Parameter(torch.zeros(1, dtype=torch.int, device=x.device), requires_grad=False)
+        self._n_updates = state_parameter(torch.zeros(1, dtype=torch.int, device=x.device))
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        adopt_state_parameters(self)     # unpickling rebuilds plain Parameters
 
     def is_active(self) -> bool:
         """whether the next forward quantizes (used by the fused prune->quantize path)."""

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 from qsparse_amd import distributed as qdist
-from qsparse_amd.common import HostMirror
+from qsparse_amd.common import HostMirror, adopt_state_parameters, state_parameter
 from qsparse_amd.imitation import imitate
 from qsparse_amd.util import (_reduction_plan, _staged_mean_hip, calculate_mask_given_importance, get_option, logging,
                               squeeze_tensor_to_shape, threshold_rank)
@@ -111,8 +111,12 @@ class MagnitudePruningCallback(nn.Module):
         self.l0 = l0
         self.forward_hook = forward_hook
         self.prev_grad_hook = None
-        self.t = nn.Parameter(torch.full((1,), -1), requires_grad=False)
+        self.t = state_parameter(torch.full((1,), -1))
         self._t_host = HostMirror()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        adopt_state_parameters(self)     # unpickling rebuilds plain Parameters
 
     @property
     def initted(self) -> bool:
@@ -293,10 +297,15 @@ class PruneLayer(nn.Module):
         self.callback = callback
         self.rampup_interval = 0 if rampup else interval
         self.dimensions = set(dimensions)
-        for key in ("mask", "_n_updates", "_cur_sparsity"):   # shape-less placeholders until the first forward
-            self.register_parameter(key, nn.Parameter(torch.tensor(-1, dtype=torch.int), requires_grad=False))
+        self.register_parameter("mask", nn.Parameter(torch.tensor(-1, dtype=torch.int), requires_grad=False))
+        for key in ("_n_updates", "_cur_sparsity"):   # shape-less placeholders until the first forward
+            self.register_parameter(key, state_parameter(torch.tensor(-1, dtype=torch.int)))
         self._steps = HostMirror()
         self._sparsity_host = HostMirror()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        adopt_state_parameters(self)     # unpickling rebuilds plain Parameters
 
     @property
     def initted(self) -> bool:
@@ -308,8 +317,8 @@ class PruneLayer(nn.Module):
         self.mask = nn.Parameter(torch.ones(*mask_shape, dtype=torch.bool, device=x.device), requires_grad=False)
         if self.mask.numel() == 1:
             logging.warn(f"the mask shape of {self.name} is {tuple(self.mask.shape)}, which is not prunable")
-        self._n_updates = nn.Parameter(torch.zeros(1, dtype=torch.int, device=x.device), requires_grad=False)
-        self._cur_sparsity = nn.Parameter(torch.zeros(1, device=x.device), requires_grad=False)
+        self._n_updates = state_parameter(torch.zeros(1, dtype=torch.int, device=x.device))
+        self._cur_sparsity = state_parameter(torch.zeros(1, device=x.device))
 
     def scheduled_sparsity(self, n: int) -> float:
         """cubic ramp evaluated in Python doubles, stored as fp32 (reference sparse.py:252-257)."""

@@ -11,12 +11,14 @@ import torch.nn as nn
 
 from qsparse_amd import _hip
 
-_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True}
+_options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
+             "elide_pruned": "forward"}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
-                preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None):
+                preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
+                elide_pruned: Optional[str] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
@@ -26,7 +28,17 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     instead of the reference's float32 promotion: the value is the float32 result rounded once, i.e. exactly
     what a following autocast convolution would consume, at 4 instead of 6 B/elem and without the cast pass;
     ``fold_relu`` (default True, bit-identical) lets a convert-built ``ReLU -> prune -> quantize`` site apply the
-    ReLU inside the fused kernels instead of materialising its output."""
+    ReLU inside the fused kernels instead of materialising its output;
+    ``elide_pruned`` (extension): mask-aware traffic elision in the GPU kernels that carry a channel mask.  A pruned
+    channel's input only ever meets ``* 0``, so it need not be loaded: ``"forward"`` (default) elides in the fused
+    prune->quantize forward, bit-identical for every finite input; ``"all"`` also in the backward and mask-apply
+    kernels, which then write ``+0.0`` where the reference's ``g * 0`` / ``x * 0`` has ``-0.0`` (numerically equal);
+    ``"off"`` loads everything (a NaN / Inf on a pruned channel then behaves exactly as in the reference)."""
+    if elide_pruned is not None:
+        if elide_pruned not in ("off", "forward", "all"):
+            raise ValueError(f"elide_pruned must be 'off', 'forward' or 'all', got {elide_pruned!r}")
+        _hip.elide_mode = elide_pruned
+        _options_["elide_pruned"] = elide_pruned
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
                      ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu)):
@@ -191,6 +203,7 @@ def calculate_mask_given_importance(importance: torch.Tensor, sparsity: float) -
 def preload_qsparse_state_dict(model: nn.Module, state_dict: Dict[str, torch.Tensor]) -> nn.Module:
     """install checkpoint tensors into the (shape-less until first forward) parameters of every
     Prune/Quantize layer so that a following ``load_state_dict`` succeeds (reference util.py:120-145)."""
+    from qsparse_amd.common import STATE_KEYS, state_parameter
     from qsparse_amd.quantize import QuantizeLayer
     from qsparse_amd.sparse import PruneLayer
 
@@ -203,7 +216,8 @@ def preload_qsparse_state_dict(model: nn.Module, state_dict: Dict[str, torch.Ten
             for key, value in state_dict.items():
                 leaf = key[len(prefix):]
                 if key.startswith(prefix) and "." not in leaf:
-                    sub._parameters[leaf] = nn.Parameter(value.to(device), requires_grad=False)
+                    make = state_parameter if leaf in STATE_KEYS else (lambda t: nn.Parameter(t, requires_grad=False))
+                    sub._parameters[leaf] = make(value.to(device))
     return model
 
 

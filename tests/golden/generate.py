@@ -22,6 +22,8 @@ Reference entry points exercised (file:line in /root/reference):
   F8 convert() module trees                    qsparse/convert.py:21-245
   F9 state_dict schema + preload               qsparse/util.py:120-145
   F10 prune->quantize pair trajectory (the headline pair, small shape)
+  F13 UniformPruningCallback trajectories      qsparse/sparse.py:125-152 (numpy global RNG, seeded per case)
+  F14 counters written through ``.data``       qsparse/quantize.py:495, qsparse/sparse.py:251-269,104-118
 """
 import io
 import json
@@ -42,7 +44,7 @@ import qsparse  # the real reference
 from qsparse import convert, prune, quantize
 from qsparse.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer,
                               quantize_with_decimal, quantize_with_line, quantize_with_scaler)
-from qsparse.sparse import MagnitudePruningCallback, devise_layerwise_pruning_schedule
+from qsparse.sparse import MagnitudePruningCallback, UniformPruningCallback, devise_layerwise_pruning_schedule
 from qsparse.util import (calculate_mask_given_importance, preload_qsparse_state_dict,
                           squeeze_tensor_to_shape)
 
@@ -621,6 +623,168 @@ def f12():
     save("f12_api_surface", {}, dict(cases=[dict(api=api, methods=methods, version=qsparse.__version__)]))
 
 
+# --------------------------------------------------------------------------------------------
+# F13: UniformPruningCallback.  The reference draws from numpy's GLOBAL RNG (sparse.py:148-150), so a case is pinned by
+# seeding it right before the trajectory; a replay seeds it with the same value and must reproduce every mask.
+# --------------------------------------------------------------------------------------------
+def f13():
+    store, cases = {}, []
+    idx = 0
+    specs = [
+        dict(shape=(3, 10, 4, 4), dims=[1, 2, 3], sparsity=0.5, start=2, interval=2, repetition=3, rampup=False,
+             cb=dict(), dtype="float32", steps=11, seed=1301),
+        dict(shape=(3, 10, 4, 4), dims=[0, 1, 2, 3], sparsity=0.7, start=1, interval=3, repetition=2, rampup=True,
+             cb=dict(mask_refresh_interval=2), dtype="bfloat16", steps=12, seed=1302),
+        dict(shape=(4, 24), dims=[1], sparsity=0.75, start=1, interval=1, repetition=4, rampup=False,
+             cb=dict(), dtype="float32", steps=8, seed=1303),
+        dict(shape=(2, 6, 5, 5), dims=[1, 2, 3], sparsity=0.6, start=2, interval=2, repetition=2, rampup=False,
+             cb=dict(mask_refresh_interval=3, stop_mask_refresh=6), dtype="float32", steps=10, seed=1304),
+    ]
+    for sp in specs:
+        dt = getattr(torch, sp["dtype"])
+        with quiet():
+            layer = prune(sparsity=sp["sparsity"], dimensions=set(sp["dims"]), start=sp["start"], interval=sp["interval"],
+                          repetition=sp["repetition"], rampup=sp["rampup"], callback=UniformPruningCallback(**sp["cb"]))
+        layer.train()
+        k = f"c{idx}_"
+        np.random.seed(sp["seed"])
+        for s in range(sp["steps"] + 2):
+            if s == sp["steps"]:
+                layer.eval()
+            x = torch.randn(sp["shape"], generator=gen(13000 + 31 * idx + s)).to(dt).requires_grad_(True)
+            gout = torch.randn(sp["shape"], generator=gen(14000 + 31 * idx + s)).to(dt)
+            with quiet():
+                y = layer(x)
+            y.backward(gout)
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_gout", gout)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_gx", x.grad)
+            put(store, k + f"s{s}_mask", layer.mask)
+            put(store, k + f"s{s}_n_updates", layer._n_updates)
+            put(store, k + f"s{s}_cur_sparsity", layer._cur_sparsity)
+            put(store, k + f"s{s}_t", layer.callback.t)
+        cases.append(dict(id=idx, **{**sp, "shape": list(sp["shape"])}, total_steps=sp["steps"] + 2))
+        idx += 1
+
+    # weight side: prune(Conv2d) with unstructured uniform masks
+    torch.manual_seed(13)
+    conv = nn.Conv2d(6, 8, 3)
+    w0 = conv.weight.detach().clone()
+    with quiet():
+        pconv = prune(conv, sparsity=0.6, dimensions={0, 1, 2, 3}, start=1, interval=2, repetition=3,
+                      callback=UniformPruningCallback())
+    pconv.train()
+    k = f"c{idx}_"
+    put(store, k + "w0", w0)
+    put(store, k + "b0", conv.bias)
+    x = torch.rand((2, 6, 8, 8), generator=gen(1377))
+    put(store, k + "x", x)
+    np.random.seed(1305)
+    steps = 9
+    for s in range(steps):
+        with quiet():
+            y = pconv(x)
+        put(store, k + f"s{s}_y", y)
+        put(store, k + f"s{s}_mask", pconv.prune.mask)
+    cases.append(dict(id=idx, kind="conv_weight", dims=[0, 1, 2, 3], steps=steps, sparsity=0.6, start=1, interval=2,
+                      repetition=3, seed=1305))
+    save("f13_uniform_prune", store, dict(cases=cases))
+
+
+# --------------------------------------------------------------------------------------------
+# F14: step counters written from outside through ``.data`` (the reference's own idiom, sparse.py:106) between
+# forwards.  The reference re-reads every counter with .item() on each forward, so the write decides the very next
+# step: fast-forwarding a quantizer past its timeout, rewinding it, moving a pruning schedule, restarting callback.t.
+# --------------------------------------------------------------------------------------------
+def f14():
+    store, cases = {}, []
+    idx = 0
+
+    def record(k, s, layer, x, gout, y, extra=()):
+        put(store, k + f"s{s}_x", x)
+        put(store, k + f"s{s}_gout", gout)
+        put(store, k + f"s{s}_y", y)
+        put(store, k + f"s{s}_gx", x.grad)
+        for name, t in extra:
+            put(store, k + f"s{s}_{name}", t)
+
+    # quantizers: (step, value) writes to _n_updates.data
+    qspecs = [
+        dict(kind="scaler", bits=8, channelwise=-1, timeout=3, shape=(4, 6, 5, 5), dtype="float32", steps=9,
+             writes={2: 10, 5: 0, 7: 3}),
+        dict(kind="scaler", bits=4, channelwise=-1, timeout=4, shape=(4, 6, 5, 5), dtype="bfloat16", steps=8,
+             writes={1: 100, 4: 2}),
+        dict(kind="decimal", bits=6, channelwise=-1, timeout=2, shape=(3, 8), dtype="float32", steps=7,
+             writes={1: 2, 3: 1}),
+    ]
+    for sp in qspecs:
+        dt = getattr(torch, sp["dtype"])
+        cb = ScalerQuantizer() if sp["kind"] == "scaler" else DecimalQuantizer()
+        with quiet():
+            layer = quantize(bits=sp["bits"], channelwise=sp["channelwise"], timeout=sp["timeout"], callback=cb)
+        layer.train()
+        k = f"c{idx}_"
+        for s in range(sp["steps"] + 1):
+            if s == sp["steps"]:
+                layer.eval()
+            if s in sp["writes"]:
+                if not layer.initted:     # the parameter exists only after the first forward
+                    raise RuntimeError("write before first forward")
+                layer._n_updates.data[:] = sp["writes"][s]
+            x = (torch.randn(sp["shape"], generator=gen(15000 + 31 * idx + s)) * 3).to(dt).requires_grad_(True)
+            gout = torch.randn(sp["shape"], generator=gen(16000 + 31 * idx + s))
+            with quiet():
+                y = layer(x)
+            gout = gout.to(y.dtype)
+            y.backward(gout)
+            record(k, s, layer, x, gout, y, (("n_updates", layer._n_updates), ("weight", layer.weight)))
+        cases.append(dict(id=idx, op="quantize", **{**sp, "shape": list(sp["shape"]),
+                                                     "writes": {str(a): b for a, b in sp["writes"].items()}},
+                          total_steps=sp["steps"] + 1))
+        idx += 1
+
+    # prune layers: writes to _n_updates.data and callback.t.data
+    pspecs = [
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=4, interval=2, repetition=2, dtype="float32", steps=12,
+             writes={2: ("n", 4), 6: ("t", 0), 8: ("n", 6), 10: ("n", 0)}),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.75, start=2, interval=3, repetition=2, dtype="bfloat16", steps=11,
+             writes={1: ("n", 5), 5: ("t", 7), 7: ("n", 2)}),
+    ]
+    for sp in pspecs:
+        dt = getattr(torch, sp["dtype"])
+        with quiet():
+            layer = prune(sparsity=sp["sparsity"], dimensions=set(sp["dims"]), start=sp["start"], interval=sp["interval"],
+                          repetition=sp["repetition"], callback=MagnitudePruningCallback())
+        layer.train()
+        k = f"c{idx}_"
+        scale = torch.linspace(0.25, 4, sp["shape"][1]).view(1, -1, 1, 1)
+        for s in range(sp["steps"] + 1):
+            if s == sp["steps"]:
+                layer.eval()
+            if s in sp["writes"]:
+                which, v = sp["writes"][s]
+                if which == "n":
+                    layer._n_updates.data[:] = v
+                else:
+                    layer.callback.t.data[:] = v
+            x = (torch.randn(sp["shape"], generator=gen(17000 + 31 * idx + s)) * scale).to(dt).requires_grad_(True)
+            gout = torch.randn(sp["shape"], generator=gen(18000 + 31 * idx + s)).to(dt)
+            with quiet():
+                y = layer(x)
+            y.backward(gout)
+            extra = [("mask", layer.mask), ("n_updates", layer._n_updates), ("cur_sparsity", layer._cur_sparsity),
+                     ("t", layer.callback.t)]
+            if hasattr(layer.callback, "magnitude"):
+                extra.append(("magnitude", layer.callback.magnitude))
+            record(k, s, layer, x, gout, y, extra)
+        cases.append(dict(id=idx, op="prune", **{**sp, "shape": list(sp["shape"]),
+                                                  "writes": {str(a): list(b) for a, b in sp["writes"].items()}},
+                          total_steps=sp["steps"] + 1))
+        idx += 1
+    save("f14_state_writes", store, dict(cases=cases))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     f1_f2()
@@ -633,3 +797,5 @@ if __name__ == "__main__":
     f10()
     f11()
     f12()
+    f13()
+    f14()

@@ -42,7 +42,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 6
+    assert lib.qs_version() == 7
     assert torch.cuda.is_available()
 
 
@@ -74,6 +74,16 @@ def test_golden_f7_prune_layer():
 @pytest.mark.parametrize("fused", [False, True])
 def test_golden_f10_pair(fused):
     H.run_f10(DEV, fused)
+
+
+def test_golden_f13_uniform_pruning_callback():
+    H.run_f13(DEV)
+
+
+def test_golden_f14_counters_written_through_data():
+    """`.data` writes to GPU-resident counters are seen by the next forward without a per-step sync"""
+    H.run_f14(DEV)
+    H.run_data_write_fast_forward(DEV)
 
 
 # ---- (2) oracle parity on seeded inputs -----------------------------------------------------------
@@ -326,9 +336,9 @@ def test_abi_rejects_bad_arguments_loudly():
         quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
     lib = _hip.load()
     y = torch.empty(64, device=DEV)
-    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, None)
+    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None)
     assert st == -3 and b"aligned" in lib.qs_status_string(st)
-    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, 0, None) == -1
     # odd storage offsets are re-packed by the binding instead of failing
     base = torch.randn(1001, device=DEV)
     assert same(quantize_with_scaler(base[1:], 8, 0.1).cpu(), O.scaler_fwd(base[1:].cpu(), 8, 0.1))
@@ -468,9 +478,9 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
-                                       1, 0, 0, 0, 0, 0, 0, stream) == 0
+                                       1, 0, 0, 0, 0, 0, 0, 1, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
-                                    N, C, H * W, 0, 1, stream) == 0
+                                    N, C, H * W, 0, 1, 0, stream) == 0
 
     sequence(None)
     torch.cuda.synchronize()

@@ -24,6 +24,8 @@ from qsparse_amd import _hip
 
 SHAPE = (256, 256, 56, 56)
 PEAK = 8000.0
+ELIDE_FWD = int(os.environ.get("QS_TUNE_ELIDE_FWD", "1"))   # mask-aware elision in the forward (library default)
+ELIDE_BWD = int(os.environ.get("QS_TUNE_ELIDE_BWD", "0"))
 
 
 def time_ms(fn, iters=20, warm=3):
@@ -63,11 +65,11 @@ def run_variant(path):
 
     def fwd():
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C,
-                                       H * W, 1, 0, 0, 0, 0, 0, 0, None) == 0
+                                       H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE_FWD, None) == 0
 
     def bwd():
         assert lib.qs_quant_ste_bwd(gout.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0,
-                                    mask.data_ptr(), N, C, H * W, 0, 1, None) == 0
+                                    mask.data_ptr(), N, C, H * W, 0, 1, ELIDE_BWD, None) == 0
 
     def stats():
         assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C,
