@@ -11,11 +11,18 @@ One "step" = one pass of the hot path over one batch of synthetic input, everyth
     select  (C-sized)           running magnitude, k-th value, mask, scale
     apply   (read x, write y)   y = dequant(round(x*mask / s))         bf16 -> fp32
     bwd     (read g, write gx)  gx = clamp(g) * mask                    fp32 -> bf16
-Algorithmic bytes: 14 B/elem for the step (2 + 6 + 6), 6 B/elem for each apply kernel.
-Rank 0 prints ONE JSON line.  With N > 1 every rank processes its own batch shard (weak scaling) and
-the C-sized statistics are all-reduced over RCCL each step (qsparse_amd/distributed.py).
+Algorithmic bytes: 14 B/elem for the dense step (2 + 6 + 6), 6 B/elem for each apply kernel.  The
+library's default (`elide_pruned="forward"`, bit-identical for finite inputs) does not load the x of pruned channels
+in the apply forward, so its forward moves (2 * kept + 4) B/elem: every byte count below is the mask-aware one for the
+mode that ran, and `config.variants` carries the dense step ("off") and the fully elided one ("all") next to it.
+
+Rank 0 prints ONE JSON line.  With N > 1 every rank processes its own batch shard (weak scaling) and the C-sized
+statistics are exchanged over RCCL each step (qsparse_amd/distributed.py).  At N == 1 the line also carries
+`configs`: BASELINE.json's configs 2-4 (the 8-bit quantizer alone on 256x64x56x56; ResNet-18 CIFAR shape and ResNet-50
+ImageNet shape, plain vs converted, eager and hipGraph replay) measured in the same process.
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -27,9 +34,11 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+import torch.nn.functional as F
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
 SHAPE = (256, 256, 56, 56)
+SHAPE2 = (256, 64, 56, 56)   # BASELINE config 2
 
 
 def make_input(shape, device, seed=0):
@@ -71,6 +80,10 @@ def make_pair(device):
     return fuse_prune_quantize_pairs(pair)
 
 
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (test infrastructure) timed on the host cores -- reported next to the GPU number, never
+# part of it
+# ---------------------------------------------------------------------------------------------------
 def _cpu_steps(batch, reps, threads):
     from oracle import qs_oracle as O
 
@@ -94,24 +107,189 @@ def _cpu_steps(batch, reps, threads):
 
 def cpu_baseline(batch=64, reps=8, threads=None):
     """the oracle (a port of the reference's ATen op chain) timed on this host's cores on a bounded sample of the
-    same workload: the same tensor restricted to `batch` samples (about 10 s of CPU work in total), with the
-    best thread count found on the GPU box's EPYC (32; 8/16/64/128 threads were slower) and with one thread."""
+    same workload: the same tensor restricted to `batch` samples (a SLICE of the headline tensor, about 10 s of CPU
+    work in total), with the best thread count found on the GPU box's EPYC (32; 8/16/64/128 threads were slower) and
+    with one thread."""
     cores = threads or int(os.environ.get("QS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
     multi = _cpu_steps(batch, reps, cores)
     single = _cpu_steps(max(batch // 2, 1), 2, 1)
     return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
             "value_1thread": round(single, 4),
-            "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on "
-                      f"{batch}x256x56x56 bf16, best of {reps} ({cores} threads); {max(batch // 2, 1)}x256x56x56, best of 2 "
-                      f"(1 thread); torch {torch.__version__} CPU"}
+            "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on a "
+                      f"{batch}x256x56x56 bf16 slice of the headline tensor, best of {reps} ({cores} threads); "
+                      f"{max(batch // 2, 1)}x256x56x56, best of 2 (1 thread); torch {torch.__version__} CPU"}
 
 
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 2-4 (N == 1 only)
+# ---------------------------------------------------------------------------------------------------
+def _timed_loop(fn, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def config2(device, steps=200, nbuf=4):
+    """BASELINE config 2: QuantizeLayer(bits=8, tensor-wise) alone, training step (abs-max + running scale + apply
+    forward + STE backward = 14 B/elem) on 256x64x56x56 bf16, `nbuf` rotating buffer sets (4 x 103 MB of inputs + 4 x 206 MB
+    of gradients: the 256 MiB Infinity Cache cannot hold a working set across steps), eager and as hipGraph replay (what the kernels alone take)."""
+    import qsparse_amd as qs
+
+    q = qs.quantize(bits=8, channelwise=-1, timeout=1).to(device).train()
+    xs, gs = [], []
+    for k in range(nbuf):
+        x, g = make_input(SHAPE2, device, seed=100 + k)
+        xs.append(x.requires_grad_(True))
+        gs.append(g)
+
+    def step(i):
+        k = i % nbuf
+        return torch.autograd.grad(q(xs[k]), xs[k], gs[k])
+
+    for i in range(12):
+        step(i)
+    eager = _timed_loop(step, steps)
+    qs.set_qsparse_options(graph_safe=True)
+    try:
+        for i in range(4):
+            step(i)
+        gr = torch.cuda.CUDAGraph()      # ONE graph of nbuf steps: a hipGraphLaunch costs more than a 3-kernel step
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gr):
+            for k in range(nbuf):
+                step(k)
+        gr.replay()
+        graphed = _timed_loop(lambda i: gr.replay(), max(steps // nbuf, 1)) / nbuf
+    finally:
+        qs.set_qsparse_options(graph_safe=False)
+        qs.resync_host_state(q)
+    n = xs[0].numel()
+
+    def rec(ms):
+        return {"ms_per_step": round(ms, 4), "Gelem/s": round(n / ms / 1e6, 1),
+                "frac_of_hbm_peak": round(14 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    return {"workload": "QuantizeLayer(bits=8, tensor-wise) train fwd+bwd, 256x64x56x56 bf16 in / fp32 out, 14 B/elem",
+            "rotating_buffers": nbuf, "steps": steps, "eager": rec(eager), "graph_replay": rec(graphed)}
+
+
+def resnet_config(arch, batch, device, steps):
+    """BASELINE configs 3 / 4: full-width ResNet-18 (CIFAR shape, 50 % channel pruning) / ResNet-50 (ImageNet shape,
+    75 %), 4-bit weights and activations, bf16 autocast, channels_last (MIOpen's native layout), SGD with momentum,
+    synthetic data: ms per training step of the plain network and of the network converted with the reference's --pq
+    recipe, eager and as whole-step hipGraph replay, plus the time the library's own kernels take inside a step."""
+    import qsparse_amd as qs
+    from examples.models import convert_pq, resnet18, resnet50
+    from qsparse_amd import _hip, graphs
+
+    if arch == "resnet18":
+        make, shape, classes, sparsity = (lambda: resnet18(10, True)), (batch, 3, 32, 32), 10, 0.5
+    else:
+        make, shape, classes, sparsity = (lambda: resnet50(1000, False)), (batch, 3, 224, 224), 1000, 0.75
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(shape, generator=g, device=device).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, classes, (batch,), generator=g, device=device)
+    out = {"model": arch, "input_shape": list(shape), "dtype": "bf16 autocast, fp32 master weights", "layout": "channels_last",
+           "optimizer": "SGD momentum 0.9", "steps": steps}
+
+    def build(pq):
+        torch.manual_seed(0)
+        model = make()
+        if pq:
+            model = convert_pq(model, sparsity=sparsity, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+        model = model.to(device).to(memory_format=torch.channels_last).train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+
+        def step(_=0):
+            opt.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.cross_entropy(model(x).float(), y)
+            loss.backward()
+            opt.step()
+
+        return model, step
+
+    def capture(step):
+        gr = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gr):
+            step()
+        gr.replay()
+        return gr
+
+    # plain network
+    model, step = build(False)
+    for _ in range(6):
+        step()
+    out["plain_ms"] = round(_timed_loop(step, steps), 3)
+    gr = capture(step)
+    out["plain_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
+    del model, step, gr
+    torch.cuda.empty_cache()
+
+    # converted network (the --pq recipe), schedules finished after 3 steps
+    qs.set_qsparse_options(graph_safe=True)
+    try:
+        model, step = build(True)
+        for _ in range(8):
+            step()
+        out["pq_ms"] = round(_timed_loop(step, steps), 3)
+        _hip.start_event_log(only=None)        # one step with a HIP event pair around every launch of the library
+        step()
+        per = _hip.stop_event_log()
+        lib_ms = sum(sum(v) for v in per.values())
+        out["library_kernels"] = {"ms_per_step": round(lib_ms, 3), "launches": sum(len(v) for v in per.values()),
+                                  "by_kernel_ms": {k: round(sum(v), 3) for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))}}
+        assert graphs.steady_state(model), "converted network did not reach its steady state"
+        gr = capture(step)
+        out["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
+        out["library_share_of_pq_graph_step"] = round(lib_ms / out["pq_graph_ms"], 4)
+        out["pq_over_plain"] = {"eager": round(out["pq_ms"] / out["plain_ms"], 4),
+                                "graph": round(out["pq_graph_ms"] / out["plain_graph_ms"], 4)}
+        masks = [m.mask.float().mean().item() for m in model.modules() if isinstance(m, qs.sparse.PruneLayer)]
+        out["mean_kept_channel_fraction"] = round(sum(masks) / max(len(masks), 1), 4)
+        del model, step, gr
+    finally:
+        qs.set_qsparse_options(graph_safe=False)
+        torch.cuda.empty_cache()
+    return out
+
+
+def extra_configs(device, only=None):
+    """configs 2-4 of BASELINE.json; a failure in one of them is recorded, it never costs the headline line"""
+    out = {}
+    for name, fn in (("config2_quantize8_256x64x56x56", lambda: config2(device)),
+                     ("config3_resnet18_cifar_b128", lambda: resnet_config("resnet18", 128, device, 10)),
+                     ("config4_resnet50_imagenet_b256", lambda: resnet_config("resnet50", 256, device, 5))):
+        if only and not any(name.startswith(o) for o in only):
+            continue
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            torch.cuda.empty_cache()
+        out[name]["bench_seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-4 (they run at N == 1 only)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the other elision modes after the timed region")
+    ap.add_argument("--configs-only", default=None, metavar="NAMES",
+                    help="run only these BASELINE configs (comma-separated prefixes, e.g. config2,config4) and print "
+                         "{'configs': ...}: the command the per-config profiles under profiles/ are taken with")
+    ap.add_argument("--elide", default=None, choices=["off", "forward", "all"],
+                    help="headline mode (default: the library's default, 'forward')")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS",
                     help="only time the CPU oracle with this many threads (no GPU needed)")
     args = ap.parse_args()
@@ -154,9 +332,20 @@ def main():
             qs.set_qsparse_options(sync_statistics="always")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
+    import qsparse_amd as qs
     from qsparse_amd import _hip
 
     _hip.load()
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    if args.configs_only:
+        assert world == 1, "--configs-only is a single-GPU mode"
+        rec = {"configs": extra_configs(device, only=args.configs_only.split(","))}
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        os.close(real_stdout)
+        return
+    if args.elide:
+        qs.set_qsparse_options(elide_pruned=args.elide)
+    mode = qs.get_qsparse_option("elide_pruned")
     x, gout = make_input(SHAPE, device, seed=rank)
     x.requires_grad_(True)
     pair = make_pair(device)
@@ -202,49 +391,88 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # the other two elision modes, outside the timed region, on rank 0's clock (continuity with round 1: "off" is the
+    # dense 14 B/elem step; "all" also elides the backward, which then writes +0.0 for the reference's -0.0)
+    variants = {}
+    if world == 1 and not args.no_variants:
+        for other in ("off", "forward", "all"):
+            if other == mode:
+                continue
+            qs.set_qsparse_options(elide_pruned=other)
+            for _ in range(5):
+                step()
+            k = max(min(args.steps // 2, 60), 1)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            variants[other] = (time.perf_counter() - tv) / k * 1e3
+        qs.set_qsparse_options(elide_pruned=mode)
+
     numel = x.numel()
     if rank == 0:
+        kept = pair[0][1].mask.float().mean().item()
+        fwd_bpe = {"off": 6.0}.get(mode, 2.0 * kept + 4.0)        # apply forward: bf16 in (kept rows only), fp32 out
+        bwd_bpe = 4.0 * kept + 2.0 if mode == "all" else 6.0       # apply backward: fp32 in, bf16 out
+        step_bpe = 2.0 + fwd_bpe + bwd_bpe
         ms_step = elapsed / args.steps * 1e3
         value = world * numel * args.steps / elapsed / 1e9
         avg = {k: sum(v) / len(v) for k, v in events.items() if v}
-        fwd_ms = avg.get("quant_scaler_fwd+mask")
-        bwd_ms = avg.get("quant_ste_bwd+mask")
-        stats_ms = avg.get("mean_dim+absmax")
-        # dominant kernel: the fused apply forward (bf16 in, fp32 out: 6 B/elem); backward is its mirror image
-        dom_name, dom_ms = ("quant_scaler_fwd+mask", fwd_ms) if (fwd_ms or 0) >= (bwd_ms or 0) else ("quant_ste_bwd+mask", bwd_ms)
-        achieved = 6 * numel / (dom_ms * 1e-3) / 1e9 if dom_ms else None
-        traffic, traffic_src = pmc_traffic("apply_fwd" if dom_name.startswith("quant_scaler_fwd") else "apply_bwd")
         kern = {}
-        for name, ms, bpe in (("apply_fwd", fwd_ms, 6), ("apply_bwd", bwd_ms, 6), ("stats", stats_ms, 2)):
+        for name, key, bpe in (("apply_fwd", "quant_scaler_fwd+mask", fwd_bpe), ("apply_bwd", "quant_ste_bwd+mask", bwd_bpe),
+                               ("stats", "mean_dim+absmax", 2.0)):
+            ms = avg.get(key)
             if ms:
-                kern[name] = {"ms": round(ms, 4), "GB/s": round(bpe * numel / ms / 1e6, 1),
+                kern[name] = {"ms": round(ms, 4), "bytes_per_elem": round(bpe, 4), "GB/s": round(bpe * numel / ms / 1e6, 1),
                               "frac": round(bpe * numel / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        # dominant kernel: the longest-running one
+        dom_name = max((k for k in ("apply_fwd", "apply_bwd") if k in kern), key=lambda k: kern[k]["ms"], default=None)
+        roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None}
+        if dom_name:
+            traffic, traffic_src = pmc_traffic(dom_name)
+            roof.update({"kernel": {"apply_fwd": "quant_scaler_fwd+mask", "apply_bwd": "quant_ste_bwd+mask"}[dom_name],
+                         "achieved": kern[dom_name]["GB/s"], "frac": kern[dom_name]["frac"], "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(round(kern[dom_name]["bytes_per_elem"] * numel)),
+                         "kernels": kern})
         out = {
-            "metric": "Gelem/s quantize+prune fwd+bwd, 256\u00d7256\u00d756\u00d756 bf16; % HBM roofline",   # BASELINE.json's string
+            "metric": "Gelem/s quantize+prune fwd+bwd, 256×256×56×56 bf16; % HBM roofline",   # BASELINE.json's string
             "value": round(value, 3), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "prune(0.75,dims={1})->quantize(4-bit,tensor-wise) train fwd+bwd, live mask+scale "
                                    "statistics every step, 256x256x56x56 bf16 in / fp32 out / fp32 grad in / bf16 grad out "
-                                   "per GPU (SURVEY 8d scope ii, 14 B/elem)",
-                       "shape_per_gpu": list(SHAPE), "fused": True,
-                       "step_frac_of_hbm_peak": round(14 * numel / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1) if achieved else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": 6 * numel, "kernels": kern},
+                                   "per GPU (SURVEY 8d scope ii)",
+                       "shape_per_gpu": list(SHAPE), "fused": True, "elide_pruned": mode,
+                       "kept_channel_fraction": round(kept, 4),
+                       "algorithmic_bytes_per_elem": {"step": round(step_bpe, 4), "stats": 2.0, "apply_fwd": round(fwd_bpe, 4),
+                                                      "apply_bwd": round(bwd_bpe, 4), "dense_step": 14.0},
+                       "step_frac_of_hbm_peak": round(step_bpe * numel / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roof,
         }
+        if variants:
+            out["config"]["variants"] = {
+                m: {"ms_per_step": round(ms, 4), "Gelem/s": round(numel / ms / 1e6, 1),
+                    "note": {"off": "dense: every element loaded, 14 B/elem (round-1 record)",
+                             "forward": "apply forward skips pruned channels; bit-identical for finite inputs (library default)",
+                             "all": "backward elided as well: +0.0 where the reference has -0.0 (opt-in)"}[m]}
+                for m, ms in variants.items()}
         if world > 1 or force_exchange:
             out["config"]["exchange"] = ("one all-gather of a 2C-float record per step over " +
                                          ("gloo (shared GPU, development)" if share_gpu else "RCCL") +
                                          (" in a ONE-rank group (QS_BENCH_FORCE_EXCHANGE)" if force_exchange else ""))
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
     if world > 1 or force_exchange:
         torch.cuda.synchronize()
         dist.destroy_process_group()
     if rank == 0:
+        if world == 1 and not force_exchange and not args.no_configs:
+            del pair, x, gout
+            torch.cuda.empty_cache()
+            out["configs"] = extra_configs(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
 

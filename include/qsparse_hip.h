@@ -124,10 +124,14 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
  * accumulate != 0: out is max-accumulated instead of overwritten (the caller keeps it zeroed between steps, e.g.
  * through qs_scale_update's clear_absmax), which saves the initialisation launch.
  * pre_relu != 0: the statistic of max(x, 0) -- a preceding nn.ReLU folded into the quantizer's kernels.
+ * out_lines (1 unless per_channel == 0 and accumulate != 0): the tensor-wise maximum is accumulated into `out_lines`
+ * partial accumulators, QS_AMAX_LINE_STRIDE floats (one 128-byte line) apart, out[l * QS_AMAX_LINE_STRIDE]; their
+ * maximum is the result (qs_scale_update folds them).  Same-address atomics serialise on MI355X (~12 ns each), which
+ * caps a one-word reduction at ~256 workgroups; 16 lines lift that cap.
  * ws (nullable): qs_workspace_bytes(QS_WS_REDUCE, C*inner) bytes of scratch; with it a per-channel reduction over few
  * columns and many rows (channels_last activations: inner == 1, C <= 512) runs as two atomics-free stages; 0 bytes means the shape never takes that route. */
 int qs_absmax(const void* x, float* out, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, int pre_relu,
+              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, int pre_relu, int out_lines,
               void* ws, size_t ws_bytes, qs_stream_t stream);
 
 /* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
@@ -147,9 +151,10 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
  * dtype of the tensor the abs-max was taken from: the reference divides in that dtype, which matters for fp16,
  * where small maxima underflow into subnormals (quantize.py:340,344-348).  clear_absmax != 0 zeroes absmax[i]
  * after use; bump_i32 (nullable) is a one-element device counter incremented once (QuantizeLayer._n_updates,
- * quantize.py:515). */
-int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev, int bits,
-                    int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream);
+ * quantize.py:515).  absmax_lines > 1 (n == 1 only): the tensor-wise abs-max arrives as that many partial accumulators
+ * QS_AMAX_LINE_STRIDE floats apart (qs_absmax with out_lines); their maximum is used and all of them are cleared. */
+int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, int64_t t, int64_t* t_dev,
+                    int advance_t_dev, int bits, int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream);
 
 /* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
  * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */

@@ -40,9 +40,9 @@ SIGNATURES = {
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
-    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _P, c_size_t, _P]),
+    "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P, c_size_t, _P]),
-    "qs_scale_update": (c_int, [_P, _P, _L, _L, _P, _I, _I, _I, _P, _I, _P]),
+    "qs_scale_update": (c_int, [_P, _I, _P, _L, _L, _P, _I, _I, _I, _P, _I, _P]),
     "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _I, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _L, _P]),
@@ -291,8 +291,9 @@ def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_inde
     y = torch.empty_like(like, dtype=torch.float32)
     if numel == 0:
         return y
-    st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C, inner,
-                               dt(x), F32, _stream(x))
+    with _timed("quant_line_fwd"):
+        st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C, inner,
+                                   dt(x), F32, _stream(x))
     _check(st, "qs_quant_line_fwd")
     return y
 
@@ -364,21 +365,37 @@ def _reduce_workspace(x: torch.Tensor, channel_index: int, outer: int, C: int, i
     return torch.empty(nbytes, dtype=torch.uint8, device=x.device), nbytes
 
 
+TENSOR_AMAX_LINES = 16   # partial accumulators of a tensor-wise abs-max, one 128-byte line each
+
+
+def tensor_amax_accumulator(device) -> torch.Tensor:
+    """zeroed accumulator of a tensor-wise abs-max: [16, 32] floats, partial maxima in [:, 0] (qs_absmax out_lines);
+    qs_scale_update folds and re-zeroes it."""
+    return torch.zeros(TENSOR_AMAX_LINES, AMAX_LINE_STRIDE, dtype=torch.float32, device=device)
+
+
 def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.Tensor] = None,
            pre_relu: bool = False) -> torch.Tensor:
     """max|x| per channel / over the tensor.  `accumulate_into`: zeroed persistent fp32 buffer that is
-    max-accumulated instead of allocating + initialising a fresh one (one launch instead of two).
+    max-accumulated instead of allocating + initialising a fresh one (one launch instead of two); for a tensor-wise
+    maximum it may be a `tensor_amax_accumulator` ([lines, 32]: partial maxima, see there).
     `pre_relu`: the statistic of max(x, 0) (folded nn.ReLU)."""
     lib = load()
     x, channel_index, _ = mem_view(x, channel_index)
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
     out = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x.device)
-    assert out.numel() == n and out.dtype == torch.float32
+    lines = 1
+    if channel_index < 0 and out.dim() == 2:
+        assert out.shape[1] == AMAX_LINE_STRIDE and out.is_contiguous() and accumulate_into is not None
+        lines = out.shape[0]
+    else:
+        assert out.numel() == n
+    assert out.dtype == torch.float32
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
     with _timed("absmax"):
         st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
-                           int(accumulate_into is not None), int(bool(pre_relu)), _ptr(ws), ws_bytes, _stream(x))
+                           int(accumulate_into is not None), int(bool(pre_relu)), lines, _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_absmax")
     return out
 
@@ -391,8 +408,9 @@ def minmax(x: torch.Tensor, channel_index: int):
     mn = torch.empty(n, dtype=torch.float32, device=x.device)
     mx = torch.empty(n, dtype=torch.float32, device=x.device)
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
-    st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _ptr(ws), ws_bytes,
-                       _stream(x))
+    with _timed("minmax"):
+        st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _ptr(ws), ws_bytes,
+                           _stream(x))
     _check(st, "qs_minmax")
     return mn, mx
 
@@ -406,7 +424,9 @@ def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int
     `stat_dtype`: dtype of the tensor the abs-max came from (the reference divides in that dtype)."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
     assert bump is None or bump.dtype == torch.int32
-    st = load().qs_scale_update(_ptr(absmax_t), _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(advance_t_dev),
+    lines = absmax_t.shape[0] if (absmax_t.dim() == 2 and weight.numel() == 1) else 1     # tensor_amax_accumulator
+    with _timed("scale_update"):
+        st = load().qs_scale_update(_ptr(absmax_t), lines, _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(advance_t_dev),
                                 int(bits), int(clear_absmax), _ptr(bump), _DT.get(stat_dtype, F32), _stream(weight))
     _check(st, "qs_scale_update")
 
@@ -414,7 +434,8 @@ def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int
 def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int,
                  t_dev: Optional[torch.Tensor] = None, advance_t_dev: bool = False):
     assert lines.dtype == torch.float32 and lines.is_contiguous()
-    st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), int(advance_t_dev),
+    with _timed("lines_update"):
+        st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), int(advance_t_dev),
                                 _stream(lines))
     _check(st, "qs_lines_update")
 
@@ -422,7 +443,8 @@ def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_afte
 def decimal_from_scale(scale: torch.Tensor) -> torch.Tensor:
     s = scale.detach().to(torch.float32).contiguous()
     d = torch.empty_like(s)
-    st = load().qs_decimal_from_scale(_ptr(s), _ptr(d), s.numel(), _stream(s))
+    with _timed("decimal_from_scale"):
+        st = load().qs_decimal_from_scale(_ptr(s), _ptr(d), s.numel(), _stream(s))
     _check(st, "qs_decimal_from_scale")
     return d
 
@@ -495,7 +517,8 @@ def l0_flag(x: torch.Tensor) -> torch.Tensor:
     x = dense(x)
     flag = torch.empty(1, dtype=torch.int32, device=x.device)
     scratch = torch.empty(2, dtype=torch.float32, device=x.device)
-    st = load().qs_l0_flag(_ptr(x), x.numel(), dt(x), _ptr(flag), _ptr(scratch), _stream(x))
+    with _timed("l0_flag"):
+        st = load().qs_l0_flag(_ptr(x), x.numel(), dt(x), _ptr(flag), _ptr(scratch), _stream(x))
     _check(st, "qs_l0_flag")
     return flag
 
@@ -503,7 +526,8 @@ def l0_flag(x: torch.Tensor) -> torch.Tensor:
 def running_mean(state: torch.Tensor, new: torch.Tensor, t: int, t_dev: Optional[torch.Tensor] = None):
     assert state.dtype == torch.float32 and state.is_contiguous() and new.numel() == state.numel()
     new = new.contiguous()
-    st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _ptr(t_dev), _stream(state))
+    with _timed("running_mean"):
+        st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _ptr(t_dev), _stream(state))
     _check(st, "qs_running_mean")
 
 
@@ -517,7 +541,8 @@ def kth_value(imp: torch.Tensor, k: int) -> torch.Tensor:
     thr = torch.empty(1, dtype=torch.float32, device=imp.device)
     nbytes = lib.qs_workspace_bytes(WS_KTH_VALUE, n)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=imp.device)
-    st = lib.qs_kth_value(_ptr(imp), n, int(k), _ptr(thr), _ptr(ws), ws.numel(), _stream(imp))
+    with _timed("kth_value"):
+        st = lib.qs_kth_value(_ptr(imp), n, int(k), _ptr(thr), _ptr(ws), ws.numel(), _stream(imp))
     _check(st, "qs_kth_value")
     return thr
 
@@ -526,7 +551,8 @@ def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
     """out_mask (bool, contiguous, same numel) <- imp >= thr, in place."""
     imp = imp.detach().to(torch.float32).contiguous()
     assert out_mask.dtype == torch.bool and out_mask.is_contiguous() and out_mask.numel() == imp.numel()
-    st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(out_mask), imp.numel(), _stream(imp))
+    with _timed("mask_ge"):
+        st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(out_mask), imp.numel(), _stream(imp))
     _check(st, "qs_mask_ge")
 
 
@@ -586,7 +612,8 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
 
 def stats_pack(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], C: int, device) -> torch.Tensor:
     rec = torch.empty(2 * C, dtype=torch.float32, device=device)
-    st = load().qs_stats_pack(_ptr(stage), dt(stage) if stage is not None else F32, _ptr(chan_absmax),
+    with _timed("stats_pack"):
+        st = load().qs_stats_pack(_ptr(stage), dt(stage) if stage is not None else F32, _ptr(chan_absmax),
                               amax_stride(chan_absmax), C, _ptr(rec), _stream(rec))
     _check(st, "qs_stats_pack")
     return rec
@@ -594,7 +621,8 @@ def stats_pack(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor
 
 def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, absmax_out: Optional[torch.Tensor]):
     stage = torch.empty(C, dtype=torch.float32, device=gathered.device) if want_stage else None
-    st = load().qs_stats_combine(_ptr(gathered), int(world), C, _ptr(stage), _ptr(absmax_out),
+    with _timed("stats_combine"):
+        st = load().qs_stats_combine(_ptr(gathered), int(world), C, _ptr(stage), _ptr(absmax_out),
                                  amax_stride(absmax_out), _stream(gathered))
     _check(st, "qs_stats_combine")
     return stage
@@ -623,16 +651,19 @@ def _device_stream(device):
 
 
 def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
-    st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
+    with _timed("multi_absmax"):
+        st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
     _check(st, "qs_multi_absmax")
 
 
 def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device):
-    st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs,
+    with _timed("multi_scale_update"):
+        st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs,
                                       _device_stream(device))
     _check(st, "qs_multi_scale_update")
 
 
 def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device):
-    st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
+    with _timed("multi_quant_fwd"):
+        st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
     _check(st, "qs_multi_quant_fwd")

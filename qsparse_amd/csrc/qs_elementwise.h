@@ -344,6 +344,58 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 
     for (; g0 < geo.ngroups; g0 += stride * UNROLL) {
         Raw8<XDT> raw[UNROLL];
+        if constexpr (ELIDE && CM == CM_ROW) {
+            // Three phases over the lane's UNROLL groups, so that their latencies overlap instead of adding up (a wave
+            // of an eliding kernel mostly waits: mask look-up -> load or nothing -> store): (A) all mask look-ups,
+            // (B) all loads that are needed, (C) compute + store.  A pruned lane applies the op ONCE to +0.0 and
+            // stores the result eight times.
+            typename Op::P pp[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t g = g0 + u * stride;
+                pp[u] = p_scalar;
+                if (g < geo.ngroups) {
+                    if (geo.groups_per_row >= 64u) {    // rows of >= 512 elements: wave-uniform look-up through the scalar cache
+                        const uint32_t lane = threadIdx.x & 63u;
+                        WaveRows wr;
+                        wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)g - lane), geo.groups_per_row, geo.C, op.mask_ptr());
+                        const bool first = lane < wr.split;
+                        pp[u] = Op::keep_of(op.channel(PARAM_PER_CHANNEL ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
+                    } else {
+                        const uint32_t c = (uint32_t)((uint64_t)g / geo.groups_per_row) % geo.C;
+                        pp[u] = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t g = g0 + u * stride;
+                raw[u] = zero_raw8<XDT>();
+                if (g < geo.ngroups && pp[u].keep != 0.0f) raw[u] = load8_raw<XDT, NT>(x, g);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t g = g0 + u * stride;
+                if (g >= geo.ngroups) break;
+                float v[8];
+                int32_t q[8];
+                if (pp[u].keep == 0.0f) {
+                    const float z = op.apply(0.0f, pp[u], q[0]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = z;
+                        q[j] = q[0];
+                    }
+                } else {
+                    unpack8<XDT>(raw[u], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], pp[u], q[j]);
+                }
+                store8<YDT, NT>(y, g, v);
+                if (codes) store8_i32(codes, g, q);
+            }
+            continue;
+        }
         if constexpr (!ELIDE) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
@@ -362,26 +414,9 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
             } else if constexpr (CM == CM_ROW) {
-                typename Op::P p;
-                if constexpr (ELIDE) {      // mask first; pruned rows are never loaded
-                    if (geo.groups_per_row >= 64u) {    // rows of >= 512 elements: wave-uniform look-up through the scalar cache
-                        const uint32_t lane = threadIdx.x & 63u;
-                        WaveRows wr;
-                        wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)g - lane), geo.groups_per_row, geo.C, op.mask_ptr());
-                        const bool first = lane < wr.split;
-                        p = Op::keep_of(op.channel(PARAM_PER_CHANNEL ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
-                    } else {
-                        const uint32_t c = (uint32_t)((uint64_t)g / geo.groups_per_row) % geo.C;
-                        p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
-                    }
-                    raw[u] = zero_raw8<XDT>();
-                    if (p.keep != 0.0f) raw[u] = load8_raw<XDT, NT>(x, g);
-                    unpack8<XDT>(raw[u], v);
-                } else {
-                    const uint32_t row = (uint32_t)((uint64_t)g / geo.groups_per_row);
-                    const uint32_t c = row % geo.C;
-                    p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
-                }
+                const uint32_t row = (uint32_t)((uint64_t)g / geo.groups_per_row);
+                const uint32_t c = row % geo.C;
+                typename Op::P p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, q[j]);
             } else if constexpr (CM == CM_LAST) {
@@ -807,6 +842,40 @@ struct BcastGeom {
     int64_t sizes[QS_MAX_DIMS];
     int64_t mstrides[QS_MAX_DIMS];
 };
+
+// General broadcast pattern, 8 elements per lane: needs the innermost collapsed extent to be a multiple of 8, so that
+// a lane's 16-byte group stays inside one innermost row; its mask bytes are then either 8 consecutive bytes (mask
+// dense along that dim) or one byte (mask broadcast along it).  The scalar kernel below ran at 13 % of the HBM peak.
+template <int DT, bool NT>
+__global__ __launch_bounds__(kBlock) void mask_bcast_vec_kernel(const void* __restrict__ x, const uint8_t* __restrict__ m,
+                                                                 void* __restrict__ y, int64_t ngroups, BcastGeom geo) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= ngroups) return;
+    const Raw8<DT> raw = load8_raw<DT, NT>(x, g);
+    int64_t rem = g * 8, moff = 0;
+    const int last = geo.ndim - 1;
+    {
+        const int64_t q = rem / geo.sizes[last];
+        moff = (rem - q * geo.sizes[last]) * geo.mstrides[last];
+        rem = q;
+    }
+    for (int d = last - 1; d >= 0; --d) {
+        const int64_t q = rem / geo.sizes[d];
+        moff += (rem - q * geo.sizes[d]) * geo.mstrides[d];
+        rem = q;
+    }
+    float v[8];
+    unpack8<DT>(raw, v);
+    if (geo.mstrides[last] == 0) {
+        const float keep = m[moff] ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * keep;
+    } else {      // stride 1 (a dense innermost run of the mask)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * (m[moff + j] ? 1.0f : 0.0f);
+    }
+    store8<DT, NT>(y, g, v);
+}
 
 template <int DT>
 __global__ __launch_bounds__(kBlock) void mask_bcast_kernel(const void* __restrict__ x, const uint8_t* __restrict__ m,

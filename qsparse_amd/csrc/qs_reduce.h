@@ -40,7 +40,7 @@ struct RedAcc {
 // halves their number at the same number of waves per CU.
 template <int DT, bool MINMAX, int BS>
 __global__ __launch_bounds__(BS) void reduce_all_kernel(const void* __restrict__ x, int64_t numel,
-                                                             uint32_t* out_max, uint32_t* out_min, int relu) {
+                                                             uint32_t* out_max, uint32_t* out_min, int relu, int lines) {
     RedAcc<DT, MINMAX> acc;
     acc.relu = relu;
     const int64_t ngroups = numel / 8;
@@ -81,7 +81,9 @@ __global__ __launch_bounds__(BS) void reduce_all_kernel(const void* __restrict__
             acc.mx = smx[i] > acc.mx ? smx[i] : acc.mx;
             acc.mn = smn[i] < acc.mn ? smn[i] : acc.mn;
         }
-        acc.flush(out_max, out_min, 0);
+        // `lines` accumulators, one 128-byte line each (QS_AMAX_LINE_STRIDE floats apart): same-address atomics serialise
+        // at ~12 ns each, so with one word the last of 256 workgroups waits ~3 us; the consumer (scale_update_kernel) folds
+        acc.flush(out_max, out_min, (uint32_t)(blockIdx.x % (uint32_t)lines) * (uint32_t)QS_AMAX_LINE_STRIDE);
     }
 }
 
@@ -413,13 +415,23 @@ __device__ __forceinline__ float round_to_dtype(float v, int dt) {
     return v;
 }
 __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
-                                    int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt) {
+                                    int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt, int lines) {
     if (t_dev) {
         t = (float)*t_dev;
         tp1 = (float)(*t_dev + 1);
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float nw = round_to_dtype(absmax[i] / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
+        float am = absmax[i];
+        if (lines > 1) {      // n == 1: the tensor-wise abs-max arrives in `lines` partial accumulators (reduce_all_kernel)
+            uint32_t k = __float_as_uint(am);
+            for (int l = 1; l < lines; ++l) {
+                const uint32_t o = __float_as_uint(absmax[(int64_t)l * QS_AMAX_LINE_STRIDE]);
+                k = o > k ? o : k;          // keys of |x|: non-negative floats (and NaN on top) order like their bits
+                if (clear) absmax[(int64_t)l * QS_AMAX_LINE_STRIDE] = 0.0f;
+            }
+            am = __uint_as_float(k);
+        }
+        const float nw = round_to_dtype(am / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
         weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
         if (clear) absmax[i] = 0.0f;
     }

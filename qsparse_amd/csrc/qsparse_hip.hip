@@ -15,7 +15,7 @@
 #define QS_EW_UNROLL 1
 #endif
 #ifndef QS_EW_UNROLL_ELIDE
-#define QS_EW_UNROLL_ELIDE 1   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
+#define QS_EW_UNROLL_ELIDE 2   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
 #endif
 #ifndef QS_EW_NT
 #define QS_EW_NT 1
@@ -40,6 +40,10 @@ inline int max_blocks() {
 }
 inline int reduce_blocks() {
     static int v = env_int("QS_REDUCE_BLOCKS", 256);
+    return v;
+}
+inline int reduce_blocks_lines() {
+    static int v = env_int("QS_REDUCE_BLOCKS_LINES", 1024);
     return v;
 }
 // Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
@@ -389,7 +393,7 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
 // ------------------------------------------------------------------------------------------------
 static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
                        int64_t inner, int xdt, hipStream_t s, bool accumulate = false, int relu = 0, void* ws = nullptr,
-                       size_t ws_bytes = 0) {
+                       size_t ws_bytes = 0, int lines = 1) {
     if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
     if (!dt_ok(xdt)) return QS_ERR_DTYPE;
     if (outer < 0 || C < 1 || inner < 1) return QS_ERR_ARG;
@@ -410,9 +414,13 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     // 512-thread workgroups, at most 256 of them: every one ends with an atomic on the same word, which
                     // serialise at ~12 ns each (256x512 vs 512x256 threads: 256x64x56x56 bf16 23.6 -> 21.2 us,
                     // 64x64x56x56 12.4 -> 9.8 us; tools/bench_reduce.py)
+                    // With `lines` > 1 accumulator lines the atomics no longer limit the workgroup count: 4 workgroups per
+                    // CU keep 4x the bytes in flight (QS_REDUCE_BLOCKS_LINES; tools/bench_reduce.py)
                     int grid = (grid_for(numel / 8, 4) + 1) / 2;
-                    if (grid > reduce_blocks()) grid = reduce_blocks();
-                    hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu);
+                    const int cap = lines > 1 ? reduce_blocks_lines() : reduce_blocks();
+                    if (grid > cap) grid = cap;
+                    hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu,
+                                       lines);
                 } else if (inner >= 64 && C < 65536 && !(inner < 512 && vec_ptr && (C * inner) % 8 == 0)) {
                     // (rows of 64..511 elements -- 14x14 maps -- go to the column kernel below when it can use vector
                     //  loads: a wave there reads 1 KiB of consecutive columns per row instead of one short ragged row)
@@ -466,9 +474,10 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
 }
 
 int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate,
-              int pre_relu, void* ws, size_t ws_bytes, qs_stream_t stream) {
+              int pre_relu, int out_lines, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    if (out_lines < 1 || out_lines > 64 || (out_lines > 1 && (per_channel || !accumulate))) return QS_ERR_ARG;
     return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0,
-                       pre_relu != 0, ws, ws_bytes);
+                       pre_relu != 0, ws, ws_bytes, out_lines);
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
@@ -477,15 +486,17 @@ int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, in
                        ws_bytes);
 }
 
-int qs_scale_update(float* absmax, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev, int bits,
-                    int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream) {
+int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev,
+                    int bits, int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream) {
     if (!absmax || !weight || n < 0 || t < 0 || bits < 1 || bits > 31) return QS_ERR_ARG;
+    if (absmax_lines < 1 || absmax_lines > 64 || (absmax_lines > 1 && n != 1)) return QS_ERR_ARG;
     if (!dt_ok(stat_dt)) return QS_ERR_DTYPE;
     if (n == 0) return QS_OK;
     const int advance = (advance_t_dev && t_dev) ? 1 : 0;
     const int blocks = advance ? 1 : (int)((n + 255) / 256);
     hipLaunchKernelGGL(scale_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, absmax, weight, n, (float)t,
-                       (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, advance, clear_absmax, bump_i32, stat_dt);
+                       (float)(t + 1), (float)((int64_t)1 << (bits - 1)), t_dev, advance, clear_absmax, bump_i32, stat_dt,
+                       absmax_lines);
     return launch_status();
 }
 
@@ -793,6 +804,15 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
     for (int d = 0; d < nd; ++d) {
         geo.sizes[d] = cs[d];
         geo.mstrides[d] = cm[d];
+    }
+    if (cs[nd - 1] % 8 == 0 && (cm[nd - 1] == 0 || cm[nd - 1] == 1) && numel / 8 / kBlock < 0x7fffffff) {
+        const int64_t ngroups = numel / 8;    // 16-byte accesses: a lane's 8 elements share every index but the innermost
+        return with_dtype(dt, [&](auto D) {
+            constexpr int DD = decltype(D)::value;
+            hipLaunchKernelGGL((mask_bcast_vec_kernel<DD, (QS_EW_NT != 0)>), dim3((int)((ngroups + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, s, x, mask, y, ngroups, geo);
+            return launch_status();
+        });
     }
     int64_t blocks = (numel + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;   // grid-stride

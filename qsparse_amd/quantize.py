@@ -296,8 +296,9 @@ class DecimalQuantizer(BaseQuantizer):
                 n_stat = wshape[0]
                 bufs = self.__dict__.setdefault("_absmax_bufs", {})
                 buf = bufs.get((n_stat, x.device))
-                if buf is None:
-                    buf = bufs[(n_stat, x.device)] = torch.zeros(n_stat, dtype=torch.float32, device=x.device)
+                if buf is None:     # tensor-wise: 16 partial accumulators on lines of their own (see _hip.absmax)
+                    buf = bufs[(n_stat, x.device)] = (_hip.tensor_amax_accumulator(x.device) if channel_index < 0 else
+                                                      torch.zeros(n_stat, dtype=torch.float32, device=x.device))
                 stat = _hip.absmax(x, channel_index, accumulate_into=buf, pre_relu=bool(kwargs.get("pre_relu", False)))
                 if batched:      # activations differ per rank; weights and biases (batched=False) are identical under DDP
                     stat = qdist.allreduce_max_(stat)

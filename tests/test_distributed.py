@@ -225,3 +225,75 @@ def test_statistics_exchange_through_rccl_with_one_rank():
     assert len(plain) == len(with_rccl) > 0
     for a, b in zip(plain, with_rccl):
         assert np.array_equal(a, b)
+
+
+def _ddp_resnet_worker(rank, world, port, out):
+    """BASELINE config 5 on four ranks: a converted ResNet-18 (narrow, CIFAR shape) under DistributedDataParallel (gloo),
+    every rank with its OWN data and its own batch size."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import qsparse_amd as qs
+    from examples.models import convert_pq, resnet18
+    from qsparse_amd.quantize import QuantizeLayer
+    from qsparse_amd.sparse import PruneLayer
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    torch.manual_seed(0)
+    net = convert_pq(resnet18(10, True, width=8), sparsity=0.5, bits=4, prune_start=2, prune_interval=2, repetition=2,
+                     quant_timeout=2, log=False)
+    ddp = DDP(net)
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.05, momentum=0.9)
+    batch = 2 + rank                                             # unequal shards: 2, 3, 4, 5 samples
+    for step in range(8):                                        # the schedule ends at step 4 (start 2, interval 2, 2 ramps)
+        g = torch.Generator().manual_seed(1000 * rank + step)   # a different stream per rank
+        x = torch.randn(batch, 3, 32, 32, generator=g) * (1.0 + 0.4 * rank)
+        y = torch.randint(0, 10, (batch,), generator=g)
+        opt.zero_grad()
+        F.cross_entropy(ddp(x), y).backward()
+        opt.step()
+    state, counters = {}, {}
+    for name, m in qs.util.nn_module(ddp).named_modules():
+        if isinstance(m, PruneLayer):
+            state[name + ".mask"] = m.mask.detach().clone()
+            state[name + ".magnitude"] = m.callback.magnitude.detach().clone()
+            counters[name] = (m._n_updates.item(), round(m._cur_sparsity.item(), 6), m.callback.t.item())
+        elif isinstance(m, QuantizeLayer) and m.initted:
+            state[name + ".weight"] = m.weight.detach().clone()
+            counters[name] = (m._n_updates.item(),)
+    state.update({"param." + k: v.detach().clone() for k, v in net.named_parameters() if v.requires_grad})
+    out.put((rank, {k: v.numpy().copy() for k, v in state.items()}, counters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_converted_resnet18_under_ddp_on_four_ranks_with_unequal_shards():
+    """after the sparsity schedule has completed on shards of different content and size, all four ranks hold the
+    same network: weights through DDP's all-reduce, masks / magnitudes / scales through the statistics exchange
+    (qsparse_amd/distributed.py), counters through the common step count."""
+    import numpy as np
+    world = 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_resnet_worker, args=(r, world, port, out)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [out.get(timeout=600) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    res = {r: (s, c) for r, s, c in got}
+    ref_state, ref_counters = res[0]
+    masks = [k for k in ref_state if k.endswith(".mask")]
+    assert len(masks) >= 8 and any(k.endswith(".weight") for k in ref_state)
+    for r in range(1, world):
+        assert res[r][1] == ref_counters, r
+        assert res[r][0].keys() == ref_state.keys()
+        for k in ref_state:
+            assert np.array_equal(res[r][0][k], ref_state[k]), (r, k)
+    for k in masks:                                              # the schedule completed: ~50 % of the channels pruned
+        kept = ref_state[k].mean()
+        assert 0.4 <= kept <= 0.75, (k, kept)
+    assert all(c[0] == 8 for c in ref_counters.values())

@@ -80,6 +80,47 @@ def test_golden_f13_uniform_pruning_callback():
     H.run_f13(DEV)
 
 
+def test_golden_f9_reference_checkpoint_on_gpu():
+    """row f3 of SURVEY 8: a checkpoint written by the REFERENCE (fixture F9: quantize(prune(Conv2d)) after 45 steps) is
+    preloaded + loaded, moved to the GPU and evaluated there.  State tensors survive `.cuda()` bit for bit; the
+    pruned weight the GPU operator hands the convolution is the reference's; quirk B7 (`_quantized` is not
+    checkpointed, so a freshly loaded quantizer is a pass-through in eval) is reproduced; and training continues on
+    the GPU exactly as it continues on the CPU from the same checkpoint."""
+    g, _, schema = H._trees()
+    ref_sd = {key: g.get("sd_" + key) for key in schema}
+    xt = g.get("eval_x")
+
+    def load(dev):
+        m = H._make_conv()
+        qs.preload_qsparse_state_dict(m, {k: v.clone() for k, v in ref_sd.items()})
+        m.load_state_dict(ref_sd)
+        return m.to(dev)
+
+    gpu, cpu = load(DEV), load("cpu")
+    for k, v in gpu.state_dict().items():
+        assert v.is_cuda and same(v.cpu(), ref_sd[k]), k
+    gpu.eval(), cpu.eval()
+    w = gpu.weight.detach()
+    pruned = gpu.prune(w)
+    assert same(pruned.cpu(), ref_sd["weight"] * ref_sd["prune.mask"])
+    assert gpu.quantize(pruned) is pruned                      # B7: pass-through until a training step sets _quantized
+    y = gpu(xt.to(DEV))
+    y_ref = g.get("eval_y_reloaded")
+    assert y.shape == y_ref.shape and torch.allclose(y.cpu(), y_ref, rtol=1e-4, atol=1e-5)     # MIOpen vs CPU convolution
+    assert same(torch.nn.functional.conv2d(xt, pruned.cpu(), ref_sd["bias"]), y_ref)            # same operands, CPU conv
+    # resume training: the weight-side operators see the same parameters on both devices
+    gpu.train(), cpu.train()
+    for s in range(8):
+        x = torch.rand(4, 16, 7, 7, generator=gen(7000 + s))
+        gpu(x.to(DEV)), cpu(x)
+        sg, sc = gpu.state_dict(), cpu.state_dict()
+        for k in sc:
+            assert same(sg[k].cpu(), sc[k]), (s, k)
+    assert gpu.quantize._quantized and gpu.quantize._n_updates.item() == int(ref_sd["quantize._n_updates"][0]) + 8
+    gpu.eval(), cpu.eval()
+    assert same(gpu.quantize(gpu.prune(gpu.weight)).cpu(), cpu.quantize(cpu.prune(cpu.weight)))
+
+
 def test_golden_f14_counters_written_through_data():
     """`.data` writes to GPU-resident counters are seen by the next forward without a per-step sync"""
     H.run_f14(DEV)

@@ -66,12 +66,19 @@ def test_resnet_pq_fused_equals_unfused_on_gpu(arch):
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
         runs.append((losses, state))
     (lref, sref), (l0, s0), (l1, s1) = runs
-    if lref != l0:
-        pytest.skip("convolution backward is not run-to-run deterministic on this stack; nothing to compare exactly")
-    assert l0 == l1, (l0, l1)
     assert s0.keys() == s1.keys()
-    for k in s0:
-        assert torch.equal(s0[k], s1[k]), k
+    if lref == l0:      # deterministic convolutions (the case on this stack): whole trajectories agree bit for bit
+        assert l0 == l1, (l0, l1)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+    else:               # run-to-run noise in MIOpen's backward: what does not depend on it must still agree exactly
+        #                 (per-site bit-exactness against the oracle is tests/test_sites_gpu.py's job, on real inputs)
+        for k in s0:
+            if k.endswith(("_n_updates", "_cur_sparsity", ".t")):
+                assert torch.equal(s0[k], s1[k]), k
+            elif k.endswith(".mask"):
+                assert s0[k].sum().item() == s1[k].sum().item(), k
+        assert all(abs(a - b) < 0.25 * max(abs(a), 1.0) for a, b in zip(l0, l1)), (l0, l1)
     masks = [v for k, v in s0.items() if k.endswith(".mask")]
     assert masks and all(abs(m.float().mean().item() - 0.5) < 0.26 for m in masks)
     assert all(torch.isfinite(torch.tensor(l0)))

@@ -52,8 +52,10 @@ def one():
             return round(ts[len(ts) // 2] * 1e3, 1)
 
         r = {}
-        r["all"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), a1.data_ptr(), 0, 1, 1, x.numel(), 1, 1, 0, None, 0, None))
-        r["chan"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N, C, H * W, 1, 1, 0, None, 0, None))
+        r["all"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), a1.data_ptr(), 0, 1, 1, x.numel(), 1, 1, 0, 1, None, 0, None))
+        a16 = torch.zeros(16, 32, device="cuda")
+        r["all_16lines"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), a16.data_ptr(), 0, 1, 1, x.numel(), 1, 1, 0, 16, None, 0, None))
+        r["chan"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N, C, H * W, 1, 1, 0, 1, None, 0, None))
         r["chan_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N, C, H * W, 1, None, 0, None))
         r["ideal@6TB/s"] = round(x.numel() * 2 / 6e6, 1)
         out[str(shp)] = r

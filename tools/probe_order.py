@@ -25,7 +25,7 @@ big = torch.empty(300 * 1024 * 1024, device=dev, dtype=torch.uint8)
 def fwd(): lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE, None)
 def bwd(): lib.qs_quant_ste_bwd(gout.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(), N, C, H * W, 0, 1, 0, None)
 def stats(): lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, None)
-def readg(): lib.qs_absmax(gout.data_ptr(), amax.data_ptr(), 0, 1, 1, numel, 0, 0, 0, None, 0, None)
+def readg(): lib.qs_absmax(gout.data_ptr(), amax.data_ptr(), 0, 1, 1, numel, 0, 0, 0, 1, None, 0, None)
 def fill(): big.zero_()
 
 def timed(pre, fn, iters=15):

@@ -78,10 +78,10 @@ def run_variant(path):
     am1 = torch.empty(1, device=dev)
 
     def read_all():
-        assert lib.qs_absmax(x.data_ptr(), am1.data_ptr(), 0, 1, 1, numel, 1, 0, 0, None, 0, None) == 0
+        assert lib.qs_absmax(x.data_ptr(), am1.data_ptr(), 0, 1, 1, numel, 1, 0, 0, 1, None, 0, None) == 0
 
     def read_rows():
-        assert lib.qs_absmax(x.data_ptr(), amax.data_ptr(), 1, N, C, H * W, 1, 0, 0, None, 0, None) == 0
+        assert lib.qs_absmax(x.data_ptr(), amax.data_ptr(), 1, N, C, H * W, 1, 0, 0, 1, None, 0, None) == 0
 
     imp = torch.empty(C, device=dev, dtype=torch.bfloat16)
 
