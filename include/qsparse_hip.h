@@ -184,15 +184,17 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C, qs_stream_t stream);
 
-/* The first stage for a channels_last (NHWC in memory) activation x[n][hw][C], C % 8 == 0: mean over n ->
+/* The first stage for a channels_last (NHWC in memory) activation x[n][hw][C]: mean over n ->
  * out[C][hw], NCHW-contiguous like the result of Tensor.mean(0, keepdim=True) on a channels_last tensor, in the
  * summation order ATen uses for that layout (per channel, positions hw < 4*floor(hw/4) in cascade order, the rest
- * 4-way interleaved; the later stages are the NCHW ones: qs_mean_last2 / qs_mean_dim).  flags: 0, QS_MEAN_ABS or
- * QS_MEAN_ABS|QS_MEAN_RELU.  amax_part (nullable, device float[C*hw], not with flags == 0) receives the maximum over
- * n of the mean's operand per output element; hand it to qs_mean_last2, which reduces it to the per-channel
- * abs-max without atomics. */
+ * 4-way interleaved; the later stages are the NCHW ones: qs_mean_last2 / qs_mean_dim).  flags as for qs_mean_dim
+ * (QS_MEAN_L0 reads l0_flag, nullable otherwise).  C % 8 == 0 with flags 0, QS_MEAN_ABS or QS_MEAN_ABS|QS_MEAN_RELU and
+ * a 16-byte aligned x take the vector kernels (16-byte loads, 8 channels per lane); every other channel count and flag
+ * combination a scalar kernel in the same order.  amax_part (nullable, device float[C*hw]) receives the maximum over
+ * n of |x| (or max(x, 0) with QS_MEAN_RELU) per output element; hand it to qs_mean_last2, which reduces it to the
+ * per-channel abs-max without atomics. */
 int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
-                   float* amax_part, qs_stream_t stream);
+                   const int32_t* l0_flag, float* amax_part, qs_stream_t stream);
 
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].

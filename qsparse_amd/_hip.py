@@ -53,7 +53,7 @@ SIGNATURES = {
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
-    "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
@@ -499,16 +499,17 @@ def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype
     return out
 
 
-def mean_dim_cl(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, want_amax: bool):
+def mean_dim_cl(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, want_amax: bool,
+                l0_flag: Optional[torch.Tensor] = None):
     """first squeeze stage of a channels_last activation given as its contiguous [N, H, W, C] view: mean over N ->
-    ([C*H*W] in NCHW order, per-element maxima or None)."""
+    ([C*H*W] in NCHW order, per-element maxima or None).  Any C; `l0_flag` with MEAN_L0 in `flags`."""
     N, C = x_nhwc.shape[0], x_nhwc.shape[-1]
     hw = x_nhwc.numel() // (N * C)
     out = torch.empty(C * hw, dtype=out_dtype, device=x_nhwc.device)
     part = torch.empty(C * hw, dtype=torch.float32, device=x_nhwc.device) if want_amax else None
     with _timed("mean_dim" + ("+absmax" if want_amax else "")):
-        st = load().qs_mean_dim_cl(_ptr(x_nhwc), _ptr(out), N, hw, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(part),
-                                   _stream(x_nhwc))
+        st = load().qs_mean_dim_cl(_ptr(x_nhwc), _ptr(out), N, hw, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(l0_flag),
+                                   _ptr(part), _stream(x_nhwc))
     _check(st, "qs_mean_dim_cl")
     return out, part
 

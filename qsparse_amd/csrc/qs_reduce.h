@@ -14,23 +14,40 @@ namespace qs {
 template <int DT, bool MINMAX>
 struct RedAcc {
     uint32_t mx = 0u, mn = 0xffffffffu;
+    // min/max run on the float pipeline (v_min_f32 / v_max_f32 order -0 < +0 and drop NaN operands, so a NaN is
+    // tracked on the side): 3 VALU ops per element instead of the ~9 of key conversion + integer min/max, which made
+    // the min/max kernels VALU-bound (4.3 TB/s on the headline tensor)
+    float fmx = -__builtin_inff(), fmn = __builtin_inff();
+    bool nan = false;
     int relu = 0;   // abs-max of max(x, 0): the statistics of a folded nn.ReLU
     __device__ __forceinline__ void add(float v) {
         if (relu) v = relu_aten(v);
         if constexpr (MINMAX) {
-            uint32_t k = f32_to_key(v);
-            mx = k > mx ? k : mx;
-            mn = k < mn ? k : mn;
+            fmx = __builtin_fmaxf(fmx, v);
+            fmn = __builtin_fminf(fmn, v);
+            nan |= (v != v);
         } else {
             uint32_t k = __float_as_uint(v) & 0x7fffffffu;
             mx = k > mx ? k : mx;
         }
     }
+    __device__ __forceinline__ void fold() {      // float state -> order-preserving keys (NaN sorts on top, as before)
+        if constexpr (MINMAX) {
+            const uint32_t kx = nan ? 0xffffffffu : f32_to_key(fmx), kn = f32_to_key(fmn);
+            mx = kx > mx ? kx : mx;
+            mn = kn < mn ? kn : mn;
+            fmx = -__builtin_inff();
+            fmn = __builtin_inff();
+            nan = false;
+        }
+    }
     __device__ __forceinline__ void wave_reduce() {
+        fold();
         mx = wave_max_u32(mx);
         if constexpr (MINMAX) mn = wave_min_u32(mn);
     }
-    __device__ __forceinline__ void flush(uint32_t* out_max, uint32_t* out_min, uint32_t idx) const {
+    __device__ __forceinline__ void flush(uint32_t* out_max, uint32_t* out_min, uint32_t idx) {
+        fold();
         atomicMax(out_max + idx, mx);
         if constexpr (MINMAX) atomicMin(out_min + idx, mn);
     }
@@ -145,26 +162,45 @@ __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restr
             if (has_tail[u]) acc.add(tail[u]);
         }
     }
-    for (int64_t o = o0 + wave; !short_rows && o < o1; o += kBlock / 64) {
-        const int64_t base = (o * C + c) * inner;
-        if (vec_ok == 1) {  // inner % 8 == 0 and base pointer aligned: rows start on 16-byte boundaries
-            const int64_t g0 = base / 8, ng = inner / 8;
-            for (int64_t g = lane; g < ng; g += 8 * 64) {   // up to eight 16-byte loads in flight per lane
-                Raw8<DT> r[8];
+    // long aligned rows: TWO rows of the wave per iteration, up to eight 16-byte loads in flight per lane and row -- with
+    // one row (6.1 loads per lane on 56x56 maps) a wave idled between its rows (256x256x56x56 bf16: 5.4 TB/s)
+    const bool row_pairs = !short_rows && vec_ok == 1;
+    for (int64_t o = o0 + wave; row_pairs && o < o1; o += 2 * (kBlock / 64)) {
+        const int64_t ng = inner / 8;
+        const int64_t ga = ((o * C + c) * inner) / 8;
+        const bool two = o + kBlock / 64 < o1;
+        const int64_t gb = (((o + kBlock / 64) * C + c) * inner) / 8;
+        for (int64_t g = lane; g < ng; g += 8 * 64) {
+            Raw8<DT> ra[8], rb[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (g + u * 64 < ng) r[u] = load8_raw<DT, false>(x, g0 + g + u * 64);
+            for (int u = 0; u < 8; ++u)
+                if (g + u * 64 < ng) ra[u] = load8_raw<DT, false>(x, ga + g + u * 64);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (g + u * 64 < ng) {
-                        float v[8];
-                        unpack8<DT>(r[u], v);
+            for (int u = 0; u < 8; ++u)
+                if (two && g + u * 64 < ng) rb[u] = load8_raw<DT, false>(x, gb + g + u * 64);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc.add(v[j]);
-                    }
+            for (int u = 0; u < 8; ++u) {
+                if (g + u * 64 < ng) {
+                    float v[8];
+                    unpack8<DT>(ra[u], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.add(v[j]);
                 }
             }
-        } else if (vec_ok == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (two && g + u * 64 < ng) {
+                    float v[8];
+                    unpack8<DT>(rb[u], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.add(v[j]);
+                }
+            }
+        }
+    }
+    for (int64_t o = o0 + wave; !short_rows && !row_pairs && o < o1; o += kBlock / 64) {
+        const int64_t base = (o * C + c) * inner;
+        if (vec_ok == 2) {
             // aligned tensor, ragged rows (14x14, 7x7 maps): the 8-element groups that lie inside the row with vector
             // loads, the few elements in front of the first and behind the last one with scalar loads
             const int64_t e1 = base + inner;
@@ -270,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int li = (int)((gc * 8 + j) / inner - c_block);
+            acc[j].fold();
             atomicMax(&lmx[li], acc[j].mx);
             if constexpr (MINMAX) atomicMin(&lmn[li], acc[j].mn);
         }
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __r
 // i.e. one contiguous span), strides over its share of the rows with eight loads in flight, folds its lanes per column
 // through LDS and writes ONE partial row; a second, tiny launch folds the partial rows into the result.  No global
 // atomics: 512 workgroups x C channels of them cost more than the whole read (64x64x56x56 bf16: 76 us -> 12 us).
-constexpr int kFewColsMaxBlocks = 256;
+constexpr int kFewColsMaxBlocks = 512;   // 2 workgroups per CU (measured: 256 -> 98 us, 512 -> 73 us, 1024 -> 76 us + a longer finish on 411 MB)
 constexpr int kFewColsMaxCols = 512;
 
 template <int DT, bool MINMAX>
@@ -300,8 +337,11 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
     const int gcols = (int)(cols / 8);
     const int rows_per_iter = kBlock / gcols;
     const int row_l = threadIdx.x / gcols, gc = threadIdx.x - row_l * gcols;
-    const int64_t chunk = (outer + gridDim.x - 1) / gridDim.x;
-    const int64_t o0 = (int64_t)blockIdx.x * chunk, o1 = o0 + chunk < outer ? o0 + chunk : outer;
+    // grid-stride over blocks of 8 * rows_per_iter rows: at any moment the whole grid reads ONE moving window of
+    // gridDim.x * 32 KiB (as reduce_all_kernel does) instead of gridDim.x far-apart private streams, which cost DRAM page
+    // locality (5.5 TB/s where the tensor-wise kernel streams at 6.3)
+    const int64_t o0 = (int64_t)blockIdx.x * rows_per_iter * 8, o1 = outer;
+    const int64_t ostride = (int64_t)gridDim.x * rows_per_iter * 8;
     for (int i = threadIdx.x; i < cols; i += kBlock) {
         lmx[i] = 0u;
         lmn[i] = 0xffffffffu;
@@ -310,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j].relu = relu;
     if (row_l < rows_per_iter) {
-        for (int64_t o = o0 + row_l; o < o1; o += (int64_t)rows_per_iter * 8) {
+        for (int64_t o = o0 + row_l; o < o1; o += ostride) {
             Raw8<DT> r[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -330,6 +370,7 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
     if (row_l < rows_per_iter) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            acc[j].fold();
             atomicMax(&lmx[gc * 8 + j], acc[j].mx);
             if constexpr (MINMAX) atomicMin(&lmn[gc * 8 + j], acc[j].mn);
         }
@@ -650,6 +691,10 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                         amax = k > amax ? k : amax;
                     }
                     acc[j].add(mean_prep<DT>(v[j], flags, l0));
+                } else if constexpr (MODE >= 4) {   // abs-max ONLY (4: |x|, 5: max(x, 0)): no sum, no output -- the column walk
+                    const float w = (MODE == 5) ? relu_aten(v[j]) : v[j];     // as the per-channel abs-max of a big tensor
+                    const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
+                    amax = k > amax ? k : amax;
                 } else {
                     const float w = (MODE == 2) ? relu_aten(v[j]) : v[j];
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
@@ -676,7 +721,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                         for (int u = 0; u < 16; ++u) consume(r[c * 16 + u]);
                         i += 16;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+                        for (int j = 0; j < 8; ++j) if constexpr (MODE < 4) acc[j].carry(i, lp, lmask);
                     }
                 }
             }
@@ -696,14 +741,16 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
             }
             i += step;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j].carry(i, lp, lmask);
+            for (int j = 0; j < 8; ++j) if constexpr (MODE < 4) acc[j].carry(i, lp, lmask);
         }
         for (; i < n; ++i) consume(load8_raw<DT, false>(x, g_base + i * row_groups));
 
-        float m[8];
+        if constexpr (MODE < 4) {
+            float m[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;   // .div_(n) in fp32, then one rounding to ODT
-        store8<ODT, false>(out, p * row_groups + gc, m);
+            for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;   // .div_(n) in fp32, then one rounding to ODT
+            store8<ODT, false>(out, p * row_groups + gc, m);
+        }
     }
 
     if (absmax) {   // whole wave takes part: idle lanes contribute 0
@@ -936,6 +983,38 @@ __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict
         store1<ODT>(out, o, (((p[0][j] + p[1][j]) + p[2][j]) + p[3][j]) / fn);
         if (MODE != 3 && amax_part) amax_part[o] = amax[j];
     }
+}
+
+// ---- channels_last first stage for ANY channel count and every flag combination ----------------------------------
+// One lane per (position, channel) of a sample, in memory order (so a wave's loads are contiguous), scalar accesses.
+// Same summation rule as mean_cl_kernel / mean_cl_tail_kernel: positions below 4*floor(HW/4) in multi-row order, the
+// rest in row-sum order (checked against ATen's CPU result for C = 3 ... 100, tests/test_gpu_parity.py).  Serves
+// channels_last activations whose C is not a multiple of 8 and the L0 variant (sparse.py:85-86), which used to be
+// copied to NCHW first -- and were then summed in NCHW order, i.e. not in the order the reference's CPU path uses.
+template <int DT, int ODT>
+__global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                                  int64_t n, int64_t hw, int64_t C, int flags,
+                                                                  const int32_t* __restrict__ l0_flag,
+                                                                  uint32_t* __restrict__ amax_part) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= hw * C) return;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int64_t pos = t / C, c = t - pos * C;
+    const int64_t sample = hw * C;
+    uint32_t amax = 0u;
+    auto get = [&](int64_t i) {
+        const float v = load1<DT>(x, i * sample + t);
+        if (amax_part) {
+            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v) : v;
+            const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
+            amax = k > amax ? k : amax;
+        }
+        return mean_prep<DT>(v, flags, l0);
+    };
+    const float s = (pos < (hw / 4) * 4) ? sum_multi_row(n, get) : sum_row_sum(n, get);
+    const int64_t o = c * hw + pos;                       // the result is NCHW-contiguous, as ATen's is
+    store1<ODT>(out, o, s / (float)n);
+    if (amax_part) amax_part[o] = amax;
 }
 
 // ---- the same stage for tensors with FEW columns: rows split over R waves of one workgroup -------------------

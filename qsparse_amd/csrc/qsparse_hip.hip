@@ -43,7 +43,7 @@ inline int reduce_blocks() {
     return v;
 }
 inline int reduce_blocks_lines() {
-    static int v = env_int("QS_REDUCE_BLOCKS_LINES", 1024);
+    static int v = env_int("QS_REDUCE_BLOCKS_LINES", 256);   // measured: 512 / 1024 / 2048 workgroups are 9-22 % SLOWER on 411 MB
     return v;
 }
 // Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
@@ -414,13 +414,29 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     // 512-thread workgroups, at most 256 of them: every one ends with an atomic on the same word, which
                     // serialise at ~12 ns each (256x512 vs 512x256 threads: 256x64x56x56 bf16 23.6 -> 21.2 us,
                     // 64x64x56x56 12.4 -> 9.8 us; tools/bench_reduce.py)
-                    // With `lines` > 1 accumulator lines the atomics no longer limit the workgroup count: 4 workgroups per
-                    // CU keep 4x the bytes in flight (QS_REDUCE_BLOCKS_LINES; tools/bench_reduce.py)
+                    // `lines` > 1 accumulator lines take the serialised same-address atomics off the kernel's tail
+                    // (64x64x56x56 bf16: 10.0 -> 8.6 us); more workgroups than one per CU do not pay (tools/bench_reduce.py)
                     int grid = (grid_for(numel / 8, 4) + 1) / 2;
                     const int cap = lines > 1 ? reduce_blocks_lines() : reduce_blocks();
                     if (grid > cap) grid = cap;
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu,
                                        lines);
+                } else if (!M && vec_ptr && inner % 8 == 0 && outer >= 16 && (C * inner) / 8 >= 64 * 1024) {
+                    // big tensors ([N, C, H*W] with >= 1024 waves of column groups): the column walk of the statistics
+                    // kernel -- a lane keeps 8 adjacent columns and loops over N in registers, one atomic per wave and
+                    // channel at the end -- streams at the statistics kernel's rate, where workgroups that hop from row
+                    // to row (reduce_rows_kernel) reach 5.4 TB/s (256x256x56x56 bf16: 76 us)
+                    const int64_t post = C * inner, total = post / 8;
+                    const int lanes = mean_lanes(total);
+                    const int blocks = (int)((total + lanes - 1) / lanes);
+                    if (relu)
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 5>), dim3(blocks), dim3(64), 0, s, x,
+                                           (void*)nullptr, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
+                                           inner, (uint32_t)C, lanes);
+                    else
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 4>), dim3(blocks), dim3(64), 0, s, x,
+                                           (void*)nullptr, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
+                                           inner, (uint32_t)C, lanes);
                 } else if (inner >= 64 && C < 65536 && !(inner < 512 && vec_ptr && (C * inner) % 8 == 0)) {
                     // (rows of 64..511 elements -- 14x14 maps -- go to the column kernel below when it can use vector
                     //  loads: a wave there reads 1 KiB of consecutive columns per row instead of one short ragged row)
@@ -438,7 +454,8 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                         // few columns, many rows: two stages through the caller's workspace, no atomics
                         const int64_t rows_per_iter = kBlock / (cols / 8);
                         int64_t nblk = outer / (rows_per_iter * 32);     // >= 4 rounds of 8 loads per workgroup
-                        nblk = std::min<int64_t>(std::max<int64_t>(nblk, 1), kFewColsMaxBlocks);
+                        static const int fewcols_cap = env_int("QS_FEWCOLS_BLOCKS", kFewColsMaxBlocks);
+                        nblk = std::min<int64_t>(std::max<int64_t>(nblk, 1), std::min(fewcols_cap, kFewColsMaxBlocks));
                         if (ws_bytes >= (size_t)(2 * nblk * cols) * sizeof(uint32_t) && outer >= 32 * rows_per_iter) {
                             uint32_t* pmax = (uint32_t*)ws;
                             uint32_t* pmin = pmax + nblk * cols;
@@ -615,12 +632,27 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
 }
 
 int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
-                   float* amax_part, qs_stream_t stream) {
-    if (!x || !out || n < 1 || hw < 1 || C < 8 || C % 8 != 0) return QS_ERR_ARG;
+                   const int32_t* l0_flag, float* amax_part, qs_stream_t stream) {
+    if (!x || !out || n < 1 || hw < 1 || C < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
-    if (!aligned16(x)) return QS_ERR_ALIGN;
-    const int mode = flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : (flags == 0 ? 3 : 0));
-    if (mode == 0 || (mode == 3 && amax_part)) return QS_ERR_ARG;
+    const int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                                 (flags == 0 ? 3 : 0)));
+    if (C % 8 != 0 || mode == 0 || (mode == 3 && amax_part) || !aligned16(x)) {
+        // any channel count, the L0 variant, unaligned views: one lane per element of a sample, same summation order
+        const int64_t total = hw * C;
+        if ((total + kBlock - 1) / kBlock > 0x7fffffff) return QS_ERR_ARG;
+        return with_dtype(xdt, [&](auto X) {
+            constexpr int XD = decltype(X)::value;
+            const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+            if (odt == QS_F32)
+                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw,
+                                   C, flags, l0_flag, (uint32_t*)amax_part);
+            else
+                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw, C,
+                                   flags, l0_flag, (uint32_t*)amax_part);
+            return launch_status();
+        });
+    }
     const int64_t main_groups = (hw / 4) * 4 * C / 8, tail_groups = hw * C / 8 - main_groups;   // ATen's split of H*W
     const int lanes = mean_lanes(main_groups > 0 ? main_groups : 1);
     const int blocks = (int)((main_groups + lanes - 1) / lanes);

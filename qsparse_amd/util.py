@@ -99,24 +99,34 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
     ``record`` (a dict with a float32 ``buf`` of 2C elements): when the plan ends in the fused last-two-dims launch over
     C slices, that launch also writes the rank's exchange record (means | values of ``record_absmax``, the per-channel
     abs-max accumulator that is complete by then) and ``record["filled"]`` is set."""
-    if (x.dim() == 4 and dims == [0, 2, 3] and l0_flag is None and x.shape[1] % 8 == 0
-            and (x.shape[2] * x.shape[3] + x.shape[3]) * 4 <= 48 * 1024 and (absmax_out is None or absmax_channel_dim == 1)):
-        # channels_last activation reduced to its channels: no NCHW copy.  ATen's mean over N of such a tensor returns
-        # an NCHW-contiguous result (summed in the order qs_mean_dim_cl reproduces), so stages 2 and 3 are the usual ones
+    cur = None
+    first = True
+    if x.dim() == 4 and dims and dims[0] == 0 and (absmax_out is None or absmax_channel_dim == 1):
+        # channels_last activation whose batch dim is reduced first: no NCHW copy.  ATen's mean over N of such a tensor
+        # returns an NCHW-contiguous result (summed in the order qs_mean_dim_cl reproduces, any channel count), so the
+        # remaining stages are the usual NCHW ones
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
             N, C, H, W = x.shape
             flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
-            if flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU) and not (flags == 0 and absmax_out is not None):
+            fusable = (dims == [0, 2, 3] and l0_flag is None and C % 8 == 0 and (H * W + W) * 4 <= 48 * 1024
+                       and flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU)
+                       and not (flags == 0 and absmax_out is not None))
+            if fusable:       # stages 2 + 3 in one launch, which also folds the per-element maxima per channel
                 stage, part = _hip.mean_dim_cl(xm, x.dtype, flags, absmax_out is not None)
                 rec = _record_for(record, C)
                 # (with a record and no riding abs-max the accumulator is only read, for the record's second half)
                 acc = absmax_out if absmax_out is not None else (record_absmax if rec is not None else None)
                 return _hip.mean_last2(stage, C, H, W, x.dtype, part, acc, rec).view(1, C, 1, 1)
-    cur = _hip.dense(x)
+            if absmax_out is None:
+                if l0_flag is not None:
+                    flags |= _hip.MEAN_L0
+                stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
+                cur, dims, first = stage.view(1, C, H, W), dims[1:], False
+    if cur is None:
+        cur = _hip.dense(x)
     shape = list(cur.shape)
     out_dtype = torch.float32 if l0_flag is not None else cur.dtype
-    first = True
     for pos, d in enumerate(dims):
         nd = len(shape)
         if (not first and len(dims) - pos == 2 and d == nd - 2 and dims[pos + 1] == nd - 1

@@ -1087,3 +1087,42 @@ def test_select_on_gathered_records_equals_combine_then_select(C):
     assert torch.equal(a[1], want_mask)
     new = want_amax[want_mask].max() / 8                       # 4 bits
     assert same(a[2].view(-1), ((2 * torch.tensor(0.25) + new) / 3).view(-1))
+
+
+def test_channels_last_statistics_any_channel_count_masks_and_l0_vs_oracle():
+    """channels_last activations whose batch dim is reduced first are summed in place, in the order ATen's CPU path uses
+    for that layout (reference util.py:92-99 on a channels_last tensor): channel counts that are not a multiple of 8,
+    masks other than the channel mask ((1,C,H,W), (1,C,H,1), (1,1,H,W), (1,C,1,W)) and the L0 variant
+    (sparse.py:85-86) -- none of them pays an NCHW copy any more, all bit-identical to the oracle at <= 8 CPU threads."""
+    from qsparse_amd.util import squeeze_tensor_to_shape
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads))
+    try:
+        for si, shape in enumerate(((16, 3, 5, 5), (64, 12, 7, 7), (33, 20, 3, 3), (40, 10, 14, 14), (128, 36, 2, 2), (17, 5, 1, 7),
+                                    (64, 100, 6, 1), (48, 24, 9, 9), (32, 64, 8, 8))):
+            N, C, H, W = shape
+            for dt in (torch.float32, torch.bfloat16, torch.float16):
+                x = (torch.randn(shape, generator=gen(900 + si)) * torch.linspace(0.3, 3, C).view(1, -1, 1, 1)).to(dt)
+                xcl = x.contiguous(memory_format=torch.channels_last)
+                for mshape in ((1, C, 1, 1), (1, C, H, W), (1, C, H, 1), (1, 1, H, W), (1, C, 1, W), (1, 1, 1, 1)):
+                    ref = O.squeeze_mean(xcl.abs(), mshape)
+                    got = squeeze_tensor_to_shape(xcl.to(DEV).abs(), mshape)
+                    assert got.shape == ref.shape and same(got.cpu().contiguous(), ref.contiguous()), (shape, dt, mshape)
+        # whole PruneLayer trajectories on channels_last inputs: C % 8 != 0, L0 magnitudes, a (1, C, H, W) mask
+        for kw, dims, shape in ((dict(), {1}, (8, 12, 6, 6)), (dict(l0=True), {1}, (8, 12, 6, 6)), (dict(l0=True), {1}, (8, 16, 6, 6)),
+                                (dict(), {1, 2, 3}, (8, 6, 5, 5))):
+            for dt in (torch.float32, torch.bfloat16):
+                sim = O.PruneSim(0.5, sorted(dims), 1, 1, 2, False, l0=kw.get("l0", False))
+                layer = qs.prune(sparsity=0.5, dimensions=dims, start=1, interval=1, repetition=2,
+                                 callback=qs.MagnitudePruningCallback(**kw)).to(DEV).train()
+                for s in range(6):
+                    x = (torch.randn(shape, generator=gen(950 + s)) * torch.linspace(0.2, 2, shape[1]).view(1, -1, 1, 1)).relu().to(dt)
+                    xcl = x.contiguous(memory_format=torch.channels_last)
+                    y = layer(xcl.to(DEV))
+                    y_ref = sim.step(xcl)
+                    assert same(y.cpu().contiguous(), y_ref.contiguous()), (kw, dims, dt, s)
+                    assert same(layer.mask.cpu(), sim.mask), (kw, dims, dt, s)
+                    if sim.magnitude is not None:
+                        assert same(layer.callback.magnitude.cpu(), sim.magnitude), (kw, dims, dt, s)
+    finally:
+        torch.set_num_threads(threads)

@@ -56,6 +56,11 @@ def one():
         a16 = torch.zeros(16, 32, device="cuda")
         r["all_16lines"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), a16.data_ptr(), 0, 1, 1, x.numel(), 1, 1, 0, 16, None, 0, None))
         r["chan"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N, C, H * W, 1, 1, 0, 1, None, 0, None))
+        nb = lib.qs_workspace_bytes(2, C)
+        if nb and C % 8 == 0:      # the same tensor taken as channels_last: [N*H*W, C], channel dim innermost (reduce_fewcols_kernel)
+            ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            r["chan_cl"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N * H * W, C, 1, 1, 1, 0, 1, ws.data_ptr(), nb, None))
+            r["chan_cl_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N * H * W, C, 1, 1, ws.data_ptr(), nb, None))
         r["chan_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N, C, H * W, 1, None, 0, None))
         r["ideal@6TB/s"] = round(x.numel() * 2 / 6e6, 1)
         out[str(shp)] = r
