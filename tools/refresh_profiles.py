@@ -3,12 +3,13 @@
 
   rNN_bench_default.json                 the JSON record of a plain `python3 bench.py`
   rNN_bench_kernel_stats.csv             rocprofv3 --kernel-trace --stats summary of the same command
-  rNN_bench_step_timeline.txt            the last three steps of that trace, kernel by kernel
+  rNN_bench_step_timeline.txt            the last three headline steps of that trace, kernel by kernel
+  rNN_configN_kernel_stats.csv           the same summary for `python3 bench.py --configs-only configN` (N = 2, 3, 4)
   rNN_pmc_<COUNTER>_counter_collection.csv   rocprofv3 --pmc <COUNTER> rows of the library's kernels (one pass per counter)
   rNN_pmc_traffic.json                   HBM bytes per launch of the three streaming kernels, corrected as
                                          /opt/skills/guides/MI355X_MICROARCH.md prescribes, next to the algorithmic bytes
 
-usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r01]
+usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r02]
 """
 import csv
 import glob
@@ -19,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 BENCH = os.path.join(ROOT, "bench.py")
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -56,26 +57,41 @@ def main():
     rows = list(csv.DictReader(open(find(os.path.join(d, "**", "*kernel_trace.csv")))))
     rows.sort(key=lambda x: int(x["Start_Timestamp"]))
     qs_rows = [x for x in rows if "qs::" in x["Kernel_Name"]]
-    tail = qs_rows[-15:]
+    # the "off" variant runs right after the timed region and is the only user of the dense (non-eliding) widening
+    # forward: the 15 library launches before its first launch are the last three steps of the timed region
+    def dense_fwd(name):
+        base = name.split("(")[0].rstrip()
+        return "ew_widen_kernel" in base and base.endswith("false>")
+
+    end = next((i for i, x in enumerate(qs_rows) if dense_fwd(x["Kernel_Name"])), len(qs_rows))
+    tail = qs_rows[max(end - 15, 0):end]
     with open(os.path.join(OUT, f"{TAG}_bench_step_timeline.txt"), "w") as f:
         f.write("rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py\n")
-        f.write("last 3 steps of the timed region (durations under the profiler; a gap holds a HIP event pair on sampled steps)\n\n")
+        f.write("3 consecutive headline steps of the timed region (durations under the profiler; a gap holds a HIP event pair on sampled steps)\n\n")
         prev_end = None
         for x in tail:
-            s, e = int(x["Start_Timestamp"]), int(x["End_Timestamp"])
-            gap = 0.0 if prev_end is None else (s - prev_end) / 1e3
+            s_, e = int(x["Start_Timestamp"]), int(x["End_Timestamp"])
+            gap = 0.0 if prev_end is None else (s_ - prev_end) / 1e3
             name = x["Kernel_Name"].split("(")[0]
-            f.write(f"{name:72s} dur={(e - s) / 1e3:8.1f}us gap={gap:6.1f}us grid={x.get('Grid_Size_X', x.get('Grid_Size', '?')):>10s} wg={x.get('Workgroup_Size_X', x.get('Workgroup_Size', '?')):>4s} "
+            f.write(f"{name:84s} dur={(e - s_) / 1e3:8.1f}us gap={gap:6.1f}us grid={x.get('Grid_Size_X', x.get('Grid_Size', '?')):>10s} wg={x.get('Workgroup_Size_X', x.get('Workgroup_Size', '?')):>4s} "
                     f"vgpr={x.get('VGPR_Count', '?')}\n")
             prev_end = e
     shutil.rmtree(d)
+
+    # 2b. per-config kernel stats (BASELINE configs 2-4), each from its own command
+    for cfg in ("config2", "config3", "config4"):
+        d = os.path.join(OUT, "stats_" + cfg)
+        if sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+               "python3", BENCH, "--configs-only", cfg]).returncode == 0:
+            shutil.copy(find(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(OUT, f"{TAG}_{cfg}_kernel_stats.csv"))
+        shutil.rmtree(d, ignore_errors=True)
 
     # 3. PMC passes, one counter each (never combined with other trace domains)
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(OUT, "pmc_" + counter)
         assert sh(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "bench", "--",
-                   "python3", BENCH, "--steps", "8", "--warmup", "3", "--no-cpu-baseline"]).returncode == 0
+                   "python3", BENCH, "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-configs", "--no-variants"]).returncode == 0
         src = find(os.path.join(d, "**", "*counter_collection.csv"))
         rows = [x for x in csv.DictReader(open(src)) if "qs::" in x["Kernel_Name"]]
         rows = rows[-8 * 5:]                                     # the 8 timed steps, 5 launches each
@@ -92,17 +108,22 @@ def main():
         assert len(names) == 1, (sub, list(per))
         return names[0]
 
-    kernels = {"apply_fwd": (pick("ew_widen_kernel<qs::ScalerFwdOp"), 6 * NUMEL), "apply_bwd": (pick("SteBwdOp"), 6 * NUMEL),
+    kept = rec["config"]["kept_channel_fraction"]
+    bpe = rec["config"]["algorithmic_bytes_per_elem"]
+    kernels = {"apply_fwd": (pick("ew_widen_kernel<qs::ScalerFwdOp"), int(round(bpe["apply_fwd"] * NUMEL))),
+               "apply_bwd": (pick("SteBwdOp"), int(round(bpe["apply_bwd"] * NUMEL))),
                "stats": (pick("mean_outer_vec_kernel"), 2 * NUMEL)}
     traffic = {
         "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 8 --warmup 3 "
-                   "--no-cpu-baseline  (one pass per counter; tools/refresh_profiles.py)",
+                   "--no-cpu-baseline --no-configs --no-variants  (one pass per counter; tools/refresh_profiles.py)",
+        "mode": rec["config"]["elide_pruned"], "kept_channel_fraction": kept,
+        "note": "algorithmic_bytes are mask-aware: the apply forward of the default mode reads only the kept channels "
+                "((2*kept + 4) B/elem); FETCH_SIZE must show the same drop",
         "unit": "bytes per launch",
         "correction": "FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts a wide coalesced streaming "
                       "read at exactly half its bytes (MI355X_MICROARCH.md, HBM section), so fetch bytes = FETCH_SIZE*1024*2.  "
-                      "That section calibrates 16-byte/lane loads, which is what all three kernels issue (the apply forward as "
-                      "well since it takes one 16-byte load per lane); cross-check on the forward's known input: "
-                      "FETCH_SIZE*1024*2 reproduces the 411,041,792-byte bf16 tensor.  "
+                      "That section calibrates 16-byte/lane loads, which is what all three kernels issue; cross-check on the "
+                      "statistics kernel's known input: FETCH_SIZE*1024*2 reproduces the 411,041,792-byte bf16 tensor.  "
                       "WRITE_SIZE is used as reported.",
         "kernels": {},
     }
