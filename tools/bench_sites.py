@@ -32,23 +32,23 @@ def run(site, shape, nbuf, bytes_per_elem, label, steps=200):
     for i in range(50):
         torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
     torch.cuda.synchronize()
-    graphs = None
-    if GRAPH:      # one captured step per buffer: what the kernels alone take, without the Python between them
-        graphs = []
-        for k in range(nbuf):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+    graph = None
+    if GRAPH:      # ONE captured graph of nbuf steps (a hipGraphLaunch costs more than a 3-kernel step): what the kernels
+        #            alone take, without the Python between them
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for k in range(nbuf):
                 torch.autograd.grad(site(xs[k]), xs[k], g)
-            graphs.append(gr)
-        for k in range(nbuf):
-            graphs[k].replay()
+        graph.replay()
         torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for i in range(steps):
-        if graphs:
-            graphs[i % nbuf].replay()
-        else:
+    if graph:
+        for i in range(steps // nbuf):
+            graph.replay()
+        steps = (steps // nbuf) * nbuf
+    else:
+        for i in range(steps):
             torch.autograd.grad(site(xs[i % nbuf]), xs[i % nbuf], g)
     b.record()
     torch.cuda.synchronize()

@@ -60,7 +60,7 @@ def main():
                 def stats_cl():      # the same activation in NHWC memory order through qs_mean_dim_cl
                     turn[0] += 1
                     assert lib.qs_mean_dim_cl(xs[turn[0] % nrot].data_ptr(), stage.data_ptr(), N, H * W, C, code, code, 1 | 4,
-                                              None if noabs else part.data_ptr(), None) == 0
+                                              None, None if noabs else part.data_ptr(), None) == 0
 
                 def stats():
                     turn[0] += 1
