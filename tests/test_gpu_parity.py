@@ -1126,3 +1126,85 @@ def test_channels_last_statistics_any_channel_count_masks_and_l0_vs_oracle():
                         assert same(layer.callback.magnitude.cpu(), sim.magnitude), (kw, dims, dt, s)
     finally:
         torch.set_num_threads(threads)
+
+
+def test_folded_relu_propagates_nan_like_the_module_by_module_path():
+    """ATen's relu keeps NaN (clamp_min = max(0, x)); the folded kernels must not turn a diverged activation into a clean
+    zero.  A NaN input gives the same (NaN-carrying) scale, output and gradient with and without the fold -- the fused
+    pair, the ReLU -> quantize site and the ReLU -> prune site."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    shape = (4, 16, 8, 8)
+    for si, make in enumerate((
+            lambda: nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1)),
+            lambda: nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                                  qs.quantize(bits=4, channelwise=-1, timeout=1)),
+            lambda: nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)))):
+        runs = []
+        for fold in (True, False):
+            qs.set_qsparse_options(fold_relu=fold)
+            site = fuse_prune_quantize_pairs(make().to(DEV).train())
+            outs = []
+            for s in range(4):
+                x = torch.randn(shape, generator=gen(3100 + s)).bfloat16()
+                if s == 2:
+                    x[1, 3, 2, 2] = float("nan")        # a kept or pruned channel, whichever the mask says
+                    x[0, 5, 0, 0] = float("nan")
+                xg = x.to(DEV).requires_grad_(True)
+                y = site(xg)
+                y.backward(torch.ones_like(y))
+                outs.append((y.detach().cpu(), xg.grad.cpu()))
+            runs.append(outs)
+        qs.set_qsparse_options(fold_relu=True)
+        for s, ((ya, ga), (yb, gb)) in enumerate(zip(*runs)):
+            assert same(ya, yb) and same(ga, gb), s
+        if si != 1:     # (in the pair a NaN channel has NaN magnitude, is pruned, and never reaches the output or the scale)
+            assert bool(runs[0][2][0].isnan().any())      # the NaN is visible in the step that received it
+
+
+def test_fused_sites_with_hooks_on_children_run_module_by_module():
+    """forward (pre-)hooks registered on the PruneLayer / QuantizeLayer / ReLU children of a convert-built site keep
+    firing on the GPU: a hooked site falls back to q(p(act(x))) -- same numbers, the fused path just is not taken."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    shape = (4, 16, 8, 8)
+
+    def build():
+        torch.manual_seed(0)
+        return fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train())
+
+    plain, hooked = build(), build()
+    seen = {"relu": 0, "prune": 0, "quant": 0, "pre": 0}
+    hooked[0][0].register_forward_hook(lambda m, i, o: seen.__setitem__("relu", seen["relu"] + 1))
+    hooked[0][1].register_forward_hook(lambda m, i, o: seen.__setitem__("prune", seen["prune"] + 1))
+    hooked[1].register_forward_hook(lambda m, i, o: seen.__setitem__("quant", seen["quant"] + 1))
+    hooked[1].register_forward_pre_hook(lambda m, i: seen.__setitem__("pre", seen["pre"] + 1))
+    for s in range(5):
+        x = torch.randn(shape, generator=gen(3200 + s)).bfloat16().to(DEV)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = plain(xa), hooked(xb)
+        ya.backward(torch.ones_like(ya)), yb.backward(torch.ones_like(yb))
+        assert same(ya.detach().cpu(), yb.detach().cpu()) and same(xa.grad.cpu(), xb.grad.cpu()), s
+        assert same(plain[0][1].mask.cpu(), hooked[0][1].mask.cpu())
+    assert seen == {"relu": 5, "prune": 5, "quant": 5, "pre": 5}
+
+
+def test_channel_mismatch_in_eval_raises_runtime_error_like_the_reference():
+    """reference tests/test_sparse.py:75-96: a channel mask meets an input with another channel count in evaluation mode
+    -> RuntimeError (the broadcast of x * mask), also on the fused GPU path (it used to be an AssertionError)."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    pair = fuse_prune_quantize_pairs(nn.Sequential(
+        nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+        qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train())
+    for s in range(3):
+        pair(torch.randn(4, 16, 8, 8, generator=gen(3300 + s)).to(DEV))
+    pair.eval()
+    assert pair(torch.randn(2, 16, 5, 5).to(DEV)).shape == (2, 16, 5, 5)        # other spatial size: the channel mask broadcasts (quirk B17)
+    with pytest.raises(RuntimeError):
+        pair(torch.randn(2, 12, 8, 8).to(DEV))
+    lone = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1).to(DEV).train()
+    for s in range(3):
+        lone(torch.randn(4, 16, 8, 8, generator=gen(3400 + s)).to(DEV))
+    lone.eval()
+    with pytest.raises(RuntimeError):
+        lone(torch.randn(2, 12, 8, 8).to(DEV))

@@ -99,6 +99,23 @@ def test_steady_state_detection():
         assert flags[:4] == [False] * 4 and flags[-1] is True
         qs.set_qsparse_options(graph_safe=False)
         assert graphs.steady_state(pair) is False
+        # a live L0 callback takes a host-side decision (flag.item()) on every step for 2-byte inputs: never capturable
+        # while its mask still refreshes; capturable once the refresh has stopped for good
+        qs.set_qsparse_options(graph_safe=True)
+        for stop, expect in ((float("inf"), False), (3, True)):
+            pl = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1,
+                          callback=qs.MagnitudePruningCallback(l0=True, stop_mask_refresh=stop)).cuda().train()
+            xb = torch.randn(4, 8, 4, 4, device="cuda").relu().bfloat16()
+            for _ in range(7):
+                pl(xb)
+            assert graphs.steady_state(pl) is expect, stop
+            if expect:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    y = pl(xb)
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(y, xb * pl.mask)
     finally:
         qs.set_qsparse_options(graph_safe=False)
 
