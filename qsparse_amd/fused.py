@@ -240,9 +240,15 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
 
 
 def _hooked(*modules) -> bool:
-    """forward (pre-)hooks registered on a child: the fused forward never calls the child, so its hooks would not
-    fire -- such a site runs module by module, exactly as the plain ``Sequential`` it replaces"""
-    return any(m._forward_hooks or m._forward_pre_hooks for m in modules)
+    """hooks registered on a child (forward, forward-pre, backward, backward-pre) or installed globally for all modules:
+    the fused forward never calls the children, so their hooks would not fire -- such a site runs module by module,
+    exactly as the plain ``Sequential`` it replaces"""
+    from torch.nn.modules import module as _m
+
+    if (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks
+            or _m._global_backward_pre_hooks):
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in modules)
 
 
 class FusedPruneQuantize(nn.Sequential):

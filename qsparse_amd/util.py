@@ -109,7 +109,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         if xm is not like:
             N, C, H, W = x.shape
             flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
-            fusable = (dims == [0, 2, 3] and l0_flag is None and C % 8 == 0 and (H * W + W) * 4 <= 48 * 1024
+            fusable = (dims == [0, 2, 3] and l0_flag is None and (H * W + W) * 4 <= 48 * 1024
                        and flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU)
                        and not (flags == 0 and absmax_out is not None))
             if fusable:       # stages 2 + 3 in one launch, which also folds the per-element maxima per channel

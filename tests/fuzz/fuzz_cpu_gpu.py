@@ -292,9 +292,8 @@ def one_case(rng, idx, dry=False):
     steps = rng.choice([3, 5, 6])
     eval_from = rng.choice([steps, steps - 1])
     channels_last = rng.random() < 0.4
-    if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact where a native kernel exists
-        channels_last = (channels_last and desc.get("dimensions", [1]) == [1] and shape[1] % 8 == 0 and shape[0] > 1
-                         and len(shape) == 4 and desc.get("policy") != "l0")
+    if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact whenever the batch dim is reduced first
+        channels_last = (channels_last and 0 not in desc.get("dimensions", [1]) and shape[0] > 1 and len(shape) == 4)
     batcher = rng.random() < 0.6
     desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher)
     if dry:
@@ -325,7 +324,7 @@ def one_case(rng, idx, dry=False):
 
 
 def main():
-    torch.set_num_threads(min(8, torch.get_num_threads()))     # see tests/fuzz/fuzz_parity.py
+    torch.set_num_threads(min(4, torch.get_num_threads()))     # see tests/fuzz/fuzz_parity.py
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)

@@ -54,20 +54,21 @@ def one_case(rng, idx):
     channels_last = rng.random() < 0.35
     preserve = rng.random() < 0.2
     graph_safe = rng.random() < 0.25       # counters read from (and advanced in) device memory by the kernels
+    elide = rng.choice(["forward", "forward", "off", "all"])      # mask-aware load elision (qs_elementwise.h)
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last, preserve, graph_safe)
+                    channels_last, preserve, graph_safe, elide)
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False, preserve=False, graph_safe=False):
+             channels_last=False, preserve=False, graph_safe=False, elide="forward"):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe)
+                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -75,7 +76,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
     k = max(int(sparsity * shape[1] - 1), 0) + 1
     if k >= shape[1]:
         return None
-    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve, graph_safe=graph_safe and DEV != "cpu")
+    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve, graph_safe=graph_safe and DEV != "cpu", elide_pruned=elide)
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
     has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
     has_p = has_p or "pair" in site_kind
@@ -98,9 +99,9 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (fp16 underflow): torch's own CPU and GPU ReLU disagree on its sign
-        # channels_last statistics are bit-exact for the configuration with a native kernel (C % 8 == 0, a batch to
-        # reduce); other channels_last inputs are summed in NCHW order, 1 ulp away from ATen's layout-dependent order
-        cl = channels_last and len(shape) == 4 and shape[1] % 8 == 0 and shape[0] > 1
+        # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count); a batch of one
+        # is summed in NCHW order after a copy, 1 ulp away from ATen's layout-dependent order
+        cl = channels_last and len(shape) == 4 and shape[0] > 1
         if cl:                      # the oracle then sees ATen's channels_last behaviour (summation order included)
             x = x.contiguous(memory_format=torch.channels_last)
         xg = x.to(DEV).requires_grad_(True)
@@ -124,7 +125,12 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
             gr = ps.grad(gr, (not training) or n_before >= start)
         if has_relu:
             gr = torch.where(x <= 0, torch.zeros_like(gr), gr)
-        ok = same(y.detach().cpu(), y_ref) and same(xg.grad.cpu(), gr.to(dtype))
+        if elide == "all":      # backward / mask apply write +0.0 where the reference's g*0 / x*0 has -0.0: compare as numbers
+            def same_num(a, b):
+                return a.dtype == b.dtype and a.shape == b.shape and bool(((a.float() == b.float()) | (a.isnan() & b.isnan())).all())
+            ok = same_num(y.detach().cpu(), y_ref) and same_num(xg.grad.cpu(), gr.to(dtype))     # (y: an inactive quantizer leaves x*mask)
+        else:
+            ok = same(y.detach().cpu(), y_ref) and same(xg.grad.cpu(), gr.to(dtype))
         if VERBOSE and not same(y.detach().cpu(), y_ref) and y.shape == y_ref.shape:
             bad = (y.detach().cpu().view(-1).view(torch.int16 if y.element_size() == 2 else torch.int32)
                    != y_ref.contiguous().view(-1).view(torch.int16 if y_ref.element_size() == 2 else torch.int32)).nonzero().view(-1)[:6]
@@ -162,9 +168,10 @@ DRY = False
 
 
 def main():
-    # ATen's CPU reduction of a channels_last tensor depends on how its threads split the work (the 128-thread result
-    # differs from the 1..32-thread one in half of the elements); the kernels reproduce the few-thread order
-    torch.set_num_threads(min(8, torch.get_num_threads()))
+    # ATen's CPU reduction of a channels_last tensor depends on how its threads split the work (at 8 threads a few
+    # small-channel shapes such as (N, 6, 28, 28) already differ from its own 1..4-thread result, at 128 threads half of
+    # all elements do); the kernels reproduce the 1..4-thread order
+    torch.set_num_threads(min(4, torch.get_num_threads()))
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)

@@ -26,7 +26,7 @@ def t_us(fn, iters=30):
     return ts[len(ts) // 2] * 1e3
 
 
-for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7)):
+for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7), (256, 256, 56, 56), (256, 1024, 14, 14)):
     for xdt in (torch.float32, torch.bfloat16):
         for cl in (False, True):
             C = shape[1]
