@@ -22,7 +22,6 @@ statistics are exchanged over RCCL each step (qsparse_amd/distributed.py).  At N
 ImageNet shape, plain vs converted, eager and hipGraph replay) measured in the same process.
 """
 import argparse
-import copy
 import json
 import os
 import sys

@@ -170,6 +170,20 @@ void qo_mean_dim(const float* x, int64_t pre, int64_t n, int64_t post, float* ou
     }
 }
 
+/* The same stage for a channels_last (NHWC in memory) activation x[n][hw][C] (what `Tensor.mean(0, keepdim=True)` does
+ * on such a tensor; qsparse/util.py:92-99 reaches it whenever the network runs in torch.channels_last): the result is
+ * NCHW-contiguous, out[c*hw + pos], and ATen (one intra-op thread) sums position `pos` of every channel in multi-row
+ * order when pos < 4*floor(hw/4) and in row-sum order otherwise -- for ANY channel count. */
+void qo_mean_dim_cl(const float* x, int64_t n, int64_t hw, int64_t C, float* out) {
+    const int64_t sample = hw * C, main_pos = (hw / 4) * 4;
+    for (int64_t pos = 0; pos < hw; ++pos)
+        for (int64_t c = 0; c < C; ++c) {
+            const float* base = x + pos * C + c;
+            const float s = pos < main_pos ? sum_multi_row(base, sample, n) : sum_row_sum(base, sample, n);
+            out[c * hw + pos] = s / (float)n;
+        }
+}
+
 /* calculate_mask_given_importance, qsparse/util.py:113-117: thr = sort(imp)[k]; mask = imp >= thr */
 static int cmp_float(const void* a, const void* b) {
     const float x = *(const float*)a, y = *(const float*)b;

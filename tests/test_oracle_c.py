@@ -80,6 +80,28 @@ def test_c_staged_mean_matches_aten_order(clib):
             assert torch.equal(cur.to(dtype), O.squeeze_mean(x, mshape)), (dtype, shape)
 
 
+def test_c_channels_last_stage_matches_aten_order(clib):
+    """the channels_last first stage (any channel count) against ATen's CPU result on channels_last tensors, one to four
+    intra-op threads (at 8 threads ATen's own result changes for a few small-channel shapes)"""
+    threads = torch.get_num_threads()
+    try:
+        for nthr in (1, min(4, threads)):
+            torch.set_num_threads(nthr)
+            for dtype in (torch.float32, torch.bfloat16):
+                for shape in ((16, 3, 5, 5), (64, 12, 7, 7), (33, 20, 3, 3), (256, 6, 4, 6), (40, 10, 14, 14), (128, 36, 2, 2),
+                              (17, 5, 1, 7), (64, 8, 7, 7), (64, 100, 6, 1), (64, 2, 28, 28), (33, 6, 28, 28), (48, 64, 8, 8)):
+                    N, C, H, W = shape
+                    x = torch.randn(shape, generator=gen(31)).abs().to(dtype).contiguous(memory_format=torch.channels_last)
+                    ref = x.mean(0, keepdim=True)                        # the reference's first squeeze stage on this tensor
+                    assert ref.is_contiguous()                           # ... is NCHW-contiguous
+                    xm = x.float().permute(0, 2, 3, 1).contiguous()      # [N, H, W, C]: the tensor as it lies in memory
+                    out = torch.empty(C * H * W)
+                    clib.qo_mean_dim_cl(fp(xm), I64(N), I64(H * W), I64(C), fp(out))
+                    assert torch.equal(out.to(dtype).view(1, C, H, W), ref), (nthr, dtype, shape)
+    finally:
+        torch.set_num_threads(threads)
+
+
 def test_c_mask_and_running_mean(clib):
     imp = torch.rand(5000, generator=gen(9))
     imp = (imp * 40).floor() / 40
