@@ -216,7 +216,9 @@ def resnet_config(arch, batch, device, steps):
         torch.cuda.synchronize()
         with torch.cuda.graph(gr):
             step()
-        gr.replay()
+        for _ in range(3):      # the first replays of a large graph carry one-time work (observed: 64.9 vs 59.0 ms/step)
+            gr.replay()
+        torch.cuda.synchronize()
         return gr
 
     # plain network
@@ -251,8 +253,28 @@ def resnet_config(arch, batch, device, steps):
         masks = [m.mask.float().mean().item() for m in model.modules() if isinstance(m, qs.sparse.PruneLayer)]
         out["mean_kept_channel_fraction"] = round(sum(masks) / max(len(masks), 1), 4)
         del model, step, gr
+        torch.cuda.empty_cache()
+
+        # the same network with every opt-in extension of the library switched on (none of them is the default, none of
+        # them enters the numbers above): bf16 outputs instead of the reference's fp32 promotion (preserve_dtype), all
+        # weight quantizers in three multi-tensor launches (WeightBatcher), backward / mask-apply elision
+        qs.set_qsparse_options(preserve_dtype=True, elide_pruned="all")
+        model, step = build(True)
+        qs.WeightBatcher(model)
+        for _ in range(8):
+            step()
+        opt_in = {"options": "preserve_dtype=True, elide_pruned='all', qs.WeightBatcher(model)",
+                  "pq_ms": round(_timed_loop(step, steps), 3)}
+        if graphs.steady_state(model):
+            gr = capture(step)
+            opt_in["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
+            del gr
+        opt_in["best_over_plain"] = round(min(v for k, v in opt_in.items() if k.endswith("_ms")) /
+                                          min(out["plain_ms"], out["plain_graph_ms"]), 4)
+        out["opt_in_extensions"] = opt_in
+        del model, step
     finally:
-        qs.set_qsparse_options(graph_safe=False)
+        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward")
         torch.cuda.empty_cache()
     return out
 
