@@ -1,0 +1,67 @@
+"""The driver's contract for bench.py (task statement): ONE JSON line on stdout with the prescribed keys, launched
+exactly as the driver launches it -- plain for N = 1, through `python -m torch.distributed.run` for N > 1 (here two
+ranks sharing the box's single GPU over gloo, QS_BENCH_SHARE_GPU=1, which drives the whole N > 1 code path: rendezvous,
+statistics exchange every step, barrier + max-over-ranks timing, rank-0-only output)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check(rec, n, steps):
+    assert KEYS <= set(rec), sorted(KEYS - set(rec))
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert rec["metric"] == baseline["metric"] and rec["unit"] == "Gelem/s"
+    assert rec["n_gpus"] == n and rec["steps"] == steps and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert rec["vs_baseline"] is None and rec["dtype"] == "f32" and rec["data"] == "synthetic"
+    numel = 256 * 256 * 56 * 56
+    assert abs(rec["value"] - n * numel / (rec["ms_per_step"] * 1e-3) / 1e9) < 0.01 * rec["value"]      # whole-job aggregate
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert 0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    for k in roof["kernels"].values():
+        assert 0 < k["frac"] <= 1.0        # mask-aware byte counts: no kernel "beats" the roofline
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+
+
+def test_single_gpu_line_with_roofline_variants_and_cpu_baseline():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "2", "--no-configs"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    _check(rec, 1, 24)
+    assert rec["config"]["elide_pruned"] == "forward" and set(rec["config"]["variants"]) == {"off", "all"}
+    assert rec["config"]["variants"]["all"]["ms_per_step"] < rec["ms_per_step"] < rec["config"]["variants"]["off"]["ms_per_step"] * 1.02
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and 0 < cpu["value"] < rec["value"]
+    assert rec["roofline"]["algorithmic_bytes_per_launch"] in (6 * 256 * 256 * 56 * 56,
+                                                               int(round(rec["config"]["algorithmic_bytes_per_elem"]["apply_fwd"] * 256 * 256 * 56 * 56)))
+
+
+def test_two_ranks_through_torch_distributed_run():
+    env = dict(os.environ, QS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                # rank 0 only
+    rec = json.loads(lines[0])
+    _check(rec, 2, 12)
+    assert "exchange" in rec["config"] and "configs" not in rec and "cpu_baseline" not in rec
