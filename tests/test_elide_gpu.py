@@ -40,7 +40,10 @@ SHAPES = [(4, 16, 8, 8),        # rows of 64: CM_ROW, whole waves
           (2, 8, 3, 1),         # rows shorter than a lane
           (9, 40, 56, 56),      # many full waves + reverse walk
           (6, 33),              # 2-d activation: channel dim innermost, C % 8 != 0
-          (64, 48)]             # 2-d, C % 8 == 0: CM_LAST
+          (64, 48),             # 2-d, C % 8 == 0: CM_LAST
+          (3, 5, 8, 8),         # whole waves + a partial last wave (960 elements), rows shorter than a wave
+          (2, 3, 24, 24),       # rows of 576 >= 512 elements (wave-uniform mask look-up) with a partial last wave
+          (3, 4, 32, 40)]       # rows of 1280 elements: waves inside one row, waves straddling two rows
 
 
 def _mask(C, seed, keep=0.3):
