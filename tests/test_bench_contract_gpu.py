@@ -47,7 +47,7 @@ def test_single_gpu_line_with_roofline_variants_and_cpu_baseline():
     rec = json.loads(lines[0])
     _check(rec, 1, 24)
     assert rec["config"]["elide_pruned"] == "forward" and set(rec["config"]["variants"]) == {"off", "all"}
-    assert rec["config"]["variants"]["all"]["ms_per_step"] < rec["ms_per_step"] < rec["config"]["variants"]["off"]["ms_per_step"] * 1.02
+    assert rec["config"]["variants"]["all"]["ms_per_step"] < rec["ms_per_step"] < rec["config"]["variants"]["off"]["ms_per_step"] * 1.05
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and 0 < cpu["value"] < rec["value"]
     assert rec["roofline"]["algorithmic_bytes_per_launch"] in (6 * 256 * 256 * 56 * 56,
