@@ -146,6 +146,22 @@ __device__ __forceinline__ void store8(void* base, int64_t g, const float (&v)[8
     }
 }
 
+// eight copies of one value (the eliding kernels' pruned lanes): ONE conversion instead of eight
+template <int DT, bool NT>
+__device__ __forceinline__ void store8_splat(void* base, int64_t g, float z) {
+    if constexpr (DT == QS_F32) {
+        const uint32_t w = __float_as_uint(z);
+        const u32x4 a = {w, w, w, w};
+        u32x4* p = (u32x4*)base + 2 * g;
+        st16<NT>(p, a);
+        st16<NT>(p + 1, a);
+    } else {
+        const uint32_t h = (DT == QS_BF16) ? f32_to_bf16_bits(z) : f32_to_f16_bits(z);
+        const uint32_t w = h | (h << 16);
+        st16<NT>((u32x4*)base + g, u32x4{w, w, w, w});
+    }
+}
+
 __device__ __forceinline__ void store8_i32(int32_t* base, int64_t g, const int32_t (&q)[8]) {
     u32x4 a, b;
 #pragma unroll

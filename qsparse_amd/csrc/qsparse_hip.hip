@@ -17,6 +17,9 @@
 #ifndef QS_EW_UNROLL_ELIDE
 #define QS_EW_UNROLL_ELIDE 2   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
 #endif
+#ifndef QS_EW_UNROLL_ROW
+#define QS_EW_UNROLL_ROW 2     // groups per lane of the dense per-row (CM_ROW) 8-per-lane kernels (three-phase path)
+#endif
 #ifndef QS_EW_NT
 #define QS_EW_NT 1
 #endif
@@ -164,14 +167,17 @@ int launch_ew_impl(const Op& op, const EwPlan& plan, bool param_per_channel, con
                 hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
             break;
-        case CM_ROW:
+        case CM_ROW: {
+            constexpr int UR = ELIDE ? QS_EW_UNROLL_ELIDE : QS_EW_UNROLL_ROW;
+            const int grid_r = grid_for(plan.geo.ngroups, UR);
             if (param_per_channel)
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, true, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, true, NT, UR, ELIDE>), dim3(grid_r), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
             else
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_ROW, false, NT, UR, ELIDE>), dim3(grid_r), dim3(kBlock), 0, s, op,
                                    plan.geo, x, y, codes);
             break;
+        }
         case CM_LAST:
             hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_LAST, false, NT, U, ELIDE>), dim3(grid), dim3(kBlock), 0, s, op,
                                plan.geo, x, y, codes);
