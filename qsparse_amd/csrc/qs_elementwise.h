@@ -302,6 +302,12 @@ __device__ __forceinline__ Raw8<DT> zero_raw8() {
     return r;
 }
 
+// first channel of element `e` (a multiple of 4) in the channel-innermost layout (CM_LAST: C % 8 == 0): 32-bit
+// arithmetic on the 8-element group index (< 2^32 by plan_ew) instead of a 64-bit modulo per lane
+__device__ __forceinline__ uint32_t last_dim_channel(int64_t e, uint32_t C) {
+    return (((uint32_t)((uint64_t)e >> 3) % (C >> 3)) << 3) + ((uint32_t)e & 7u);
+}
+
 // whether an eliding kernel may skip this lane (its parameter block says the channel is pruned); false for dense kernels
 // and for ops without a mask (their P has no `keep`)
 template <bool ELIDE, typename P>
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
             } else if constexpr (CM == CM_LAST) {
-                const uint32_t c0 = (uint32_t)(((uint64_t)g * 8) % geo.C);
+                const uint32_t c0 = last_dim_channel(g * 8, geo.C);
                 const uint8_t* mp = op.mask_ptr();
                 u32x2 mm = {0x01010101u, 0x01010101u};
                 if (mp) mm = *(const u32x2*)(mp + c0);
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
             if constexpr (CM == CM_LAST) {
                 const uint8_t* mp = op.mask_ptr();
                 u32x2 mm = {0x01010101u, 0x01010101u};
-                if (mp) mm = *(const u32x2*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 8 consecutive channels
+                if (mp) mm = *(const u32x2*)(mp + last_dim_channel(e, geo.C));   // 8 consecutive channels
                 if constexpr (ELIDE) {
                     Raw8<XDT> r = zero_raw8<XDT>();
                     if ((mm[0] | mm[1]) != 0u) r = load8_raw<XDT, NT>(x, e / 8);
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                     need = p.keep != 0.0f;
                 } else {
                     const uint8_t* mp = op.mask_ptr();
-                    if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));
+                    if (mp) mm = *(const uint32_t*)(mp + last_dim_channel(e, geo.C));
                     need = mm != 0u;
                 }
             }
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                 }
                 if constexpr (CM == CM_LAST) {
                     const uint8_t* mp = op.mask_ptr();
-                    if (mp) mm = *(const uint32_t*)(mp + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+                    if (mp) mm = *(const uint32_t*)(mp + last_dim_channel(e, geo.C));   // 4 consecutive channels
                 }
             }
             int32_t q;
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                         need = op.cmask[c] != 0;
                     }
                 } else if constexpr (ELIDE && CM == CM_LAST) {
-                    need = *(const uint32_t*)(op.cmask + (uint32_t)((uint64_t)e % geo.C)) != 0u;
+                    need = *(const uint32_t*)(op.cmask + last_dim_channel(e, geo.C)) != 0u;
                 }
                 if (need) {
                     rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 if constexpr (CM == CM_LAST) {
                     const SteBwdOp::P p0 = op.channel(0);
                     uint32_t mm = 0x01010101u;
-                    if (op.cmask) mm = *(const uint32_t*)(op.cmask + (uint32_t)((uint64_t)e % geo.C));   // 4 consecutive channels
+                    if (op.cmask) mm = *(const uint32_t*)(op.cmask + last_dim_channel(e, geo.C));   // 4 consecutive channels
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f
@@ -730,8 +736,15 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 } else {
                     SteBwdOp::P p = op.channel(0);
                     if constexpr (CM == CM_ROW) {
-                        const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
-                        p = op.channel_masked(param_per_channel ? c : 0u, c);
+                        if (geo.groups_per_row >= 64u && geo.inner % 8u == 0u) {     // wave-uniform look-up (WaveRows), dense too
+                            WaveRows wr;
+                            wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)(e_wave >> 3)), geo.groups_per_row, geo.C, op.cmask);
+                            const bool first = (uint32_t)(half * 256 + lane * 4) < wr.split * 8u;
+                            p = SteBwdOp::keep_of(op.channel(param_per_channel ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
+                        } else {
+                            const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;   // inner % 4 == 0: 4 elements share a row
+                            p = op.channel_masked(param_per_channel ? c : 0u, c);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 need = op.cmask[c] != 0;
             }
         } else if constexpr (ELIDE && CM == CM_LAST) {
-            const u32x2 m8 = *(const u32x2*)(op.cmask + (uint32_t)(((uint64_t)grp * 8) % geo.C));
+            const u32x2 m8 = *(const u32x2*)(op.cmask + last_dim_channel(grp * 8, geo.C));
             need = (m8[0] | m8[1]) != 0u;
         }
         if (need) {
@@ -772,13 +785,22 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
 #pragma unroll
             for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
         } else if constexpr (CM == CM_ROW) {
-            const uint32_t c = (uint32_t)((uint64_t)grp / geo.groups_per_row) % geo.C;
-            const SteBwdOp::P p = op.channel_masked(param_per_channel ? c : 0u, c);
+            SteBwdOp::P p;
+            if (geo.groups_per_row >= 64u) {         // wave-uniform look-up (WaveRows), dense too
+                const uint32_t lane = threadIdx.x & 63u;
+                WaveRows wr;
+                wr.seek(__builtin_amdgcn_readfirstlane((uint32_t)grp - lane), geo.groups_per_row, geo.C, op.cmask);
+                const bool first = lane < wr.split;
+                p = SteBwdOp::keep_of(op.channel(param_per_channel ? (first ? wr.c0 : wr.c1) : 0u), first ? wr.k0 : wr.k1);
+            } else {
+                const uint32_t c = (uint32_t)((uint64_t)grp / geo.groups_per_row) % geo.C;
+                p = op.channel_masked(param_per_channel ? c : 0u, c);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
         } else if constexpr (CM == CM_LAST) {
             const SteBwdOp::P p0 = op.channel(0);
-            const uint32_t c0 = (uint32_t)(((uint64_t)grp * 8) % geo.C);
+            const uint32_t c0 = last_dim_channel(grp * 8, geo.C);
             u32x2 mm = {0x01010101u, 0x01010101u};
             if (op.cmask) mm = *(const u32x2*)(op.cmask + c0);
 #pragma unroll
