@@ -168,10 +168,10 @@ DRY = False
 
 
 def main():
-    # ATen's CPU reduction of a channels_last tensor depends on how its threads split the work (at 8 threads a few
-    # small-channel shapes such as (N, 6, 28, 28) already differ from its own 1..4-thread result, at 128 threads half of
-    # all elements do); the kernels reproduce the 1..4-thread order
-    torch.set_num_threads(min(4, torch.get_num_threads()))
+    # ATen's CPU reduction of a channels_last tensor depends on how its threads split the work (from 4 threads on a few
+    # small-channel shapes such as (64, 3, 14, 14) differ from its own 1-thread result -- this campaign found that one --, at
+    # 128 threads half of all elements do); the kernels reproduce the 1-thread order
+    torch.set_num_threads(1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)

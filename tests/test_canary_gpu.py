@@ -82,7 +82,7 @@ def guarded(monkeypatch):
     before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu", "preserve_dtype", "graph_safe")}
     threads = torch.get_num_threads()
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
-    torch.set_num_threads(min(4, threads))
+    torch.set_num_threads(1)
     g = _Guarded()
     monkeypatch.setattr(_hip, "torch", g)
     yield g

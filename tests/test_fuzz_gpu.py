@@ -26,7 +26,7 @@ def _quiet_and_restore():
     before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu", "preserve_dtype", "graph_safe", "elide_pruned")}
     threads = torch.get_num_threads()
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
-    torch.set_num_threads(min(4, threads))      # ATen's channels_last reductions depend on the thread split (tests/fuzz/fuzz_parity.py)
+    torch.set_num_threads(1)      # ATen's channels_last reductions depend on the thread split (tests/fuzz/fuzz_parity.py)
     yield
     torch.set_num_threads(threads)
     qs.set_qsparse_options(**before)

@@ -81,11 +81,11 @@ def test_c_staged_mean_matches_aten_order(clib):
 
 
 def test_c_channels_last_stage_matches_aten_order(clib):
-    """the channels_last first stage (any channel count) against ATen's CPU result on channels_last tensors, one to four
-    intra-op threads (at 8 threads ATen's own result changes for a few small-channel shapes)"""
+    """the channels_last first stage (any channel count) against ATen's CPU result on channels_last tensors, one and two
+    intra-op threads (from 4 threads on ATen's own result changes for a few small-channel shapes)"""
     threads = torch.get_num_threads()
     try:
-        for nthr in (1, min(4, threads)):
+        for nthr in (1, min(2, threads)):
             torch.set_num_threads(nthr)
             for dtype in (torch.float32, torch.bfloat16):
                 for shape in ((16, 3, 5, 5), (64, 12, 7, 7), (33, 20, 3, 3), (256, 6, 4, 6), (40, 10, 14, 14), (128, 36, 2, 2),

@@ -119,7 +119,7 @@ def run_sites(arch, device, site_names, batch, width=64, channels_last=False, st
     opt = torch.optim.SGD(model.parameters(), lr=0.02, momentum=0.9)
     g = torch.Generator().manual_seed(1)
     threads = torch.get_num_threads()
-    torch.set_num_threads(min(threads, 4))        # the staged mean's bits are ATen's at <= 4 CPU threads
+    torch.set_num_threads(1)                       # the staged mean's bits are ATen's with ONE intra-op thread
     try:
         for s in range(steps):
             x = torch.randn(shape, generator=g).to(device)
