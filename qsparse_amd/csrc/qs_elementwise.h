@@ -507,13 +507,21 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 // backward (contiguous 1 KiB loads, 8-byte stores) changed nothing (0.2045 vs 0.2042 ms) and was dropped:
 // it is the stores whose per-instruction footprint matters.
 // ------------------------------------------------------------------------------------------------
+#ifndef QS_WIDEN_BLOCK
+#define QS_WIDEN_BLOCK 256
+#endif
+#ifndef QS_WIDEN_NT_STORE
+#define QS_WIDEN_NT_STORE 1
+#endif
+constexpr int kWidenBlock = QS_WIDEN_BLOCK;   // threads per workgroup of the widening kernel (a wave owns 512 elements)
+
 template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT, bool ELIDE = false>
-__global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, const void* __restrict__ x,
+__global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                            float* __restrict__ y) {
     static_assert(!ELIDE || (Op::kHasMask && (CM == CM_ROW || CM == CM_LAST)), "elision needs a channel mask");
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t e_wave = (blk * (kBlock / 64) + wave) * 512;          // first element of this wave
+    const int64_t e_wave = (blk * (kWidenBlock / 64) + wave) * 512;          // first element of this wave
     typename Op::P p_scalar = op.channel(0);
     bool done = false;
     if constexpr (XDT != QS_F32) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
         // 16-byte stores still covers one contiguous 1 KiB span per instruction.  The kernel is bound by the bytes its
         // resident waves keep in flight (capping it at 4 / 2 waves per SIMD costs 1.55x / 2.3x): headline forward
         // 0.2008 -> 0.1898 ms (6.1 -> 6.5 TB/s).
-        __shared__ __attribute__((aligned(16))) float stage[kBlock * 8];
+        __shared__ __attribute__((aligned(16))) float stage[kWidenBlock * 8];
         if (e_wave + 512 <= (int64_t)geo.ngroups * 8 && (CM != CM_ROW || geo.inner % 8 == 0)) {
             float* ws = stage + wave * 512;
             const int64_t e = e_wave + lane * 8;
@@ -558,8 +566,8 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                             const uint32_t split_e = wr.split >= 64u ? 512u : wr.split * 8u;
                             const uint32_t za = __float_as_uint((uint32_t)lane * 4u < split_e ? z0 : z1);
                             const uint32_t zb = __float_as_uint(256u + (uint32_t)lane * 4u < split_e ? z0 : z1);
-                            st16<NT>((u32x4*)(y + e_wave + lane * 4), u32x4{za, za, za, za});
-                            st16<NT>((u32x4*)(y + e_wave + 256 + lane * 4), u32x4{zb, zb, zb, zb});
+                            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + lane * 4), u32x4{za, za, za, za});
+                            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + 256 + lane * 4), u32x4{zb, zb, zb, zb});
                             return;     // (inner % 8 == 0 here, so numel % 8 == 0: there is no ragged tail for this wave to serve)
                         }
                         const bool first = (uint32_t)lane < wr.split;
@@ -593,8 +601,8 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
             __builtin_amdgcn_wave_barrier();
             const u32x4 o0 = *(const u32x4*)(ws + lane * 4);
             const u32x4 o1 = *(const u32x4*)(ws + 256 + lane * 4);
-            st16<NT>((u32x4*)(y + e_wave + lane * 4), o0);
-            st16<NT>((u32x4*)(y + e_wave + 256 + lane * 4), o1);
+            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + lane * 4), o0);
+            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + 256 + lane * 4), o1);
             done = true;
         }
     }
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void ew_widen_kernel(Op op, EwGeom geo, con
                 if constexpr (CM == CM_LAST) out[j] = __float_as_uint(op.apply(v[j], Op::keep_of(p_scalar, (mm >> (8 * j)) & 0xffu), q));
                 else out[j] = __float_as_uint(op.apply(v[j], p, q));
             }
-            st16<NT>((u32x4*)(y + e), out);
+            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e), out);
         }
     }
     // ragged tail (numel % 8 elements)

@@ -143,19 +143,19 @@ int launch_ew_impl(const Op& op, const EwPlan& plan, bool param_per_channel, con
         const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
         if (ew_widen() >= (XDT == QS_F32 ? 2 : 1) && !codes && cm_w != CM_ELEM) {
             const int64_t waves = (plan.geo.ngroups * 8 + 511) / 512;
-            const int gridw = (int)std::max<int64_t>(1, (waves + kBlock / 64 - 1) / (kBlock / 64));   // < 8 elements: tail only
+            const int gridw = (int)std::max<int64_t>(1, (waves + kWidenBlock / 64 - 1) / (kWidenBlock / 64));   // < 8 elements: tail only
             if (cm_w == CM_SCALAR) {
                 if constexpr (!ELIDE)
-                    hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kBlock), 0, s, op,
+                    hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_SCALAR, false, NT>), dim3(gridw), dim3(kWidenBlock), 0, s, op,
                                        plan.geo, x, (float*)y);
             } else if (cm_w == CM_LAST)
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_LAST, false, NT, ELIDE>), dim3(gridw), dim3(kWidenBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else if (param_per_channel)
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, true, NT, ELIDE>), dim3(gridw), dim3(kWidenBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             else
-                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, false, NT, ELIDE>), dim3(gridw), dim3(kBlock), 0, s, op,
+                hipLaunchKernelGGL((ew_widen_kernel<Op, XDT, CM_ROW, false, NT, ELIDE>), dim3(gridw), dim3(kWidenBlock), 0, s, op,
                                    plan.geo, x, (float*)y);
             return launch_status();
         }

@@ -83,6 +83,12 @@ int main() {
         run<1, 0, true, 1024>(buf, bytes, "wave-contig");
         run<2, 1, true, 1024>(buf, bytes, "wg-contig");
         run<4, 1, true, 1024>(buf, bytes, "wg-contig");
+        run<1, 0, true, 128>(buf, bytes, "wave-contig");
+        run<2, 0, true, 128>(buf, bytes, "wave-contig");
+        run<2, 1, true, 128>(buf, bytes, "wg-contig");
+        run<2, 2, true, 128>(buf, bytes, "grid-strided");
+        run<4, 0, true, 128>(buf, bytes, "wave-contig");
+        run<2, 0, true, 64>(buf, bytes, "wave-contig");
         run<1, 0, true, 64>(buf, bytes, "wave-contig");
         run<4, 0, true, 64>(buf, bytes, "wave-contig");
         printf("\n");
