@@ -17,6 +17,9 @@
 #ifndef QS_EW_UNROLL_ELIDE
 #define QS_EW_UNROLL_ELIDE 2   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
 #endif
+#ifndef QS_EW_UNROLL_SCALAR
+#define QS_EW_UNROLL_SCALAR 1  // groups per lane of the tensor-wise (CM_SCALAR) 8-per-lane kernels
+#endif
 #ifndef QS_EW_UNROLL_ROW
 #define QS_EW_UNROLL_ROW 2     // groups per lane of the dense per-row (CM_ROW) 8-per-lane kernels (three-phase path)
 #endif
@@ -163,9 +166,11 @@ int launch_ew_impl(const Op& op, const EwPlan& plan, bool param_per_channel, con
     const int grid = grid_for(plan.geo.ngroups, U);
     switch (plan.cm) {
         case CM_SCALAR:
-            if constexpr (!ELIDE)
-                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, U>), dim3(grid), dim3(kBlock), 0, s, op,
-                                   plan.geo, x, y, codes);
+            if constexpr (!ELIDE) {
+                constexpr int US = QS_EW_UNROLL_SCALAR;
+                hipLaunchKernelGGL((ew_kernel<Op, XDT, YDT, CM_SCALAR, false, NT, US>), dim3(grid_for(plan.geo.ngroups, US)),
+                                   dim3(kBlock), 0, s, op, plan.geo, x, y, codes);
+            }
             break;
         case CM_ROW: {
             constexpr int UR = ELIDE ? QS_EW_UNROLL_ELIDE : QS_EW_UNROLL_ROW;
