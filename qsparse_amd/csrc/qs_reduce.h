@@ -388,7 +388,7 @@ template <bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_fewcols_finish_kernel(const uint32_t* __restrict__ part_max,
                                                                         const uint32_t* __restrict__ part_min, int nblk,
                                                                         int64_t cols, int64_t inner, uint32_t* out_max,
-                                                                        uint32_t* out_min) {
+                                                                        uint32_t* out_min, int finalize) {
     __shared__ uint32_t smx[kBlock], smn[kBlock];
     const int ch_l = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int64_t ch = (int64_t)blockIdx.x * 16 + ch_l, nch = cols / inner;
@@ -420,8 +420,13 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_finish_kernel(const uin
             mx = smx[g * 16 + ch_l] > mx ? smx[g * 16 + ch_l] : mx;
             mn = smn[g * 16 + ch_l] < mn ? smn[g * 16 + ch_l] : mn;
         }
-        out_max[ch] = mx > out_max[ch] ? mx : out_max[ch];
-        if constexpr (MINMAX) out_min[ch] = mn < out_min[ch] ? mn : out_min[ch];
+        if (finalize) {      // a non-accumulating call: the final floats, no initialisation / conversion launches around us
+            ((float*)out_max)[ch] = MINMAX ? key_to_f32(mx) : __uint_as_float(mx);
+            if constexpr (MINMAX) ((float*)out_min)[ch] = key_to_f32(mn);
+        } else {
+            out_max[ch] = mx > out_max[ch] ? mx : out_max[ch];
+            if constexpr (MINMAX) out_min[ch] = mn < out_min[ch] ? mn : out_min[ch];
+        }
     }
 }
 

@@ -413,9 +413,26 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
     uint32_t* omax = (uint32_t*)(minmax ? out_b : out_a);
     uint32_t* omin = minmax ? (uint32_t*)out_a : nullptr;
     const int ib = (int)((nout + 255) / 256);
-    if (!accumulate) hipLaunchKernelGGL(keys_init_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    const bool vec_ptr = aligned16(x);
+    // the few-columns route (channels_last activations, 2-d inputs) ends in a finish kernel that can write the final
+    // floats itself: a non-accumulating call then needs neither the key initialisation nor the key -> float launch
+    // (two launches instead of four for a per-channel min/max)
+    int64_t few_nblk = 0;
+    if (per_channel && numel > 0 && vec_ptr && ws) {
+        const int64_t cols = C * inner;
+        const bool rows_route = !minmax && inner % 8 == 0 && outer >= 16 && cols / 8 >= 64 * 1024;          // column walk
+        const bool long_rows = inner >= 64 && C < 65536 && !(inner < 512 && cols % 8 == 0);                     // reduce_rows
+        if (!rows_route && !long_rows && cols % 8 == 0 && cols <= kFewColsMaxCols && cols / 8 <= kBlock) {
+            const int64_t rows_per_iter = kBlock / (cols / 8);
+            static const int fewcols_cap = env_int("QS_FEWCOLS_BLOCKS", kFewColsMaxBlocks);
+            int64_t nblk = outer / (rows_per_iter * 32);     // >= 4 rounds of 8 loads per workgroup
+            nblk = std::min<int64_t>(std::max<int64_t>(nblk, 1), std::min(fewcols_cap, kFewColsMaxBlocks));
+            if (ws_bytes >= (size_t)(2 * nblk * cols) * sizeof(uint32_t) && outer >= 32 * rows_per_iter) few_nblk = nblk;
+        }
+    }
+    const bool finalize = few_nblk > 0 && !accumulate;
+    if (!accumulate && !finalize) hipLaunchKernelGGL(keys_init_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
     if (numel > 0) {
-        const bool vec_ptr = aligned16(x);
         int st = with_dtype(xdt, [&](auto X) {
             constexpr int XD = decltype(X)::value;
             auto run = [&](auto MM) {
@@ -461,21 +478,16 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                 } else {
                     const int64_t cols = C * inner;
                     const bool vec = vec_ptr && (cols % 8 == 0);
-                    if (vec && ws && cols <= kFewColsMaxCols && cols / 8 <= kBlock) {
+                    if (few_nblk > 0) {
                         // few columns, many rows: two stages through the caller's workspace, no atomics
-                        const int64_t rows_per_iter = kBlock / (cols / 8);
-                        int64_t nblk = outer / (rows_per_iter * 32);     // >= 4 rounds of 8 loads per workgroup
-                        static const int fewcols_cap = env_int("QS_FEWCOLS_BLOCKS", kFewColsMaxBlocks);
-                        nblk = std::min<int64_t>(std::max<int64_t>(nblk, 1), std::min(fewcols_cap, kFewColsMaxBlocks));
-                        if (ws_bytes >= (size_t)(2 * nblk * cols) * sizeof(uint32_t) && outer >= 32 * rows_per_iter) {
-                            uint32_t* pmax = (uint32_t*)ws;
-                            uint32_t* pmin = pmax + nblk * cols;
-                            hipLaunchKernelGGL((reduce_fewcols_kernel<XD, M>), dim3((int)nblk), dim3(kBlock), 0, s, x, outer,
-                                               cols, pmax, pmin, relu);
-                            hipLaunchKernelGGL((reduce_fewcols_finish_kernel<M>), dim3((int)((C + 15) / 16)), dim3(kBlock), 0, s,
-                                               pmax, pmin, (int)nblk, cols, inner, omax, omin);
-                            return launch_status();
-                        }
+                        const int64_t nblk = few_nblk;
+                        uint32_t* pmax = (uint32_t*)ws;
+                        uint32_t* pmin = pmax + nblk * cols;
+                        hipLaunchKernelGGL((reduce_fewcols_kernel<XD, M>), dim3((int)nblk), dim3(kBlock), 0, s, x, outer,
+                                           cols, pmax, pmin, relu);
+                        hipLaunchKernelGGL((reduce_fewcols_finish_kernel<M>), dim3((int)((C + 15) / 16)), dim3(kBlock), 0, s,
+                                           pmax, pmin, (int)nblk, cols, inner, omax, omin, (int)finalize);
+                        return launch_status();
                     }
                     const int64_t per_block = vec ? (int64_t)kBlock * 8 : kBlock;
                     const int gx = (int)((cols + per_block - 1) / per_block);
@@ -497,7 +509,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
         });
         if (st) return st;
     }
-    if (minmax) hipLaunchKernelGGL(keys_to_float_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    if (minmax && !finalize) hipLaunchKernelGGL(keys_to_float_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
     return launch_status();
 }
 
