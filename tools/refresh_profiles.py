@@ -9,7 +9,8 @@
   rNN_pmc_traffic.json                   HBM bytes per launch of the three streaming kernels, corrected as
                                          /opt/skills/guides/MI355X_MICROARCH.md prescribes, next to the algorithmic bytes
 
-usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r02]
+usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r02] [all]
+(a second argument "all": only the PMC passes, for the opt-in mode elide_pruned="all" -> rNN_pmc_traffic_all.json)
 """
 import csv
 import glob
@@ -21,6 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+MODE_ALL = len(sys.argv) > 2 and sys.argv[2] == "all"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 BENCH = os.path.join(ROOT, "bench.py")
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -41,6 +43,10 @@ def find(pattern):
 def main():
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(OUT)
+    if MODE_ALL:
+        r = sh(["python3", BENCH, "--elide", "all", "--no-configs", "--no-cpu-baseline", "--no-variants"], stdout=subprocess.PIPE)
+        assert r.returncode == 0
+        return pmc_passes(json.loads(r.stdout.strip().splitlines()[-1]), ["--elide", "all"], "_all")
 
     # 1. the plain command
     r = sh(["python3", BENCH], stdout=subprocess.PIPE)
@@ -86,16 +92,21 @@ def main():
             shutil.copy(find(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(OUT, f"{TAG}_{cfg}_kernel_stats.csv"))
         shutil.rmtree(d, ignore_errors=True)
 
+    pmc_passes(rec, [], "")
+    print("value", rec["value"], "ms/step", rec["ms_per_step"], "frac", rec["roofline"]["frac"])
+
+
+def pmc_passes(rec, extra, suffix):
     # 3. PMC passes, one counter each (never combined with other trace domains)
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(OUT, "pmc_" + counter)
         assert sh(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "bench", "--",
-                   "python3", BENCH, "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-configs", "--no-variants"]).returncode == 0
+                   "python3", BENCH, "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-configs", "--no-variants"] + extra).returncode == 0
         src = find(os.path.join(d, "**", "*counter_collection.csv"))
         rows = [x for x in csv.DictReader(open(src)) if "qs::" in x["Kernel_Name"]]
         rows = rows[-8 * 5:]                                     # the 8 timed steps, 5 launches each
-        with open(os.path.join(OUT, f"{TAG}_pmc_{counter}_counter_collection.csv"), "w", newline="") as f:
+        with open(os.path.join(OUT, f"{TAG}_pmc_{counter}{suffix}_counter_collection.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
             w.writeheader()
             w.writerows(rows)
@@ -115,7 +126,7 @@ def main():
                "stats": (pick("mean_outer_vec_kernel"), 2 * NUMEL)}
     traffic = {
         "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 8 --warmup 3 "
-                   "--no-cpu-baseline --no-configs --no-variants  (one pass per counter; tools/refresh_profiles.py)",
+                   "--no-cpu-baseline --no-configs --no-variants" + "".join(" " + e for e in extra) + "  (one pass per counter; tools/refresh_profiles.py)",
         "mode": rec["config"]["elide_pruned"], "kept_channel_fraction": kept,
         "note": "algorithmic_bytes are mask-aware: the apply forward of the default mode reads only the kept channels "
                 "((2*kept + 4) B/elem); FETCH_SIZE must show the same drop",
@@ -133,10 +144,9 @@ def main():
         hbm = int(fk * 1024 * 2 + wk * 1024)
         traffic["kernels"][key] = {"kernel": name, "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
                                    "hbm_bytes": hbm, "algorithmic_bytes": algo, "ratio": round(hbm / algo, 4)}
-    with open(os.path.join(OUT, f"{TAG}_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(OUT, f"{TAG}_pmc_traffic{suffix}.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps({k: v["ratio"] for k, v in traffic["kernels"].items()}))
-    print("value", rec["value"], "ms/step", rec["ms_per_step"], "frac", rec["roofline"]["frac"])
 
 
 if __name__ == "__main__":
