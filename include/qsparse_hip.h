@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 7
+#define QS_ABI_VERSION 8
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -67,14 +67,18 @@ size_t qs_workspace_bytes(int op, int64_t n);
  * (qsparse/convert.py:214-218) folded into the same pass.
  * elide_masked != 0 (with chan_mask): the x of a pruned channel is not loaded at all -- it only ever meets `* 0`
  * (sparse.py:116) -- and the quantizer is applied to +0.0 instead: bit-identical to the loading path for every finite
- * x; a NaN / Inf on a pruned channel yields f32(0)*s instead of the reference's f32(INT_MIN)*s. */
+ * x; a NaN / Inf on a pruned channel yields f32(0)*s instead of the reference's f32(INT_MIN)*s.
+ * gate_out (nullable; needs pre_relu != 0; ceil(numel / 8) bytes): the folded ReLU's gate for the backward, one BIT per
+ * element in memory order -- bit (e & 7) of gate_out[e >> 3] = !(x[e] <= 0), ATen's threshold_backward -- so that
+ * qs_quant_ste_relu_bwd reads one bit instead of x per element and x need not be kept.  Every element is loaded then;
+ * with elide_masked != 0 the x of a pruned channel still counts as +0.0, i.e. the result is the eliding call's. */
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
                         const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask,
                         int64_t outer, int64_t C, int64_t inner,
                         int xdt, int ydt, int qdt,
                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                        qs_stream_t stream);
+                        uint8_t* gate_out, qs_stream_t stream);
 
 /* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
@@ -83,7 +87,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          int64_t outer, int64_t C, int64_t inner,
                          int xdt, int ydt, int qdt,
                          int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                         qs_stream_t stream);
+                         uint8_t* gate_out, qs_stream_t stream);
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
@@ -110,8 +114,10 @@ int qs_quant_ste_bwd(const void* g, void* gx,
 
 /* The same backward with the gate of a folded nn.ReLU (threshold_backward: 0 where x <= 0):
  *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)
- * x is the ReLU's INPUT (dtype xdt); gx has x's dtype. */
-int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx,
+ * x is the ReLU's INPUT (dtype xdt); gx has x's dtype.  gate (nullable): the bitmap a forward call recorded through
+ * gate_out over the same [outer, C, inner] geometry; when given, x is not read (it may be NULL) and xdt only names the
+ * dtype of gx: 4 + 1/8 + sizeof(xdt) bytes per element instead of 4 + 2 * sizeof(xdt). */
+int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx,
                           const float* step, int64_t nstep, float step_host, int step_is_decimal,
                           float lo_mul, float hi_mul, const uint8_t* chan_mask,
                           int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked,

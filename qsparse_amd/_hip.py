@@ -35,9 +35,9 @@ SIGNATURES = {
     "qs_version": (c_int, []),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
-    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P]),
-    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P]),
-    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
+    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
@@ -259,17 +259,36 @@ def _f32param(p, device):
 # ----------------------------------------------------------------------------------------------
 # quantizers
 # ----------------------------------------------------------------------------------------------
+class ReluGate:
+    """the gate of a folded ReLU as the forward kernel recorded it: one bit per element in the MEMORY order the kernel
+    addressed (`channels_last`: the activation was used in place through its NHWC view), plus what the backward needs to
+    know about the ReLU's input without keeping it: shape, dtype, layout."""
+    __slots__ = ("bits", "shape", "dtype", "channels_last")
+
+    def __init__(self, bits: torch.Tensor, like: torch.Tensor, channels_last: bool):
+        self.bits, self.shape, self.dtype, self.channels_last = bits, like.shape, like.dtype, channels_last
+
+
 def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
               chan_mask: Optional[torch.Tensor] = None, mask_channel_index: Optional[int] = None,
-              want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False):
-    """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU)."""
+              want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False,
+              want_gate: bool = False):
+    """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU).
+    want_gate (with pre_relu): returns (y, codes|None, ReluGate) -- the ReLU's gate as one bit per element, recorded by
+    the same pass, for `ste_relu_bwd(gate=...)`."""
     lib = load()
     pt, n, host = _f32param(param, x.device)
     ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
     x, ci, like = mem_view(x, ci if ci is not None else -1)
     outer, C, inner, numel = split3(x.shape, ci)
+    gate = None
+    if want_gate:
+        if not pre_relu:
+            raise ValueError("want_gate records the gate of a folded ReLU: pre_relu must be set")
+        gate = ReluGate(torch.empty((numel + 7) // 8, dtype=torch.uint8, device=x.device), like, x is not like)
     if numel == 0:
-        return torch.empty_like(like, dtype=out_dtype), None
+        y = torch.empty_like(like, dtype=out_dtype)
+        return (y, None, gate) if want_gate else (y, None)
     y = torch.empty_like(like, dtype=out_dtype)
     codes = torch.empty_like(like, dtype=torch.int32) if want_codes else None
     cm = _chan_mask_bytes(chan_mask, C)
@@ -277,9 +296,10 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else "")):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0, _stream(x))
+                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0,
+                _ptr(gate.bits) if gate is not None else None, _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
-    return y, codes
+    return (y, codes, gate) if want_gate else (y, codes)
 
 
 def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_index: int, float_zero_point: bool):
@@ -318,13 +338,37 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
     return gx
 
 
-def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
-                 chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1):
-    """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate."""
+def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
+                 chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1, gate: Optional[ReluGate] = None):
+    """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate.  With `gate` (the
+    bitmap `quant_fwd(want_gate=True)` recorded) x is not needed."""
     lib = load()
-    assert g.shape == x.shape
     pt, n, host = _f32param(step, g.device)
     ci = mask_channel_index if chan_mask is not None else -1
+    if gate is not None:
+        assert tuple(g.shape) == tuple(gate.shape)
+        if gate.channels_last:         # the bitmap follows the NHWC memory order the forward addressed
+            fmt = torch.channels_last if g.dim() == 4 else torch.channels_last_3d
+            gcl = g.contiguous(memory_format=fmt)
+            if gcl.data_ptr() % 16:
+                gcl = gcl.clone(memory_format=torch.preserve_format)
+            gm = gcl.permute((0, 2, 3, 1) if g.dim() == 4 else (0, 2, 3, 4, 1))
+            ci_mem = -1 if ci < 0 else g.dim() - 1
+            gx = torch.empty(gate.shape, dtype=gate.dtype, device=g.device, memory_format=fmt)
+        else:
+            gm, ci_mem = dense(g), ci
+            gx = torch.empty(gate.shape, dtype=gate.dtype, device=g.device)
+        outer, C, inner, numel = split3(gm.shape, ci_mem)
+        if numel == 0:
+            return gx
+        cm = _chan_mask_bytes(chan_mask, C)
+        with _timed("quant_ste_relu_bwd"):
+            st = lib.qs_quant_ste_relu_bwd(_ptr(gm), None, _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host,
+                                           int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner,
+                                           dt(gm), _DT[gate.dtype], _elide_all() if cm is not None else 0, _stream(gm))
+        _check(st, "qs_quant_ste_relu_bwd")
+        return gx
+    assert g.shape == x.shape
     xm, ci_mem, like = mem_view(x, ci)
     gm = None
     if like is x and xm is not x:        # x is addressed in place as channels_last: the gradient must share that layout
@@ -342,7 +386,7 @@ def ste_relu_bwd(g: torch.Tensor, x: torch.Tensor, step, step_is_decimal: bool, 
         return gx
     cm = _chan_mask_bytes(chan_mask, C)
     with _timed("quant_ste_relu_bwd"):
-        st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
+        st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), None, _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
                                        float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x),
                                        _elide_all() if cm is not None else 0, _stream(g))
     _check(st, "qs_quant_ste_relu_bwd")

@@ -282,6 +282,52 @@ struct ChanMaskOp {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Gate bitmap of a folded ReLU.  A forward op wrapped in GateOp also records, for every element in MEMORY order, whether
+// the ReLU lets the gradient through: bit (e & 7) of gate[e >> 3] = !(x[e] <= 0) (ATen's threshold_backward: NaN passes).
+// The fused backward then reads g and one BIT per element instead of g and x -- 2 or 4 bytes per element less, the
+// largest avoidable stream of a ReLU -> prune -> quantize site -- and x need not be kept for the backward at all.
+// Every kernel path hands a lane 8 consecutive elements (one byte) or 4 (a nibble; lanes 2k and 2k+1 share a byte and
+// combine it with one DPP move).  Never combined with ELIDE: a lane that skips its load cannot know its gate bits
+// (`zero_pruned` keeps the eliding kernels' arithmetic instead).
+// ------------------------------------------------------------------------------------------------
+template <typename Base>
+struct GateOp : Base {
+    uint8_t* gate;      // ceil(numel / 8) bytes
+    int zero_pruned;    // the caller asked for elision: a pruned channel's x counts as +0.0, as in the eliding kernels, so that
+                        // a site gives the same bits with and without the bitmap (NaN / Inf on a pruned channel, quirk B15)
+    __device__ __forceinline__ float apply(float v, const typename Base::P& p, int32_t& code) const {
+        if (zero_pruned && p.keep == 0.0f) v = 0.0f;
+        return Base::apply(v, p, code);
+    }
+};
+template <typename Op>
+struct OpGate {
+    static constexpr bool value = false;
+    __device__ __forceinline__ static uint8_t* ptr(const Op&) { return nullptr; }
+};
+template <typename Base>
+struct OpGate<GateOp<Base>> {
+    static constexpr bool value = true;
+    __device__ __forceinline__ static uint8_t* ptr(const GateOp<Base>& op) { return op.gate; }
+};
+template <int N>
+__device__ __forceinline__ uint32_t gate_bits(const float* v) {
+    uint32_t b = 0u;
+#pragma unroll
+    for (int j = 0; j < N; ++j) b |= (v[j] <= 0.0f ? 0u : 1u) << j;
+    return b;
+}
+// the nibble of the neighbouring lane (lane ^ 1): quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ uint32_t gate_pair_swap(uint32_t nib) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, false);
+}
+// ragged tail: the (numel % 8) threads that serve it are lanes 0.. of one wave; lane 0 stores their ballot
+__device__ __forceinline__ void gate_store_tail(uint8_t* gate, int64_t ngroups, bool open) {
+    const uint64_t b = __ballot(open);
+    if (threadIdx.x == 0) gate[ngroups] = (uint8_t)(b & 0xffu);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Mask-aware traffic elision (ELIDE).  With a channel mask the input of a pruned channel only ever meets
 // `* 0`: the mask byte is read FIRST and the load of x (or g) is skipped for lanes whose elements are all pruned; the
 // op is applied to +0.0 instead.  At 75 % channel sparsity the fused forward reads a quarter of x.  Exactness:
@@ -353,6 +399,8 @@ template <typename Op, int XDT, int YDT, int CM, bool PARAM_PER_CHANNEL, bool NT
 __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                      void* __restrict__ y, int32_t* __restrict__ codes) {
     static_assert(!ELIDE || (Op::kHasMask && CM != CM_SCALAR), "elision needs a channel mask");
+    constexpr bool GATE = OpGate<Op>::value;
+    static_assert(!(GATE && ELIDE), "a lane that skips its load cannot record the ReLU gate");
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     int64_t g0 = blk * kBlock + threadIdx.x;
@@ -410,6 +458,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                     continue;
                 }
                 unpack8<XDT>(raw[u], v);
+                if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], pp[u], q[j]);
                 store8<YDT, NT>(y, g, v);
@@ -431,6 +480,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
             float v[8];
             int32_t q[8];
             if constexpr (!ELIDE) unpack8<XDT>(raw[u], v);
+            if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v);
             if constexpr (CM == CM_SCALAR) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
@@ -491,7 +541,9 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
         it.seek((uint64_t)e);
         typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
         int32_t qi;
-        float r = op.apply(load1<XDT>(x, e), p, qi);
+        const float xe = load1<XDT>(x, e);
+        if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, !(xe <= 0.0f));
+        float r = op.apply(xe, p, qi);
         store1<YDT>(y, e, r);
         if (codes) codes[e] = qi;
     }
@@ -519,6 +571,8 @@ template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT, bool EL
 __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo, const void* __restrict__ x,
                                                            float* __restrict__ y) {
     static_assert(!ELIDE || (Op::kHasMask && (CM == CM_ROW || CM == CM_LAST)), "elision needs a channel mask");
+    constexpr bool GATE = OpGate<Op>::value;
+    static_assert(!(GATE && ELIDE), "a lane that skips its load cannot record the ReLU gate");
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t e_wave = (blk * (kWidenBlock / 64) + wave) * 512;          // first element of this wave
@@ -536,6 +590,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
             const int64_t e = e_wave + lane * 8;
             float v[8];
             if constexpr (!ELIDE) unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
+            if constexpr (GATE) OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)gate_bits<8>(v);
             int32_t q;
             u32x4 a, b;
             if constexpr (CM == CM_LAST) {
@@ -657,6 +712,11 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                     if (mp) mm = *(const uint32_t*)(mp + last_dim_channel(e, geo.C));   // 4 consecutive channels
                 }
             }
+            if constexpr (GATE) {       // 4 elements = a nibble; the even lane stores the byte it shares with its neighbour
+                const uint32_t nib = gate_bits<4>(v);
+                const uint32_t other = gate_pair_swap(nib);      // both lanes of a pair are inside or outside the tensor together
+                if ((lane & 1) == 0) OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)(nib | (other << 4));
+            }
             int32_t q;
             u32x4 out;
 #pragma unroll
@@ -677,15 +737,25 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
         it.seek((uint64_t)e);
         typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
         int32_t qi;
-        y[e] = op.apply(load1<XDT>(x, e), p, qi);
+        const float xe = load1<XDT>(x, e);
+        if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, !(xe <= 0.0f));
+        y[e] = op.apply(xe, p, qi);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // STE backward with the folded ReLU's gate: gx = (x <= 0) ? 0 : clamp(g) * mask.  Two streamed inputs (the
 // gradient and the ReLU's input), one output in x's dtype.  Same geometry and channel modes as ew_kernel.
+// GATE: `x` is not the ReLU's input but the gate bitmap the forward recorded (GateOp above; one bit per element in
+// memory order): the second stream shrinks from 2 / 4 bytes to one bit per element; XDT is then only the output dtype.
 // ------------------------------------------------------------------------------------------------
-template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false>
+template <int N>
+__device__ __forceinline__ void gate_to_floats(uint32_t bits, float* vx) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) vx[j] = ((bits >> j) & 1u) ? 1.0f : 0.0f;
+}
+
+template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
                                                               void* __restrict__ gx) {
@@ -718,7 +788,13 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 }
                 if (need) {
                     rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
-                    rx4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                    if constexpr (GATE) {
+                        const uint32_t bits = (uint32_t)((const uint8_t*)x)[e >> 3] >> ((uint32_t)e & 4u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rx4[j] = ((bits >> j) & 1u) ? 0x3f800000u : 0u;
+                    } else {
+                        rx4 = ld16<NT>((const u32x4*)((const float*)x + e));
+                    }
                 }
                 int32_t dummy;
                 u32x4 out;
@@ -780,13 +856,16 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
             const u32x2 m8 = *(const u32x2*)(op.cmask + last_dim_channel(grp * 8, geo.C));
             need = (m8[0] | m8[1]) != 0u;
         }
+        uint32_t gbits = 0u;
         if (need) {
             rg = load8_raw<GDT, NT>(g, grp);
-            rx = load8_raw<XDT, NT>(x, grp);
+            if constexpr (GATE) gbits = ((const uint8_t*)x)[grp];
+            else rx = load8_raw<XDT, NT>(x, grp);
         }
         float vg[8], vx[8];
         unpack8<GDT>(rg, vg);
-        unpack8<XDT>(rx, vx);
+        if constexpr (GATE) gate_to_floats<8>(gbits, vx);
+        else unpack8<XDT>(rx, vx);
         int32_t dummy;
         if constexpr (CM == CM_SCALAR) {
             const SteBwdOp::P p = op.channel(0);
@@ -845,7 +924,10 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         it.seek((uint64_t)e);
         const SteBwdOp::P p = (CM == CM_SCALAR) ? op.channel(0) : op.channel_masked(param_per_channel ? it.c : 0u, it.c);
         int32_t dummy;
-        const float r = (load1<XDT>(x, e) <= 0.0f) ? 0.0f : op.apply(load1<GDT>(g, e), p, dummy);
+        float xe;
+        if constexpr (GATE) xe = ((((const uint8_t*)x)[e >> 3] >> ((uint32_t)e & 7u)) & 1u) ? 1.0f : 0.0f;
+        else xe = load1<XDT>(x, e);
+        const float r = (xe <= 0.0f) ? 0.0f : op.apply(load1<GDT>(g, e), p, dummy);
         store1<XDT>(gx, e, r);
     }
 }

@@ -203,7 +203,7 @@ template <typename Op, int XDT, int YDT>
 int launch_ew(const Op& op, const EwPlan& plan, bool param_per_channel, const void* x, void* y, int32_t* codes,
               hipStream_t s, bool elide = false) {
     if (plan.geo.numel == 0) return QS_OK;
-    if constexpr (Op::kHasMask) {
+    if constexpr (Op::kHasMask && !OpGate<Op>::value) {     // (a gate-recording op loads every element: no elision)
         if (elide && plan.cm != CM_SCALAR && op.mask_ptr() != nullptr)
             return launch_ew_impl<Op, XDT, YDT, true>(op, plan, param_per_channel, x, y, codes, s);
     }
@@ -247,8 +247,9 @@ size_t qs_workspace_bytes(int op, int64_t n) {
 // ------------------------------------------------------------------------------------------------
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
-                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked, qs_stream_t stream) {
-    if (!x || !y) return QS_ERR_ARG;
+                        int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked, uint8_t* gate_out,
+                        qs_stream_t stream) {
+    if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -264,6 +265,10 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
+            if (gate_out) {
+                GateOp<ScalerFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr};
+                return launch_ew<GateOp<ScalerFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
+            }
             return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
@@ -274,8 +279,8 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
                          float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
                          int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, int pre_relu,
-                         int elide_masked, qs_stream_t stream) {
-    if (!x || !y) return QS_ERR_ARG;
+                         int elide_masked, uint8_t* gate_out, qs_stream_t stream) {
+    if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -291,6 +296,10 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
+            if (gate_out) {
+                GateOp<DecimalFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr};
+                return launch_ew<GateOp<DecimalFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
+            }
             return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
         };
         if (ydt == QS_F32) return (qdt == QS_F32) ? go(IC<QS_F32>{}, IC<QS_F32>{}) : go(IC<QS_F32>{}, X);
@@ -345,12 +354,12 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
     });
 }
 
-int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* step, int64_t nstep, float step_host,
-                          int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask, int64_t outer,
-                          int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, qs_stream_t stream) {
-    if (!g || !x || !gx) return QS_ERR_ARG;
+int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx, const float* step, int64_t nstep,
+                          float step_host, int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask,
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, qs_stream_t stream) {
+    if (!g || (!x && !gate) || !gx) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
-    if (!aligned16(g) || !aligned16(x) || !aligned16(gx)) return QS_ERR_ALIGN;
+    if (!aligned16(g) || (!gate && !aligned16(x)) || !aligned16(gx)) return QS_ERR_ALIGN;
     int st = check_param(step, nstep, C);
     if (st) return st;
     const bool ppc = nstep > 1;
@@ -362,42 +371,45 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, void* gx, const float* s
     SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, 0, chan_mask};
     const int grid = grid_for(plan.geo.ngroups, 1);
     constexpr bool NT = QS_EW_NT != 0;
+    const void* second = gate ? (const void*)gate : x;       // the gate bitmap replaces the ReLU's input (GATE kernels)
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
-        auto go = [&](auto G) {
+        auto go = [&](auto G, auto GT) {
             constexpr int GD = decltype(G)::value;
+            constexpr bool GATE = decltype(GT)::value;
             int cm = plan.cm;
             if (GD == QS_F32 && XD == QS_F32 && cm == CM_ELEM && plan.geo.inner % 4 == 0) cm = CM_ROW;   // 4 elements per lane
             const bool el = elide_masked != 0 && chan_mask != nullptr;
             switch (cm) {
                 case CM_SCALAR:
-                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                       plan.geo, (int)ppc, g, x, gx);
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx);
                     break;
                 case CM_ROW:
                     if (el)
-                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, true>), dim3(grid), dim3(kBlock), 0, s, op,
-                                           plan.geo, (int)ppc, g, x, gx);
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                           op, plan.geo, (int)ppc, g, second, gx);
                     else
-                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                           plan.geo, (int)ppc, g, x, gx);
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                           op, plan.geo, (int)ppc, g, second, gx);
                     break;
                 case CM_LAST:
                     if (el)
-                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, true>), dim3(grid), dim3(kBlock), 0, s, op,
-                                           plan.geo, (int)ppc, g, x, gx);
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                           op, plan.geo, (int)ppc, g, second, gx);
                     else
-                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                           plan.geo, (int)ppc, g, x, gx);
+                        hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                           op, plan.geo, (int)ppc, g, second, gx);
                     break;
                 default:
-                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT>), dim3(grid), dim3(kBlock), 0, s, op,
-                                       plan.geo, (int)ppc, g, x, gx);
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx);
                     break;
             }
             return launch_status();
         };
-        return gdt == QS_F32 ? go(IC<QS_F32>{}) : go(X);
+        if (gate) return gdt == QS_F32 ? go(IC<QS_F32>{}, std::true_type{}) : go(X, std::true_type{});
+        return gdt == QS_F32 ? go(IC<QS_F32>{}, std::false_type{}) : go(X, std::false_type{});
     });
 }
 

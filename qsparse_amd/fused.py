@@ -70,19 +70,22 @@ class _FusedApply(torch.autograd.Function):
     def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False):
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
         ctx.pre_relu = pre_relu
-        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
-                              h if pre_relu else h.new_empty(0))
         ctx.has_mask = mask_c is not None
+        ctx.gate = None
+        # a folded ReLU's backward needs nothing of x but the sign test: the forward records it as one bit per element
+        # (qs_quant_*_fwd gate_out) and x is not kept -- the backward reads g and the bitmap instead of g and x
+        want_gate = bool(pre_relu and quant_on and ctx.needs_input_grad[0] and get_option("relu_gate"))
+        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
+                              h if (pre_relu and not want_gate) else h.new_empty(0))
         if not quant_on:
             return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
         out_dtype = _out_dtype(h)
-        if kind == "scaler":
-            y, _ = _hip.quant_fwd("scaler", h, scale, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1,
-                                  out_dtype=out_dtype, pre_relu=pre_relu)
-        else:
-            y, _ = _hip.quant_fwd("decimal", h, _hip.decimal_from_scale(scale), -1, torch.float32, chan_mask=mask_c,
-                                  mask_channel_index=1, out_dtype=out_dtype, pre_relu=pre_relu)
-        return y
+        param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
+        res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
+                             pre_relu=pre_relu, want_gate=want_gate)
+        if want_gate:
+            ctx.gate = res[2]
+        return res[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -93,7 +96,8 @@ class _FusedApply(torch.autograd.Function):
         limit = 2.0 ** (ctx.bits - 1)
         step = scale if ctx.kind == "scaler" else _hip.decimal_from_scale(scale)
         if ctx.pre_relu:
-            gx = _hip.ste_relu_bwd(g, x, step, ctx.kind == "decimal", -limit + ctx.notch, limit - 1 + ctx.notch, mask_c)
+            gx = _hip.ste_relu_bwd(g, None if ctx.gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
+                                   limit - 1 + ctx.notch, mask_c, gate=ctx.gate)
             return (gx,) + (None,) * 7
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,

@@ -12,13 +12,13 @@ import torch.nn as nn
 from qsparse_amd import _hip
 
 _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
-             "elide_pruned": "forward"}
+             "elide_pruned": "forward", "relu_gate": True}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
-                elide_pruned: Optional[str] = None):
+                elide_pruned: Optional[str] = None, relu_gate: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
@@ -28,7 +28,9 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     instead of the reference's float32 promotion: the value is the float32 result rounded once, i.e. exactly
     what a following autocast convolution would consume, at 4 instead of 6 B/elem and without the cast pass;
     ``fold_relu`` (default True, bit-identical) lets a convert-built ``ReLU -> prune -> quantize`` site apply the
-    ReLU inside the fused kernels instead of materialising its output;
+    ReLU inside the fused kernels instead of materialising its output; ``relu_gate`` (default True, bit-identical)
+    lets the forward of such a site record the ReLU's gate as one bit per element, so that the backward reads the
+    gradient and that bitmap instead of the gradient and the ReLU's input (which is then not kept for the backward);
     ``elide_pruned`` (extension): mask-aware traffic elision in the GPU kernels that carry a channel mask.  A pruned
     channel's input only ever meets ``* 0``, so it need not be loaded: ``"forward"`` (default) elides in the fused
     prune->quantize forward, bit-identical for every finite input; ``"all"`` also in the backward and mask-apply
@@ -41,7 +43,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
         _options_["elide_pruned"] = elide_pruned
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
-                     ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu)):
+                     ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu), ("relu_gate", relu_gate)):
         if val is not None:
             _options_[key] = val
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/qsparse_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes prototypes out of sync with the header"
     lib.qs_version.restype = ctypes.c_int
-    assert lib.qs_version() == 7
+    assert lib.qs_version() == 8
     lib.qs_status_string.restype = ctypes.c_char_p
     assert b"aligned" in lib.qs_status_string(-3)
 
@@ -40,9 +40,9 @@ def test_argument_validation_without_a_gpu():
     from qsparse_amd import _hip
 
     lib = _hip.load()
-    assert lib.qs_quant_scaler_fwd(None, None, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None) == -2
-    assert lib.qs_quant_scaler_fwd(16, 32, None, None, 1, 0.1, None, 1, 1, 8, 5, 0, 0, 0, 0, 0, 0, 0, None) == -1
-    assert lib.qs_quant_scaler_fwd(20, 32, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None) == -3
+    assert lib.qs_quant_scaler_fwd(None, None, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None) == -2
+    assert lib.qs_quant_scaler_fwd(16, 32, None, None, 1, 0.1, None, 1, 1, 8, 5, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
+    assert lib.qs_quant_scaler_fwd(20, 32, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None) == -3
     assert lib.qs_kth_value(16, 10, 10, 32, None, 0, None) == -2          # k out of range
     assert lib.qs_pq_select(16, None, 0, 70000, 0, 0, 0, 0, 32, None, 1, 0, 0, 4, None, None, None, None, None, None, None, 0, None, 1, None) == -2
 

@@ -49,9 +49,12 @@ class _Guarded:
             acc *= max(int(s), 1)
         return tuple(reversed(strides))
 
-    def empty(self, *size, dtype=None, device=None):
+    def empty(self, *size, dtype=None, device=None, memory_format=None):
         shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
-        return self._alloc(shape, self._contiguous_strides(shape), dtype or torch.float32, device)
+        strides = self._contiguous_strides(shape)
+        if memory_format in (torch.channels_last, torch.channels_last_3d):
+            strides = torch.empty(shape, device="meta").contiguous(memory_format=memory_format).stride()
+        return self._alloc(shape, strides, dtype or torch.float32, device)
 
     def zeros(self, *size, dtype=None, device=None):
         return self.empty(*size, dtype=dtype, device=device).zero_()

@@ -50,9 +50,25 @@ for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 204
                 _hip.quant_fwd("scaler", xs[turn[0] % nrot], scale, -1, torch.float32, chan_mask=mask, mask_channel_index=1,
                                pre_relu=True)
 
+            gates = [_hip.quant_fwd("scaler", x, scale, -1, torch.float32, chan_mask=mask, mask_channel_index=1, pre_relu=True,
+                                    want_gate=True)[2] for x in xs]
+
+            def run_gate():     # the same backward from the gate bitmap the forward recorded (1 bit instead of x per element)
+                turn[0] += 1
+                i = turn[0] % nrot
+                _hip.ste_relu_bwd(gs[i], None, scale, False, -8.0, 7.0, mask, 1, gate=gates[i])
+
+            def fwd_gate():
+                turn[0] += 1
+                _hip.quant_fwd("scaler", xs[turn[0] % nrot], scale, -1, torch.float32, chan_mask=mask, mask_channel_index=1,
+                               pre_relu=True, want_gate=True)
+
             us = t_us(run)
-            nbytes = xs[0].numel() * (4 + xs[0].element_size() * 2)
+            n, eb = xs[0].numel(), xs[0].element_size()
+            nbytes = n * (4 + eb * 2)
             usf = t_us(fwd)
-            nbf = xs[0].numel() * (4 + xs[0].element_size())
+            nbf = n * (4 + eb)
+            usg, usfg = t_us(run_gate), t_us(fwd_gate)
             print(f"{str(shape):20s} x {str(xdt)[6:]:8s} {'channels_last' if cl else 'nchw':13s} bwd {us:7.1f} us {nbytes / us / 1e3:6.0f} GB/s"
-                  f"   fwd {usf:7.1f} us {nbf / usf / 1e3:6.0f} GB/s", flush=True)
+                  f"   fwd {usf:7.1f} us {nbf / usf / 1e3:6.0f} GB/s   | gate: bwd {usg:7.1f} us {n * (4.125 + eb) / usg / 1e3:6.0f} GB/s"
+                  f"   fwd {usfg:7.1f} us {n * (4.125 + eb) / usfg / 1e3:6.0f} GB/s", flush=True)
