@@ -55,20 +55,21 @@ def one_case(rng, idx):
     preserve = rng.random() < 0.2
     graph_safe = rng.random() < 0.25       # counters read from (and advanced in) device memory by the kernels
     elide = rng.choice(["forward", "forward", "off", "all"])      # mask-aware load elision (qs_elementwise.h)
+    gate = rng.random() < 0.75             # the folded ReLU's gate as a bitmap (backward without x)
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last, preserve, graph_safe, elide)
+                    channels_last, preserve, graph_safe, elide, gate)
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False, preserve=False, graph_safe=False, elide="forward"):
+             channels_last=False, preserve=False, graph_safe=False, elide="forward", gate=True):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide)
+                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide, gate=gate)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -76,7 +77,8 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
     k = max(int(sparsity * shape[1] - 1), 0) + 1
     if k >= shape[1]:
         return None
-    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve, graph_safe=graph_safe and DEV != "cpu", elide_pruned=elide)
+    qs.set_qsparse_options(fold_relu=fold, preserve_dtype=preserve, graph_safe=graph_safe and DEV != "cpu", elide_pruned=elide,
+                           relu_gate=gate)
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
     has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
     has_p = has_p or "pair" in site_kind

@@ -82,7 +82,7 @@ def _load(name):
 
 @pytest.fixture
 def guarded(monkeypatch):
-    before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu", "preserve_dtype", "graph_safe")}
+    before = {k: qs.get_qsparse_option(k) for k in ("log_on_created", "log_during_train", "fold_relu", "preserve_dtype", "graph_safe", "elide_pruned", "relu_gate")}
     threads = torch.get_num_threads()
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     torch.set_num_threads(1)
