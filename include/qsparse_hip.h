@@ -242,9 +242,11 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
  * vary along one run of dims (channel masks; QS_ERR_ARG otherwise).  Its backward is
  * qs_quant_ste_relu_bwd with step_host = 1 and lo_mul / hi_mul = -inf / +inf.
  * elide_masked != 0 (channel-type masks): pruned channels are not loaded and y = +0.0 there; the reference's x*0
- * carries the sign of x, so this is numerically equal, not bit-identical (opt-in). */
+ * carries the sign of x, so this is numerically equal, not bit-identical (opt-in).
+ * gate_out (nullable; needs pre_relu != 0): the ReLU's gate bitmap for that backward, as in qs_quant_scaler_fwd. */
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes,
-                  const int64_t* mask_strides, int dt, int pre_relu, int elide_masked, qs_stream_t stream);
+                  const int64_t* mask_strides, int dt, int pre_relu, int elide_masked, uint8_t* gate_out,
+                  qs_stream_t stream);
 
 /* ---- fused channel-prune -> tensor-wise-quantize statistics (the headline pair) -------------------- */
 

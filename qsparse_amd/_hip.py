@@ -50,7 +50,7 @@ SIGNATURES = {
     "qs_running_mean": (c_int, [_P, _P, _I, _L, _L, _P, _P]),
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
-    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
@@ -352,8 +352,9 @@ def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decim
             gcl = g.contiguous(memory_format=fmt)
             if gcl.data_ptr() % 16:
                 gcl = gcl.clone(memory_format=torch.preserve_format)
-            gm = gcl.permute((0, 2, 3, 1) if g.dim() == 4 else (0, 2, 3, 4, 1))
-            ci_mem = -1 if ci < 0 else g.dim() - 1
+            perm = (0, 2, 3, 1) if g.dim() == 4 else (0, 2, 3, 4, 1)
+            gm = gcl.permute(perm)
+            ci_mem = -1 if ci < 0 else perm.index(ci)
             gx = torch.empty(gate.shape, dtype=gate.dtype, device=g.device, memory_format=fmt)
         else:
             gm, ci_mem = dense(g), ci
@@ -601,9 +602,9 @@ def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
     _check(st, "qs_mask_ge")
 
 
-def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
+def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False, want_gate: bool = False):
     """x * mask for a bool mask broadcastable to x (same rank, extents 1 or equal); `pre_relu`: max(x, 0) * mask
-    (channel-type masks only)."""
+    (channel-type masks only).  want_gate (with pre_relu): returns (y, ReluGate) -- see quant_fwd."""
     lib = load()
     if mask.dim() != x.dim():
         raise RuntimeError(f"mask rank {mask.dim()} does not match input rank {x.dim()}")
@@ -617,15 +618,21 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> t
         m = m.permute((0, 2, 3, 1) if x.dim() == 4 else (0, 2, 3, 4, 1))
     x = xm
     y = torch.empty_like(like)
+    gate = None
+    if want_gate:
+        if not pre_relu:
+            raise ValueError("want_gate records the gate of a folded ReLU: pre_relu must be set")
+        gate = ReluGate(torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device), like, xm is not like)
     if x.numel() == 0:
-        return y
+        return (y, gate) if want_gate else y
     nd = x.dim()
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
     with _timed("mask_apply"):
-        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _elide_all(), _stream(x))
+        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _elide_all(),
+                               _ptr(gate.bits) if gate is not None else None, _stream(x))
     _check(st, "qs_mask_apply")
-    return y
+    return (y, gate) if want_gate else y
 
 
 def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], update_magnitude: bool, t_mag: int,

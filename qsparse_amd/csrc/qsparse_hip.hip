@@ -804,8 +804,8 @@ int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_
 
 // ------------------------------------------------------------------------------------------------
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes, const int64_t* mask_strides,
-                  int dt, int pre_relu, int elide_masked, qs_stream_t stream) {
-    if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1) return QS_ERR_ARG;
+                  int dt, int pre_relu, int elide_masked, uint8_t* gate_out, qs_stream_t stream) {
+    if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1 || (gate_out && !pre_relu)) return QS_ERR_ARG;
     if (!dt_ok(dt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
@@ -853,6 +853,10 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         ChanMaskOp op{mask, pre_relu != 0};
         return with_dtype(dt, [&](auto D) {
             constexpr int DD = decltype(D)::value;
+            if (gate_out) {      // the folded ReLU's gate bitmap for the backward (GateOp, qs_elementwise.h)
+                GateOp<ChanMaskOp> gop{op, gate_out, elide_masked != 0};
+                return launch_ew<GateOp<ChanMaskOp>, DD, DD>(gop, plan, true, x, y, nullptr, s);
+            }
             return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s, elide_masked != 0);
         });
     }

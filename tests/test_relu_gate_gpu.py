@@ -136,7 +136,65 @@ def test_backward_from_bitmap_equals_backward_from_x(xdtype, elide):
                     assert same(a.cpu().contiguous(), b.cpu().contiguous()), tag
 
 
-def _site(quantize_only=False):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_mask_apply_records_the_same_bitmap(dtype):
+    """the ReLU -> PruneLayer site: max(x, 0) * mask forward (qs_mask_apply), gate * g * mask backward"""
+    for si, shape in enumerate(SHAPES):
+        for layout in layouts(shape):
+            for mode in ("forward", "all"):
+                qs.set_qsparse_options(elide_pruned=mode)
+                C = shape[1]
+                x = special((torch.randn(shape, generator=gen(si)) * 3).to(dtype), si + 100).to(DEV)
+                g = special((torch.randn(shape, generator=gen(si + 50)) * 2).to(dtype), si + 200).to(DEV)
+                if layout == "channels_last":
+                    x = x.contiguous(memory_format=torch.channels_last)
+                mask = (torch.rand(C, generator=gen(si + 7)) < 0.5).to(DEV).view([1, C] + [1] * (len(shape) - 2))
+                y0 = _hip.mask_apply(x, mask, pre_relu=True)
+                y1, gate = _hip.mask_apply(x, mask, pre_relu=True, want_gate=True)
+                tag = (shape, layout, mode)
+                a, b = y0.cpu(), y1.cpu()
+                assert y0.stride() == y1.stride() and a.dtype == b.dtype, tag
+                if mode == "all":
+                    # an eliding kernel skips a pruned lane or not depending on the geometry: a pruned NaN / Inf / -0.0 gives NaN /
+                    # NaN / -0.0 when loaded and +0.0 when skipped; the recording kernel always counts a pruned x as +0.0.  Mode
+                    # "all" promises numerical equality for finite inputs, bit equality on kept channels.
+                    kept = mask.expand_as(x).cpu()
+                    assert same(torch.where(kept, a, torch.zeros_like(a)), torch.where(kept, b, torch.zeros_like(b))), tag
+                    fin = (~kept) & torch.isfinite(x).cpu()
+                    assert bool((a[fin].float() == b[fin].float()).all()), tag
+                else:
+                    assert same(a, b), tag
+                x_mem = x.permute(0, 2, 3, 1) if gate.channels_last else x
+                got, want, n = gate.bits.cpu().numpy().copy(), expected_bits(x_mem).copy(), x.numel()
+                if n % 8:
+                    got[-1] &= (1 << (n % 8)) - 1
+                    want[-1] &= (1 << (n % 8)) - 1
+                assert np.array_equal(got, want), tag
+                inf = float("inf")
+                ga = _hip.ste_relu_bwd(g, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=1)
+                gb = _hip.ste_relu_bwd(g, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=1, gate=gate)
+                assert ga.stride() == gb.stride() and same(ga.cpu().contiguous(), gb.cpu().contiguous()), tag
+
+
+def test_gate_with_a_mask_along_another_dim_of_a_channels_last_tensor():
+    """PruneLayer(dimensions={2}) behind a ReLU: the mask varies along H; in channels_last memory that is dim 1 of the NHWC view"""
+    x = special(torch.randn(3, 8, 6, 16, generator=gen(5)) * 2, 9).to(DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(3, 8, 6, 16, generator=gen(6)).to(DEV)
+    mask = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.bool, device=DEV).view(1, 1, 6, 1)
+    y, gate = _hip.mask_apply(x, mask, pre_relu=True, want_gate=True)
+    assert same(y.cpu(), torch.relu(x.cpu()) * mask.cpu())       # (ATen's CPU relu: the reference path; the GPU one treats -0.0 differently)
+    inf = float("inf")
+    ga = _hip.ste_relu_bwd(g, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=2)
+    gb = _hip.ste_relu_bwd(g, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=2, gate=gate)
+    assert same(ga.cpu().contiguous(), gb.cpu().contiguous())
+    want = torch.where(x <= 0, torch.zeros_like(g), g * mask)
+    assert same(gb.cpu().contiguous(), want.cpu().contiguous())
+
+
+def _site(quantize_only=False, prune_only=False):
+    if prune_only:
+        return fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=2,
+                                                                           repetition=2))).to(DEV).train()
     if quantize_only:
         return fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=2))).to(DEV).train()
     site = nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=2, repetition=2)),
@@ -145,14 +203,14 @@ def _site(quantize_only=False):
 
 
 @pytest.mark.parametrize("channels_last", [False, True])
-@pytest.mark.parametrize("quantize_only", [False, True])
+@pytest.mark.parametrize("kind", ["pair", "quantize_only", "prune_only"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_site_trains_to_the_same_bits_with_and_without_the_bitmap(channels_last, quantize_only, dtype):
+def test_site_trains_to_the_same_bits_with_and_without_the_bitmap(channels_last, kind, dtype):
     runs = {}
     for gate in (False, True):
         qs.set_qsparse_options(relu_gate=gate)
         torch.manual_seed(0)
-        site = _site(quantize_only)
+        site = _site(kind == "quantize_only", kind == "prune_only")
         outs = []
         for step in range(7):
             x = (torch.randn((6, 16, 14, 14), generator=gen(step)) * 2).to(dtype).to(DEV)
