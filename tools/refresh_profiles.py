@@ -9,8 +9,10 @@
   rNN_pmc_traffic.json                   HBM bytes per launch of the three streaming kernels, corrected as
                                          /opt/skills/guides/MI355X_MICROARCH.md prescribes, next to the algorithmic bytes
 
-usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r02] [all]
-(a second argument "all": only the PMC passes, for the opt-in mode elide_pruned="all" -> rNN_pmc_traffic_all.json)
+usage (from the repository root, on the GPU box):  python3 tools/refresh_profiles.py [round-tag, default r02] [all|gate]
+(a second argument "all": only the PMC passes, for the opt-in mode elide_pruned="all" -> rNN_pmc_traffic_all.json;
+ "gate": the PMC passes of tools/gate_traffic.py -- a ReLU site's forward / backward with and without the gate bitmap
+ -> rNN_pmc_traffic_gate.json)
 """
 import csv
 import glob
@@ -23,6 +25,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 MODE_ALL = len(sys.argv) > 2 and sys.argv[2] == "all"
+MODE_GATE = len(sys.argv) > 2 and sys.argv[2] == "gate"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 BENCH = os.path.join(ROOT, "bench.py")
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -43,6 +46,8 @@ def find(pattern):
 def main():
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(OUT)
+    if MODE_GATE:
+        return gate_passes()
     if MODE_ALL:
         r = sh(["python3", BENCH, "--elide", "all", "--no-configs", "--no-cpu-baseline", "--no-variants"], stdout=subprocess.PIPE)
         assert r.returncode == 0
@@ -94,6 +99,44 @@ def main():
 
     pmc_passes(rec, [], "")
     print("value", rec["value"], "ms/step", rec["ms_per_step"], "frac", rec["roofline"]["frac"])
+
+
+def gate_passes():
+    """HBM traffic of a channels_last fp32 ReLU site (256x256x56x56) with and without the gate bitmap"""
+    driver = os.path.join(ROOT, "tools", "gate_traffic.py")
+    numel = 256 * 256 * 56 * 56
+    kinds = {"fwd_plain": ("ew_widen_kernel<qs::ScalerFwdOp<0>, 0, 3", 8.0), "fwd_recording": ("ew_widen_kernel<qs::GateOp<", 8.125),
+             "bwd_from_x": ("ste_relu_bwd_kernel<0, 0, 3, true, false, false>", 12.0),
+             "bwd_from_bitmap": ("ste_relu_bwd_kernel<0, 0, 3, true, false, true>", 8.125)}
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(OUT, "pmc_gate_" + counter)
+        assert sh(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "gate", "--",
+                   "python3", driver]).returncode == 0
+        src = find(os.path.join(d, "**", "*counter_collection.csv"))
+        rows = [x for x in csv.DictReader(open(src)) if "qs::" in x["Kernel_Name"]]
+        with open(os.path.join(OUT, f"{TAG}_pmc_{counter}_gate_counter_collection.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+            w.writeheader()
+            w.writerows(rows)
+        for x in rows:
+            per.setdefault(x["Kernel_Name"].split("(")[0], {}).setdefault(counter, []).append(float(x["Counter_Value"]))
+        shutil.rmtree(d)
+    out = {"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 tools/gate_traffic.py  (one pass per counter)",
+           "site": "ReLU -> prune -> quantize, channels_last fp32 256x256x56x56, 50 % channel mask (the site behind a residual add)",
+           "unit": "bytes per launch", "correction": "fetch bytes = FETCH_SIZE*1024*2, write bytes = WRITE_SIZE*1024 (see rNN_pmc_traffic.json)",
+           "kernels": {}}
+    for key, (sub, bpe) in kinds.items():
+        names = [k for k in per if sub in k]
+        assert len(names) == 1, (sub, list(per))
+        fk = sum(per[names[0]]["FETCH_SIZE"]) / len(per[names[0]]["FETCH_SIZE"])
+        wk = sum(per[names[0]]["WRITE_SIZE"]) / len(per[names[0]]["WRITE_SIZE"])
+        hbm, algo = int(fk * 1024 * 2 + wk * 1024), int(bpe * numel)
+        out["kernels"][key] = {"kernel": names[0], "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes": hbm,
+                               "algorithmic_bytes_per_elem": bpe, "algorithmic_bytes": algo, "ratio": round(hbm / algo, 4)}
+    with open(os.path.join(OUT, f"{TAG}_pmc_traffic_gate.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: (v["hbm_bytes"], v["ratio"]) for k, v in out["kernels"].items()}))
 
 
 def pmc_passes(rec, extra, suffix):
