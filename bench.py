@@ -17,7 +17,9 @@ in the apply forward, so its forward moves (2 * kept + 4) B/elem: every byte cou
 mode that ran, and `config.variants` carries the dense step ("off") and the fully elided one ("all") next to it.
 
 Rank 0 prints ONE JSON line.  With N > 1 every rank processes its own batch shard (weak scaling) and the C-sized
-statistics are exchanged over RCCL each step (qsparse_amd/distributed.py).  At N == 1 the line also carries
+statistics are exchanged over RCCL each step (qsparse_amd/distributed.py); after the timed region the ranks also run
+BASELINE config 5 -- ResNet-50, the --pq recipe, DistributedDataParallel -- and the line carries its whole-job images/s
+in `configs.config5_resnet50_ddp` (under a watchdog: it can never cost the headline record).  At N == 1 the line also carries
 `configs`: BASELINE.json's configs 2-4 (the 8-bit quantizer alone on 256x64x56x56; ResNet-18 CIFAR shape and ResNet-50
 ImageNet shape, plain vs converted, eager and hipGraph replay) measured in the same process.
 """
@@ -297,6 +299,75 @@ def extra_configs(device, only=None):
     return out
 
 
+def config5(device, world, rank, steps=5):
+    """BASELINE config 5 (N > 1 only): full-width ResNet-50 on synthetic ImageNet-shape data, 4-bit weights and
+    activations + 75 % channel pruning (the --pq recipe), bf16 autocast, channels_last, one process per GPU under
+    `DistributedDataParallel` -- gradients follow DDP's bucketed all-reduce, masks and scales the library's C-sized
+    statistics exchange.  Batch per GPU fixed (weak scaling); images/s is the WHOLE job (all ranks), time = max over
+    ranks.  Every rank calls this (it is collective); rank 0's return value goes into the JSON line."""
+    import qsparse_amd as qs
+    from examples.models import convert_pq, resnet50
+
+    batch = int(os.environ.get("QS_BENCH_DDP_BATCH", "256"))
+    shape = (batch, 3, 224, 224)
+    g = torch.Generator(device=device).manual_seed(1000 + rank)        # every rank its own shard
+    x = torch.randn(shape, generator=g, device=device).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 1000, (batch,), generator=g, device=device)
+    out = {"model": "resnet50", "input_shape_per_gpu": list(shape), "world": world, "dtype": "bf16 autocast, fp32 master weights",
+           "layout": "channels_last", "optimizer": "SGD momentum 0.9", "steps": steps,
+           "parallelism": f"dp{world} (DistributedDataParallel, bucketed gradient all-reduce; one 2C-float statistics "
+                          f"all-gather per operator site and step)"}
+
+    def run(pq):
+        torch.manual_seed(0)                                            # identical initial weights on every rank
+        model = resnet50(1000, False)
+        if pq:
+            model = convert_pq(model, sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+        model = model.to(device).to(memory_format=torch.channels_last).train()
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[device.index])
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.cross_entropy(net(x).float(), y)
+            loss.backward()
+            opt.step()
+
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = t.item() / steps * 1e3
+        same = None
+        if pq:      # the point of the statistics exchange: every rank ends with the same masks and scales
+            sd = model.state_dict()
+            digest = torch.stack([v.double().sum() for k, v in sd.items()
+                                  if k.endswith(("mask", "quantize.weight", "1.weight", "magnitude"))]).sum()
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            same = bool((lo == hi).item())
+        del net, model, opt
+        torch.cuda.empty_cache()
+        return ms, same
+
+    plain_ms, _ = run(False)
+    pq_ms, same = run(True)
+    out.update({"plain_ms": round(plain_ms, 3), "plain_images_per_s": round(world * batch / plain_ms * 1e3, 1),
+                "pq_ms": round(pq_ms, 3), "pq_images_per_s": round(world * batch / pq_ms * 1e3, 1),
+                "pq_over_plain": round(pq_ms / plain_ms, 4), "operator_state_identical_across_ranks": same})
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -304,7 +375,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-4 (they run at N == 1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-4 (N == 1) / config 5 (N > 1)")
     ap.add_argument("--no-variants", action="store_true", help="skip the other elision modes after the timed region")
     ap.add_argument("--configs-only", default=None, metavar="NAMES",
                     help="run only these BASELINE configs (comma-separated prefixes, e.g. config2,config4) and print "
@@ -484,6 +555,43 @@ def main():
             out["config"]["exchange"] = ("one all-gather of a 2C-float record per step over " +
                                          ("gloo (shared GPU, development)" if share_gpu else "RCCL") +
                                          (" in a ONE-rank group (QS_BENCH_FORCE_EXCHANGE)" if force_exchange else ""))
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
+
+    def emit():
+        """rank 0 writes its ONE line exactly once, whoever gets here first (main thread or the watchdog below)"""
+        with emit_lock:
+            if rank == 0 and not emitted[0]:
+                emitted[0] = True
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+    if world > 1 and not args.no_configs and os.environ.get("QS_BENCH_NO_DDP_CONFIG", "0") != "1":
+        # BASELINE config 5 after the headline's timed region.  It is collective, so a rank that fails alone would leave
+        # the others waiting in RCCL: a watchdog on every rank ends the process cleanly at the deadline -- rank 0 after
+        # writing the headline record with the failure noted -- so config 5 can never cost the headline line.
+        del pair, x, gout
+        torch.cuda.empty_cache()
+        limit = float(os.environ.get("QS_BENCH_DDP_TIMEOUT", "480"))
+        t5 = time.perf_counter()
+
+        def bark():
+            if rank == 0 and "configs" not in out:
+                out["configs"] = {"config5_resnet50_ddp": {"error": f"did not finish within {limit:.0f} s (a rank failed or "
+                                                                    f"hung); the headline record is unaffected"}}
+            emit()
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, bark)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            rec5 = config5(device, world, rank)
+        except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
+            rec5 = {"error": f"{type(e).__name__}: {e}"[:400]}
+        rec5["bench_seconds"] = round(time.perf_counter() - t5, 1)
+        if rank == 0:
+            out["configs"] = {"config5_resnet50_ddp": rec5}
+        emit()                      # before the group is torn down: a hang in there ends at the watchdog, line already out
     if world > 1 or force_exchange:
         torch.cuda.synchronize()
         dist.destroy_process_group()
@@ -494,7 +602,7 @@ def main():
             out["configs"] = extra_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    emit()
     os.close(real_stdout)
 
 

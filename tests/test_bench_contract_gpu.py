@@ -1,7 +1,7 @@
 """The driver's contract for bench.py (task statement): ONE JSON line on stdout with the prescribed keys, launched
 exactly as the driver launches it -- plain for N = 1, through `python -m torch.distributed.run` for N > 1 (here two
 ranks sharing the box's single GPU over gloo, QS_BENCH_SHARE_GPU=1, which drives the whole N > 1 code path: rendezvous,
-statistics exchange every step, barrier + max-over-ranks timing, rank-0-only output)."""
+statistics exchange every step, barrier + max-over-ranks timing, rank-0-only output, config 5 under DDP)."""
 import json
 import os
 import socket
@@ -55,7 +55,7 @@ def test_single_gpu_line_with_roofline_variants_and_cpu_baseline():
 
 
 def test_two_ranks_through_torch_distributed_run():
-    env = dict(os.environ, QS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, QS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", QS_BENCH_DDP_BATCH="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
@@ -64,4 +64,10 @@ def test_two_ranks_through_torch_distributed_run():
     assert len(lines) == 1, r.stdout[-2000:]                # rank 0 only
     rec = json.loads(lines[0])
     _check(rec, 2, 12)
-    assert "exchange" in rec["config"] and "configs" not in rec and "cpu_baseline" not in rec
+    assert "exchange" in rec["config"] and "cpu_baseline" not in rec
+    # BASELINE config 5 rides on the N > 1 line: ResNet-50 --pq under DistributedDataParallel (here batch 8 per rank)
+    c5 = rec["configs"]["config5_resnet50_ddp"]
+    assert "error" not in c5, c5
+    assert c5["world"] == 2 and c5["input_shape_per_gpu"] == [8, 3, 224, 224]
+    assert c5["pq_images_per_s"] > 0 and c5["plain_images_per_s"] > 0
+    assert c5["operator_state_identical_across_ranks"] is True
