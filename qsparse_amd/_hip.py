@@ -529,6 +529,9 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     return out
 
 
+LAST2_MAX_TILE_BYTES = 63 * 1024 - 64     # qs_mean_last2 holds an [H*W + W + 8] float tile in LDS (64 KiB per workgroup)
+
+
 def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype, amax_part: Optional[torch.Tensor] = None,
                absmax_out: Optional[torch.Tensor] = None, record: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x viewed as [pre, H, W] -> [pre]: mean over H then over W, each rounded like ``Tensor.mean``.  `amax_part`

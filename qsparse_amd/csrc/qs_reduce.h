@@ -838,86 +838,127 @@ __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x,
     }
 }
 
-// mean_cl_kernel for launches with few waves (small maps, small batches): the R waves of a workgroup own the same
-// column groups and share the rows chunk-wise exactly as mean_outer_split_kernel does -- chunk sums (what ATen's
-// level-0 accumulator holds when it is dumped into level 1) parked in LDS, wave 0 feeds them in order through levels
-// 1..3 and adds the n % 2^p last rows; the waves' abs-max keys are combined through LDS as well.
-// LDS: [n / 2^p][8][64] floats + [R][8][64] keys.
+// mean_cl_kernel AND mean_cl_tail_kernel for launches with few waves (small maps, small batches), in ONE launch: the R
+// waves of a workgroup own the same column groups and share the rows.  ATen's order per column is a cascade over level-0
+// sums of 2^p consecutive items ("chunks": what its level-0 accumulator holds when it is dumped into level 1).  For a
+// main position (hw < 4*floor(HW/4), multi-row order) the items are the n rows; for one of the HW % 4 tail positions
+// (row-sum order) there are four interleaved sums k = 0..3 over the rows 4i + k, each a cascade of its own over n/4
+// items.  Every (chunk, k) pair is an independent sum from zero -- a "slot" -- so the waves take slots round robin,
+// park the slot sums in LDS, and wave 0 then feeds them IN ORDER through levels 1..3, adds the leftover items and
+// finishes (tail: ((p0 + p1) + p2) + p3 with the n % 4 last rows added to p0 first).  The waves' abs-max keys are
+// combined through LDS as well.  Workgroups [0, main_blocks) serve the main positions, the others the tail positions:
+// the tail used to be a launch of its own whose single wave per 512 columns walked all n rows alone (256 x 512 x 7 x 7
+// bf16: 32 of the stage's 47 us).  `lanes` (<= 64) lanes of each wave own a column group: narrow waves spread a small
+// tensor over more workgroups.  LDS: [slots][8][lanes] floats + [R][8][lanes] keys.
 template <int DT, int ODT, int R, int MODE>
-__global__ __launch_bounds__(64 * R) void mean_cl_split_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
-                                                                int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
-                                                                int lanes, int64_t ngroups) {
-    extern __shared__ __attribute__((aligned(16))) float cl_chunk_sums[];
+__global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
+                                                             int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
+                                                             int lanes, int64_t main_groups, int main_blocks,
+                                                             int64_t tail_groups, int slots) {
+    extern __shared__ __attribute__((aligned(16))) float cl_slot_sums[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t groups = hw * C / 8;
-    const int64_t t = (int64_t)blockIdx.x * lanes + lane;
-    const bool active = lane < lanes && t < ngroups;
-    const int lp = max(4, ceil_log2_i64(n) / 4);
+    const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
+    const bool tail = (int)blockIdx.x >= main_blocks;
+    const int64_t local = (int64_t)(tail ? (int)blockIdx.x - main_blocks : (int)blockIdx.x) * lanes + lane;
+    const bool active = lane < lanes && local < (tail ? tail_groups : main_groups);
+    const int64_t t = (tail ? main_groups : 0) + local;   // the group of every row this lane owns
+    const int64_t items = tail ? n / 4 : n;            // items per cascade
+    const int lp = max(4, ceil_log2_i64(items) / 4);
     const int64_t step = (int64_t)1 << lp, lmask = step - 1;
-    const int nchunks = (int)(n / step);
-    uint32_t* amax_lds = (uint32_t*)(cl_chunk_sums + (size_t)nchunks * 8 * 64);
+    const int nch = (int)(items / step);               // full chunks per cascade
+    const int nslots = tail ? 4 * nch : nch;
+    uint32_t* amax_lds = (uint32_t*)(cl_slot_sums + (size_t)slots * 8 * lanes);
     uint32_t amax[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax[j] = 0u;
     if (active) {
-        for (int ch = wave; ch < nchunks; ch += R) {
+        for (int v = wave; v < nslots; v += R) {
+            // rows of slot v: main  v*step + e;  tail (chunk v >> 2 of sum v & 3)  4*((v >> 2)*step + e) + (v & 3)
+            const int64_t r0 = tail ? 4 * (int64_t)(v >> 2) * step + (v & 3) : (int64_t)v * step;
+            const int64_t rs = tail ? 4 : 1;
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            const int64_t r0 = (int64_t)ch * step;
-            for (int64_t j = 0; j < step; j += 16) {
+            for (int64_t e = 0; e < step; e += 16) {
                 Raw8<DT> r[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (r0 + j + u) * groups);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 16; ++u) r[u] = load8_raw<DT, QS_MEAN_NT_LOADS>(x, t + (r0 + (e + u) * rs) * groups);
+                __builtin_amdgcn_sched_barrier(0);      // all 16 rows in flight before the first add
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    float v[8];
-                    unpack8<DT>(r[u], v);
+                    float w[8];
+                    unpack8<DT>(r[u], w);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += mean_cl_prep<MODE>(v[k], amax[k]);
+                    for (int k = 0; k < 8; ++k) acc[k] += mean_cl_prep<MODE>(w[k], amax[k]);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cl_chunk_sums[(ch * 8 + k) * 64 + lane] = acc[k];
+            for (int k = 0; k < 8; ++k) cl_slot_sums[((size_t)v * 8 + k) * lanes + lane] = acc[k];
         }
         if (wave > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) amax_lds[(wave * 8 + k) * 64 + lane] = amax[k];
+            for (int k = 0; k < 8; ++k) amax_lds[((size_t)wave * 8 + k) * lanes + lane] = amax[k];
         }
     }
     __syncthreads();
-    if (wave == 0 && active) {
+    if (wave != 0 || !active) return;
+    auto row = [&](int64_t i, auto add) {               // one leftover row, its 8 values handed to add(k, value)
+        float w[8];
+        unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) add(k, mean_cl_prep<MODE>(w[k], amax[k]));
+    };
+    float res[8];
+    if (!tail) {
         Cascade c[8];
-        for (int ch = 0; ch < nchunks; ++ch) {
+        for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                c[k].a0 = cl_chunk_sums[(ch * 8 + k) * 64 + lane];
+                c[k].a0 = cl_slot_sums[((size_t)ch * 8 + k) * lanes + lane];
                 c[k].carry((int64_t)(ch + 1) * step, lp, lmask);
             }
         }
-        for (int64_t i = (int64_t)nchunks * step; i < n; ++i) {
-            float v[8];
-            unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), v);
+        for (int64_t i = (int64_t)nch * step; i < n; ++i) row(i, [&](int k, float val) { c[k].add(val); });
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c[k].add(mean_cl_prep<MODE>(v[k], amax[k]));
-        }
-        for (int w = 1; w < R; ++w) {
+        for (int k = 0; k < 8; ++k) res[k] = c[k].total();
+    } else {
+        const int64_t n4 = items;
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {                   // the four interleaved sums, one after the other (registers)
+            Cascade c[8];
+            for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t o = amax_lds[(w * 8 + k) * 64 + lane];
-                amax[k] = o > amax[k] ? o : amax[k];
+                for (int k = 0; k < 8; ++k) {
+                    c[k].a0 = cl_slot_sums[((size_t)(ch * 4 + q) * 8 + k) * lanes + lane];
+                    c[k].carry((int64_t)(ch + 1) * step, lp, lmask);
+                }
+            }
+            for (int64_t e = (int64_t)nch * step; e < n4; ++e) row(4 * e + q, [&](int k, float val) { c[k].add(val); });
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) res[k] = c[k].total();
+                for (int64_t i = n4 * 4; i < n; ++i) row(i, [&](int k, float val) { res[k] += val; });   // n % 4 rows -> p0
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) res[k] += c[k].total();                                      // ((p0 + p1) + p2) + p3
             }
         }
-        const int64_t col0 = t * 8;
-        const int64_t pos = col0 / C, c0 = col0 - pos * C;
-        const float fn = (float)n;
+    }
+    for (int w = 1; w < R; ++w) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int64_t o = (c0 + k) * hw + pos;
-            store1<ODT>(out, o, c[k].total() / fn);
-            if (MODE != 3 && amax_part) amax_part[o] = amax[k];
+            const uint32_t o = amax_lds[((size_t)w * 8 + k) * lanes + lane];
+            amax[k] = o > amax[k] ? o : amax[k];
         }
+    }
+    const int64_t col0 = t * 8;
+    const int64_t pos = col0 / C, c0 = col0 - pos * C;
+    const float fn = (float)n;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t o = (c0 + k) * hw + pos;
+        store1<ODT>(out, o, res[k] / fn);               // .div_(n) in fp32, then one rounding to ODT
+        if (MODE != 3 && amax_part) amax_part[o] = amax[k];
     }
 }
 

@@ -78,6 +78,8 @@ inline int mean_lanes(int64_t total) {
     return best;
 }
 
+constexpr size_t kLast2MaxLds = 63 * 1024;    // qs_mean_last2's [H*W + W + 8] float tile (a workgroup may hold 64 KiB)
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 inline int dt_ok(int dt) { return dt == QS_F32 || dt == QS_BF16 || dt == QS_F16; }
 inline int hip_status(hipError_t e) { return (int)e; }
@@ -689,21 +691,41 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
         });
     }
     const int64_t main_groups = (hw / 4) * 4 * C / 8, tail_groups = hw * C / 8 - main_groups;   // ATen's split of H*W
-    const int lanes = mean_lanes(main_groups > 0 ? main_groups : 1);
-    const int blocks = (int)((main_groups + lanes - 1) / lanes);
-    const int tail_blocks = (int)((tail_groups + 63) / 64);
-    // few waves: split the rows over R waves per workgroup (measured: tools/bench_stats.py --cl)
-    const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
-    const int64_t nchunks = n >> lp;
+    auto chunks_of = [](int64_t items) {               // full level-0 chunks of a cascade over `items` items
+        const int lp = std::max(4, (items <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(items - 1))) / 4);
+        return items >> lp;
+    };
+    const int64_t nchunks = chunks_of(n), tail_slots = 4 * chunks_of(n / 4);
+    // Few waves: ONE launch of the workgroup kernel -- rows shared by the R waves of a workgroup, main and tail positions
+    // together, narrow waves when even that leaves CUs idle.  Many waves: the one-wave-per-512-columns kernel for the
+    // main positions; the tail positions still take the workgroup kernel.
+    const int64_t waves64 = (main_groups + 63) / 64;
+    const bool big = waves64 >= 512;
+    // measured on the activation shapes of a ResNet-50 step at batch 256 (tools/bench_stats.py --cl --b256; columns of
+    // 64-lane waves the main positions would fill -> best waves per workgroup : lanes per wave):
+    //   >= 784 -> 1 (the one-wave kernel);  392 and 196 -> 4 : 64 (R = 8 / 16 and narrower waves are slower: 22.5 vs 24-38 us on
+    //   256x128x28x28 bf16);  98 and 48 -> 8 : 32 (256x256x14x14 bf16 22.3 -> 15.7 us, 256x512x7x7 17.4 -> 15.5 us)
+    const int64_t g = big ? tail_groups : std::max(main_groups, tail_groups);
+    const int64_t gwaves = (g + 63) / 64;
+    int lanes = env_int("QS_CL_LANES", 0);
+    if (lanes != 16 && lanes != 32 && lanes != 64) lanes = gwaves < 128 ? 32 : 64;
+    const int64_t slots = std::max<int64_t>(big ? 0 : nchunks, tail_groups > 0 ? tail_slots : 0);
     int R = env_int("QS_MEAN_SPLIT", 0);
-    if (R == 0) {
-        const int64_t waves = (main_groups + 63) / 64;
-        R = waves < 512 ? 4 : (waves < 1024 ? 2 : 1);
-    }
-    R = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
-    while (R > 1 && R > nchunks) R >>= 1;
-    if (nchunks < 2 || nchunks + R > kMaxSplitChunks) R = 1;         // 64 KiB of LDS
-    const size_t lds = (size_t)(nchunks + R) * 8 * 64 * sizeof(float);
+    if (R == 0) R = gwaves >= 512 ? 1 : (gwaves < 128 ? 8 : 4);
+    R = R >= 16 ? 16 : (R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1)));
+    if (xdt == QS_F32 && R > 8) R = 8;                 // 16 fp32 rows in flight need > 128 VGPRs: 512-thread workgroups at most
+    while (R > 1 && (R > slots || (size_t)(slots + R) * 8 * lanes * sizeof(float) > 63 * 1024)) R >>= 1;
+    const size_t lds = (size_t)(slots + R) * 8 * lanes * sizeof(float);
+    const bool wg_ok = slots >= 1 && lds <= 63 * 1024;
+    // without the workgroup kernel (very long batches: the slot sums do not fit the LDS) both parts fall back to their
+    // one-wave kernels
+    const bool wg_main = wg_ok && !big && main_groups > 0;
+    const bool wg_tail = wg_ok && tail_groups > 0;
+    const int lanes1 = mean_lanes(main_groups > 0 ? main_groups : 1);
+    const int blocks1 = (int)((main_groups + lanes1 - 1) / lanes1);
+    const int wg_main_blocks = wg_main ? (int)((main_groups + lanes - 1) / lanes) : 0;
+    const int wg_tail_blocks = wg_tail ? (int)((tail_groups + lanes - 1) / lanes) : 0;
+    const int tail_blocks1 = (int)((tail_groups + 63) / 64);
     hipStream_t s = (hipStream_t)stream;
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
@@ -712,17 +734,26 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
             uint32_t* am = (uint32_t*)amax_part;
             auto launch = [&](auto M) {
                 constexpr int kM = decltype(M)::value;
-                if (blocks > 0 && R == 4)
-                    hipLaunchKernelGGL((mean_cl_split_kernel<XD, OD, 4, kM>), dim3(blocks), dim3(256), lds, s, x, out, n, hw, C,
-                                       am, lanes, main_groups);
-                else if (blocks > 0 && R == 2)
-                    hipLaunchKernelGGL((mean_cl_split_kernel<XD, OD, 2, kM>), dim3(blocks), dim3(128), lds, s, x, out, n, hw, C,
-                                       am, lanes, main_groups);
-                else if (blocks > 0)
-                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks), dim3(64), 0, s, x, out, n, hw, C, am, lanes,
+                if (!wg_main && main_groups > 0)
+                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks1), dim3(64), 0, s, x, out, n, hw, C, am, lanes1,
                                        main_groups);
-                if (tail_blocks > 0)
-                    hipLaunchKernelGGL((mean_cl_tail_kernel<XD, OD, kM>), dim3(tail_blocks), dim3(64), 0, s, x, out, n, hw, C,
+                if (wg_main || wg_tail) {
+                    auto wg = [&](auto RR) {
+                        constexpr int kR = decltype(RR)::value;
+                        hipLaunchKernelGGL((mean_cl_wg_kernel<XD, OD, kR, kM>), dim3(wg_main_blocks + wg_tail_blocks), dim3(64 * kR),
+                                           lds, s, x, out, n, hw, C, am, lanes, main_groups, wg_main_blocks, tail_groups,
+                                           (int)slots);
+                    };
+                    if constexpr (XD != QS_F32) {
+                        if (R == 16) wg(IC<16>{});
+                    }
+                    if (R == 8) wg(IC<8>{});
+                    else if (R == 4) wg(IC<4>{});
+                    else if (R == 2) wg(IC<2>{});
+                    else if (R == 1) wg(IC<1>{});
+                }
+                if (!wg_tail && tail_groups > 0)
+                    hipLaunchKernelGGL((mean_cl_tail_kernel<XD, OD, kM>), dim3(tail_blocks1), dim3(64), 0, s, x, out, n, hw, C,
                                        am, main_groups, tail_groups);
             };
             if (mode == 1) launch(IC<1>{});
@@ -740,7 +771,7 @@ int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, i
     if ((amax_part || (record && absmax_out)) && (!absmax_out || absmax_stride < 1)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     const size_t lds = (size_t)(H * W + W + 8) * sizeof(float);
-    if (lds > 48 * 1024 + 32 || pre > 0x7fffffff) return QS_ERR_ARG;
+    if (lds > kLast2MaxLds || pre > 0x7fffffff) return QS_ERR_ARG;
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         if (odt == QS_F32)

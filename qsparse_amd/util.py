@@ -111,7 +111,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         if xm is not like:
             N, C, H, W = x.shape
             flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
-            fusable = (dims == [0, 2, 3] and l0_flag is None and (H * W + W) * 4 <= 48 * 1024
+            fusable = (dims == [0, 2, 3] and l0_flag is None and (H * W + W) * 4 <= _hip.LAST2_MAX_TILE_BYTES
                        and flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU)
                        and not (flags == 0 and absmax_out is not None))
             if fusable:       # stages 2 + 3 in one launch, which also folds the per-element maxima per channel
@@ -132,7 +132,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
     for pos, d in enumerate(dims):
         nd = len(shape)
         if (not first and len(dims) - pos == 2 and d == nd - 2 and dims[pos + 1] == nd - 1
-                and (shape[d] * shape[d + 1] + shape[d + 1]) * 4 <= 48 * 1024):
+                and (shape[d] * shape[d + 1] + shape[d + 1]) * 4 <= _hip.LAST2_MAX_TILE_BYTES):
             # the two trailing dims are what is left: one fused launch (same order, same rounding points)
             pre = 1
             for s in shape[:d]:

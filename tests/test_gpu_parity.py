@@ -639,7 +639,9 @@ def test_row_split_statistics_kernel_all_widths(monkeypatch):
         from qsparse_amd.util import _staged_mean_hip
         g = torch.Generator().manual_seed(1)
         torch.set_num_threads(1)     # ATen's channels_last order depends on the thread split
-        for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7), (70, 16, 5, 5)):
+        for shape in ((64, 32, 7, 7), (256, 16, 8, 8), (100, 24, 6, 6), (512, 8, 4, 8), (37, 64, 7, 7), (70, 16, 5, 5),
+                      (300, 16, 3, 3), (63, 8, 5, 7), (130, 8, 1, 3), (257, 24, 2, 3), (1100, 8, 3, 3), (16, 40, 1, 1), (9, 16, 3, 3),
+                      (520, 16, 2, 2)):
             for dt in (torch.bfloat16, torch.float32, torch.float16):
                 for cl in (False, True):      # NCHW: qs_mean_dim's kernels; channels_last: qs_mean_dim_cl's
                     x = (torch.randn(shape, generator=g) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1)).to(dt)
@@ -655,8 +657,10 @@ def test_row_split_statistics_kernel_all_widths(monkeypatch):
         print('ok')
     """)
     # (split "1" + depth: the unsplit kernel with 16 / 32 rows in flight per wave)
-    for split, depth in (("0", "0"), ("2", "0"), ("4", "0"), ("8", "0"), ("1", "16"), ("1", "32")):
-        env = dict(os.environ, QS_MEAN_SPLIT=split, QS_MEAN_DEPTH=depth)
+    # (channels_last: the workgroup kernel also with 16 waves and with narrow waves, QS_CL_LANES)
+    for split, depth, lanes in (("0", "0", "0"), ("2", "0", "0"), ("4", "0", "16"), ("8", "0", "32"), ("16", "0", "0"), ("16", "0", "16"),
+                                ("1", "16", "64"), ("1", "32", "0")):
+        env = dict(os.environ, QS_MEAN_SPLIT=split, QS_MEAN_DEPTH=depth, QS_CL_LANES=lanes)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "ok" in r.stdout, (split, r.stdout[-500:], r.stderr[-1500:])

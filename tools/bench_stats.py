@@ -15,6 +15,10 @@ SHAPES = [(64, 64, 56, 56), (64, 256, 56, 56), (64, 128, 28, 28), (64, 512, 28, 
           (256, 128, 28, 28), (256, 256, 56, 56)]
 
 
+B256 = [(256, 64, 112, 112), (256, 64, 56, 56), (256, 256, 56, 56), (256, 128, 56, 56), (256, 128, 28, 28), (256, 512, 28, 28),
+        (256, 256, 28, 28), (256, 256, 14, 14), (256, 1024, 14, 14), (256, 512, 14, 14), (256, 512, 7, 7), (256, 2048, 7, 7)]
+
+
 def t_us(fn, iters=30, warm=5):
     for _ in range(warm):
         fn()
@@ -38,9 +42,10 @@ def main():
     stride = 1 if "--dense" in sys.argv else 32     # abs-max accumulator: dense float[C] or one 128-byte line per channel
     channels_last = "--cl" in sys.argv
     depth_sweep = "--depth" in sys.argv          # sweep the rows in flight per wave (QS_MEAN_DEPTH) of the unsplit kernel instead
-    splits = [int(s) for s in sys.argv[1:] if s.isdigit()] or ([0, 16, 32] if depth_sweep else [0, 1, 2, 4, 8])
+    # cells: R (waves per workgroup, 0 = the host's own choice) or R:lanes (channels_last: QS_CL_LANES)
+    splits = [s for s in sys.argv[1:] if s.replace(":", "").isdigit()] or (["0", "16", "32"] if depth_sweep else ["0", "1", "2", "4", "8"])
     print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{('D=' if depth_sweep else 'R=') + str(r):>14s}" for r in splits))
-    for shp in SHAPES:
+    for shp in (B256 if "--b256" in sys.argv else SHAPES):
         N, C, H, W = shp
         for dtype, code, nbytes in ((torch.bfloat16, 1, 2), (torch.float32, 0, 4)):
             nrot = max(1, min(6, int(6e8 // (N * C * H * W * nbytes))))     # rotate inputs past the 256 MiB Infinity Cache
@@ -51,7 +56,9 @@ def main():
             amax = torch.zeros(C * 32, device=dev)
             part = torch.empty(C * H * W, device=dev)
             cells = []
-            for r in splits:
+            for cell in splits:
+                r = int(cell.split(":")[0])
+                os.environ["QS_CL_LANES"] = cell.split(":")[1] if ":" in cell else "0"
                 if depth_sweep:
                     os.environ["QS_MEAN_SPLIT"], os.environ["QS_MEAN_DEPTH"] = ("1" if r else "0"), str(r)
                 else:
@@ -70,7 +77,7 @@ def main():
                 us = t_us(stats_cl if channels_last else stats)
                 cells.append(f"{us:6.1f}us {x.numel() * nbytes / us / 1e3:5.0f}GB/s"[:14].rjust(14))
             print(f"{str(shp):24s} {str(dtype)[6:]:6s} " + " ".join(cells), flush=True)
-    os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = "0"
+    os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = os.environ["QS_CL_LANES"] = "0"
 
 
 if __name__ == "__main__":
