@@ -204,7 +204,8 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
 
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].
- * Same summation order and rounding points as two qs_mean_dim calls.  (H*W + W)*4 bytes of LDS <= 48 KiB,
+ * Same summation order and rounding points as two qs_mean_dim calls.  (H*W + W + 8)*4 bytes of LDS <= 63 KiB
+ * (112 x 112 maps fit),
  * otherwise QS_ERR_ARG (use two qs_mean_dim calls).
  * amax_part (nullable, [pre, H, W] from qs_mean_dim_cl): absmax_out[p * absmax_stride] is max-accumulated with the
  * maximum of slice p.

@@ -49,7 +49,7 @@ def build(rng):
     dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
     if what in ("conv", "linear"):
         dtype = torch.float32
-    n = rng.choice([1, 2, 4, 8, 16, 17, 48, 64, 130])
+    n = rng.choice([1, 2, 4, 8, 16, 17, 48, 64, 130, 256, 300])
     c = rng.choice([2, 4, 6, 16, 33, 64, 96, 256])
     hw = rng.choice([(1, 1), (3, 3), (7, 7), (8, 8), (5, 6), (14, 14), (16, 16), (28, 28)])
     if what in ("conv", "linear"):

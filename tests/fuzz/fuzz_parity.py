@@ -25,7 +25,7 @@ VERBOSE = bool(os.environ.get("QS_FUZZ_ONLY"))
 
 def rand_shape(rng):
     kind = rng.choice(["nchw", "nchw", "nchw", "nc", "ncl", "ncdhw"])
-    n = rng.choice([1, 2, 3, 4, 8, 16, 17, 32, 33, 64, 100])
+    n = rng.choice([1, 2, 3, 4, 8, 16, 17, 32, 33, 64, 100, 130, 256, 300])
     c = rng.choice([2, 3, 8, 16, 24, 31, 64, 130, 256, 300])
     if kind == "nc":
         return (n, c)
