@@ -462,24 +462,34 @@ __device__ __forceinline__ float round_to_dtype(float v, int dt) {
 }
 __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
                                     int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt, int lines) {
-    if (t_dev) {
-        t = (float)*t_dev;
-        tp1 = (float)(*t_dev + 1);
-    }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float am = absmax[i];
-        if (lines > 1) {      // n == 1: the tensor-wise abs-max arrives in `lines` partial accumulators (reduce_all_kernel)
-            uint32_t k = __float_as_uint(am);
-            for (int l = 1; l < lines; ++l) {
-                const uint32_t o = __float_as_uint(absmax[(int64_t)l * QS_AMAX_LINE_STRIDE]);
-                k = o > k ? o : k;          // keys of |x|: non-negative floats (and NaN on top) order like their bits
-                if (clear) absmax[(int64_t)l * QS_AMAX_LINE_STRIDE] = 0.0f;
-            }
-            am = __uint_as_float(k);
+    if (lines > 1) {
+        // n == 1 (one workgroup): the tensor-wise abs-max arrives in `lines` (<= 64) partial accumulators on lines of their
+        // own (reduce_all_kernel).  Lane l fetches line l and the counter / the old scale are fetched alongside: ONE memory
+        // round trip.  (A loop over the lines in one thread was sixteen dependent round trips -- 6.8 us per launch in a
+        // ResNet-18 step, rocprofv3, for a kernel that computes one number.)
+        const int l = threadIdx.x;
+        uint32_t k = (l < lines) ? __float_as_uint(absmax[(int64_t)l * QS_AMAX_LINE_STRIDE]) : 0u;
+        const float w_old = weight[0];
+        if (t_dev) {
+            t = (float)*t_dev;
+            tp1 = (float)(*t_dev + 1);
         }
-        const float nw = round_to_dtype(am / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
-        weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;  // (:344-347)
-        if (clear) absmax[i] = 0.0f;
+        if (clear && l < lines) absmax[(int64_t)l * QS_AMAX_LINE_STRIDE] = 0.0f;
+        if (l < 64) k = wave_max_u32(k);      // keys of |x|: non-negative floats (and NaN on top) order like their bits
+        if (l == 0) {
+            const float nw = round_to_dtype(__uint_as_float(k) / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
+            weight[0] = (t == 0.0f) ? nw : (t * w_old + nw) / tp1;                  // (:344-347)
+        }
+    } else {
+        if (t_dev) {
+            t = (float)*t_dev;
+            tp1 = (float)(*t_dev + 1);
+        }
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const float nw = round_to_dtype(absmax[i] / denom, stat_dt);   // max / 2**(bits-1) in x's dtype (quantize.py:340)
+            weight[i] = (t == 0.0f) ? nw : (t * weight[i] + nw) / tp1;     // (:344-347)
+            if (clear) absmax[i] = 0.0f;
+        }
     }
     if (bump && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(bump, 1);
     if (advance && t_dev) {      // single-workgroup launch: every thread has read the counter before it moves
@@ -1499,6 +1509,7 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
 template <int SDT, int ITEMS>
 __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* stage, SelectShared& sh, uint32_t* sh_max) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
+    const float scale_old = a.update_scale ? a.scale[0] : 0.f;   // fetched with the first round trip, not as one of its own at the end
     float mag[ITEMS];
     uint32_t amax[ITEMS];
     uint8_t keep[ITEMS];
@@ -1544,7 +1555,7 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
         if (tid == 0) {
             for (int i = 1; i < nthreads / 64; ++i) m = sh_max[i] > m ? sh_max[i] : m;
             const float nw = round_to_dtype(__uint_as_float(m) / a.denom, a.stat_dt);
-            a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * a.scale[0] + nw) / a.t_q1;
+            a.scale[0] = (a.t_q == 0.0f) ? nw : (a.t_q * scale_old + nw) / a.t_q1;
         }
     }
     if (tid == 0) {
@@ -1585,9 +1596,26 @@ __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restri
     if (amax_part) {   // per-element maxima left by mean_cl_kernel -> per-channel abs-max (this workgroup owns channel p)
         __shared__ uint32_t wmax[kBlock / 64];
         uint32_t m = 0u;
-        for (int i = threadIdx.x; i < hw; i += kBlock) {
-            const uint32_t k = amax_part[p * hw + i];
-            m = k > m ? k : m;
+        if ((hw & 3) == 0 && (((uintptr_t)amax_part) & 15) == 0) {
+            // 16-byte loads, four in flight per thread: 56 x 56 maps took thirteen dependent 4-byte round trips here
+            const uint4* part4 = reinterpret_cast<const uint4*>(amax_part + p * hw);
+            const int n4 = hw >> 2;
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * kBlock) {
+                uint4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = (i0 + u * kBlock < n4) ? part4[i0 + u * kBlock] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t a = q[u].x > q[u].y ? q[u].x : q[u].y, b = q[u].z > q[u].w ? q[u].z : q[u].w;
+                    const uint32_t k = a > b ? a : b;
+                    m = k > m ? k : m;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < hw; i += kBlock) {
+                const uint32_t k = amax_part[p * hw + i];
+                m = k > m ? k : m;
+            }
         }
         m = wave_max_u32(m);
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
