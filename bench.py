@@ -106,19 +106,21 @@ def _cpu_steps(batch, reps, threads):
     return x.numel() / best / 1e9
 
 
-def cpu_baseline(batch=64, reps=8, threads=None):
-    """the oracle (a port of the reference's ATen op chain) timed on this host's cores on a bounded sample of the
-    same workload: the same tensor restricted to `batch` samples (a SLICE of the headline tensor, about 10 s of CPU
-    work in total), with the best thread count found on the GPU box's EPYC (32; 8/16/64/128 threads were slower) and
-    with one thread."""
+def cpu_baseline(batch=None, reps=3, threads=None):
+    """the oracle (a port of the reference's ATen op chain) timed on this host's cores as BASELINE.md section 3 plans it:
+    the SAME tensor as the GPU run (all 256 samples; QS_CPU_BATCH restricts it to a slice on small hosts), training mode
+    in steady state, min of 3 after the warm-up steps -- about 10 s of CPU work -- with the best thread count found on
+    the GPU box's EPYC (32; 8/16/64/128 threads were slower) and, on a 32-sample slice, with one thread."""
     cores = threads or int(os.environ.get("QS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+    batch = batch or int(os.environ.get("QS_CPU_BATCH", "0")) or SHAPE[0]
     multi = _cpu_steps(batch, reps, cores)
-    single = _cpu_steps(max(batch // 2, 1), 2, 1)
+    single = _cpu_steps(min(32, batch), 2, 1)
+    what = "the headline tensor itself" if batch == SHAPE[0] else f"a {batch}-sample slice of the headline tensor"
     return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
             "value_1thread": round(single, 4),
-            "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on a "
-                      f"{batch}x256x56x56 bf16 slice of the headline tensor, best of {reps} ({cores} threads); "
-                      f"{max(batch // 2, 1)}x256x56x56, best of 2 (1 thread); torch {torch.__version__} CPU"}
+            "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on {what} "
+                      f"({batch}x256x56x56 bf16), min of {reps} after 2 warm-up steps ({cores} threads); "
+                      f"{min(32, batch)}x256x56x56, best of 2 (1 thread); torch {torch.__version__} CPU"}
 
 
 # ---------------------------------------------------------------------------------------------------
