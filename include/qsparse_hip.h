@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 8
+#define QS_ABI_VERSION 9
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -141,9 +141,14 @@ int qs_absmax(const void* x, float* out, int per_channel,
               void* ws, size_t ws_bytes, qs_stream_t stream);
 
 /* min and max of x over the tensor or per channel; AdaptiveQuantizer.optimize, quantize.py:410-418
- * (min over the batch of per-sample minima == global per-channel minimum). */
+ * (min over the batch of per-sample minima == global per-channel minimum).
+ * accumulate == 0: out_min / out_max receive floats (three launches: key initialisation, reduction, key -> float).
+ * accumulate != 0: out_min / out_max are persistent buffers of order-preserving uint32 KEYS, neutral on entry (min keys
+ * 0xffffffff, max keys 0), min- / max-accumulated by ONE launch and left as keys: qs_lines_update(from_keys = 1) turns them
+ * into floats and makes them neutral again -- two launches per AdaptiveQuantizer step instead of four (ABI v9). */
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel,
-              int64_t outer, int64_t C, int64_t inner, int xdt, void* ws, size_t ws_bytes, qs_stream_t stream);
+              int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate, void* ws, size_t ws_bytes,
+              qs_stream_t stream);
 
 /* Step counters.  The reference keeps them on the host (Python ints / `.item()` reads) and they enter the
  * arithmetic of every running mean.  A by-value kernel argument is frozen when a launch is captured into a
@@ -163,9 +168,10 @@ int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, i
                     int advance_t_dev, int bits, int clear_absmax, int32_t* bump_i32, int stat_dt, qs_stream_t stream);
 
 /* lines[i] <- (lines[i]*(t-1) + (mn[i], mx[i])) / t   with t already incremented (quantize.py:427-430);
- * t_dev holds the counter BEFORE the increment (t = *t_dev + 1). */
-int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after,
-                    int64_t* t_dev, int advance_t_dev, qs_stream_t stream);
+ * t_dev holds the counter BEFORE the increment (t = *t_dev + 1).  from_keys != 0: mn / mx hold the keys of
+ * qs_minmax(accumulate = 1); they are converted here and reset to the neutral keys. */
+int qs_lines_update(float* mn, float* mx, float* lines, int64_t n, int64_t t_after,
+                    int64_t* t_dev, int advance_t_dev, int from_keys, qs_stream_t stream);
 
 /* d[i] = rint(log2(nan_to_num(1/scale[i], posinf=1, neginf=1)))  (quantize.py:316) */
 int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stream_t stream);

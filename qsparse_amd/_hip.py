@@ -41,9 +41,9 @@ SIGNATURES = {
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
-    "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _P, c_size_t, _P]),
+    "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _I, _P, c_size_t, _P]),
     "qs_scale_update": (c_int, [_P, _I, _P, _L, _L, _P, _I, _I, _I, _P, _I, _P]),
-    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _I, _P]),
+    "qs_lines_update": (c_int, [_P, _P, _P, _L, _L, _P, _I, _I, _P]),
     "qs_decimal_from_scale": (c_int, [_P, _P, _L, _P]),
     "qs_mean_dim": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _L, _L, _L, _P]),
     "qs_l0_flag": (c_int, [_P, _L, _I, _P, _P, _P]),
@@ -445,17 +445,30 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
     return out
 
 
-def minmax(x: torch.Tensor, channel_index: int):
+def minmax_key_buffers(n: int, device):
+    """persistent accumulators of a min/max statistic as order-preserving uint32 keys (held in int32 tensors), neutral:
+    min keys 0xffffffff, max keys 0 -- `minmax(accumulate_into=...)` accumulates into them, `lines_update(from_keys=True)`
+    consumes and resets them."""
+    return (torch.full((n,), -1, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.int32, device=device))
+
+
+def minmax(x: torch.Tensor, channel_index: int, accumulate_into=None):
+    """(min, max) of x over the tensor / per channel as float32 tensors; with `accumulate_into` (a `minmax_key_buffers`
+    pair) ONE launch that leaves keys in those buffers (returned as they are)."""
     lib = load()
     x, channel_index, _ = mem_view(x, channel_index)
     outer, C, inner, numel = split3(x.shape, channel_index)
     n = C if channel_index >= 0 else 1
-    mn = torch.empty(n, dtype=torch.float32, device=x.device)
-    mx = torch.empty(n, dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        mn, mx = accumulate_into
+        assert mn.numel() == n and mx.numel() == n and mn.dtype == torch.int32 and mx.dtype == torch.int32
+    else:
+        mn = torch.empty(n, dtype=torch.float32, device=x.device)
+        mx = torch.empty(n, dtype=torch.float32, device=x.device)
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
     with _timed("minmax"):
-        st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x), _ptr(ws), ws_bytes,
-                           _stream(x))
+        st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x),
+                           int(accumulate_into is not None), _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_minmax")
     return mn, mx
 
@@ -477,11 +490,13 @@ def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int
 
 
 def lines_update(mn: torch.Tensor, mx: torch.Tensor, lines: torch.Tensor, t_after: int,
-                 t_dev: Optional[torch.Tensor] = None, advance_t_dev: bool = False):
+                 t_dev: Optional[torch.Tensor] = None, advance_t_dev: bool = False, from_keys: bool = False):
+    """`from_keys`: mn / mx are the key buffers `minmax(accumulate_into=...)` filled; consumed and reset here."""
     assert lines.dtype == torch.float32 and lines.is_contiguous()
+    assert mn.dtype == mx.dtype == (torch.int32 if from_keys else torch.float32)
     with _timed("lines_update"):
         st = load().qs_lines_update(_ptr(mn), _ptr(mx), _ptr(lines), mn.numel(), int(t_after), _ptr(t_dev), int(advance_t_dev),
-                                _stream(lines))
+                                int(from_keys), _stream(lines))
     _check(st, "qs_lines_update")
 
 

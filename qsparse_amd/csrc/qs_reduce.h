@@ -497,15 +497,25 @@ __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, flo
         if (threadIdx.x == 0) *t_dev += 1;
     }
 }
-__global__ void lines_update_kernel(const float* mn, const float* mx, float* lines, int64_t n, float tm1, float t,
-                                    int64_t* t_dev, int advance) {
+// `from_keys`: mn / mx hold the order-preserving keys qs_minmax(accumulate) leaves behind; they are turned into floats here
+// and reset to the neutral keys (max 0, min 0xffffffff) for the next statistics pass -- which saves the key-initialisation
+// and the key -> float launches of a min/max call
+__global__ void lines_update_kernel(float* mn, float* mx, float* lines, int64_t n, float tm1, float t,
+                                    int64_t* t_dev, int advance, int from_keys) {
     if (t_dev) {   // counter BEFORE this step's increment
         tm1 = (float)*t_dev;
         t = (float)(*t_dev + 1);
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        lines[2 * i] = (lines[2 * i] * tm1 + mn[i]) / t;          // (quantize.py:430)
-        lines[2 * i + 1] = (lines[2 * i + 1] * tm1 + mx[i]) / t;
+        float lo = mn[i], hi = mx[i];
+        if (from_keys) {
+            lo = key_to_f32(__float_as_uint(lo));
+            hi = key_to_f32(__float_as_uint(hi));
+            ((uint32_t*)mn)[i] = 0xffffffffu;
+            ((uint32_t*)mx)[i] = 0u;
+        }
+        lines[2 * i] = (lines[2 * i] * tm1 + lo) / t;          // (quantize.py:430)
+        lines[2 * i + 1] = (lines[2 * i + 1] * tm1 + hi) / t;
     }
     if (advance && t_dev) {
         __syncthreads();
@@ -686,6 +696,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
     const int64_t row_groups = post / 8;             // 16-byte groups per row (post % 8 == 0 guaranteed)
     const int64_t g_base = p * n * row_groups + gc;
     uint32_t amax = 0u;
+    RedAcc<DT, true> mm;                             // MODE 6: per-channel min and max (qs_minmax's column walk)
 
     if (active) {
         Cascade acc[8];
@@ -706,6 +717,8 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                         amax = k > amax ? k : amax;
                     }
                     acc[j].add(mean_prep<DT>(v[j], flags, l0));
+                } else if constexpr (MODE == 6) {   // min / max ONLY, no sum, no output: the column walk of a per-channel min/max
+                    mm.add(v[j]);
                 } else if constexpr (MODE >= 4) {   // abs-max ONLY (4: |x|, 5: max(x, 0)): no sum, no output -- the column walk
                     const float w = (MODE == 5) ? relu_aten(v[j]) : v[j];     // as the per-channel abs-max of a big tensor
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
@@ -768,6 +781,25 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
         }
     }
 
+    if constexpr (MODE == 6) {
+        // keys as RedAcc keeps them (NaN on top of the maxima); `out` carries the MIN keys of this mode, `absmax` the MAX
+        // keys; the host guarantees chan_div % 8 == 0 (a lane inside one channel).  Idle lanes hold the neutral keys.
+        uint32_t* kmin = (uint32_t*)out;
+        mm.fold();
+        const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
+        const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
+        if (__all(!active || c == c0)) {
+            const uint32_t hi = wave_max_u32(mm.mx), lo = wave_min_u32(mm.mn);
+            if (threadIdx.x == 0) {
+                atomicMax(absmax + (size_t)c0 * astride, hi);
+                atomicMin(kmin + (size_t)c0 * astride, lo);
+            }
+        } else if (active) {
+            atomicMax(absmax + (size_t)c * astride, mm.mx);
+            atomicMin(kmin + (size_t)c * astride, mm.mn);
+        }
+        return;
+    }
     if (absmax) {   // whole wave takes part: idle lanes contribute 0
         if (chan_div % 8 == 0) {   // all 8 columns of a lane share a channel
             const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);

@@ -463,7 +463,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     if (grid > cap) grid = cap;
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu,
                                        lines);
-                } else if (!M && vec_ptr && inner % 8 == 0 && outer >= 16 && (C * inner) / 8 >= 64 * 1024) {
+                } else if (vec_ptr && inner % 8 == 0 && outer >= 16 && (C * inner) / 8 >= 64 * 1024) {
                     // big tensors ([N, C, H*W] with >= 1024 waves of column groups): the column walk of the statistics
                     // kernel -- a lane keeps 8 adjacent columns and loops over N in registers, one atomic per wave and
                     // channel at the end -- streams at the statistics kernel's rate, where workgroups that hop from row
@@ -471,7 +471,11 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     const int64_t post = C * inner, total = post / 8;
                     const int lanes = mean_lanes(total);
                     const int blocks = (int)((total + lanes - 1) / lanes);
-                    if (relu)
+                    if (M)       // min and max: `out` carries the min keys (MODE 6)
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 6>), dim3(blocks), dim3(64), 0, s, x,
+                                           (void*)omin, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
+                                           inner, (uint32_t)C, lanes);
+                    else if (relu)
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 5>), dim3(blocks), dim3(64), 0, s, x,
                                            (void*)nullptr, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
                                            inner, (uint32_t)C, lanes);
@@ -523,7 +527,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
         });
         if (st) return st;
     }
-    if (minmax && !finalize) hipLaunchKernelGGL(keys_to_float_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
+    if (minmax && !finalize && !accumulate) hipLaunchKernelGGL(keys_to_float_kernel, dim3(ib), dim3(256), 0, s, omax, omin, nout);
     return launch_status();
 }
 
@@ -535,9 +539,9 @@ int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
-              int xdt, void* ws, size_t ws_bytes, qs_stream_t stream) {
-    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream, false, 0, ws,
-                       ws_bytes);
+              int xdt, int accumulate, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0, 0,
+                       ws, ws_bytes);
 }
 
 int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev,
@@ -554,14 +558,14 @@ int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, i
     return launch_status();
 }
 
-int qs_lines_update(const float* mn, const float* mx, float* lines, int64_t n, int64_t t_after, int64_t* t_dev,
-                    int advance_t_dev, qs_stream_t stream) {
+int qs_lines_update(float* mn, float* mx, float* lines, int64_t n, int64_t t_after, int64_t* t_dev,
+                    int advance_t_dev, int from_keys, qs_stream_t stream) {
     if (!mn || !mx || !lines || n < 0 || t_after < 1) return QS_ERR_ARG;
     if (n == 0) return QS_OK;
     const int advance = (advance_t_dev && t_dev) ? 1 : 0;
     const int blocks = advance ? 1 : (int)((n + 255) / 256);
     hipLaunchKernelGGL(lines_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mn, mx, lines, n,
-                       (float)(t_after - 1), (float)t_after, t_dev, advance);
+                       (float)(t_after - 1), (float)t_after, t_dev, advance, from_keys != 0);
     return launch_status();
 }
 

@@ -389,15 +389,25 @@ class AdaptiveQuantizer(DecimalQuantizer):
     def optimize(self, x, bits, weight=None, channel_index=-1, batched=False, **kwargs):
         with torch.no_grad():
             if x.is_cuda:
-                lo, hi = _hip.minmax(x, channel_index)
-                if batched:
+                # nothing to exchange between the reduction and the update (one process, or a weight): ONE reduction launch
+                # into persistent key buffers, which the running-mean launch converts and resets -- two launches instead of
+                # four (key initialisation, reduction, key -> float, running mean)
+                keyed = weight is not None and not (batched and qdist.exchange_active())
+                if keyed:
+                    n_stat = weight.shape[0]
+                    bufs = self.__dict__.setdefault("_minmax_keys", {})
+                    keys = bufs.get((n_stat, x.device))
+                    if keys is None:
+                        keys = bufs[(n_stat, x.device)] = _hip.minmax_key_buffers(n_stat, x.device)
+                lo, hi = _hip.minmax(x, channel_index, accumulate_into=keys if keyed else None)
+                if batched and not keyed:
                     qdist.allreduce_min_(lo), qdist.allreduce_max_(hi)
                 if weight is None:
                     self.t += 1
                     return torch.stack([lo, hi], dim=1)
                 assert weight.shape == (lo.numel(), 2)
                 t_dev = self.device_t(x.device) if get_option("graph_safe") else None
-                _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev, advance_t_dev=True)
+                _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev, advance_t_dev=True, from_keys=keyed)
                 self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight
             bounds = self._bounds_cpu(x, channel_index, batched)

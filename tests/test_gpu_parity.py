@@ -42,7 +42,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 8
+    assert lib.qs_version() == 9
     assert torch.cuda.is_available()
 
 
@@ -1213,3 +1213,33 @@ def test_channel_mismatch_in_eval_raises_runtime_error_like_the_reference():
     lone.eval()
     with pytest.raises(RuntimeError):
         lone(torch.randn(2, 12, 8, 8).to(DEV))
+
+
+def test_minmax_key_accumulation_equals_the_float_route():
+    """qs_minmax(accumulate) leaves order-preserving keys in persistent buffers and qs_lines_update(from_keys) converts and
+    resets them: the running (min, max) lines must carry the same bits as the four-launch route (key initialisation,
+    reduction, key -> float, running mean) over several steps -- tensor-wise and per channel, NCHW (rows, columns and the big
+    tensors' column walk) and channels_last, with -0.0 and NaN in the data."""
+    cases = (((64, 48, 9, 9), 1), ((3, 5, 64), 1), ((1000, 16), 1), ((16, 2048, 7, 7), 1), ((4, 6, 10, 10), 2), ((70000,), -1),
+             ((37, 12, 14, 14), 1), ((50, 1024, 14, 14), 1), ((8192, 256), 1), ((16, 128, 64, 64), 1), ((32, 1024, 8, 8), 1))
+    for si, (shape, ci) in enumerate(cases):
+        for dtype in (torch.float32, torch.bfloat16):
+            for cl in ((False, True) if len(shape) == 4 and ci == 1 else (False,)):
+                n = shape[ci] if ci >= 0 else 1
+                keys = _hip.minmax_key_buffers(n, DEV)
+                la, lb = torch.zeros(n, 2, device=DEV), torch.zeros(n, 2, device=DEV)
+                for t in range(3):
+                    x = (torch.randn(shape, generator=gen(7000 + 10 * si + t)) * 3).to(dtype)
+                    if t == 1:
+                        x.view(-1)[0] = -0.0
+                    if t == 2 and x.numel() > 100:
+                        x.view(-1)[77] = float("nan")
+                    xg = x.to(DEV)
+                    if cl:
+                        xg = xg.contiguous(memory_format=torch.channels_last)
+                    kmn, kmx = _hip.minmax(xg, ci, accumulate_into=keys)
+                    _hip.lines_update(kmn, kmx, la, t + 1, from_keys=True)
+                    mn, mx = _hip.minmax(xg, ci)
+                    _hip.lines_update(mn, mx, lb, t + 1)
+                    assert same(la.cpu(), lb.cpu()), (shape, ci, dtype, cl, t)
+                    assert bool((keys[0] == -1).all()) and not keys[1].any(), (shape, ci, dtype, cl, t)     # neutral again

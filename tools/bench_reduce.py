@@ -60,8 +60,15 @@ def one():
         if nb and C % 8 == 0:      # the same tensor taken as channels_last: [N*H*W, C], channel dim innermost (reduce_fewcols_kernel)
             ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
             r["chan_cl"] = t_us(lambda: lib.qs_absmax(x.data_ptr(), ac.data_ptr(), 1, N * H * W, C, 1, 1, 1, 0, 1, ws.data_ptr(), nb, None))
-            r["chan_cl_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N * H * W, C, 1, 1, ws.data_ptr(), nb, None))
-        r["chan_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N, C, H * W, 1, None, 0, None))
+            r["chan_cl_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N * H * W, C, 1, 1, 0, ws.data_ptr(), nb, None))
+            kmn, kmx = _hip.minmax_key_buffers(C, "cuda")
+            r["chan_cl_minmax_keys"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), kmn.data_ptr(), kmx.data_ptr(), 1, N * H * W, C, 1, 1, 1, ws.data_ptr(), nb, None))
+        r["chan_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 1, N, C, H * W, 1, 0, None, 0, None))
+        kmn, kmx = _hip.minmax_key_buffers(C, "cuda")      # accumulate mode: ONE launch, keys left for qs_lines_update(from_keys)
+        r["chan_minmax_keys"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), kmn.data_ptr(), kmx.data_ptr(), 1, N, C, H * W, 1, 1, None, 0, None))
+        k1n, k1x = _hip.minmax_key_buffers(1, "cuda")
+        r["all_minmax"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), mn.data_ptr(), mx.data_ptr(), 0, 1, 1, x.numel(), 1, 0, None, 0, None))
+        r["all_minmax_keys"] = t_us(lambda: lib.qs_minmax(x.data_ptr(), k1n.data_ptr(), k1x.data_ptr(), 0, 1, 1, x.numel(), 1, 1, None, 0, None))
         r["ideal@6TB/s"] = round(x.numel() * 2 / 6e6, 1)
         out[str(shp)] = r
     print(json.dumps(out))
