@@ -328,6 +328,9 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __r
 // atomics: 512 workgroups x C channels of them cost more than the whole read (64x64x56x56 bf16: 76 us -> 12 us).
 constexpr int kFewColsMaxBlocks = 512;   // 2 workgroups per CU (measured: 256 -> 98 us, 512 -> 73 us, 1024 -> 76 us + a longer finish on 411 MB)
 constexpr int kFewColsMaxCols = 512;
+#ifndef QS_FEWCOLS_INFLIGHT
+#define QS_FEWCOLS_INFLIGHT 8      // 16-byte loads in flight per lane (16: no faster -- channels_last min/max of the headline tensor 101 vs 105 us)
+#endif
 
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
     // grid-stride over blocks of 8 * rows_per_iter rows: at any moment the whole grid reads ONE moving window of
     // gridDim.x * 32 KiB (as reduce_all_kernel does) instead of gridDim.x far-apart private streams, which cost DRAM page
     // locality (5.5 TB/s where the tensor-wise kernel streams at 6.3)
-    const int64_t o0 = (int64_t)blockIdx.x * rows_per_iter * 8, o1 = outer;
-    const int64_t ostride = (int64_t)gridDim.x * rows_per_iter * 8;
+    const int64_t o0 = (int64_t)blockIdx.x * rows_per_iter * QS_FEWCOLS_INFLIGHT, o1 = outer;
+    const int64_t ostride = (int64_t)gridDim.x * rows_per_iter * QS_FEWCOLS_INFLIGHT;
     for (int i = threadIdx.x; i < cols; i += kBlock) {
         lmx[i] = 0u;
         lmn[i] = 0xffffffffu;
@@ -351,12 +354,13 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
     for (int j = 0; j < 8; ++j) acc[j].relu = relu;
     if (row_l < rows_per_iter) {
         for (int64_t o = o0 + row_l; o < o1; o += ostride) {
-            Raw8<DT> r[8];
+            constexpr int F = QS_FEWCOLS_INFLIGHT;
+            Raw8<DT> r[F];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < F; ++u)
                 if (o + (int64_t)u * rows_per_iter < o1) r[u] = load8_raw<DT, false>(x, (o + (int64_t)u * rows_per_iter) * gcols + gc);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < F; ++u) {
                 if (o + (int64_t)u * rows_per_iter < o1) {
                     float v[8];
                     unpack8<DT>(r[u], v);
