@@ -565,6 +565,9 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
 #ifndef QS_WIDEN_NT_STORE
 #define QS_WIDEN_NT_STORE 1
 #endif
+#ifndef QS_WIDEN_PRUNED_NT_STORE
+#define QS_WIDEN_PRUNED_NT_STORE QS_WIDEN_NT_STORE   // the store-only waves of an eliding forward (all rows of the wave pruned)
+#endif
 constexpr int kWidenBlock = QS_WIDEN_BLOCK;   // threads per workgroup of the widening kernel (a wave owns 512 elements)
 
 template <typename Op, int XDT, int CM, bool PARAM_PER_CHANNEL, bool NT, bool ELIDE = false>
@@ -621,8 +624,8 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                             const uint32_t split_e = wr.split >= 64u ? 512u : wr.split * 8u;
                             const uint32_t za = __float_as_uint((uint32_t)lane * 4u < split_e ? z0 : z1);
                             const uint32_t zb = __float_as_uint(256u + (uint32_t)lane * 4u < split_e ? z0 : z1);
-                            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + lane * 4), u32x4{za, za, za, za});
-                            st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e_wave + 256 + lane * 4), u32x4{zb, zb, zb, zb});
+                            st16<(NT && QS_WIDEN_PRUNED_NT_STORE != 0)>((u32x4*)(y + e_wave + lane * 4), u32x4{za, za, za, za});
+                            st16<(NT && QS_WIDEN_PRUNED_NT_STORE != 0)>((u32x4*)(y + e_wave + 256 + lane * 4), u32x4{zb, zb, zb, zb});
                             return;     // (inner % 8 == 0 here, so numel % 8 == 0: there is no ragged tail for this wave to serve)
                         }
                         const bool first = (uint32_t)lane < wr.split;
