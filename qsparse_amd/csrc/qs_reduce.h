@@ -1118,9 +1118,11 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
 // n % 2^p tail rows and finishes.  Bit-identical to the single-wave kernel; needs n / 2^p <= kMaxSplitChunks.
 constexpr int kMaxSplitChunks = 32;
 
-// MODE 1 (|x|) / 2 (max(x, 0)) as in mean_outer_vec_kernel: mean operand == abs-max key, every lane inside one channel
-// (chan_div % 8 == 0); MODE 0 handles every other flag combination.
-template <int DT, int ODT, int R, int MODE>
+// MODE 1 (|x|) / 2 (max(x, 0)) as in mean_outer_vec_kernel: mean operand == abs-max key; RAGGED: a lane's 8 columns may
+// straddle two channels (chan_div % 8 != 0: 14x14, 7x7 maps), the key goes to the first or the second of them -- until
+// the second half of round 2 such maps took the generic MODE 0 (8 VALU ops per element); MODE 0 handles every other
+// flag combination.
+template <int DT, int ODT, int R, int MODE, bool RAGGED = false>
 __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                    int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                                    int flags, const int32_t* __restrict__ l0_flag,
@@ -1162,7 +1164,8 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
             for (int k = 0; k < 8; ++k) {
                 const float w = (MODE == 2) ? relu_aten(v[k]) : v[k];
                 const uint32_t key = __float_as_uint(w) & 0x7fffffffu;
-                amax0 = key > amax0 ? key : amax0;
+                if (!RAGGED || k < first_col_next) amax0 = key > amax0 ? key : amax0;
+                else amax1 = key > amax1 ? key : amax1;
                 add(k, __uint_as_float(key));
             }
         } else {

@@ -599,6 +599,7 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
         const int64_t waves = (pre * (vcols / 8) + 63) / 64;
         const int want = env_int("QS_MEAN_SPLIT", 0);
         if (want > 0) R = want;
+        else if (waves < 128 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 8;   // with narrow waves, see below
         else if (waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
         else if (waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
         while (R > 1 && R > nchunks) R >>= 1;
@@ -612,7 +613,10 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
             constexpr int OD = decltype(O)::value;
             if (vcols > 0) {
                 const int64_t total = pre * (vcols / 8);
-                const int lanes = mean_lanes(total);
+                // tiny tensors (fewer than 128 waves of column groups: 14x14 / 7x7 maps of a few hundred channels) are
+                // spread over more workgroups by narrow waves, as in qs_mean_dim_cl (QS_MEAN_NARROW=0: off)
+                const bool narrow = R > 1 && (total + 63) / 64 < 128 && env_int("QS_MEAN_NARROW", 1) != 0;
+                const int lanes = narrow ? 32 : mean_lanes(total);
                 const int blocks = (int)((total + lanes - 1) / lanes);
                 const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
                 const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
@@ -643,17 +647,20 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 }
                 else {
                     const int64_t cd = chan_div > 0 ? chan_div : 1;
-                    const int smode = (l0_flag || !am || cd % 8 != 0) ? 0 : (flags == QS_MEAN_ABS ? 1 :
+                    const bool rag = am && cd % 8 != 0;         // a lane's 8 columns may straddle two channels
+                    const int smode = (l0_flag || !am) ? 0 : (flags == QS_MEAN_ABS ? 1 :
                                       (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
-                    auto launch = [&](auto RR, auto M) {
+                    auto launch = [&](auto RR, auto M, auto RG) {
                         constexpr int kR = decltype(RR)::value;
-                        hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value>), dim3(blocks), dim3(64 * kR),
-                                           lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes);
+                        hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value, decltype(RG)::value>), dim3(blocks),
+                                           dim3(64 * kR), lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes);
                     };
                     auto by_mode = [&](auto RR) {
-                        if (smode == 1) launch(RR, IC<1>{});
-                        else if (smode == 2) launch(RR, IC<2>{});
-                        else launch(RR, IC<0>{});
+                        if (smode == 1 && rag) launch(RR, IC<1>{}, std::true_type{});
+                        else if (smode == 2 && rag) launch(RR, IC<2>{}, std::true_type{});
+                        else if (smode == 1) launch(RR, IC<1>{}, std::false_type{});
+                        else if (smode == 2) launch(RR, IC<2>{}, std::false_type{});
+                        else launch(RR, IC<0>{}, std::false_type{});
                     };
                     if (R == 2) by_mode(IC<2>{});
                     else if (R == 4) by_mode(IC<4>{});
