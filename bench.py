@@ -577,11 +577,15 @@ def main():
         t5 = time.perf_counter()
 
         def bark():
-            if rank == 0 and "configs" not in out:
-                out["configs"] = {"config5_resnet50_ddp": {"error": f"did not finish within {limit:.0f} s (a rank failed or "
-                                                                    f"hung); the headline record is unaffected"}}
+            # a rank failed or hung inside a collective: the headline (measured before config 5 started) is still written,
+            # marked `degraded`, and EVERY rank leaves with a non-zero code so that torchrun and the harness see the failure
+            with emit_lock:
+                if rank == 0 and "configs" not in out:
+                    out["degraded"] = True
+                    out["configs"] = {"config5_resnet50_ddp": {"error": f"did not finish within {limit:.0f} s (a rank failed "
+                                                                        f"or hung); the headline record is unaffected"}}
             emit()
-            os._exit(0)
+            os._exit(3)
 
         watchdog = threading.Timer(limit, bark)
         watchdog.daemon = True
@@ -592,7 +596,10 @@ def main():
             rec5 = {"error": f"{type(e).__name__}: {e}"[:400]}
         rec5["bench_seconds"] = round(time.perf_counter() - t5, 1)
         if rank == 0:
-            out["configs"] = {"config5_resnet50_ddp": rec5}
+            with emit_lock:
+                out["configs"] = {"config5_resnet50_ddp": rec5}
+                if "error" in rec5:
+                    out["degraded"] = True
         emit()                      # before the group is torn down: a hang in there ends at the watchdog, line already out
     if world > 1 or force_exchange:
         torch.cuda.synchronize()

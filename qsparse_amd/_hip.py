@@ -17,6 +17,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
+ABI_VERSION = 10          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -142,6 +143,13 @@ def load(path: Optional[str] = None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == ABI mismatch
         fn.restype, fn.argtypes = res, args
+    # same symbol names with different argument lists across ABI versions: a stale library would be called with shifted
+    # arguments (ints in pointer slots), so the version is part of loading, not of the tests
+    found = lib.qs_version()
+    if found != ABI_VERSION:
+        raise QsparseHipError(
+            f"{p} is ABI v{found}, this package needs v{ABI_VERSION}: rebuild it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`")
     if path is None:
         _lib = lib
     return lib
@@ -267,6 +275,13 @@ class ReluGate:
 
     def __init__(self, bits: torch.Tensor, like: torch.Tensor, channels_last: bool):
         self.bits, self.shape, self.dtype, self.channels_last = bits, like.shape, like.dtype, channels_last
+
+    @classmethod
+    def from_saved(cls, bits: torch.Tensor, shape, dtype, channels_last: bool) -> "ReluGate":
+        """rebuild the gate in a backward from the bitmap autograd saved and the description kept on ctx"""
+        g = cls.__new__(cls)
+        g.bits, g.shape, g.dtype, g.channels_last = bits, shape, dtype, channels_last
+        return g
 
 
 def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
@@ -475,14 +490,17 @@ def minmax(x: torch.Tensor, channel_index: int, accumulate_into=None):
 
 def scale_update(absmax_t: torch.Tensor, weight: torch.Tensor, t: int, bits: int, t_dev: Optional[torch.Tensor] = None,
                  clear_absmax: bool = False, bump: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32,
-                 advance_t_dev: bool = False):
+                 advance_t_dev: bool = False, lines: Optional[int] = None):
     """in place on `weight` (fp32, contiguous); `t_dev`: optional device int64 counter read instead of `t` (and
     incremented by the kernel with `advance_t_dev`);
     `clear_absmax`: zero the statistics buffer after use; `bump`: int32 one-element counter to increment;
-    `stat_dtype`: dtype of the tensor the abs-max came from (the reference divides in that dtype)."""
+    `stat_dtype`: dtype of the tensor the abs-max came from (the reference divides in that dtype);
+    `lines`: number of partial accumulators when `absmax_t` is a `tensor_amax_accumulator` (tensor-wise only)."""
     assert weight.dtype == torch.float32 and weight.is_contiguous()
     assert bump is None or bump.dtype == torch.int32
-    lines = absmax_t.shape[0] if (absmax_t.dim() == 2 and weight.numel() == 1) else 1     # tensor_amax_accumulator
+    if lines is None:     # callers that own a `tensor_amax_accumulator` say so; a bare [n] / [1] statistic is one line
+        lines = 1
+    assert lines == 1 or (weight.numel() == 1 and absmax_t.numel() == lines * AMAX_LINE_STRIDE)
     with _timed("scale_update"):
         st = load().qs_scale_update(_ptr(absmax_t), lines, _ptr(weight), weight.numel(), int(t), _ptr(t_dev), int(advance_t_dev),
                                 int(bits), int(clear_absmax), _ptr(bump), _DT.get(stat_dtype, F32), _stream(weight))

@@ -1,0 +1,224 @@
+// libqsparse_hip.so -- C ABI (include/qsparse_hip.h), version / status / workspace queries, k-th value + masks, the C-sized select launch, the statistics
+// exchange records and the multi-tensor weight path (qs_reduce.h, qs_multi.h).
+// Host side: argument checks, geometry, launch configuration.  No allocation, no synchronisation: every entry
+// point only enqueues work on the caller's stream.
+#include "qs_host.h"
+#include "qs_reduce.h"
+#include "qs_multi.h"
+
+extern "C" {
+
+int qs_version(void) { return QS_ABI_VERSION; }
+
+const char* qs_status_string(int status) {
+    switch (status) {
+        case QS_OK: return "ok";
+        case QS_ERR_DTYPE: return "qsparse_hip: unsupported dtype combination";
+        case QS_ERR_ARG: return "qsparse_hip: inconsistent arguments";
+        case QS_ERR_ALIGN: return "qsparse_hip: data pointer is not 16-byte aligned";
+        case QS_ERR_WORKSPACE: return "qsparse_hip: workspace too small";
+        case QS_ERR_RANK: return "qsparse_hip: broadcast pattern has too many dimensions";
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "qsparse_hip: unknown status";
+}
+
+size_t qs_workspace_bytes(int op, int64_t n) {
+    (void)n;
+    switch (op) {
+        case QS_WS_KTH_VALUE: return sizeof(SelectState);
+        case QS_WS_REDUCE: return n >= 8 && n <= kFewColsMaxCols ? (size_t)2 * kFewColsMaxBlocks * n * sizeof(uint32_t) : 0;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int qs_kth_value(const float* imp, int64_t n, int64_t k, float* thr, void* ws, size_t ws_bytes, qs_stream_t stream) {
+    if (!imp || !thr || n < 1 || k < 0 || k >= n || n >= ((int64_t)1 << 32)) return QS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 32768) {
+        hipLaunchKernelGGL(kth_small_kernel, dim3(1), dim3(kSelectThreads), 0, s, imp, n, (uint32_t)k, thr);
+        return launch_status();
+    }
+    if (!ws || ws_bytes < sizeof(SelectState)) return QS_ERR_WORKSPACE;
+    SelectState* st = (SelectState*)ws;
+    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, st, (uint32_t)k);
+    int64_t blocks = (n + kBlock * 8 - 1) / (kBlock * 8);
+    if (blocks > 1024) blocks = 1024;
+    for (int pass = 3; pass >= 0; --pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3((int)blocks), dim3(kBlock), 0, s, imp, n, pass, st);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(256), 0, s, st, pass, thr);
+    }
+    return launch_status();
+}
+
+int qs_mask_ge(const float* imp, const float* thr, uint8_t* mask, int64_t n, qs_stream_t stream) {
+    if (!imp || !thr || !mask || n < 0) return QS_ERR_ARG;
+    if (n == 0) return QS_OK;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > max_blocks()) blocks = max_blocks();
+    hipLaunchKernelGGL(mask_ge_kernel, dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, imp, thr, mask, n);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude, int64_t t_mag, int refresh_mask,
+                   int64_t k, uint8_t* mask, float* chan_absmax, int64_t amax_stride, int update_scale, int64_t t_q, int bits, float* scale,
+                   int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
+                   const int64_t* t_mag_dev, const int64_t* t_q_dev, const float* gathered, int world) {
+    if (!magnitude || !mask || C < 1 || C > 65536) return QS_ERR_ARG;
+    if (update_magnitude && t_mag < 0) return QS_ERR_ARG;
+    if (refresh_mask && (k < 0 || k >= C)) return QS_ERR_ARG;
+    if (gathered && world < 1) return QS_ERR_ARG;
+    if (update_scale && ((!chan_absmax && !gathered) || amax_stride < 1 || !scale || bits < 1 || bits > 31 || t_q < 0))
+        return QS_ERR_ARG;
+    a->gathered = gathered;
+    a->world = gathered ? world : 1;
+    a->magnitude = magnitude;
+    a->C = C;
+    a->update_magnitude = update_magnitude;
+    a->t_mag = (float)t_mag;
+    a->t_mag1 = (float)(t_mag + 1);
+    a->refresh_mask = refresh_mask;
+    a->k = (uint32_t)k;
+    a->mask = mask;
+    a->chan_absmax = (uint32_t*)chan_absmax;
+    a->amax_stride = amax_stride;
+    a->update_scale = update_scale;
+    a->t_q = (float)t_q;
+    a->t_q1 = (float)(t_q + 1);
+    a->denom = (float)((int64_t)1 << (bits > 0 ? bits - 1 : 0));
+    a->scale = scale;
+    a->bump_a = bump_i32_a;
+    a->bump_b = bump_i32_b;
+    a->bump_c = bump_i64_a;
+    a->bump_d = bump_i64_b;
+    a->t_mag_dev = t_mag_dev;
+    a->t_q_dev = t_q_dev;
+    static const int rank_small = env_int("QS_RANK_SMALL", kRankSmall);
+    a->rank_small = rank_small;
+    return QS_OK;
+}
+
+int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, int update_magnitude, int64_t t_mag,
+                 int refresh_mask, int64_t k, uint8_t* mask, float* chan_absmax, int64_t chan_absmax_stride, int update_scale,
+                 int64_t t_q, int bits,
+                 float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
+                 const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
+                 qs_stream_t stream) {
+    PqArgs a;
+    int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, chan_absmax_stride, update_scale, t_q, bits,
+                     scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev, gathered, world);
+    if (st == QS_OK && update_scale && !dt_ok(stat_dt)) st = QS_ERR_DTYPE;
+    a.stat_dt = stat_dt;
+    if (st) return st;
+    if (update_magnitude && !stage_mean && !gathered) return QS_ERR_ARG;
+    if (gathered) sdt = QS_F32;      // the records are float32; `stage_mean` is not read
+    if (!dt_ok(sdt)) return QS_ERR_DTYPE;
+    return with_dtype(sdt, [&](auto S) {
+        constexpr int SD = decltype(S)::value;
+        if (C <= 256)
+            hipLaunchKernelGGL((pq_select_kernel<SD, 256>), dim3(1), dim3(256), 0, (hipStream_t)stream, a, stage_mean);
+        else
+            hipLaunchKernelGGL((pq_select_kernel<SD, kSelectThreads>), dim3(1), dim3(kSelectThreads), 0,
+                               (hipStream_t)stream, a, stage_mean);
+        return launch_status();
+    });
+}
+
+int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t absmax_stride, int64_t C, float* record,
+                  qs_stream_t stream) {
+    if (!record || C < 1) return QS_ERR_ARG;
+    if (stage && !dt_ok(sdt)) return QS_ERR_DTYPE;
+    return with_dtype(stage ? sdt : QS_F32, [&](auto S) {
+        constexpr int SD = decltype(S)::value;
+        hipLaunchKernelGGL((stats_pack_kernel<SD>), dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stage,
+                           (const uint32_t*)absmax, absmax_stride > 0 ? absmax_stride : 1, C, record);
+        return launch_status();
+    });
+}
+
+int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
+                     int64_t absmax_stride, qs_stream_t stream) {
+    if (!gathered || world < 1 || C < 1) return QS_ERR_ARG;
+    hipLaunchKernelGGL(stats_combine_kernel, dim3((int)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
+                       C, stage_out, (uint32_t*)absmax_out, absmax_stride > 0 ? absmax_stride : 1);
+    return launch_status();
+}
+
+// ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
+int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !numel || !amax))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiTensors a{};
+        MultiUpdate u{};
+        a.n = u.n = std::min(kMultiMax, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int k = base + i;
+            if (!x[k] || !amax[k] || numel[k] < 0) return QS_ERR_ARG;
+            if (!aligned16(x[k])) return QS_ERR_ALIGN;
+            a.x[i] = x[k];
+            a.numel[i] = numel[k];
+            u.amax[i] = (uint32_t*)amax[k];
+            a.block0[i] = blocks;
+            const int64_t want = (numel[k] / 8 + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);   // ~4 groups per lane
+            blocks += (int)std::min<int64_t>(std::max<int64_t>(want, 1), 64);
+        }
+        a.block0[a.n] = blocks;
+        hipLaunchKernelGGL(multi_absmax_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, a, u);
+    }
+    return launch_status();
+}
+
+int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
+                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!amax || !scale || !t || !bits))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiUpdate u{};
+        u.n = std::min(kMultiMax, n - base);
+        for (int i = 0; i < u.n; ++i) {
+            const int k = base + i;
+            if (!amax[k] || !scale[k] || t[k] < 0 || bits[k] < 1 || bits[k] > 31) return QS_ERR_ARG;
+            u.amax[i] = (uint32_t*)amax[k];
+            u.scale[i] = scale[k];
+            u.decimal[i] = decimal ? decimal[k] : nullptr;
+            u.t_dev[i] = t_dev ? t_dev[k] : nullptr;
+            u.bump[i] = bump ? bump[k] : nullptr;
+            u.t[i] = (float)t[k];
+            u.denom[i] = (float)((int64_t)1 << (bits[k] - 1));
+        }
+        hipLaunchKernelGGL(multi_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
+    }
+    return launch_status();
+}
+
+int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
+                       int decimal, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !y || !param || !numel))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiTensors a{};
+        a.n = std::min(kMultiMax, n - base);
+        int64_t blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int k = base + i;
+            if (!x[k] || !y[k] || !param[k] || numel[k] < 0) return QS_ERR_ARG;
+            if (!aligned16(x[k]) || !aligned16(y[k])) return QS_ERR_ALIGN;
+            a.x[i] = x[k];
+            a.y[i] = y[k];
+            a.scale[i] = param[k];
+            a.numel[i] = numel[k];
+            a.block0[i] = (int32_t)blocks;
+            blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
+            if (blocks > 0x7fffffff) return QS_ERR_ARG;
+        }
+        a.block0[a.n] = (int32_t)blocks;
+        if (decimal)
+            hipLaunchKernelGGL((multi_quant_kernel<true>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((multi_quant_kernel<false>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+    }
+    return launch_status();
+}
+
+}  // extern "C"

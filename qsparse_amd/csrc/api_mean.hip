@@ -1,0 +1,228 @@
+// libqsparse_hip.so -- C ABI (include/qsparse_hip.h), statistics: the staged means of squeeze_tensor_to_shape in ATen's
+// summation order (qs_reduce.h).
+// Host side: argument checks, geometry, launch configuration.  No allocation, no synchronisation: every entry
+// point only enqueues work on the caller's stream.
+#include "qs_host.h"
+#include "qs_reduce.h"
+
+extern "C" {
+
+int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
+                const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
+                qs_stream_t stream) {
+    if (!x || !out || pre < 1 || n < 1 || post < 1) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
+    if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    if (absmax_out && (chan_div < 1 || C < 1 || absmax_stride < 1)) return QS_ERR_ARG;
+    const int64_t as = absmax_out ? absmax_stride : 1;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t vcols = 0;
+    const bool ragged_absmax = absmax_out && (chan_div % 8 != 0);
+    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!ragged_absmax || chan_div >= 8))
+        vcols = (post / 32) * 32;
+    uint32_t* am = (uint32_t*)absmax_out;
+    // rows are split over R waves per workgroup when there are too few column groups to fill the chip
+    const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
+    const int64_t nchunks = n >> lp;
+    int R = 1;
+    if (vcols > 0) {
+        const int64_t waves = (pre * (vcols / 8) + 63) / 64;
+        const int want = env_int("QS_MEAN_SPLIT", 0);
+        if (want > 0) R = want;
+        else if (waves < 128 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 8;   // with narrow waves, see below
+        else if (waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
+        else if (waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
+        while (R > 1 && R > nchunks) R >>= 1;
+        if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
+        if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
+        if (R == 0) vcols = 0;
+    }
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto run = [&](auto O) {
+            constexpr int OD = decltype(O)::value;
+            if (vcols > 0) {
+                const int64_t total = pre * (vcols / 8);
+                // tiny tensors (fewer than 128 waves of column groups: 14x14 / 7x7 maps of a few hundred channels) are
+                // spread over more workgroups by narrow waves, as in qs_mean_dim_cl (QS_MEAN_NARROW=0: off)
+                const bool narrow = R > 1 && (total + 63) / 64 < 128 && env_int("QS_MEAN_NARROW", 1) != 0;
+                const int lanes = narrow ? 32 : mean_lanes(total);
+                const int blocks = (int)((total + lanes - 1) / lanes);
+                const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
+                const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
+                if (R == 1) {
+                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                                    (flags == 0 && !am ? 3 : 0)));
+                    // few waves per CU: keep more rows in flight per wave instead (latency-, not bandwidth-bound)
+                    // (2-byte inputs only: 32 fp32 rows of 8 columns do not fit the register file)
+                    int depth = env_int("QS_MEAN_DEPTH", 0);
+                    if (depth == 0) depth = (blocks < 4 * 256 && n >= 32) ? 32 : QS_MEAN_ROWS_IN_FLIGHT;
+                    if (XD == QS_F32) depth = QS_MEAN_ROWS_IN_FLIGHT;
+                    auto launch = [&](auto D, auto M) {
+                        hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, decltype(D)::value, decltype(M)::value>), dim3(blocks),
+                                           dim3(64), 0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
+                    };
+                    auto by_mode = [&](auto D) {
+                        if (mode == 3) launch(D, IC<3>{});
+                        else if (mode == 1) launch(D, IC<1>{});
+                        else if (mode == 2) launch(D, IC<2>{});
+                        else launch(D, IC<0>{});
+                    };
+                    if constexpr (XD != QS_F32) {
+                        if (depth >= 32) by_mode(IC<32>{});
+                        else by_mode(IC<QS_MEAN_ROWS_IN_FLIGHT>{});
+                    } else {
+                        by_mode(IC<QS_MEAN_ROWS_IN_FLIGHT>{});
+                    }
+                }
+                else {
+                    const int64_t cd = chan_div > 0 ? chan_div : 1;
+                    const bool rag = am && cd % 8 != 0;         // a lane's 8 columns may straddle two channels
+                    const int smode = (l0_flag || !am) ? 0 : (flags == QS_MEAN_ABS ? 1 :
+                                      (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
+                    auto launch = [&](auto RR, auto M, auto RG) {
+                        constexpr int kR = decltype(RR)::value;
+                        hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value, decltype(RG)::value>), dim3(blocks),
+                                           dim3(64 * kR), lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes);
+                    };
+                    auto by_mode = [&](auto RR) {
+                        if (smode == 1 && rag) launch(RR, IC<1>{}, std::true_type{});
+                        else if (smode == 2 && rag) launch(RR, IC<2>{}, std::true_type{});
+                        else if (smode == 1) launch(RR, IC<1>{}, std::false_type{});
+                        else if (smode == 2) launch(RR, IC<2>{}, std::false_type{});
+                        else launch(RR, IC<0>{}, std::false_type{});
+                    };
+                    if (R == 2) by_mode(IC<2>{});
+                    else if (R == 4) by_mode(IC<4>{});
+                    else by_mode(IC<8>{});
+                }
+            }
+            if (vcols < post) {
+                const int64_t total = pre * (post - vcols);
+                hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
+                                   0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1,
+                                   (uint32_t)(C > 0 ? C : 1));
+            }
+            return launch_status();
+        };
+        return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
+    });
+}
+
+int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
+                   const int32_t* l0_flag, float* amax_part, qs_stream_t stream) {
+    if (!x || !out || n < 1 || hw < 1 || C < 1) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    const int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                                 (flags == 0 ? 3 : 0)));
+    if (C % 8 != 0 || mode == 0 || (mode == 3 && amax_part) || !aligned16(x)) {
+        // any channel count, the L0 variant, unaligned views: one lane per element of a sample, same summation order
+        const int64_t total = hw * C;
+        if ((total + kBlock - 1) / kBlock > 0x7fffffff) return QS_ERR_ARG;
+        return with_dtype(xdt, [&](auto X) {
+            constexpr int XD = decltype(X)::value;
+            const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+            if (odt == QS_F32)
+                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw,
+                                   C, flags, l0_flag, (uint32_t*)amax_part);
+            else
+                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw, C,
+                                   flags, l0_flag, (uint32_t*)amax_part);
+            return launch_status();
+        });
+    }
+    const int64_t main_groups = (hw / 4) * 4 * C / 8, tail_groups = hw * C / 8 - main_groups;   // ATen's split of H*W
+    auto chunks_of = [](int64_t items) {               // full level-0 chunks of a cascade over `items` items
+        const int lp = std::max(4, (items <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(items - 1))) / 4);
+        return items >> lp;
+    };
+    const int64_t nchunks = chunks_of(n), tail_slots = 4 * chunks_of(n / 4);
+    // Few waves: ONE launch of the workgroup kernel -- rows shared by the R waves of a workgroup, main and tail positions
+    // together, narrow waves when even that leaves CUs idle.  Many waves: the one-wave-per-512-columns kernel for the
+    // main positions; the tail positions still take the workgroup kernel.
+    const int64_t waves64 = (main_groups + 63) / 64;
+    const bool big = waves64 >= 512;
+    // measured on the activation shapes of a ResNet-50 step at batch 256 (tools/bench_stats.py --cl --b256; columns of
+    // 64-lane waves the main positions would fill -> best waves per workgroup : lanes per wave):
+    //   >= 784 -> 1 (the one-wave kernel);  392 and 196 -> 4 : 64 (R = 8 / 16 and narrower waves are slower: 22.5 vs 24-38 us on
+    //   256x128x28x28 bf16);  98 and 48 -> 8 : 32 (256x256x14x14 bf16 22.3 -> 15.7 us, 256x512x7x7 17.4 -> 15.5 us)
+    const int64_t g = big ? tail_groups : std::max(main_groups, tail_groups);
+    const int64_t gwaves = (g + 63) / 64;
+    int lanes = env_int("QS_CL_LANES", 0);
+    if (lanes != 16 && lanes != 32 && lanes != 64) lanes = gwaves < 128 ? 32 : 64;
+    const int64_t slots = std::max<int64_t>(big ? 0 : nchunks, tail_groups > 0 ? tail_slots : 0);
+    int R = env_int("QS_MEAN_SPLIT", 0);
+    if (R == 0) R = gwaves >= 512 ? 1 : (gwaves < 128 ? 8 : 4);
+    R = R >= 16 ? 16 : (R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1)));
+    if (xdt == QS_F32 && R > 8) R = 8;                 // 16 fp32 rows in flight need > 128 VGPRs: 512-thread workgroups at most
+    while (R > 1 && (R > slots || (size_t)(slots + R) * 8 * lanes * sizeof(float) > 63 * 1024)) R >>= 1;
+    const size_t lds = (size_t)(slots + R) * 8 * lanes * sizeof(float);
+    const bool wg_ok = slots >= 1 && lds <= 63 * 1024;
+    // without the workgroup kernel (very long batches: the slot sums do not fit the LDS) both parts fall back to their
+    // one-wave kernels
+    const bool wg_main = wg_ok && !big && main_groups > 0;
+    const bool wg_tail = wg_ok && tail_groups > 0;
+    const int lanes1 = mean_lanes(main_groups > 0 ? main_groups : 1);
+    const int blocks1 = (int)((main_groups + lanes1 - 1) / lanes1);
+    const int wg_main_blocks = wg_main ? (int)((main_groups + lanes - 1) / lanes) : 0;
+    const int wg_tail_blocks = wg_tail ? (int)((tail_groups + lanes - 1) / lanes) : 0;
+    const int tail_blocks1 = (int)((tail_groups + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        auto run = [&](auto O) {
+            constexpr int OD = decltype(O)::value;
+            uint32_t* am = (uint32_t*)amax_part;
+            auto launch = [&](auto M) {
+                constexpr int kM = decltype(M)::value;
+                if (!wg_main && main_groups > 0)
+                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks1), dim3(64), 0, s, x, out, n, hw, C, am, lanes1,
+                                       main_groups);
+                if (wg_main || wg_tail) {
+                    auto wg = [&](auto RR) {
+                        constexpr int kR = decltype(RR)::value;
+                        hipLaunchKernelGGL((mean_cl_wg_kernel<XD, OD, kR, kM>), dim3(wg_main_blocks + wg_tail_blocks), dim3(64 * kR),
+                                           lds, s, x, out, n, hw, C, am, lanes, main_groups, wg_main_blocks, tail_groups,
+                                           (int)slots);
+                    };
+                    if constexpr (XD != QS_F32) {
+                        if (R == 16) wg(IC<16>{});
+                    }
+                    if (R == 8) wg(IC<8>{});
+                    else if (R == 4) wg(IC<4>{});
+                    else if (R == 2) wg(IC<2>{});
+                    else if (R == 1) wg(IC<1>{});
+                }
+                if (!wg_tail && tail_groups > 0)
+                    hipLaunchKernelGGL((mean_cl_tail_kernel<XD, OD, kM>), dim3(tail_blocks1), dim3(64), 0, s, x, out, n, hw, C,
+                                       am, main_groups, tail_groups);
+            };
+            if (mode == 1) launch(IC<1>{});
+            else if (mode == 2) launch(IC<2>{});
+            else launch(IC<3>{});
+            return launch_status();
+        };
+        return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
+    });
+}
+
+int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, const float* amax_part,
+                  float* absmax_out, int64_t absmax_stride, float* record, qs_stream_t stream) {
+    if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;
+    if ((amax_part || (record && absmax_out)) && (!absmax_out || absmax_stride < 1)) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    const size_t lds = (size_t)(H * W + W + 8) * sizeof(float);
+    if (lds > kLast2MaxLds || pre > 0x7fffffff) return QS_ERR_ARG;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        if (odt == QS_F32)
+            hipLaunchKernelGGL((mean_last2_kernel<XD, QS_F32>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x,
+                               out, (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride, record);
+        else
+            hipLaunchKernelGGL((mean_last2_kernel<XD, XD>), dim3((int)pre), dim3(kBlock), lds, (hipStream_t)stream, x, out,
+                               (int)H, (int)W, (const uint32_t*)amax_part, (uint32_t*)absmax_out, absmax_stride, record);
+        return launch_status();
+    });
+}
+
+}  // extern "C"

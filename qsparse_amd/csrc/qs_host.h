@@ -1,0 +1,107 @@
+// Host-side helpers shared by the translation units of libqsparse_hip.so (api_*.hip): argument checks, dtype dispatch,
+// launch geometry knobs.  Everything here has internal linkage; each TU compiles in parallel (see __graft_entry__.build_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "qs_common.h"
+
+#ifndef QS_EW_UNROLL
+#define QS_EW_UNROLL 1
+#endif
+#ifndef QS_EW_UNROLL_ELIDE
+#define QS_EW_UNROLL_ELIDE 2   // groups per lane of the 8-per-lane kernels when they elide (their pruned waves only store)
+#endif
+#ifndef QS_EW_UNROLL_SCALAR
+#define QS_EW_UNROLL_SCALAR 1  // groups per lane of the tensor-wise (CM_SCALAR) 8-per-lane kernels
+#endif
+#ifndef QS_EW_UNROLL_ROW
+#define QS_EW_UNROLL_ROW 2     // groups per lane of the dense per-row (CM_ROW) 8-per-lane kernels (three-phase path)
+#endif
+#ifndef QS_EW_NT
+#define QS_EW_NT 1
+#endif
+#ifndef QS_MEAN_ROWS_IN_FLIGHT
+#define QS_MEAN_ROWS_IN_FLIGHT 16   // 16 KiB per wave outstanding; 8 was 8 % slower once the loads bypass the Infinity Cache, 32 no faster
+#endif
+
+using namespace qs;
+
+namespace {
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+// streaming kernels: one workgroup per kBlock*UNROLL groups (measured best on MI355X: exact grids beat a
+// capped grid-stride loop by 8-10 %); QS_MAX_BLOCKS caps the grid for experiments
+inline int max_blocks() {
+    static int v = env_int("QS_MAX_BLOCKS", 1 << 30);
+    return v;
+}
+inline int reduce_blocks() {
+    static int v = env_int("QS_REDUCE_BLOCKS", 256);
+    return v;
+}
+inline int reduce_blocks_lines() {
+    static int v = env_int("QS_REDUCE_BLOCKS_LINES", 256);   // measured: 512 / 1024 / 2048 workgroups are 9-22 % SLOWER on 411 MB
+    return v;
+}
+// Streaming kernels walk their tensors from the END: the producer (or the statistics pass that has just read
+// the same tensor front to back) leaves the tail of the tensor in the 256 MiB Infinity Cache, and an LRU
+// cache serves a reverse walk from it where a forward walk would evict it before use.  QS_EW_REVERSE=0 disables.
+inline int ew_reverse() {
+    static int v = env_int("QS_EW_REVERSE", 1);
+    return v;
+}
+// active lanes per wave of the column-parallel mean kernel: the busiest CU carries ceil(waves / 256) * lanes
+// column groups; pick the widest wave that minimises it (QS_MEAN_LANES overrides)
+inline int mean_lanes(int64_t total) {
+    static int forced = env_int("QS_MEAN_LANES", 0);
+    if (forced >= 1 && forced <= 64) return forced;
+    const int64_t kCUs = 256;
+    int best = 64;
+    int64_t best_cost = -1;
+    for (int l = 64; l >= 40; --l) {
+        const int64_t waves = (total + l - 1) / l;
+        const int64_t cost = ((waves + kCUs - 1) / kCUs) * l;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = l;
+        }
+    }
+    return best;
+}
+
+constexpr size_t kLast2MaxLds = 63 * 1024;    // qs_mean_last2's [H*W + W + 8] float tile (a workgroup may hold 64 KiB)
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+inline int dt_ok(int dt) { return dt == QS_F32 || dt == QS_BF16 || dt == QS_F16; }
+inline int hip_status(hipError_t e) { return (int)e; }
+inline int launch_status() { return hip_status(hipGetLastError()); }
+
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+template <typename F>
+int with_dtype(int dt, F&& f) {
+    switch (dt) {
+        case QS_F32: return f(IC<QS_F32>{});
+        case QS_BF16: return f(IC<QS_BF16>{});
+        case QS_F16: return f(IC<QS_F16>{});
+    }
+    return QS_ERR_DTYPE;
+}
+inline int grid_for(int64_t ngroups, int unroll) {
+    int64_t b = (ngroups + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
+    if (b < 1) b = 1;
+    if (b > max_blocks()) b = max_blocks();
+    return (int)b;
+}
+
+inline bool aligned8(const void* p) { return (((uintptr_t)p) & 7u) == 0; }
+
+}  // namespace

@@ -43,7 +43,7 @@ __device__ __forceinline__ int multi_find(const int32_t* block0, int n, int b) {
 }
 
 // abs-max of every tensor; a tensor's workgroups stride over its 8-element groups, one atomic per workgroup
-__global__ __launch_bounds__(kBlock) void multi_absmax_kernel(MultiTensors a, MultiUpdate u) {
+static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(MultiTensors a, MultiUpdate u) {
     const int i = multi_find(a.block0, a.n, blockIdx.x);
     const int nb = a.block0[i + 1] - a.block0[i], b = blockIdx.x - a.block0[i];
     const float* x = a.x[i];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(MultiTensors a, Mu
 }
 
 // one thread per tensor: the running mean of scale_update_kernel, the decimal of decimal_from_scale_kernel, counters
-__global__ void multi_scale_update_kernel(MultiUpdate u) {
+static __global__ void multi_scale_update_kernel(MultiUpdate u) {
     const int i = threadIdx.x;
     if (i >= u.n) return;
     float t = u.t[i];

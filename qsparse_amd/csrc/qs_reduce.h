@@ -434,14 +434,14 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_finish_kernel(const uin
     }
 }
 
-__global__ void keys_init_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
+static __global__ void keys_init_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         mx[i] = 0u;
         if (mn) mn[i] = 0xffffffffu;
     }
 }
-__global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
+static __global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         ((float*)mx)[i] = key_to_f32(mx[i]);
@@ -464,7 +464,7 @@ __device__ __forceinline__ float round_to_dtype(float v, int dt) {
     if (dt == QS_BF16) return round_through<QS_BF16>(v);
     return v;
 }
-__global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
+static __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
                                     int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt, int lines) {
     if (lines > 1) {
         // n == 1 (one workgroup): the tensor-wise abs-max arrives in `lines` (<= 64) partial accumulators on lines of their
@@ -504,7 +504,7 @@ __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, flo
 // `from_keys`: mn / mx hold the order-preserving keys qs_minmax(accumulate) leaves behind; they are turned into floats here
 // and reset to the neutral keys (max 0, min 0xffffffff) for the next statistics pass -- which saves the key-initialisation
 // and the key -> float launches of a min/max call
-__global__ void lines_update_kernel(float* mn, float* mx, float* lines, int64_t n, float tm1, float t,
+static __global__ void lines_update_kernel(float* mn, float* mx, float* lines, int64_t n, float tm1, float t,
                                     int64_t* t_dev, int advance, int from_keys) {
     if (t_dev) {   // counter BEFORE this step's increment
         tm1 = (float)*t_dev;
@@ -526,7 +526,7 @@ __global__ void lines_update_kernel(float* mn, float* mx, float* lines, int64_t 
         if (threadIdx.x == 0) *t_dev += 1;
     }
 }
-__global__ void decimal_from_scale_kernel(const float* scale, float* d, int64_t n) {
+static __global__ void decimal_from_scale_kernel(const float* scale, float* d, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         float r = 1.0f / scale[i];
@@ -544,7 +544,7 @@ __global__ void running_mean_kernel(float* state, const void* nv, int64_t n, flo
     }
     if (i < n) state[i] = (t * state[i] + load1<DT>(nv, i)) / tp1;       // sparse.py:89
 }
-__global__ void l0_flag_kernel(const float* mn, int32_t* flag) { *flag = (mn[0] == 0.0f) ? 1 : 0; }
+static __global__ void l0_flag_kernel(const float* mn, int32_t* flag) { *flag = (mn[0] == 0.0f) ? 1 : 0; }
 
 // =================================================================================================
 // Staged mean in ATen's CPU order.  at::mean on CPU (ReduceOps.cpp, mean_out) is
@@ -1279,7 +1279,7 @@ struct SelectState {
 };
 
 // multi-block pass: histogram of byte `pass` (3 = most significant) among keys matching the prefix
-__global__ __launch_bounds__(kBlock) void select_hist_kernel(const float* __restrict__ imp, int64_t n, int pass,
+static __global__ __launch_bounds__(kBlock) void select_hist_kernel(const float* __restrict__ imp, int64_t n, int pass,
                                                               SelectState* st) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(kBlock) void select_hist_kernel(const float* __rest
     if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
 }
 // single-thread-block scan: pick the bin holding rank k, descend
-__global__ void select_scan_kernel(SelectState* st, int pass, float* thr) {
+static __global__ void select_scan_kernel(SelectState* st, int pass, float* thr) {
     if (threadIdx.x == 0) {
         uint32_t k = st->k, cum = 0;
         int b = 0;
@@ -1313,7 +1313,7 @@ __global__ void select_scan_kernel(SelectState* st, int pass, float* thr) {
     __syncthreads();
     st->hist[threadIdx.x] = 0;   // blockDim.x == 256
 }
-__global__ void select_init_kernel(SelectState* st, uint32_t k) {
+static __global__ void select_init_kernel(SelectState* st, uint32_t k) {
     st->hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         st->prefix = 0;
@@ -1426,14 +1426,14 @@ __device__ __forceinline__ uint32_t block_select_key(const float* v, int64_t n, 
     return radix_select([&](int64_t i) { return f32_to_key(v[i]); }, n, k, sh);
 }
 
-__global__ __launch_bounds__(kSelectThreads) void kth_small_kernel(const float* __restrict__ imp, int64_t n, uint32_t k,
+static __global__ __launch_bounds__(kSelectThreads) void kth_small_kernel(const float* __restrict__ imp, int64_t n, uint32_t k,
                                                                     float* thr) {
     __shared__ SelectShared sh;
     const uint32_t key = block_select_key(imp, n, k, sh);
     if (threadIdx.x == 0) *thr = key_to_f32(key);
 }
 
-__global__ __launch_bounds__(kBlock) void mask_ge_kernel(const float* __restrict__ imp, const float* __restrict__ thr,
+static __global__ __launch_bounds__(kBlock) void mask_ge_kernel(const float* __restrict__ imp, const float* __restrict__ thr,
                                                           uint8_t* __restrict__ mask, int64_t n) {
     const float t = *thr;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -1697,7 +1697,7 @@ __global__ void stats_pack_kernel(const void* stage, const uint32_t* absmax, int
         rec[C + i] = absmax ? __uint_as_float(absmax[i * astride]) : 0.f;
     }
 }
-__global__ void stats_combine_kernel(const float* gathered, int world, int64_t C, float* stage_out, uint32_t* absmax_out,
+static __global__ void stats_combine_kernel(const float* gathered, int world, int64_t C, float* stage_out, uint32_t* absmax_out,
                                      int64_t astride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) {

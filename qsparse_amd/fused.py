@@ -71,20 +71,26 @@ class _FusedApply(torch.autograd.Function):
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
         ctx.pre_relu = pre_relu
         ctx.has_mask = mask_c is not None
-        ctx.gate = None
+        ctx.gate_meta = None
         # a folded ReLU's backward needs nothing of x but the sign test: the forward records it as one bit per element
         # (qs_quant_*_fwd gate_out) and x is not kept -- the backward reads g and the bitmap instead of g and x
         want_gate = bool(pre_relu and quant_on and ctx.needs_input_grad[0] and get_option("relu_gate"))
-        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
-                              h if (pre_relu and not want_gate) else h.new_empty(0))
+        empty = h.new_empty(0)
         if not quant_on:
+            ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, h if pre_relu else empty)
             return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
         out_dtype = _out_dtype(h)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
         res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
                              pre_relu=pre_relu, want_gate=want_gate)
+        # the bitmap travels through save_for_backward like any saved activation (released with the graph, visible to
+        # saved-tensor hooks); only its description -- shape, dtype, layout -- stays on ctx
         if want_gate:
-            ctx.gate = res[2]
+            gate = res[2]
+            ctx.gate_meta = (gate.shape, gate.dtype, gate.channels_last)
+            ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, gate.bits)
+        else:
+            ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, h if pre_relu else empty)
         return res[0]
 
     @staticmethod
@@ -96,8 +102,9 @@ class _FusedApply(torch.autograd.Function):
         limit = 2.0 ** (ctx.bits - 1)
         step = scale if ctx.kind == "scaler" else _hip.decimal_from_scale(scale)
         if ctx.pre_relu:
-            gx = _hip.ste_relu_bwd(g, None if ctx.gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
-                                   limit - 1 + ctx.notch, mask_c, gate=ctx.gate)
+            gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
+                                   limit - 1 + ctx.notch, mask_c, gate=gate)
             return (gx,) + (None,) * 7
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,

@@ -295,10 +295,13 @@ class DecimalQuantizer(BaseQuantizer):
                 # (which also clears that buffer and bumps the layer's step counter), quantization
                 n_stat = wshape[0]
                 bufs = self.__dict__.setdefault("_absmax_bufs", {})
-                buf = bufs.get((n_stat, x.device))
+                # (a callback shared by a tensor-wise layer and a channel-wise layer over ONE channel has n_stat == 1 twice
+                # with different accumulator layouts: the layout is part of the key)
+                key = (n_stat, channel_index < 0, x.device)
+                buf = bufs.get(key)
                 if buf is None:     # tensor-wise: 16 partial accumulators on lines of their own (see _hip.absmax)
-                    buf = bufs[(n_stat, x.device)] = (_hip.tensor_amax_accumulator(x.device) if channel_index < 0 else
-                                                      torch.zeros(n_stat, dtype=torch.float32, device=x.device))
+                    buf = bufs[key] = (_hip.tensor_amax_accumulator(x.device) if channel_index < 0 else
+                                       torch.zeros(n_stat, dtype=torch.float32, device=x.device))
                 stat = _hip.absmax(x, channel_index, accumulate_into=buf, pre_relu=bool(kwargs.get("pre_relu", False)))
                 if batched:      # activations differ per rank; weights and biases (batched=False) are identical under DDP
                     stat = qdist.allreduce_max_(stat)
@@ -308,7 +311,7 @@ class DecimalQuantizer(BaseQuantizer):
                 counter = kwargs.get("step_counter")
                 bump = counter.data if (counter is not None and counter.is_cuda and counter.device == x.device) else None
                 _hip.scale_update(stat, weight.data, self.t, bits, t_dev=t_dev, clear_absmax=True, bump=bump, stat_dtype=x.dtype,
-                                  advance_t_dev=True)
+                                  advance_t_dev=True, lines=_hip.TENSOR_AMAX_LINES if channel_index < 0 else 1)
                 self.__dict__["_bumped_step_counter"] = bump is not None
                 self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight

@@ -29,12 +29,14 @@ class _MaskApply(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, relu_dim=-1):
         ctx.relu_dim = relu_dim
-        ctx.gate = None
+        ctx.gate_meta = None
         if relu_dim >= 0:
             if ctx.needs_input_grad[0] and get_option("relu_gate"):
-                # the backward needs one bit of x per element (x <= 0): recorded by this pass, x itself is not kept
-                ctx.save_for_backward(mask)
-                y, ctx.gate = _hip.mask_apply(x, mask, pre_relu=True, want_gate=True)
+                # the backward needs one bit of x per element (x <= 0): recorded by this pass, x itself is not kept; the
+                # bitmap is a saved tensor like any other (released with the graph, visible to saved-tensor hooks)
+                y, gate = _hip.mask_apply(x, mask, pre_relu=True, want_gate=True)
+                ctx.gate_meta = (gate.shape, gate.dtype, gate.channels_last)
+                ctx.save_for_backward(mask, gate.bits)
                 return y
             ctx.save_for_backward(mask, x)
             return _hip.mask_apply(x, mask, pre_relu=True)
@@ -45,10 +47,10 @@ class _MaskApply(torch.autograd.Function):
     def backward(ctx, grad):
         if ctx.relu_dim >= 0:
             inf = float("inf")   # no clamp: qs_quant_ste_relu_bwd reduces to gate(x) * g * mask
-            if ctx.gate is not None:
-                (mask,) = ctx.saved_tensors
+            if ctx.gate_meta is not None:
+                mask, bits = ctx.saved_tensors
                 return _hip.ste_relu_bwd(grad, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim,
-                                         gate=ctx.gate), None, None
+                                         gate=_hip.ReluGate.from_saved(bits, *ctx.gate_meta)), None, None
             mask, x = ctx.saved_tensors
             return _hip.ste_relu_bwd(grad, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim), None, None
         (mask,) = ctx.saved_tensors

@@ -74,3 +74,19 @@ def test_two_ranks_through_torch_distributed_run():
     assert c5["world"] == 2 and c5["input_shape_per_gpu"] == [8, 3, 224, 224]
     assert c5["pq_images_per_s"] > 0 and c5["plain_images_per_s"] > 0
     assert c5["operator_state_identical_across_ranks"] is True
+
+
+def test_config5_watchdog_keeps_the_headline_marks_it_degraded_and_fails_the_run():
+    """a rank that hangs in config 5's collectives must not cost the headline record, and must not look like success:
+    the line carries a top-level `degraded: true` and every rank exits non-zero (here the deadline is simply too short)"""
+    env = dict(os.environ, QS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", QS_BENCH_DDP_BATCH="8",
+               QS_BENCH_DDP_TIMEOUT="0.5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    _check(rec, 2, 8)
+    assert rec["degraded"] is True and "error" in rec["configs"]["config5_resnet50_ddp"]

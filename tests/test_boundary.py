@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/qsparse_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes prototypes out of sync with the header"
     lib.qs_version.restype = ctypes.c_int
-    assert lib.qs_version() == 9
+    assert lib.qs_version() == _hip.ABI_VERSION
     lib.qs_status_string.restype = ctypes.c_char_p
     assert b"aligned" in lib.qs_status_string(-3)
 

@@ -42,7 +42,7 @@ def close(a, b):
 
 def test_library_is_loaded_and_versioned():
     lib = _hip.load()
-    assert lib.qs_version() == 9
+    assert lib.qs_version() == _hip.ABI_VERSION
     assert torch.cuda.is_available()
 
 
