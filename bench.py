@@ -179,6 +179,76 @@ def config2(device, steps=200, nbuf=4):
             "rotating_buffers": nbuf, "steps": steps, "eager": rec(eager), "graph_replay": rec(graphed)}
 
 
+# kernel families of the in-model accounting: the streaming launches carry the bytes the reference's dtype contract makes
+# them move (every data operand once, in the dtype and layout the site really saw -- qsparse_amd/_hip.py `_timed`); the
+# C-sized launches (running means, selects, scale updates) are latency and carry none
+FAMILIES = (("apply_fwd", ("quant_scaler_fwd", "quant_decimal_fwd", "quant_line_fwd", "multi_quant_fwd")),
+            ("apply_bwd", ("quant_ste_bwd", "quant_ste_relu_bwd")),
+            ("mask_apply", ("mask_apply",)),
+            ("statistics", ("mean_dim", "mean_last2", "absmax", "minmax", "l0_flag", "multi_absmax", "kth_value", "mask_ge")))
+
+
+def library_kernel_accounting(step, reps=3):
+    """`reps` training steps with a HIP event pair around every launch of the library: per kernel family the time per
+    step, the algorithmic bytes per step and the fraction of the 8 TB/s roofline they amount to; overall the same with
+    the C-sized launches' time in the denominator as well (they move nothing, so they only cost)."""
+    from qsparse_amd import _hip
+
+    _hip.start_event_log(only=None)
+    for _ in range(reps):
+        step()
+    per = _hip.stop_event_log(with_bytes=True)
+    # what an event pair costs by itself: the pair brackets the launch's dispatch latency as well as its execution, which
+    # back-to-back launches overlap; an EMPTY pair on the same (busy) stream measures that floor
+    torch.cuda.synchronize()
+    empty = []
+    for _ in range(200):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        empty.append((a, b))
+    torch.cuda.synchronize()
+    pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+
+    def family_of(kernel):
+        base = kernel.split("+")[0]
+        for fam, names in FAMILIES:
+            if base in names:
+                return fam
+        return "c_sized"
+
+    fams, by_kernel = {}, {}
+    for k, launches in per.items():
+        f = fams.setdefault(family_of(k), {"ms": 0.0, "net": 0.0, "bytes": 0, "launches": 0})
+        f["ms"] += sum(ms for ms, _ in launches) / reps
+        f["net"] += sum(max(ms - pair_ms, 0.0) for ms, _ in launches) / reps
+        f["bytes"] += sum(nb for _, nb in launches) // reps
+        f["launches"] += len(launches) // reps
+        by_kernel[k] = round(sum(ms for ms, _ in launches) / reps, 3)
+    total_ms = sum(f["ms"] for f in fams.values())
+    total_net = sum(f["net"] for f in fams.values())
+    total_bytes = sum(f["bytes"] for f in fams.values())
+
+    def frac(nbytes, ms):
+        return round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (nbytes and ms) else None
+
+    rec = {"ms_per_step": round(total_ms, 3), "launches": sum(f["launches"] for f in fams.values()),
+           "algorithmic_GB_per_step": round(total_bytes / 1e9, 3), "frac_of_hbm_peak": frac(total_bytes, total_ms),
+           "event_pair_overhead_us": round(pair_ms * 1e3, 2), "ms_per_step_net_of_event_overhead": round(total_net, 3),
+           "frac_of_hbm_peak_net_of_event_overhead": frac(total_bytes, total_net),
+           "families": {}, "by_kernel_ms": dict(sorted(by_kernel.items(), key=lambda kv: -kv[1]))}
+    for name, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]):
+        rec["families"][name] = {"ms": round(f["ms"], 3), "ms_net": round(f["net"], 3), "launches": f["launches"],
+                                 "GB": round(f["bytes"] / 1e9, 3), "frac_of_hbm_peak": frac(f["bytes"], f["ms"]),
+                                 "frac_net": frac(f["bytes"], f["net"])}
+    rec["note"] = ("HIP event pairs around every library launch; `ms` is the raw sum (what `frac_of_hbm_peak` uses), `*_net` subtracts "
+                   "the cost of an empty event pair from every launch (the pair also brackets dispatch latency that back-to-back "
+                   "launches overlap; rocprofv3 kernel durations, profiles/r03_config*_kernel_stats.csv, are the reference). "
+                   "bytes = every data operand of a launch once, dense, in the dtype / layout the site saw; c_sized launches "
+                   "carry no bytes and count in the overall fractions' time only")
+    return rec
+
+
 def resnet_config(arch, batch, device, steps):
     """BASELINE configs 3 / 4: full-width ResNet-18 (CIFAR shape, 50 % channel pruning) / ResNet-50 (ImageNet shape,
     75 %), 4-bit weights and activations, bf16 autocast, channels_last (MIOpen's native layout), SGD with momentum,
@@ -242,12 +312,8 @@ def resnet_config(arch, batch, device, steps):
         for _ in range(8):
             step()
         out["pq_ms"] = round(_timed_loop(step, steps), 3)
-        _hip.start_event_log(only=None)        # one step with a HIP event pair around every launch of the library
-        step()
-        per = _hip.stop_event_log()
-        lib_ms = sum(sum(v) for v in per.values())
-        out["library_kernels"] = {"ms_per_step": round(lib_ms, 3), "launches": sum(len(v) for v in per.values()),
-                                  "by_kernel_ms": {k: round(sum(v), 3) for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))}}
+        out["library_kernels"] = library_kernel_accounting(step)
+        lib_ms = out["library_kernels"]["ms_per_step"]
         assert graphs.steady_state(model), "converted network did not reach its steady state"
         gr = capture(step)
         out["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)

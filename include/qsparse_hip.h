@@ -91,8 +91,11 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
- * float_zero_point == 0: (clamp(rint(xc/step)-rint(start/step),0,N-1)+rint(start/step))*step  (:161-166) */
-int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines, int bits,
+ * float_zero_point == 0: (clamp(rint(xc/step)-rint(start/step),0,N-1)+rint(start/step))*step  (:161-166)
+ * `codes` (nullable, int32, x's shape): the level index in [0, N-1] -- the clamp's result, before `* step + start` /
+ * `+ rint(start/step)` -- for the integer export (the arithmetic tests/test_quantize.py:73-101 pins for the decimal
+ * quantizer); INT32_MIN where x is NaN. */
+int qs_quant_line_fwd(const void* x, void* y, int32_t* codes, const float* lines, int64_t nlines, int bits,
                       int float_zero_point, int64_t outer, int64_t C, int64_t inner,
                       int xdt, int ydt, qs_stream_t stream);
 

@@ -323,7 +323,10 @@ class PruneSim:
 
     def __init__(self, sparsity: float = 0.5, dimensions=(1,), start: int = 1000, interval: int = 1000,
                  repetition: int = 4, rampup: bool = False, mask_refresh_interval: int = -1,
-                 stop_mask_refresh: float = float("inf"), running_average: bool = True, l0: bool = False):
+                 stop_mask_refresh: float = float("inf"), running_average: bool = True, l0: bool = False,
+                 use_gradient: bool = False):
+        assert running_average or not use_gradient                         # sparse.py:44-47
+        self.use_gradient, self.hook_armed = use_gradient, False
         self.sparsity, self.dimensions = sparsity, set(dimensions)
         self.start, self.interval, self.repetition, self.rampup = int(start), int(interval), repetition, rampup
         self.schedules = schedule_steps(self.start, self.interval, repetition, rampup)
@@ -335,7 +338,9 @@ class PruneSim:
         self.t = -1
         self.magnitude = None
 
-    def step(self, x: torch.Tensor, training: bool = True) -> torch.Tensor:
+    def step(self, x: torch.Tensor, training: bool = True, requires_grad: bool = True) -> torch.Tensor:
+        """`requires_grad`: whether the layer input requires grad (only the use_gradient mode looks at it, :73)."""
+        self._x_requires_grad = requires_grad
         if self.mask is None:                                              # sparse.py:228-249
             assert x.dim() > 1
             self.mask = torch.ones([s if i in self.dimensions else 1 for i, s in enumerate(x.shape)], dtype=torch.bool)
@@ -359,7 +364,13 @@ class PruneSim:
             if self.mask_refresh_interval <= 0:
                 self.mask_refresh_interval = 1
         t = self.t
-        if t < self.stop_mask_refresh and self.running_average:
+        if self.use_gradient:
+            # receive_input (sparse.py:69-78): the previous hook is removed, a new one is registered on THIS input if it
+            # requires grad; the magnitude is updated when (and if) that input's gradient arrives -- see receive_grad.
+            # Past stop_mask_refresh receive_input is not called (:107-108): this step's input carries no hook (the old
+            # one stays on the old input, whose backward has long run)
+            self.hook_armed = t < self.stop_mask_refresh and bool(getattr(self, "_x_requires_grad", True))
+        elif t < self.stop_mask_refresh and self.running_average:
             self.magnitude = magnitude_update(self.magnitude, x.detach(), t, self.l0)
         if sparsity >= 0 and (t % self.mask_refresh_interval == 0 and t <= self.stop_mask_refresh) and (
                 t > 0 or not self.running_average):
@@ -371,3 +382,10 @@ class PruneSim:
     def grad(self, g: torch.Tensor, active: bool = True) -> torch.Tensor:
         """autograd backward of `x * mask` (MulBackward0): g * mask in g's dtype."""
         return g * self.mask if active else g
+
+    def receive_grad(self, grad_x: torch.Tensor):
+        """use_gradient mode: the tensor hook of sparse.py:74-75 fires with the TOTAL gradient of the layer input (all
+        consumers of x) during backward, i.e. after `forward` advanced t (:117): update_magnitude(grad) with the
+        already-incremented t (:82-89).  Call once per backward that reaches the most recent training input."""
+        if self.use_gradient and self.hook_armed:
+            self.magnitude = magnitude_update(self.magnitude, grad_x.detach(), self.t, self.l0)

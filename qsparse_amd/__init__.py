@@ -7,6 +7,7 @@ hand-written HIP kernels for gfx950 behind a C ABI (``include/qsparse_hip.h``,
 """
 from qsparse_amd.batch import WeightBatcher
 from qsparse_amd.convert import convert
+from qsparse_amd.export import LayerExport, QuantizedTensor, export_integer
 from qsparse_amd.fuse import fuse_bn
 from qsparse_amd.graphs import resync_host_state
 from qsparse_amd.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQuantizer, quantize,

@@ -39,7 +39,7 @@ SIGNATURES = {
     "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
     "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
-    "qs_quant_line_fwd": (c_int, [_P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
+    "qs_quant_line_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
     "qs_minmax": (c_int, [_P, _P, _P, _I, _L, _L, _L, _I, _I, _P, c_size_t, _P]),
@@ -98,22 +98,28 @@ def take_event_pairs():
     """hand over the recorded (start, end) event pairs without synchronising; stops logging."""
     global _event_log
     log, _event_log = _event_log, None
-    return log or {}
+    return {k: [(a, b) for a, b, _ in v] for k, v in (log or {}).items()}
 
 
-def stop_event_log():
-    """returns {kernel name: [ms, ...]} (synchronises)."""
+def stop_event_log(with_bytes: bool = False):
+    """returns {kernel name: [ms, ...]} (synchronises); `with_bytes`: {kernel name: [(ms, algorithmic bytes), ...]} --
+    the bytes each launch has to move by the reference's dtype contract (see `_timed`), for roofline accounting."""
     global _event_log
     log, _event_log = _event_log, None
     torch.cuda.synchronize()
-    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (log or {}).items()}
+    if with_bytes:
+        return {k: [(a.elapsed_time(b), nb) for a, b, nb in v] for k, v in (log or {}).items()}
+    return {k: [a.elapsed_time(b) for a, b, _ in v] for k, v in (log or {}).items()}
 
 
 class _timed:
-    __slots__ = ("name", "a")
+    """`operands`: the data tensors the launch reads or writes (or a byte count): its algorithmic bytes are every one of
+    them moved ONCE in its own dtype (dense: the mask-aware elision of NCHW launches is not subtracted); nothing for the
+    C-sized launches, which are latency, not bandwidth.  Only evaluated while an event log is being recorded."""
+    __slots__ = ("name", "a", "operands")
 
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, *operands):
+        self.name, self.operands = name, operands
 
     def __enter__(self):
         self.a = None
@@ -125,7 +131,8 @@ class _timed:
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
-            _event_log.setdefault(self.name, []).append((self.a, b))
+            nbytes = sum(o if isinstance(o, int) else o.numel() * o.element_size() for o in self.operands if o is not None)
+            _event_log.setdefault(self.name, []).append((self.a, b, nbytes))
         return False
 
 
@@ -309,7 +316,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     cm = _chan_mask_bytes(chan_mask, C)
     sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
-    with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else "")):
+    with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
                 _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0,
                 _ptr(gate.bits) if gate is not None else None, _stream(x))
@@ -317,20 +324,23 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     return (y, codes, gate) if want_gate else (y, codes)
 
 
-def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_index: int, float_zero_point: bool):
+def quant_line_fwd(x: torch.Tensor, lines: torch.Tensor, bits: int, channel_index: int, float_zero_point: bool,
+                   want_codes: bool = False):
+    """returns y, or (y, codes) with `want_codes`: the int32 level index of every element (see qs_quant_line_fwd)"""
     lib = load()
     ln = lines.detach().to(device=x.device, dtype=torch.float32).contiguous().view(-1, 2)
     n = ln.shape[0]
     x, ci, like = mem_view(x, channel_index if n > 1 else -1)
     outer, C, inner, numel = split3(x.shape, ci)
     y = torch.empty_like(like, dtype=torch.float32)
+    codes = torch.empty_like(like, dtype=torch.int32) if want_codes else None
     if numel == 0:
-        return y
-    with _timed("quant_line_fwd"):
-        st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C, inner,
-                                   dt(x), F32, _stream(x))
+        return (y, codes) if want_codes else y
+    with _timed("quant_line_fwd", x, y, codes):
+        st = lib.qs_quant_line_fwd(_ptr(x), _ptr(y), _ptr(codes), _ptr(ln), n, int(bits), int(bool(float_zero_point)), outer, C,
+                                   inner, dt(x), F32, _stream(x))
     _check(st, "qs_quant_line_fwd")
-    return y
+    return (y, codes) if want_codes else y
 
 
 def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo_mul: float, hi_mul: float,
@@ -345,7 +355,7 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
     if numel == 0:
         return gx
     cm = _chan_mask_bytes(chan_mask, C)
-    with _timed("quant_ste_bwd" + ("+mask" if cm is not None else "")):
+    with _timed("quant_ste_bwd" + ("+mask" if cm is not None else ""), g, gx):
         st = lib.qs_quant_ste_bwd(_ptr(g), _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)), float(lo_mul),
                                   float(hi_mul), int(bool(passthrough)), _ptr(cm), outer, C, inner, dt(g),
                                   _DT[out_dtype], _elide_all() if cm is not None else 0, _stream(g))
@@ -378,7 +388,7 @@ def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decim
         if numel == 0:
             return gx
         cm = _chan_mask_bytes(chan_mask, C)
-        with _timed("quant_ste_relu_bwd"):
+        with _timed("quant_ste_relu_bwd", gm, gate.bits, gx):
             st = lib.qs_quant_ste_relu_bwd(_ptr(gm), None, _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host,
                                            int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner,
                                            dt(gm), _DT[gate.dtype], _elide_all() if cm is not None else 0, _stream(gm))
@@ -401,7 +411,7 @@ def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decim
     if numel == 0:
         return gx
     cm = _chan_mask_bytes(chan_mask, C)
-    with _timed("quant_ste_relu_bwd"):
+    with _timed("quant_ste_relu_bwd", g, x, gx):
         st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), None, _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
                                        float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x),
                                        _elide_all() if cm is not None else 0, _stream(g))
@@ -453,7 +463,7 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
         assert out.numel() == n
     assert out.dtype == torch.float32
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
-    with _timed("absmax"):
+    with _timed("absmax", x):
         st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
                            int(accumulate_into is not None), int(bool(pre_relu)), lines, _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_absmax")
@@ -481,7 +491,7 @@ def minmax(x: torch.Tensor, channel_index: int, accumulate_into=None):
         mn = torch.empty(n, dtype=torch.float32, device=x.device)
         mx = torch.empty(n, dtype=torch.float32, device=x.device)
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
-    with _timed("minmax"):
+    with _timed("minmax", x):
         st = lib.qs_minmax(_ptr(x), _ptr(mn), _ptr(mx), int(channel_index >= 0), outer, C, inner, dt(x),
                            int(accumulate_into is not None), _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_minmax")
@@ -555,7 +565,7 @@ def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtyp
     """x: contiguous storage viewed as [pre, n, post]; returns a flat [pre*post] tensor."""
     x = dense(x)
     out = torch.empty(pre * post, dtype=out_dtype, device=x.device)
-    with _timed("mean_dim" + ("+absmax" if absmax_out is not None else "")):
+    with _timed("mean_dim" + ("+absmax" if absmax_out is not None else ""), x, out):
         st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
                                 _ptr(absmax_out), amax_stride(absmax_out), int(chan_div), int(C), _stream(x))
     _check(st, "qs_mean_dim")
@@ -573,7 +583,7 @@ def mean_last2(x: torch.Tensor, pre: int, H: int, W: int, out_dtype: torch.dtype
     x = dense(x)
     out = torch.empty(pre, dtype=out_dtype, device=x.device)
     assert record is None or (record.dtype == torch.float32 and record.numel() == 2 * pre and record.is_contiguous())
-    with _timed("mean_last2"):
+    with _timed("mean_last2", x, amax_part):
         st = load().qs_mean_last2(_ptr(x), _ptr(out), pre, H, W, dt(x), _DT[out_dtype], _ptr(amax_part), _ptr(absmax_out),
                                   amax_stride(absmax_out), _ptr(record), _stream(x))
     _check(st, "qs_mean_last2")
@@ -588,7 +598,7 @@ def mean_dim_cl(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, want_a
     hw = x_nhwc.numel() // (N * C)
     out = torch.empty(C * hw, dtype=out_dtype, device=x_nhwc.device)
     part = torch.empty(C * hw, dtype=torch.float32, device=x_nhwc.device) if want_amax else None
-    with _timed("mean_dim" + ("+absmax" if want_amax else "")):
+    with _timed("mean_dim" + ("+absmax" if want_amax else ""), x_nhwc, out, part):
         st = load().qs_mean_dim_cl(_ptr(x_nhwc), _ptr(out), N, hw, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(l0_flag),
                                    _ptr(part), _stream(x_nhwc))
     _check(st, "qs_mean_dim_cl")
@@ -599,7 +609,7 @@ def l0_flag(x: torch.Tensor) -> torch.Tensor:
     x = dense(x)
     flag = torch.empty(1, dtype=torch.int32, device=x.device)
     scratch = torch.empty(2, dtype=torch.float32, device=x.device)
-    with _timed("l0_flag"):
+    with _timed("l0_flag", x):
         st = load().qs_l0_flag(_ptr(x), x.numel(), dt(x), _ptr(flag), _ptr(scratch), _stream(x))
     _check(st, "qs_l0_flag")
     return flag
@@ -623,7 +633,7 @@ def kth_value(imp: torch.Tensor, k: int) -> torch.Tensor:
     thr = torch.empty(1, dtype=torch.float32, device=imp.device)
     nbytes = lib.qs_workspace_bytes(WS_KTH_VALUE, n)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=imp.device)
-    with _timed("kth_value"):
+    with _timed("kth_value", imp):
         st = lib.qs_kth_value(_ptr(imp), n, int(k), _ptr(thr), _ptr(ws), ws.numel(), _stream(imp))
     _check(st, "qs_kth_value")
     return thr
@@ -633,7 +643,7 @@ def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
     """out_mask (bool, contiguous, same numel) <- imp >= thr, in place."""
     imp = imp.detach().to(torch.float32).contiguous()
     assert out_mask.dtype == torch.bool and out_mask.is_contiguous() and out_mask.numel() == imp.numel()
-    with _timed("mask_ge"):
+    with _timed("mask_ge", imp, out_mask):
         st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(out_mask), imp.numel(), _stream(imp))
     _check(st, "qs_mask_ge")
 
@@ -664,7 +674,7 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False, want
     nd = x.dim()
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
-    with _timed("mask_apply"):
+    with _timed("mask_apply", x, y, gate.bits if gate is not None else None):
         st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _elide_all(),
                                _ptr(gate.bits) if gate is not None else None, _stream(x))
     _check(st, "qs_mask_apply")
@@ -739,7 +749,7 @@ def _device_stream(device):
 
 
 def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
-    with _timed("multi_absmax"):
+    with _timed("multi_absmax", 4 * sum(numels)):
         st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
     _check(st, "qs_multi_absmax")
 
@@ -752,6 +762,6 @@ def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_pt
 
 
 def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device):
-    with _timed("multi_quant_fwd"):
+    with _timed("multi_quant_fwd", 8 * sum(numels)):
         st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
     _check(st, "qs_multi_quant_fwd")

@@ -68,11 +68,11 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
     });
 }
 
-int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines, int bits, int float_zero_point,
+int qs_quant_line_fwd(const void* x, void* y, int32_t* codes, const float* lines, int64_t nlines, int bits, int float_zero_point,
                       int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, qs_stream_t stream) {
     if (!x || !y || !lines) return QS_ERR_ARG;
     if (!dt_ok(xdt) || ydt != QS_F32) return QS_ERR_DTYPE;
-    if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
+    if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
     if (bits < 1 || bits > 24) return QS_ERR_ARG;
     int st = check_param(lines, nlines, C);
     if (st) return st;
@@ -86,10 +86,10 @@ int qs_quant_line_fwd(const void* x, void* y, const float* lines, int64_t nlines
         constexpr int XD = decltype(X)::value;
         if (float_zero_point) {
             LineFwdOp<true> op{lines, nlevels, 1.0f / nlevels};
-            return launch_ew<LineFwdOp<true>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
+            return launch_ew<LineFwdOp<true>, XD, QS_F32>(op, plan, ppc, x, y, codes, s);
         }
         LineFwdOp<false> op{lines, nlevels, 1.0f / nlevels};
-        return launch_ew<LineFwdOp<false>, XD, QS_F32>(op, plan, ppc, x, y, nullptr, s);
+        return launch_ew<LineFwdOp<false>, XD, QS_F32>(op, plan, ppc, x, y, codes, s);
     });
 }
 

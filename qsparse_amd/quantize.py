@@ -65,25 +65,36 @@ def _reference_shape(y: torch.Tensor, x: torch.Tensor, param) -> torch.Tensor:
     return y
 
 
+def _with_codes(ctx, y: torch.Tensor, codes, return_codes: bool):
+    """forward result of the quantizer Functions: ``y``, or ``(y, codes)`` with the integer codes as an int32,
+    non-differentiable second output (a NaN level index of the line quantizer becomes INT32_MIN, as on the GPU)"""
+    if not return_codes:
+        return y
+    if codes.dtype != torch.int32:
+        codes = torch.where(codes != codes, torch.full_like(codes, -2.0 ** 31), codes).to(torch.int32)
+    ctx.mark_non_differentiable(codes)
+    return y, codes
+
+
 class _SteFunction(torch.autograd.Function):
     """shared backward of the scaler and decimal quantizers (reference quantize.py:66-77, 120-131)."""
 
     @staticmethod
     def _backward(ctx, grad_output, step_is_decimal: bool):
         if ctx.backward_passthrough:
-            return (grad_output,) + (None,) * 6
+            return (grad_output,) + (None,) * 7
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         (step,) = ctx.saved_tensors
         if grad_output.is_cuda:
             out_dtype = ctx.x_dtype if grad_output.dtype == torch.float32 else grad_output.dtype
             gx = _hip.ste_bwd(grad_output, step, step_is_decimal, ctx.channel_index, lo_mul, hi_mul, False, out_dtype)
-            return (gx,) + (None,) * 6
+            return (gx,) + (None,) * 7
         s = torch.pow(2.0, -step) if step_is_decimal else step
         if s.numel() > 1:
             s = _on_channel(s, grad_output.dim(), ctx.channel_index, grad_output.shape[ctx.channel_index])
         # values are clamped; nothing is zeroed (the reference's masked assignment is a no-op)
-        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 6
+        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 7
 
 
 class ScalerQuantization(_SteFunction):
@@ -91,7 +102,10 @@ class ScalerQuantization(_SteFunction):
 
     @staticmethod
     def forward(ctx, input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = 1,
-                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False):
+                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
+                return_codes: bool = False):
+        """``return_codes`` (extension): also return the int32 codes ``q`` -- on the GPU the kernel's own ``codes`` output
+        of the same pass, never a second evaluation"""
         ctx.backward_passthrough = backward_passthrough
         ctx.notch = 1 if flip_axis else 0
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
@@ -102,14 +116,15 @@ class ScalerQuantization(_SteFunction):
             if isinstance(scaler, torch.Tensor) and scaler.numel() > 1:
                 assert len(scaler) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
-            y, _ = _hip.quant_fwd("scaler", input, scaler, channel_index, qd, out_dtype=_out_dtype(input))
-            return _reference_shape(y, input, scaler)
+            y, codes = _hip.quant_fwd("scaler", input, scaler, channel_index, qd, out_dtype=_out_dtype(input),
+                                      want_codes=return_codes)
+            return _with_codes(ctx, _reference_shape(y, input, scaler), codes, return_codes)
         s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
         codes = torch.round(input / s).int()
-        return (codes.float() * s).to(_out_dtype(input))  # no saturation: see module docstring
+        return _with_codes(ctx, (codes.float() * s).to(_out_dtype(input)), codes, return_codes)  # no saturation: see module docstring
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, grad_codes=None):
         return _SteFunction._backward(ctx, grad_output, step_is_decimal=False)
 
 
@@ -118,7 +133,8 @@ class DecimalQuantization(_SteFunction):
 
     @staticmethod
     def forward(ctx, input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = 1,
-                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False):
+                use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
+                return_codes: bool = False):
         ctx.backward_passthrough = backward_passthrough
         ctx.notch = 1 if flip_axis else 0
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
@@ -129,14 +145,16 @@ class DecimalQuantization(_SteFunction):
             if isinstance(decimal, torch.Tensor) and decimal.numel() > 1:
                 assert len(decimal) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
-            y, _ = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input))
-            return _reference_shape(y, input, decimal)
+            y, codes = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input),
+                                      want_codes=return_codes)
+            return _with_codes(ctx, _reference_shape(y, input, decimal), codes, return_codes)
         to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
         to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
-        return ((input * to_int).int().float() * to_float).to(_out_dtype(input))
+        codes = (input * to_int).int()
+        return _with_codes(ctx, (codes.float() * to_float).to(_out_dtype(input)), codes, return_codes)
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, grad_codes=None):
         return _SteFunction._backward(ctx, grad_output, step_is_decimal=True)
 
 
@@ -146,7 +164,8 @@ class LineQuantization(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, bits: int = 8, lines=(-0.1, 0.9), channel_index=-1, inplace=False,
-                float_zero_point=True):
+                float_zero_point=True, return_codes=False):
+        """``return_codes`` (extension): also return the int32 level index in [0, 2^bits - 1] of every element"""
         if not isinstance(lines, torch.Tensor):
             lines = torch.tensor(lines).view(-1, 2).to(x.device)
         if channel_index >= 0:
@@ -155,6 +174,8 @@ class LineQuantization(torch.autograd.Function):
         if x.is_cuda:
             if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or lines.dtype != torch.float32:
                 raise _hip.QsparseHipError(f"HIP line quantizer: unsupported dtypes {x.dtype} / {lines.dtype}")
+            if return_codes:
+                return _with_codes(ctx, *_hip.quant_line_fwd(x, lines, bits, channel_index, float_zero_point, want_codes=True), True)
             return _hip.quant_line_fwd(x, lines, bits, channel_index, float_zero_point)
         levels = 2 ** bits
         view = [1] * x.dim()
@@ -166,40 +187,48 @@ class LineQuantization(torch.autograd.Function):
         step = torch.where(step == 0, torch.full_like(step, 0.0001), step)
         if float_zero_point:   # training form (:168-181): separate multiply and add
             idx = ((xc - lo) / step).round().clamp(0, levels - 1)
-            return idx * step + lo
+            return _with_codes(ctx, idx * step + lo, idx, return_codes)
         zero_point = (lo / step).round()   # evaluation form (:161-166): integer zero point
         idx = ((xc / step).round() - zero_point).clamp(0, levels - 1)
-        return (idx + zero_point) * step
+        return _with_codes(ctx, (idx + zero_point) * step, idx, return_codes)
 
     @staticmethod
-    def backward(ctx, grad_output):
-        return (grad_output,) + (None,) * 5
+    def backward(ctx, grad_output, grad_codes=None):
+        return (grad_output,) + (None,) * 6
 
 
 def quantize_with_decimal(input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = -1,
                           use_uint: bool = False, backward_passthrough: bool = False,
-                          flip_axis: bool = False) -> torch.Tensor:
+                          flip_axis: bool = False, return_codes: bool = False) -> torch.Tensor:
     """power-of-two uniform quantization (reference quantize.py:188-208).
 
     Args mirror the reference: ``decimal`` is the number of fractional bits (int, or per-channel
     tensor viewed along ``channel_index``); ``use_uint`` is accepted and, as in the reference, has no
     effect; ``backward_passthrough`` skips the gradient clamp; ``flip_axis`` shifts the clamp
-    interval by one step."""
-    return DecimalQuantization.apply(input, bits, decimal, channel_index, use_uint, backward_passthrough, flip_axis)
+    interval by one step.  ``return_codes`` (extension of this package): return ``(y, q)`` with the int32 codes
+    ``q = int(x * 2^d)`` the output was built from (``y == q.float() * 2^-d``) -- the integers an int8/int32 inference
+    engine consumes (reference tests/test_quantize.py:73-101)."""
+    return DecimalQuantization.apply(input, bits, decimal, channel_index, use_uint, backward_passthrough, flip_axis,
+                                     return_codes)
 
 
 def quantize_with_scaler(input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = -1,
                          use_uint: bool = False, backward_passthrough: bool = False,
-                         flip_axis: bool = False) -> torch.Tensor:
-    """scaling-factor based uniform quantization (reference quantize.py:210-230)."""
-    return ScalerQuantization.apply(input, bits, scaler, channel_index, use_uint, backward_passthrough, flip_axis)
+                         flip_axis: bool = False, return_codes: bool = False) -> torch.Tensor:
+    """scaling-factor based uniform quantization (reference quantize.py:210-230).  ``return_codes`` (extension):
+    return ``(y, q)`` with the int32 codes ``q = int(round(x / s))``, ``y == q.float() * s``."""
+    return ScalerQuantization.apply(input, bits, scaler, channel_index, use_uint, backward_passthrough, flip_axis,
+                                    return_codes)
 
 
 def quantize_with_line(x: torch.Tensor, bits: int = 8,
                        lines: Union[Tuple[float, float], List[Tuple[float, float]]] = (-0.1, 0.9),
-                       channel_index: int = -1, inplace: bool = False, float_zero_point: bool = True) -> torch.Tensor:
-    """asymmetric uniform quantization (reference quantize.py:232-255)."""
-    return LineQuantization.apply(x, bits, lines, channel_index, inplace, float_zero_point)
+                       channel_index: int = -1, inplace: bool = False, float_zero_point: bool = True,
+                       return_codes: bool = False) -> torch.Tensor:
+    """asymmetric uniform quantization (reference quantize.py:232-255).  ``return_codes`` (extension): return
+    ``(y, idx)`` with the int32 level index ``idx`` in ``[0, 2^bits - 1]``: ``y == idx * step + start`` in the training
+    form, ``y == (idx + round(start / step)) * step`` with ``float_zero_point=False``."""
+    return LineQuantization.apply(x, bits, lines, channel_index, inplace, float_zero_point, return_codes)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -278,6 +307,22 @@ class DecimalQuantizer(BaseQuantizer):
             param = (1 / scaler).nan_to_num(posinf=1, neginf=1).log2().round()   # quantize.py:316
         return self.function(tensor, bits, param, channel_index, self.use_uint, self.backward_passthrough,
                              self.flip_axis)
+
+    def export(self, tensor, bits, scaler, channel_index=-1) -> dict:
+        """integer form of ``self(tensor, bits, scaler, channel_index)`` (extension, see qsparse_amd/export.py): the
+        codes are the second output of the very call ``forward`` makes -- group-wise scales included."""
+        with torch.no_grad():
+            if self.t >= self.group_timeout and self.group_num > 0 and scaler.numel() > self.group_num:
+                scaler = self._group_scales(scaler)
+            if self.use_float_scaler:
+                y, codes = self.function(tensor, bits, scaler, channel_index, self.use_uint, self.backward_passthrough,
+                                         self.flip_axis, True)
+                return dict(kind="scaler", codes=codes, values=y, scale=scaler.detach().clone())
+            decimal = (_hip.decimal_from_scale(scaler).view(scaler.shape) if scaler.is_cuda
+                       else (1 / scaler).nan_to_num(posinf=1, neginf=1).log2().round())
+            y, codes = self.function(tensor, bits, decimal, channel_index, self.use_uint, self.backward_passthrough,
+                                     self.flip_axis, True)
+            return dict(kind="decimal", codes=codes, values=y, decimal=decimal.to(torch.int32))
 
     def optimize(self, x, bits, weight=None, batched=False, channel_index=-1, **kwargs):
         """running mean of ``max|x| / 2^(bits-1)`` (reference quantize.py:327-349)."""
@@ -371,6 +416,16 @@ class AdaptiveQuantizer(DecimalQuantizer):
 
     def quantize(self, tensor, bits, lines, channel_index=-1, **kwargs):
         return self.function(tensor, bits, lines, channel_index, kwargs.get("inplace", False), self.training)
+
+    def export(self, tensor, bits, lines, channel_index=-1) -> dict:
+        """integer form of the EVALUATION-mode output (integer zero point, reference quantize.py:161-166):
+        ``values == (codes + zero_point) * step``"""
+        with torch.no_grad():
+            y, codes = self.function(tensor, bits, lines, channel_index, False, False, True)
+            step = (lines[:, 1] - lines[:, 0]) / 2 ** bits
+            step = torch.where(step == 0, torch.full_like(step, 0.0001), step)
+            return dict(kind="line", codes=codes, values=y, lines=lines.detach().clone(), step=step,
+                        zero_point=(lines[:, 0] / step).round().to(torch.int32))
 
     @staticmethod
     def _bounds_cpu(x, channel_index, batched):

@@ -24,6 +24,7 @@ Reference entry points exercised (file:line in /root/reference):
   F10 prune->quantize pair trajectory (the headline pair, small shape)
   F13 UniformPruningCallback trajectories      qsparse/sparse.py:125-152 (numpy global RNG, seeded per case)
   F14 counters written through ``.data``       qsparse/quantize.py:495, qsparse/sparse.py:251-269,104-118
+  F15 MagnitudePruningCallback(use_gradient=True)  qsparse/sparse.py:69-80 (tensor hook -> update_magnitude(grad), :82-89)
 """
 import io
 import json
@@ -785,6 +786,73 @@ def f14():
     save("f14_state_writes", store, dict(cases=cases))
 
 
+# --------------------------------------------------------------------------------------------
+# F15: gradient-magnitude pruning -- MagnitudePruningCallback(use_gradient=True), qsparse/sparse.py:69-80.  The callback
+# registers a tensor hook on the layer INPUT; the hook runs update_magnitude(grad) during backward, i.e. after the
+# forward has already advanced `t` (:117), with the TOTAL gradient of the input (every consumer of x, not only x * mask).
+# --------------------------------------------------------------------------------------------
+def f15():
+    store, cases = {}, []
+    specs = [
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=2, interval=2, repetition=3, rampup=False,
+             cb=dict(), dtype="float32", steps=12),
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.75, start=1, interval=2, repetition=2, rampup=True,
+             cb=dict(), dtype="bfloat16", steps=10),
+        dict(shape=(4, 12, 3, 5), dims=[1], sparsity=0.6, start=1, interval=2, repetition=3, rampup=False,
+             cb=dict(mask_refresh_interval=2, stop_mask_refresh=6), dtype="bfloat16", steps=11),
+        # non-negative upstream gradients with exact zeros: grad.min() == 0 switches the L0 variant on (:85-86)
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=1, interval=1, repetition=2, rampup=False,
+             cb=dict(l0=True), dtype="float32", steps=8, relu_gout=True),
+        # the input has a second consumer: the hook sees gout * mask + 0.5 * gout
+        dict(shape=(2, 8, 6, 6), dims=[1], sparsity=0.5, start=1, interval=1, repetition=2, rampup=False,
+             cb=dict(), dtype="float32", steps=8, residual=True),
+        # steps 3 and 6 feed a tensor that does not require grad ("meeting no-grad tensor"), step 4 runs no backward
+        dict(shape=(3, 10, 4, 4), dims=[1], sparsity=0.5, start=1, interval=1, repetition=2, rampup=False,
+             cb=dict(), dtype="float32", steps=9, no_grad_steps=[3, 6], no_backward_steps=[4]),
+        dict(shape=(6, 16), dims=[1], sparsity=0.5, start=1, interval=1, repetition=2, rampup=False,
+             cb=dict(), dtype="bfloat16", steps=7),
+        dict(shape=(2, 6, 5, 5), dims=[1, 2, 3], sparsity=0.7, start=1, interval=2, repetition=2, rampup=False,
+             cb=dict(), dtype="float32", steps=8),
+    ]
+    for idx, sp in enumerate(specs):
+        dt = getattr(torch, sp["dtype"])
+        with quiet():
+            layer = prune(sparsity=sp["sparsity"], dimensions=set(sp["dims"]), start=sp["start"], interval=sp["interval"],
+                          repetition=sp["repetition"], rampup=sp["rampup"],
+                          callback=MagnitudePruningCallback(use_gradient=True, **sp["cb"]))
+        layer.train()
+        k = f"c{idx}_"
+        scale = torch.linspace(0.25, 4, sp["shape"][1]).view([1, -1] + [1] * (len(sp["shape"]) - 2))
+        for s in range(sp["steps"] + 2):
+            if s == sp["steps"]:
+                layer.eval()
+            needs_grad = s not in sp.get("no_grad_steps", [])
+            runs_backward = needs_grad and s not in sp.get("no_backward_steps", [])
+            x = (torch.randn(sp["shape"], generator=gen(9000 + 37 * idx + s)) * scale).to(dt).requires_grad_(needs_grad)
+            gout = torch.randn(sp["shape"], generator=gen(9500 + 37 * idx + s)) * scale.flip(1)
+            if sp.get("relu_gout"):
+                gout = gout.relu()
+            gout = gout.to(dt)
+            with quiet():
+                y = layer(x)
+                out = y + x * 0.5 if sp.get("residual") else y
+                if runs_backward:
+                    out.backward(gout)
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_gout", gout)
+            put(store, k + f"s{s}_y", y)
+            if runs_backward:
+                put(store, k + f"s{s}_gx", x.grad)
+            put(store, k + f"s{s}_mask", layer.mask)
+            put(store, k + f"s{s}_n_updates", layer._n_updates)
+            put(store, k + f"s{s}_cur_sparsity", layer._cur_sparsity)
+            put(store, k + f"s{s}_t", layer.callback.t)
+            if hasattr(layer.callback, "magnitude"):
+                put(store, k + f"s{s}_magnitude", layer.callback.magnitude)     # AFTER the backward of this step
+        cases.append(dict(id=idx, **{**sp, "shape": list(sp["shape"])}, total_steps=sp["steps"] + 2))
+    save("f15_prune_use_gradient", store, dict(cases=cases))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     f1_f2()
@@ -799,3 +867,4 @@ if __name__ == "__main__":
     f12()
     f13()
     f14()
+    f15()

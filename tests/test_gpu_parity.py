@@ -71,6 +71,10 @@ def test_golden_f7_prune_layer():
     H.run_f7(DEV)
 
 
+def test_golden_f15_prune_layer_use_gradient():
+    H.run_f15(DEV)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_golden_f10_pair(fused):
     H.run_f10(DEV, fused)

@@ -171,6 +171,38 @@ def test_f7_prune_layer():
     run_f7(DEV)
 
 
+def run_f15(dev):
+    """gradient-magnitude pruning (reference sparse.py:69-80) replayed through the package: outputs, gradients, masks,
+    counters and the magnitude AFTER every backward, bit for bit"""
+    g = Golden("f15_prune_use_gradient")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        layer = qs.prune(sparsity=c["sparsity"], dimensions=set(c["dims"]), start=c["start"], interval=c["interval"],
+                         repetition=c["repetition"], rampup=c["rampup"],
+                         callback=MagnitudePruningCallback(use_gradient=True, **c["cb"]))
+        layer.train()
+        for s in range(c["total_steps"]):
+            if s == c["steps"]:
+                layer.eval()
+            x = g.get(k + f"s{s}_x").to(dev).requires_grad_(s not in c.get("no_grad_steps", []))
+            gout = g.get(k + f"s{s}_gout").to(dev)
+            y = layer(x)
+            if g.has(k + f"s{s}_gx"):
+                (y + x * 0.5 if c.get("residual") else y).backward(gout)
+                assert same(x.grad.cpu(), g.get(k + f"s{s}_gx")), (c, s)
+            assert same(y.detach().cpu(), g.get(k + f"s{s}_y")), (c, s)
+            assert same(layer.mask.detach().cpu(), g.get(k + f"s{s}_mask")), (c, s)
+            assert same(layer._n_updates.detach().cpu(), g.get(k + f"s{s}_n_updates")), (c, s)
+            assert same(layer._cur_sparsity.detach().cpu(), g.get(k + f"s{s}_cur_sparsity")), (c, s)
+            assert same(layer.callback.t.detach().cpu(), g.get(k + f"s{s}_t")), (c, s)
+            if g.has(k + f"s{s}_magnitude"):
+                assert same(layer.callback.magnitude.detach().cpu(), g.get(k + f"s{s}_magnitude")), (c, s)
+
+
+def test_f15_prune_layer_use_gradient():
+    run_f15(DEV)
+
+
 def run_f10(dev, fused):
     g = Golden("f10_prune_quant_pair")
     for c in g.cases:

@@ -130,6 +130,36 @@ def test_f7_prune_layer_trajectories():
             assert same(sim.grad(g.get(k + f"s{s}_gout"), active), g.get(k + f"s{s}_gx")), (c, s)
 
 
+def test_f15_prune_layer_use_gradient_trajectories():
+    """MagnitudePruningCallback(use_gradient=True), reference sparse.py:69-80: the magnitude follows the input's gradient"""
+    g = Golden("f15_prune_use_gradient")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        sim = O.PruneSim(c["sparsity"], c["dims"], c["start"], c["interval"], c["repetition"], c["rampup"], use_gradient=True,
+                         **c["cb"])
+        for s in range(c["total_steps"]):
+            training = s < c["steps"]
+            x, gout = g.get(k + f"s{s}_x"), g.get(k + f"s{s}_gout")
+            needs_grad = s not in c.get("no_grad_steps", [])
+            n_before = sim.n_updates
+            y = sim.step(x, training, requires_grad=needs_grad)
+            assert same(y, g.get(k + f"s{s}_y")), (c, s)
+            assert same(sim.mask, g.get(k + f"s{s}_mask")), (c, s)
+            if g.has(k + f"s{s}_gx"):          # a backward ran: the hook saw the input's total gradient
+                active = (not training) or n_before >= c["start"]
+                gx = sim.grad(gout, active)
+                if c.get("residual"):
+                    gx = gx + gout * 0.5
+                assert same(gx, g.get(k + f"s{s}_gx")), (c, s)
+                if training and n_before >= c["start"]:
+                    sim.receive_grad(gx)
+            assert sim.n_updates == int(g.get(k + f"s{s}_n_updates")[0])
+            assert sim.cur_sparsity == float(g.get(k + f"s{s}_cur_sparsity")[0])
+            assert sim.t == int(g.get(k + f"s{s}_t")[0])
+            if g.has(k + f"s{s}_magnitude"):
+                assert same(sim.magnitude, g.get(k + f"s{s}_magnitude")), (c, s)
+
+
 def test_f7_conv_weight_pruning():
     g = Golden("f7_prune_layer")
     for c in g.cases:

@@ -34,7 +34,8 @@ SCHEDULE = dict(prune_start=2, prune_interval=2, repetition=2, quant_timeout=3)
 class SiteChecker:
     """oracle twin of one operator site; `fwd` / `bwd` are the hook bodies"""
 
-    def __init__(self, name, module, sparsity, bits, log):
+    def __init__(self, name, module, sparsity, bits, log, schedule=None):
+        schedule = schedule or SCHEDULE
         self.name, self.module, self.log = name, module, log
         self.relu = False
         self.p = self.q = None
@@ -51,8 +52,8 @@ class SiteChecker:
         self.psim = None
         if self.p is not None:
             assert isinstance(self.p, PruneLayer) and self.p.dimensions == {1}
-            self.psim = O.PruneSim(sparsity, [1], SCHEDULE["prune_start"], SCHEDULE["prune_interval"], SCHEDULE["repetition"], False)
-        self.qsim = O.QuantizeSim("scaler", bits, -1, SCHEDULE["quant_timeout"], batch_dimension=self.q.batch_dimension)
+            self.psim = O.PruneSim(sparsity, [1], schedule["prune_start"], schedule["prune_interval"], schedule["repetition"], False)
+        self.qsim = O.QuantizeSim("scaler", bits, -1, schedule["quant_timeout"], batch_dimension=self.q.batch_dimension)
         self.steps = 0
         self.saved = None
 
@@ -97,7 +98,23 @@ class SiteChecker:
         assert got.dtype == gin.dtype and same(got, gin), ("input gradient", self.name, self.steps - 1)
 
 
-def run_sites(arch, device, site_names, batch, width=64, channels_last=False, steps=7, autocast=True):
+def all_site_names(model):
+    """every operator site `convert_pq` built: activation sites (`Sequential(Sequential(act, P), Q)`, `Sequential(act, Q)`) and
+    every QuantizeLayer outside one (the input quantizer, the weight quantizers `<layer>.quantize`)"""
+    sites, inside = [], set()
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[1], QuantizeLayer):
+            sites.append(name)
+            inside.update(id(c) for c in m.modules())
+    for name, m in model.named_modules():
+        if isinstance(m, QuantizeLayer) and id(m) not in inside:
+            sites.append(name)
+    return sites
+
+
+def run_sites(arch, device, site_names, batch, width=64, channels_last=False, steps=7, autocast=True, schedule=None):
+    """`site_names`: a list, or "all" for every site of the converted network"""
+    schedule = schedule or SCHEDULE
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     torch.manual_seed(0)
     if arch == "resnet18":
@@ -105,13 +122,15 @@ def run_sites(arch, device, site_names, batch, width=64, channels_last=False, st
     else:
         model, shape, classes, sparsity = resnet50(1000 if width == 64 else 10, False, width), (batch, 3, 224, 224), \
             (1000 if width == 64 else 10), 0.75
-    model = convert_pq(model, sparsity=sparsity, bits=4, **SCHEDULE).to(device).train()
+    model = convert_pq(model, sparsity=sparsity, bits=4, **schedule).to(device).train()
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
     modules = dict(model.named_modules())
+    if site_names == "all":
+        site_names = all_site_names(model)
     log, checkers = [], []
     for name in site_names:
-        ck = SiteChecker(name, modules[name], sparsity, 4, log)
+        ck = SiteChecker(name, modules[name], sparsity, 4, log, schedule)
         modules[name].register_forward_hook(ck.fwd)
         if not isinstance(modules[name], QuantizeLayer) or name != "0":
             modules[name].register_full_backward_hook(ck.bwd)
@@ -186,3 +205,34 @@ def test_resnet18_cifar_sites_vs_oracle(channels_last):
     assert final["1.stem.2"][0] == (64, 64, 32, 32) and final["1.stages.6.relu1"][0] == (64, 512, 4, 4)
     for name in ("1.stem.2", "1.stages.2.relu1", "1.stages.6.relu1"):
         assert final[name][2] and 0.45 <= final[name][3] <= 0.7, (name, final[name])
+
+
+FAST = dict(prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)     # inactive -> live -> steady state in 3 steps
+
+
+def test_all_sites_harness_on_cpu_miniature():
+    log, model = run_sites("resnet50", "cpu", "all", batch=2, width=8, autocast=False, steps=3, schedule=FAST)
+    names = {n for n, *_ in log}
+    assert len(names) == 49 + 54 + 1              # activation sites, conv / fc weights, the input quantizer
+
+
+@pytest.mark.gpu
+def test_resnet50_every_operator_site_vs_oracle():
+    """BASELINE config 4, EVERY operator site of the full-width network (49 activation sites, 54 weight quantizers, the
+    input quantizer) hooked for three steps at batch 8, channels_last, bf16 autocast: each site's output, input
+    gradient, mask, magnitude, scale and counters against the oracle on the tensors it really received
+    (reference sparse.py:215-273, quantize.py:473-518, imitation.py:42-68)"""
+    log, model = run_sites("resnet50", "cuda", "all", batch=8, channels_last=True, steps=3, schedule=FAST)
+    final = _summary(log, 3)
+    assert len(final) == 104
+    live = [v for v in final.values() if v[3] is not None]
+    assert len(live) == 48 and all(v[2] for v in final.values())          # every site quantizes; 48 of the 49 also prune
+    assert all(0.2 <= v[3] <= 0.5 for v in live)
+
+
+@pytest.mark.gpu
+def test_resnet50_imagenet_sites_at_batch_64_vs_oracle():
+    """the eleven chosen sites at batch 64 (the stem is a 51 M-element tensor): the grids a batch of 16 does not reach"""
+    log, model = run_sites("resnet50", "cuda", RN50_SITES, batch=64, channels_last=True, steps=4, schedule=FAST)
+    final = _summary(log, 4)
+    assert final["1.stem.2"][0] == (64, 64, 112, 112) and final["1.stages.0.relu3"][0] == (64, 256, 56, 56)
