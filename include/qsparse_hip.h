@@ -308,12 +308,16 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
  *   qs_multi_scale_update:  scale[i][0] <- t == 0 ? new : (t*scale + new)/(t+1), new = amax[i][0] / 2^(bits[i]-1);
  *                           amax[i][0] <- 0; decimal[i][0] <- rint(log2(1/scale)) where decimal[i] != NULL;
  *                           t from t_dev[i] (then incremented there) where non-NULL, else t[i]; bump[i] (nullable
- *                           int32 counters) incremented
+ *                           int32 counters) incremented; backup[i][0] (nullable array, nullable entries) <- the scale
+ *                           this update replaces, so that a caller that evaluated a layer ahead of time can restore the
+ *                           state of one the forward pass then never reached (reference imitation.py:61-68 evaluates the
+ *                           operator only when the layer's weight is read)
  *   qs_multi_quant_fwd:     y[i] = Q(x[i]) with param[i][0] the scale (decimal == 0, qs_quant_scaler_fwd's
  *                           arithmetic) or the decimal (decimal != 0, qs_quant_decimal_fwd's) */
 int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream);
 int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
-                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, qs_stream_t stream);
+                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, float* const* backup,
+                          qs_stream_t stream);
 int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
                        int decimal, qs_stream_t stream);
 

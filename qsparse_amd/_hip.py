@@ -56,7 +56,7 @@ SIGNATURES = {
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
-    "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
@@ -754,9 +754,9 @@ def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
     _check(st, "qs_multi_absmax")
 
 
-def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device):
+def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device, backup_ptrs=None):
     with _timed("multi_scale_update"):
-        st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs,
+        st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, backup_ptrs,
                                       _device_stream(device))
     _check(st, "qs_multi_scale_update")
 

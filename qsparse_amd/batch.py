@@ -1,24 +1,36 @@
 """Multi-tensor weight path.
 
-``quantize(conv)`` reads ``conv.weight`` through a ``QuantizeLayer`` (reference quantize.py:559-571 via imitation.py):
+``quantize(conv)`` reads ``conv.weight`` through a ``QuantizeLayer`` (reference quantize.py:559-571 via imitation.py:61-68):
 per layer and training step an abs-max, a running-scale update and a quantization -- three launches of 3-5 us each
 plus ~100 us of Python.  A converted ResNet-50 has 54 such layers.  They depend on nothing but the parameters, so
-``WeightBatcher`` evaluates all of them at the start of the forward pass with THREE launches in total
+``WeightBatcher`` evaluates all of them at the start of the root's forward pass with THREE launches in total
 (``qs_multi_absmax``, ``qs_multi_scale_update``, ``qs_multi_quant_fwd``; same arithmetic, bit-identical results) and
 hands every layer its quantized weight when its forward asks for it.  The STE backward stays per layer (gradients
 become ready one layer at a time).
 
-    model = qs.convert(...).cuda()
-    qs.WeightBatcher(model)        # once; .remove() undoes it
+``convert`` installs it on the network it returns (``set_qsparse_options(batch_weights=False)`` or
+``convert(..., batch_weights=False)`` opt out; ``WeightBatcher.install(model)`` does the same by hand, ``.remove()``
+undoes it).  It is safe by construction for anything a forward pass may do:
+
+  * The reference evaluates a layer's operator when -- and only when -- the layer's weight is read
+    (imitation.py:61-68).  A layer whose precomputed weight was NOT consumed by the end of the root's forward -- a branch
+    the forward skipped, an exception half-way -- is rolled back to exactly the state it had before: running scale (from
+    the backup ``qs_multi_scale_update`` wrote), ``_n_updates``, the callback's ``t`` (host and device copy) and
+    ``_quantized``.  The forward hook that does this also runs when the forward raised.
+  * A weight that is read a second time in the same forward takes the inline path, as the second read of the reference.
+  * A weight written between the precomputation and its read is rolled back and re-evaluated inline.  The write is seen
+    through ``Tensor._version`` (every in-place operation); the one route that bypasses the counter is ``param.data``.  The
+    place where user code runs between the two is a forward pre-hook of the layer itself: layers that carry one are not
+    batched.  (A raw ``.data`` write to a layer's weight from OTHER code running inside the same forward, before that
+    layer's read, is not visible -- switch ``batch_weights`` off for such a network.)
+  * Layers whose quantizer carries hooks, layers on the CPU, pruned or bias-quantized layers and per-channel quantizers
+    never take part; they keep their inline path.
 
 Only layers whose weight is read through exactly one tensor-wise Scaler / Decimal ``QuantizeLayer`` (no weight pruning,
-no bias quantizer, float32 parameter on the GPU) take part; every other layer keeps its inline path.  In evaluation
-mode the quantized weights are computed once and handed out again until a parameter or a scale changes (serving: no
-weight-side launch at all per request).  A layer that the
-forward pass never reaches has its statistics advanced all the same -- unlike the inline path; do not use the batcher
-for networks that skip layers data-dependently.
+no bias quantizer, float32 parameter on the GPU) take part.  In evaluation mode the quantized weights are computed once
+and handed out again until a parameter or a scale changes (serving: no weight-side launch at all per request).
 """
-from typing import Dict, List
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -28,6 +40,8 @@ from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantize
 from qsparse_amd.util import get_option, logging
 
 _ALIGN = 64   # elements between the starts of two outputs in the flat buffer (256 bytes)
+_READY = "_qs_ready_weight"        # layer.__dict__ key of a precomputed weight waiting for its read
+_ATTR = "_qs_weight_batcher"       # root.__dict__ key of the installed batcher
 
 
 class _PrecomputedSte(torch.autograd.Function):
@@ -50,7 +64,10 @@ class _PrecomputedSte(torch.autograd.Function):
 
 
 def _imitation_depth(layer: nn.Module) -> int:
-    return sum(1 for cls in type(layer).__mro__ if isinstance(cls.__dict__.get("weight"), property))
+    """number of operators the layer's weight is read through (imitation.py stacks one subclass per operator); the
+    batcher's own hand-out subclass is not one of them"""
+    return sum(1 for cls in type(layer).__mro__
+               if isinstance(cls.__dict__.get("weight"), property) and "_qs_batcher_base" not in cls.__dict__)
 
 
 def _eligible(layer: nn.Module) -> bool:
@@ -65,32 +82,79 @@ def _eligible(layer: nn.Module) -> bool:
             and q.batch_dimension == -1 and q.timeout > 0)
 
 
+def _hooked(q: QuantizeLayer) -> bool:
+    """hooks on the quantizer or its callback (or global module hooks) must see the calls they were registered for: such a
+    layer keeps its inline path"""
+    from torch.nn.modules import module as _m
+
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (q, q.callback))
+
+
+class _Pending:
+    """what has to be undone if a precomputed layer's weight is never read"""
+    __slots__ = ("layer", "slot", "was_quantized", "t_dev", "version", "training")
+
+    def __init__(self, layer, slot, was_quantized, t_dev, version, training):
+        self.layer, self.slot, self.was_quantized, self.t_dev, self.version, self.training = (layer, slot, was_quantized, t_dev,
+                                                                                             version, training)
+
+
+def _patched_class(base):
+    """subclass of `base` whose `weight` hands out a waiting precomputed tensor once, else reads like `base`.  The
+    property finds everything through the instance (nothing closes over a batcher), so a deep copy of the network keeps
+    working on its own."""
+
+    def read_weight(self_):
+        entry = self_.__dict__.pop(_READY, None)
+        if entry is not None:
+            y, pending, batcher = entry
+            w = self_._parameters["weight"]
+            if w._version == pending.version:
+                batcher._consumed(pending)
+                return y
+            batcher._rollback(pending)           # the parameter was written since the precomputation: evaluate inline
+        return base.weight.__get__(self_)
+
+    return type(base.__name__, (base,), {"weight": property(read_weight), "_qs_batcher_base": base})
+
+
 class WeightBatcher:
     def __init__(self, model: nn.Module):
+        for m in model.modules():                # one batcher per tree: an earlier one (convert installs one) steps aside
+            old = m.__dict__.get(_ATTR)
+            if old is not None:
+                old.remove()
         self.model = model
         self.layers: List[nn.Module] = [m for m in model.modules() if _eligible(m)]
         if len({id(m.quantize.callback) for m in self.layers}) != len(self.layers):
             raise ValueError("WeightBatcher needs one quantizer callback per layer (convert() makes them so)")
-        self._cache: Dict[int, torch.Tensor] = {}
-        self._orig = {}
+        self._pending: List[_Pending] = []
         self._amax = None
         self._decimals = None
+        self._backup = None
         self._eval_key = None
         self._eval_outs = None
         for layer in self.layers:
-            self._patch(layer)
+            if "_qs_batcher_base" not in type(layer).__dict__:
+                layer.__class__ = _patched_class(type(layer))
         self._hook = model.register_forward_pre_hook(self._precompute)
+        self._post = model.register_forward_hook(self._finish, always_call=True)
+        model.__dict__[_ATTR] = self
 
-    def _patch(self, layer: nn.Module):
-        base = type(layer)
-        self._orig[id(layer)] = base
-        cache = self._cache
-
-        def read_weight(self_):
-            y = cache.pop(id(self_), None)
-            return y if y is not None else base.weight.__get__(self_)
-
-        layer.__class__ = type(base.__name__, (base,), {"weight": property(read_weight)})
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def install(model: nn.Module) -> Optional["WeightBatcher"]:
+        """(re-)install on `model`: batchers found anywhere in its tree are removed first (a further ``convert`` changes
+        the set of layers); returns None when no layer is eligible"""
+        if not any(_eligible(m) for m in model.modules()):
+            for m in model.modules():
+                old = m.__dict__.get(_ATTR)
+                if old is not None:
+                    old.remove()
+            return None
+        return WeightBatcher(model)
 
     def invalidate(self):
         """forget the quantized weights kept for evaluation.  They are reused while no parameter and no scale has been
@@ -99,22 +163,67 @@ class WeightBatcher:
         self._eval_key = self._eval_outs = None
 
     def remove(self):
+        self._rollback_all()
         self._hook.remove()
+        self._post.remove()
         for layer in self.layers:
-            layer.__class__ = self._orig[id(layer)]
-        self._cache.clear()
+            base = type(layer).__dict__.get("_qs_batcher_base")
+            if base is not None:
+                layer.__class__ = base
+            layer.__dict__.pop(_READY, None)
+        self.model.__dict__.pop(_ATTR, None)
+
+    # ------------------------------------------------------------------------------------------
+    def _consumed(self, pending: _Pending):
+        try:
+            self._pending.remove(pending)
+        except ValueError:
+            pass
+
+    def _rollback(self, p: _Pending):
+        """put the layer back where it was before `_precompute` advanced it (stream-ordered device writes, no sync)"""
+        self._consumed(p)
+        p.layer.__dict__.pop(_READY, None)
+        if not p.training:
+            return                               # evaluation-mode hand-outs change no state
+        q, qc = p.layer.quantize, p.layer.quantize.callback
+        with torch.no_grad():
+            q.weight.data.view(-1).copy_(self._backup[p.slot:p.slot + 1])
+            q._steps.add(q._n_updates, -1)
+            qc.t -= 1
+            if p.t_dev is not None:
+                p.t_dev.sub_(1)
+                qc.__dict__["_t_dev_value"] = qc.t
+        q._quantized = p.was_quantized
+
+    def _rollback_all(self):
+        for p in list(self._pending):
+            self._rollback(p)
+
+    def _finish(self, module, args, output=None):
+        """forward hook of the root (also after a forward that raised): whatever was precomputed and not read is undone"""
+        if self._pending:
+            self._rollback_all()
 
     # ------------------------------------------------------------------------------------------
     def _precompute(self, module, args):
-        self._cache.clear()
+        if module is not self.model:             # a replica (nn.DataParallel) shares the hook but not the layers
+            return
+        if self._pending:                        # leftovers of a forward whose hook could not run
+            self._rollback_all()
+        if not get_option("batch_weights"):
+            return
         train, frozen = [], []          # layers that update statistics this step / that only quantize
         for layer in self.layers:
             q, w = layer.quantize, layer._parameters["weight"]
             dense = w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))
             if not (w.is_cuda and w.dtype == torch.float32 and dense and w.data_ptr() % 16 == 0):
                 continue                # (tensor-wise quantization does not care about the order of a dense tensor's elements)
+            if "_qs_batcher_base" not in type(layer).__dict__ or _hooked(q) or layer._forward_pre_hooks:
+                continue                # re-wrapped since (a further imitation); hooks that want to see the quantizer's calls;
+                                        # a pre-hook on the layer (code that runs between this precomputation and the read)
             if not q.initted:
-                q._lazy_init(w)
+                continue                # first read ever: the inline path creates the layer's state when (and if) it happens
             if not (q.weight.is_cuda and q._n_updates.is_cuda):
                 continue
             t = q._steps.read(q._n_updates)
@@ -136,6 +245,7 @@ class WeightBatcher:
         if self._amax is None or self._amax.device != dev or self._amax.shape[0] != n_all:
             self._amax = torch.zeros(n_all, _hip.AMAX_LINE_STRIDE, dtype=torch.float32, device=dev)   # one line per layer
             self._decimals = torch.zeros(n_all, dtype=torch.float32, device=dev)
+            self._backup = torch.zeros(n_all, dtype=torch.float32, device=dev)
         slot = {id(l): i for i, l in enumerate(self.layers)}
         weights = [l._parameters["weight"] for l in todo]
         # evaluation / serving: nothing changes between calls unless someone writes a parameter or a scale (both bump
@@ -146,9 +256,10 @@ class WeightBatcher:
                               tuple(w.stride())) for l, w in zip(todo, weights))
             if eval_key == self._eval_key:
                 for l, w, y in zip(todo, weights, self._eval_outs):
-                    self._hand_out(l, w, y, slot)
+                    self._hand_out(l, w, y, slot, None)
                 return
         self._eval_key = None
+        undo = {}
         with torch.no_grad():
             if train:
                 graph_safe = get_option("graph_safe")
@@ -157,14 +268,17 @@ class WeightBatcher:
                 scales = [l.quantize.weight.data for l in train]
                 decs = [self._decimals[slot[id(l)]:slot[id(l)] + 1] if isinstance(l.quantize.callback, DecimalQuantizer)
                         and not l.quantize.callback.use_float_scaler else None for l in train]
+                backups = [self._backup[slot[id(l)]:slot[id(l)] + 1] for l in train]
                 t_devs = [l.quantize.callback.device_t(dev) if graph_safe else None for l in train]
                 _hip.multi_absmax(len(train), _hip.ptr_array(tw), _hip.i64_array([w.numel() for w in tw]), _hip.ptr_array(amax), dev)
                 _hip.multi_scale_update(len(train), _hip.ptr_array(amax), _hip.ptr_array(scales), _hip.ptr_array(decs),
                                         _hip.i64_array([l.quantize.callback.t for l in train]), _hip.ptr_array(t_devs),
                                         (_hip.c_int * len(train))(*[l.quantize.bits for l in train]),
-                                        _hip.ptr_array([l.quantize._n_updates.data for l in train]), dev)
+                                        _hip.ptr_array([l.quantize._n_updates.data for l in train]), dev,
+                                        backup_ptrs=_hip.ptr_array(backups))
                 for l, t_dev in zip(train, t_devs):
                     q, qc = l.quantize, l.quantize.callback
+                    undo[id(l)] = _Pending(l, slot[id(l)], q._quantized, t_dev, l._parameters["weight"]._version, True)
                     qc._advance_t(t_dev, bumped_by_kernel=True)
                     q._quantized = True
                     q._steps.note_device_add(q._n_updates, 1)
@@ -191,11 +305,14 @@ class WeightBatcher:
         if eval_key is not None:
             self._eval_key, self._eval_outs = eval_key, outs
         for l, w, y in zip(todo, weights, outs):
-            self._hand_out(l, w, y, slot)
+            self._hand_out(l, w, y, slot, undo.get(id(l)))
 
-    def _hand_out(self, l, w, y, slot):
+    def _hand_out(self, l, w, y, slot, pending: Optional[_Pending]):
         q, qc = l.quantize, l.quantize.callback
         is_decimal = not qc.use_float_scaler
         step = self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data
-        self._cache[id(l)] = _PrecomputedSte.apply(w, y, step, is_decimal, q.bits, 1 if qc.flip_axis else 0,
-                                                   bool(qc.backward_passthrough))
+        if pending is None:
+            pending = _Pending(l, slot[id(l)], q._quantized, None, w._version, False)
+        self._pending.append(pending)
+        l.__dict__[_READY] = (_PrecomputedSte.apply(w, y, step, is_decimal, q.bits, 1 if qc.flip_axis else 0,
+                                                    bool(qc.backward_passthrough)), pending, self)

@@ -55,7 +55,7 @@ def convert(model: nn.Module, operator: Union[PruneLayer, QuantizeLayer], inplac
             excluded_weight_layer_indexes: Sequence[Tuple[Type[nn.Module], Sequence[int]]] = [],
             excluded_activation_layer_indexes: Sequence[Tuple[Type[nn.Module], Sequence[int]]] = [],
             include: Optional[Union[str, List[str]]] = None, exclude: Optional[Union[str, List[str]]] = None,
-            order: str = "post", fuse: bool = True) -> nn.Module:
+            order: str = "post", fuse: bool = True, batch_weights: Optional[bool] = None) -> nn.Module:
     """apply ``operator`` (a layer made by ``prune(...)`` or ``quantize(...)``) across ``model``.
 
     Args:
@@ -70,6 +70,9 @@ def convert(model: nn.Module, operator: Union[PruneLayer, QuantizeLayer], inplac
         include / exclude: substrings a module path must all contain / must not contain.
         order: ``"post"`` or ``"pre"``.
         fuse: (extension) run convert-built prune->quantize pairs through the fused GPU path.
+        batch_weights: (extension) evaluate the weight quantizers of the returned network with three multi-tensor launches
+            per forward instead of three per layer (``qsparse_amd/batch.py``; bit-identical, rolled back for layers a
+            forward does not reach).  Default: the ``batch_weights`` option (True).
     """
     assert isinstance(operator, (PruneLayer, QuantizeLayer)), "`operator` does not belong to (PruneLayer, QuantizeLayer)"
     assert order in ["pre", "post"], "`order` must be either 'pre' or 'post'"
@@ -183,4 +186,8 @@ def convert(model: nn.Module, operator: Union[PruneLayer, QuantizeLayer], inplac
     if fuse:
         from qsparse_amd.fused import fuse_prune_quantize_pairs
         fuse_prune_quantize_pairs(nn_module(model))
+    from qsparse_amd.batch import WeightBatcher
+    from qsparse_amd.util import get_option
+    if get_option("batch_weights") if batch_weights is None else batch_weights:
+        WeightBatcher.install(nn_module(model))        # (re-)installed after every conversion: the set of layers may have grown
     return model

@@ -172,7 +172,8 @@ int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* c
 }
 
 int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
-                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, qs_stream_t stream) {
+                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, float* const* backup,
+                          qs_stream_t stream) {
     if (n < 0 || (n > 0 && (!amax || !scale || !t || !bits))) return QS_ERR_ARG;
     for (int base = 0; base < n; base += kMultiMax) {
         MultiUpdate u{};
@@ -185,6 +186,7 @@ int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float*
             u.decimal[i] = decimal ? decimal[k] : nullptr;
             u.t_dev[i] = t_dev ? t_dev[k] : nullptr;
             u.bump[i] = bump ? bump[k] : nullptr;
+            u.backup[i] = backup ? backup[k] : nullptr;
             u.t[i] = (float)t[k];
             u.denom[i] = (float)((int64_t)1 << (bits[k] - 1));
         }

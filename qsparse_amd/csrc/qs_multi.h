@@ -21,9 +21,10 @@ struct MultiTensors {           // 48 * (8 + 8 + 8 + 8 + 4) + 8 = 1736 bytes of 
     int32_t n;
 };
 
-struct MultiUpdate {            // 48 * (8 + 8 + 8 + 8 + 8 + 4 + 4) + 8 = 2312 bytes
+struct MultiUpdate {            // 48 * (8 + 8 + 8 + 8 + 8 + 8 + 4 + 4) + 8 = 2696 bytes
     uint32_t* amax[kMultiMax];  // one-element abs-max accumulators (max-accumulated, zero between steps)
     float* scale[kMultiMax];
+    float* backup[kMultiMax];   // nullable: receives the scale this update replaces (for a caller that may have to undo it)
     float* decimal[kMultiMax];  // nullable: receives rint(log2(1/scale)) for the decimal quantizer
     int64_t* t_dev[kMultiMax];  // nullable: device-resident running-mean counter, read INSTEAD of t and incremented
     int32_t* bump[kMultiMax];   // nullable: the layer's step counter, incremented
@@ -74,7 +75,9 @@ static __global__ void multi_scale_update_kernel(MultiUpdate u) {
     float t = u.t[i];
     if (u.t_dev[i]) t = (float)*u.t_dev[i];
     const float nw = __uint_as_float(*u.amax[i]) / u.denom[i];                 // fp32 weights: no dtype rounding
-    const float s = (t == 0.0f) ? nw : (t * *u.scale[i] + nw) / (t + 1.0f);   // quantize.py:344-347
+    const float old = *u.scale[i];
+    if (u.backup[i]) *u.backup[i] = old;
+    const float s = (t == 0.0f) ? nw : (t * old + nw) / (t + 1.0f);           // quantize.py:344-347
     *u.scale[i] = s;
     *u.amax[i] = 0u;
     if (u.decimal[i]) {

@@ -169,6 +169,7 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
         results = []
         for batched in (False, True):
             torch.manual_seed(0)
+            qs.set_qsparse_options(batch_weights=batched)       # (convert installs the batcher when the option is on -- the default)
             base = resnet18(num_classes=10, cifar_stem=True, width=16)
             if quantizer == "scaler":
                 model = convert_pq(base, sparsity=0.5, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=2)
@@ -178,8 +179,9 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
             model = model.cuda().train()
             if channels_last:
                 model = model.to(memory_format=torch.channels_last)
+            wb = model.__dict__.get("_qs_weight_batcher")
+            assert (wb is not None) == batched
             if batched:
-                wb = qs.WeightBatcher(model)
                 assert len(wb.layers) >= 10
             opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
 
@@ -197,7 +199,7 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
                 assert step.captured
                 step.finish()
             if batched and channels_last:     # every layer took part, the 3x3 convolutions with their NHWC weights included
-                assert not wb._cache and all(l.quantize._quantized for l in wb.layers)
+                assert not wb._pending and all(l.quantize._quantized for l in wb.layers)
             model.eval()
             with torch.no_grad():
                 ev = model(data[0][0]).float().cpu()
@@ -221,7 +223,7 @@ def test_weight_batcher_is_bit_identical(graphed, quantizer, channels_last):
             assert torch.equal(sa[k], sb[k]), k
         assert torch.equal(ea, eb)
     finally:
-        qs.set_qsparse_options(graph_safe=False)
+        qs.set_qsparse_options(graph_safe=False, batch_weights=True)
 
 
 @pytest.mark.parametrize("kind", ["scaler_300_channels", "adaptive"])
