@@ -297,6 +297,61 @@ int qs_stats_pack(const void* stage, int sdt, const float* absmax, int64_t absma
 int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_out, float* absmax_out,
                      int64_t absmax_stride, qs_stream_t stream);
 
+/* ---- one activation site per call ------------------------------------------------------------------- */
+
+/* A convert-built activation site -- Sequential(Sequential(act, PruneLayer{dims={1}}), QuantizeLayer{tensor-wise
+ * ScalerQuantizer}), reference convert.py:214-218 -- runs, per training step, the launches
+ *     statistics (qs_mean_dim | qs_mean_dim_cl)  ->  qs_mean_last2  ->  qs_pq_select  ->  qs_quant_scaler_fwd
+ * and one launch backward.  Issued one by one from the host language each of them costs an FFI transition plus argument
+ * marshalling (20-30 us of Python each); these two entry points enqueue the whole sequence from ONE call.  They add no
+ * arithmetic: they call the entry points above with the arguments the plan describes, in that order, on `stream`.
+ *
+ * The plan names what does not change from step to step: the geometry of x as the kernels address it (NCHW-contiguous:
+ * layout 0, x = [N][C][H*W]; dense channels_last: layout 1, x = [N][H*W][C]), dtypes, the layer state (running
+ * magnitude, mask, running scale, step counters -- all device pointers, the objects PruneLayer / QuantizeLayer /
+ * MagnitudePruningCallback hold, reference sparse.py:58-122, quantize.py:327-349, 473-518) and the caller's workspaces
+ * (stage: C*H*W elements of xdt; amax_part: C*H*W floats, channels_last only; chan_absmax: C * absmax_stride floats,
+ * zero on entry and re-zeroed by the select).  The caller builds it once per site and input signature and rebuilds it
+ * when a pointer or a shape changes. */
+typedef struct qs_site_plan {
+    int64_t N, C, H, W;
+    int32_t layout;              /* 0: NCHW-contiguous, 1: channels_last (NHWC in memory) */
+    int32_t xdt, ydt;            /* input dtype; output dtype (QS_F32: the reference's promotion, or xdt) */
+    int32_t bits;                /* of the quantizer */
+    float* magnitude;            /* [C]  MagnitudePruningCallback.magnitude */
+    uint8_t* mask;               /* [C]  PruneLayer.mask */
+    float* scale;                /* [1]  QuantizeLayer.weight */
+    float* chan_absmax;          /* [C * absmax_stride] scratch accumulator */
+    int64_t absmax_stride;
+    void* stage;                 /* [C*H*W] xdt scratch: first-stage means */
+    float* amax_part;            /* [C*H*W] scratch (layout 1), NULL for layout 0 */
+    void* stage_mean;            /* [C] xdt scratch: the importance of this step */
+    int32_t* prune_n_updates;    /* nullable: PruneLayer._n_updates, incremented by the select */
+    int32_t* quant_n_updates;    /* nullable: QuantizeLayer._n_updates, incremented by the select */
+    int64_t* callback_t;         /* nullable: MagnitudePruningCallback.t, incremented by the select */
+    int64_t* quantizer_t_dev;    /* nullable: device copy of the quantizer callback's t (graph-safe mode): read instead of
+                                    t_q and incremented */
+    int32_t callback_t_from_device; /* != 0: the running-magnitude counter is read from *callback_t instead of t_mag */
+} qs_site_plan;
+
+/* flags of qs_site_fwd */
+#define QS_SITE_LIVE 1        /* training step with live statistics: magnitude and scale are updated (else: apply only) */
+#define QS_SITE_REFRESH 2     /* rebuild the mask from the running magnitude, threshold rank k */
+#define QS_SITE_PRE_RELU 4    /* x is the input of a folded nn.ReLU */
+#define QS_SITE_ELIDE 8       /* elide_masked of qs_quant_scaler_fwd */
+#define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
+
+/* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
+ * gate_out: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
+ * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116). */
+int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
+                int64_t t_q, qs_stream_t stream);
+
+/* gx = gate * clamp(g) * mask in xdt (qs_quant_ste_relu_bwd with the bitmap when `gate` is given, qs_quant_ste_bwd
+ * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there. */
+int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
+                float hi_mul, qs_stream_t stream);
+
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 
 /* The weight-side operators of a converted network (quantize(conv) / quantize(linear), reference quantize.py:559-571

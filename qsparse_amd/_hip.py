@@ -58,9 +58,25 @@ SIGNATURES = {
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
+    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P]),
+    "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
+
+
+
+class SitePlanStruct(ctypes.Structure):
+    """`qs_site_plan` of include/qsparse_hip.h, field for field"""
+    _fields_ = [("N", c_int64), ("C", c_int64), ("H", c_int64), ("W", c_int64),
+                ("layout", c_int32), ("xdt", c_int32), ("ydt", c_int32), ("bits", c_int32),
+                ("magnitude", c_void_p), ("mask", c_void_p), ("scale", c_void_p), ("chan_absmax", c_void_p),
+                ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
+                ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
+                ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32)]
+
+
+SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK = 1, 2, 4, 8, 16
 
 _lib = None
 
@@ -724,6 +740,30 @@ def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, 
                                  amax_stride(absmax_out), _stream(gathered))
     _check(st, "qs_stats_combine")
     return stage
+
+
+# ----------------------------------------------------------------------------------------------
+# one activation site per call (qs_site_fwd / qs_site_bwd: the launches above in sequence, one FFI transition)
+# ----------------------------------------------------------------------------------------------
+def logging_events() -> bool:
+    """an event log is being recorded: callers keep to the fine-grained entry points so that every launch is bracketed"""
+    return _event_log is not None
+
+
+def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,
+             t_q: int):
+    st = load().qs_site_fwd(plan_ref, x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), flags,
+                            t_mag, k, t_q, _stream(x))
+    if st:
+        _check(st, "qs_site_fwd")
+
+
+def site_bwd(plan_ref, g: torch.Tensor, gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
+             hi_mul: float):
+    st = load().qs_site_bwd(plan_ref, g.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), gx.data_ptr(),
+                            _DT[g.dtype], flags, lo_mul, hi_mul, _stream(g))
+    if st:
+        _check(st, "qs_site_bwd")
 
 
 # ----------------------------------------------------------------------------------------------

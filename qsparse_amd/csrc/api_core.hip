@@ -146,6 +146,57 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
     return launch_status();
 }
 
+// ---- one activation site per call: the fine-grained entry points in sequence (no arithmetic of its own) --------------
+int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
+                int64_t t_q, qs_stream_t stream) {
+    if (!p || !x || !y || p->N < 1 || p->C < 2 || p->H < 1 || p->W < 1 || (p->layout != 0 && p->layout != 1)) return QS_ERR_ARG;
+    if (!p->mask || !p->scale) return QS_ERR_ARG;
+    const int64_t hw = p->H * p->W;
+    const int pre_relu = (flags & QS_SITE_PRE_RELU) ? 1 : 0;
+    if (flags & QS_SITE_LIVE) {
+        if (!p->magnitude || !p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
+        if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
+        const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_RELU : 0);
+        int st;
+        if (p->layout == 0) {
+            st = qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride,
+                             hw, p->C, stream);
+            if (st) return st;
+            st = qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, nullptr, nullptr, 1, nullptr, stream);
+        } else {
+            if (!p->amax_part) return QS_ERR_ARG;
+            st = qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, p->amax_part, stream);
+            if (st) return st;
+            st = qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, p->amax_part, p->chan_absmax,
+                               p->absmax_stride, nullptr, stream);
+        }
+        if (st) return st;
+        st = qs_pq_select(p->magnitude, p->stage_mean, p->xdt, p->C, 1, t_mag, (flags & QS_SITE_REFRESH) ? 1 : 0, k, p->mask,
+                          p->chan_absmax, p->absmax_stride, 1, t_q, p->bits, p->scale, p->prune_n_updates, p->quant_n_updates,
+                          p->callback_t, p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr,
+                          p->quantizer_t_dev, p->xdt, nullptr, 1, stream);
+        if (st) return st;
+    }
+    const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
+    const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
+    return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, cm ? outer : 1, cm ? p->C : 1, cm ? inner : outer * p->C * inner,
+                               p->xdt, p->ydt, QS_F32, 0, 0, 0, pre_relu, (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, stream);
+}
+
+int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
+                float hi_mul, qs_stream_t stream) {
+    if (!p || !g || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1) return QS_ERR_ARG;
+    const int64_t hw = p->H * p->W;
+    const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
+    const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
+    const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
+    const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
+    if (gate)
+        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt, elide,
+                                     stream);
+    return qs_quant_ste_bwd(g, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
+}
+
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
 int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream) {
     if (n < 0 || (n > 0 && (!x || !numel || !amax))) return QS_ERR_ARG;

@@ -112,6 +112,108 @@ class _FusedApply(torch.autograd.Function):
         return (gx,) + (None,) * 7
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# one FFI call per site and direction (qs_site_fwd / qs_site_bwd, include/qsparse_hip.h): the launches of a live training
+# step -- statistics, last two stages, select, apply -- enqueued from ONE ctypes call with a cached plan instead of four
+# calls with their argument marshalling (the fine-grained entry points stay the per-call-site binding of INTEGRATION.md)
+# ----------------------------------------------------------------------------------------------------------------------
+class _SitePlan:
+    """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
+    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt")
+
+
+def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
+    """the cached plan of this site for inputs like `h`, or None when the site is not one the composite call covers
+    (4-d NCHW / channels_last activation with a batch of at least two, tensor-wise ScalerQuantizer, state on h's device)"""
+    cb, qc = p.callback, q.callback
+    if h.dim() != 4 or h.shape[0] < 2 or type(qc) is not ScalerQuantizer or not hasattr(cb, "magnitude"):
+        return None
+    N, C, H, W = h.shape
+    if H < 2 or W < 2:
+        return None                      # (an extent of 1 is not reduced -- and turns its neighbour into an inner reduction)
+    cl = not h.is_contiguous()
+    if cl and not h.is_contiguous(memory_format=torch.channels_last):
+        return None
+    if h.data_ptr() % 16 or (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES:
+        return None
+    if cl and C % 8:
+        return None                      # (any channel count works through the fine-grained path's generic kernel)
+    state = (cb.magnitude, p.mask, q.weight, p._n_updates, q._n_updates, cb.t)
+    if any((not t.is_cuda) or t.device != h.device for t in state):
+        return None
+    if p.mask.numel() != C or cb.magnitude.numel() != C or q.weight.numel() != 1:
+        return None                      # (a channel count that does not match the mask raises on the fine-grained route)
+    graph_safe = bool(get_option("graph_safe"))
+    t_q_dev = qc.device_t(h.device) if graph_safe else None
+    out_dtype = _out_dtype(h)
+    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits) + tuple(t.data_ptr() for t in state) + \
+        ((t_q_dev.data_ptr(),) if t_q_dev is not None else ())
+    plan = q.__dict__.get("_qs_site_plan")
+    if plan is not None and plan.key == key:
+        return plan
+    plan = _SitePlan()
+    plan.key, plan.out_dtype, plan.channels_last, plan.xdt = key, out_dtype, cl, h.dtype
+    acc = _absmax_accumulator(q, C, h.device)
+    stage = torch.empty(C * H * W, dtype=h.dtype, device=h.device)
+    part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
+    stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
+    plan.keep = (acc, stage, part, stage_mean, t_q_dev) + state
+    c = _hip.SitePlanStruct()
+    c.N, c.C, c.H, c.W = N, C, H, W
+    c.layout, c.xdt, c.ydt, c.bits = int(cl), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
+    c.magnitude, c.mask, c.scale = cb.magnitude.data_ptr(), p.mask.data_ptr(), q.weight.data_ptr()
+    c.chan_absmax, c.absmax_stride = acc.data_ptr(), _hip.amax_stride(acc)
+    c.stage, c.amax_part, c.stage_mean = stage.data_ptr(), (part.data_ptr() if cl else None), stage_mean.data_ptr()
+    c.prune_n_updates, c.quant_n_updates, c.callback_t = p._n_updates.data_ptr(), q._n_updates.data_ptr(), cb.t.data_ptr()
+    c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
+    c.callback_t_from_device = int(graph_safe)
+    import ctypes
+    plan.c, plan.ref = c, ctypes.byref(c)
+    q.__dict__["_qs_site_plan"] = plan
+    return plan
+
+
+class _SiteStep(torch.autograd.Function):
+    """the whole site through qs_site_fwd / qs_site_bwd; same results as the statistics + select + `_FusedApply` route"""
+
+    @staticmethod
+    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale):
+        want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
+        y = torch.empty_like(h, dtype=plan.out_dtype)
+        bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if want_gate else None
+        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q)
+        ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
+        ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
+        keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
+        ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
+                              bits_t if want_gate else (h if keep_x else h.new_empty(0)))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, flags = ctx.plan, ctx.flags
+        mask_c, scale, third = ctx.saved_tensors
+        limit = 2.0 ** (ctx.bits - 1)
+        lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
+        pre_relu = bool(flags & _hip.SITE_PRE_RELU)
+        fmt = torch.channels_last if plan.channels_last else torch.contiguous_format
+        fast = (g.is_contiguous(memory_format=fmt) and g.data_ptr() % 16 == 0 and tuple(g.shape) == tuple(ctx.x_shape)
+                and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype) and not _hip.logging_events())
+        if fast:
+            gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g.device, memory_format=fmt)
+            bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
+            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul)
+            return (gx,) + (None,) * 9
+        mask = mask_c if mask_c.numel() else None
+        if pre_relu:
+            gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, False, lo_mul, hi_mul, mask, gate=gate)
+        else:
+            out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
+            gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
+        return (gx,) + (None,) * 9
+
+
 def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
     """one training / evaluation step of ``q(p(h))`` on a GPU tensor -- or of ``q(p(relu(h)))`` with ``pre_relu``
     (the caller guarantees that the quantizer is active this step, so the ReLU is applied inside the kernels)."""
@@ -162,11 +264,22 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     q_counts = q.timeout > 0 and q.training
     bump_p = bump_q = bump_t = None
     select_bumped_tq = False
+    # one FFI call for the whole site (qs_site_fwd) when this is a live steady-state step -- magnitude, mask policy and
+    # scale all updated from this input -- or a pure apply step (evaluation, frozen statistics) of a plain 4-d site
+    site = None
+    live = update_mag and update_scale and prune_on and p_counts and q_counts and n >= p.start
+    idle = not (update_mag or refresh or update_scale) and quant_on
+    world = qdist.stats_world_size()
+    if (live or idle) and not qdist.exchange_active(world) and not _hip.logging_events():
+        site = _site_plan(p, q, h)
     with torch.no_grad():
         hd = h.detach()
         stage = chan_absmax = record = None
-        world = qdist.stats_world_size()
-        if update_scale and not prune_on:
+        if site is not None:
+            if live:        # the counters ride in the select launch, as on the fine-grained route
+                bump_p, bump_q, bump_t = p._n_updates.data, q._n_updates.data, cb.t.data
+                select_bumped_tq = bool(get_option("graph_safe"))
+        elif update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)
             _hip.scale_update(am, q.weight.data.view(-1), t_q, q.bits,
@@ -246,6 +359,11 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     if pre_relu and not quant_on:      # cannot happen when the caller checked q.is_active(); stay correct anyway
         h, pre_relu = torch.relu(h), False
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
+    if site is not None:
+        flags = ((_hip.SITE_LIVE if live else 0) | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
+                 | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0) | (0 if prune_on else _hip.SITE_NO_MASK))
+        return _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
+                               p.mask.data.view(-1) if prune_on else None, q.weight.data)
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
                              1 if qc.flip_axis else 0, quant_on, pre_relu)
 
