@@ -32,6 +32,12 @@ def steady_state(model: nn.Module) -> bool:
     """True when another training step takes exactly the same host-side decisions as the last one."""
     if not get_option("graph_safe"):
         return False
+    from qsparse_amd import distributed as qdist
+    if qdist.exchange_active():
+        # a live statistics exchange puts an RCCL collective inside every site's step; capturing one into a hipGraph
+        # crashes on this stack (torch 2.10 + ROCm 7.2, one-rank group: SIGSEGV during capture,
+        # tests/test_distributed.py) -- data-parallel steps therefore always run eagerly
+        return False
     for m in model.modules():
         if isinstance(m, PruneLayer):
             if not m.initted:

@@ -297,3 +297,132 @@ def test_converted_resnet18_under_ddp_on_four_ranks_with_unequal_shards():
         kept = ref_state[k].mean()
         assert 0.4 <= kept <= 0.75, (k, kept)
     assert all(c[0] == 8 for c in ref_counters.values())
+
+
+# ---- one-rank RCCL: what can be pinned about the N > 1 path without a multi-GPU node ---------------------------------
+_RCCL_GRAPH_AND_COUNTER = r'''
+import os, sys, json
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+import torch, torch.nn as nn, torch.distributed as dist
+import qsparse_amd as qs
+from qsparse_amd import graphs
+from qsparse_amd.fused import fuse_prune_quantize_pairs
+torch.cuda.set_device(0)
+qs.set_qsparse_options(log_on_created=False, log_during_train=False, graph_safe=True)
+
+def make():
+    pair = nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                         qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train()
+    return fuse_prune_quantize_pairs(pair)
+
+def data(i):
+    g = torch.Generator().manual_seed(700 + i)
+    return ((torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().cuda(),
+            torch.randn(8, 16, 8, 8, generator=g).cuda())
+
+captured = []
+
+def run(replay):
+    pair = make()
+    sx, sg = data(0)
+    sx.requires_grad_(True)
+    outs = []
+    def step():
+        y = pair(sx)
+        (gx,) = torch.autograd.grad(y, sx, sg)
+        return y, gx
+    for i in range(4):
+        x, g = data(i)
+        sx.data.copy_(x); sg.copy_(g)
+        y, gx = step()
+        outs.append((y.detach().clone(), gx.clone()))
+    def step_fn(x, g):
+        x = x.detach().requires_grad_(True)
+        y = pair(x)
+        (gx,) = torch.autograd.grad(y, x, g)
+        return y, gx
+    gstep = graphs.GraphedStep(pair, step_fn, settle=0) if replay else None
+    for i in range(4, 8):
+        x, g = data(i)
+        if replay:
+            y, gx = gstep(x, g)
+        else:
+            sx.data.copy_(x); sg.copy_(g)
+            y, gx = step()
+        outs.append((y.detach().clone(), gx.clone()))
+    if replay:
+        captured.append(gstep.captured)
+    torch.cuda.synchronize()
+    graphs.resync_host_state(pair)
+    state = [pair[0][1].mask.clone(), pair[0][1].callback.magnitude.clone(), pair[1].weight.clone(),
+             pair[0][1]._n_updates.clone(), pair[1]._n_updates.clone(), pair[0][1].callback.t.clone()]
+    return outs, state
+
+def mark(m):
+    print("MARK", m, file=sys.stderr, flush=True)
+
+plain = run(False)                                   # no process group, eager: the single-process truth
+plain_graph = run(True)                              # without an exchange GraphedStep does capture -- and equals eager
+assert captured[-1] is True
+for (ya, ga), (yb, gb) in zip(plain_graph[0], plain[0]):
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+mark("plain done")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+qs.set_qsparse_options(sync_statistics="always")     # the exchange really runs: pack -> all_gather_into_tensor (RCCL) -> combining select
+eager_x = run(False)
+mark("eager with exchange done")
+graph_x = run(True)                                  # GraphedStep with the exchange live: must NOT capture (see graphs.steady_state)
+mark("graphed-step with exchange done")
+res = {"captured_with_live_exchange": captured[-1]}
+for (oa, sa), tag in ((eager_x, "eager"), (graph_x, "graph")):
+    for (ya, ga), (yb, gb) in zip(oa, plain[0]):
+        assert torch.equal(ya, yb) and torch.equal(ga, gb), tag
+    for a, b in zip(sa, plain[1]):
+        assert torch.equal(a, b), tag
+
+# a counter written by a COLLECTIVE (raw-pointer write into the parameter's storage)
+qs.set_qsparse_options(graph_safe=False)
+layer = qs.quantize(bits=8, channelwise=-1, timeout=5).cuda().train()
+x = torch.randn(4, 8, 6, 6).cuda()
+for _ in range(2):
+    layer(x)                                          # n_updates = 2 < timeout: identity
+mark("comparisons done")
+v0 = layer._n_updates._version
+dist.all_gather_into_tensor(layer._n_updates.data, torch.full((1,), 9, dtype=torch.int32, device="cuda"))
+torch.cuda.synchronize()
+res["collective_bumped_version"] = bool(layer._n_updates._version != v0)
+y = layer(x)
+res["seen_without_resync"] = bool(not torch.equal(y, x))          # quantizes iff the host mirror noticed n_updates = 9 >= 5
+qs.resync_host_state(layer)
+y = layer(x)
+res["seen_after_resync"] = bool(not torch.equal(y, x))
+res["n_updates_after"] = int(layer._n_updates.item())
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_graph_capture_with_live_exchange_and_collective_counter_writes():
+    """(i) a graph-safe fused step with the statistics exchange LIVE -- pack, RCCL all_gather_into_tensor, combining
+    select -- equals the run without a process group, bit for bit, eagerly AND through `GraphedStep`, which refuses to
+    capture while an exchange is live (an RCCL collective inside a hipGraph capture is a SIGSEGV on this stack: found by
+    this very test; `graphs.steady_state` is False for data-parallel steps); (ii) a step counter written by a collective (`dist.all_gather_into_tensor(layer._n_updates.data, ...)`, what
+    re-syncing ranks does): the documented contract is that `resync_host_state` makes the host mirror see it -- pinned
+    here together with what happens without it (the mirror notices exactly when the write bumped the version counter)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_GRAPH_AND_COUNTER], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    print(res)
+    assert res["captured_with_live_exchange"] is False
+    assert res["seen_after_resync"] is True                      # the documented route always works
+    assert res["seen_without_resync"] == res["collective_bumped_version"], res
+    assert res["n_updates_after"] >= 10, res
