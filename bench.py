@@ -183,7 +183,7 @@ def config2(device, steps=200, nbuf=4):
 # them move (every data operand once, in the dtype and layout the site really saw -- qsparse_amd/_hip.py `_timed`); the
 # C-sized launches (running means, selects, scale updates) are latency and carry none
 FAMILIES = (("apply_fwd", ("quant_scaler_fwd", "quant_decimal_fwd", "quant_line_fwd", "multi_quant_fwd")),
-            ("apply_bwd", ("quant_ste_bwd", "quant_ste_relu_bwd")),
+            ("apply_bwd", ("quant_ste_bwd", "quant_ste_relu_bwd", "multi_ste_bwd")),
             ("mask_apply", ("mask_apply",)),
             ("statistics", ("mean_dim", "mean_last2", "absmax", "minmax", "l0_flag", "multi_absmax", "kth_value", "mask_ge")))
 

@@ -375,6 +375,11 @@ int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float*
                           qs_stream_t stream);
 int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
                        int decimal, qs_stream_t stream);
+/*   qs_multi_ste_bwd:       gx[i] = clamp(g[i], lo_mul[i] * s_i, hi_mul[i] * s_i) with s_i = step[i][0] (or 2^-step[i][0]
+ *                           with step_is_decimal): qs_quant_ste_bwd's arithmetic (quantize.py:66-77, 120-131) for the
+ *                           gradients of a GROUP of weight quantizers that are handed over together */
+int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
+                     const float* lo_mul, const float* hi_mul, int step_is_decimal, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
+    "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -788,8 +789,8 @@ def _device_stream(device):
     return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
 
 
-def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device):
-    with _timed("multi_absmax", 4 * sum(numels)):
+def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device, nbytes: int = 0):
+    with _timed("multi_absmax", int(nbytes)):
         st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
     _check(st, "qs_multi_absmax")
 
@@ -801,7 +802,17 @@ def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_pt
     _check(st, "qs_multi_scale_update")
 
 
-def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device):
-    with _timed("multi_quant_fwd", 8 * sum(numels)):
+def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device, nbytes: int = 0):
+    with _timed("multi_quant_fwd", int(nbytes)):
         st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
     _check(st, "qs_multi_quant_fwd")
+
+
+def f32_array(values):
+    return (c_float * len(values))(*[float(v) for v in values])
+
+
+def multi_ste_bwd(n: int, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, decimal: bool, device, nbytes: int = 0):
+    with _timed("multi_ste_bwd", int(nbytes)):
+        st = load().qs_multi_ste_bwd(n, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, int(bool(decimal)), _device_stream(device))
+    _check(st, "qs_multi_ste_bwd")

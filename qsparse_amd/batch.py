@@ -44,23 +44,52 @@ _READY = "_qs_ready_weight"        # layer.__dict__ key of a precomputed weight 
 _ATTR = "_qs_weight_batcher"       # root.__dict__ key of the installed batcher
 
 
-class _PrecomputedSte(torch.autograd.Function):
-    """hands out a quantized weight computed by the batched kernels; backward = the quantizer's STE clamp."""
+_GROUP = 8      # layers per hand-out node: their weight gradients are clamped together, by ONE launch, when the group's
+                # earliest layer has finished its backward (small groups keep DDP's bucketed all-reduce overlapping)
+
+
+class _GroupSte(torch.autograd.Function):
+    """hands out the precomputed quantized weights of a GROUP of consecutive layers through one autograd node whose
+    backward applies the quantizers' STE clamp (reference quantize.py:66-77, 120-131) to all of their gradients with one
+    multi-tensor launch (qs_multi_ste_bwd) -- instead of one node, one Python backward and one 4 us launch per layer."""
 
     @staticmethod
-    def forward(ctx, w, y, step, is_decimal, bits, notch, passthrough):
-        ctx.is_decimal, ctx.bits, ctx.notch, ctx.passthrough = is_decimal, bits, notch, passthrough
-        ctx.save_for_backward(step)
-        return y.view_as(y)
+    def forward(ctx, meta, *tensors):
+        k = len(meta)
+        ctx.meta = meta                                     # per layer: (is_decimal, lo_mul, hi_mul, passthrough)
+        ctx.save_for_backward(*tensors[2 * k:])             # the steps (scale or decimal, one element each)
+        return tuple(y.view_as(y) for y in tensors[k:2 * k])
 
     @staticmethod
-    def backward(ctx, g):
-        if ctx.passthrough:
-            return g, None, None, None, None, None, None
-        (step,) = ctx.saved_tensors
-        limit = 2.0 ** (ctx.bits - 1)
-        gx = _hip.ste_bwd(g, step, ctx.is_decimal, -1, -limit + ctx.notch, limit - 1 + ctx.notch, False, torch.float32)
-        return gx, None, None, None, None, None, None
+    def backward(ctx, *grads):
+        meta, steps = ctx.meta, ctx.saved_tensors
+        k = len(meta)
+        out = [None] * k
+        for decimal in (False, True):
+            idx = [i for i in range(k) if grads[i] is not None and ctx.needs_input_grad[1 + i] and meta[i][0] == decimal
+                   and not meta[i][3]]
+            fast = [i for i in idx if grads[i].dtype == torch.float32 and grads[i].data_ptr() % 16 == 0
+                    and (grads[i].is_contiguous() or (grads[i].dim() == 4 and grads[i].is_contiguous(memory_format=torch.channels_last)))]
+            for i in idx:
+                if i not in fast:                           # odd layouts / dtypes: the per-layer entry point
+                    out[i] = _hip.ste_bwd(grads[i], steps[i], decimal, -1, meta[i][1], meta[i][2], False, torch.float32)
+            if fast:
+                gs = [grads[i] for i in fast]
+                flat = torch.empty(sum((g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for g in gs), dtype=torch.float32, device=gs[0].device)
+                outs, off = [], 0
+                for g in gs:
+                    outs.append(flat.as_strided(g.shape, g.stride(), flat.storage_offset() + off))     # the gradient's own (dense) layout
+                    off += (g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                numels = [g.numel() for g in gs]
+                _hip.multi_ste_bwd(len(fast), _hip.ptr_array(gs), _hip.ptr_array(outs), _hip.ptr_array([steps[i] for i in fast]),
+                                   _hip.i64_array(numels), _hip.f32_array([meta[i][1] for i in fast]),
+                                   _hip.f32_array([meta[i][2] for i in fast]), decimal, gs[0].device, nbytes=8 * sum(numels))
+                for i, o in zip(fast, outs):
+                    out[i] = o
+        for i in range(k):
+            if out[i] is None and grads[i] is not None and meta[i][3]:
+                out[i] = grads[i]                           # backward_passthrough
+        return (None,) + tuple(out) + (None,) * (2 * k)
 
 
 def _imitation_depth(layer: nn.Module) -> int:
@@ -90,6 +119,16 @@ def _hooked(q: QuantizeLayer) -> bool:
     if _m._global_forward_hooks or _m._global_forward_pre_hooks:
         return True
     return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (q, q.callback))
+
+
+class _LaunchPlan(dict):
+    """cached pointer arrays of the three launches (ctypes objects): never copied or pickled with the network"""
+
+    def __deepcopy__(self, memo):
+        return _LaunchPlan()
+
+    def __reduce__(self):
+        return (_LaunchPlan, ())
 
 
 class _Pending:
@@ -136,6 +175,7 @@ class WeightBatcher:
         self._backup = None
         self._eval_key = None
         self._eval_outs = None
+        self._plan = None
         for layer in self.layers:
             if "_qs_batcher_base" not in type(layer).__dict__:
                 layer.__class__ = _patched_class(type(layer))
@@ -255,27 +295,53 @@ class WeightBatcher:
             eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
                               tuple(w.stride())) for l, w in zip(todo, weights))
             if eval_key == self._eval_key:
-                for l, w, y in zip(todo, weights, self._eval_outs):
-                    self._hand_out(l, w, y, slot, None)
+                self._hand_out(todo, weights, self._eval_outs, slot, {})
                 return
         self._eval_key = None
         undo = {}
         with torch.no_grad():
+            # everything that does not change from step to step -- the pointer arrays of the three launches, the layout of
+            # the flat output buffer -- is built once per (set of layers, parameter storage) and reused
+            key = (len(train), get_option("graph_safe")) + tuple((id(l), w.data_ptr(), w.numel(), l.quantize.weight.data_ptr(),
+                                                                   l.quantize._n_updates.data_ptr()) for l, w in zip(todo, weights))
+            plan = self._plan if self._plan is not None and self._plan.get("key") == key else None
+            if plan is None:
+                offsets, total = [], 0
+                for w in weights:
+                    offsets.append(total)
+                    total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                plan = _LaunchPlan(key=key, offsets=offsets, total=total, numels=[w.numel() for w in weights], keep=[])
+                if train:
+                    amax = [self._amax[slot[id(l)]] for l in train]
+                    decs = [self._decimals[slot[id(l)]:slot[id(l)] + 1] if not l.quantize.callback.use_float_scaler else None
+                            for l in train]
+                    backups = [self._backup[slot[id(l)]:slot[id(l)] + 1] for l in train]
+                    plan["keep"] += amax + decs + backups
+                    plan.update(w_ptrs=_hip.ptr_array(weights[:len(train)]), w_numels=_hip.i64_array(plan["numels"][:len(train)]),
+                                amax_ptrs=_hip.ptr_array(amax), scale_ptrs=_hip.ptr_array([l.quantize.weight.data for l in train]),
+                                dec_ptrs=_hip.ptr_array(decs), backup_ptrs=_hip.ptr_array(backups),
+                                bits=(_hip.c_int * len(train))(*[l.quantize.bits for l in train]),
+                                bump_ptrs=_hip.ptr_array([l.quantize._n_updates.data for l in train]),
+                                w_bytes=4 * sum(plan["numels"][:len(train)]))
+                groups = []
+                for decimal in (False, True):
+                    idx = [i for i, l in enumerate(todo) if (not l.quantize.callback.use_float_scaler) == decimal]
+                    if idx:
+                        params = [self._decimals[slot[id(todo[i])]:slot[id(todo[i])] + 1] if decimal else todo[i].quantize.weight.data
+                                  for i in idx]
+                        plan["keep"] += params
+                        groups.append((decimal, idx, _hip.ptr_array([weights[i] for i in idx]), _hip.ptr_array(params),
+                                       _hip.i64_array([plan["numels"][i] for i in idx]), 8 * sum(plan["numels"][i] for i in idx)))
+                plan["groups"] = groups
+                self._plan = plan
             if train:
                 graph_safe = get_option("graph_safe")
-                tw = [l._parameters["weight"] for l in train]
-                amax = [self._amax[slot[id(l)]] for l in train]
-                scales = [l.quantize.weight.data for l in train]
-                decs = [self._decimals[slot[id(l)]:slot[id(l)] + 1] if isinstance(l.quantize.callback, DecimalQuantizer)
-                        and not l.quantize.callback.use_float_scaler else None for l in train]
-                backups = [self._backup[slot[id(l)]:slot[id(l)] + 1] for l in train]
                 t_devs = [l.quantize.callback.device_t(dev) if graph_safe else None for l in train]
-                _hip.multi_absmax(len(train), _hip.ptr_array(tw), _hip.i64_array([w.numel() for w in tw]), _hip.ptr_array(amax), dev)
-                _hip.multi_scale_update(len(train), _hip.ptr_array(amax), _hip.ptr_array(scales), _hip.ptr_array(decs),
-                                        _hip.i64_array([l.quantize.callback.t for l in train]), _hip.ptr_array(t_devs),
-                                        (_hip.c_int * len(train))(*[l.quantize.bits for l in train]),
-                                        _hip.ptr_array([l.quantize._n_updates.data for l in train]), dev,
-                                        backup_ptrs=_hip.ptr_array(backups))
+                _hip.multi_absmax(len(train), plan["w_ptrs"], plan["w_numels"], plan["amax_ptrs"], dev, nbytes=plan["w_bytes"])
+                _hip.multi_scale_update(len(train), plan["amax_ptrs"], plan["scale_ptrs"], plan["dec_ptrs"],
+                                        _hip.i64_array([l.quantize.callback.t for l in train]),
+                                        _hip.ptr_array(t_devs) if graph_safe else None, plan["bits"], plan["bump_ptrs"], dev,
+                                        backup_ptrs=plan["backup_ptrs"])
                 for l, t_dev in zip(train, t_devs):
                     q, qc = l.quantize, l.quantize.callback
                     undo[id(l)] = _Pending(l, slot[id(l)], q._quantized, t_dev, l._parameters["weight"]._version, True)
@@ -287,32 +353,34 @@ class WeightBatcher:
                     qc = l.quantize.callback
                     if not qc.use_float_scaler:
                         self._decimals[slot[id(l)]:slot[id(l)] + 1] = _hip.decimal_from_scale(l.quantize.weight.data.view(-1))
-            offsets, total = [], 0
-            for w in weights:
-                offsets.append(total)
-                total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-            flat = torch.empty(total, dtype=torch.float32, device=dev)
-            outs = [flat[o:o + w.numel()].as_strided(w.shape, w.stride()) for o, w in zip(offsets, weights)]   # w's own layout
-            numels = [w.numel() for w in weights]
-            for decimal in (False, True):
-                idx = [i for i, l in enumerate(todo) if (not l.quantize.callback.use_float_scaler) == decimal]
-                if not idx:
-                    continue
-                params = [self._decimals[slot[id(todo[i])]:slot[id(todo[i])] + 1] if decimal else todo[i].quantize.weight.data
-                          for i in idx]
-                _hip.multi_quant_fwd(len(idx), _hip.ptr_array([weights[i] for i in idx]), _hip.ptr_array([outs[i] for i in idx]),
-                                     _hip.ptr_array(params), _hip.i64_array([numels[i] for i in idx]), decimal, dev)
+            flat = torch.empty(plan["total"], dtype=torch.float32, device=dev)
+            base = flat.data_ptr()
+            so = flat.storage_offset()
+            outs = [flat.as_strided(w.shape, w.stride(), so + o) for o, w in zip(plan["offsets"], weights)]   # w's own layout
+            for decimal, idx, x_ptrs, param_ptrs, numels, nbytes in plan["groups"]:
+                y_ptrs = (_hip.ctypes.c_void_p * len(idx))(*[base + 4 * plan["offsets"][i] for i in idx])
+                _hip.multi_quant_fwd(len(idx), x_ptrs, y_ptrs, param_ptrs, numels, decimal, dev, nbytes=nbytes)
         if eval_key is not None:
             self._eval_key, self._eval_outs = eval_key, outs
-        for l, w, y in zip(todo, weights, outs):
-            self._hand_out(l, w, y, slot, undo.get(id(l)))
+        self._hand_out(todo, weights, outs, slot, undo)
 
-    def _hand_out(self, l, w, y, slot, pending: Optional[_Pending]):
-        q, qc = l.quantize, l.quantize.callback
-        is_decimal = not qc.use_float_scaler
-        step = self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data
-        if pending is None:
-            pending = _Pending(l, slot[id(l)], q._quantized, None, w._version, False)
-        self._pending.append(pending)
-        l.__dict__[_READY] = (_PrecomputedSte.apply(w, y, step, is_decimal, q.bits, 1 if qc.flip_axis else 0,
-                                                    bool(qc.backward_passthrough)), pending, self)
+    def _hand_out(self, todo, weights, outs, slot, undo):
+        """park every layer's quantized weight on the layer, `_GROUP` consecutive layers per autograd node (a node per layer
+        in evaluation mode under no_grad costs nothing either way)"""
+        for base in range(0, len(todo), _GROUP):
+            group = todo[base:base + _GROUP]
+            meta, steps = [], []
+            for l in group:
+                q, qc = l.quantize, l.quantize.callback
+                is_decimal = not qc.use_float_scaler
+                limit = 2.0 ** (q.bits - 1)
+                notch = 1 if qc.flip_axis else 0
+                meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough)))
+                steps.append(self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data)
+            ys = _GroupSte.apply(tuple(meta), *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
+            for l, w, y in zip(group, weights[base:base + _GROUP], ys):
+                pending = undo.get(id(l))
+                if pending is None:
+                    pending = _Pending(l, slot[id(l)], l.quantize._quantized, None, w._version, False)
+                self._pending.append(pending)
+                l.__dict__[_READY] = (y, pending, self)

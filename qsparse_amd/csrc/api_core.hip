@@ -274,4 +274,34 @@ int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* con
     return launch_status();
 }
 
+int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
+                     const float* lo_mul, const float* hi_mul, int step_is_decimal, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!g || !gx || !step || !numel || !lo_mul || !hi_mul))) return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiMax) {
+        MultiSte a{};
+        a.n = std::min(kMultiMax, n - base);
+        int64_t blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int k = base + i;
+            if (!g[k] || !gx[k] || !step[k] || numel[k] < 0) return QS_ERR_ARG;
+            if (!aligned16(g[k]) || !aligned16(gx[k])) return QS_ERR_ALIGN;
+            a.g[i] = g[k];
+            a.gx[i] = gx[k];
+            a.step[i] = step[k];
+            a.numel[i] = numel[k];
+            a.lo_mul[i] = lo_mul[k];
+            a.hi_mul[i] = hi_mul[k];
+            a.block0[i] = (int32_t)blocks;
+            blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
+            if (blocks > 0x7fffffff) return QS_ERR_ARG;
+        }
+        a.block0[a.n] = (int32_t)blocks;
+        if (step_is_decimal)
+            hipLaunchKernelGGL((multi_ste_kernel<true>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((multi_ste_kernel<false>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+    }
+    return launch_status();
+}
+
 }  // extern "C"

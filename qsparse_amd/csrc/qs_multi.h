@@ -127,4 +127,38 @@ __global__ __launch_bounds__(kBlock) void multi_quant_kernel(MultiTensors a) {
     }
 }
 
+// gx = clamp(g, lo_mul * s, hi_mul * s) for every tensor (SteBwdOp's arithmetic, reference quantize.py:66-77, 120-131): the
+// STE backward of MANY weight quantizers in one launch -- gradients of a group of layers handed over together
+struct MultiSte {               // 48 * (8 + 8 + 8 + 8 + 4 + 4 + 4) + 8 = 2120 bytes
+    const float* g[kMultiMax];
+    float* gx[kMultiMax];
+    const float* step[kMultiMax];   // one-element scale, or decimal with DECIMAL
+    int64_t numel[kMultiMax];
+    int32_t block0[kMultiMax + 1];
+    float lo_mul[kMultiMax];
+    float hi_mul[kMultiMax];
+    int32_t n;
+};
+
+template <bool DECIMAL>
+__global__ __launch_bounds__(kBlock) void multi_ste_kernel(MultiSte a) {
+    const int i = multi_find(a.block0, a.n, blockIdx.x);
+    const int64_t g0 = (int64_t)(blockIdx.x - a.block0[i]) * kBlock + threadIdx.x;
+    const float* g = a.g[i];
+    float* gx = a.gx[i];
+    const int64_t numel = a.numel[i], ngroups = numel / 8;
+    const SteBwdOp op{a.step[i], 0.0f, DECIMAL ? 1 : 0, a.lo_mul[i], a.hi_mul[i], 0, nullptr};
+    const auto p = op.channel(0);
+    int32_t code;
+    if (g0 < ngroups) {
+        float v[8];
+        unpack8<QS_F32>(load8_raw<QS_F32, false>(g, g0), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
+        store8<QS_F32, false>(gx, g0, v);
+    }
+    if (g0 == 0)
+        for (int64_t e = ngroups * 8; e < numel; ++e) gx[e] = op.apply(g[e], p, code);
+}
+
 }  // namespace qs

@@ -121,6 +121,15 @@ class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
     __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt")
 
+    def __init__(self):
+        self.key = None
+
+    def __deepcopy__(self, memo):        # a cache of raw pointers never travels: copies and pickles rebuild their own
+        return _SitePlan()
+
+    def __reduce__(self):
+        return (_SitePlan, ())
+
 
 def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     """the cached plan of this site for inputs like `h`, or None when the site is not one the composite call covers

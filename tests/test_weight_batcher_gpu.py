@@ -245,3 +245,27 @@ def test_under_ddp_on_two_ranks():
         assert out[key].keys() == ref.keys()
         for k in ref:
             assert torch.equal(out[key][k], ref[k]), (key, k)
+
+
+def test_deep_copy_of_a_converted_network_with_warm_caches():
+    """site plans (fused.py) and launch plans (batch.py) cache raw device pointers in ctypes objects; a deep copy of the
+    network must neither fail on them nor share them: the twin trains on, bit-identically to the original"""
+    from examples.models import convert_pq, resnet18
+    torch.manual_seed(0)
+    model = convert_pq(resnet18(10, True, 8), sparsity=0.5, bits=4, prune_start=1, prune_interval=1, repetition=1,
+                       quant_timeout=1).cuda().train()
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(8, 3, 32, 32, generator=g).cuda() for _ in range(6)]
+    for x in xs[:4]:
+        model(x).sum().backward()                       # caches are warm now
+    twin = copy.deepcopy(model)
+    with torch.no_grad():                               # (identical parameters from here on: no optimizer, grads unused)
+        outs = [(model(x), twin(x)) for x in xs[4:]]
+    torch.cuda.synchronize()
+    sa, sb = _state(model), _state(twin)
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for a, b in outs:
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
+    assert twin.__dict__["_qs_weight_batcher"] is not model.__dict__["_qs_weight_batcher"]

@@ -15,7 +15,7 @@ PEAK = 8000.0  # GB/s
 
 def family(name):
     base = name.split("(")[0]
-    if "ste_relu_bwd_kernel" in base or "SteBwdOp" in base:
+    if "ste_relu_bwd_kernel" in base or "SteBwdOp" in base or "multi_ste_kernel" in base:
         return "apply_bwd"
     if "ChanMaskOp" in base or "mask_full" in base or "mask_bcast" in base:
         return "mask_apply"
