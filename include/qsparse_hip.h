@@ -352,6 +352,16 @@ int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_
 int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
                 float hi_mul, qs_stream_t stream);
 
+/* A lone tensor-wise ScalerQuantizer step -- QuantizeLayer.forward in training (reference quantize.py:473-518 with
+ * optimize :327-349 and ScalerQuantization.forward :100-117) -- from ONE call: with `update` != 0
+ *     qs_absmax(x, amax_lines, tensor-wise, accumulate, pre_relu, lines)  ->  qs_scale_update(amax_lines, lines, scale, 1, t,
+ *     t_dev, advance, bits, clear, n_updates, xdt)  ->  qs_quant_scaler_fwd(x, y, scale, pre_relu, gate_out)
+ * and with `update` == 0 the last of them alone (evaluation).  amax_lines: [lines][QS_AMAX_LINE_STRIDE] floats, zero on entry,
+ * re-zeroed by the update; n_updates (nullable) is incremented; t_dev (nullable) is read instead of t and incremented. */
+int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
+                     int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
+                     qs_stream_t stream);
+
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 
 /* The weight-side operators of a converted network (quantize(conv) / quantize(linear), reference quantize.py:559-571

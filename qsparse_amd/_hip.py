@@ -59,6 +59,7 @@ SIGNATURES = {
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -749,6 +750,19 @@ def stats_combine(gathered: torch.Tensor, world: int, C: int, want_stage: bool, 
 def logging_events() -> bool:
     """an event log is being recorded: callers keep to the fine-grained entry points so that every launch is bracketed"""
     return _event_log is not None
+
+
+def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], amax_lines: Optional[torch.Tensor],
+                  scale: torch.Tensor, bits: int, t: int, t_dev: Optional[torch.Tensor], n_updates: Optional[torch.Tensor],
+                  pre_relu: bool, update: bool):
+    """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout"""
+    st = load().qs_quantize_step(x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
+                                 None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
+                                 x.numel(), _DT[x.dtype], _DT[y.dtype], int(bits), int(t),
+                                 None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
+                                 int(bool(pre_relu)), int(bool(update)), _stream(x))
+    if st:
+        _check(st, "qs_quantize_step")
 
 
 def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,

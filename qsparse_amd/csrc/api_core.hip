@@ -197,6 +197,22 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
     return qs_quant_ste_bwd(g, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
 }
 
+int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
+                     int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
+                     qs_stream_t stream) {
+    if (!x || !y || !scale || numel < 0) return QS_ERR_ARG;
+    if (numel == 0) return QS_OK;
+    if (update) {
+        if (!amax_lines) return QS_ERR_ARG;
+        int st = qs_absmax(x, amax_lines, 0, 1, 1, numel, xdt, 1, pre_relu, lines, nullptr, 0, stream);
+        if (st) return st;
+        st = qs_scale_update(amax_lines, lines, scale, 1, t, t_dev, 1, bits, 1, n_updates, xdt, stream);
+        if (st) return st;
+    }
+    return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, 0, 0, 0, pre_relu, 0, gate_out,
+                               stream);
+}
+
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
 int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream) {
     if (n < 0 || (n > 0 && (!x || !numel || !amax))) return QS_ERR_ARG;

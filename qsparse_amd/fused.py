@@ -427,6 +427,9 @@ def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
     applies the ReLU gate and the STE clamp in one pass.  Bookkeeping as QuantizeLayer.forward
     (reference quantize.py:482-517)."""
     qc = q.callback
+    y = q.single_call_step(x, q._steps.read(q._n_updates), pre_relu=True)
+    if y is not None:
+        return y
     if q.training:
         t = q._steps.read(q._n_updates)
         if t == q.timeout and get_option("log_during_train"):

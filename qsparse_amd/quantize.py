@@ -291,6 +291,15 @@ class DecimalQuantizer(BaseQuantizer):
             self.__dict__["_t_dev_value"] = self.t
         return buf
 
+    def tensor_accumulator(self, device) -> torch.Tensor:
+        """the zeroed [16, 32] accumulator of a tensor-wise abs-max on `device` (see _hip.absmax), created once"""
+        bufs = self.__dict__.setdefault("_absmax_bufs", {})
+        key = (1, True, device)
+        buf = bufs.get(key)
+        if buf is None:
+            buf = bufs[key] = _hip.tensor_amax_accumulator(device)
+        return buf
+
     def _advance_t(self, t_dev: torch.Tensor = None, bumped_by_kernel: bool = False):
         self.t += 1
         if t_dev is not None:
@@ -482,6 +491,42 @@ class AdaptiveQuantizer(DecimalQuantizer):
 # ----------------------------------------------------------------------------------------------
 # the layer
 # ----------------------------------------------------------------------------------------------
+class _QuantStep(torch.autograd.Function):
+    """a lone tensor-wise ScalerQuantizer step through ONE call into the library (qs_quantize_step: abs-max, running scale,
+    quantization -- or the quantization alone); backward = the STE clamp, with the gate of a folded ReLU when `pre_relu`"""
+
+    @staticmethod
+    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype):
+        want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
+        y = torch.empty_like(x, dtype=out_dtype)
+        gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if want_gate else None
+        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update)
+        ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        ctx.channels_last = x.dim() in (4, 5) and not x.is_contiguous()
+        ctx.save_for_backward(scale, gate_bits if want_gate else (x if pre_relu else x.new_empty(0)))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, second = ctx.saved_tensors
+        limit = 2.0 ** (ctx.bits - 1)
+        lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
+        if ctx.pre_relu:
+            gate = _hip.ReluGate.from_saved(second, ctx.x_shape, ctx.x_dtype, ctx.channels_last) if ctx.has_gate else None
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else second, scale, False, lo_mul, hi_mul, None, gate=gate)
+        else:
+            out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
+            gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)
+        return (gx,) + (None,) * 10
+
+
+def _dense(x: torch.Tensor) -> bool:
+    if x.is_contiguous():
+        return True
+    return x.dim() in (4, 5) and x.is_contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+
+
 class QuantizeLayer(nn.Module):
     """stateful quantization operator (reference quantize.py:434-518): identity for the first
     ``timeout`` training steps, then statistics update (training) + quantization."""
@@ -527,6 +572,33 @@ class QuantizeLayer(nn.Module):
         t = self._steps.read(self._n_updates)
         return t >= self.timeout and (self.training or self._quantized)
 
+    def single_call_step(self, x: torch.Tensor, t: int, pre_relu: bool = False):
+        """the active step of a tensor-wise ScalerQuantizer on a dense GPU tensor through one call into the library
+        (qs_quantize_step); None when this layer / input is not one it covers -- the caller then takes the protocol route
+        (callback.optimize, callback.forward), which the composite reproduces launch for launch"""
+        cb = self.callback
+        if (type(cb) is not ScalerQuantizer or self.channelwise != -1 or cb.group_num > 0 or cb.backward_passthrough
+                or not x.is_cuda or x.dim() < 2 or x.numel() == 0 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16)
+                or x.data_ptr() % 16 or not _dense(x) or _hip.logging_events()
+                or self.weight.device != x.device or self._n_updates.device != x.device
+                or cb._forward_hooks or cb._forward_pre_hooks):
+            return None
+        update = self.training
+        if update and self.batch_dimension == 0 and qdist.exchange_active():
+            return None                     # an activation's abs-max is exchanged between ranks: the fine-grained route
+        if not update and not self._quantized:
+            return None
+        t_dev = cb.device_t(x.device) if (update and get_option("graph_safe")) else None
+        y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
+                             self._n_updates.data if update else None, pre_relu, update, 1 if cb.flip_axis else 0, _out_dtype(x))
+        if update:
+            if t == self.timeout and get_option("log_during_train"):
+                logging.warn(f"quantizing {self.name} with {self.bits} bits")
+            cb._advance_t(t_dev, bumped_by_kernel=True)
+            self._quantized = True
+            self._steps.note_device_add(self._n_updates, 1)
+        return y
+
     def forward(self, x):
         if not self.initted:
             self._lazy_init(x)
@@ -535,6 +607,10 @@ class QuantizeLayer(nn.Module):
         t = self._steps.read(self._n_updates)
         out = x
         counter_on_device = False
+        if t >= self.timeout and isinstance(x, torch.Tensor):
+            y = self.single_call_step(x, t)
+            if y is not None:
+                return y
         if t >= self.timeout:
             if self.training:
                 if t == self.timeout and get_option("log_during_train"):
