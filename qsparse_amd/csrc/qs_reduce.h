@@ -14,31 +14,30 @@ namespace qs {
 template <int DT, bool MINMAX>
 struct RedAcc {
     uint32_t mx = 0u, mn = 0xffffffffu;
-    // min/max run on the float pipeline (v_min_f32 / v_max_f32 order -0 < +0 and drop NaN operands, so a NaN is
-    // tracked on the side): 3 VALU ops per element instead of the ~9 of key conversion + integer min/max, which made
-    // the min/max kernels VALU-bound (4.3 TB/s on the headline tensor)
+    // min/max run on the float pipeline with gfx950's IEEE-754-2019 maximum / minimum (v_maximum3_f32 / v_minimum3_f32:
+    // -0 < +0, and a NaN operand PROPAGATES, as torch.min / torch.max do): one instruction per two elements and statistic.
+    // (Round 2 used v_max_f32 / v_min_f32, which drop NaN operands, plus a NaN flag on the side -- 3 VALU ops per element,
+    // and a minimum that ignored NaNs where the reference's rows.min() returns NaN; before that, key conversion + integer
+    // min/max at ~9 ops made these kernels VALU-bound at 4.3 TB/s.)
     float fmx = -__builtin_inff(), fmn = __builtin_inff();
-    bool nan = false;
     int relu = 0;   // abs-max of max(x, 0): the statistics of a folded nn.ReLU
     __device__ __forceinline__ void add(float v) {
         if (relu) v = relu_aten(v);
         if constexpr (MINMAX) {
-            fmx = __builtin_fmaxf(fmx, v);
-            fmn = __builtin_fminf(fmn, v);
-            nan |= (v != v);
+            fmx = __builtin_elementwise_maximum(fmx, v);
+            fmn = __builtin_elementwise_minimum(fmn, v);
         } else {
             uint32_t k = __float_as_uint(v) & 0x7fffffffu;
             mx = k > mx ? k : mx;
         }
     }
-    __device__ __forceinline__ void fold() {      // float state -> order-preserving keys (NaN sorts on top, as before)
-        if constexpr (MINMAX) {
-            const uint32_t kx = nan ? 0xffffffffu : f32_to_key(fmx), kn = f32_to_key(fmn);
+    __device__ __forceinline__ void fold() {      // float state -> order-preserving keys; a NaN wins both: key 0xffffffff on
+        if constexpr (MINMAX) {                   // top of the maxima, key 0 below every minimum (both decode to NaN)
+            const uint32_t kx = f32_to_key(fmx), kn = (fmn != fmn) ? 0u : f32_to_key(fmn);
             mx = kx > mx ? kx : mx;
             mn = kn < mn ? kn : mn;
             fmx = -__builtin_inff();
             fmn = __builtin_inff();
-            nan = false;
         }
     }
     __device__ __forceinline__ void wave_reduce() {

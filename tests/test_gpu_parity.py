@@ -1219,6 +1219,30 @@ def test_channel_mismatch_in_eval_raises_runtime_error_like_the_reference():
         lone(torch.randn(2, 12, 8, 8).to(DEV))
 
 
+def test_minmax_propagates_nan_like_torch():
+    """AdaptiveQuantizer's statistics are `rows.min(dim=1)` / `rows.max(dim=1)` (reference quantize.py:410-411): torch
+    propagates a NaN into BOTH; so do the kernels (v_minimum3_f32 / v_maximum3_f32), on every route -- tensor-wise, per channel
+    NCHW (rows, columns, the big tensors' column walk), channels_last, 2-d"""
+    for shape, ci in (((64, 48, 9, 9), 1), ((3, 5, 64), 1), ((1000, 16), 1), ((70000,), -1), ((16, 128, 64, 64), 1), ((37, 12, 14, 14), 1),
+                      ((8192, 256), 1), ((32, 1024, 8, 8), 1)):
+        for dtype in (torch.float32, torch.bfloat16):
+            for cl in ((False, True) if len(shape) == 4 else (False,)):
+                x = (torch.randn(shape, generator=gen(4242)) * 3).to(dtype)
+                flat = x.view(-1)
+                flat[5], flat[flat.numel() // 2], flat[3] = float("nan"), float("nan"), -0.0
+                xg = x.to(DEV).contiguous(memory_format=torch.channels_last) if cl else x.to(DEV)
+                mn, mx = _hip.minmax(xg, ci)
+                xf = x.float()
+                if ci < 0:
+                    want_mn, want_mx = xf.min().view(1), xf.max().view(1)
+                else:
+                    rows = xf.transpose(0, ci).reshape(shape[ci], -1)
+                    want_mn, want_mx = rows.min(dim=1).values, rows.max(dim=1).values
+                for got, want in ((mn.cpu(), want_mn), (mx.cpu(), want_mx)):
+                    assert torch.equal(got.isnan(), want.isnan()) and want.isnan().any(), (shape, ci, dtype, cl)
+                    assert torch.equal(got[~want.isnan()], want[~want.isnan()]), (shape, ci, dtype, cl)
+
+
 def test_minmax_key_accumulation_equals_the_float_route():
     """qs_minmax(accumulate) leaves order-preserving keys in persistent buffers and qs_lines_update(from_keys) converts and
     resets them: the running (min, max) lines must carry the same bits as the four-launch route (key initialisation,
