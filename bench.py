@@ -342,8 +342,21 @@ def resnet_config(arch, batch, device, steps):
                                           min(out["plain_ms"], out["plain_graph_ms"]), 4)
         out["opt_in_extensions"] = opt_in
         del model, step
+        torch.cuda.empty_cache()
+
+        # the value-identical opt-in: under autocast every fused site hands its first convolution the bf16 image of its
+        # float32 output and takes that convolution's bf16 gradient as it is (fused.py "Autocast image") -- same values as
+        # the default path, no fp32 <-> bf16 cast pass in the backward; opt-in because the site's output is a Tensor subclass
+        qs.set_qsparse_options(preserve_dtype=False, elide_pruned="forward", autocast_image=True)
+        model, step = build(True)
+        for _ in range(8):
+            step()
+        img = {"options": "autocast_image=True (value-identical)", "pq_ms": round(_timed_loop(step, steps), 3)}
+        img["over_plain"] = round(img["pq_ms"] / min(out["plain_ms"], out["plain_graph_ms"]), 4)
+        out["value_identical_opt_in"] = img
+        del model, step
     finally:
-        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward")
+        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward", autocast_image=False)
         torch.cuda.empty_cache()
     return out
 

@@ -119,12 +119,16 @@ int qs_quant_ste_bwd(const void* g, void* gx,
  *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)
  * x is the ReLU's INPUT (dtype xdt); gx has x's dtype.  gate (nullable): the bitmap a forward call recorded through
  * gate_out over the same [outer, C, inner] geometry; when given, x is not read (it may be NULL) and xdt only names the
- * dtype of gx: 4 + 1/8 + sizeof(xdt) bytes per element instead of 4 + 2 * sizeof(xdt). */
+ * dtype of gx: 4 + 1/8 + sizeof(xdt) bytes per element instead of 4 + 2 * sizeof(xdt).
+ * g2 (nullable, dtype g2dt = QS_BF16 / QS_F16, with gate and gdt == QS_F32 and elide_masked == 0): a second gradient of
+ * the same geometry that is ADDED to g in float32 before the clamp -- g may then be NULL (g2 alone).  It is autograd's
+ * accumulation of the gradients a float32 output receives under autocast (float32 from float32 consumers, bf16 from the
+ * convolution that consumed its bf16 image) done inside the kernel: no cast pass, no add pass, 2 instead of 4 bytes read. */
 int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx,
                           const float* step, int64_t nstep, float step_host, int step_is_decimal,
                           float lo_mul, float hi_mul, const uint8_t* chan_mask,
                           int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked,
-                          qs_stream_t stream);
+                          const void* g2, int g2dt, qs_stream_t stream);
 
 /* ---- statistics ---------------------------------------------------------------------------------- */
 
@@ -348,9 +352,10 @@ int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_
                 int64_t t_q, qs_stream_t stream);
 
 /* gx = gate * clamp(g) * mask in xdt (qs_quant_ste_relu_bwd with the bitmap when `gate` is given, qs_quant_ste_bwd
- * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there. */
+ * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there.  g2 / g2dt: the second gradient of
+ * qs_quant_ste_relu_bwd (needs `gate`; g may then be NULL). */
 int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
-                float hi_mul, qs_stream_t stream);
+                float hi_mul, const void* g2, int g2dt, qs_stream_t stream);
 
 /* A lone tensor-wise ScalerQuantizer step -- QuantizeLayer.forward in training (reference quantize.py:473-518 with
  * optimize :327-349 and ScalerQuantization.forward :100-117) -- from ONE call: with `update` != 0

@@ -38,7 +38,7 @@ SIGNATURES = {
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
     "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
     "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
-    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P]),
+    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
@@ -61,7 +61,7 @@ SIGNATURES = {
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P]),
-    "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
+    "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
@@ -381,35 +381,50 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
     return gx
 
 
-def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
-                 chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1, gate: Optional[ReluGate] = None):
+def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
+                 chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1, gate: Optional[ReluGate] = None,
+                 g2: Optional[torch.Tensor] = None):
     """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate.  With `gate` (the
-    bitmap `quant_fwd(want_gate=True)` recorded) x is not needed."""
+    bitmap `quant_fwd(want_gate=True)` recorded) x is not needed.  `g2` (with `gate`; bf16 / fp16): a second gradient that
+    is added to the float32 `g` in float32 before the clamp; `g` may then be None."""
     lib = load()
-    pt, n, host = _f32param(step, g.device)
+    ref = g if g is not None else g2
+    pt, n, host = _f32param(step, ref.device)
     ci = mask_channel_index if chan_mask is not None else -1
     if gate is not None:
-        assert tuple(g.shape) == tuple(gate.shape)
-        if gate.channels_last:         # the bitmap follows the NHWC memory order the forward addressed
-            fmt = torch.channels_last if g.dim() == 4 else torch.channels_last_3d
-            gcl = g.contiguous(memory_format=fmt)
-            if gcl.data_ptr() % 16:
-                gcl = gcl.clone(memory_format=torch.preserve_format)
-            perm = (0, 2, 3, 1) if g.dim() == 4 else (0, 2, 3, 4, 1)
-            gm = gcl.permute(perm)
-            ci_mem = -1 if ci < 0 else perm.index(ci)
-            gx = torch.empty(gate.shape, dtype=gate.dtype, device=g.device, memory_format=fmt)
+        assert tuple(ref.shape) == tuple(gate.shape) and (g2 is None or g is None or g.dtype == torch.float32)
+
+        def as_mem(t):
+            if t is None:
+                return None, ci
+            if gate.channels_last:         # the bitmap follows the NHWC memory order the forward addressed
+                fmt = torch.channels_last if t.dim() == 4 else torch.channels_last_3d
+                tcl = t.contiguous(memory_format=fmt)
+                if tcl.data_ptr() % 16:
+                    tcl = tcl.clone(memory_format=torch.preserve_format)
+                perm = (0, 2, 3, 1) if t.dim() == 4 else (0, 2, 3, 4, 1)
+                return tcl.permute(perm), (-1 if ci < 0 else perm.index(ci))
+            return dense(t), ci
+
+        gm, ci_mem = as_mem(g)
+        g2m, ci2 = as_mem(g2)
+        refm = gm if gm is not None else g2m
+        ci_mem = ci_mem if gm is not None else ci2
+        if gate.channels_last:
+            gx = torch.empty(gate.shape, dtype=gate.dtype, device=ref.device,
+                             memory_format=torch.channels_last if ref.dim() == 4 else torch.channels_last_3d)
         else:
-            gm, ci_mem = dense(g), ci
-            gx = torch.empty(gate.shape, dtype=gate.dtype, device=g.device)
-        outer, C, inner, numel = split3(gm.shape, ci_mem)
+            gx = torch.empty(gate.shape, dtype=gate.dtype, device=ref.device)
+        outer, C, inner, numel = split3(refm.shape, ci_mem)
         if numel == 0:
             return gx
         cm = _chan_mask_bytes(chan_mask, C)
-        with _timed("quant_ste_relu_bwd", gm, gate.bits, gx):
+        with _timed("quant_ste_relu_bwd", gm, g2m, gate.bits, gx):
             st = lib.qs_quant_ste_relu_bwd(_ptr(gm), None, _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host,
                                            int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner,
-                                           dt(gm), _DT[gate.dtype], _elide_all() if cm is not None else 0, _stream(gm))
+                                           F32 if gm is None else dt(gm), _DT[gate.dtype],
+                                           _elide_all() if (cm is not None and g2m is None) else 0, _ptr(g2m),
+                                           0 if g2m is None else dt(g2m), _stream(refm))
         _check(st, "qs_quant_ste_relu_bwd")
         return gx
     assert g.shape == x.shape
@@ -432,7 +447,7 @@ def ste_relu_bwd(g: torch.Tensor, x: Optional[torch.Tensor], step, step_is_decim
     with _timed("quant_ste_relu_bwd", g, x, gx):
         st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), None, _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
                                        float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x),
-                                       _elide_all() if cm is not None else 0, _stream(g))
+                                       _elide_all() if cm is not None else 0, None, 0, _stream(g))
     _check(st, "qs_quant_ste_relu_bwd")
     return gx
 
@@ -773,10 +788,12 @@ def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[tor
         _check(st, "qs_site_fwd")
 
 
-def site_bwd(plan_ref, g: torch.Tensor, gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
-             hi_mul: float):
-    st = load().qs_site_bwd(plan_ref, g.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), gx.data_ptr(),
-                            _DT[g.dtype], flags, lo_mul, hi_mul, _stream(g))
+def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
+             hi_mul: float, g2: Optional[torch.Tensor] = None):
+    """g2: a second, 2-byte gradient added to g in float32 (g may then be None), see qs_quant_ste_relu_bwd"""
+    st = load().qs_site_bwd(plan_ref, None if g is None else g.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
+                            gx.data_ptr(), F32 if g is None else _DT[g.dtype], flags, lo_mul, hi_mul,
+                            None if g2 is None else g2.data_ptr(), 0 if g2 is None else _DT[g2.dtype], _stream(gx))
     if st:
         _check(st, "qs_site_bwd")
 

@@ -184,16 +184,16 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
 }
 
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
-                float hi_mul, qs_stream_t stream) {
-    if (!p || !g || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1) return QS_ERR_ARG;
+                float hi_mul, const void* g2, int g2dt, qs_stream_t stream) {
+    if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate)) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
     if (gate)
-        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt, elide,
-                                     stream);
+        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt,
+                                     g2 ? 0 : elide, g2, g2dt, stream);
     return qs_quant_ste_bwd(g, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
 }
 

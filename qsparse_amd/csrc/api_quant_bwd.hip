@@ -29,10 +29,12 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
 
 int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx, const float* step, int64_t nstep,
                           float step_host, int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask,
-                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, qs_stream_t stream) {
-    if (!g || (!x && !gate) || !gx) return QS_ERR_ARG;
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, const void* g2, int g2dt,
+                          qs_stream_t stream) {
+    if ((!g && !g2) || (!x && !gate) || !gx) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
-    if (!aligned16(g) || (!gate && !aligned16(x)) || !aligned16(gx)) return QS_ERR_ALIGN;
+    if (g2 && (!gate || gdt != QS_F32 || (g2dt != QS_BF16 && g2dt != QS_F16))) return QS_ERR_DTYPE;
+    if ((g && !aligned16(g)) || (!gate && !aligned16(x)) || !aligned16(gx) || (g2 && !aligned16(g2))) return QS_ERR_ALIGN;
     int st = check_param(step, nstep, C);
     if (st) return st;
     const bool ppc = nstep > 1;
@@ -45,6 +47,34 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
     const int grid = grid_for(plan.geo.ngroups, 1);
     constexpr bool NT = QS_EW_NT != 0;
     const void* second = gate ? (const void*)gate : x;       // the gate bitmap replaces the ReLU's input (GATE kernels)
+    if (g2) {
+        // two gradient streams (fp32 + a 2-byte one, or the 2-byte one alone): gate bitmap kernels, never eliding
+        auto dual = [&](auto X, auto G2) {
+            constexpr int XD = decltype(X)::value, G2D = decltype(G2)::value;
+            int cm = plan.cm;
+            if (XD == QS_F32 && cm == CM_ELEM && plan.geo.inner % 4 == 0) cm = CM_ROW;
+            switch (cm) {
+                case CM_SCALAR:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_SCALAR, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                    break;
+                case CM_ROW:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ROW, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                    break;
+                case CM_LAST:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_LAST, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                    break;
+                default:
+                    hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ELEM, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
+                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                    break;
+            }
+            return launch_status();
+        };
+        return with_dtype(xdt, [&](auto X) { return g2dt == QS_BF16 ? dual(X, IC<QS_BF16>{}) : dual(X, IC<QS_F16>{}); });
+    }
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto G, auto GT) {

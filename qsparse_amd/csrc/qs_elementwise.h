@@ -758,10 +758,15 @@ __device__ __forceinline__ void gate_to_floats(uint32_t bits, float* vx) {
     for (int j = 0; j < N; ++j) vx[j] = ((bits >> j) & 1u) ? 1.0f : 0.0f;
 }
 
-template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false>
+// G2DT >= 0: a SECOND gradient stream `g2` of that dtype is added to `g` in float32 before the clamp, and `g` itself may be
+// NULL (then g2 alone is the gradient).  This is autograd's accumulation of the two gradients a site's float32 output
+// receives under autocast -- float32 from its float32 consumers, bf16 / fp16 from the convolution that consumed its
+// low-precision image (see fused.py, "autocast image") -- evaluated in the kernel instead of by a cast pass plus an add pass.
+template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false, int G2DT = -1>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
-                                                              void* __restrict__ gx) {
+                                                              void* __restrict__ gx, const void* __restrict__ g2 = nullptr) {
+    static_assert(G2DT < 0 || (!ELIDE && GDT == QS_F32 && G2DT != QS_F32), "the second gradient is a 2-byte stream next to an fp32 one");
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int64_t grp = blk * kBlock + threadIdx.x;
     if constexpr (GDT == QS_F32 && XDT == QS_F32) {
@@ -790,7 +795,16 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                     need = *(const uint32_t*)(op.cmask + last_dim_channel(e, geo.C)) != 0u;
                 }
                 if (need) {
-                    rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
+                    if (G2DT < 0 || g) rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
+                    if constexpr (G2DT >= 0) {      // 4 two-byte values of the second gradient: g + float(g2), or float(g2) alone
+                        const u32x2 r2 = *(const u32x2*)((const uint16_t*)g2 + e);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t h = (j & 1) ? (r2[j >> 1] >> 16) : (r2[j >> 1] & 0xffffu);
+                            const float v2 = (G2DT == QS_BF16) ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
+                            rg4[j] = __float_as_uint(g ? __uint_as_float(rg4[j]) + v2 : v2);
+                        }
+                    }
                     if constexpr (GATE) {
                         const uint32_t bits = (uint32_t)((const uint8_t*)x)[e >> 3] >> ((uint32_t)e & 4u);
 #pragma unroll
@@ -861,12 +875,18 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         }
         uint32_t gbits = 0u;
         if (need) {
-            rg = load8_raw<GDT, NT>(g, grp);
+            if (G2DT < 0 || g) rg = load8_raw<GDT, NT>(g, grp);
             if constexpr (GATE) gbits = ((const uint8_t*)x)[grp];
             else rx = load8_raw<XDT, NT>(x, grp);
         }
         float vg[8], vx[8];
         unpack8<GDT>(rg, vg);
+        if constexpr (G2DT >= 0) {
+            float v2[8];
+            unpack8<G2DT>(load8_raw<G2DT, NT>(g2, grp), v2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vg[j] = g ? vg[j] + v2[j] : v2[j];
+        }
         if constexpr (GATE) gate_to_floats<8>(gbits, vx);
         else unpack8<XDT>(rx, vx);
         int32_t dummy;
@@ -930,7 +950,12 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         float xe;
         if constexpr (GATE) xe = ((((const uint8_t*)x)[e >> 3] >> ((uint32_t)e & 7u)) & 1u) ? 1.0f : 0.0f;
         else xe = load1<XDT>(x, e);
-        const float r = (xe <= 0.0f) ? 0.0f : op.apply(load1<GDT>(g, e), p, dummy);
+        float ge = (G2DT < 0 || g) ? load1<GDT>(g, e) : 0.0f;
+        if constexpr (G2DT >= 0) {
+            const float v2 = load1<G2DT>(g2, e);
+            ge = g ? ge + v2 : v2;
+        }
+        const float r = (xe <= 0.0f) ? 0.0f : op.apply(ge, p, dummy);
         store1<XDT>(gx, e, r);
     }
 }

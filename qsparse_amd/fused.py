@@ -119,10 +119,11 @@ class _FusedApply(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------------
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
-    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt")
+    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used")
 
     def __init__(self):
         self.key = None
+        self.image_ok, self.image_made, self.image_used = True, False, False
 
     def __deepcopy__(self, memo):        # a cache of raw pointers never travels: copies and pickles rebuild their own
         return _SitePlan()
@@ -182,11 +183,74 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     return plan
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Autocast image.  The reference's quantizers return float32 for a bf16 input (quantize.py:109-117), so under autocast every
+# convolution that consumes a site's output casts it back: an `fp32 -> bf16` pass in the forward and its `bf16 -> fp32` mirror
+# image in the backward, 6.1 ms of a 56.5 ms ResNet-50 step.  With the option `autocast_image` the site
+# hands its FIRST autocast consumer the bf16 image itself -- the very values ATen's cast would produce -- and receives that
+# consumer's bf16 gradient directly: its backward kernel adds it, in float32, to whatever float32 gradient the output's
+# other consumers delivered (qs_quant_ste_relu_bwd g2).  Every value is the reference's: the image is RNE(y), the gradient
+# sum is autograd's own accumulation (the first consumer's backward is the last to arrive, so even the grouping of more
+# than two terms is kept).  What changes is the TYPE of the site's output: a `torch.Tensor` subclass that carries the image
+# until a convolution / linear / matmul under autocast takes it; every other operation sees a plain float32 tensor.
+# Opt-in, because one thing is observable: the image consumer's gradient reaches the site's backward directly, NOT through
+# the output tensor -- `register_hook` / `retain_grad` on the output before the consumer ran simply cancel the image (the
+# whole gradient then flows through the tensor as usual), but a hook registered AFTER the consumer took it, or
+# `torch.autograd.grad(loss, y)`, sees only the float32 consumers' share.
+# ----------------------------------------------------------------------------------------------------------------------
+def _image_consumers():
+    import torch.nn.functional as F
+    fns = [torch.conv1d, torch.conv2d, torch.conv3d, torch.conv_transpose1d, torch.conv_transpose2d, torch.conv_transpose3d,
+           F.linear, torch.matmul, torch.mm, torch.bmm, F.conv1d, F.conv2d, F.conv3d]
+    return frozenset(fns)
+
+
+_IMAGE_CONSUMERS = _image_consumers()
+_GRADIENT_OBSERVERS = frozenset([torch.Tensor.register_hook, torch.Tensor.retain_grad])
+
+
+class AutocastImageTensor(torch.Tensor):
+    """float32 output of a quantize site that also carries its low-precision image for ONE autocast consumer"""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            if func in _GRADIENT_OBSERVERS and args and type(args[0]) is cls:
+                # someone wants to SEE this tensor's gradient: it must be the whole one, so no consumer may bypass it
+                args[0].__dict__.pop("_qs_image", None)
+            elif func in _IMAGE_CONSUMERS and args and type(args[0]) is cls:
+                held = args[0].__dict__.get("_qs_image")
+                if held is not None:
+                    img, version, plan = held
+                    if (args[0]._version == version and torch.is_autocast_enabled("cuda")
+                            and torch.get_autocast_dtype("cuda") == img.dtype):
+                        del args[0].__dict__["_qs_image"]       # one consumer only: a second one casts for itself, as before
+                        plan.image_used = True
+                        args = (img,) + tuple(args[1:])
+            return func(*args, **(kwargs or {}))
+
+    def __repr__(self):
+        with torch._C.DisableTorchFunctionSubclass():
+            return torch.Tensor.__repr__(self.as_subclass(torch.Tensor))
+
+
+def _image_dtype(plan, training_needs_gate: bool):
+    """dtype of the image this step should produce, or None"""
+    if not get_option("autocast_image") or not plan.image_ok or plan.out_dtype != torch.float32:
+        return None
+    if not torch.is_autocast_enabled("cuda"):
+        return None
+    dt = torch.get_autocast_dtype("cuda")
+    if dt not in (torch.bfloat16, torch.float16) or (training_needs_gate and not get_option("relu_gate")):
+        return None
+    return dt
+
+
 class _SiteStep(torch.autograd.Function):
     """the whole site through qs_site_fwd / qs_site_bwd; same results as the statistics + select + `_FusedApply` route"""
 
     @staticmethod
-    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale):
+    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None):
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
         bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if want_gate else None
@@ -196,23 +260,41 @@ class _SiteStep(torch.autograd.Function):
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
                               bits_t if want_gate else (h if keep_x else h.new_empty(0)))
+        ctx.set_materialize_grads(False)
+        if image_dtype is not None and (want_gate or not ctx.needs_input_grad[0]):
+            return y, y.to(image_dtype)             # RNE, the cast autocast would apply to y in front of a convolution
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g16=None):
         plan, flags = ctx.plan, ctx.flags
+        n_in = 11
+        if g is None and g16 is None:
+            return (None,) * n_in
         mask_c, scale, third = ctx.saved_tensors
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         pre_relu = bool(flags & _hip.SITE_PRE_RELU)
         fmt = torch.channels_last if plan.channels_last else torch.contiguous_format
-        fast = (g.is_contiguous(memory_format=fmt) and g.data_ptr() % 16 == 0 and tuple(g.shape) == tuple(ctx.x_shape)
-                and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype) and not _hip.logging_events())
+
+        def dense(t):
+            return t.is_contiguous(memory_format=fmt) and t.data_ptr() % 16 == 0 and tuple(t.shape) == tuple(ctx.x_shape)
+
+        if g16 is not None:
+            # the image's consumer delivered its low-precision gradient: g + float(g16) inside the kernel (qs_site_bwd g2)
+            if (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
+                    and _hip.elide_mode != "all" and not _hip.logging_events()):
+                gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g16.device, memory_format=fmt)
+                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16)
+                return (gx,) + (None,) * (n_in - 1)
+            g = g16.float() if g is None else g + g16.float()          # autograd's own accumulation, then the usual routes
+        fast = (dense(g) and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype)
+                and not _hip.logging_events())
         if fast:
             gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g.device, memory_format=fmt)
             bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
             _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul)
-            return (gx,) + (None,) * 9
+            return (gx,) + (None,) * (n_in - 1)
         mask = mask_c if mask_c.numel() else None
         if pre_relu:
             gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
@@ -220,7 +302,7 @@ class _SiteStep(torch.autograd.Function):
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
-        return (gx,) + (None,) * 9
+        return (gx,) + (None,) * (n_in - 1)
 
 
 def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
@@ -371,8 +453,19 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     if site is not None:
         flags = ((_hip.SITE_LIVE if live else 0) | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
                  | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0) | (0 if prune_on else _hip.SITE_NO_MASK))
-        return _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
-                               p.mask.data.view(-1) if prune_on else None, q.weight.data)
+        if site.image_made and not site.image_used:
+            site.image_ok = False        # nobody took the last image (the consumer is not an autocast matmul / convolution): stop making them
+        site.image_made = site.image_used = False
+        image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
+        out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
+                              p.mask.data.view(-1) if prune_on else None, q.weight.data, image_dtype)
+        if type(out) is tuple:
+            y, img = out
+            site.image_made = True
+            dual = y.as_subclass(AutocastImageTensor)
+            dual.__dict__["_qs_image"] = (img, y._version, site)
+            return dual
+        return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
                              1 if qc.flip_axis else 0, quant_on, pre_relu)
 

@@ -12,13 +12,14 @@ import torch.nn as nn
 from qsparse_amd import _hip
 
 _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
-             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True}
+             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": False}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
-                elide_pruned: Optional[str] = None, relu_gate: Optional[bool] = None, batch_weights: Optional[bool] = None):
+                elide_pruned: Optional[str] = None, relu_gate: Optional[bool] = None, batch_weights: Optional[bool] = None,
+                autocast_image: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
@@ -38,7 +39,11 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     ``"off"`` loads everything (a NaN / Inf on a pruned channel then behaves exactly as in the reference);
     ``batch_weights`` (default True, bit-identical): the weight quantizers of a network built by ``convert`` are evaluated
     with three multi-tensor launches at the start of the root's forward instead of three per layer (see batch.py; a
-    layer the forward never reaches is rolled back, so the state machines advance exactly as layer by layer)."""
+    layer the forward never reaches is rolled back, so the state machines advance exactly as layer by layer);
+    ``autocast_image`` (extension, default False; value-identical): under ``torch.autocast`` a fused ReLU -> prune -> quantize
+    site hands the first convolution / linear that consumes its float32 output the bf16 image directly and takes that
+    consumer's bf16 gradient as it is -- no ``fp32 <-> bf16`` cast passes around the site (see fused.py, "Autocast image");
+    the site's output is then a ``torch.Tensor`` subclass."""
     if elide_pruned is not None:
         if elide_pruned not in ("off", "forward", "all"):
             raise ValueError(f"elide_pruned must be 'off', 'forward' or 'all', got {elide_pruned!r}")
@@ -47,7 +52,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
                      ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu), ("relu_gate", relu_gate),
-                     ("batch_weights", batch_weights)):
+                     ("batch_weights", batch_weights), ("autocast_image", autocast_image)):
         if val is not None:
             _options_[key] = val
 

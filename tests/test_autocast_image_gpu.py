@@ -1,0 +1,187 @@
+"""The `autocast_image` extension (qsparse_amd/fused.py): under torch.autocast a fused ReLU -> prune -> quantize site hands
+its first convolution / linear consumer the bf16 image of its float32 output and takes that consumer's bf16 gradient as it
+is.  The claim is that every VALUE stays the reference's (quantize.py:109-131 + autocast's casts + autograd's float32
+accumulation); what is checked:
+
+  * the backward kernel with two gradient streams against torch's own arithmetic (float32 add, clamp, mask, ReLU gate, cast),
+    bit for bit, over layouts / dtypes / ragged shapes / with and without the float32 stream;
+  * whole sites with real consumers -- a linear layer (deterministic GEMM), a second float32 consumer (residual add), a
+    second low-precision consumer -- option on against option off: outputs, consumer outputs, input gradients bit for bit;
+  * the image is taken exactly once, never after an in-place write, never outside autocast; a site whose consumer is no
+    autocast matmul stops producing it; evaluation mode works; the output is a Tensor subclass only while it carries one."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import qsparse_amd as qs
+from golden_io import same
+from qsparse_amd import _hip
+from qsparse_amd.fused import AutocastImageTensor, fuse_prune_quantize_pairs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float32, torch.float16])
+def test_backward_kernel_with_two_gradient_streams_equals_autograd_arithmetic(xdt):
+    for shape in ((6, 16, 8, 8), (3, 24, 7, 7), (5, 8, 14, 14), (2, 40, 3, 5), (4, 64, 1, 1)):
+        for cl in (False, True):
+            for with_g32 in (True, False):
+                for g2dt in ((torch.bfloat16, torch.float16) if xdt == torch.float32 else (xdt,)):
+                    C = shape[1]
+                    fmt = torch.channels_last if cl else torch.contiguous_format
+                    x = (torch.randn(shape, generator=gen(1)) * 2).to(xdt)
+                    x.view(-1)[:3] = torch.tensor([0.0, -0.0, float("nan")], dtype=xdt)
+                    x = x.to(DEV).contiguous(memory_format=fmt)
+                    mask = (torch.rand(C, generator=gen(2)) > 0.4).to(DEV)
+                    scale = torch.tensor([[0.37]], device=DEV)
+                    # the forward records the gate bitmap in the layout it addressed
+                    _, _, gate = _hip.quant_fwd("scaler", x, scale, -1, torch.float32, chan_mask=mask, mask_channel_index=1, pre_relu=True,
+                                                want_gate=True)
+                    g32 = None
+                    if with_g32:
+                        g32 = torch.randn(shape, generator=gen(3)) * 3
+                        g32.view(-1)[5] = float("nan")
+                        g32 = g32.to(DEV).contiguous(memory_format=fmt)
+                    g16 = (torch.randn(shape, generator=gen(4)) * 3).to(g2dt).to(DEV).contiguous(memory_format=fmt)
+                    lo, hi = -8.0, 7.0
+                    gx = _hip.ste_relu_bwd(g32, None, scale, False, lo, hi, mask, gate=gate, g2=g16)
+                    total = g16.float() if g32 is None else g32 + g16.float()            # autograd's accumulation
+                    lo_b, hi_b = (scale * lo).item(), (scale * hi).item()                # float32 products, as quantize.py:123-129
+                    ref = torch.clamp(total, lo_b, hi_b) * mask.view(1, -1, 1, 1)
+                    ref = torch.where(x > 0, ref, torch.zeros_like(ref)).to(xdt)         # threshold_backward, then the cast to x's dtype
+                    ref = torch.where(x != x, (torch.clamp(total, lo_b, hi_b) * mask.view(1, -1, 1, 1)).to(xdt), ref)   # NaN passes the gate
+                    a, b = gx.cpu(), ref.cpu()          # (a NaN only has to be a NaN: payload and sign depend on the instruction mix)
+                    assert gx.dtype == xdt and torch.equal(a.isnan(), b.isnan()), (shape, cl, with_g32, g2dt)
+                    assert same(torch.where(a.isnan(), torch.zeros_like(a), a), torch.where(b.isnan(), torch.zeros_like(b), b)), \
+                        (shape, cl, with_g32, g2dt)
+
+
+class Net(nn.Module):
+    """site -> linear over the last dim (a deterministic GEMM under autocast) [+ a float32 consumer] [+ a second bf16 consumer]"""
+
+    def __init__(self, C, W, residual, second):
+        super().__init__()
+        self.site = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1)))
+        torch.manual_seed(5)
+        self.w1 = nn.Parameter(torch.randn(12, W) * 0.3)
+        self.w2 = nn.Parameter(torch.randn(9, W) * 0.3)
+        self.residual, self.second = residual, second
+        self.seen = []
+
+    def forward(self, x):
+        y = self.site(x)
+        self.seen.append(type(y))
+        out = F.linear(y, self.w1).float().sum(-1)
+        if self.second:
+            out = out + F.linear(y, self.w2).float().sum(-1)
+        if self.residual:
+            out = out + (y * 0.5).sum(-1)
+        return y, out
+
+
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("residual,second", [(False, False), (True, False), (False, True), (True, True)])
+def test_sites_with_real_consumers_are_value_identical(cl, residual, second):
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            net = Net(16, 8, residual, second).to(DEV).train()
+            trace = []
+            for s in range(5):
+                x = (torch.randn(6, 16, 8, 8, generator=gen(20 + s)) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().to(DEV)
+                if cl:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                x.requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y, out = net(x)
+                out.sum().backward()
+                trace += [y.detach().as_subclass(torch.Tensor).clone(), out.detach().clone(), x.grad.clone(), net.w1.grad.clone()]
+                net.zero_grad()
+            runs.append((trace, net.seen, net.site[0][1].mask.clone(), net.site[1].weight.clone()))
+        finally:
+            qs.set_qsparse_options(autocast_image=False)
+    (ta, seen_a, ma, sa), (tb, seen_b, mb, sb) = runs
+    assert all(t is torch.Tensor for t in seen_a)
+    assert seen_b[0] is torch.Tensor and all(t is AutocastImageTensor for t in seen_b[2:])      # from the first ACTIVE step on
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
+    assert torch.equal(ma, mb) and torch.equal(sa, sb)
+
+
+def test_the_image_is_taken_once_and_only_when_it_is_still_valid():
+    qs.set_qsparse_options(autocast_image=True)
+    try:
+        site = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1))).to(DEV).train()
+        w = torch.randn(5, 8, device=DEV)
+
+        def run(consume):
+            x = torch.randn(4, 16, 8, 8, device=DEV).bfloat16().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = site(x)
+                return y, consume(y)
+
+
+        for _ in range(3):
+            run(lambda y: F.linear(y, w))
+        # taken exactly once
+        y, _ = run(lambda y: F.linear(y, w))
+        assert type(y) is AutocastImageTensor and "_qs_image" not in y.__dict__
+        # an in-place write invalidates it: the consumer casts the WRITTEN values itself
+        def inplace(y):
+            y.mul_(2.0)
+            return F.linear(y, w)
+        y, out = run(inplace)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert torch.equal(out, F.linear(y.detach().as_subclass(torch.Tensor), w))
+        # a gradient hook on the output cancels the image: the hook then sees the WHOLE gradient, as without the extension
+        seen = []
+        def hooked(y):
+            y.register_hook(lambda g: seen.append(g.clone()))
+            return F.linear(y, w)
+        y, out = run(hooked)
+        assert "_qs_image" not in y.__dict__
+        out.float().sum().backward()
+        assert len(seen) == 1 and seen[0].dtype == torch.float32 and float(seen[0].abs().sum()) > 0
+        # outside autocast nothing is substituted (and nothing is made)
+        x = torch.randn(4, 16, 8, 8, device=DEV).bfloat16()
+        assert type(site(x)) is torch.Tensor
+        # a site whose consumer is no autocast matmul stops making images after the first unused one
+        lone = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1))).to(DEV).train()
+        kinds = []
+        for _ in range(6):
+            x = torch.randn(4, 16, 8, 8, device=DEV).bfloat16().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = lone(x)
+                kinds.append(type(y))
+                F.adaptive_avg_pool2d(y, 1).sum().backward()
+        assert kinds[-1] is torch.Tensor and AutocastImageTensor in kinds
+        # evaluation mode: forward only, the image still saves the consumer's cast
+        site = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1))).to(DEV).train()
+        for _ in range(3):
+            run(lambda y: F.linear(y, w))
+        site.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            x = torch.randn(4, 16, 8, 8, device=DEV).bfloat16()
+            y = site(x)
+            assert type(y) is AutocastImageTensor
+            a = F.linear(y, w)
+            qs.set_qsparse_options(autocast_image=False)
+            assert torch.equal(a, F.linear(site(x), w))
+    finally:
+        qs.set_qsparse_options(autocast_image=False)
