@@ -249,6 +249,27 @@ def library_kernel_accounting(step, reps=3):
     return rec
 
 
+def kernel_trace_reference(tag):
+    """the committed rocprofv3 per-family table of this config (tools/profile_model.sh -> profiles/rNN_<tag>_family_table.txt):
+    kernel-trace durations are the reference for what the library's launches cost on the GPU -- the live event pairs above
+    bracket dispatch latency as well.  Returned as recorded (another box, another day): a cross-check, not a live number."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_family_table.txt")))
+    if not files:
+        return None
+    try:
+        fams = {}
+        for line in open(files[-1]):
+            m = re.match(r"^(apply_fwd|apply_bwd|statistics|c_sized|mask_apply|all)\s+([0-9.]+)\s+(\d+)\s+([0-9.]+)\s+\d+\s+([0-9.]+)", line)
+            if m:
+                fams[m.group(1)] = {"ms": float(m.group(2)), "launches": int(m.group(3)), "GB": float(m.group(4)),
+                                    "frac_of_hbm_peak": float(m.group(5)) or None}
+        return {"source": os.path.relpath(files[-1], ROOT), "method": "rocprofv3 --kernel-trace, last 5 steps", **fams} if "all" in fams else None
+    except (OSError, ValueError):
+        return None
+
+
 def resnet_config(arch, batch, device, steps):
     """BASELINE configs 3 / 4: full-width ResNet-18 (CIFAR shape, 50 % channel pruning) / ResNet-50 (ImageNet shape,
     75 %), 4-bit weights and activations, bf16 autocast, channels_last (MIOpen's native layout), SGD with momentum,
@@ -314,6 +335,9 @@ def resnet_config(arch, batch, device, steps):
         out["pq_ms"] = round(_timed_loop(step, steps), 3)
         out["library_kernels"] = library_kernel_accounting(step)
         lib_ms = out["library_kernels"]["ms_per_step"]
+        ref = kernel_trace_reference("config3" if arch == "resnet18" else "config4")
+        if ref:
+            out["library_kernels"]["kernel_trace_reference"] = ref
         assert graphs.steady_state(model), "converted network did not reach its steady state"
         gr = capture(step)
         out["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)

@@ -78,7 +78,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
                         int64_t outer, int64_t C, int64_t inner,
                         int xdt, int ydt, int qdt,
                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                        uint8_t* gate_out, qs_stream_t stream);
+                        uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream);
 
 /* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
@@ -87,7 +87,13 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          int64_t outer, int64_t C, int64_t inner,
                          int xdt, int ydt, int qdt,
                          int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                         uint8_t* gate_out, qs_stream_t stream);
+                         uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream);
+
+/* image_out (nullable; qs_quant_scaler_fwd / qs_quant_decimal_fwd, with gate_out, ydt == QS_F32 and codes == NULL): the same
+ * pass also writes RNE(y) in imgdt (QS_BF16 / QS_F16) -- the low-precision image autocast would make of y in front of a
+ * convolution -- at +2 instead of a 6 B/elem cast pass.  Served by the gate-recording widening kernels; qs_quant_image_ok tells
+ * whether a geometry is one of theirs (1) or the call would be rejected with QS_ERR_ARG (0). */
+int qs_quant_image_ok(int64_t outer, int64_t C, int64_t inner, int per_channel_param, int has_mask, int mask_aligned8, int xdt);
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
@@ -346,10 +352,10 @@ typedef struct qs_site_plan {
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
 
 /* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
- * gate_out: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
+ * gate_out, image_out / imgdt: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
  * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116). */
 int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, qs_stream_t stream);
+                int64_t t_q, void* image_out, int imgdt, qs_stream_t stream);
 
 /* gx = gate * clamp(g) * mask in xdt (qs_quant_ste_relu_bwd with the bitmap when `gate` is given, qs_quant_ste_bwd
  * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there.  g2 / g2dt: the second gradient of

@@ -36,8 +36,9 @@ SIGNATURES = {
     "qs_version": (c_int, []),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
-    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
-    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P]),
+    "qs_quant_image_ok": (c_int, [_L, _L, _L, _I, _I, _I, _I]),
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
@@ -60,7 +61,7 @@ SIGNATURES = {
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _P]),
-    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P]),
+    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
@@ -337,7 +338,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
                 _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0,
-                _ptr(gate.bits) if gate is not None else None, _stream(x))
+                _ptr(gate.bits) if gate is not None else None, None, 0, _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     return (y, codes, gate) if want_gate else (y, codes)
 
@@ -781,9 +782,11 @@ def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Te
 
 
 def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,
-             t_q: int):
+             t_q: int, image: Optional[torch.Tensor] = None):
+    """image: optional bf16 / fp16 tensor of y's shape and layout that receives RNE(y) from the same pass (see qs_quant_image_ok)"""
     st = load().qs_site_fwd(plan_ref, x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), flags,
-                            t_mag, k, t_q, _stream(x))
+                            t_mag, k, t_q, None if image is None else image.data_ptr(), 0 if image is None else _DT[image.dtype],
+                            _stream(x))
     if st:
         _check(st, "qs_site_fwd")
 

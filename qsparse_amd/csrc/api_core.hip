@@ -148,7 +148,7 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
 
 // ---- one activation site per call: the fine-grained entry points in sequence (no arithmetic of its own) --------------
 int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, qs_stream_t stream) {
+                int64_t t_q, void* image_out, int imgdt, qs_stream_t stream) {
     if (!p || !x || !y || p->N < 1 || p->C < 2 || p->H < 1 || p->W < 1 || (p->layout != 0 && p->layout != 1)) return QS_ERR_ARG;
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
@@ -180,7 +180,8 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, cm ? outer : 1, cm ? p->C : 1, cm ? inner : outer * p->C * inner,
-                               p->xdt, p->ydt, QS_F32, 0, 0, 0, pre_relu, (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, stream);
+                               p->xdt, p->ydt, QS_F32, 0, 0, 0, pre_relu, (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out,
+                               imgdt, stream);
 }
 
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
@@ -210,7 +211,7 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
         if (st) return st;
     }
     return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, 0, 0, 0, pre_relu, 0, gate_out,
-                               stream);
+                               nullptr, 0, stream);
 }
 
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------

@@ -168,7 +168,7 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         return with_dtype(dt, [&](auto D) {
             constexpr int DD = decltype(D)::value;
             if (gate_out) {      // the folded ReLU's gate bitmap for the backward (GateOp, qs_elementwise.h)
-                GateOp<ChanMaskOp> gop{op, gate_out, elide_masked != 0};
+                GateOp<ChanMaskOp> gop{op, gate_out, elide_masked != 0, nullptr, QS_BF16};
                 return launch_ew<GateOp<ChanMaskOp>, DD, DD>(gop, plan, true, x, y, nullptr, s);
             }
             return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s, elide_masked != 0);

@@ -3,14 +3,37 @@
 // point only enqueues work on the caller's stream.
 #include "qs_host_ew.h"
 
+namespace {
+// the image of a quantizer's float32 output is written by the gate-recording widening kernels only (ew_widen_kernel<GateOp<..>>):
+// float32 output, no codes, a gate bitmap, and a geometry those kernels serve (launch_ew_impl's own conditions)
+bool image_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
+                    const uint8_t* gate_out, int xdt, int ydt, int imgdt, const void* image_out) {
+    if (!gate_out || codes || ydt != QS_F32 || (imgdt != QS_BF16 && imgdt != QS_F16) || !aligned16(image_out)) return false;
+    EwPlan plan;
+    if (plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask)) != QS_OK) return false;
+    const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
+    return ew_widen() >= (xdt == QS_F32 ? 2 : 1) && cm_w != CM_ELEM;
+}
+}  // namespace
+
 extern "C" {
+
+int qs_quant_image_ok(int64_t outer, int64_t C, int64_t inner, int per_channel_param, int has_mask, int mask_aligned8, int xdt) {
+    static const uint8_t dummy_gate = 0;
+    alignas(16) static const char img[16] = {0};
+    // (only the alignment class of the mask pointer matters to the plan: an aligned or a deliberately odd stand-in)
+    alignas(8) static const uint8_t mask8[16] = {0};
+    const uint8_t* cm = has_mask ? (mask_aligned8 ? mask8 : mask8 + 1) : nullptr;
+    return image_route_ok(outer, C, inner, per_channel_param != 0, cm, nullptr, &dummy_gate, xdt, QS_F32, QS_BF16, img) ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked, uint8_t* gate_out,
-                        qs_stream_t stream) {
+                        void* image_out, int imgdt, qs_stream_t stream) {
     if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
+    if (image_out && !image_route_ok(outer, C, inner, nscale > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -27,7 +50,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
             if (gate_out) {
-                GateOp<ScalerFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr};
+                GateOp<ScalerFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt};
                 return launch_ew<GateOp<ScalerFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
             }
             return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
@@ -40,8 +63,9 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
                          float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
                          int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, int pre_relu,
-                         int elide_masked, uint8_t* gate_out, qs_stream_t stream) {
+                         int elide_masked, uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream) {
     if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
+    if (image_out && !image_route_ok(outer, C, inner, ndecimal > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -58,7 +82,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
             DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
             if (gate_out) {
-                GateOp<DecimalFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr};
+                GateOp<DecimalFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt};
                 return launch_ew<GateOp<DecimalFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
             }
             return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);

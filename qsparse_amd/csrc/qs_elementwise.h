@@ -295,20 +295,39 @@ struct GateOp : Base {
     uint8_t* gate;      // ceil(numel / 8) bytes
     int zero_pruned;    // the caller asked for elision: a pruned channel's x counts as +0.0, as in the eliding kernels, so that
                         // a site gives the same bits with and without the bitmap (NaN / Inf on a pruned channel, quirk B15)
+    void* image;        // nullable: the low-precision IMAGE of the float32 output -- RNE(y) in image_dt, the very cast autocast
+    int image_dt;       // applies to y in front of a convolution -- written by the same pass (+2 B/elem instead of a 6 B/elem pass)
     __device__ __forceinline__ float apply(float v, const typename Base::P& p, int32_t& code) const {
         if (zero_pruned && p.keep == 0.0f) v = 0.0f;
         return Base::apply(v, p, code);
     }
 };
+// N (4 or 8) consecutive results starting at element e (a multiple of N) into the image: one 8- / 16-byte store
+template <int N>
+__device__ __forceinline__ void image_store(void* img, int dt, int64_t e, const float* r) {
+    uint32_t w[N / 2];
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        const uint32_t lo = (dt == QS_BF16) ? f32_to_bf16_bits(r[2 * j]) : f32_to_f16_bits(r[2 * j]);
+        const uint32_t hi = (dt == QS_BF16) ? f32_to_bf16_bits(r[2 * j + 1]) : f32_to_f16_bits(r[2 * j + 1]);
+        w[j] = lo | (hi << 16);
+    }
+    if constexpr (N == 8) *(u32x4*)((uint16_t*)img + e) = u32x4{w[0], w[1], w[2], w[3]};
+    else *(u32x2*)((uint16_t*)img + e) = u32x2{w[0], w[1]};
+}
 template <typename Op>
 struct OpGate {
     static constexpr bool value = false;
     __device__ __forceinline__ static uint8_t* ptr(const Op&) { return nullptr; }
+    __device__ __forceinline__ static void* image(const Op&) { return nullptr; }
+    __device__ __forceinline__ static int image_dt(const Op&) { return QS_BF16; }
 };
 template <typename Base>
 struct OpGate<GateOp<Base>> {
     static constexpr bool value = true;
     __device__ __forceinline__ static uint8_t* ptr(const GateOp<Base>& op) { return op.gate; }
+    __device__ __forceinline__ static void* image(const GateOp<Base>& op) { return op.image; }
+    __device__ __forceinline__ static int image_dt(const GateOp<Base>& op) { return op.image_dt; }
 };
 template <int N>
 __device__ __forceinline__ uint32_t gate_bits(const float* v) {
@@ -654,6 +673,17 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                     b[j] = __float_as_uint(op.apply(v[4 + j], p, q));
                 }
             }
+            if constexpr (GATE) {
+                if (void* img = OpGate<Op>::image(op)) {   // the lane's 8 results are 8 consecutive elements: one 16-byte store
+                    float r[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        r[j] = __uint_as_float(a[j]);
+                        r[4 + j] = __uint_as_float(b[j]);
+                    }
+                    image_store<8>(img, OpGate<Op>::image_dt(op), e, r);
+                }
+            }
             *(u32x4*)(ws + lane * 8) = a;              // wave-private LDS region: no workgroup barrier
             *(u32x4*)(ws + lane * 8 + 4) = b;
             __builtin_amdgcn_wave_barrier();
@@ -728,6 +758,12 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                 else out[j] = __float_as_uint(op.apply(v[j], p, q));
             }
             st16<(NT && QS_WIDEN_NT_STORE != 0)>((u32x4*)(y + e), out);
+            if constexpr (GATE) {
+                if (void* img = OpGate<Op>::image(op)) {
+                    const float r[4] = {__uint_as_float(out[0]), __uint_as_float(out[1]), __uint_as_float(out[2]), __uint_as_float(out[3])};
+                    image_store<4>(img, OpGate<Op>::image_dt(op), e, r);
+                }
+            }
         }
     }
     // ragged tail (numel % 8 elements)
@@ -743,6 +779,12 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
         const float xe = load1<XDT>(x, e);
         if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, !(xe <= 0.0f));
         y[e] = op.apply(xe, p, qi);
+        if constexpr (GATE) {
+            if (void* img = OpGate<Op>::image(op)) {
+                if (OpGate<Op>::image_dt(op) == QS_BF16) store1<QS_BF16>(img, e, y[e]);
+                else store1<QS_F16>(img, e, y[e]);
+            }
+        }
     }
 }
 

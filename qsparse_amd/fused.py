@@ -119,11 +119,11 @@ class _FusedApply(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------------
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
-    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used")
+    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused")
 
     def __init__(self):
         self.key = None
-        self.image_ok, self.image_made, self.image_used = True, False, False
+        self.image_ok, self.image_made, self.image_used, self.image_fused = True, False, False, False
 
     def __deepcopy__(self, memo):        # a cache of raw pointers never travels: copies and pickles rebuild their own
         return _SitePlan()
@@ -177,6 +177,9 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     c.prune_n_updates, c.quant_n_updates, c.callback_t = p._n_updates.data_ptr(), q._n_updates.data_ptr(), cb.t.data_ptr()
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
+    # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
+    outer, inner = (N * H * W, 1) if cl else (N, H * W)
+    plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
     import ctypes
     plan.c, plan.ref = c, ctypes.byref(c)
     q.__dict__["_qs_site_plan"] = plan
@@ -254,15 +257,19 @@ class _SiteStep(torch.autograd.Function):
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
         bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if want_gate else None
-        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q)
+        make_image = image_dtype is not None and (want_gate or not ctx.needs_input_grad[0])
+        # the image comes out of the forward kernel itself when that kernel records a gate and serves this geometry with the mask
+        fused_image = make_image and want_gate and plan.image_fused and not (flags & _hip.SITE_NO_MASK)
+        img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
+        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img)
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
                               bits_t if want_gate else (h if keep_x else h.new_empty(0)))
         ctx.set_materialize_grads(False)
-        if image_dtype is not None and (want_gate or not ctx.needs_input_grad[0]):
-            return y, y.to(image_dtype)             # RNE, the cast autocast would apply to y in front of a convolution
+        if make_image:
+            return y, (img if fused_image else y.to(image_dtype))      # RNE(y): the cast autocast would apply in front of a convolution
         return y
 
     @staticmethod

@@ -90,15 +90,20 @@ class Net(nn.Module):
 
 @pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("residual,second", [(False, False), (True, False), (False, True), (True, True)])
-def test_sites_with_real_consumers_are_value_identical(cl, residual, second):
+@pytest.mark.parametrize("shape,xdt", [((6, 16, 8, 8), torch.bfloat16), ((3, 16, 32, 32), torch.bfloat16), ((4, 24, 7, 7), torch.bfloat16),
+                                       ((5, 8, 14, 14), torch.float32), ((2, 16, 32, 32), torch.float32), ((6, 16, 8, 8), torch.float16)])
+def test_sites_with_real_consumers_are_value_identical(cl, residual, second, shape, xdt):
+    """(rows of 64 / 1024 elements, ragged 7x7 maps whose image is a cast of y, float32 inputs as behind a residual add: every
+    route by which the image is made -- by the forward kernel itself or by a cast -- and consumed)"""
     runs = []
+    C, W = shape[1], shape[3]
     for image in (False, True):
         qs.set_qsparse_options(autocast_image=image)
         try:
-            net = Net(16, 8, residual, second).to(DEV).train()
+            net = Net(C, W, residual, second).to(DEV).train()
             trace = []
             for s in range(5):
-                x = (torch.randn(6, 16, 8, 8, generator=gen(20 + s)) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().to(DEV)
+                x = (torch.randn(shape, generator=gen(20 + s)) * torch.linspace(0.3, 3, C).view(1, -1, 1, 1)).to(xdt).to(DEV)
                 if cl:
                     x = x.contiguous(memory_format=torch.channels_last)
                 x.requires_grad_(True)
