@@ -12,6 +12,6 @@ meta=$(grep '^{' $d.stdout | tail -1)
 trace=$(find $d -name '*kernel_trace.csv' | head -1)
 stats=$(find $d -name '*kernel_stats.csv' | head -1)
 python3 $root/tools/family_table.py $trace "$meta" > $out/${tag}_family_table.txt
-cp $stats $out/${tag}_kernel_stats.csv
-echo "$meta" > $out/${tag}_meta.json
+cp $stats $out/${tag}_model_kernel_stats.csv
+echo "$meta" > $out/${tag}_model_meta.json
 cat $out/${tag}_family_table.txt | head -40

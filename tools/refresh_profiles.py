@@ -23,7 +23,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 MODE_ALL = len(sys.argv) > 2 and sys.argv[2] == "all"
 MODE_GATE = len(sys.argv) > 2 and sys.argv[2] == "gate"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
