@@ -349,36 +349,36 @@ def resnet_config(arch, batch, device, steps):
         del model, step, gr
         torch.cuda.empty_cache()
 
-        # the same network with every opt-in extension of the library switched on (none of them is the default, none of
-        # them enters the numbers above): bf16 outputs instead of the reference's fp32 promotion (preserve_dtype),
-        # backward / mask-apply elision.  (The multi-tensor weight path is part of the default since round 3.)
-        qs.set_qsparse_options(preserve_dtype=True, elide_pruned="all")
-        model, step = build(True)
-        for _ in range(8):
-            step()
-        opt_in = {"options": "preserve_dtype=True, elide_pruned='all'",
-                  "pq_ms": round(_timed_loop(step, steps), 3)}
-        if graphs.steady_state(model):
-            gr = capture(step)
-            opt_in["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
-            del gr
-        opt_in["best_over_plain"] = round(min(v for k, v in opt_in.items() if k.endswith("_ms")) /
-                                          min(out["plain_ms"], out["plain_graph_ms"]), 4)
-        out["opt_in_extensions"] = opt_in
-        del model, step
-        torch.cuda.empty_cache()
+        # the same network with every numerics-changing opt-in extension of the library switched on (none of them is the
+        # default, none of them enters the numbers above): bf16 outputs instead of the reference's fp32 promotion
+        # (preserve_dtype), backward / mask-apply elision.  (The multi-tensor weight path is part of the default since round 3.)
+        def opt_in_run(key, label, graph, **options):
+            """an opt-in configuration measured like the default one; its failure is recorded under its own key only"""
+            try:
+                qs.set_qsparse_options(**options)
+                model, step = build(True)
+                for _ in range(8):
+                    step()
+                rec = {"options": label, "pq_ms": round(_timed_loop(step, steps), 3)}
+                if graph and graphs.steady_state(model):
+                    gr = capture(step)
+                    rec["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
+                    del gr
+                rec["best_over_plain"] = round(min(v for k, v in rec.items() if k.endswith("_ms")) /
+                                               min(out["plain_ms"], out["plain_graph_ms"]), 4)
+                del model, step
+            except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
+                rec = {"options": label, "error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                qs.set_qsparse_options(preserve_dtype=False, elide_pruned="forward", autocast_image=False)
+                torch.cuda.empty_cache()
+            out[key] = rec
 
+        opt_in_run("opt_in_extensions", "preserve_dtype=True, elide_pruned='all'", True, preserve_dtype=True, elide_pruned="all")
         # the value-identical opt-in: under autocast every fused site hands its first convolution the bf16 image of its
         # float32 output and takes that convolution's bf16 gradient as it is (fused.py "Autocast image") -- same values as
-        # the default path, no fp32 <-> bf16 cast pass in the backward; opt-in because the site's output is a Tensor subclass
-        qs.set_qsparse_options(preserve_dtype=False, elide_pruned="forward", autocast_image=True)
-        model, step = build(True)
-        for _ in range(8):
-            step()
-        img = {"options": "autocast_image=True (value-identical)", "pq_ms": round(_timed_loop(step, steps), 3)}
-        img["over_plain"] = round(img["pq_ms"] / min(out["plain_ms"], out["plain_graph_ms"]), 4)
-        out["value_identical_opt_in"] = img
-        del model, step
+        # the default path, no fp32 <-> bf16 cast passes around the site; opt-in because the site's output is a Tensor subclass
+        opt_in_run("value_identical_opt_in", "autocast_image=True (value-identical)", True, autocast_image=True)
     finally:
         qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward", autocast_image=False)
         torch.cuda.empty_cache()

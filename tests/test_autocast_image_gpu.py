@@ -190,3 +190,38 @@ def test_the_image_is_taken_once_and_only_when_it_is_still_valid():
             assert torch.equal(a, F.linear(site(x), w))
     finally:
         qs.set_qsparse_options(autocast_image=False)
+
+
+def test_whole_step_graph_capture_with_the_image_equals_eager():
+    """the subclass dispatch is host-side only: a captured and replayed training step (graphs.GraphedStep) with the extension
+    on gives the eager results"""
+    from qsparse_amd import graphs
+    outs = []
+    try:
+        for graphed in (False, True):
+            qs.set_qsparse_options(autocast_image=True, graph_safe=True)
+            net = Net(16, 8, True, False).to(DEV).train()
+
+            def train_step(x):
+                x = x.detach().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y, out = net(x)
+                (gx,) = torch.autograd.grad(out.sum(), x)
+                return y.as_subclass(torch.Tensor), out, gx
+
+            step = graphs.GraphedStep(net, train_step, settle=1) if graphed else train_step
+            trace = []
+            for s in range(8):
+                x = (torch.randn(6, 16, 8, 8, generator=gen(60 + s)) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().to(DEV)
+                y, out, gx = step(x)
+                trace += [y.detach().clone(), out.detach().clone(), gx.clone()]
+            if graphed:
+                assert step.captured
+                step.finish()
+            outs.append((trace, net.site[0][1].mask.clone(), net.site[1].weight.clone()))
+    finally:
+        qs.set_qsparse_options(autocast_image=False, graph_safe=False)
+    (ta, ma, sa), (tb, mb, sb) = outs
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert same(a.cpu(), b.cpu()), i
+    assert torch.equal(ma, mb) and torch.equal(sa, sb)
