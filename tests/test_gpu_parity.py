@@ -381,9 +381,12 @@ def test_abi_rejects_bad_arguments_loudly():
         quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
     lib = _hip.load()
     y = torch.empty(64, device=DEV)
-    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None)
+    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None)
     assert st == -3 and b"aligned" in lib.qs_status_string(st)
-    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None) == -1
+    # an image without a gate bitmap (or from a geometry the gate-recording kernels do not serve) is rejected, nothing enqueued
+    img = torch.empty(64, device=DEV, dtype=torch.bfloat16)
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 64, 0, 0, 0, 0, 0, 0, 1, 0, None, img.data_ptr(), 1, None) == -2
     # odd storage offsets are re-packed by the binding instead of failing
     base = torch.randn(1001, device=DEV)
     assert same(quantize_with_scaler(base[1:], 8, 0.1).cpu(), O.scaler_fwd(base[1:].cpu(), 8, 0.1))
@@ -523,7 +526,7 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
-                                       1, 0, 0, 0, 0, 0, 0, 1, None, stream) == 0
+                                       1, 0, 0, 0, 0, 0, 0, 1, None, None, 0, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
                                     N, C, H * W, 0, 1, 0, stream) == 0
 
