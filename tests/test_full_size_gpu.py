@@ -149,3 +149,30 @@ def test_config2_quantize8_three_live_steps_equal_the_oracle_on_the_full_tensor(
         assert _bits_equal(q.weight.detach().cpu(), qsim.weight), ("scale", s)
         assert (q._n_updates.item(), q.callback.t) == (qsim.n_updates, qsim.shared["t"]), ("counters", s)
         del y, gx, y_ref, gx_ref
+
+
+@pytest.mark.parametrize("kind", ["decimal", "adaptive"])
+def test_config2_size_other_quantizers_equal_the_oracle_on_the_full_tensor(kind):
+    """the other two quantizers of the reference on the config-2 tensor (256x64x56x56 bf16), live statistics:
+    DecimalQuantizer (power-of-two scale from the running abs-max, truncation; quantize.py:31-63, 312-349) tensor-wise and
+    AdaptiveQuantizer (running min/max lines per channel; :141-181, 393-430)"""
+    if kind == "decimal":
+        q = qs.quantize(bits=8, channelwise=-1, timeout=1, callback=qs.DecimalQuantizer()).to(DEV).train()
+        qsim = O.QuantizeSim("decimal", 8, -1, 1)
+    else:
+        q = qs.quantize(bits=8, channelwise=1, timeout=1, callback=qs.AdaptiveQuantizer()).to(DEV).train()
+        qsim = O.QuantizeSim("adaptive", 8, 1, 1)
+    for s in range(3):
+        x, gout = _inputs(CONFIG2, s, False, True)
+        y_ref = qsim.step(x.cpu(), True)
+        x.requires_grad_(True)
+        y = q(x)
+        if s == 0:
+            assert y is x
+            continue
+        (gx,) = torch.autograd.grad(y, x, gout)
+        gx_ref = qsim.grad(gout.cpu(), torch.bfloat16)
+        assert _bits_equal(y.detach(), y_ref.to(DEV)), ("output", kind, s)
+        assert _bits_equal(gx, gx_ref.to(DEV)), ("input gradient", kind, s)
+        assert _bits_equal(q.weight.detach().cpu(), qsim.weight), ("state", kind, s)
+        del y, gx, y_ref, gx_ref
