@@ -256,10 +256,11 @@ class _SiteStep(torch.autograd.Function):
     def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None):
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
-        bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if want_gate else None
         make_image = image_dtype is not None and (want_gate or not ctx.needs_input_grad[0])
-        # the image comes out of the forward kernel itself when that kernel records a gate and serves this geometry with the mask
-        fused_image = make_image and want_gate and plan.image_fused and not (flags & _hip.SITE_NO_MASK)
+        # the image comes out of the forward kernel itself when the gate-recording kernels serve this geometry with the mask
+        # (forward-only calls -- evaluation, serving -- let them record a bitmap nobody reads: 1/8 B/elem for a 6 B/elem pass)
+        fused_image = bool(make_image and (flags & _hip.SITE_PRE_RELU) and plan.image_fused and not (flags & _hip.SITE_NO_MASK))
+        bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if (want_gate or fused_image) else None
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
         _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img)
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate

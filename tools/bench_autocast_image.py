@@ -55,6 +55,43 @@ def run(image, pq=True, steps=10):
     return ms, losses
 
 
+def run_eval(image, pq=True, steps=20):
+    """inference: evaluation mode, no_grad, autocast -- after a few training steps so that masks and scales exist"""
+    qs.set_qsparse_options(autocast_image=image)
+    torch.manual_seed(0)
+    model, shape = (resnet18(10, True), (batch, 3, 32, 32)) if arch == "resnet18" else (resnet50(1000, False), (batch, 3, 224, 224))
+    if pq:
+        model = convert_pq(model, sparsity=0.5 if arch == "resnet18" else 0.75, bits=4, prune_start=1, prune_interval=1, repetition=1,
+                           quant_timeout=1)
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(3):
+            model(x).float().sum().backward()
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(5):
+            out = model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(x)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    res = out.float().clone()
+    del model
+    torch.cuda.empty_cache()
+    return ms, res
+
+
+if "--eval" in sys.argv:
+    p_ms, _ = run_eval(False, pq=False)
+    a_ms, a = run_eval(False)
+    b_ms, b = run_eval(True)
+    print(f"{arch} b{batch} inference: plain {p_ms:.2f} ms, pq {a_ms:.2f} ms ({a_ms / p_ms:.3f}x), pq + autocast_image {b_ms:.2f} ms "
+          f"({b_ms / p_ms:.3f}x); outputs equal: {torch.equal(a, b)}")
+    sys.exit(0)
+
 plain, _ = run(False, pq=False)
 off, la = run(False)
 off2, la2 = run(False)
