@@ -50,7 +50,9 @@ def main():
     # wall time of the K steps: first launch of the window to the end of the last kernel of the trace
     t0 = int(tail[0]["Start_Timestamp"])
     t1 = max(int(r["End_Timestamp"]) for r in rows)
-    print(f"{meta['arch']} batch {meta['batch']}, channels_last, bf16 autocast, default options: last {steps} steps of the trace, "
+    opts = "autocast_image=True (bytes are those of the DEFAULT mode: the backward reads 2 instead of 4 B/elem of gradient here)" \
+        if meta.get("autocast_image") else "default options"
+    print(f"{meta['arch']} batch {meta['batch']}, channels_last, bf16 autocast, {opts}: last {steps} steps of the trace, "
           f"{meta['launches_per_step']} library launches per step; step wall time ~{(t1 - t0) / 1e6 / steps:.2f} ms")
     print("(durations: rocprofv3 --kernel-trace; bytes: every data operand of a launch once, dense, in the dtype/layout the site saw)\n")
     total_ms = sum(v[0] for v in fam.values()) / 1e3 / steps
@@ -61,6 +63,19 @@ def main():
         gb = meta["families"].get(f, {}).get("GB", 0.0)
         print(f"{f:12s} {ms:8.3f} {n // steps:9d} {gb:8.3f} {gb / ms * 1e3 if gb else 0:8.0f} {gb / ms * 1e3 / PEAK if gb else 0:10.3f}")
     print(f"{'all':12s} {total_ms:8.3f} {want // steps:9d} {total_gb:8.3f} {total_gb / total_ms * 1e3:8.0f} {total_gb / total_ms * 1e3 / PEAK:10.3f}\n")
+    # ATen's cast passes around the sites (the fp32-promotion tax), same window of the trace
+    t_first = int(tail[0]["Start_Timestamp"])
+    casts = {}
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= t_first and ("bfloat16_copy_kernel" in r["Kernel_Name"] or "bfloat16tofloat32" in r["Kernel_Name"]
+                                                      or "float16" in r["Kernel_Name"] and "copy_kernel" in r["Kernel_Name"]):
+            k = "fp32 -> bf16 casts" if "bfloat16_copy_kernel" in r["Kernel_Name"] else "bf16 -> fp32 casts"
+            a = casts.setdefault(k, [0.0, 0])
+            a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a[1] += 1
+    for k, (us, n) in sorted(casts.items()):
+        print(f"(not library) ATen {k}: {us / 1e3 / steps:.3f} ms/step in {n / steps:.1f} launches")
+    print()
     print(f"{'kernel':100s} {'family':10s} {'ms/step':>8s} {'calls/step':>10s} {'avg us':>8s}")
     for k, (us, n, f) in sorted(ker.items(), key=lambda kv: -kv[1][0]):
         print(f"{k[:100]:100s} {f:10s} {us / 1e3 / steps:8.3f} {n / steps:10.1f} {us / n:8.1f}")

@@ -27,7 +27,8 @@ def main():
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     dev = torch.device("cuda", 0)
-    qs.set_qsparse_options(log_on_created=False, log_during_train=False,
+    image = os.environ.get("QS_PROFILE_IMAGE", "0") == "1"          # the value-identical opt-in (fused.py "Autocast image")
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, autocast_image=image,
                            batch_weights=os.environ.get("QS_PROFILE_NO_BATCHER", "0") != "1")
     if arch == "resnet18":
         model, shape, classes, sparsity = resnet18(10, True), (batch, 3, 32, 32), 10, 0.5
@@ -55,7 +56,11 @@ def main():
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    print(json.dumps({"arch": arch, "batch": batch, "steps": steps, "launches_per_step": acct["launches"],
+    if image:
+        # the event log keeps to the fine-grained entry points (one gradient stream): count the launches of a real step instead
+        from qsparse_amd import fused
+        acct["launches"] = int(os.environ.get("QS_PROFILE_LAUNCHES", acct["launches"]))
+    print(json.dumps({"arch": arch, "batch": batch, "steps": steps, "launches_per_step": acct["launches"], "autocast_image": image,
                       "families": {k: {"GB": v["GB"], "launches": v["launches"]} for k, v in acct["families"].items()},
                       "algorithmic_GB_per_step": acct["algorithmic_GB_per_step"]}))
 
