@@ -35,6 +35,8 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from torch.nn.modules import module as _m
+
 from qsparse_amd import _hip
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
 from qsparse_amd.util import get_option, logging
@@ -114,8 +116,6 @@ def _eligible(layer: nn.Module) -> bool:
 def _hooked(q: QuantizeLayer) -> bool:
     """hooks on the quantizer or its callback (or global module hooks) must see the calls they were registered for: such a
     layer keeps its inline path"""
-    from torch.nn.modules import module as _m
-
     if _m._global_forward_hooks or _m._global_forward_pre_hooks:
         return True
     return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (q, q.callback))

@@ -19,8 +19,11 @@ The state machines of both layers (schedules, counters, refresh policy: referenc
 The same idea one operator at a time: ``FusedActQuantize`` and ``FusedActPrune`` fold a plain ``nn.ReLU`` into a lone
 quantize / prune site (``Sequential(act, op)``), see the classes below.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
+from torch.nn.modules import module as _m
 
 from qsparse_amd import _hip
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer, _out_dtype
@@ -180,7 +183,6 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
-    import ctypes
     plan.c, plan.ref = c, ctypes.byref(c)
     q.__dict__["_qs_site_plan"] = plan
     return plan
@@ -303,7 +305,8 @@ class _SiteStep(torch.autograd.Function):
             bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
             _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul)
             return (gx,) + (None,) * (n_in - 1)
-        mask = mask_c if mask_c.numel() else None
+        mask = mask_c.detach().view(-1) if mask_c.numel() else None      # (the layers' own parameters were saved, not aliases)
+        scale = scale.detach()
         if pre_relu:
             gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, False, lo_mul, hi_mul, mask, gate=gate)
@@ -371,13 +374,14 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     world = qdist.stats_world_size()
     if (live or idle) and not qdist.exchange_active(world) and not _hip.logging_events():
         site = _site_plan(p, q, h)
+    if site is not None and live:        # the counters ride in the select launch, as on the fine-grained route (the flags
+        bump_p = bump_q = bump_t = True   # below only ask WHETHER they did)
+        select_bumped_tq = bool(get_option("graph_safe"))
     with torch.no_grad():
-        hd = h.detach()
+        hd = h.detach() if site is None else None
         stage = chan_absmax = record = None
         if site is not None:
-            if live:        # the counters ride in the select launch, as on the fine-grained route
-                bump_p, bump_q, bump_t = p._n_updates.data, q._n_updates.data, cb.t.data
-                select_bumped_tq = bool(get_option("graph_safe"))
+            pass
         elif update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)
@@ -466,7 +470,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         site.image_made = site.image_used = False
         image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
         out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
-                              p.mask.data.view(-1) if prune_on else None, q.weight.data, image_dtype)
+                              p.mask if prune_on else None, q.weight, image_dtype)
         if type(out) is tuple:
             y, img = out
             site.image_made = True
@@ -482,8 +486,6 @@ def _hooked(*modules) -> bool:
     """hooks registered on a child (forward, forward-pre, backward, backward-pre) or installed globally for all modules:
     the fused forward never calls the children, so their hooks would not fire -- such a site runs module by module,
     exactly as the plain ``Sequential`` it replaces"""
-    from torch.nn.modules import module as _m
-
     if (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks
             or _m._global_backward_pre_hooks):
         return True
