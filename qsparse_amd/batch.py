@@ -16,7 +16,11 @@ undoes it).  It is safe by construction for anything a forward pass may do:
     (imitation.py:61-68).  A layer whose precomputed weight was NOT consumed by the end of the root's forward -- a branch
     the forward skipped, an exception half-way -- is rolled back to exactly the state it had before: running scale (from
     the backup ``qs_multi_scale_update`` wrote), ``_n_updates``, the callback's ``t`` (host and device copy) and
-    ``_quantized``.  The forward hook that does this also runs when the forward raised.
+    ``_quantized``.  The forward hook that does this also runs when the forward raised.  Such a layer's weight receives NO
+    gradient from its place in the hand-out node (like the layer the reference never evaluated: ``.grad`` stays ``None``, an
+    optimizer with weight decay does not touch it) -- except under an initialised process group, where
+    ``DistributedDataParallel`` counts the parameter as used and waits for a gradient: there it contributes zeros, as DDP's
+    own unused parameters do.
   * A weight that is read a second time in the same forward takes the inline path, as the second read of the reference.
   * A weight written between the precomputation and its read is rolled back and re-evaluated inline.  The write is seen
     through ``Tensor._version`` (every in-place operation); the one route that bypasses the counter is ``param.data``.  The
@@ -56,10 +60,14 @@ class _GroupSte(torch.autograd.Function):
     multi-tensor launch (qs_multi_ste_bwd) -- instead of one node, one Python backward and one 4 us launch per layer."""
 
     @staticmethod
-    def forward(ctx, meta, *tensors):
+    def forward(ctx, meta, dead, *tensors):
         k = len(meta)
-        ctx.meta = meta                                     # per layer: (is_decimal, lo_mul, hi_mul, passthrough)
+        ctx.meta, ctx.dead = meta, dead                     # per layer: (is_decimal, lo_mul, hi_mul, passthrough); rolled back?
+        ctx.shapes = [(w.shape, w.stride()) for w in tensors[:k]]
         ctx.save_for_backward(*tensors[2 * k:])             # the steps (scale or decimal, one element each)
+        # a member whose weight is never read gets NO gradient, exactly like the layer the reference never evaluated
+        # (zero_grad(set_to_none=True) + weight decay would otherwise start to move a parameter the forward did not use)
+        ctx.set_materialize_grads(False)
         return tuple(y.view_as(y) for y in tensors[k:2 * k])
 
     @staticmethod
@@ -67,8 +75,18 @@ class _GroupSte(torch.autograd.Function):
         meta, steps = ctx.meta, ctx.saved_tensors
         k = len(meta)
         out = [None] * k
+        if any(ctx.dead):
+            # the one combination in which "no gradient" is not an option: DistributedDataParallel counts this parameter as
+            # used (it is reachable through the group's node) and waits for its gradient -- there a rolled-back member
+            # contributes zeros, what DDP itself uses for a parameter that is unused on a rank
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                for i in range(k):
+                    if ctx.dead[i] and grads[i] is None and ctx.needs_input_grad[2 + i]:
+                        shape, stride = ctx.shapes[i]
+                        out[i] = torch.empty_strided(shape, stride, dtype=torch.float32, device=steps[i].device).zero_()
         for decimal in (False, True):
-            idx = [i for i in range(k) if grads[i] is not None and ctx.needs_input_grad[1 + i] and meta[i][0] == decimal
+            idx = [i for i in range(k) if grads[i] is not None and ctx.needs_input_grad[2 + i] and meta[i][0] == decimal
                    and not meta[i][3]]
             fast = [i for i in idx if grads[i].dtype == torch.float32 and grads[i].data_ptr() % 16 == 0
                     and (grads[i].is_contiguous() or (grads[i].dim() == 4 and grads[i].is_contiguous(memory_format=torch.channels_last)))]
@@ -91,7 +109,7 @@ class _GroupSte(torch.autograd.Function):
         for i in range(k):
             if out[i] is None and grads[i] is not None and meta[i][3]:
                 out[i] = grads[i]                           # backward_passthrough
-        return (None,) + tuple(out) + (None,) * (2 * k)
+        return (None, None) + tuple(out) + (None,) * (2 * k)
 
 
 def _imitation_depth(layer: nn.Module) -> int:
@@ -133,11 +151,12 @@ class _LaunchPlan(dict):
 
 class _Pending:
     """what has to be undone if a precomputed layer's weight is never read"""
-    __slots__ = ("layer", "slot", "was_quantized", "t_dev", "version", "training")
+    __slots__ = ("layer", "slot", "was_quantized", "t_dev", "version", "training", "dead", "index")
 
     def __init__(self, layer, slot, was_quantized, t_dev, version, training):
         self.layer, self.slot, self.was_quantized, self.t_dev, self.version, self.training = (layer, slot, was_quantized, t_dev,
                                                                                              version, training)
+        self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this layer's place in them
 
 
 def _patched_class(base):
@@ -224,6 +243,8 @@ class WeightBatcher:
         """put the layer back where it was before `_precompute` advanced it (stream-ordered device writes, no sync)"""
         self._consumed(p)
         p.layer.__dict__.pop(_READY, None)
+        if p.dead is not None:
+            p.dead[p.index] = True               # its place in the group's autograd node delivers no gradient
         if not p.training:
             return                               # evaluation-mode hand-outs change no state
         q, qc = p.layer.quantize, p.layer.quantize.callback
@@ -377,10 +398,12 @@ class WeightBatcher:
                 notch = 1 if qc.flip_axis else 0
                 meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough)))
                 steps.append(self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data)
-            ys = _GroupSte.apply(tuple(meta), *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
-            for l, w, y in zip(group, weights[base:base + _GROUP], ys):
+            dead = [False] * len(group)
+            ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
+            for i, (l, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):
                 pending = undo.get(id(l))
                 if pending is None:
                     pending = _Pending(l, slot[id(l)], l.quantize._quantized, None, w._version, False)
+                pending.dead, pending.index = dead, i
                 self._pending.append(pending)
                 l.__dict__[_READY] = (y, pending, self)

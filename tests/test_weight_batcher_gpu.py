@@ -269,3 +269,34 @@ def test_deep_copy_of_a_converted_network_with_warm_caches():
     for a, b in outs:
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
     assert twin.__dict__["_qs_weight_batcher"] is not model.__dict__["_qs_weight_batcher"]
+
+
+def test_a_layer_the_forward_never_reads_receives_no_gradient():
+    """`.grad` of a skipped layer's weight stays None (zero_grad(set_to_none=True) world): an optimizer with weight decay must
+    not start moving a parameter the forward did not use -- with the grouped hand-out node as with the layer-by-layer path"""
+    for batched in (True, False):
+        qs.set_qsparse_options(batch_weights=batched)
+        try:
+            model, _ = _build()
+            model.route = "left"
+            opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=0.1)
+            before = model.right._parameters["weight"].detach().clone()
+            for _ in range(5):
+                opt.zero_grad(set_to_none=True)
+                x = torch.randn(4, 3, 10, 10, device="cuda")
+                model(x).sum().backward()
+                assert model.right._parameters["weight"].grad is None and model.left._parameters["weight"].grad is not None
+                opt.step()
+            assert torch.equal(model.right._parameters["weight"].detach(), before)
+            assert not model.right.quantize.initted
+        finally:
+            qs.set_qsparse_options(batch_weights=True)
+    # once `right` has been read (and is batched from then on), skipping it again still leaves its gradient alone
+    model, _ = _build()
+    for i in range(8):
+        model.route = "right" if i < 4 else "left"
+        model.zero_grad(set_to_none=True)
+        model(torch.randn(4, 3, 10, 10, device="cuda")).sum().backward()
+        if i >= 4:
+            assert model.right._parameters["weight"].grad is None
+    assert model.right.quantize._n_updates.item() == 4
