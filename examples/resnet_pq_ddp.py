@@ -2,7 +2,7 @@
 """BASELINE.json configs 3-5 as a runnable recipe: ResNet-18 (CIFAR shape) / ResNet-50 (ImageNet shape) with 4-bit
 weights and activations + channel pruning of every activation, synthetic data, bf16 autocast, one process per GPU.
 
-    python examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last --graph --batch-weights      # 1 GPU
+    python examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last --graph [--autocast-image]      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last                                   # 8 GPUs
 
@@ -37,8 +37,10 @@ def main(argv=None):
     ap.add_argument("--no-pq", action="store_true", help="the unconverted network, for comparison")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--graph", action="store_true")
-    ap.add_argument("--batch-weights", action="store_true")
+    ap.add_argument("--no-batch-weights", action="store_true", help="layer-by-layer weight quantizers (the multi-tensor path is the default)")
     ap.add_argument("--preserve-dtype", action="store_true")
+    ap.add_argument("--autocast-image", action="store_true",
+                    help="value-identical opt-in: sites hand their first convolution the bf16 image of their float32 output")
     args = ap.parse_args(argv)
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -47,7 +49,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    qs.set_qsparse_options(log_on_created=False, log_during_train=False, preserve_dtype=args.preserve_dtype)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, preserve_dtype=args.preserve_dtype,
+                           batch_weights=not args.no_batch_weights, autocast_image=args.autocast_image)
 
     torch.manual_seed(0)                      # identical initial weights on every rank
     if args.arch == "resnet18":
@@ -64,8 +67,6 @@ def main(argv=None):
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
         x = x.contiguous(memory_format=torch.channels_last)
-    if args.batch_weights and not args.no_pq:
-        qs.WeightBatcher(model)
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
 
