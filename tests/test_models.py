@@ -109,7 +109,7 @@ def test_resnet_recipe_example_runs(capsys):
     from examples import resnet_pq_ddp
     try:
         resnet_pq_ddp.main(["--arch", "resnet18", "--batch", "16", "--steps", "3", "--warmup", "14", "--channels-last", "--graph",
-                            "--batch-weights"])
+                            "--autocast-image"])
     finally:
         qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, log_on_created=True, log_during_train=True)
     out = capsys.readouterr().out
