@@ -194,6 +194,7 @@ class WeightBatcher:
         self._backup = None
         self._eval_key = None
         self._eval_outs = None
+        self._eval_decimals = None
         self._plan = None
         for layer in self.layers:
             if "_qs_batcher_base" not in type(layer).__dict__:
@@ -219,7 +220,7 @@ class WeightBatcher:
         """forget the quantized weights kept for evaluation.  They are reused while no parameter and no scale has been
         written -- detected through ``Tensor._version``, which optimizers, ``load_state_dict`` and any in-place op bump;
         writes through ``param.data`` do not, call this after such a write."""
-        self._eval_key = self._eval_outs = None
+        self._eval_key = self._eval_outs = self._eval_decimals = None
 
     def remove(self):
         self._rollback_all()
@@ -316,7 +317,7 @@ class WeightBatcher:
             eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
                               tuple(w.stride())) for l, w in zip(todo, weights))
             if eval_key == self._eval_key:
-                self._hand_out(todo, weights, self._eval_outs, slot, {})
+                self._hand_out(todo, weights, self._eval_outs, slot, {}, self._eval_decimals)
                 return
         self._eval_key = None
         undo = {}
@@ -381,11 +382,15 @@ class WeightBatcher:
             for decimal, idx, x_ptrs, param_ptrs, numels, nbytes in plan["groups"]:
                 y_ptrs = (_hip.ctypes.c_void_p * len(idx))(*[base + 4 * plan["offsets"][i] for i in idx])
                 _hip.multi_quant_fwd(len(idx), x_ptrs, y_ptrs, param_ptrs, numels, decimal, dev, nbytes=nbytes)
+            # a DecimalQuantizer's backward clamps with the decimal of ITS forward (the reference computes a fresh tensor per
+            # call, quantize.py:312-325, and the Function saves that one, :41): the hand-out nodes get this step's values, not
+            # the buffer the next precomputation overwrites (a ScalerQuantizer's saves the scale parameter itself, :108)
+            decimals = self._decimals.clone() if any(g[0] for g in plan["groups"]) else self._decimals
         if eval_key is not None:
-            self._eval_key, self._eval_outs = eval_key, outs
-        self._hand_out(todo, weights, outs, slot, undo)
+            self._eval_key, self._eval_outs, self._eval_decimals = eval_key, outs, decimals
+        self._hand_out(todo, weights, outs, slot, undo, decimals)
 
-    def _hand_out(self, todo, weights, outs, slot, undo):
+    def _hand_out(self, todo, weights, outs, slot, undo, decimals):
         """park every layer's quantized weight on the layer, `_GROUP` consecutive layers per autograd node (a node per layer
         in evaluation mode under no_grad costs nothing either way)"""
         for base in range(0, len(todo), _GROUP):
@@ -397,7 +402,7 @@ class WeightBatcher:
                 limit = 2.0 ** (q.bits - 1)
                 notch = 1 if qc.flip_axis else 0
                 meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough)))
-                steps.append(self._decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data)
+                steps.append(decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)
             ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
             for i, (l, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):

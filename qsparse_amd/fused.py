@@ -83,6 +83,9 @@ class _FusedApply(torch.autograd.Function):
             ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, h if pre_relu else empty)
             return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
         out_dtype = _out_dtype(h)
+        # what the backward clamps with is what the reference's Function saved: the scale PARAMETER itself for a
+        # ScalerQuantizer (quantize.py:108 -- a later statistics update is seen by an earlier forward's backward), the
+        # decimal computed at THIS forward for a DecimalQuantizer (a fresh tensor, quantize.py:312-325 -> :41)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
         res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
                              pre_relu=pre_relu, want_gate=want_gate)
@@ -91,19 +94,18 @@ class _FusedApply(torch.autograd.Function):
         if want_gate:
             gate = res[2]
             ctx.gate_meta = (gate.shape, gate.dtype, gate.channels_last)
-            ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, gate.bits)
+            ctx.save_for_backward(mask_c if mask_c is not None else empty, param, gate.bits)
         else:
-            ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, h if pre_relu else empty)
+            ctx.save_for_backward(mask_c if mask_c is not None else empty, param, h if pre_relu else empty)
         return res[0]
 
     @staticmethod
     def backward(ctx, g):
-        mask_c, scale, x = ctx.saved_tensors
+        mask_c, step, x = ctx.saved_tensors
         mask_c = mask_c if ctx.has_mask else None
         if not ctx.quant_on:
             return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 7
         limit = 2.0 ** (ctx.bits - 1)
-        step = scale if ctx.kind == "scaler" else _hip.decimal_from_scale(scale)
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,

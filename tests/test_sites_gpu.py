@@ -227,7 +227,12 @@ def test_resnet50_every_operator_site_vs_oracle():
     assert len(final) == 104
     live = [v for v in final.values() if v[3] is not None]
     assert len(live) == 48 and all(v[2] for v in final.values())          # every site quantizes; 48 of the 49 also prune
-    assert all(0.2 <= v[3] <= 0.5 for v in live)
+    # 75 % pruning keeps a quarter of the channels -- plus every tie at the threshold (`>=`, util.py:117): at batch 8 a deep
+    # site can have enough dead (all-zero) channels for the threshold itself to be zero, and which ones are dead varies with
+    # MIOpen's algorithm choice from run to run (0.53 seen once at 1.stages.5.relu2); parity is checked inside run_sites
+    kept = sorted(v[3] for v in live)
+    odd = {k: v[3] for k, v in final.items() if v[3] is not None and not 0.2 <= v[3] <= 0.8}
+    assert not odd and kept[len(kept) // 2] <= 0.35, (odd, kept)
 
 
 @pytest.mark.gpu
