@@ -68,7 +68,13 @@ class _GroupSte(torch.autograd.Function):
         # a member whose weight is never read gets NO gradient, exactly like the layer the reference never evaluated
         # (zero_grad(set_to_none=True) + weight decay would otherwise start to move a parameter the forward did not use)
         ctx.set_materialize_grads(False)
-        return tuple(y.view_as(y) for y in tensors[k:2 * k])
+        ys = tuple(y.view_as(y) for y in tensors[k:2 * k])
+        # a frozen weight (requires_grad=False: fine-tuning a head on a frozen backbone) hands out a quantized weight that
+        # does not require grad either, as layer by layer -- its convolution then skips the weight-gradient pass altogether
+        frozen = [ys[i] for i in range(k) if not ctx.needs_input_grad[2 + i]]
+        if frozen:
+            ctx.mark_non_differentiable(*frozen)
+        return ys
 
     @staticmethod
     def backward(ctx, *grads):
@@ -288,6 +294,8 @@ class WeightBatcher:
                 continue                # first read ever: the inline path creates the layer's state when (and if) it happens
             if not (q.weight.is_cuda and q._n_updates.is_cuda):
                 continue
+            if w.is_inference() or q.weight.is_inference():
+                continue                # created under torch.inference_mode(): no version counter to see a write with
             t = q._steps.read(q._n_updates)
             if t < q.timeout:
                 continue                # identity phase: the inline path only counts

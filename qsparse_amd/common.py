@@ -86,10 +86,13 @@ class HostMirror:
         self._obj, self._version, self._epoch, self._value = None, -1, -1, None
 
     def _stamp(self, p):
+        if p.is_inference():             # no version counter to watch (created under torch.inference_mode()): never trusted
+            self._obj = None
+            return
         self._obj, self._version, self._epoch = p, p._version, p.__dict__.get("_qs_epoch", 0)
 
     def read(self, p: torch.Tensor):
-        if not p.is_cuda and not HostMirror.track_cpu:
+        if (not p.is_cuda and not HostMirror.track_cpu) or p.is_inference():
             return p.item()
         if p is not self._obj or p._version != self._version or p.__dict__.get("_qs_epoch", 0) != self._epoch:
             self._value = _adopt(p).item()

@@ -245,8 +245,8 @@ def _image_dtype(plan, training_needs_gate: bool):
     """dtype of the image this step should produce, or None"""
     if not get_option("autocast_image") or not plan.image_ok or plan.out_dtype != torch.float32:
         return None
-    if not torch.is_autocast_enabled("cuda"):
-        return None
+    if not torch.is_autocast_enabled("cuda") or torch.is_inference_mode_enabled():
+        return None      # (an inference tensor has no version counter: a write to the site's output could not be seen)
     dt = torch.get_autocast_dtype("cuda")
     if dt not in (torch.bfloat16, torch.float16) or (training_needs_gate and not get_option("relu_gate")):
         return None

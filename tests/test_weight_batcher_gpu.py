@@ -300,3 +300,42 @@ def test_a_layer_the_forward_never_reads_receives_no_gradient():
         if i >= 4:
             assert model.right._parameters["weight"].grad is None
     assert model.right.quantize._n_updates.item() == 4
+
+
+class _Probe(nn.Linear):
+    """records whether the weight its forward computes with requires grad"""
+
+    def forward(self, x):
+        w = self.weight
+        self.__dict__["seen"] = w.requires_grad
+        return F.linear(x, w, self.bias)
+
+
+def test_a_frozen_weight_hands_out_a_weight_that_does_not_require_grad():
+    """fine-tuning on a frozen backbone: the quantized weight of a `requires_grad=False` parameter does not require grad -- as
+    layer by layer -- so the layer's backward skips the weight-gradient pass; its neighbours in the hand-out node train on"""
+    res = []
+    for batched in (True, False):
+        qs.set_qsparse_options(batch_weights=batched)
+        try:
+            torch.manual_seed(0)
+            net = nn.Sequential(_Probe(8, 8), nn.Tanh(), _Probe(8, 8), nn.Tanh(), _Probe(8, 4))
+            net = qs.convert(net, qs.quantize(bits=4, channelwise=-1, timeout=1), weight_layers=[_Probe], log=False).cuda().train()
+            assert (net.__dict__.get("_qs_weight_batcher") is not None) == batched
+            net[0]._parameters["weight"].requires_grad_(False)
+            net[2]._parameters["weight"].requires_grad_(False)
+            g = torch.Generator().manual_seed(5)
+            for _ in range(4):
+                net.zero_grad(set_to_none=True)
+                x = torch.randn(6, 8, generator=g).cuda().requires_grad_()
+                net(x).square().sum().backward()
+                assert [net[i].__dict__["seen"] for i in (0, 2, 4)] == [False, False, True]
+                assert net[0]._parameters["weight"].grad is None and net[2]._parameters["weight"].grad is None
+            res.append((x.grad.clone(), net[4]._parameters["weight"].grad.clone(), net[0].bias.grad.clone(),
+                        {k: v.detach().clone() for k, v in net.state_dict().items()}))
+        finally:
+            qs.set_qsparse_options(batch_weights=True)
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
