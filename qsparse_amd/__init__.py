@@ -14,8 +14,8 @@ from qsparse_amd.quantize import (AdaptiveQuantizer, DecimalQuantizer, ScalerQua
                                   quantize_with_decimal, quantize_with_line, quantize_with_scaler)
 from qsparse_amd.sparse import (MagnitudePruningCallback, UniformPruningCallback, devise_layerwise_pruning_schedule,
                                 prune)
-from qsparse_amd.util import (auto_name_prune_quantize_layers, calculate_mask_given_importance,
-                              preload_qsparse_state_dict)
+from qsparse_amd.util import (auto_name_prune_quantize_layers, calculate_mask_given_importance, extra_state_dict,
+                              load_extra_state_dict, preload_qsparse_state_dict)
 from qsparse_amd.util import get_option as get_qsparse_option
 from qsparse_amd.util import set_options as set_qsparse_options
 

@@ -242,6 +242,34 @@ def preload_qsparse_state_dict(model: nn.Module, state_dict: Dict[str, torch.Ten
     return model
 
 
+def extra_state_dict(model: nn.Module) -> Dict[str, Dict[str, int]]:
+    """the two pieces of operator state the reference's ``state_dict`` forgets (quirk B7): ``QuantizeLayer._quantized``
+    (a plain attribute, reference quantize.py:466,505 -- without it a freshly loaded network in ``eval()`` passes its inputs
+    through un-quantized until one training step has run) and the quantizer callback's running-mean count ``t`` (a Python
+    int, quantize.py:307,348 -- without it the running scale restarts at the first resumed step).  Extension:
+    a SEPARATE dict keyed by module path, so ``state_dict()`` keeps the reference's schema key for key; store it next to the
+    checkpoint and hand it to ``load_extra_state_dict`` after ``load_state_dict`` to resume bit-identically."""
+    from qsparse_amd.quantize import QuantizeLayer
+    return {path: {"quantized": int(bool(m._quantized)), "t": int(m.callback.t)}
+            for path, m in model.named_modules() if isinstance(m, QuantizeLayer)}
+
+
+def load_extra_state_dict(model: nn.Module, extra: Dict[str, Dict[str, int]], strict: bool = True) -> nn.Module:
+    """restore what ``extra_state_dict`` saved (a weight and a bias quantizer that share one callback, reference
+    quantize.py:548,559-571, carry the same ``t``)."""
+    from qsparse_amd.quantize import QuantizeLayer
+    layers = {path: m for path, m in model.named_modules() if isinstance(m, QuantizeLayer)}
+    if strict and set(layers) != set(extra):
+        missing, unexpected = sorted(set(layers) - set(extra)), sorted(set(extra) - set(layers))
+        raise KeyError(f"extra state does not match the network: missing {missing}, unexpected {unexpected}")
+    for path, m in layers.items():
+        rec = extra.get(path)
+        if rec is not None:
+            m._quantized = bool(rec["quantized"])
+            m.callback.t = int(rec["t"])     # (a device-resident copy of t notices the change by itself: device_t)
+    return model
+
+
 # ----------------------------------------------------------------------------------------------
 # print-based logger (reference util.py:150-182)
 # ----------------------------------------------------------------------------------------------
