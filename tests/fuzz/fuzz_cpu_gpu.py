@@ -57,7 +57,7 @@ def build(rng):
     while n * c * hw[0] * hw[1] > 1_500_000 and n > 1:
         n = max(1, n // 2)
     shape = (n, c) + hw
-    bits = rng.choice([2, 4, 8])
+    bits = rng.choice([2, 4, 8, 4, 8, 1, 3, 6, 12, 16])
     timeout = rng.choice([0, 1, 2])
     kind, qcb = make_quantizer(rng)
     start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2])
@@ -229,7 +229,7 @@ def one_functional(rng, idx, dry=False):
 ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
 
 
-def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False):
+def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -251,6 +251,10 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             w = m.weight
             gw = torch.randn(w.shape, generator=g)
             outs.append(("w", w.detach().cpu()))
+            if twin and m.training:     # a second read before the first one's backward (siamese recipes): the statistics move on,
+                w2 = m.weight           # each read's backward clamps with what the reference's Function saved for it
+                outs.append(("w2", w2.detach().cpu()))
+                (w2 * 1.0).backward(torch.randn(w2.shape, generator=g).to(device) * 3, retain_graph=True)
             b = m.bias
             if b is not None and b.requires_grad:
                 (w * 1.0).backward(gw.to(device), retain_graph=True)
@@ -270,6 +274,12 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             x = x.contiguous(memory_format=torch.channels_last)
         xd = x.to(device).requires_grad_(True)
         y = m(xd)
+        if twin and m.training:         # a second forward before the first one's backward
+            x2 = (x.detach().float() * 4).to(dtype).to(device).requires_grad_(True)
+            y2 = m(x2)
+            y2.backward((torch.randn(y2.shape, generator=g) * 3).to(y2.dtype).to(device))
+            outs.append(("y2", y2.detach().cpu()))
+            outs.append(("gx2", x2.grad.cpu()))
         gout = torch.randn(y.shape, generator=g).to(y.dtype)
         if channels_last and gout.dim() == 4:
             gout = gout.contiguous(memory_format=torch.channels_last)
@@ -295,7 +305,8 @@ def one_case(rng, idx, dry=False):
     if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact whenever the batch dim is reduced first
         channels_last = (channels_last and 0 not in desc.get("dimensions", [1]) and shape[0] > 1 and len(shape) == 4)
     batcher = rng.random() < 0.6
-    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher)
+    twin = rng.random() < 0.25
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin)
     if dry:
         return None
     if VERBOSE:
@@ -304,7 +315,7 @@ def one_case(rng, idx, dry=False):
     for device in ("cpu", "cuda"):
         try:
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher)
+                                  channels_last, batcher, twin)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
     a, b = results["cpu"], results["cuda"]

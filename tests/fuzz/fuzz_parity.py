@@ -44,7 +44,7 @@ def one_case(rng, idx):
     dtype = rng.choice([torch.bfloat16, torch.float32, torch.float16])
     site_kind = rng.choice(["pair", "pair", "relu_pair", "relu_pair", "q", "relu_q", "p", "relu_p"])
     kind = rng.choice(["scaler", "scaler", "decimal"])
-    bits = rng.choice([2, 4, 8])
+    bits = rng.choice([2, 4, 8, 4, 8, 1, 3, 6, 12, 16])
     sparsity = rng.choice([0.25, 0.5, 0.75, 0.9])
     start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2, 3])
     timeout = rng.choice([1, 2, 3])
