@@ -484,6 +484,64 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                              1 if qc.flip_axis else 0, quant_on, pre_relu)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# nn.ReLU(inplace=True) in front of a site (what torchvision-style networks carry): the ReLU still has to land in x's own
+# storage -- other holders of x see relu(x), as with the plain module -- but its BACKWARD need not be a pass of its own: the
+# fused site that consumes the result gates with the bits it recorded (h > 0 <=> x > 0).  Two nodes without kernels of
+# their own do the bookkeeping: `_OwnedRelu` (x <- relu(x), marked dirty) and `_Tap` (an alias of the result for the site;
+# its backward remembers the gradient the site returned).  When the site is the only consumer of the modified tensor -- the
+# rule -- the gradient arriving at `_OwnedRelu` IS that tensor, already gated: it passes through.  A further consumer of the
+# modified tensor makes autograd hand over a sum instead; that one is gated here (gating twice changes nothing).
+# ----------------------------------------------------------------------------------------------------------------------
+class _OwnedRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cell):
+        x.relu_()
+        ctx.mark_dirty(x)
+        ctx.cell = cell
+        ctx.save_for_backward(x)             # (what ATen's own in-place ReLU keeps for its backward, too)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        gated = ctx.cell.pop("g", None)
+        if g is None or g is gated:
+            return g, None
+        (h,) = ctx.saved_tensors
+        return torch.where(h > 0, g, torch.zeros((), dtype=g.dtype, device=g.device)), None
+
+
+class _Tap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, cell):
+        ctx.cell = cell
+        return h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.cell["g"] = g                    # (holding it also keeps the engine from accumulating INTO this tensor)
+        return g, None
+
+
+def _foldable_relu(act, x) -> int:
+    """0: not a ReLU the kernels can absorb; 1: out-of-place nn.ReLU; 2: nn.ReLU(inplace=True) on a tensor the library may own
+    (a leaf that requires grad raises in the plain module -- let it; in-place on views stays with ATen's view bookkeeping)"""
+    if type(act) is not nn.ReLU or not get_option("fold_relu"):
+        return 0
+    if not act.inplace:
+        return 1
+    if (not isinstance(x, torch.Tensor) or not x.is_cuda or x._is_view() or (x.is_leaf and x.requires_grad)
+            or not get_option("relu_gate")):
+        return 0
+    return 2
+
+
+def _own_relu(x: torch.Tensor) -> torch.Tensor:
+    """x <- relu(x) in place; returns the alias the fused site reads (with `pre_relu`: max(h, 0) == h, the bits are h > 0)"""
+    cell = {}
+    return _Tap.apply(_OwnedRelu.apply(x, cell), cell)
+
+
 def _hooked(*modules) -> bool:
     """hooks registered on a child (forward, forward-pre, backward, backward-pre) or installed globally for all modules:
     the fused forward never calls the children, so their hooks would not fire -- such a site runs module by module,
@@ -506,9 +564,9 @@ class FusedPruneQuantize(nn.Sequential):
         # a plain, out-of-place nn.ReLU in front of an active quantizer is folded into the kernels: relu(x) is
         # never materialised (statistics, apply and backward read x itself); the gate of its backward rides in
         # the fused backward kernel
-        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and q.is_active()
-                and isinstance(x, torch.Tensor) and _eligible(p, q, x)):
-            return fused_prune_quantize(p, q, x, pre_relu=True)
+        fold = _foldable_relu(act, x)
+        if fold and q.is_active() and isinstance(x, torch.Tensor) and _eligible(p, q, x):
+            return fused_prune_quantize(p, q, x if fold == 1 else _own_relu(x), pre_relu=True)
         h = act(x)
         if _eligible(p, q, h):
             return fused_prune_quantize(p, q, h)
@@ -561,9 +619,9 @@ class FusedActQuantize(nn.Sequential):
 
     def forward(self, x):
         act, q = self[0], self[1]
-        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and q.is_active()
-                and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback)):
-            return fused_relu_quantize(q, x)
+        fold = _foldable_relu(act, x)
+        if fold and q.is_active() and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback):
+            return fused_relu_quantize(q, x if fold == 1 else _own_relu(x))
         return q(act(x))
 
 
@@ -578,11 +636,12 @@ class FusedActPrune(nn.Sequential):
 
     def forward(self, x):
         act, p = self[0], self[1]
-        if (type(act) is nn.ReLU and not act.inplace and get_option("fold_relu") and isinstance(x, torch.Tensor)
+        fold = _foldable_relu(act, x)
+        if (fold and isinstance(x, torch.Tensor)
                 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and p.is_active()
                 and type(p.callback) is MagnitudePruningCallback and not p.callback.l0
                 and not p.callback.use_gradient and len(p.dimensions) == 1 and not _hooked(act, p.callback)):
-            return p(x, pre_relu=True)
+            return p(x if fold == 1 else _own_relu(x), pre_relu=True)
         return p(act(x))
 
 

@@ -1,0 +1,125 @@
+"""nn.ReLU(inplace=True) in front of a site (torchvision-style networks).
+
+The plain module writes relu(x) into x's storage and autograd runs a ReLU backward pass of its own.  The fused sites keep
+the first (other holders of x must see relu(x)) and drop the second: `_OwnedRelu` / `_Tap` (qsparse_amd/fused.py) hand the
+site an alias of the modified tensor, the site's backward gates with the bits it recorded, and the gradient passes through
+the in-place node untouched -- unless the modified tensor has a further consumer, whose share is gated there.  Everything is
+compared bit for bit with the module-by-module route (`fold_relu=False`: ATen's relu_ and its backward)."""
+import pytest
+import torch
+import torch.nn as nn
+
+import qsparse_amd as qs
+
+pytestmark = pytest.mark.gpu
+qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+
+
+def _site(kind, inplace=True, quantizer="scaler"):
+    cb = qs.DecimalQuantizer() if quantizer == "decimal" else None
+    net = nn.Sequential(nn.ReLU(inplace=inplace))
+    if kind in ("pair", "relu_p"):
+        net = qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=1, dimensions={1}),
+                         activation_layers=[nn.ReLU], log=False)
+    if kind in ("pair", "relu_q"):
+        net = qs.convert(net, qs.quantize(bits=4, channelwise=-1, timeout=1, callback=cb), activation_layers=[nn.ReLU], log=False)
+    return net.cuda().train()
+
+
+def _graph_names(fn, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return set()
+    seen.add(fn)
+    names = {type(fn).__name__}
+    for nxt, _ in fn.next_functions:
+        names |= _graph_names(nxt, seen)
+    return names
+
+
+def _run(kind, fold, inplace, dtype, channels_last, second_consumer=False, quantizer="scaler"):
+    qs.set_qsparse_options(fold_relu=fold)
+    try:
+        net = _site(kind, inplace, quantizer)
+        g = torch.Generator().manual_seed(0)
+        out = []
+        for step in range(5):
+            x0 = torch.randn(6, 16, 5, 7, generator=g).cuda().to(dtype)
+            if channels_last:
+                x0 = x0.contiguous(memory_format=torch.channels_last)
+            x0.requires_grad_()
+            h = x0 * 1.0                                     # what a convolution / batch norm hands the in-place ReLU
+            y = net(h)
+            loss = (y.float() * torch.randn(y.shape, generator=g).cuda() * 3).sum()
+            if second_consumer:                              # someone else still holds the (modified) tensor and uses it
+                loss = loss + (h.float() * torch.randn(h.shape, generator=g).cuda()).sum()
+            names = _graph_names(y.grad_fn)
+            loss.backward()
+            out.append((y.detach().clone(), h.detach().clone(), x0.grad.clone()))
+        net.eval()
+        with torch.no_grad():
+            x0 = torch.randn(6, 16, 5, 7, generator=g).cuda().to(dtype)
+            h = x0 * 1.0
+            out.append((net(h).clone(), h.clone(), x0))
+        state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        return out, state, names
+    finally:
+        qs.set_qsparse_options(fold_relu=True)
+
+
+def _same(a, b):
+    (oa, sa, _), (ob, sb, _) = a, b
+    for i, (ta, tb) in enumerate(zip(oa, ob)):
+        for j, (u, v) in enumerate(zip(ta, tb)):
+            assert u.dtype == v.dtype and torch.equal(u, v), (i, j)
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["pair", "relu_q", "relu_p"])
+def test_inplace_relu_site_equals_the_module_by_module_route(kind, dtype, channels_last):
+    owned = _run(kind, True, True, dtype, channels_last)
+    plain = _run(kind, False, True, dtype, channels_last)
+    _same(owned, plain)
+    # x's storage holds relu(x) afterwards, as with the plain module
+    for y, h, _ in owned[0]:
+        assert bool((h >= 0).all())
+    # ... and the ReLU's backward is not a pass of its own any more
+    assert "ReluBackward0" in plain[2] and "ReluBackward0" not in owned[2] and "_OwnedReluBackward" in owned[2]
+    # same values as the out-of-place ReLU's fused site
+    out_of_place = _run(kind, True, False, dtype, channels_last)
+    for (ya, _, ga), (yb, _, gb) in zip(owned[0][:5], out_of_place[0][:5]):
+        assert torch.equal(ya, yb) and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("kind", ["pair", "relu_q", "relu_p"])
+def test_a_second_consumer_of_the_modified_tensor_is_gated_too(kind):
+    _same(_run(kind, True, True, torch.float32, False, second_consumer=True),
+          _run(kind, False, True, torch.float32, False, second_consumer=True))
+
+
+def test_decimal_quantizer_behind_an_inplace_relu():
+    _same(_run("pair", True, True, torch.bfloat16, True, quantizer="decimal"),
+          _run("pair", False, True, torch.bfloat16, True, quantizer="decimal"))
+
+
+def test_a_leaf_that_requires_grad_raises_as_with_the_plain_module():
+    net = _site("relu_q")
+    for _ in range(3):
+        net(torch.randn(2, 4, 3, 3, device="cuda") * 1.0)
+    x = torch.randn(2, 4, 3, 3, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="leaf Variable that requires grad"):
+        net(x)
+
+
+def test_a_view_keeps_atens_own_inplace_route():
+    net = _site("relu_q")
+    g = torch.Generator().manual_seed(1)
+    for _ in range(4):
+        base = (torch.randn(2, 8, 3, 3, generator=g).cuda().requires_grad_()) * 1.0
+        y = net(base[:, :4])                                  # in-place ReLU on a view: ATen's view bookkeeping
+        assert "_OwnedReluBackward" not in _graph_names(y.grad_fn)
+        y.sum().backward()
