@@ -6,6 +6,7 @@ this module without the library present raises ``QsparseHipError``.
 """
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from typing import Optional
 
@@ -293,6 +294,27 @@ def _f32param(p, device):
 # ----------------------------------------------------------------------------------------------
 # quantizers
 # ----------------------------------------------------------------------------------------------
+_gate_sink = threading.local()
+
+
+def note_gate(bits: torch.Tensor):
+    """a forward just recorded a ReLU gate: whoever asked to be told (fused.py::_with_owned_relu) gets the bitmap"""
+    cell = getattr(_gate_sink, "cell", None)
+    if cell is not None:
+        cell["bits"] = bits
+
+
+def unpack_gate(bits: torch.Tensor, shape, strides) -> torch.Tensor:
+    """the recorded gate as a bool tensor laid out like the (dense) activation it belongs to: True where the ReLU lets the
+    gradient through, !(x <= 0) (a torch composition for the rare route that needs the gate outside the backward kernels)"""
+    numel = 1
+    for d in shape:
+        numel *= d
+    shifts = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    flat = ((bits.view(-1, 1) >> shifts) & 1).bool().view(-1)[:numel]
+    return flat.as_strided(tuple(shape), tuple(strides))
+
+
 class ReluGate:
     """the gate of a folded ReLU as the forward kernel recorded it: one bit per element in the MEMORY order the kernel
     addressed (`channels_last`: the activation was used in place through its NHWC view), plus what the backward needs to
@@ -301,6 +323,7 @@ class ReluGate:
 
     def __init__(self, bits: torch.Tensor, like: torch.Tensor, channels_last: bool):
         self.bits, self.shape, self.dtype, self.channels_last = bits, like.shape, like.dtype, channels_last
+        note_gate(bits)
 
     @classmethod
     def from_saved(cls, bits: torch.Tensor, shape, dtype, channels_last: bool) -> "ReluGate":

@@ -265,6 +265,8 @@ class _SiteStep(torch.autograd.Function):
         # (forward-only calls -- evaluation, serving -- let them record a bitmap nobody reads: 1/8 B/elem for a 6 B/elem pass)
         fused_image = bool(make_image and (flags & _hip.SITE_PRE_RELU) and plan.image_fused and not (flags & _hip.SITE_NO_MASK))
         bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if (want_gate or fused_image) else None
+        if want_gate:
+            _hip.note_gate(bits_t)
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
         _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img)
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
@@ -499,16 +501,18 @@ class _OwnedRelu(torch.autograd.Function):
         x.relu_()
         ctx.mark_dirty(x)
         ctx.cell = cell
-        ctx.save_for_backward(x)             # (what ATen's own in-place ReLU keeps for its backward, too)
+        ctx.layout = (x.shape, x.stride())   # (x itself is NOT kept for the backward, unlike ATen's in-place ReLU)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        gated = ctx.cell.pop("g", None)
+        cell = ctx.cell
+        gated = cell.pop("g", None)
         if g is None or g is gated:
             return g, None
-        (h,) = ctx.saved_tensors
-        return torch.where(h > 0, g, torch.zeros((), dtype=g.dtype, device=g.device)), None
+        # the rare route: the gate as the site recorded it (or, where the site recorded none, from the tensor itself)
+        open_ = (_hip.unpack_gate(cell["bits"], *ctx.layout) if "bits" in cell else ~(cell["h"] <= 0))
+        return torch.where(open_, g, torch.zeros((), dtype=g.dtype, device=g.device)), None      # threshold_backward: NaN passes
 
 
 class _Tap(torch.autograd.Function):
@@ -536,10 +540,20 @@ def _foldable_relu(act, x) -> int:
     return 2
 
 
-def _own_relu(x: torch.Tensor) -> torch.Tensor:
-    """x <- relu(x) in place; returns the alias the fused site reads (with `pre_relu`: max(h, 0) == h, the bits are h > 0)"""
+def _with_owned_relu(x: torch.Tensor, site):
+    """x <- relu(x) in place, then `site(h)` on the alias the fused site reads (with `pre_relu`: max(h, 0) == h, its gate bits
+    are h > 0); the bitmap the site records is also what `_OwnedRelu`'s rare route gates with"""
     cell = {}
-    return _Tap.apply(_OwnedRelu.apply(x, cell), cell)
+    h = _Tap.apply(_OwnedRelu.apply(x, cell), cell)
+    outer = getattr(_hip._gate_sink, "cell", None)
+    _hip._gate_sink.cell = cell
+    try:
+        y = site(h)
+    finally:
+        _hip._gate_sink.cell = outer
+    if "bits" not in cell and torch.is_grad_enabled() and h.requires_grad:
+        cell["h"] = h.detach()               # a site that recorded no gate this step (quantizer idle ...) kept x itself anyway
+    return y
 
 
 def _hooked(*modules) -> bool:
@@ -566,7 +580,9 @@ class FusedPruneQuantize(nn.Sequential):
         # the fused backward kernel
         fold = _foldable_relu(act, x)
         if fold and q.is_active() and isinstance(x, torch.Tensor) and _eligible(p, q, x):
-            return fused_prune_quantize(p, q, x if fold == 1 else _own_relu(x), pre_relu=True)
+            if fold == 2:
+                return _with_owned_relu(x, lambda h: fused_prune_quantize(p, q, h, pre_relu=True))
+            return fused_prune_quantize(p, q, x, pre_relu=True)
         h = act(x)
         if _eligible(p, q, h):
             return fused_prune_quantize(p, q, h)
@@ -621,7 +637,7 @@ class FusedActQuantize(nn.Sequential):
         act, q = self[0], self[1]
         fold = _foldable_relu(act, x)
         if fold and q.is_active() and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback):
-            return fused_relu_quantize(q, x if fold == 1 else _own_relu(x))
+            return _with_owned_relu(x, lambda h: fused_relu_quantize(q, h)) if fold == 2 else fused_relu_quantize(q, x)
         return q(act(x))
 
 
@@ -641,7 +657,7 @@ class FusedActPrune(nn.Sequential):
                 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and p.is_active()
                 and type(p.callback) is MagnitudePruningCallback and not p.callback.l0
                 and not p.callback.use_gradient and len(p.dimensions) == 1 and not _hooked(act, p.callback)):
-            return p(x if fold == 1 else _own_relu(x), pre_relu=True)
+            return _with_owned_relu(x, lambda h: p(h, pre_relu=True)) if fold == 2 else p(x, pre_relu=True)
         return p(act(x))
 
 

@@ -500,6 +500,8 @@ class _QuantStep(torch.autograd.Function):
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
         gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if want_gate else None
+        if want_gate:
+            _hip.note_gate(gate_bits)
         _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update)
         ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype

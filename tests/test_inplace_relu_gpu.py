@@ -26,6 +26,33 @@ def _site(kind, inplace=True, quantizer="scaler"):
     return net.cuda().train()
 
 
+def _find(fn, name, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return None
+    seen.add(fn)
+    if type(fn).__name__ == name:
+        return fn
+    for nxt, _ in fn.next_functions:
+        hit = _find(nxt, name, seen)
+        if hit is not None:
+            return hit
+    return None
+
+
+def test_the_owned_relu_keeps_nothing_for_its_backward():
+    """ATen's in-place ReLU saves its result (2 B/elem until the backward); the owned one relies on the site's bitmap"""
+    net = _site("pair")
+    g = torch.Generator().manual_seed(0)
+    for _ in range(4):
+        x0 = torch.randn(6, 16, 5, 7, generator=g).cuda().requires_grad_()
+        y = net(x0 * 1.0)
+        node = _find(y.grad_fn, "_OwnedReluBackward")
+        kept = None if node is None else len(node.saved_tensors)
+        y.sum().backward()
+    assert kept == 0
+
+
 def _graph_names(fn, seen=None):
     seen = set() if seen is None else seen
     if fn is None or fn in seen:

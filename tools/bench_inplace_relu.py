@@ -18,7 +18,7 @@ from examples.models import convert_pq, resnet18, resnet50
 arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda", 0)
-qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+qs.set_qsparse_options(log_on_created=False, log_during_train=False, autocast_image=bool(int(os.environ.get("QS_IMAGE", "0"))))
 
 
 def run(inplace, fold, pq=True, steps=10):
