@@ -41,6 +41,7 @@ def main(argv=None):
     ap.add_argument("--preserve-dtype", action="store_true")
     ap.add_argument("--autocast-image", action="store_true",
                     help="value-identical opt-in: sites hand their first convolution the bf16 image of their float32 output")
+    ap.add_argument("--inplace-relu", action="store_true", help="build the network with nn.ReLU(inplace=True) modules (torchvision style)")
     args = ap.parse_args(argv)
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -57,6 +58,10 @@ def main(argv=None):
         model, shape, classes, sparsity = resnet18(10, True), (args.batch, 3, 32, 32), 10, 0.5
     else:
         model, shape, classes, sparsity = resnet50(1000, False), (args.batch, 3, 224, 224), 1000, 0.75
+    if args.inplace_relu:
+        for m in model.modules():
+            if type(m) is torch.nn.ReLU:
+                m.inplace = True
     if not args.no_pq:
         model = convert_pq(model, sparsity=args.sparsity or sparsity, bits=args.bits, prune_start=2, prune_interval=2,
                            repetition=3, quant_timeout=4)
