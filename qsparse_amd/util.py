@@ -112,10 +112,11 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
     abs-max accumulator that is complete by then) and ``record["filled"]`` is set."""
     cur = None
     first = True
-    if x.dim() == 4 and dims and dims[0] == 0 and (absmax_out is None or absmax_channel_dim == 1):
+    if x.dim() == 4 and dims and dims[0] == 0 and x.shape[0] > 1 and (absmax_out is None or absmax_channel_dim == 1):
         # channels_last activation whose batch dim is reduced first: no NCHW copy.  ATen's mean over N of such a tensor
         # returns an NCHW-contiguous result (summed in the order qs_mean_dim_cl reproduces, any channel count), so the
-        # remaining stages are the usual NCHW ones
+        # remaining stages are the usual NCHW ones.  (A batch of ONE has nothing to sum in that stage: ATen's result is the
+        # NCHW copy of x and the later stages run in plain NCHW order -- the dense route below, bit for bit.)
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
             N, C, H, W = x.shape
@@ -134,6 +135,32 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
                     flags |= _hip.MEAN_L0
                 stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
                 cur, dims, first = stage.view(1, C, H, W), dims[1:], False
+    if cur is None and x.dim() == 4 and dims and dims[0] == 2 and absmax_out is None:
+        # channels_last activation whose batch dim is NOT reduced (a per-sample mask -- or a batch of one, whose dim 0 equals
+        # the mask's): ATen reduces H of the NHWC tensor directly, into an NCHW-contiguous result.  Its order for one sample
+        # is exactly its order for the batch reduction of the [H, C, 1, W] channels_last tensor that sample's memory also is
+        # (rows H apart by W*C elements, positions W, channels innermost; tests/test_gpu_parity.py pins the identity on the
+        # CPU), which qs_mean_dim_cl reproduces: one launch per sample, no NCHW copy; the W stage is the usual NCHW one
+        xm, _, like = _hip.mem_view(x, 1)
+        if xm is not like:
+            N, C, H, W = x.shape
+            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            odt = torch.float32 if l0_flag is not None else x.dtype
+            rows = [_hip.mean_dim_cl(xm[i].view(H, 1, W, C), odt, flags, False, l0_flag=l0_flag)[0] for i in range(N)]
+            cur = (rows[0] if N == 1 else torch.cat(rows)).view(N, C, 1, W)
+            dims, first = dims[1:], False
+    if cur is None and x.dim() == 4 and dims and dims[0] == 1 and absmax_out is None:
+        # channels_last activation, batch dim kept, CHANNEL dim reduced first (a (N, 1, H, W) or (1, 1, H, W) mask at batch one):
+        # for ATen that is the inner reduction of the [N*H*W, C] matrix the memory is, into an NCHW-contiguous result -- the
+        # plain last-dim stage on the memory view, no copy (identity pinned in tests/test_aten_contract.py)
+        xm, _, like = _hip.mem_view(x, 1)
+        if xm is not like:
+            N, C, H, W = x.shape
+            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            kw = {"l0_flag": l0_flag} if l0_flag is not None else {}
+            cur = _hip.mean_dim(xm.reshape(N * H * W, C), N * H * W, C, 1, torch.float32 if l0_flag is not None else x.dtype,
+                                flags, **kw).view(N, 1, H, W)
+            dims, first = dims[1:], False
     if cur is None:
         cur = _hip.dense(x)
     shape = list(cur.shape)

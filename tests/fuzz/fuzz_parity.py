@@ -56,20 +56,21 @@ def one_case(rng, idx):
     graph_safe = rng.random() < 0.25       # counters read from (and advanced in) device memory by the kernels
     elide = rng.choice(["forward", "forward", "off", "all"])      # mask-aware load elision (qs_elementwise.h)
     gate = rng.random() < 0.75             # the folded ReLU's gate as a bitmap (backward without x)
+    inplace = rng.random() < 0.3           # nn.ReLU(inplace=True) in front of the site (torchvision-style networks)
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last, preserve, graph_safe, elide, gate)
+                    channels_last, preserve, graph_safe, elide, gate, inplace)
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False, preserve=False, graph_safe=False, elide="forward", gate=True):
+             channels_last=False, preserve=False, graph_safe=False, elide="forward", gate=True, inplace=False):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide, gate=gate)
+                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide, gate=gate, inplace=inplace)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
@@ -82,7 +83,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
     cbs = {"scaler": qs.ScalerQuantizer, "decimal": qs.DecimalQuantizer}
     has_p, has_q, has_relu = "p" in site_kind.replace("relu", ""), "q" in site_kind or "pair" in site_kind, "relu" in site_kind
     has_p = has_p or "pair" in site_kind
-    act = nn.ReLU() if has_relu else nn.Identity()
+    act = nn.ReLU(inplace=inplace) if has_relu else nn.Identity()
     p = qs.prune(sparsity=sparsity, dimensions={1}, start=start, interval=interval, repetition=rep) if has_p else None
     q = qs.quantize(bits=bits, channelwise=-1, timeout=timeout, callback=cbs[kind]()) if has_q else None
     if has_p and has_q:
@@ -101,13 +102,14 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (fp16 underflow): torch's own CPU and GPU ReLU disagree on its sign
-        # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count); a batch of one
-        # is summed in NCHW order after a copy, 1 ulp away from ATen's layout-dependent order
-        cl = channels_last and len(shape) == 4 and shape[0] > 1
+        # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count, any batch)
+        cl = channels_last and len(shape) == 4
         if cl:                      # the oracle then sees ATen's channels_last behaviour (summation order included)
             x = x.contiguous(memory_format=torch.channels_last)
         xg = x.to(DEV).requires_grad_(True)
-        y = site(xg)
+        # an in-place ReLU needs a non-leaf input, as in a network (clone: ATen's fp16 `x * 1.0` backward on the GPU loses the sign of -0.0)
+        xin = xg.clone() if (inplace and has_relu) else xg
+        y = site(xin)
         gout = torch.randn(shape, generator=g).to(y.dtype)
         if cl:
             gout = gout.contiguous(memory_format=torch.channels_last)
@@ -138,6 +140,11 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
                    != y_ref.contiguous().view(-1).view(torch.int16 if y_ref.element_size() == 2 else torch.int32)).nonzero().view(-1)[:6]
             print("   first mismatches (x, got, want):", [(float(x.reshape(-1)[i]), float(y.detach().cpu().reshape(-1)[i]),
                                                             float(y_ref.reshape(-1)[i])) for i in bad.tolist()], flush=True)
+        if VERBOSE and not same(xg.grad.cpu(), gr.to(dtype)) and xg.grad.shape == gr.shape:
+            ga, gb = xg.grad.cpu().reshape(-1).float(), gr.to(dtype).reshape(-1).float()
+            bad = ((ga != gb) | (torch.signbit(ga) != torch.signbit(gb))).nonzero().view(-1)[:6]
+            print("   first gx mismatches (index, x, gout, got, want):", [(i, float(x.reshape(-1)[i]), float(gout.reshape(-1)[i]), float(ga[i]),
+                                                                          float(gb[i])) for i in bad.tolist()], flush=True)
         if VERBOSE:
             print(s, "y", same(y.detach().cpu(), y_ref), "gx", same(xg.grad.cpu(), gr.to(dtype)),
                   "mask", (same((site[0][1] if has_q else site[1]).mask.cpu(), ps.mask) if ps else None),
@@ -151,6 +158,8 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         if qsim:
             ql = site[1]
             ok = ok and int(ql._n_updates) == qsim.n_updates and (qsim.weight is None or same(ql.weight.detach().cpu(), qsim.weight))
+        if inplace and has_relu:    # x's own storage holds relu(x) afterwards, whichever route the site took
+            ok = ok and same(xin.detach().cpu(), torch.relu(x))
         if not ok:
             return dict(desc, failed_step=s)
     return "ok"

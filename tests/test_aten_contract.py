@@ -25,3 +25,33 @@ def test_aten_staged_mean_vs_intra_op_threads():
         assert stats[4] <= 0.05 * total and stats[8] <= 0.1 * total, (stats, examples)
     finally:
         torch.set_num_threads(before)
+
+
+def test_aten_reduces_h_of_a_channels_last_sample_like_the_batch_of_its_rows():
+    """What the GPU route for channels_last activations whose batch dim is NOT reduced rests on (qsparse_amd/util.py,
+    `_staged_mean_hip`: per-sample masks, and every batch of one): ATen's ``mean(2)`` of an NHWC tensor -- it reduces H in
+    place, into an NCHW-contiguous result -- sums one sample exactly as its ``mean(0)`` sums the [H, C, 1, W] channels_last
+    tensor that the sample's memory also is.  The latter order is the one ``qs_mean_dim_cl`` reproduces on the GPU."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        g = torch.Generator().manual_seed(0)
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            for shape in [(1, 64, 14, 14), (2, 8, 7, 7), (1, 130, 5, 9), (1, 3, 28, 28), (1, 256, 56, 56), (3, 31, 3, 32), (2, 6, 28, 28),
+                          (1, 7, 300, 5), (1, 16, 17, 70), (1, 2, 64, 64), (1, 1, 9, 9)]:
+                N, C, H, W = shape
+                x = torch.randn(shape, generator=g).abs().to(dtype).contiguous(memory_format=torch.channels_last)
+                want = x.mean(2, keepdim=True)
+                assert want.is_contiguous()
+                rows = [x.permute(0, 2, 3, 1)[n].reshape(H, 1, W, C).permute(0, 3, 1, 2).mean(0, keepdim=True) for n in range(N)]
+                assert torch.equal(want, torch.cat(rows, 0)), (dtype, shape)
+                # ... and it is NOT the order of the NCHW copy (why a copy-and-reduce route is a last-bit off in float32)
+                # the channel dim reduced first (batch kept): the inner reduction of the [N*H*W, C] matrix the memory is
+                want = x.mean(1, keepdim=True)
+                assert want.is_contiguous()
+                assert torch.equal(want, x.permute(0, 2, 3, 1).reshape(N * H * W, C).mean(1).view(N, 1, H, W)), (dtype, shape)
+        x = torch.randn(1, 64, 14, 14, generator=g).abs().contiguous(memory_format=torch.channels_last)
+        assert not torch.equal(x.mean(2, keepdim=True), x.contiguous().mean(2, keepdim=True))
+        assert not torch.equal(x.mean(1, keepdim=True), x.contiguous().mean(1, keepdim=True))
+    finally:
+        torch.set_num_threads(before)

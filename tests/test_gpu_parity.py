@@ -1140,6 +1140,62 @@ def test_channels_last_statistics_any_channel_count_masks_and_l0_vs_oracle():
         torch.set_num_threads(threads)
 
 
+def test_channels_last_statistics_with_the_batch_dim_kept_vs_oracle():
+    """channels_last activations whose batch dim is NOT reduced -- every batch of one (dim 0 equals the mask's), and per-sample
+    masks (N, C, 1, 1): ATen reduces H of the NHWC tensor in place, in an order of its own (a last float32 bit away from the
+    NCHW copy's); `_staged_mean_hip` reproduces it through qs_mean_dim_cl, one launch per sample
+    (tests/test_aten_contract.py pins the identity it rests on).  Bit-identical to the oracle at one CPU thread: the plain
+    squeeze, L0, and whole PruneLayer / fused-pair trajectories at batch one."""
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    from qsparse_amd.util import squeeze_tensor_to_shape
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for si, shape in enumerate(((1, 64, 14, 14), (1, 3, 28, 28), (1, 256, 56, 56), (1, 130, 5, 9), (1, 8, 7, 7), (3, 64, 14, 14),
+                                    (5, 12, 9, 17), (1, 24, 2, 2), (1, 16, 40, 3))):
+            N, C, H, W = shape
+            for dt in (torch.float32, torch.bfloat16, torch.float16):
+                x = (torch.randn(shape, generator=gen(1200 + si)) * torch.linspace(0.3, 3, C).view(1, -1, 1, 1)).to(dt)
+                xcl = x.contiguous(memory_format=torch.channels_last)
+                for mshape in ((N, C, 1, 1), (N, 1, H, W), (N, 1, 1, 1), (N, C, 1, W), (N, 1, 1, W), (N, 1, H, 1)):
+                    ref = O.squeeze_mean(xcl.abs(), mshape)
+                    got = squeeze_tensor_to_shape(xcl.to(DEV).abs(), mshape)
+                    assert got.shape == ref.shape and same(got.cpu().contiguous(), ref.contiguous()), (shape, dt, mshape)
+        for kw, shape in ((dict(), (1, 64, 14, 14)), (dict(l0=True), (1, 24, 6, 6)), (dict(), (1, 130, 5, 9))):
+            for dt in (torch.float32, torch.bfloat16):
+                sim = O.PruneSim(0.5, [1], 1, 1, 2, False, l0=kw.get("l0", False))
+                layer = qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2,
+                                 callback=qs.MagnitudePruningCallback(**kw)).to(DEV).train()
+                for s in range(6):
+                    x = (torch.randn(shape, generator=gen(1250 + s)) * torch.linspace(0.2, 2, shape[1]).view(1, -1, 1, 1)).relu().to(dt)
+                    xcl = x.contiguous(memory_format=torch.channels_last)
+                    y = layer(xcl.to(DEV))
+                    y_ref = sim.step(xcl)
+                    assert same(y.cpu().contiguous(), y_ref.contiguous()), (kw, shape, dt, s)
+                    assert same(layer.mask.cpu(), sim.mask), (kw, shape, dt, s)
+                    if sim.magnitude is not None:
+                        assert same(layer.callback.magnitude.cpu(), sim.magnitude), (kw, shape, dt, s)
+        # the fused ReLU -> prune -> quantize site at batch one
+        for dt in (torch.float32, torch.bfloat16):
+            shape = (1, 64, 14, 14)
+            site = fuse_prune_quantize_pairs(nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
+                                                                                               repetition=2)),
+                                                           qs.quantize(bits=4, channelwise=-1, timeout=1)).to(DEV).train())
+            ps, qsim = O.PruneSim(0.5, [1], 1, 1, 2, False), O.QuantizeSim("scaler", 4, -1, 1)
+            for s in range(6):
+                x = (torch.randn(shape, generator=gen(1300 + s)) * torch.linspace(0.2, 2, 64).view(1, -1, 1, 1)).to(dt)
+                xcl = x.contiguous(memory_format=torch.channels_last)
+                y = site(xcl.to(DEV))
+                y_ref = qsim.step(ps.step(torch.relu(xcl), True).contiguous(), True)
+                assert same(y.cpu().contiguous(), y_ref.contiguous()), (dt, s)
+                assert same(site[0][1].mask.cpu(), ps.mask), (dt, s)
+                if ps.magnitude is not None:
+                    assert same(site[0][1].callback.magnitude.cpu(), ps.magnitude), (dt, s)
+                assert qsim.weight is None or same(site[1].weight.detach().cpu(), qsim.weight), (dt, s)
+    finally:
+        torch.set_num_threads(threads)
+
+
 def test_folded_relu_propagates_nan_like_the_module_by_module_path():
     """ATen's relu keeps NaN (clamp_min = max(0, x)); the folded kernels must not turn a diverged activation into a clean
     zero.  A NaN input gives the same (NaN-carrying) scale, output and gradient with and without the fold -- the fused
