@@ -407,6 +407,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 # in front of the channel dim (the batch); with a batch of one there is no such stage and the
                 # abs-max is a pass of its own
                 rides = update_scale and bool(dims) and dims[0] < 1
+                if rides and hd.dim() == 5 and not hd.is_contiguous():
+                    rides = False      # channels_last_3d: the in-place first stage (ATen's order for that layout) carries no abs-max
                 if rides:
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 elif update_scale:

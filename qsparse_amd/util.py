@@ -135,6 +135,14 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
                     flags |= _hip.MEAN_L0
                 stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
                 cur, dims, first = stage.view(1, C, H, W), dims[1:], False
+    elif x.dim() == 5 and dims and dims[0] == 0 and x.shape[0] > 1 and absmax_out is None:
+        # channels_last_3d: the same first stage with D*H*W positions per sample (ATen's mean over N of an NDHWC tensor is the
+        # batch reduction of the [N, C, 1, D*H*W] channels_last tensor its memory also is; NCDHW-contiguous result)
+        xm, _, like = _hip.mem_view(x, 1)
+        if xm is not like:
+            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
+            cur, dims, first = stage.view((1,) + tuple(x.shape[1:])), dims[1:], False
     if cur is None and x.dim() == 4 and dims and dims[0] == 2 and absmax_out is None:
         # channels_last activation whose batch dim is NOT reduced (a per-sample mask -- or a batch of one, whose dim 0 equals
         # the mask's): ATen reduces H of the NHWC tensor directly, into an NCHW-contiguous result.  Its order for one sample

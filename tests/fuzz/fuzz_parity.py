@@ -102,17 +102,19 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (fp16 underflow): torch's own CPU and GPU ReLU disagree on its sign
-        # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count, any batch)
-        cl = channels_last and len(shape) == 4
+        # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count, any batch);
+        # channels_last_3d (5-d) with a batch of at least two
+        cl = channels_last and (len(shape) == 4 or (len(shape) == 5 and shape[0] > 1))
+        fmt = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
         if cl:                      # the oracle then sees ATen's channels_last behaviour (summation order included)
-            x = x.contiguous(memory_format=torch.channels_last)
+            x = x.contiguous(memory_format=fmt)
         xg = x.to(DEV).requires_grad_(True)
         # an in-place ReLU needs a non-leaf input, as in a network (clone: ATen's fp16 `x * 1.0` backward on the GPU loses the sign of -0.0)
         xin = xg.clone() if (inplace and has_relu) else xg
         y = site(xin)
         gout = torch.randn(shape, generator=g).to(y.dtype)
         if cl:
-            gout = gout.contiguous(memory_format=torch.channels_last)
+            gout = gout.contiguous(memory_format=fmt)
         y.backward(gout.to(DEV))
         h = torch.relu(x) if has_relu else x
         n_before = ps.n_updates if ps else 0

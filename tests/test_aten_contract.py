@@ -50,6 +50,13 @@ def test_aten_reduces_h_of_a_channels_last_sample_like_the_batch_of_its_rows():
                 want = x.mean(1, keepdim=True)
                 assert want.is_contiguous()
                 assert torch.equal(want, x.permute(0, 2, 3, 1).reshape(N * H * W, C).mean(1).view(N, 1, H, W)), (dtype, shape)
+            # channels_last_3d, batch reduced first: the batch reduction of the [N, C, 1, D*H*W] channels_last tensor
+            for shape in [(8, 16, 3, 4, 8), (5, 32, 2, 7, 7), (16, 3, 4, 4, 4), (3, 130, 1, 5, 9)]:
+                N, C, D, H, W = shape
+                x = torch.randn(shape, generator=g).abs().to(dtype).contiguous(memory_format=torch.channels_last_3d)
+                want = x.mean(0, keepdim=True)
+                z = x.permute(0, 2, 3, 4, 1).reshape(N, 1, D * H * W, C).permute(0, 3, 1, 2)
+                assert want.is_contiguous() and torch.equal(want, z.mean(0, keepdim=True).reshape(1, C, D, H, W)), (dtype, shape)
         x = torch.randn(1, 64, 14, 14, generator=g).abs().contiguous(memory_format=torch.channels_last)
         assert not torch.equal(x.mean(2, keepdim=True), x.contiguous().mean(2, keepdim=True))
         assert not torch.equal(x.mean(1, keepdim=True), x.contiguous().mean(1, keepdim=True))

@@ -1161,6 +1161,15 @@ def test_channels_last_statistics_with_the_batch_dim_kept_vs_oracle():
                     ref = O.squeeze_mean(xcl.abs(), mshape)
                     got = squeeze_tensor_to_shape(xcl.to(DEV).abs(), mshape)
                     assert got.shape == ref.shape and same(got.cpu().contiguous(), ref.contiguous()), (shape, dt, mshape)
+        # channels_last_3d activations, batch reduced first
+        for si, shape in enumerate(((8, 16, 3, 4, 8), (5, 32, 2, 7, 7), (16, 3, 4, 4, 4), (3, 130, 1, 5, 9))):
+            for dt in (torch.float32, torch.bfloat16):
+                x = (torch.randn(shape, generator=gen(1230 + si)) * torch.linspace(0.3, 3, shape[1]).view(1, -1, 1, 1, 1)).to(dt)
+                xcl = x.contiguous(memory_format=torch.channels_last_3d)
+                for mshape in ((1, shape[1], 1, 1, 1), (1, shape[1]) + shape[2:], (1, 1, 1, 1, 1)):
+                    ref = O.squeeze_mean(xcl.abs(), mshape)
+                    got = squeeze_tensor_to_shape(xcl.to(DEV).abs(), mshape)
+                    assert got.shape == ref.shape and same(got.cpu().contiguous(), ref.contiguous()), (shape, dt, mshape)
         for kw, shape in ((dict(), (1, 64, 14, 14)), (dict(l0=True), (1, 24, 6, 6)), (dict(), (1, 130, 5, 9))):
             for dt in (torch.float32, torch.bfloat16):
                 sim = O.PruneSim(0.5, [1], 1, 1, 2, False, l0=kw.get("l0", False))
