@@ -147,7 +147,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         # channels_last activation whose batch dim is NOT reduced (a per-sample mask -- or a batch of one, whose dim 0 equals
         # the mask's): ATen reduces H of the NHWC tensor directly, into an NCHW-contiguous result.  Its order for one sample
         # is exactly its order for the batch reduction of the [H, C, 1, W] channels_last tensor that sample's memory also is
-        # (rows H apart by W*C elements, positions W, channels innermost; tests/test_gpu_parity.py pins the identity on the
+        # (rows H apart by W*C elements, positions W, channels innermost; tests/test_aten_contract.py pins the identity on the
         # CPU), which qs_mean_dim_cl reproduces: one launch per sample, no NCHW copy; the W stage is the usual NCHW one
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
