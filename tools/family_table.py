@@ -73,6 +73,13 @@ def main():
             a = casts.setdefault(k, [0.0, 0])
             a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             a[1] += 1
+    for r in rows:      # ATen's own ReLU passes (networks with in-place ReLU modules, or fold_relu=False)
+        name = r["Kernel_Name"]
+        if int(r["Start_Timestamp"]) >= t_first and "qs::" not in name and ("threshold" in name or "clamp" in name or "relu" in name.lower()):
+            k = "ReLU backward (threshold_backward)" if "threshold" in name else "ReLU forward (clamp / relu)"
+            a = casts.setdefault(k, [0.0, 0])
+            a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a[1] += 1
     for k, (us, n) in sorted(casts.items()):
         print(f"(not library) ATen {k}: {us / 1e3 / steps:.3f} ms/step in {n / steps:.1f} launches")
     print()

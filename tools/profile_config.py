@@ -29,11 +29,16 @@ def main():
     dev = torch.device("cuda", 0)
     image = os.environ.get("QS_PROFILE_IMAGE", "0") == "1"          # the value-identical opt-in (fused.py "Autocast image")
     qs.set_qsparse_options(log_on_created=False, log_during_train=False, autocast_image=image,
-                           batch_weights=os.environ.get("QS_PROFILE_NO_BATCHER", "0") != "1")
+                           batch_weights=os.environ.get("QS_PROFILE_NO_BATCHER", "0") != "1",
+                           fold_relu=os.environ.get("QS_PROFILE_NO_FOLD", "0") != "1")
     if arch == "resnet18":
         model, shape, classes, sparsity = resnet18(10, True), (batch, 3, 32, 32), 10, 0.5
     else:
         model, shape, classes, sparsity = resnet50(1000, False), (batch, 3, 224, 224), 1000, 0.75
+    if os.environ.get("QS_PROFILE_INPLACE", "0") == "1":             # the network written torchvision-style
+        for m in model.modules():
+            if type(m) is torch.nn.ReLU:
+                m.inplace = True
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.randn(shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, classes, (batch,), generator=g, device=dev)
