@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""channels_last activations whose batch dim is not reduced (a batch of one, per-sample masks): the GPU staged mean against
+ATen's one-thread CPU result for the same NHWC tensor, float32 and bf16 (development probe).
+    python tools/probe_cl_n1.py        # on a GPU box: every line OK"""
 import sys, torch
 sys.path.insert(0, '.')
 import qsparse_amd as qs
