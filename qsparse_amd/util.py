@@ -285,15 +285,15 @@ def extra_state_dict(model: nn.Module) -> Dict[str, Dict[str, int]]:
     a SEPARATE dict keyed by module path, so ``state_dict()`` keeps the reference's schema key for key; store it next to the
     checkpoint and hand it to ``load_extra_state_dict`` after ``load_state_dict`` to resume bit-identically."""
     from qsparse_amd.quantize import QuantizeLayer
-    return {path: {"quantized": int(bool(m._quantized)), "t": int(m.callback.t)}
-            for path, m in model.named_modules() if isinstance(m, QuantizeLayer)}
+    return {path: {"quantized": int(bool(m._quantized)), "t": int(m.callback.t)}       # (paths of the unwrapped network:
+            for path, m in nn_module(model).named_modules() if isinstance(m, QuantizeLayer)}   # no DataParallel / DDP prefix)
 
 
 def load_extra_state_dict(model: nn.Module, extra: Dict[str, Dict[str, int]], strict: bool = True) -> nn.Module:
     """restore what ``extra_state_dict`` saved (a weight and a bias quantizer that share one callback, reference
     quantize.py:548,559-571, carry the same ``t``)."""
     from qsparse_amd.quantize import QuantizeLayer
-    layers = {path: m for path, m in model.named_modules() if isinstance(m, QuantizeLayer)}
+    layers = {path: m for path, m in nn_module(model).named_modules() if isinstance(m, QuantizeLayer)}
     if strict and set(layers) != set(extra):
         missing, unexpected = sorted(set(layers) - set(extra)), sorted(set(extra) - set(layers))
         raise KeyError(f"extra state does not match the network: missing {missing}, unexpected {unexpected}")

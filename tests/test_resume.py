@@ -83,6 +83,13 @@ def _resume_case(dev, quantizer):
     net, o = load()
     got = _steps(net.train(), o, xs[6:])
     assert not all(torch.equal(a, b) for a, b in zip(want, got))
+    # a DataParallel / DDP style wrapper on either side changes nothing (paths are those of the unwrapped network)
+    class Wrapper(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+    assert qs.extra_state_dict(Wrapper(ref)) == qs.extra_state_dict(ref)
+    qs.load_extra_state_dict(Wrapper(net), qs.extra_state_dict(ref))
     # strictness
     with pytest.raises(KeyError):
         qs.load_extra_state_dict(net, {"nope": {"quantized": 1, "t": 1}})
