@@ -1,0 +1,82 @@
+"""More than 2^31 elements in one activation (the GPU has 288 GB: a 2052 x 256 x 64 x 64 bf16 tensor is 4.3 GB).
+
+Every kernel of the fused ReLU -> prune -> quantize site -- statistics, select, apply forward with the gate bitmap, backward --
+addresses such a tensor with 64-bit element offsets and 32-bit group / row counters; nothing in the BASELINE configurations
+comes near the limits.  One live training step in NCHW and in channels_last, checked chunk by chunk against torch's own
+element-wise arithmetic on the GPU (exact: correctly rounded division, half-to-even, one rounding per operator -- the chain
+of reference quantize.py:87-131 / sparse.py:263), the scale against the order-independent abs-max, the running magnitude of
+four channels against the oracle's staged mean of that slice."""
+import pytest
+import torch
+import torch.nn as nn
+
+import qsparse_amd as qs
+from golden_io import same
+from oracle import qs_oracle as O
+from qsparse_amd.fused import fuse_prune_quantize_pairs
+
+pytestmark = pytest.mark.gpu
+qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+SHAPE = (2052, 256, 64, 64)          # 2,151,677,952 elements > 2^31 = 2,147,483,648
+BITS = 4
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_one_live_step_on_more_than_2_pow_31_elements(channels_last):
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 * 2 ** 30:
+        pytest.skip("needs 48 GiB of free device memory")
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        N, C, H, W = SHAPE
+        assert N * C * H * W > 2 ** 31
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.empty(SHAPE, dtype=torch.bfloat16, device="cuda")
+        for i in range(0, N, 171):               # filled in pieces: no float32 copy of the whole tensor
+            part = torch.randn((min(171, N - i), C, H, W), generator=g, device="cuda")
+            x[i:i + 171] = (part * torch.linspace(0.25, 4.0, C, device="cuda").view(1, C, 1, 1)).to(torch.bfloat16)
+        del part
+        if channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        site = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.75, dimensions={1}, start=0, interval=1, repetition=1)),
+            qs.quantize(bits=BITS, channelwise=-1, timeout=1)).cuda().train())
+        small = x[:2].clone()
+        site(small)                                                                # the identity step of the quantizer (timeout 1)
+        xg = x.requires_grad_(True)
+        y = site(xg)                                                               # the live step on the big tensor
+        assert y.dtype == torch.float32 and y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last) == channels_last
+        gout = torch.empty(SHAPE, dtype=torch.float32, device="cuda")
+        if channels_last:
+            gout = gout.contiguous(memory_format=torch.channels_last)
+        for i in range(0, N, 171):
+            gout[i:i + 171] = torch.randn((min(171, N - i), C, H, W), generator=g, device="cuda") * 2
+        y.backward(gout)
+        gx = xg.grad
+        p, q = site[0][1], site[1]
+        mask, s = p.mask.view(1, C, 1, 1), q.weight.detach().view(())
+        assert int(mask.sum()) == C // 4 and int(p._n_updates) == 2 and int(q._n_updates) == 2
+        lo, hi = O.ste_bounds(BITS, s.cpu().view(1, 1))
+        lo, hi = float(lo), float(hi)
+        amax = torch.zeros((), device="cuda")
+        with torch.no_grad():
+            for i in range(0, N, 108):
+                sl = slice(i, min(i + 108, N))
+                h = torch.relu(x[sl]).float() * mask
+                amax = torch.maximum(amax, h.amax())
+                assert torch.equal(y[sl], torch.round(h / s) * s), ("forward", i)
+                want = torch.where(x[sl] > 0, torch.clamp(gout[sl], lo, hi) * mask, torch.zeros((), device="cuda")).to(torch.bfloat16)
+                assert torch.equal(gx[sl], want), ("backward", i)
+        # the first live statistics step of the quantizer: scale = max|relu(x) * mask| / 2^(bits-1), exactly
+        assert torch.equal(s, amax / 2 ** (BITS - 1))
+        # running magnitude of four channels (two steps: the small tensor, then the big one) against the oracle's staged mean
+        m_small = O.squeeze_mean(torch.relu(small[:, :4]).cpu().contiguous(memory_format=torch.channels_last if channels_last
+                                                                           else torch.contiguous_format).abs(), (1, 4, 1, 1)).float().view(-1)
+        xs = torch.relu(x.detach()[:, :4]).cpu()
+        xs = xs.contiguous(memory_format=torch.channels_last) if channels_last else xs.contiguous()
+        m_big = O.squeeze_mean(xs.abs(), (1, 4, 1, 1)).float().view(-1)
+        ref = (1 * m_small + m_big) / 2          # sparse.py:89 at t = 1
+        assert same(p.callback.magnitude.view(-1)[:4].cpu(), ref)
+    finally:
+        torch.set_num_threads(threads)
