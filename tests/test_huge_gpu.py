@@ -1,4 +1,5 @@
-"""More than 2^31 elements in one activation (the GPU has 288 GB: a 2052 x 256 x 64 x 64 bf16 tensor is 4.3 GB).
+"""More than 2^31 -- and more than 2^32 -- elements in one activation (the GPU has 288 GB: a 2052 x 256 x 64 x 64 bf16 tensor is
+4.3 GB, a 4212 x 256 x 64 x 64 one 8.8 GB).
 
 Every kernel of the fused ReLU -> prune -> quantize site -- statistics, select, apply forward with the gate bitmap, backward --
 addresses such a tensor with 64-bit element offsets and 32-bit group / row counters; nothing in the BASELINE configurations
@@ -17,15 +18,16 @@ from qsparse_amd.fused import fuse_prune_quantize_pairs
 
 pytestmark = pytest.mark.gpu
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
-SHAPE = (2052, 256, 64, 64)          # 2,151,677,952 elements > 2^31 = 2,147,483,648
 BITS = 4
 
 
 @pytest.mark.parametrize("channels_last", [False, True])
-def test_one_live_step_on_more_than_2_pow_31_elements(channels_last):
+@pytest.mark.parametrize("batch", [2052, 4212])      # x 256 x 64 x 64: 2,151,677,952 > 2^31 and 4,416,602,112 > 2^32 elements
+def test_one_live_step_on_more_than_2_pow_31_elements(batch, channels_last):
+    SHAPE = (batch, 256, 64, 64)
     free, _ = torch.cuda.mem_get_info()
-    if free < 48 * 2 ** 30:
-        pytest.skip("needs 48 GiB of free device memory")
+    if free < 48 * 2 ** 30 * (batch / 2052):
+        pytest.skip("needs 48 GiB (100 GiB) of free device memory")
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
