@@ -82,3 +82,76 @@ def test_one_live_step_on_more_than_2_pow_31_elements(batch, channels_last):
         assert same(p.callback.magnitude.view(-1)[:4].cpu(), ref)
     finally:
         torch.set_num_threads(threads)
+
+
+def _filled(shape, seed, dtype=torch.bfloat16, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty(shape, dtype=dtype, device="cuda")
+    for i in range(0, shape[0], 171):
+        n = min(171, shape[0] - i)
+        x[i:i + n] = (torch.randn((n,) + tuple(shape[1:]), generator=g, device="cuda") * scale).to(dtype)
+    return x
+
+
+def test_functional_operators_and_reductions_on_more_than_2_pow_31_elements():
+    """the other entry points on such a tensor: scaler / decimal / line quantizers with per-channel parameters and their STE
+    backward, broadcast mask apply, abs-max and min/max (tensor-wise and per channel), the plain staged mean"""
+    from qsparse_amd import _hip
+    from qsparse_amd.quantize import quantize_with_decimal, quantize_with_line, quantize_with_scaler
+    from qsparse_amd.sparse import apply_mask
+    from qsparse_amd.util import squeeze_tensor_to_shape
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 * 2 ** 30:
+        pytest.skip("needs 48 GiB of free device memory")
+    N, C, H, W = shape = (2052, 256, 64, 64)
+    x = _filled(shape, 11, scale=2.0)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    chunks = [slice(i, min(i + 108, N)) for i in range(0, N, 108)]
+    # per-channel scaler, 8 bits, forward + backward
+    s = (torch.rand(C, 1, generator=gen, device="cuda") * 0.05 + 0.01)
+    xg = x.requires_grad_(True)
+    y = quantize_with_scaler(xg, 8, s, 1)
+    gout = _filled(shape, 13, torch.float32, 3.0)
+    y.backward(gout)
+    sv = s.view(1, C, 1, 1)
+    with torch.no_grad():
+        for sl in chunks:
+            assert torch.equal(y[sl], torch.round(x[sl].float() / sv) * sv), ("scaler", sl)
+            assert torch.equal(xg.grad[sl], torch.minimum(torch.maximum(gout[sl], -128 * sv), 127 * sv).to(torch.bfloat16)), ("ste", sl)
+    x = x.detach()
+    del y, xg
+    # per-channel decimal (truncation), tensor-wise line quantizer in evaluation form
+    d = torch.randint(2, 7, (C, 1), generator=gen, device="cuda").float()
+    y = quantize_with_decimal(x, 8, d, 1)
+    dv = d.view(1, C, 1, 1)
+    for sl in chunks:
+        assert torch.equal(y[sl], torch.trunc(x[sl].float() * 2.0 ** dv) * 2.0 ** -dv), ("decimal", sl)
+    del y
+    lines = torch.tensor([[-1.5, 2.25]], device="cuda")
+    y = quantize_with_line(x, 4, lines, -1, False, True)
+    lo_t, hi_t = lines[0, 0], lines[0, 1]
+    step = (hi_t - lo_t) / 16                     # a TENSOR divisor: torch divides by a Python scalar on the GPU through its reciprocal
+    for sl in chunks:
+        xc = torch.clamp(x[sl].float(), -1.5, 2.25)
+        assert torch.equal(y[sl], ((xc - lo_t) / step).round().clamp(0, 15) * step + lo_t), ("line", sl)
+    del y
+    # mask apply with a (1, C, 1, W) mask
+    mask = torch.rand(1, C, 1, W, generator=gen, device="cuda") > 0.4
+    y = apply_mask(x, mask)
+    for sl in chunks:
+        assert torch.equal(y[sl], x[sl] * mask), ("mask", sl)
+    del y
+    # order-independent reductions
+    assert torch.equal(_hip.absmax(x, -1).view(()), x.abs().amax().float())
+    assert torch.equal(_hip.absmax(x, 1), torch.stack([x[sl].abs().amax(dim=(0, 2, 3)) for sl in chunks]).amax(0).float())
+    lo, hi = _hip.minmax(x, -1)
+    assert float(lo) == float(x.amin()) and float(hi) == float(x.amax())
+    lo, hi = _hip.minmax(x, 1)
+    assert torch.equal(lo.view(-1), torch.stack([x[sl].amin(dim=(0, 2, 3)) for sl in chunks]).amin(0).float())
+    assert torch.equal(hi.view(-1), torch.stack([x[sl].amax(dim=(0, 2, 3)) for sl in chunks]).amax(0).float())
+    # the staged mean of |x| down to (1, C, 1, 1): four channels against the oracle, all of them against float64 sums
+    m = squeeze_tensor_to_shape(x.abs(), (1, C, 1, 1)).float().view(-1)
+    ref = O.squeeze_mean(x[:, :4].abs().cpu().contiguous(), (1, 4, 1, 1)).float().view(-1)
+    assert same(m[:4].cpu(), ref)
+    exact = torch.stack([x[sl].abs().double().sum(dim=(0, 2, 3)) for sl in chunks]).sum(0) / (N * H * W)
+    assert torch.allclose(m.double(), exact, rtol=2e-2)       # (bf16 stages: three roundings to 8 bits)
