@@ -155,3 +155,21 @@ def test_functional_operators_and_reductions_on_more_than_2_pow_31_elements():
     assert same(m[:4].cpu(), ref)
     exact = torch.stack([x[sl].abs().double().sum(dim=(0, 2, 3)) for sl in chunks]).sum(0) / (N * H * W)
     assert torch.allclose(m.double(), exact, rtol=2e-2)       # (bf16 stages: three roundings to 8 bits)
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_mask_from_importance_of_150_million_entries(ties):
+    """unstructured pruning of an embedding-sized weight (reference util.py:103-117: sort, threshold at rank k, `>=`): the
+    multi-block radix select against torch's own order statistic on the GPU"""
+    from qsparse_amd.util import calculate_mask_given_importance, threshold_rank
+    n = 150_000_001
+    g = torch.Generator(device="cuda").manual_seed(21)
+    imp = torch.randn(n, generator=g, device="cuda").abs()
+    if ties:
+        imp = (imp * 64).round() / 64
+    for sparsity in (0.6, 0.999):
+        mask = calculate_mask_given_importance(imp, sparsity)
+        k = threshold_rank(sparsity, n)
+        thr = torch.kthvalue(imp, k + 1).values          # ascending position k (0-based) = the (k+1)-th smallest
+        assert torch.equal(mask, imp >= thr), (ties, sparsity)
+        assert int(mask.sum()) >= n - k
