@@ -173,3 +173,34 @@ def test_mask_from_importance_of_150_million_entries(ties):
         thr = torch.kthvalue(imp, k + 1).values          # ascending position k (0-based) = the (k+1)-th smallest
         assert torch.equal(mask, imp >= thr), (ties, sparsity)
         assert int(mask.sum()) >= n - k
+
+
+@pytest.mark.parametrize("shape", [(64, 100_003), (8, 70_001, 2, 4)])
+def test_sites_with_a_hundred_thousand_channels(shape):
+    """channel counts beyond the fused pair's 65,536-channel select (a wide nn.Linear's activation): the sites fall back to their
+    multi-block kernels; prune -> quantize trajectories on the GPU equal the CPU path's (the op-by-op mirror of the reference)"""
+    import copy
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        torch.manual_seed(0)
+        cpu = fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.7, dimensions={1}, start=1, interval=1, repetition=2)),
+            qs.quantize(bits=6, channelwise=-1, timeout=1)).train())
+        gpu = copy.deepcopy(cpu).cuda()
+        g = torch.Generator().manual_seed(3)
+        scale = torch.linspace(0.2, 3.0, shape[1]).view([1, -1] + [1] * (len(shape) - 2))
+        for step in range(4):
+            x = (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+            go = torch.randn(shape, generator=g) * 4
+            outs = []
+            for net, dev in ((cpu, "cpu"), (gpu, "cuda")):
+                xd = x.clone().to(dev).requires_grad_(True)
+                y = net(xd)
+                y.backward(go.clone().to(dev).to(y.dtype))
+                outs.append((y.detach().cpu(), xd.grad.cpu()))
+            assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1]), step
+            for (ka, va), (kb, vb) in zip(cpu.state_dict().items(), gpu.state_dict().items()):
+                assert ka == kb and same(va, vb.cpu()), (step, ka)
+    finally:
+        torch.set_num_threads(threads)
