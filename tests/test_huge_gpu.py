@@ -204,3 +204,37 @@ def test_sites_with_a_hundred_thousand_channels(shape):
                 assert ka == kb and same(va, vb.cpu()), (step, ka)
     finally:
         torch.set_num_threads(threads)
+
+
+def test_weight_path_with_a_layer_of_more_than_2_pow_31_weights():
+    """the multi-tensor weight path (qs_multi_absmax / _scale_update / _quant_fwd, qs_multi_ste_bwd) on a 70,001 x 32,768 linear layer
+    (2,293,792,768 weights) next to a small one: scale, quantized weight and weight gradient equal the layer-by-layer route's"""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs 80 GiB of free device memory")
+    res = []
+    for batched in (True, False):
+        qs.set_qsparse_options(batch_weights=batched)
+        try:
+            torch.manual_seed(0)
+            big = nn.Linear(32768, 70001, bias=False, device="cuda")
+            with torch.no_grad():
+                big.weight.copy_(_filled(tuple(big.weight.shape), 31, torch.float32, 0.02))
+            net = nn.Sequential(nn.Linear(16, 32768, device="cuda"), big)
+            net = qs.convert(net, qs.quantize(bits=4, channelwise=-1, timeout=1), weight_layers=[nn.Linear], log=False).train()
+            assert (net.__dict__.get("_qs_weight_batcher") is not None) == batched
+            g = torch.Generator().manual_seed(4)
+            for _ in range(3):
+                net.zero_grad(set_to_none=True)
+                (net(torch.randn(2, 16, generator=g).cuda()) * 1e-3).sum().backward()
+            net.eval()
+            res.append((net[1].quantize.weight.detach().clone(), net[1]._parameters["weight"].grad[::4099].clone(),
+                        net[1].weight[::4099].detach().clone(), net[0].quantize.weight.detach().clone(),
+                        float(net[1]._parameters["weight"].grad.abs().amax())))
+            del net, big
+            torch.cuda.empty_cache()
+        finally:
+            qs.set_qsparse_options(batch_weights=True)
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    assert res[0][4] == res[1][4] and res[0][4] > 0
