@@ -137,6 +137,19 @@ def _eligible(layer: nn.Module) -> bool:
             and q.batch_dimension == -1 and q.timeout > 0)
 
 
+def _batchable(model: nn.Module) -> List[nn.Module]:
+    """the eligible layers of `model` that own their quantizer callback.  `convert` gives every layer a fresh copy, but a
+    hand-built network may hand ONE callback object to several layers (the reference allows it: the callback's running-mean
+    count `t` then advances once per layer read, in forward order) -- such layers keep the inline path, whose order of
+    evaluation is the forward's own."""
+    layers = [m for m in model.modules() if _eligible(m)]
+    owners = {}
+    for m in model.modules():            # every QuantizeLayer of the tree counts, not only the eligible layers' own
+        if isinstance(m, QuantizeLayer) and m.callback is not None:
+            owners[id(m.callback)] = owners.get(id(m.callback), 0) + 1
+    return [m for m in layers if owners.get(id(m.quantize.callback), 0) == 1]
+
+
 def _hooked(q: QuantizeLayer) -> bool:
     """hooks on the quantizer or its callback (or global module hooks) must see the calls they were registered for: such a
     layer keeps its inline path"""
@@ -191,9 +204,7 @@ class WeightBatcher:
             if old is not None:
                 old.remove()
         self.model = model
-        self.layers: List[nn.Module] = [m for m in model.modules() if _eligible(m)]
-        if len({id(m.quantize.callback) for m in self.layers}) != len(self.layers):
-            raise ValueError("WeightBatcher needs one quantizer callback per layer (convert() makes them so)")
+        self.layers: List[nn.Module] = _batchable(model)
         self._pending: List[_Pending] = []
         self._amax = None
         self._decimals = None
@@ -214,7 +225,7 @@ class WeightBatcher:
     def install(model: nn.Module) -> Optional["WeightBatcher"]:
         """(re-)install on `model`: batchers found anywhere in its tree are removed first (a further ``convert`` changes
         the set of layers); returns None when no layer is eligible"""
-        if not any(_eligible(m) for m in model.modules()):
+        if not _batchable(model):
             for m in model.modules():
                 old = m.__dict__.get(_ATTR)
                 if old is not None:
@@ -223,9 +234,10 @@ class WeightBatcher:
         return WeightBatcher(model)
 
     def invalidate(self):
-        """forget the quantized weights kept for evaluation.  They are reused while no parameter and no scale has been
-        written -- detected through ``Tensor._version``, which optimizers, ``load_state_dict`` and any in-place op bump;
-        writes through ``param.data`` do not, call this after such a write."""
+        """forget the quantized weights kept for evaluation.  They are reused, under ``torch.no_grad()`` only, while no
+        parameter and no scale has been written -- detected through ``Tensor._version``, which optimizers,
+        ``load_state_dict`` and any in-place op bump; writes through ``param.data`` do not: call this (or
+        ``qs.resync_host_state(model)``, which does) after such a write between two no-grad evaluation forwards."""
         self._eval_key = self._eval_outs = self._eval_decimals = None
 
     def remove(self):
@@ -321,7 +333,10 @@ class WeightBatcher:
         # evaluation / serving: nothing changes between calls unless someone writes a parameter or a scale (both bump
         # `_version`), so the quantized weights of the previous call are handed out again without a launch
         eval_key = None
-        if not train:
+        # (only under no_grad / inference_mode: a loop that runs the network in eval() WITH gradients -- fine-tuning with
+        # frozen statistics, manual SGD or EMA through `p.data.add_()` -- may write parameters by the one route the version
+        # counter does not see, and would be handed stale weights silently; such loops pay the launch per forward)
+        if not train and not torch.is_grad_enabled():
             eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
                               tuple(w.stride())) for l, w in zip(todo, weights))
             if eval_key == self._eval_key:

@@ -69,6 +69,9 @@ def steady_state(model: nn.Module) -> bool:
 def resync_host_state(model: nn.Module) -> nn.Module:
     """re-read every counter from device memory (one sync each); call after the last ``graph.replay()``."""
     for m in model.modules():
+        batcher = m.__dict__.get("_qs_weight_batcher")
+        if batcher is not None:
+            batcher.invalidate()       # quantized weights kept for evaluation: whoever asks for a resync wrote behind our back
         if isinstance(m, PruneLayer):
             m._steps.invalidate()
             m._sparsity_host.invalidate()

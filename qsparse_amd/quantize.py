@@ -523,6 +523,17 @@ class _QuantStep(torch.autograd.Function):
         return (gx,) + (None,) * 10
 
 
+def _callback_hooked(cb: nn.Module) -> bool:
+    """hooks that must see the callback's own calls (`callback.optimize` is a plain method, `callback(...)` a module call):
+    forward / forward-pre / backward hooks on the callback, or hooks installed globally for every module -- the composite
+    route never calls the callback, so such a layer keeps the protocol route (same predicate as fused._hooked, batch._hooked)"""
+    from torch.nn.modules import module as _m
+    if (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks
+            or _m._global_backward_pre_hooks):
+        return True
+    return bool(cb._forward_hooks or cb._forward_pre_hooks or cb._backward_hooks or cb._backward_pre_hooks)
+
+
 def _dense(x: torch.Tensor) -> bool:
     if x.is_contiguous():
         return True
@@ -582,8 +593,7 @@ class QuantizeLayer(nn.Module):
         if (type(cb) is not ScalerQuantizer or self.channelwise != -1 or cb.group_num > 0 or cb.backward_passthrough
                 or not x.is_cuda or x.dim() < 2 or x.numel() == 0 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16)
                 or x.data_ptr() % 16 or not _dense(x) or _hip.logging_events()
-                or self.weight.device != x.device or self._n_updates.device != x.device
-                or cb._forward_hooks or cb._forward_pre_hooks):
+                or self.weight.device != x.device or self._n_updates.device != x.device or _callback_hooked(cb)):
             return None
         update = self.training
         if update and self.batch_dimension == 0 and qdist.exchange_active():
