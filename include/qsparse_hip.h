@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 10
+#define QS_ABI_VERSION 11
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -62,8 +62,10 @@ size_t qs_workspace_bytes(int op, int64_t n);
  * dtype when it is a Python float / 0-d tensor).  `codes` (nullable) receives q.  `chan_mask` (nullable,
  * nparam-independent, length C, one byte per channel) fuses a preceding channel PruneLayer
  * (x * mask, qsparse/sparse.py:116): masked channels are quantised as x*0.  The reference never
- * saturates (its clamp at :110-116 acts on a temporary); saturate != 0 enables q = clamp(q, lo, hi) as
- * an explicit opt-in.  pre_relu != 0 quantises max(x, 0): the nn.ReLU that convert() finds in front of the pair
+ * saturates (its clamp at :110-116 acts on a temporary, `q.float().clamp_(...)`, and is lost); saturate != 0 is that
+ * clamp with the assignment it lacks -- q = clamp(q, code_lo, code_hi) on the int32 codes, i.e. after the float -> int
+ * conversion, so a NaN input (INT_MIN) lands on code_lo -- as an explicit opt-in: code_lo / code_hi = -2^(bits-1)+notch /
+ * 2^(bits-1)-1+notch, or 0 / 2^bits-1 with use_uint (:111-116).  pre_relu != 0 quantises max(x, 0): the nn.ReLU that convert() finds in front of the pair
  * (qsparse/convert.py:214-218) folded into the same pass.
  * elide_masked != 0 (with chan_mask): the x of a pruned channel is not loaded at all -- it only ever meets `* 0`
  * (sparse.py:116) -- and the quantizer is applied to +0.0 instead: bit-identical to the loading path for every finite
@@ -342,6 +344,8 @@ typedef struct qs_site_plan {
     int64_t* quantizer_t_dev;    /* nullable: device copy of the quantizer callback's t (graph-safe mode): read instead of
                                     t_q and incremented */
     int32_t callback_t_from_device; /* != 0: the running-magnitude counter is read from *callback_t instead of t_mag */
+    int32_t saturate;            /* != 0: codes are clamped to [code_lo, code_hi] (qs_quant_scaler_fwd's opt-in saturation) */
+    int32_t code_lo, code_hi;
 } qs_site_plan;
 
 /* flags of qs_site_fwd */
@@ -371,7 +375,7 @@ int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, vo
  * re-zeroed by the update; n_updates (nullable) is incremented; t_dev (nullable) is read instead of t and incremented. */
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     qs_stream_t stream);
+                     int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
 
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 
@@ -389,13 +393,15 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
  *                           state of one the forward pass then never reached (reference imitation.py:61-68 evaluates the
  *                           operator only when the layer's weight is read)
  *   qs_multi_quant_fwd:     y[i] = Q(x[i]) with param[i][0] the scale (decimal == 0, qs_quant_scaler_fwd's
- *                           arithmetic) or the decimal (decimal != 0, qs_quant_decimal_fwd's) */
+ *                           arithmetic) or the decimal (decimal != 0, qs_quant_decimal_fwd's); code_lo / code_hi (nullable
+ *                           host arrays, both or neither): tensor i's codes are clamped to [code_lo[i], code_hi[i]] where
+ *                           code_lo[i] <= code_hi[i] (the opt-in saturation of qs_quant_scaler_fwd), left alone otherwise */
 int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream);
 int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
                           int64_t* const* t_dev, const int* bits, int32_t* const* bump, float* const* backup,
                           qs_stream_t stream);
 int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
-                       int decimal, qs_stream_t stream);
+                       int decimal, const int32_t* code_lo, const int32_t* code_hi, qs_stream_t stream);
 /*   qs_multi_ste_bwd:       gx[i] = clamp(g[i], lo_mul[i] * s_i, hi_mul[i] * s_i) with s_i = step[i][0] (or 2^-step[i][0]
  *                           with step_is_decimal): qs_quant_ste_bwd's arithmetic (quantize.py:66-77, 120-131) for the
  *                           gradients of a GROUP of weight quantizers that are handed over together */

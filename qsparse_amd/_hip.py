@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 10          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 11          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -59,9 +59,9 @@ SIGNATURES = {
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
     "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P]),
+    "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _P]),
+    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -77,7 +77,8 @@ class SitePlanStruct(ctypes.Structure):
                 ("magnitude", c_void_p), ("mask", c_void_p), ("scale", c_void_p), ("chan_absmax", c_void_p),
                 ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
-                ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32)]
+                ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32)]
 
 
 SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK = 1, 2, 4, 8, 16
@@ -793,13 +794,15 @@ def logging_events() -> bool:
 
 def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], amax_lines: Optional[torch.Tensor],
                   scale: torch.Tensor, bits: int, t: int, t_dev: Optional[torch.Tensor], n_updates: Optional[torch.Tensor],
-                  pre_relu: bool, update: bool):
-    """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout"""
+                  pre_relu: bool, update: bool, saturate=None):
+    """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout; saturate: None or the
+    (code_lo, code_hi) pair of the opt-in saturation"""
+    sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
     st = load().qs_quantize_step(x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
                                  None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
                                  x.numel(), _DT[x.dtype], _DT[y.dtype], int(bits), int(t),
                                  None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
-                                 int(bool(pre_relu)), int(bool(update)), _stream(x))
+                                 int(bool(pre_relu)), int(bool(update)), sat, lo, hi, _stream(x))
     if st:
         _check(st, "qs_quantize_step")
 
@@ -859,9 +862,16 @@ def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_pt
     _check(st, "qs_multi_scale_update")
 
 
-def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device, nbytes: int = 0):
+def i32_array(values):
+    return (c_int32 * len(values))(*[int(v) for v in values])
+
+
+def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device, nbytes: int = 0, code_lo=None,
+                    code_hi=None):
+    """code_lo / code_hi: `i32_array`s (both or neither) -- tensor i saturates to [lo, hi] where lo <= hi"""
     with _timed("multi_quant_fwd", int(nbytes)):
-        st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), _device_stream(device))
+        st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), code_lo, code_hi,
+                                       _device_stream(device))
     _check(st, "qs_multi_quant_fwd")
 
 

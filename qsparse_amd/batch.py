@@ -338,7 +338,7 @@ class WeightBatcher:
         # counter does not see, and would be handed stale weights silently; such loops pay the launch per forward)
         if not train and not torch.is_grad_enabled():
             eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
-                              tuple(w.stride())) for l, w in zip(todo, weights))
+                              tuple(w.stride()), l.quantize.callback.code_range(l.quantize.bits)) for l, w in zip(todo, weights))
             if eval_key == self._eval_key:
                 self._hand_out(todo, weights, self._eval_outs, slot, {}, self._eval_decimals)
                 return
@@ -347,7 +347,8 @@ class WeightBatcher:
         with torch.no_grad():
             # everything that does not change from step to step -- the pointer arrays of the three launches, the layout of
             # the flat output buffer -- is built once per (set of layers, parameter storage) and reused
-            key = (len(train), get_option("graph_safe")) + tuple((id(l), w.data_ptr(), w.numel(), l.quantize.weight.data_ptr(),
+            sats = [l.quantize.callback.code_range(l.quantize.bits) for l in todo]
+            key = (len(train), get_option("graph_safe"), tuple(sats)) + tuple((id(l), w.data_ptr(), w.numel(), l.quantize.weight.data_ptr(),
                                                                    l.quantize._n_updates.data_ptr()) for l, w in zip(todo, weights))
             plan = self._plan if self._plan is not None and self._plan.get("key") == key else None
             if plan is None:
@@ -375,8 +376,12 @@ class WeightBatcher:
                         params = [self._decimals[slot[id(todo[i])]:slot[id(todo[i])] + 1] if decimal else todo[i].quantize.weight.data
                                   for i in idx]
                         plan["keep"] += params
+                        # opt-in saturation per layer: (lo, hi) with lo <= hi, or the empty range (1, 0) for "none"
+                        los = _hip.i32_array([1 if sats[i] is None else sats[i][0] for i in idx]) if any(sats[i] for i in idx) else None
+                        his = _hip.i32_array([0 if sats[i] is None else sats[i][1] for i in idx]) if los is not None else None
                         groups.append((decimal, idx, _hip.ptr_array([weights[i] for i in idx]), _hip.ptr_array(params),
-                                       _hip.i64_array([plan["numels"][i] for i in idx]), 8 * sum(plan["numels"][i] for i in idx)))
+                                       _hip.i64_array([plan["numels"][i] for i in idx]), 8 * sum(plan["numels"][i] for i in idx),
+                                       los, his))
                 plan["groups"] = groups
                 self._plan = plan
             if train:
@@ -402,9 +407,10 @@ class WeightBatcher:
             base = flat.data_ptr()
             so = flat.storage_offset()
             outs = [flat.as_strided(w.shape, w.stride(), so + o) for o, w in zip(plan["offsets"], weights)]   # w's own layout
-            for decimal, idx, x_ptrs, param_ptrs, numels, nbytes in plan["groups"]:
+            for decimal, idx, x_ptrs, param_ptrs, numels, nbytes, los, his in plan["groups"]:
                 y_ptrs = (_hip.ctypes.c_void_p * len(idx))(*[base + 4 * plan["offsets"][i] for i in idx])
-                _hip.multi_quant_fwd(len(idx), x_ptrs, y_ptrs, param_ptrs, numels, decimal, dev, nbytes=nbytes)
+                _hip.multi_quant_fwd(len(idx), x_ptrs, y_ptrs, param_ptrs, numels, decimal, dev, nbytes=nbytes, code_lo=los,
+                                     code_hi=his)
             # a DecimalQuantizer's backward clamps with the decimal of ITS forward (the reference computes a fresh tensor per
             # call, quantize.py:312-325, and the Function saves that one, :41): the hand-out nodes get this step's values, not
             # the buffer the next precomputation overwrites (a ScalerQuantizer's saves the scale parameter itself, :108)

@@ -180,8 +180,8 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, cm ? outer : 1, cm ? p->C : 1, cm ? inner : outer * p->C * inner,
-                               p->xdt, p->ydt, QS_F32, 0, 0, 0, pre_relu, (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out,
-                               imgdt, stream);
+                               p->xdt, p->ydt, QS_F32, p->saturate, p->code_lo, p->code_hi, pre_relu,
+                               (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out, imgdt, stream);
 }
 
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
@@ -200,7 +200,7 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
 
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     qs_stream_t stream) {
+                     int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
     if (!x || !y || !scale || numel < 0) return QS_ERR_ARG;
     if (numel == 0) return QS_OK;
     if (update) {
@@ -210,8 +210,8 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
         st = qs_scale_update(amax_lines, lines, scale, 1, t, t_dev, 1, bits, 1, n_updates, xdt, stream);
         if (st) return st;
     }
-    return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, 0, 0, 0, pre_relu, 0, gate_out,
-                               nullptr, 0, stream);
+    return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, saturate, code_lo, code_hi,
+                               pre_relu, 0, gate_out, nullptr, 0, stream);
 }
 
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
@@ -264,8 +264,8 @@ int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float*
 }
 
 int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
-                       int decimal, qs_stream_t stream) {
-    if (n < 0 || (n > 0 && (!x || !y || !param || !numel))) return QS_ERR_ARG;
+                       int decimal, const int32_t* code_lo, const int32_t* code_hi, qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !y || !param || !numel)) || ((code_lo == nullptr) != (code_hi == nullptr))) return QS_ERR_ARG;
     for (int base = 0; base < n; base += kMultiMax) {
         MultiTensors a{};
         a.n = std::min(kMultiMax, n - base);
@@ -278,6 +278,8 @@ int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* con
             a.y[i] = y[k];
             a.scale[i] = param[k];
             a.numel[i] = numel[k];
+            a.lo[i] = code_lo ? code_lo[k] : 1;
+            a.hi[i] = code_lo ? code_hi[k] : 0;
             a.block0[i] = (int32_t)blocks;
             blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
             if (blocks > 0x7fffffff) return QS_ERR_ARG;

@@ -12,12 +12,13 @@ namespace qs {
 
 constexpr int kMultiMax = 48;
 
-struct MultiTensors {           // 48 * (8 + 8 + 8 + 8 + 4) + 8 = 1736 bytes of kernel arguments
+struct MultiTensors {           // 48 * (8 + 8 + 8 + 8 + 4 + 4 + 4) + 8 = 2120 bytes of kernel arguments
     const float* x[kMultiMax];
     float* y[kMultiMax];        // quantized output (multi_quant_kernel only)
     float* scale[kMultiMax];    // one-element running scale (QuantizeLayer.weight)
     int64_t numel[kMultiMax];
     int32_t block0[kMultiMax + 1];
+    int32_t lo[kMultiMax], hi[kMultiMax];   // code range of the opt-in saturation (multi_quant_kernel; lo > hi: none)
     int32_t n;
 };
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void multi_quant_kernel(MultiTensors a) {
     const int64_t numel = a.numel[i], ngroups = numel / 8;
     int32_t code;
     if constexpr (DECIMAL) {
-        const DecimalFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, 0, 0, 0, 0};
+        const DecimalFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, a.lo[i] <= a.hi[i], a.lo[i], a.hi[i], 0};
         const auto p = op.channel(0);
         if (g < ngroups) {
             float v[8];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void multi_quant_kernel(MultiTensors a) {
         if (g == 0)
             for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(x[e], p, code);
     } else {
-        const ScalerFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, 0, 0, 0, 0};
+        const ScalerFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, a.lo[i] <= a.hi[i], a.lo[i], a.hi[i], 0};
         const auto p = op.channel(0);
         if (g < ngroups) {
             float v[8];

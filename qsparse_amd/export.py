@@ -63,12 +63,41 @@ class QuantizedTensor:
         return (q + self._on_channel(self.zero_point.float())) * self._on_channel(self.step)
 
     def int8(self) -> torch.Tensor:
-        """the codes as int8 -- raises if a code does not fit (the reference's forward does not saturate: the tensor's
-        largest element maps to +2^(bits-1), one above the two's-complement range)"""
-        lo, hi = int(self.codes.min()), int(self.codes.max())
+        """the codes as int8 -- raises if a code does not fit.  The reference's forward does not saturate (the tensor's
+        largest element maps to +2^(bits-1), one above the two's-complement range): train / export with
+        ``set_qsparse_options(saturate=True)`` or ``ScalerQuantizer(saturate=True)`` and every code fits its bit width."""
+        lo, hi = (int(self.codes.min()), int(self.codes.max())) if self.codes.numel() else (0, 0)
         if lo < -128 or hi > 127:
-            raise OverflowError(f"codes span [{lo}, {hi}]: not representable in int8 (no forward saturation, quirk B1)")
+            raise OverflowError(f"codes span [{lo}, {hi}]: not representable in int8 (no forward saturation, quirk B1; "
+                                "see the `saturate` option)")
         return self.codes.to(torch.int8)
+
+    def uint8(self) -> torch.Tensor:
+        """the codes as uint8 (``use_uint`` quantizers under ``saturate``, line quantizers of up to 8 bits)"""
+        lo, hi = (int(self.codes.min()), int(self.codes.max())) if self.codes.numel() else (0, 0)
+        if lo < 0 or hi > 255:
+            raise OverflowError(f"codes span [{lo}, {hi}]: not representable in uint8")
+        return self.codes.to(torch.uint8)
+
+    def int4_packed(self) -> torch.Tensor:
+        """two 4-bit codes per byte, flat in memory order: element 2i in the low nibble, 2i + 1 in the high one, two's
+        complement for signed codes in [-8, 7] and plain for unsigned ones in [0, 15] (an odd count pads with 0).  Raises
+        when a code needs more than four bits -- without ``saturate`` a 4-bit tensor's largest element is code +8 (quirk B1)."""
+        q = self.codes.reshape(-1)
+        lo, hi = (int(q.min()), int(q.max())) if q.numel() else (0, 0)
+        if not ((lo >= -8 and hi <= 7) or (lo >= 0 and hi <= 15)):
+            raise OverflowError(f"codes span [{lo}, {hi}]: not representable in 4 bits (see the `saturate` option)")
+        if q.numel() % 2:
+            q = torch.cat([q, q.new_zeros(1)])
+        nib = (q & 0xF).to(torch.uint8).view(-1, 2)
+        return nib[:, 0] | (nib[:, 1] << 4)
+
+    @staticmethod
+    def unpack_int4(packed: torch.Tensor, numel: int, signed: bool = True) -> torch.Tensor:
+        """inverse of ``int4_packed``: int32 codes, flat"""
+        b = packed.to(torch.int32)
+        q = torch.stack([b & 0xF, (b >> 4) & 0xF], dim=1).view(-1)[:numel]
+        return torch.where(q >= 8, q - 16, q) if signed else q
 
 
 @dataclass

@@ -70,7 +70,7 @@ class _FusedApply(torch.autograd.Function):
     """y = Q(relu?(x) * mask) forward, gx = gate * clamp(g) * mask backward, each one pass over the tensor."""
 
     @staticmethod
-    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False):
+    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False, saturate=None):
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
         ctx.pre_relu = pre_relu
         ctx.has_mask = mask_c is not None
@@ -88,7 +88,7 @@ class _FusedApply(torch.autograd.Function):
         # decimal computed at THIS forward for a DecimalQuantizer (a fresh tensor, quantize.py:312-325 -> :41)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
         res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
-                             pre_relu=pre_relu, want_gate=want_gate)
+                             pre_relu=pre_relu, want_gate=want_gate, saturate=saturate)
         # the bitmap travels through save_for_backward like any saved activation (released with the graph, visible to
         # saved-tensor hooks); only its description -- shape, dtype, layout -- stays on ctx
         if want_gate:
@@ -104,17 +104,17 @@ class _FusedApply(torch.autograd.Function):
         mask_c, step, x = ctx.saved_tensors
         mask_c = mask_c if ctx.has_mask else None
         if not ctx.quant_on:
-            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 7
+            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 8
         limit = 2.0 ** (ctx.bits - 1)
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
                                    limit - 1 + ctx.notch, mask_c, gate=gate)
-            return (gx,) + (None,) * 7
+            return (gx,) + (None,) * 8
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
                           out_dtype, chan_mask=mask_c, mask_channel_index=1)
-        return (gx,) + (None,) * 7
+        return (gx,) + (None,) * 8
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -161,7 +161,8 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     graph_safe = bool(get_option("graph_safe"))
     t_q_dev = qc.device_t(h.device) if graph_safe else None
     out_dtype = _out_dtype(h)
-    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits) + tuple(t.data_ptr() for t in state) + \
+    sat = qc.code_range(q.bits)
+    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat) + tuple(t.data_ptr() for t in state) + \
         ((t_q_dev.data_ptr(),) if t_q_dev is not None else ())
     plan = q.__dict__.get("_qs_site_plan")
     if plan is not None and plan.key == key:
@@ -182,6 +183,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     c.prune_n_updates, c.quant_n_updates, c.callback_t = p._n_updates.data_ptr(), q._n_updates.data_ptr(), cb.t.data_ptr()
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
+    c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
@@ -485,7 +487,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             return dual
         return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
-                             1 if qc.flip_axis else 0, quant_on, pre_relu)
+                             1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -626,7 +628,7 @@ def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
         else:
             q._steps.add(q._n_updates, 1)
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
-    return _FusedApply.apply(x, None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0, True, True)
+    return _FusedApply.apply(x, None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0, True, True, qc.code_range(q.bits))
 
 
 class FusedActQuantize(nn.Sequential):

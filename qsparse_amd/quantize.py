@@ -50,6 +50,19 @@ def _out_dtype(x: torch.Tensor) -> torch.dtype:
     return torch.float32
 
 
+def code_range(bits: int, notch: int = 0, use_uint: bool = False, saturate=None):
+    """``(code_lo, code_hi)`` of the opt-in forward saturation, or None when it is off (the reference's behaviour).
+    ``saturate``: True / False, or None to follow ``set_qsparse_options(saturate=...)``.  The range is the one the
+    reference's forward names in its lost clamp (quantize.py:56-62, 110-116): ``[0, 2^bits - 1]`` with ``use_uint``, else
+    ``[-2^(bits-1) + notch, 2^(bits-1) - 1 + notch]`` (``notch = 1`` with ``flip_axis``)."""
+    if saturate is None:
+        saturate = get_option("saturate")
+    if not saturate:
+        return None
+    limit = 2 ** (bits - 1)
+    return (0, 2 * limit - 1) if use_uint else (-limit + notch, limit - 1 + notch)
+
+
 def _gpu_dtype_guard(x: torch.Tensor, qd: torch.dtype):
     if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or qd not in (torch.float32, x.dtype):
         raise _hip.QsparseHipError(
@@ -82,19 +95,19 @@ class _SteFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, grad_output, step_is_decimal: bool):
         if ctx.backward_passthrough:
-            return (grad_output,) + (None,) * 7
+            return (grad_output,) + (None,) * 8
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         (step,) = ctx.saved_tensors
         if grad_output.is_cuda:
             out_dtype = ctx.x_dtype if grad_output.dtype == torch.float32 else grad_output.dtype
             gx = _hip.ste_bwd(grad_output, step, step_is_decimal, ctx.channel_index, lo_mul, hi_mul, False, out_dtype)
-            return (gx,) + (None,) * 7
+            return (gx,) + (None,) * 8
         s = torch.pow(2.0, -step) if step_is_decimal else step
         if s.numel() > 1:
             s = _on_channel(s, grad_output.dim(), ctx.channel_index, grad_output.shape[ctx.channel_index])
         # values are clamped; nothing is zeroed (the reference's masked assignment is a no-op)
-        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 7
+        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 8
 
 
 class ScalerQuantization(_SteFunction):
@@ -103,13 +116,15 @@ class ScalerQuantization(_SteFunction):
     @staticmethod
     def forward(ctx, input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = 1,
                 use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
-                return_codes: bool = False):
+                return_codes: bool = False, saturate=None):
         """``return_codes`` (extension): also return the int32 codes ``q`` -- on the GPU the kernel's own ``codes`` output
-        of the same pass, never a second evaluation"""
+        of the same pass, never a second evaluation.  ``saturate`` (extension, see ``code_range``): clamp the codes to the
+        bit width's range -- the clamp the reference's forward spells out and loses; the backward is unchanged"""
         ctx.backward_passthrough = backward_passthrough
         ctx.notch = 1 if flip_axis else 0
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
         ctx.save_for_backward(ensure_tensor(scaler).detach())
+        sat = code_range(bits, ctx.notch, use_uint, saturate)
         if input.is_cuda:
             qd = _quotient_dtype(input, scaler)
             _gpu_dtype_guard(input, qd)
@@ -117,11 +132,13 @@ class ScalerQuantization(_SteFunction):
                 assert len(scaler) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
             y, codes = _hip.quant_fwd("scaler", input, scaler, channel_index, qd, out_dtype=_out_dtype(input),
-                                      want_codes=return_codes)
+                                      want_codes=return_codes, saturate=sat)
             return _with_codes(ctx, _reference_shape(y, input, scaler), codes, return_codes)
         s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
         codes = torch.round(input / s).int()
-        return _with_codes(ctx, (codes.float() * s).to(_out_dtype(input)), codes, return_codes)  # no saturation: see module docstring
+        if sat is not None:      # (the reference's own line with the assignment it lacks; off by default: see module docstring)
+            codes = codes.clamp(sat[0], sat[1])
+        return _with_codes(ctx, (codes.float() * s).to(_out_dtype(input)), codes, return_codes)
 
     @staticmethod
     def backward(ctx, grad_output, grad_codes=None):
@@ -134,11 +151,12 @@ class DecimalQuantization(_SteFunction):
     @staticmethod
     def forward(ctx, input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = 1,
                 use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
-                return_codes: bool = False):
+                return_codes: bool = False, saturate=None):
         ctx.backward_passthrough = backward_passthrough
         ctx.notch = 1 if flip_axis else 0
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
         ctx.save_for_backward(ensure_tensor(decimal).detach().float())
+        sat = code_range(bits, ctx.notch, use_uint, saturate)
         if input.is_cuda:
             qd = _quotient_dtype(input, decimal.float() if isinstance(decimal, torch.Tensor) else 1.0)
             _gpu_dtype_guard(input, qd)
@@ -146,11 +164,13 @@ class DecimalQuantization(_SteFunction):
                 assert len(decimal) == input.shape[channel_index], \
                     "channel of input and decimal must be equal in channel-wise quantization"
             y, codes = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input),
-                                      want_codes=return_codes)
+                                      want_codes=return_codes, saturate=sat)
             return _with_codes(ctx, _reference_shape(y, input, decimal), codes, return_codes)
         to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
         to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
         codes = (input * to_int).int()
+        if sat is not None:
+            codes = codes.clamp(sat[0], sat[1])
         return _with_codes(ctx, (codes.float() * to_float).to(_out_dtype(input)), codes, return_codes)
 
     @staticmethod
@@ -199,7 +219,7 @@ class LineQuantization(torch.autograd.Function):
 
 def quantize_with_decimal(input: torch.Tensor, bits: int = 8, decimal: TensorOrInt = 5, channel_index: int = -1,
                           use_uint: bool = False, backward_passthrough: bool = False,
-                          flip_axis: bool = False, return_codes: bool = False) -> torch.Tensor:
+                          flip_axis: bool = False, return_codes: bool = False, saturate=None) -> torch.Tensor:
     """power-of-two uniform quantization (reference quantize.py:188-208).
 
     Args mirror the reference: ``decimal`` is the number of fractional bits (int, or per-channel
@@ -207,18 +227,20 @@ def quantize_with_decimal(input: torch.Tensor, bits: int = 8, decimal: TensorOrI
     effect; ``backward_passthrough`` skips the gradient clamp; ``flip_axis`` shifts the clamp
     interval by one step.  ``return_codes`` (extension of this package): return ``(y, q)`` with the int32 codes
     ``q = int(x * 2^d)`` the output was built from (``y == q.float() * 2^-d``) -- the integers an int8/int32 inference
-    engine consumes (reference tests/test_quantize.py:73-101)."""
+    engine consumes (reference tests/test_quantize.py:73-101).  ``saturate`` (extension): clamp the codes to the bit
+    width's range (``code_range``); with it ``use_uint`` selects the unsigned range the reference names."""
     return DecimalQuantization.apply(input, bits, decimal, channel_index, use_uint, backward_passthrough, flip_axis,
-                                     return_codes)
+                                     return_codes, saturate)
 
 
 def quantize_with_scaler(input: torch.Tensor, bits: int = 8, scaler: TensorOrFloat = 0.1, channel_index: int = -1,
                          use_uint: bool = False, backward_passthrough: bool = False,
-                         flip_axis: bool = False, return_codes: bool = False) -> torch.Tensor:
+                         flip_axis: bool = False, return_codes: bool = False, saturate=None) -> torch.Tensor:
     """scaling-factor based uniform quantization (reference quantize.py:210-230).  ``return_codes`` (extension):
-    return ``(y, q)`` with the int32 codes ``q = int(round(x / s))``, ``y == q.float() * s``."""
+    return ``(y, q)`` with the int32 codes ``q = int(round(x / s))``, ``y == q.float() * s``.  ``saturate`` (extension):
+    ``q = clamp(q, code_range(bits, ...))`` -- what quantize.py:110-116 spells out -- default: the ``saturate`` option (off)."""
     return ScalerQuantization.apply(input, bits, scaler, channel_index, use_uint, backward_passthrough, flip_axis,
-                                    return_codes)
+                                    return_codes, saturate)
 
 
 def quantize_with_line(x: torch.Tensor, bits: int = 8,
@@ -269,8 +291,11 @@ class DecimalQuantizer(BaseQuantizer):
     weight_size = 1
 
     def __init__(self, use_uint: bool = False, backward_passthrough: bool = False, flip_axis: bool = False,
-                 group_num=-1, group_timeout=512):
+                 group_num=-1, group_timeout=512, saturate=None):
+        """``saturate`` (extension; Scaler / Decimal): clamp the integer codes to the bit width's range, see ``code_range``;
+        None follows ``set_qsparse_options(saturate=...)`` (default off: the reference never saturates, quirk B1)"""
         super().__init__()
+        self.saturate = saturate
         self.use_uint = use_uint
         self.backward_passthrough = backward_passthrough
         self.flip_axis = flip_axis
@@ -314,8 +339,15 @@ class DecimalQuantizer(BaseQuantizer):
             param = _hip.decimal_from_scale(scaler).view(scaler.shape)
         else:
             param = (1 / scaler).nan_to_num(posinf=1, neginf=1).log2().round()   # quantize.py:316
-        return self.function(tensor, bits, param, channel_index, self.use_uint, self.backward_passthrough,
-                             self.flip_axis)
+        args = (tensor, bits, param, channel_index, self.use_uint, self.backward_passthrough, self.flip_axis)
+        sat = self.__dict__.get("saturate")
+        if sat is not None or get_option("saturate"):     # (a user-supplied `function` keeps the reference's seven arguments)
+            args += (False, sat)
+        return self.function(*args)
+
+    def code_range(self, bits: int):
+        """the (lo, hi) this quantizer saturates its codes to, or None (off)"""
+        return code_range(bits, 1 if self.flip_axis else 0, self.use_uint, self.__dict__.get("saturate"))
 
     def export(self, tensor, bits, scaler, channel_index=-1) -> dict:
         """integer form of ``self(tensor, bits, scaler, channel_index)`` (extension, see qsparse_amd/export.py): the
@@ -325,12 +357,12 @@ class DecimalQuantizer(BaseQuantizer):
                 scaler = self._group_scales(scaler)
             if self.use_float_scaler:
                 y, codes = self.function(tensor, bits, scaler, channel_index, self.use_uint, self.backward_passthrough,
-                                         self.flip_axis, True)
+                                         self.flip_axis, True, self.__dict__.get("saturate"))
                 return dict(kind="scaler", codes=codes, values=y, scale=scaler.detach().clone())
             decimal = (_hip.decimal_from_scale(scaler).view(scaler.shape) if scaler.is_cuda
                        else (1 / scaler).nan_to_num(posinf=1, neginf=1).log2().round())
             y, codes = self.function(tensor, bits, decimal, channel_index, self.use_uint, self.backward_passthrough,
-                                     self.flip_axis, True)
+                                     self.flip_axis, True, self.__dict__.get("saturate"))
             return dict(kind="decimal", codes=codes, values=y, decimal=decimal.to(torch.int32))
 
     def optimize(self, x, bits, weight=None, batched=False, channel_index=-1, **kwargs):
@@ -496,13 +528,13 @@ class _QuantStep(torch.autograd.Function):
     quantization -- or the quantization alone); backward = the STE clamp, with the gate of a folded ReLU when `pre_relu`"""
 
     @staticmethod
-    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype):
+    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None):
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
         gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if want_gate else None
         if want_gate:
             _hip.note_gate(gate_bits)
-        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update)
+        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update, saturate)
         ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.channels_last = x.dim() in (4, 5) and not x.is_contiguous()
@@ -520,7 +552,7 @@ class _QuantStep(torch.autograd.Function):
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)
-        return (gx,) + (None,) * 10
+        return (gx,) + (None,) * 11
 
 
 def _callback_hooked(cb: nn.Module) -> bool:
@@ -602,7 +634,8 @@ class QuantizeLayer(nn.Module):
             return None
         t_dev = cb.device_t(x.device) if (update and get_option("graph_safe")) else None
         y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
-                             self._n_updates.data if update else None, pre_relu, update, 1 if cb.flip_axis else 0, _out_dtype(x))
+                             self._n_updates.data if update else None, pre_relu, update, 1 if cb.flip_axis else 0, _out_dtype(x),
+                             cb.code_range(self.bits))
         if update:
             if t == self.timeout and get_option("log_during_train"):
                 logging.warn(f"quantizing {self.name} with {self.bits} bits")

@@ -12,14 +12,15 @@ import torch.nn as nn
 from qsparse_amd import _hip
 
 _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
-             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": False}
+             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": False,
+             "saturate": False}
 
 
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
                 elide_pruned: Optional[str] = None, relu_gate: Optional[bool] = None, batch_weights: Optional[bool] = None,
-                autocast_image: Optional[bool] = None):
+                autocast_image: Optional[bool] = None, saturate: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
@@ -43,7 +44,13 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     ``autocast_image`` (extension, default False; value-identical): under ``torch.autocast`` a fused ReLU -> prune -> quantize
     site hands the first convolution / linear that consumes its float32 output the bf16 image directly and takes that
     consumer's bf16 gradient as it is -- no ``fp32 <-> bf16`` cast passes around the site (see fused.py, "Autocast image");
-    the site's output is then a ``torch.Tensor`` subclass."""
+    the site's output is then a ``torch.Tensor`` subclass;
+    ``saturate`` (extension, default False): the Scaler / Decimal quantizers clamp their integer codes to the range of the
+    bit width -- ``[-2^(bits-1) + notch, 2^(bits-1) - 1 + notch]``, or ``[0, 2^bits - 1]`` with ``use_uint`` -- which is what
+    the reference's forward spells out but loses (its ``q.float().clamp_(...)`` acts on a temporary, quantize.py:56-62,
+    110-116, so its tensor's largest element maps to code ``+2^(bits-1)``, one above the range).  Per quantizer:
+    ``ScalerQuantizer(saturate=True)`` / ``quantize_with_scaler(..., saturate=True)``; ``None`` there follows this option.
+    With it every code fits its bit width, so ``export_integer(...)`` yields int8 / packed int4 tensors directly."""
     if elide_pruned is not None:
         if elide_pruned not in ("off", "forward", "all"):
             raise ValueError(f"elide_pruned must be 'off', 'forward' or 'all', got {elide_pruned!r}")
@@ -52,7 +59,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
                      ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu), ("relu_gate", relu_gate),
-                     ("batch_weights", batch_weights), ("autocast_image", autocast_image)):
+                     ("batch_weights", batch_weights), ("autocast_image", autocast_image), ("saturate", saturate)):
         if val is not None:
             _options_[key] = val
 

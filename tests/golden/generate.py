@@ -25,6 +25,7 @@ Reference entry points exercised (file:line in /root/reference):
   F13 UniformPruningCallback trajectories      qsparse/sparse.py:125-152 (numpy global RNG, seeded per case)
   F14 counters written through ``.data``       qsparse/quantize.py:495, qsparse/sparse.py:251-269,104-118
   F15 MagnitudePruningCallback(use_gradient=True)  qsparse/sparse.py:69-80 (tensor hook -> update_magnitude(grad), :82-89)
+  F16 the MNIST --pq recipe with devise_layerwise_pruning_schedule  examples/mnist.py:17-44,193-199; qsparse/sparse.py:343-359
 """
 import io
 import json
@@ -853,8 +854,120 @@ def f15():
     save("f15_prune_use_gradient", store, dict(cases=cases))
 
 
+# --------------------------------------------------------------------------------------------
+# F16: the reference's own config-1 recipe -- examples/mnist.py:193-199: convert(prune) + convert(quantize) and THEN
+# devise_layerwise_pruning_schedule(start=2E, interval=0.4E, mask_refresh_interval=0.1E) -- on its MNIST Net (:17-44) with
+# synthetic digits, Adadelta, dropout and batch norm live.  E (the epoch size) is scaled down so that the whole schedule
+# runs in a few dozen steps; the four variants keep what matters about the real E = 938:
+#   fractional        E = 7: interval 2.8, refresh interval 0.7 -- as with 938 (375.2 / 93.8) `t % interval == 0` never holds
+#                     for t > 0, the second layer's start (17.8) is never a step index: masks stay all-ones
+#   integer_default   E = 10, the recipe as written: interval 4.0, refresh 1.0 (floats, integer-valued).  The layers keep the
+#                     `rampup_interval` of prune()'s DEFAULT interval (1000, quirk B10), so the first scheduled sparsity is
+#                     0.75 * (1 - (1 - 1000/4)^3) and the first mask refresh raises IndexError -- recorded: step and message
+#   integer_prunes    E = 10 with prune(..., interval=4): rampup_interval == interval, the schedule lands on 0.75 and prunes
+#   weights           E = 10, convert(prune(0.5, interval=4), weight_layers=[Conv2d]): every PruneLayer is a `.prune`, so the
+#                     schedule switches the callbacks to running_average=False (sparse.py:355-356)
+# Recorded per step: the loss and every state tensor of every PruneLayer / QuantizeLayer (masks, magnitudes, scales, counters,
+# `_cur_sparsity`, callback.t); per case: the schedule attributes the function wrote, str(model), the exception if any.
+# --------------------------------------------------------------------------------------------
+F16_CASES = (dict(name="fractional", E=7, steps=50, prune=dict(sparsity=0.75, dimensions=[1]), where="activations", seed=11),
+             dict(name="integer_default", E=10, steps=40, prune=dict(sparsity=0.75, dimensions=[1]), where="activations", seed=12),
+             dict(name="integer_prunes", E=10, steps=66, prune=dict(sparsity=0.75, dimensions=[1], interval=4), where="activations",
+                  seed=13),
+             dict(name="weights", E=10, steps=60, prune=dict(sparsity=0.5, interval=4), where="weights", seed=14))
+
+
+def f16_recipe(ns, case):
+    """the recipe of examples/mnist.py:193-199 against the namespace `ns` (the reference here; tests/test_host_golden.py
+    carries the same lines against the package)"""
+    E = case["E"]
+    kw = dict(case["prune"])
+    if "dimensions" in kw:
+        kw["dimensions"] = set(kw["dimensions"])
+    torch.manual_seed(case["seed"])
+    model = MnistNet()
+    if case["where"] == "activations":
+        model = ns.convert(model, ns.prune(**kw), activation_layers=[nn.ReLU], excluded_activation_layer_indexes=[(nn.ReLU, [-1])])
+    else:
+        model = ns.convert(model, ns.prune(**kw), weight_layers=[nn.Conv2d])
+    model = ns.convert(model, ns.quantize(bits=4, channelwise=-1, timeout=5 * E), activation_layers=[nn.ReLU],
+                       weight_layers=[nn.Conv2d, nn.Linear], input=True)
+    return ns.devise_layerwise_pruning_schedule(model, start=2 * E, interval=0.4 * E, mask_refresh_interval=0.1 * E)
+
+
+def f16_batches(case, batch=8):
+    g = gen(1600 + case["seed"])
+    protos = torch.randn(10, 1, 28, 28, generator=g)
+    for _ in range(case["steps"]):
+        y = torch.randint(0, 10, (batch,), generator=g)
+        yield protos[y] + 0.5 * torch.randn(batch, 1, 28, 28, generator=g), y
+
+
+def f16_operator_state(model, prune_cls, quant_cls):
+    out = {}
+    for path, m in model.named_modules():
+        if isinstance(m, (prune_cls, quant_cls)):
+            for k, v in m.state_dict().items():
+                out[f"{path}.{k}"] = v
+    return out
+
+
+def f16():
+    rs, rq = sys.modules["qsparse.sparse"], sys.modules["qsparse.quantize"]     # (`qsparse.quantize` the attribute is the function)
+
+    class NS:
+        convert, prune, quantize = staticmethod(convert), staticmethod(prune), staticmethod(quantize)
+        devise_layerwise_pruning_schedule = staticmethod(devise_layerwise_pruning_schedule)
+
+    store, cases = {}, []
+    for idx, case in enumerate(F16_CASES):
+        with quiet():
+            model = f16_recipe(NS, case)
+        players = [(p, m) for p, m in model.named_modules() if isinstance(m, rs.PruneLayer)]
+        sched = [dict(path=p, start=m.start, interval=m.interval, repetition=m.repetition, schedules=list(m.schedules),
+                      rampup_interval=m.rampup_interval, mask_refresh_interval=m.callback.mask_refresh_interval,
+                      stop_mask_refresh=m.callback.stop_mask_refresh, running_average=bool(m.callback.running_average))
+                 for p, m in players]
+        opt = torch.optim.Adadelta(model.parameters(), lr=1.0)
+        model.train()
+        k = f"c{idx}_"
+        error = None
+        done = 0
+        series = {}
+        torch.manual_seed(100 + case["seed"])               # dropout
+        for s, (x, y) in enumerate(f16_batches(case)):
+            opt.zero_grad()
+            try:
+                with quiet():
+                    loss = F.nll_loss(model(x), y)
+            except Exception as e:                          # noqa: BLE001  (the reference's own failure is the datum)
+                error = dict(step=s, type=type(e).__name__, message=str(e))
+                break
+            loss.backward()
+            opt.step()
+            series.setdefault("loss", []).append(np.float64(loss.item()))
+            for name, v in f16_operator_state(model, rs.PruneLayer, rq.QuantizeLayer).items():
+                series.setdefault(name, []).append(v.detach().cpu().numpy().copy())
+            done = s + 1
+        for name, vals in series.items():                   # one array per state tensor: [steps, *shape] (a tensor whose shape
+            try:                                            # changes on first use -- the placeholders -- is stored per step)
+                store[k + name] = np.stack(vals)
+            except ValueError:
+                for s, v in enumerate(vals):
+                    store[k + f"{name}@{s}"] = v
+        cases.append(dict(id=idx, **case, steps_done=done, error=error, schedule=sched, tree=str(model),
+                          state_keys=sorted(f16_operator_state(model, rs.PruneLayer, rq.QuantizeLayer))))
+        print(f"  F16 {case['name']}: {done} steps, error={error}, kept="
+              f"{[int(m.mask.sum()) if m.mask.dim() else None for _, m in players]}")
+    save("f16_mnist_layerwise_recipe", store, dict(cases=cases))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:                                   # regenerate chosen fixtures only: generate.py f16 ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     f1_f2()
     f3()
     f4()
@@ -868,3 +981,4 @@ if __name__ == "__main__":
     f13()
     f14()
     f15()
+    f16()

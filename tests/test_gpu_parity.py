@@ -84,6 +84,13 @@ def test_golden_f13_uniform_pruning_callback():
     H.run_f13(DEV)
 
 
+def test_golden_f16_mnist_recipe_with_layerwise_schedule():
+    """the reference's config-1 recipe (examples/mnist.py:193-199) trained on the GPU: module tree, schedule attributes,
+    every counter, `_cur_sparsity`, the kept-entry count of every mask at every step and the reference's IndexError (same
+    step, same index) -- see run_f16 for what can and cannot be compared across convolution arithmetics"""
+    H.run_f16(DEV)
+
+
 def test_golden_f9_reference_checkpoint_on_gpu():
     """row f3 of SURVEY 8: a checkpoint written by the REFERENCE (fixture F9: quantize(prune(Conv2d)) after 45 steps) is
     preloaded + loaded, moved to the GPU and evaluated there.  State tensors survive `.cuda()` bit for bit; the
