@@ -379,10 +379,107 @@ def resnet_config(arch, batch, device, steps):
         # float32 output and takes that convolution's bf16 gradient as it is (fused.py "Autocast image") -- same values as
         # the default path, no fp32 <-> bf16 cast passes around the site; opt-in because the site's output is a Tensor subclass
         opt_in_run("value_identical_opt_in", "autocast_image=True (value-identical)", True, autocast_image=True)
+        # the strict-reference mode for non-finite values on pruned channels.  Since round 4 the default elides only where a
+        # pruned channel is a skippable row (NCHW, no gate recording), so in this channels_last training step "off" and the
+        # default run the same kernels: the figure is the evidence that nothing is paid for following the reference there
+        opt_in_run("elide_off", "elide_pruned='off' (every element loaded; the channels_last default already does)", False,
+                   elide_pruned="off")
     finally:
         qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward", autocast_image=False)
         torch.cuda.empty_cache()
     return out
+
+
+def exchange_live_config(arch, device, steps=None):
+    """the path a DistributedDataParallel rank really runs, measured on ONE GPU: the config-3 / config-4 network and recipe
+    inside a one-rank `nccl` (RCCL) process group with `sync_statistics="always"`, wrapped in DDP -- every operator site then
+    issues its statistics launches, the 2C-float all-gather and the combining select + apply (qs_site_stats / qs_site_fwd
+    with QS_SITE_STATS_DONE: two calls around one collective), the quantize-only sites an all-reduce of their abs-max lines;
+    hipGraph capture is off (an RCCL collective inside a capture crashes on this stack), so this is an eager figure.
+    Runs in a CHILD process of the N = 1 bench (a crash inside RCCL must not cost the headline record)."""
+    import qsparse_amd as qs
+    from examples.models import convert_pq, resnet18, resnet50
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    batch = 128 if arch == "resnet18" else 256
+    steps = steps or (10 if arch == "resnet18" else 5)
+    if arch == "resnet18":
+        make, shape, classes, sparsity = (lambda: resnet18(10, True)), (batch, 3, 32, 32), 10, 0.5
+    else:
+        make, shape, classes, sparsity = (lambda: resnet50(1000, False)), (batch, 3, 224, 224), 1000, 0.75
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(shape, generator=g, device=device).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, classes, (batch,), generator=g, device=device)
+
+    def build(pq):
+        torch.manual_seed(0)
+        model = make()
+        if pq:
+            model = convert_pq(model, sparsity=sparsity, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+        model = model.to(device).to(memory_format=torch.channels_last).train()
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[device.index])
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+
+        def step(_=0):
+            opt.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.cross_entropy(net(x).float(), y)
+            loss.backward()
+            opt.step()
+
+        return model, step
+
+    out = {"model": arch, "input_shape": list(shape), "steps": steps,
+           "group": "one-rank nccl (RCCL) process group, DistributedDataParallel, eager"}
+    model, step = build(False)
+    for _ in range(6):
+        step()
+    out["plain_ddp_ms"] = round(_timed_loop(step, steps), 3)
+    del model, step
+    torch.cuda.empty_cache()
+    qs.set_qsparse_options(sync_statistics="always")
+    model, step = build(True)
+    for _ in range(8):
+        step()
+    from qsparse_amd import distributed as qdist
+    assert qdist.exchange_active()
+    out["pq_ddp_exchange_live_ms"] = round(_timed_loop(step, steps), 3)
+    acc = library_kernel_accounting(step)
+    out["library_kernels"] = {k: acc[k] for k in ("ms_per_step", "launches", "algorithmic_GB_per_step", "frac_of_hbm_peak")}
+    out["library_kernels"]["families"] = {k: {"ms": v["ms"], "launches": v["launches"]} for k, v in acc["families"].items()}
+    qs.set_qsparse_options(sync_statistics=False)          # the same DDP network without the exchange (ranks would drift)
+    for _ in range(3):
+        step()
+    out["pq_ddp_no_exchange_ms"] = round(_timed_loop(step, steps), 3)
+    qs.set_qsparse_options(sync_statistics="always")
+    for _ in range(3):
+        step()
+    out["pq_ddp_exchange_live_ms_2"] = round(_timed_loop(step, steps), 3)
+    live = min(out["pq_ddp_exchange_live_ms"], out["pq_ddp_exchange_live_ms_2"])
+    out["exchange_live_over_no_exchange"] = round(live / out["pq_ddp_no_exchange_ms"], 4)
+    out["pq_over_plain"] = round(live / out["plain_ddp_ms"], 4)
+    sites = sum(1 for m in model.modules() if isinstance(m, qs.sparse.PruneLayer))
+    out["collectives_per_step"] = f"{sites} record all-gathers (2C floats each) + all-reduces of the quantize-only sites"
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    return out
+
+
+def exchange_live_in_child(arch, timeout=900):
+    """run `exchange_live_config` in a child process and return its record (or what went wrong)"""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exchange-live", arch], capture_output=True, text=True,
+                           timeout=timeout, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        rec = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"child exit code {r.returncode}: {r.stderr[-300:]}"}
+    except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
+        rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+    rec["bench_seconds"] = round(time.perf_counter() - t0, 1)
+    return rec
 
 
 def extra_configs(device, only=None):
@@ -400,6 +497,14 @@ def extra_configs(device, only=None):
             out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             torch.cuda.empty_cache()
         out[name]["bench_seconds"] = round(time.perf_counter() - t0, 1)
+        # the same network as a DDP rank runs it (statistics exchange live), in a child process
+        arch = {"config3": "resnet18", "config4": "resnet50"}.get(name.split("_")[0])
+        if arch and "error" not in out[name] and os.environ.get("QS_BENCH_NO_EXCHANGE_LIVE", "0") != "1":
+            torch.cuda.empty_cache()
+            out[name]["exchange_live"] = exchange_live_in_child(arch)
+            ex = out[name]["exchange_live"]
+            if "pq_ddp_exchange_live_ms" in ex:
+                ex["over_no_group_eager"] = round(min(ex["pq_ddp_exchange_live_ms"], ex["pq_ddp_exchange_live_ms_2"]) / out[name]["pq_ms"], 4)
     return out
 
 
@@ -488,9 +593,23 @@ def main():
                     help="headline mode (default: the library's default, 'forward')")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS",
                     help="only time the CPU oracle with this many threads (no GPU needed)")
+    ap.add_argument("--exchange-live", default=None, choices=["resnet18", "resnet50"],
+                    help="(child mode of the N = 1 bench) the config-3 / config-4 network in a one-rank RCCL group with the "
+                         "statistics exchange live, under DistributedDataParallel; prints its record")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(threads=args.cpu_baseline_only)))
+        return
+    if args.exchange_live:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)                  # RCCL / MIOpen banners go to stderr; the record is the only line on stdout
+        torch.cuda.set_device(0)
+        import qsparse_amd as qs
+        qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+        rec = exchange_live_config(args.exchange_live, torch.device("cuda", 0))
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        os.close(real_stdout)
         return
 
     # stdout must carry exactly ONE line, the JSON record of rank 0.  RCCL / MIOpen / the HIP runtime print banners

@@ -346,6 +346,10 @@ typedef struct qs_site_plan {
     int32_t callback_t_from_device; /* != 0: the running-magnitude counter is read from *callback_t instead of t_mag */
     int32_t saturate;            /* != 0: codes are clamped to [code_lo, code_hi] (qs_quant_scaler_fwd's opt-in saturation) */
     int32_t code_lo, code_hi;
+    float* record;               /* nullable: [2*C] float scratch.  With `ticket` it lets a live qs_site_fwd run qs_mean_last2 and
+                                    qs_pq_select as ONE launch: the workgroups publish importance | abs-max per channel here and
+                                    the last one to finish runs the select (same arithmetic, one launch boundary less) */
+    uint32_t* ticket;            /* nullable: one zero-initialised word, left zero by every call */
 } qs_site_plan;
 
 /* flags of qs_site_fwd */
@@ -354,12 +358,23 @@ typedef struct qs_site_plan {
 #define QS_SITE_PRE_RELU 4    /* x is the input of a folded nn.ReLU */
 #define QS_SITE_ELIDE 8       /* elide_masked of qs_quant_scaler_fwd */
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
+#define QS_SITE_STATS_DONE 32 /* with QS_SITE_LIVE: the statistics launches were already enqueued by qs_site_stats (a data-parallel
+                                 step: the caller exchanged the record in between); qs_site_fwd starts at the select */
 
 /* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
  * gate_out, image_out / imgdt: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
- * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116). */
+ * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116).  gathered / world: nullable / 1; the all-gathered
+ * records of qs_site_stats (see there and qs_pq_select). */
 int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, qs_stream_t stream);
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, qs_stream_t stream);
+
+/* The statistics half of a live qs_site_fwd on its own -- qs_mean_dim | qs_mean_dim_cl, then qs_mean_last2, which also writes
+ * this rank's exchange record (record: device float[2*C] = importance | per-channel abs-max, qs_stats_pack's layout) -- for a
+ * data-parallel step: the caller all-gathers the records of all ranks (RCCL / any transport) and passes them to
+ * qs_site_fwd(flags | QS_SITE_STATS_DONE, gathered, world), whose select combines them in rank order (qs_pq_select's
+ * `gathered`).  Two calls and one collective per site instead of five calls; the reference has no counterpart (its masks and
+ * scales drift per rank, sparse.py:58-122 / quantize.py:327-349 run on the rank's shard only).  flags: QS_SITE_PRE_RELU. */
+int qs_site_stats(const qs_site_plan* plan, const void* x, int flags, float* record, qs_stream_t stream);
 
 /* gx = gate * clamp(g) * mask in xdt (qs_quant_ste_relu_bwd with the bitmap when `gate` is given, qs_quant_ste_bwd
  * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there.  g2 / g2dt: the second gradient of
@@ -373,6 +388,11 @@ int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, vo
  *     t_dev, advance, bits, clear, n_updates, xdt)  ->  qs_quant_scaler_fwd(x, y, scale, pre_relu, gate_out)
  * and with `update` == 0 the last of them alone (evaluation).  amax_lines: [lines][QS_AMAX_LINE_STRIDE] floats, zero on entry,
  * re-zeroed by the update; n_updates (nullable) is incremented; t_dev (nullable) is read instead of t and incremented. */
+#define QS_QSTEP_APPLY 0      /* `update` of qs_quantize_step: quantize only (evaluation) */
+#define QS_QSTEP_ALL 1        /* abs-max, running scale, quantize */
+#define QS_QSTEP_ABSMAX 2     /* the abs-max launch alone (y may be NULL): a data-parallel step all-reduces (MAX) the accumulator
+                                 lines between this call and the next */
+#define QS_QSTEP_FINISH 3     /* running scale from the (reduced) accumulator lines, then quantize */
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
                      int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);

@@ -62,7 +62,8 @@ SIGNATURES = {
     "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P]),
-    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P]),
+    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P]),
+    "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
@@ -78,23 +79,31 @@ class SitePlanStruct(ctypes.Structure):
                 ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
-                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32)]
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32),
+                ("record", c_void_p), ("ticket", c_void_p)]
 
 
-SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK = 1, 2, 4, 8, 16
+SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE = 1, 2, 4, 8, 16, 32
+QSTEP_APPLY, QSTEP_ALL, QSTEP_ABSMAX, QSTEP_FINISH = 0, 1, 2, 3
 
 _lib = None
 
 # Mask-aware traffic elision (set through set_qsparse_options(elide_pruned=...), see qs_elementwise.h):
-#   "forward" (default)  quantizer forward kernels that carry a channel mask skip the loads of pruned channels --
-#                        bit-identical for finite inputs
-#   "all"                the backward and mask-apply kernels as well: +0.0 where the reference has -0.0 (opt-in)
+#   "forward" (default)  quantizer forward kernels that carry a channel mask skip the loads of pruned channels WHERE THAT
+#                        SAVES TRAFFIC -- an NCHW activation (a pruned channel is a whole row) in a forward that records no
+#                        ReLU gate -- bit-identical for finite inputs.  A channels_last forward (a pruned channel is a
+#                        2-byte column: nothing to skip) and a gate-recording forward (it loads every element anyway) run
+#                        the loading arithmetic, i.e. the reference's own on non-finite inputs as well
+#   "all"                every kernel that carries a channel mask, the backward and mask-apply kernels included: +0.0 where
+#                        the reference has -0.0, f32(0)*s where it has f32(INT_MIN)*s for a NaN / Inf on a pruned channel (opt-in)
 #   "off"                every element is loaded (NaN / Inf on pruned channels behave as in the reference, quirk B15)
 elide_mode = "forward"
 
 
-def _elide_fwd() -> int:
-    return int(elide_mode != "off")
+def _elide_fwd(channels_last: bool = False, records_gate: bool = False) -> int:
+    if elide_mode == "forward":
+        return int(not (channels_last or records_gate))
+    return int(elide_mode == "all")
 
 
 def _elide_all() -> int:
@@ -361,7 +370,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd() if cm is not None else 0,
+                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd(x is not like, gate is not None) if cm is not None else 0,
                 _ptr(gate.bits) if gate is not None else None, None, 0, _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     return (y, codes, gate) if want_gate else (y, codes)
@@ -794,27 +803,36 @@ def logging_events() -> bool:
 
 def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], amax_lines: Optional[torch.Tensor],
                   scale: torch.Tensor, bits: int, t: int, t_dev: Optional[torch.Tensor], n_updates: Optional[torch.Tensor],
-                  pre_relu: bool, update: bool, saturate=None):
+                  pre_relu: bool, update, saturate=None):
     """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout; saturate: None or the
-    (code_lo, code_hi) pair of the opt-in saturation"""
+    (code_lo, code_hi) pair of the opt-in saturation; update: False / True or one of QSTEP_* (ABSMAX: the abs-max launch alone,
+    y may be None; FINISH: running scale from the -- meanwhile all-reduced -- accumulator lines, then quantize)"""
     sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
-    st = load().qs_quantize_step(x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
+    st = load().qs_quantize_step(x.data_ptr(), None if y is None else y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
                                  None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
-                                 x.numel(), _DT[x.dtype], _DT[y.dtype], int(bits), int(t),
+                                 x.numel(), _DT[x.dtype], _DT[(y if y is not None else x).dtype], int(bits), int(t),
                                  None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
-                                 int(bool(pre_relu)), int(bool(update)), sat, lo, hi, _stream(x))
+                                 int(bool(pre_relu)), int(update), sat, lo, hi, _stream(x))
     if st:
         _check(st, "qs_quantize_step")
 
 
 def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,
-             t_q: int, image: Optional[torch.Tensor] = None):
-    """image: optional bf16 / fp16 tensor of y's shape and layout that receives RNE(y) from the same pass (see qs_quant_image_ok)"""
+             t_q: int, image: Optional[torch.Tensor] = None, gathered: Optional[torch.Tensor] = None, world: int = 1):
+    """image: optional bf16 / fp16 tensor of y's shape and layout that receives RNE(y) from the same pass (see qs_quant_image_ok);
+    gathered (with SITE_STATS_DONE in flags): the all-gathered [world, 2C] records of `site_stats`"""
     st = load().qs_site_fwd(plan_ref, x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), flags,
                             t_mag, k, t_q, None if image is None else image.data_ptr(), 0 if image is None else _DT[image.dtype],
-                            _stream(x))
+                            None if gathered is None else gathered.data_ptr(), world, _stream(x))
     if st:
         _check(st, "qs_site_fwd")
+
+
+def site_stats(plan_ref, x: torch.Tensor, flags: int, record: torch.Tensor):
+    """the statistics launches of a live site step; `record` (float32 [2C]) receives the rank's exchange record"""
+    st = load().qs_site_stats(plan_ref, x.data_ptr(), flags, record.data_ptr(), _stream(x))
+    if st:
+        _check(st, "qs_site_stats")
 
 
 def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,

@@ -74,6 +74,7 @@ static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude,
         return QS_ERR_ARG;
     a->gathered = gathered;
     a->world = gathered ? world : 1;
+    a->coherent = 0;
     a->magnitude = magnitude;
     a->C = C;
     a->update_magnitude = update_magnitude;
@@ -147,35 +148,93 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
 }
 
 // ---- one activation site per call: the fine-grained entry points in sequence (no arithmetic of its own) --------------
+static int site_plan_ok(const qs_site_plan* p) {
+    return p && p->N >= 1 && p->C >= 2 && p->H >= 1 && p->W >= 1 && (p->layout == 0 || p->layout == 1);
+}
+
+// first statistics stage of a live site step: mean over the batch per (c, h, w) + per-channel / per-element abs-max
+static int site_stage1(const qs_site_plan* p, const void* x, int pre_relu, qs_stream_t stream) {
+    if (!p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
+    const int64_t hw = p->H * p->W;
+    const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_RELU : 0);
+    if (p->layout == 0)
+        return qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride, hw,
+                           p->C, stream);
+    if (!p->amax_part) return QS_ERR_ARG;
+    return qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, p->amax_part, stream);
+}
+
+// the statistics launches of a live site step; `record` (nullable): the rank's exchange record, written by the last of them
+static int site_statistics(const qs_site_plan* p, const void* x, int pre_relu, float* record, qs_stream_t stream) {
+    int st = site_stage1(p, x, pre_relu, stream);
+    if (st) return st;
+    if (p->layout == 0)   // (the accumulator is complete when this launch starts: with `record` it is read for the record's second half)
+        return qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, nullptr, record ? p->chan_absmax : nullptr,
+                             record ? p->absmax_stride : 1, record, stream);
+    return qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, p->amax_part, p->chan_absmax, p->absmax_stride,
+                         record, stream);
+}
+
+// qs_mean_last2 + qs_pq_select of a live site step as one launch (mean_last2_select_kernel); QS_SITE_FUSE_SELECT=0: off
+static bool site_fused_select_ok(const qs_site_plan* p) {
+    static const int on = env_int("QS_SITE_FUSE_SELECT", 1);
+    const size_t tile = (size_t)(p->H * p->W + p->W + 8) * sizeof(float);
+    return on && p->record && p->ticket && tile <= kLast2MaxLds && p->C <= 65536;
+}
+static int site_last2_select(const qs_site_plan* p, int flags, int64_t t_mag, int64_t k, int64_t t_q, qs_stream_t stream) {
+    PqArgs a;
+    int st = pq_args(&a, p->magnitude, p->C, 1, t_mag, (flags & QS_SITE_REFRESH) ? 1 : 0, k, p->mask, p->chan_absmax,
+                     p->absmax_stride, 1, t_q, p->bits, p->scale, p->prune_n_updates, p->quant_n_updates, p->callback_t,
+                     p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr, p->quantizer_t_dev, nullptr, 1);
+    if (st) return st;
+    if (!dt_ok(p->xdt)) return QS_ERR_DTYPE;
+    a.stat_dt = p->xdt;
+    a.coherent = 0;
+    static const int max_blocks_fused = env_int("QS_SITE_FUSE_BLOCKS", 256);   // one ticket each: same-address atomics serialise
+    const int blocks = (int)std::min<int64_t>(p->C, max_blocks_fused);
+    const size_t tile = (size_t)(p->H * p->W + p->W + 8) * sizeof(float);
+    const size_t lds = std::max(tile, sizeof(SelectShared) + 16 * sizeof(uint32_t) + 64);
+    return with_dtype(p->xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        hipLaunchKernelGGL((mean_last2_select_kernel<XD>), dim3(blocks), dim3(kBlock), lds, (hipStream_t)stream, p->stage,
+                           p->stage_mean, (int)p->C, (int)p->H, (int)p->W, p->layout == 1 ? (const uint32_t*)p->amax_part : nullptr,
+                           (const uint32_t*)p->chan_absmax, p->absmax_stride, p->record, p->ticket, a);
+        return launch_status();
+    });
+}
+
+int qs_site_stats(const qs_site_plan* p, const void* x, int flags, float* record, qs_stream_t stream) {
+    if (!site_plan_ok(p) || !x || !record) return QS_ERR_ARG;
+    return site_statistics(p, x, (flags & QS_SITE_PRE_RELU) ? 1 : 0, record, stream);
+}
+
 int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, qs_stream_t stream) {
-    if (!p || !x || !y || p->N < 1 || p->C < 2 || p->H < 1 || p->W < 1 || (p->layout != 0 && p->layout != 1)) return QS_ERR_ARG;
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, qs_stream_t stream) {
+    if (!site_plan_ok(p) || !x || !y) return QS_ERR_ARG;
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
     const int pre_relu = (flags & QS_SITE_PRE_RELU) ? 1 : 0;
     if (flags & QS_SITE_LIVE) {
-        if (!p->magnitude || !p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
+        if (!p->magnitude || !p->chan_absmax || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
         if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
-        const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_RELU : 0);
+        if ((flags & QS_SITE_STATS_DONE) ? (!gathered || world < 1) : (gathered != nullptr)) return QS_ERR_ARG;
         int st;
-        if (p->layout == 0) {
-            st = qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride,
-                             hw, p->C, stream);
+        if (!(flags & QS_SITE_STATS_DONE) && site_fused_select_ok(p)) {
+            st = site_stage1(p, x, pre_relu, stream);
             if (st) return st;
-            st = qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, nullptr, nullptr, 1, nullptr, stream);
+            st = site_last2_select(p, flags, t_mag, k, t_q, stream);
+            if (st) return st;
         } else {
-            if (!p->amax_part) return QS_ERR_ARG;
-            st = qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, p->amax_part, stream);
+        if (!(flags & QS_SITE_STATS_DONE)) {
+            st = site_statistics(p, x, pre_relu, nullptr, stream);
             if (st) return st;
-            st = qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, p->amax_part, p->chan_absmax,
-                               p->absmax_stride, nullptr, stream);
         }
-        if (st) return st;
         st = qs_pq_select(p->magnitude, p->stage_mean, p->xdt, p->C, 1, t_mag, (flags & QS_SITE_REFRESH) ? 1 : 0, k, p->mask,
                           p->chan_absmax, p->absmax_stride, 1, t_q, p->bits, p->scale, p->prune_n_updates, p->quant_n_updates,
                           p->callback_t, p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr,
-                          p->quantizer_t_dev, p->xdt, nullptr, 1, stream);
+                          p->quantizer_t_dev, p->xdt, gathered, gathered ? world : 1, stream);
         if (st) return st;
+        }
     }
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
@@ -201,13 +260,15 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
                      int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
-    if (!x || !y || !scale || numel < 0) return QS_ERR_ARG;
+    if (!x || (!y && update != QS_QSTEP_ABSMAX) || !scale || numel < 0 || update < 0 || update > QS_QSTEP_FINISH) return QS_ERR_ARG;
     if (numel == 0) return QS_OK;
-    if (update) {
+    if (update != QS_QSTEP_APPLY) {
         if (!amax_lines) return QS_ERR_ARG;
-        int st = qs_absmax(x, amax_lines, 0, 1, 1, numel, xdt, 1, pre_relu, lines, nullptr, 0, stream);
-        if (st) return st;
-        st = qs_scale_update(amax_lines, lines, scale, 1, t, t_dev, 1, bits, 1, n_updates, xdt, stream);
+        if (update != QS_QSTEP_FINISH) {
+            int st = qs_absmax(x, amax_lines, 0, 1, 1, numel, xdt, 1, pre_relu, lines, nullptr, 0, stream);
+            if (st || update == QS_QSTEP_ABSMAX) return st;
+        }
+        int st = qs_scale_update(amax_lines, lines, scale, 1, t, t_dev, 1, bits, 1, n_updates, xdt, stream);
         if (st) return st;
     }
     return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, saturate, code_lo, code_hi,

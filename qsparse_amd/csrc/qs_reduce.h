@@ -1476,19 +1476,31 @@ struct PqArgs {
     // in rank order, instead of reading `stage` / `chan_absmax` (which is then only re-zeroed)
     const float* gathered;
     int world;
+    int coherent;               // `gathered` was written by OTHER workgroups of this very launch (mean_last2_select_kernel): read it
+                                // with agent-scope (sc1) loads
 };
+
+// a float another workgroup of the same launch published with an agent-scope store (see mean_last2_select_kernel)
+__device__ __forceinline__ float load_published(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void publish(float* p, float v) {
+    __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // channel i's importance / abs-max key: the local statistics, or the rank-ordered combination of every rank's record
 // (same arithmetic as stats_combine_kernel: fp32 sum in rank order divided by the world size; maximum of the keys)
 template <int SDT>
 __device__ __forceinline__ float pq_stage_value(const PqArgs& a, const void* stage, int64_t i) {
     if (!a.gathered) return load1<SDT>(stage, i);
+    if (a.coherent) return load_published(a.gathered + i);   // this rank's own record: the value mean_last2 stored in `stage`
     float sum = 0.f;
     for (int r = 0; r < a.world; ++r) sum += a.gathered[(int64_t)r * 2 * a.C + i];
     return sum / (float)a.world;
 }
 __device__ __forceinline__ uint32_t pq_amax_key(const PqArgs& a, int64_t i) {
     if (!a.gathered) return a.chan_absmax[i * a.amax_stride];
+    if (a.coherent) return __float_as_uint(load_published(a.gathered + a.C + i));
     uint32_t mx = 0u;
     for (int r = 0; r < a.world; ++r) {
         const uint32_t k = __float_as_uint(a.gathered[(int64_t)r * 2 * a.C + a.C + i]);
@@ -1631,6 +1643,110 @@ __global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const voi
 // (rounded to ODT) -> out [pre].  One workgroup per `pre` slice, tile held in LDS as fp32; both stages
 // add in ATen's order (outer rule over H, inner rule over W; see the block comment above).
 // =================================================================================================
+// maximum of slice p of the per-element maxima mean_cl_kernel left (valid in thread 0; all threads of the workgroup call it)
+__device__ __forceinline__ uint32_t last2_slice_max(const uint32_t* __restrict__ amax_part, int64_t p, int hw) {
+    __shared__ uint32_t wmax[kBlock / 64];
+    uint32_t m = 0u;
+    if ((hw & 3) == 0 && (((uintptr_t)amax_part) & 15) == 0) {
+        const uint4* part4 = reinterpret_cast<const uint4*>(amax_part + p * hw);
+        const int n4 = hw >> 2;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * kBlock) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = (i0 + u * kBlock < n4) ? part4[i0 + u * kBlock] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t a = q[u].x > q[u].y ? q[u].x : q[u].y, b = q[u].z > q[u].w ? q[u].z : q[u].w;
+                const uint32_t k = a > b ? a : b;
+                m = k > m ? k : m;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += kBlock) {
+            const uint32_t k = amax_part[p * hw + i];
+            m = k > m ? k : m;
+        }
+    }
+    m = wave_max_u32(m);
+    __syncthreads();                                   // (wmax may still be read by thread 0 of the previous slice)
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < kBlock / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+    return m;
+}
+
+// mean over H (rounded to DT) then over W of slice p of x [pre, H, W]: the unrounded mean, valid in thread 0
+template <int DT>
+__device__ __forceinline__ float last2_slice_mean(const void* __restrict__ x, int64_t p, int H, int W, float* tile) {
+    float* colmean = tile + (size_t)H * W;
+    const int hw = H * W;
+    load_tile_f32<DT>(x, p, hw, tile);
+    __syncthreads();
+    const int mr_cols = (W >= 8) ? (W / 32) * 32 : (W / 4) * 4;
+    for (int col = threadIdx.x; col < W; col += kBlock) {
+        auto get = [&](int64_t i) { return tile[i * W + col]; };
+        const float s = (col < mr_cols) ? sum_multi_row(H, get) : sum_row_sum(H, get);
+        colmean[col] = round_through<DT>(s / (float)H);
+    }
+    __syncthreads();
+    const float s = inner_sum_lds(colmean, W, colmean + W);
+    return s / (float)W;
+}
+
+// =================================================================================================
+// qs_mean_last2 and qs_pq_select in ONE launch (the composite site call, no exchange between ranks): the workgroups reduce
+// their channels' tiles as mean_last2_kernel does and PUBLISH the two numbers the select needs per channel -- importance and
+// abs-max -- into the 2C-float record with agent-scope (write-through) stores; each then draws a ticket, and the workgroup
+// that draws the last one runs the select on the record.  Nobody waits for anybody: no grid barrier, no residency
+// requirement.  Hand-off as the CDNA4 guide prescribes: sc1 payload stores, s_waitcnt vmcnt(0) in the storing lane, an
+// agent-scope ticket; the last arriver issues ONE agent acquire (one lane, then __syncthreads) and reads the record with
+// agent-scope loads.  The abs-max accumulator is NOT written here (a plain store from a producer's XCD could land after the
+// select's re-zeroing store from another XCD): in the channels_last route the slice maximum goes into the record only.
+// ticket: one zero-initialised word per site, left zero by the last arriver.
+// =================================================================================================
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mean_last2_select_kernel(const void* __restrict__ x, void* __restrict__ out, int C,
+                                                                    int H, int W, const uint32_t* __restrict__ amax_part,
+                                                                    const uint32_t* chan_absmax, int64_t astride,
+                                                                    float* record, uint32_t* ticket, PqArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // max(H*W + W + 8 floats, SelectShared + 16 words)
+    const int hw = H * W;
+    for (int p = blockIdx.x; p < C; p += gridDim.x) {
+        uint32_t m = 0u;
+        if (amax_part) m = last2_slice_max(amax_part, p, hw);
+        const float mean = last2_slice_mean<DT>(x, p, H, W, tile);
+        if (threadIdx.x == 0) {
+            const uint32_t old = chan_absmax[(int64_t)p * astride];       // NCHW route: complete since the previous launch
+            m = m > old ? m : old;
+            store1<DT>(out, p, mean);
+            publish(record + p, round_through<DT>(mean));
+            publish(record + C + p, __uint_as_float(m));
+        }
+        __syncthreads();                                                   // the tile is reused by the next slice
+    }
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the storing lane drains its write-through stores
+        const uint32_t prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    PqArgs a = pq_live_counters(a0);
+    a.gathered = record;
+    a.world = 1;
+    a.coherent = 1;
+    SelectShared& sh = *reinterpret_cast<SelectShared*>(tile);
+    uint32_t* sh_max = reinterpret_cast<uint32_t*>(tile) + (sizeof(SelectShared) + 3) / 4;
+    if (a.C <= kRankMax) pq_select_small<QS_F32, kRankMax / kBlock>(a, nullptr, sh, sh_max);
+    else pq_select_body<QS_F32>(a, nullptr, sh, sh_max);
+}
+
 template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                              int H, int W, const uint32_t* __restrict__ amax_part,

@@ -57,6 +57,13 @@ def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
     return t
 
 
+def all_gather_records(gathered: torch.Tensor, record: torch.Tensor):
+    """the one collective of a data-parallel site step: every rank's 2C-float record into `gathered` ([world * 2C], rank
+    order).  RCCL over xGMI is point-to-point and a 2 KB all-gather is latency-bound at any world size: ONE collective per
+    site is what matters (the records hold importance and abs-max together)."""
+    dist.all_gather_into_tensor(gathered, record)
+
+
 def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int,
                            record: Optional[dict] = None) -> torch.Tensor:
     """GPU half of `sync_pair_statistics` without its last step: pack the rank's record (unless the last statistics

@@ -47,6 +47,33 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
     return True
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Zero-on-entry accumulators.  The per-channel abs-max rides in the statistics launch as an atomic max into a persistent
+# buffer that the select launch re-zeroes; nothing initialises it per step.  If a step dies BETWEEN the two -- a failed
+# collective, KeyboardInterrupt, an exception in a hook -- the buffer stays dirty and the next step would silently
+# max-accumulate a stale value into the scale.  Every route that opens such a window arms a flag on the owning layer before
+# the first launch and clears it after the last; a step that finds the flag set re-zeroes the buffers first.
+# ----------------------------------------------------------------------------------------------------------------------
+_ARMED = "_qs_accumulators_armed"
+
+
+def _arm_accumulators(q: QuantizeLayer):
+    d = q.__dict__
+    if d.get(_ARMED):
+        for key in ("_chan_absmax", "_chan_absmax_dense"):
+            buf = d.get(key)
+            if buf is not None:
+                buf.zero_()
+        plan = d.get("_qs_site_plan")
+        if plan is not None and plan.key is not None:
+            plan.keep[6].zero_()           # the arrival ticket of the fused last-two-stages + select launch
+    d[_ARMED] = True
+
+
+def _disarm_accumulators(q: QuantizeLayer):
+    q.__dict__[_ARMED] = False
+
+
 def _absmax_accumulator_dense(q: QuantizeLayer, C: int, device) -> torch.Tensor:
     """persistent dense [C] accumulator for the abs-max passes that run on their own (no statistics stage to ride on):
     zero on entry because the select re-zeroes it, so the reduction needs no initialisation launch."""
@@ -124,10 +151,12 @@ class _FusedApply(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------------
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
-    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused")
+    __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused",
+                 "xbuf")
 
     def __init__(self):
         self.key = None
+        self.xbuf = None
         self.image_ok, self.image_made, self.image_used, self.image_fused = True, False, False, False
 
     def __deepcopy__(self, memo):        # a cache of raw pointers never travels: copies and pickles rebuild their own
@@ -173,7 +202,10 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     stage = torch.empty(C * H * W, dtype=h.dtype, device=h.device)
     part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
-    plan.keep = (acc, stage, part, stage_mean, t_q_dev) + state
+    # scratch of the fused last-two-stages + select launch: the per-channel record its workgroups publish, the arrival ticket
+    record = torch.empty(2 * C, dtype=torch.float32, device=h.device)
+    ticket = torch.zeros(1, dtype=torch.int32, device=h.device)
+    plan.keep = (acc, stage, part, stage_mean, t_q_dev, record, ticket) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
     c.layout, c.xdt, c.ydt, c.bits = int(cl), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
@@ -184,6 +216,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
     c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
+    c.record, c.ticket = record.data_ptr(), ticket.data_ptr()
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
@@ -255,11 +288,21 @@ def _image_dtype(plan, training_needs_gate: bool):
     return dt
 
 
+def _exchange_buffers(plan: _SitePlan, C: int, world: int, device):
+    """(this rank's record [2C], the gathered records [world * 2C]) of a data-parallel site step: persistent -- the collective
+    is ordered on the stream like the kernels around it, so one pair per site serves every step"""
+    buf = plan.xbuf
+    if buf is None or buf[1].numel() != world * 2 * C:
+        buf = plan.xbuf = (torch.empty(2 * C, dtype=torch.float32, device=device),
+                           torch.empty(world * 2 * C, dtype=torch.float32, device=device))
+    return buf
+
+
 class _SiteStep(torch.autograd.Function):
     """the whole site through qs_site_fwd / qs_site_bwd; same results as the statistics + select + `_FusedApply` route"""
 
     @staticmethod
-    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None):
+    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None, gathered=None, world=1):
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
         make_image = image_dtype is not None and (want_gate or not ctx.needs_input_grad[0])
@@ -270,7 +313,9 @@ class _SiteStep(torch.autograd.Function):
         if want_gate:
             _hip.note_gate(bits_t)
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
-        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img)
+        if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None):
+            flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic (see _hip.elide_mode)
+        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world)
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
@@ -284,7 +329,7 @@ class _SiteStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g16=None):
         plan, flags = ctx.plan, ctx.flags
-        n_in = 11
+        n_in = 13
         if g is None and g16 is None:
             return (None,) * n_in
         mask_c, scale, third = ctx.saved_tensors
@@ -378,16 +423,25 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     live = update_mag and update_scale and prune_on and p_counts and q_counts and n >= p.start
     idle = not (update_mag or refresh or update_scale) and quant_on
     world = qdist.stats_world_size()
-    if (live or idle) and not qdist.exchange_active(world) and not _hip.logging_events():
+    exchange = qdist.exchange_active(world)      # (only a live step has statistics to exchange)
+    if (live or idle) and not _hip.logging_events():
         site = _site_plan(p, q, h)
     if site is not None and live:        # the counters ride in the select launch, as on the fine-grained route (the flags
         bump_p = bump_q = bump_t = True   # below only ask WHETHER they did)
         select_bumped_tq = bool(get_option("graph_safe"))
+    site_gathered = None
     with torch.no_grad():
         hd = h.detach() if site is None else None
         stage = chan_absmax = record = None
         if site is not None:
-            pass
+            if live:
+                _arm_accumulators(q)
+                if exchange:
+                    # data-parallel step, two calls around ONE collective: the statistics launches (the last of them writes
+                    # this rank's record), the all-gather, and -- in `_SiteStep` below -- select + apply on the gathered records
+                    rec, site_gathered = _exchange_buffers(site, C, world, h.device)
+                    _hip.site_stats(site.ref, h, _hip.SITE_PRE_RELU if pre_relu else 0, rec)
+                    qdist.all_gather_records(site_gathered, rec)
         elif update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)
@@ -403,6 +457,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 bump_p = on_dev(p._n_updates) if p_counts else None
                 bump_q = on_dev(q._n_updates) if q_counts else None
                 bump_t = on_dev(cb.t) if (p_counts and n >= p.start) else None
+            if update_mag or update_scale:
+                _arm_accumulators(q)
             if update_mag:
                 dims = _reduction_plan(hd.shape, p.mask.shape)
                 # the per-channel abs-max rides along in the first statistics stage when that stage reduces a dim
@@ -438,6 +494,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                                update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t,
                                bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev, stat_dtype=h.dtype,
                                gathered=gathered, world=world if gathered is not None else 1)
+                _disarm_accumulators(q)
                 select_bumped_tq = t_q_dev is not None
         if update_scale:
             if select_bumped_tq:
@@ -477,8 +534,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             site.image_ok = False        # nobody took the last image (the consumer is not an autocast matmul / convolution): stop making them
         site.image_made = site.image_used = False
         image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
+        if site_gathered is not None:
+            flags |= _hip.SITE_STATS_DONE
         out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
-                              p.mask if prune_on else None, q.weight, image_dtype)
+                              p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world)
+        if live:
+            _disarm_accumulators(q)
         if type(out) is tuple:
             y, img = out
             site.image_made = True

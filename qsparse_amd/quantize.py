@@ -628,14 +628,25 @@ class QuantizeLayer(nn.Module):
                 or self.weight.device != x.device or self._n_updates.device != x.device or _callback_hooked(cb)):
             return None
         update = self.training
-        if update and self.batch_dimension == 0 and qdist.exchange_active():
-            return None                     # an activation's abs-max is exchanged between ranks: the fine-grained route
         if not update and not self._quantized:
             return None
         t_dev = cb.device_t(x.device) if (update and get_option("graph_safe")) else None
+        mode = _hip.QSTEP_ALL if update else _hip.QSTEP_APPLY
+        if update and self.batch_dimension == 0 and qdist.exchange_active():
+            # an activation's abs-max is exchanged between ranks (weights are identical on every rank): the abs-max launch,
+            # ONE all-reduce (MAX) of the accumulator lines, then running scale + quantization -- two calls around the collective.
+            # (The lines hold non-negative floats: reduced as int32 their order is the floats' and a NaN stays the maximum.)
+            acc = cb.tensor_accumulator(x.device)
+            if self.__dict__.get("_qs_accumulator_armed"):
+                acc.zero_()              # an earlier step died between the two calls (failed collective): stale maxima
+            self.__dict__["_qs_accumulator_armed"] = True
+            _hip.quantize_step(x, None, None, acc, self.weight.data, self.bits, cb.t, None, None, pre_relu, _hip.QSTEP_ABSMAX)
+            qdist.allreduce_max_(acc.view(torch.int32))
+            mode = _hip.QSTEP_FINISH
         y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
-                             self._n_updates.data if update else None, pre_relu, update, 1 if cb.flip_axis else 0, _out_dtype(x),
+                             self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
                              cb.code_range(self.bits))
+        self.__dict__["_qs_accumulator_armed"] = False
         if update:
             if t == self.timeout and get_option("log_during_train"):
                 logging.warn(f"quantizing {self.name} with {self.bits} bits")

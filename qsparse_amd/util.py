@@ -35,8 +35,11 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     gradient and that bitmap instead of the gradient and the ReLU's input (which is then not kept for the backward);
     ``elide_pruned`` (extension): mask-aware traffic elision in the GPU kernels that carry a channel mask.  A pruned
     channel's input only ever meets ``* 0``, so it need not be loaded: ``"forward"`` (default) elides in the fused
-    prune->quantize forward, bit-identical for every finite input; ``"all"`` also in the backward and mask-apply
-    kernels, which then write ``+0.0`` where the reference's ``g * 0`` / ``x * 0`` has ``-0.0`` (numerically equal);
+    prune->quantize forward where that saves traffic -- NCHW activations, forwards that record no ReLU gate -- bit-identical
+    for every finite input (a NaN / Inf on a PRUNED channel of such a tensor gives ``f32(0)*s`` instead of the reference's
+    ``f32(INT_MIN)*s``; channels_last and gate-recording forwards load everything and follow the reference there too);
+    ``"all"`` in every masked kernel, the backward and mask-apply ones included, which then write ``+0.0`` where the
+    reference's ``g * 0`` / ``x * 0`` has ``-0.0`` (numerically equal);
     ``"off"`` loads everything (a NaN / Inf on a pruned channel then behaves exactly as in the reference);
     ``batch_weights`` (default True, bit-identical): the weight quantizers of a network built by ``convert`` are evaluated
     with three multi-tensor launches at the start of the root's forward instead of three per layer (see batch.py; a

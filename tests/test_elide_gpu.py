@@ -160,6 +160,53 @@ def test_off_mode_reproduces_nan_on_pruned_channels_like_the_reference():
     assert bool(y_nan[:, 1].isnan().all())
 
 
+def test_default_mode_elides_only_where_it_saves_traffic():
+    """the default (`"forward"`) changed NaN / Inf on PRUNED channels everywhere.  Since round 4 it elides
+    only where a pruned channel is a row that can be skipped -- an NCHW forward without gate recording.  A channels_last
+    forward (a pruned channel is a 2-byte column, nothing is saved) and a gate-recording forward (every element is loaded
+    anyway) follow the reference on non-finite inputs too: f32(INT_MIN) * s (quirk B15), through the functional entry point
+    and through a whole convert-built ReLU -> prune -> quantize site in training and evaluation."""
+    assert qs.get_qsparse_option("elide_pruned") == "forward"
+    x = torch.randn(4, 16, 8, 8, generator=gen(6)).bfloat16()
+    x[0, 1, 0, 0], x[1, 1, 3, 3], x[2, 5, 1, 1] = float("nan"), float("inf"), float("-inf")
+    mask = torch.ones(16, dtype=torch.bool)
+    mask[1] = mask[5] = False
+    s = torch.tensor([[0.25]])
+    ref = O.scaler_fwd(x * mask.view(1, -1, 1, 1), 4, s, -1)
+    assert ref[0, 1, 0, 0].item() == float(-2 ** 31) * 0.25
+    xcl = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _hip.quant_fwd("scaler", xcl, s.to(DEV), -1, torch.float32, chan_mask=mask.to(DEV), mask_channel_index=1)[0]
+    assert same(y.cpu().contiguous(), ref)                                       # channels_last: the reference's bits
+    ref_relu = O.scaler_fwd(x.relu() * mask.view(1, -1, 1, 1), 4, s, -1)
+    for xin in (x.to(DEV), xcl):                                                 # gate recording, either layout
+        y, _, gate = _hip.quant_fwd("scaler", xin, s.to(DEV), -1, torch.float32, chan_mask=mask.to(DEV), mask_channel_index=1,
+                                    pre_relu=True, want_gate=True)
+        assert same(y.cpu().contiguous(), ref_relu)
+    # the one place the default still deviates: NCHW, no gate (a row that is really skipped)
+    y = _hip.quant_fwd("scaler", x.to(DEV), s.to(DEV), -1, torch.float32, chan_mask=mask.to(DEV), mask_channel_index=1)[0].cpu()
+    assert y[0, 1, 0, 0].item() == 0.0 and same(y[torch.isfinite(x.float())], ref[torch.isfinite(x.float())])
+
+    # whole site (the composite route) in evaluation: a trained ReLU -> prune -> quantize pair meets non-finite values on its
+    # pruned channels; fused == module by module (x * mask, then the quantizer on the product) in channels_last
+    def site():
+        return nn.Sequential(nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                             qs.quantize(bits=4, channelwise=-1, timeout=1))
+
+    fused, plain = fuse_prune_quantize_pairs(site().to(DEV)).train(), site().to(DEV).train()
+    for step in range(5):
+        xs = (torch.randn(4, 16, 8, 8, generator=gen(300 + step)) * torch.linspace(0.25, 4, 16).view(1, -1, 1, 1)).bfloat16()
+        assert same(fused(xs.to(DEV)).cpu(), plain(xs.to(DEV)).cpu())
+    fused.eval(), plain.eval()
+    pruned = (~fused[0][1].mask.view(-1)).nonzero().view(-1).tolist()
+    assert len(pruned) == 8
+    for j, c in enumerate(pruned[:3]):
+        xs[j, c, j, j] = (float("nan"), float("inf"), float("-inf"))[j]
+    xe = xs.to(DEV).contiguous(memory_format=torch.channels_last)
+    ye = fused(xe).cpu().contiguous()
+    assert same(ye, plain(xe).cpu().contiguous())
+    assert ye[0, pruned[0], 0, 0].item() == float(-2 ** 31) * float(fused[1].weight)
+
+
 @pytest.mark.parametrize("mode", ["forward", "all"])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_fused_pair_trajectory_with_elision_vs_oracle(mode, channels_last):

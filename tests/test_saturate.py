@@ -115,7 +115,7 @@ def _run(net, data, dev, fmt=torch.contiguous_format):
     net = net.to(dev).train()
     outs = []
     for x, g in data:
-        xd = x.to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+        xd = x.detach().clone().to(dev).contiguous(memory_format=fmt).requires_grad_(True)
         y = net(xd)
         y.backward(g.to(dev))
         outs.append((y.detach().cpu(), xd.grad.detach().cpu()))

@@ -32,10 +32,20 @@ def main():
     meta = json.loads(sys.argv[2])
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     qs_rows = [r for r in rows if "qs::" in r["Kernel_Name"]]
-    want = meta["steps"] * meta["launches_per_step"]
+    steps = meta["steps"]
+    # launches per step as the TRACE has them: the event log behind `launches_per_step` keeps to the fine-grained entry
+    # points, a real step may fuse launches (qs_site_fwd's last-two-stages + select kernel).  The K steady-state steps are
+    # identical, so the per-step count is the smallest period of the kernel-name sequence at the end of the trace.
+    names = [r["Kernel_Name"].split("(")[0] for r in qs_rows]
+    per_step = meta["launches_per_step"]
+    for cand in range(8, len(names) // max(steps, 2) + 1):
+        if all(names[-cand:] == names[-(k + 1) * cand:-k * cand] for k in range(1, steps)):
+            per_step = cand
+            break
+    meta = dict(meta, launches_per_step=per_step)
+    want = steps * per_step
     tail = qs_rows[-want:]
     assert len(tail) == want, (len(qs_rows), want)
-    steps = meta["steps"]
     fam, ker = {}, {}
     for r in tail:
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
