@@ -243,7 +243,7 @@ def library_kernel_accounting(step, reps=3):
                                  "frac_net": frac(f["bytes"], f["net"])}
     rec["note"] = ("HIP event pairs around every library launch; `ms` is the raw sum (what `frac_of_hbm_peak` uses), `*_net` subtracts "
                    "the cost of an empty event pair from every launch (the pair also brackets dispatch latency that back-to-back "
-                   "launches overlap; rocprofv3 kernel durations, profiles/r03_config*_kernel_stats.csv, are the reference). "
+                   "launches overlap; rocprofv3 kernel durations, profiles/r04_config*_family_table.txt, are the reference). "
                    "bytes = every data operand of a launch once, dense, in the dtype / layout the site saw; c_sized launches "
                    "carry no bytes and count in the overall fractions' time only")
     return rec
@@ -482,10 +482,42 @@ def exchange_live_in_child(arch, timeout=900):
     return rec
 
 
+def host_overhead(device, steps=300):
+    """host time per operator-site training step (forward + backward): the same sites on tensors so small (8x64x16x16) that the
+    GPU side is a few microseconds, so wall time per step IS the host's share -- Python state machines, the autograd Function,
+    the FFI call(s).  What an eager (not graph-replayed) network pays per site and step; `plain_relu` is the floor a bare
+    nn.ReLU sets on the same loop."""
+    import qsparse_amd as qs
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+
+    def pair(act):
+        return fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(act, qs.prune(sparsity=0.75, dimensions={1}, start=0, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train())
+
+    sites = {"plain_relu": nn.ReLU().to(device),
+             "relu_prune_quantize_pair": pair(nn.ReLU()),
+             "prune_quantize_pair": pair(nn.Identity()),
+             "relu_quantize": fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train()),
+             "quantize_alone": qs.quantize(bits=8, channelwise=-1, timeout=1).to(device).train()}
+    x = torch.randn(8, 64, 16, 16, device=device, dtype=torch.bfloat16, requires_grad=True)
+    gs = {torch.float32: torch.randn(8, 64, 16, 16, device=device), torch.bfloat16: torch.randn(8, 64, 16, 16, device=device).bfloat16()}
+    out = {"shape": [8, 64, 16, 16], "steps": steps, "unit": "us of host time per site step (forward + backward)"}
+    for name, site in sites.items():
+        def step(_=0):
+            y = site(x)
+            torch.autograd.grad(y, x, gs[y.dtype])
+        for _ in range(20):
+            step()
+        out[name] = round(_timed_loop(step, steps) * 1e3, 1)
+    return out
+
+
 def extra_configs(device, only=None):
     """configs 2-4 of BASELINE.json; a failure in one of them is recorded, it never costs the headline line"""
     out = {}
-    for name, fn in (("config2_quantize8_256x64x56x56", lambda: config2(device)),
+    for name, fn in (("host_overhead_per_site", lambda: host_overhead(device)),
+                     ("config2_quantize8_256x64x56x56", lambda: config2(device)),
                      ("config3_resnet18_cifar_b128", lambda: resnet_config("resnet18", 128, device, 10)),
                      ("config4_resnet50_imagenet_b256", lambda: resnet_config("resnet50", 256, device, 5))):
         if only and not any(name.startswith(o) for o in only):

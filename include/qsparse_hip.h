@@ -50,6 +50,18 @@ enum qs_workspace_op { QS_WS_KTH_VALUE = 1, QS_WS_REDUCE = 2 /* n = C * inner of
 
 typedef void* qs_stream_t; /* hipStream_t */
 
+/* Folded activations.  convert() wraps whatever activation modules the user names (qsparse/convert.py:214-218); the entry
+ * points below that take `pre_relu` -- and qs_mean_dim / qs_mean_dim_cl through their flags -- absorb the activation in front
+ * of an operator: its output is never written, statistics and forward read its input, the forward records the ONE bit per
+ * element its backward needs (gate_out) and qs_quant_ste_relu_bwd applies it.  `pre_relu` is 0 (none), 1 (nn.ReLU) or a handle
+ * from qs_activation() for the others:
+ *   QS_ACT_HARDTANH  clamp(x, a, b): nn.Hardtanh(a, b), nn.ReLU6 (a = 0, b = 6);  backward 0 where x <= a or x >= b
+ *   QS_ACT_LEAKY     x > 0 ? x : x*a (product rounded to x's dtype): nn.LeakyReLU(a);  backward g*a where x <= 0
+ * Handles are interned descriptors: small positive integers, valid for the life of the process, the same (kind, a, b) always
+ * yields the same handle; thread-safe.  Returns a negative QS_ERR_* for an unknown kind or a full table (256 entries). */
+enum qs_act_kind { QS_ACT_NONE = 0, QS_ACT_RELU = 1, QS_ACT_HARDTANH = 2, QS_ACT_LEAKY = 3 };
+int qs_activation(int kind, float a, float b);
+
 int qs_version(void);
 const char* qs_status_string(int status);
 size_t qs_workspace_bytes(int op, int64_t n);
@@ -80,7 +92,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes,
                         int64_t outer, int64_t C, int64_t inner,
                         int xdt, int ydt, int qdt,
                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                        uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream);
+                        uint8_t* gate_out, void* image_out, int imgdt, void* xback_out, qs_stream_t stream);
 
 /* DecimalQuantization.forward, qsparse/quantize.py:44-63:  q = int32(trunc(x * 2^d)); y = f32(q) * 2^-d */
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
@@ -89,13 +101,20 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          int64_t outer, int64_t C, int64_t inner,
                          int xdt, int ydt, int qdt,
                          int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
-                         uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream);
+                         uint8_t* gate_out, void* image_out, int imgdt, void* xback_out, qs_stream_t stream);
 
 /* image_out (nullable; qs_quant_scaler_fwd / qs_quant_decimal_fwd, with gate_out, ydt == QS_F32 and codes == NULL): the same
  * pass also writes RNE(y) in imgdt (QS_BF16 / QS_F16) -- the low-precision image autocast would make of y in front of a
  * convolution -- at +2 instead of a 6 B/elem cast pass.  Served by the gate-recording widening kernels; qs_quant_image_ok tells
  * whether a geometry is one of theirs (1) or the call would be rejected with QS_ERR_ARG (0). */
 int qs_quant_image_ok(int64_t outer, int64_t C, int64_t inner, int per_channel_param, int has_mask, int mask_aligned8, int xdt);
+
+/* xback_out (nullable; same kernels and conditions as image_out -- gate_out, ydt == QS_F32, codes == NULL, a geometry for which
+ * qs_quant_image_ok answers 1): the same pass also stores relu(x) in xdt at xback_out[e] -- ATen's clamp_min(x, 0), NaN and -0.0
+ * pass.  With xback_out == x this IS the forward of an nn.ReLU(inplace=True) standing in front of the operator (what
+ * torchvision-style networks carry where the reference's convert() puts its operators, qsparse/convert.py:199-229): other
+ * holders of x see relu(x) as they must, at the price of one more store (+2 / +4 B/elem) instead of ATen's read + write pass
+ * (4 / 8 B/elem).  Every lane reads the elements it rewrites before it rewrites them; no other lane touches them. */
 
 /* LineQuantization.forward, qsparse/quantize.py:148-181.  lines = device float [nlines, 2] = (start, end).
  * float_zero_point != 0: ((clamp(rint((xc-start)/step),0,N-1))*step)+start   (:168-181)
@@ -123,8 +142,10 @@ int qs_quant_ste_bwd(const void* g, void* gx,
                      int64_t outer, int64_t C, int64_t inner,
                      int gdt, int gxdt, int elide_masked, qs_stream_t stream);
 
-/* The same backward with the gate of a folded nn.ReLU (threshold_backward: 0 where x <= 0):
- *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)
+/* The same backward with the gate of a folded activation -- `act`: 1 (nn.ReLU, threshold_backward: 0 where x <= 0) or a
+ * qs_activation() handle (hardtanh_backward: 0 where x <= a or x >= b; leaky_relu_backward: v * slope where x <= 0, v the
+ * clamped, masked gradient rounded to xdt):
+ *   gx = cast(xdt, x <= 0 ? 0 : min(max(g, lo_mul*step_c), hi_mul*step_c) * mask_c)                    (nn.ReLU)
  * x is the ReLU's INPUT (dtype xdt); gx has x's dtype.  gate (nullable): the bitmap a forward call recorded through
  * gate_out over the same [outer, C, inner] geometry; when given, x is not read (it may be NULL) and xdt only names the
  * dtype of gx: 4 + 1/8 + sizeof(xdt) bytes per element instead of 4 + 2 * sizeof(xdt).
@@ -135,7 +156,7 @@ int qs_quant_ste_bwd(const void* g, void* gx,
 int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx,
                           const float* step, int64_t nstep, float step_host, int step_is_decimal,
                           float lo_mul, float hi_mul, const uint8_t* chan_mask,
-                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked,
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, int act,
                           const void* g2, int g2dt, qs_stream_t stream);
 
 /* ---- statistics ---------------------------------------------------------------------------------- */
@@ -206,7 +227,9 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
 #define QS_AMAX_LINE_STRIDE 32
 #define QS_MEAN_ABS 1
 #define QS_MEAN_L0 2
-#define QS_MEAN_RELU 4 /* statistics of max(x, 0): a folded preceding nn.ReLU (abs-max included) */
+#define QS_MEAN_RELU 4 /* statistics of act(x): a folded preceding activation (abs-max included) -- nn.ReLU, or the one whose
+                          qs_activation() handle rides in bits 8.. of the flags: QS_MEAN_ACT(handle) */
+#define QS_MEAN_ACT(handle) (QS_MEAN_RELU | ((handle) << 8))
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C, qs_stream_t stream);
@@ -346,27 +369,24 @@ typedef struct qs_site_plan {
     int32_t callback_t_from_device; /* != 0: the running-magnitude counter is read from *callback_t instead of t_mag */
     int32_t saturate;            /* != 0: codes are clamped to [code_lo, code_hi] (qs_quant_scaler_fwd's opt-in saturation) */
     int32_t code_lo, code_hi;
-    float* record;               /* nullable: [2*C] float scratch.  With `ticket` it lets a live qs_site_fwd run qs_mean_last2 and
-                                    qs_pq_select as ONE launch: the workgroups publish importance | abs-max per channel here and
-                                    the last one to finish runs the select (same arithmetic, one launch boundary less) */
-    uint32_t* ticket;            /* nullable: one zero-initialised word, left zero by every call */
+    int32_t act;                 /* the activation QS_SITE_PRE_RELU folds: 0 / 1 nn.ReLU, else a qs_activation() handle */
 } qs_site_plan;
 
 /* flags of qs_site_fwd */
 #define QS_SITE_LIVE 1        /* training step with live statistics: magnitude and scale are updated (else: apply only) */
 #define QS_SITE_REFRESH 2     /* rebuild the mask from the running magnitude, threshold rank k */
-#define QS_SITE_PRE_RELU 4    /* x is the input of a folded nn.ReLU */
+#define QS_SITE_PRE_RELU 4    /* x is the input of a folded activation (plan->act; nn.ReLU by default) */
 #define QS_SITE_ELIDE 8       /* elide_masked of qs_quant_scaler_fwd */
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
 #define QS_SITE_STATS_DONE 32 /* with QS_SITE_LIVE: the statistics launches were already enqueued by qs_site_stats (a data-parallel
                                  step: the caller exchanged the record in between); qs_site_fwd starts at the select */
 
 /* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
- * gate_out, image_out / imgdt: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
+ * gate_out, image_out / imgdt, xback_out: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
  * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116).  gathered / world: nullable / 1; the all-gathered
  * records of qs_site_stats (see there and qs_pq_select). */
 int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, qs_stream_t stream);
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, qs_stream_t stream);
 
 /* The statistics half of a live qs_site_fwd on its own -- qs_mean_dim | qs_mean_dim_cl, then qs_mean_last2, which also writes
  * this rank's exchange record (record: device float[2*C] = importance | per-channel abs-max, qs_stats_pack's layout) -- for a
@@ -395,38 +415,66 @@ int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, vo
 #define QS_QSTEP_FINISH 3     /* running scale from the (reduced) accumulator lines, then quantize */
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream);
+                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, qs_stream_t stream);
 
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 
 /* The weight-side operators of a converted network (quantize(conv) / quantize(linear), reference quantize.py:559-571
- * through imitation.py) are the same three small kernels per layer and step.  These entry points run them for a LIST
- * of n contiguous, 16-byte aligned float32 tensors in one launch each (per 48 tensors): tensor-wise Scaler / Decimal
- * quantizers only.  All arrays are HOST arrays of length n holding device pointers / values.
- *   qs_multi_absmax:        amax[i][0] = max(amax[i][0], max|x[i]|)            (keep the accumulators zero between steps;
- *                           give every accumulator its own 128-byte line, see qs_mean_dim)
- *   qs_multi_scale_update:  scale[i][0] <- t == 0 ? new : (t*scale + new)/(t+1), new = amax[i][0] / 2^(bits[i]-1);
- *                           amax[i][0] <- 0; decimal[i][0] <- rint(log2(1/scale)) where decimal[i] != NULL;
- *                           t from t_dev[i] (then incremented there) where non-NULL, else t[i]; bump[i] (nullable
- *                           int32 counters) incremented; backup[i][0] (nullable array, nullable entries) <- the scale
- *                           this update replaces, so that a caller that evaluated a layer ahead of time can restore the
- *                           state of one the forward pass then never reached (reference imitation.py:61-68 evaluates the
- *                           operator only when the layer's weight is read)
- *   qs_multi_quant_fwd:     y[i] = Q(x[i]) with param[i][0] the scale (decimal == 0, qs_quant_scaler_fwd's
- *                           arithmetic) or the decimal (decimal != 0, qs_quant_decimal_fwd's); code_lo / code_hi (nullable
- *                           host arrays, both or neither): tensor i's codes are clamped to [code_lo[i], code_hi[i]] where
- *                           code_lo[i] <= code_hi[i] (the opt-in saturation of qs_quant_scaler_fwd), left alone otherwise */
-int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream);
-int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
-                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, float* const* backup,
-                          qs_stream_t stream);
-int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
-                       int decimal, const int32_t* code_lo, const int32_t* code_hi, qs_stream_t stream);
-/*   qs_multi_ste_bwd:       gx[i] = clamp(g[i], lo_mul[i] * s_i, hi_mul[i] * s_i) with s_i = step[i][0] (or 2^-step[i][0]
- *                           with step_is_decimal): qs_quant_ste_bwd's arithmetic (quantize.py:66-77, 120-131) for the
- *                           gradients of a GROUP of weight quantizers that are handed over together */
+ * through imitation.py:61-68) are the same three small kernels per layer and step: abs-max, running scale, quantization.
+ * These entry points run them for a LIST of float32 tensors in one launch each.  The list is a DEVICE-resident table of
+ * qs_multi_row that the caller builds once per set of layers (host copy -> qs_multi_plan fills the derived fields -> upload)
+ * and reuses every step; what changes from step to step -- the output buffer, which rows train -- is either an argument
+ * (`ybase`) or a field the caller rewrites.  Tensor-wise AND per-channel Scaler / Decimal quantizers: a tensor is the
+ * CONTIGUOUS [outer, C, inner] view around the reference's channel dim (C == 1, outer == 1, inner == numel for tensor-wise;
+ * the reference's default for weights is channelwise=1, quantize.py:524); parameters have C entries.
+ *   qs_multi_absmax        rows with train != 0: amax[c] = max(amax[c], max |x| over channel c)   (quantize.py:329-340; keep
+ *                          the accumulators zero between steps -- the update below re-zeroes them)
+ *   qs_multi_scale_update  rows with train != 0, every channel c: t = *t_dev + t_offset;
+ *                          scale[c] <- t == 0 ? new : (t*scale[c] + new)/(t+1), new = amax[c] / 2^(bits-1) (denom)   (:344-347);
+ *                          amax[c] <- 0; decimal[c] <- rint(log2(nan_to_num(1/scale[c]))) where decimal != NULL (:316);
+ *                          backup[c] (nullable) <- the scale this update replaces, so that a caller that evaluated a layer
+ *                          ahead of time can restore one the forward pass then never reached (imitation.py:61-68 evaluates
+ *                          the operator only when the layer's weight is read)
+ *   qs_multi_quant_fwd     every row: y[e] = Q(x[e]) with the scale (is_decimal == 0: qs_quant_scaler_fwd's arithmetic) or the
+ *                          decimal (qs_quant_decimal_fwd's) of e's channel, y = ybase + y_off; codes clamped to
+ *                          [code_lo, code_hi] where code_lo <= code_hi (the opt-in saturation).  advance != 0: the counters of
+ *                          the rows that trained -- *t_dev (quantizer callback's t, quantize.py:348) and *bump (the layer's
+ *                          `_n_updates`, :515) -- are incremented here, i.e. after every thread of the preceding
+ *                          qs_multi_scale_update has read them (stream order).  A callback shared by a layer's weight and
+ *                          bias quantizers (:548,559-571) is two rows with the same t_dev and t_offset 0 / 1. */
+typedef struct qs_multi_row {
+    const float* x;              /* the tensor, 4-byte aligned (16-byte aligned tensors take the vector paths) */
+    float* scale;                /* [C] running scale (QuantizeLayer.weight) */
+    float* amax;                 /* [C] abs-max accumulator, zero between steps */
+    float* decimal;              /* [C] or NULL: decimals of a DecimalQuantizer (written by the update, read by the quantizer) */
+    float* backup;               /* [C] or NULL */
+    int64_t* t_dev;              /* device copy of the quantizer callback's running-mean count (required when train != 0) */
+    int32_t* bump;               /* nullable: the layer's `_n_updates` */
+    int64_t numel, y_off;        /* elements; offset of the output in `ybase`, elements */
+    int64_t outer, inner;        /* [outer, C, inner] */
+    int32_t C;
+    int32_t train;               /* != 0: this row updates its statistics this step */
+    int32_t is_decimal;
+    int32_t t_offset;            /* added to *t_dev (1 for the bias quantizer that shares its weight quantizer's callback) */
+    int32_t code_lo, code_hi;    /* code_lo > code_hi: no saturation */
+    float denom;                 /* 2^(bits-1) */
+    /* derived by qs_multi_plan: */
+    int32_t row_splits, absmax_block0, absmax_blocks, quant_block0, chan0;
+} qs_multi_row;
+
+/* fills the derived fields of a HOST table in place and returns the launch totals; QS_ERR_ARG for an inconsistent row */
+int qs_multi_plan(qs_multi_row* rows_host, int n, int* absmax_blocks, int* quant_blocks, int* channels);
+int qs_multi_absmax(const qs_multi_row* rows_dev, int n, int absmax_blocks, qs_stream_t stream);
+int qs_multi_scale_update(const qs_multi_row* rows_dev, int n, int channels, qs_stream_t stream);
+int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, float* ybase, int advance, qs_stream_t stream);
+/*   qs_multi_ste_bwd:       gx[i][e] = clamp(g[i][e], lo_mul[i] * s, hi_mul[i] * s) with s = step[i][c] (or 2^-step[i][c] with
+ *                           step_is_decimal), c the channel of e in the contiguous [*, C[i], inner[i]] view the gradient has
+ *                           (C == NULL: tensor-wise, one step per tensor): qs_quant_ste_bwd's arithmetic (quantize.py:66-77,
+ *                           120-131) for the gradients of a GROUP of weight quantizers that are handed over together.  The
+ *                           gradients are fresh tensors every step: HOST arrays of length n of device pointers / values. */
 int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
-                     const float* lo_mul, const float* hi_mul, int step_is_decimal, qs_stream_t stream);
+                     const int32_t* C, const int64_t* inner, const float* lo_mul, const float* hi_mul, int step_is_decimal,
+                     qs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,8 @@ SIGNATURES = {
     "qs_version": (c_int, []),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
-    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P]),
-    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P]),
+    "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P, _P]),
+    "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P, _P]),
     "qs_quant_image_ok": (c_int, [_L, _L, _L, _I, _I, _I, _I]),
     "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P, _I, _P]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
@@ -57,12 +57,13 @@ SIGNATURES = {
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
-    "qs_multi_absmax": (c_int, [_I, _P, _P, _P, _P]),
-    "qs_multi_scale_update": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qs_multi_quant_fwd": (c_int, [_I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P]),
-    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P]),
+    "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P]),
+    "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
+    "qs_multi_scale_update": (c_int, [_P, _I, _I, _P]),
+    "qs_multi_quant_fwd": (c_int, [_P, _I, _I, _P, _I, _P]),
+    "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
+    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P]),
     "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
@@ -79,8 +80,16 @@ class SitePlanStruct(ctypes.Structure):
                 ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
-                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32),
-                ("record", c_void_p), ("ticket", c_void_p)]
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32)]
+
+
+class MultiRow(ctypes.Structure):
+    """`qs_multi_row` of include/qsparse_hip.h, field for field"""
+    _fields_ = [("x", c_void_p), ("scale", c_void_p), ("amax", c_void_p), ("decimal", c_void_p), ("backup", c_void_p),
+                ("t_dev", c_void_p), ("bump", c_void_p), ("numel", c_int64), ("y_off", c_int64), ("outer", c_int64),
+                ("inner", c_int64), ("C", c_int32), ("train", c_int32), ("is_decimal", c_int32), ("t_offset", c_int32),
+                ("code_lo", c_int32), ("code_hi", c_int32), ("denom", c_float), ("row_splits", c_int32),
+                ("absmax_block0", c_int32), ("absmax_blocks", c_int32), ("quant_block0", c_int32), ("chan0", c_int32)]
 
 
 SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE = 1, 2, 4, 8, 16, 32
@@ -314,6 +323,14 @@ def note_gate(bits: torch.Tensor):
         cell["bits"] = bits
 
 
+def owned_relu_cell():
+    """the cell of the owned in-place ReLU whose site is being evaluated on this thread (fused.py::_with_owned_relu), or None.
+    cell["defer"]: the ReLU has NOT been applied to x yet -- the site's apply kernel may write relu(x) back itself (xback_out of
+    qs_quant_scaler_fwd) and set cell["done"]; whoever does not, leaves it to the caller's ATen pass."""
+    cell = getattr(_gate_sink, "cell", None)
+    return cell if (cell is not None and cell.get("defer") and not cell.get("done")) else None
+
+
 def unpack_gate(bits: torch.Tensor, shape, strides) -> torch.Tensor:
     """the recorded gate as a bool tensor laid out like the (dense) activation it belongs to: True where the ReLU lets the
     gradient through, !(x <= 0) (a torch composition for the rare route that needs the gate outside the backward kernels)"""
@@ -346,10 +363,12 @@ class ReluGate:
 def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
               chan_mask: Optional[torch.Tensor] = None, mask_channel_index: Optional[int] = None,
               want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False,
-              want_gate: bool = False):
+              want_gate: bool = False, xback: Optional[dict] = None):
     """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU).
     want_gate (with pre_relu): returns (y, codes|None, ReluGate) -- the ReLU's gate as one bit per element, recorded by
-    the same pass, for `ste_relu_bwd(gate=...)`."""
+    the same pass, for `ste_relu_bwd(gate=...)`.
+    xback (with want_gate): the cell of an owned in-place ReLU (fused.py::_with_owned_relu) -- when this launch is one that can
+    write relu(x) back into x's own storage (qs_quant_image_ok) it does, and says so in xback["done"]."""
     lib = load()
     pt, n, host = _f32param(param, x.device)
     ci = channel_index if n > 1 else (mask_channel_index if chan_mask is not None else -1)
@@ -368,11 +387,17 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
     cm = _chan_mask_bytes(chan_mask, C)
     sat, lo, hi = (0, 0, 0) if saturate is None else (1, int(saturate[0]), int(saturate[1]))
     fn = lib.qs_quant_scaler_fwd if kind == "scaler" else lib.qs_quant_decimal_fwd
-    with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None):
+    xb = None
+    if (xback is not None and gate is not None and codes is None and out_dtype == torch.float32 and not xback.get("done")
+            and lib.qs_quant_image_ok(outer, C, inner, int(n > 1), int(cm is not None), int(cm is None or cm.data_ptr() % 8 == 0), dt(x))):
+        xb = x                 # relu(x) lands in x's own storage (x IS the in-place ReLU's tensor, addressed in memory order)
+    with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None, xb):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
                 _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd(x is not like, gate is not None) if cm is not None else 0,
-                _ptr(gate.bits) if gate is not None else None, None, 0, _stream(x))
+                _ptr(gate.bits) if gate is not None else None, None, 0, _ptr(xb), _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
+    if xb is not None:
+        xback["done"] = True
     return (y, codes, gate) if want_gate else (y, codes)
 
 
@@ -803,7 +828,7 @@ def logging_events() -> bool:
 
 def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], amax_lines: Optional[torch.Tensor],
                   scale: torch.Tensor, bits: int, t: int, t_dev: Optional[torch.Tensor], n_updates: Optional[torch.Tensor],
-                  pre_relu: bool, update, saturate=None):
+                  pre_relu: bool, update, saturate=None, xback: bool = False):
     """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout; saturate: None or the
     (code_lo, code_hi) pair of the opt-in saturation; update: False / True or one of QSTEP_* (ABSMAX: the abs-max launch alone,
     y may be None; FINISH: running scale from the -- meanwhile all-reduced -- accumulator lines, then quantize)"""
@@ -812,18 +837,20 @@ def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Te
                                  None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
                                  x.numel(), _DT[x.dtype], _DT[(y if y is not None else x).dtype], int(bits), int(t),
                                  None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
-                                 int(bool(pre_relu)), int(update), sat, lo, hi, _stream(x))
+                                 int(bool(pre_relu)), int(update), sat, lo, hi, x.data_ptr() if xback else None, _stream(x))
     if st:
         _check(st, "qs_quantize_step")
 
 
 def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,
-             t_q: int, image: Optional[torch.Tensor] = None, gathered: Optional[torch.Tensor] = None, world: int = 1):
+             t_q: int, image: Optional[torch.Tensor] = None, gathered: Optional[torch.Tensor] = None, world: int = 1,
+             xback: bool = False):
     """image: optional bf16 / fp16 tensor of y's shape and layout that receives RNE(y) from the same pass (see qs_quant_image_ok);
-    gathered (with SITE_STATS_DONE in flags): the all-gathered [world, 2C] records of `site_stats`"""
+    gathered (with SITE_STATS_DONE in flags): the all-gathered [world, 2C] records of `site_stats`; xback: the apply kernel also
+    writes relu(x) back into x (an owned nn.ReLU(inplace=True), see qs_quant_scaler_fwd xback_out)"""
     st = load().qs_site_fwd(plan_ref, x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), flags,
                             t_mag, k, t_q, None if image is None else image.data_ptr(), 0 if image is None else _DT[image.dtype],
-                            None if gathered is None else gathered.data_ptr(), world, _stream(x))
+                            None if gathered is None else gathered.data_ptr(), world, x.data_ptr() if xback else None, _stream(x))
     if st:
         _check(st, "qs_site_fwd")
 
@@ -867,37 +894,62 @@ def _device_stream(device):
     return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
 
 
-def multi_absmax(n: int, x_ptrs, numels, amax_ptrs, device, nbytes: int = 0):
+class MultiTable:
+    """a `qs_multi_row` table: the host copy (a ctypes array the caller fills), the derived launch totals and the device
+    copy the kernels read.  Built once per set of layers; `set_train` rewrites the one per-step field and re-uploads (a few KB,
+    asynchronously) only when it changed."""
+
+    def __init__(self, rows, device):
+        self.n = len(rows)
+        self.host = (MultiRow * self.n)(*rows)
+        ab, qb, ch = c_int(0), c_int(0), c_int(0)
+        _check(load().qs_multi_plan(self.host, self.n, ctypes.byref(ab), ctypes.byref(qb), ctypes.byref(ch)), "qs_multi_plan")
+        self.absmax_blocks, self.quant_blocks, self.channels = ab.value, qb.value, ch.value
+        self.device = device
+        self.dev = None
+        self.upload()
+
+    def upload(self):
+        raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8) if self.n else torch.zeros(0, dtype=torch.uint8)
+        # pinned staging + non_blocking copy: stream-ordered with the launches that read the table
+        self.dev = raw.to(self.device, non_blocking=False)
+
+    def __deepcopy__(self, memo):
+        raise TypeError("a launch table holds raw device pointers: rebuild it, never copy it")
+
+
+def multi_absmax(table: MultiTable, nbytes: int = 0):
     with _timed("multi_absmax", int(nbytes)):
-        st = load().qs_multi_absmax(n, x_ptrs, numels, amax_ptrs, _device_stream(device))
+        st = load().qs_multi_absmax(table.dev.data_ptr(), table.n, table.absmax_blocks, _device_stream(table.device))
     _check(st, "qs_multi_absmax")
 
 
-def multi_scale_update(n: int, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, device, backup_ptrs=None):
+def multi_scale_update(table: MultiTable):
     with _timed("multi_scale_update"):
-        st = load().qs_multi_scale_update(n, amax_ptrs, scale_ptrs, decimal_ptrs, ts, t_dev_ptrs, bits, bump_ptrs, backup_ptrs,
-                                      _device_stream(device))
+        st = load().qs_multi_scale_update(table.dev.data_ptr(), table.n, table.channels, _device_stream(table.device))
     _check(st, "qs_multi_scale_update")
+
+
+def multi_quant_fwd(table: MultiTable, ybase: torch.Tensor, advance: bool, nbytes: int = 0):
+    with _timed("multi_quant_fwd", int(nbytes)):
+        st = load().qs_multi_quant_fwd(table.dev.data_ptr(), table.n, table.quant_blocks, ybase.data_ptr(), int(bool(advance)),
+                                       _device_stream(table.device))
+    _check(st, "qs_multi_quant_fwd")
 
 
 def i32_array(values):
     return (c_int32 * len(values))(*[int(v) for v in values])
 
 
-def multi_quant_fwd(n: int, x_ptrs, y_ptrs, param_ptrs, numels, decimal: bool, device, nbytes: int = 0, code_lo=None,
-                    code_hi=None):
-    """code_lo / code_hi: `i32_array`s (both or neither) -- tensor i saturates to [lo, hi] where lo <= hi"""
-    with _timed("multi_quant_fwd", int(nbytes)):
-        st = load().qs_multi_quant_fwd(n, x_ptrs, y_ptrs, param_ptrs, numels, int(bool(decimal)), code_lo, code_hi,
-                                       _device_stream(device))
-    _check(st, "qs_multi_quant_fwd")
-
-
 def f32_array(values):
     return (c_float * len(values))(*[float(v) for v in values])
 
 
-def multi_ste_bwd(n: int, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, decimal: bool, device, nbytes: int = 0):
+def multi_ste_bwd(n: int, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, decimal: bool, device, nbytes: int = 0,
+                  channels=None, inners=None):
+    """channels / inners (`i32_array` / `i64_array`, both or neither): per-channel steps -- gradient i is the contiguous
+    [*, channels[i], inners[i]] view; None: one step per tensor"""
     with _timed("multi_ste_bwd", int(nbytes)):
-        st = load().qs_multi_ste_bwd(n, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, int(bool(decimal)), _device_stream(device))
+        st = load().qs_multi_ste_bwd(n, g_ptrs, gx_ptrs, step_ptrs, numels, channels, inners, lo_muls, hi_muls, int(bool(decimal)),
+                                     _device_stream(device))
     _check(st, "qs_multi_ste_bwd")

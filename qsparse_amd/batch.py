@@ -1,38 +1,44 @@
 """Multi-tensor weight path.
 
-``quantize(conv)`` reads ``conv.weight`` through a ``QuantizeLayer`` (reference quantize.py:559-571 via imitation.py:61-68):
-per layer and training step an abs-max, a running-scale update and a quantization -- three launches of 3-5 us each
-plus ~100 us of Python.  A converted ResNet-50 has 54 such layers.  They depend on nothing but the parameters, so
-``WeightBatcher`` evaluates all of them at the start of the root's forward pass with THREE launches in total
-(``qs_multi_absmax``, ``qs_multi_scale_update``, ``qs_multi_quant_fwd``; same arithmetic, bit-identical results) and
-hands every layer its quantized weight when its forward asks for it.  The STE backward stays per layer (gradients
-become ready one layer at a time).
+``quantize(conv)`` reads ``conv.weight`` -- and, with ``bias_bits``, ``conv.bias`` -- through a ``QuantizeLayer`` (reference
+quantize.py:559-571 via imitation.py:61-68): per tensor and training step an abs-max, a running-scale update and a
+quantization -- three launches of 3-5 us each plus ~100 us of Python.  A converted ResNet-50 has 54 such layers.  They depend on
+nothing but the parameters, so ``WeightBatcher`` evaluates all of them at the start of the root's forward pass with THREE
+launches in total (``qs_multi_absmax``, ``qs_multi_scale_update``, ``qs_multi_quant_fwd`` over a device-resident table of
+tensor descriptors built once per set of layers; same arithmetic, bit-identical results) and hands every layer its quantized
+tensor when its forward asks for it.  The STE backward runs per group of eight tensors (gradients become ready layer by layer).
+
+Tensor-wise AND per-channel Scaler / Decimal quantizers take part -- per-channel along dim 1 is the reference's default
+(``quantize(bits=8)``: ``channelwise=1``, quantize.py:524) -- and so do bias quantizers, which share their layer's callback
+object and therefore its running-mean count ``t`` (quantize.py:548,559-571: the weight's update sees ``t``, the bias's
+``t + 1``).
 
 ``convert`` installs it on the network it returns (``set_qsparse_options(batch_weights=False)`` or
 ``convert(..., batch_weights=False)`` opt out; ``WeightBatcher.install(model)`` does the same by hand, ``.remove()``
 undoes it).  It is safe by construction for anything a forward pass may do:
 
-  * The reference evaluates a layer's operator when -- and only when -- the layer's weight is read
-    (imitation.py:61-68).  A layer whose precomputed weight was NOT consumed by the end of the root's forward -- a branch
-    the forward skipped, an exception half-way -- is rolled back to exactly the state it had before: running scale (from
-    the backup ``qs_multi_scale_update`` wrote), ``_n_updates``, the callback's ``t`` (host and device copy) and
-    ``_quantized``.  The forward hook that does this also runs when the forward raised.  Such a layer's weight receives NO
-    gradient from its place in the hand-out node (like the layer the reference never evaluated: ``.grad`` stays ``None``, an
-    optimizer with weight decay does not touch it) -- except under an initialised process group, where
-    ``DistributedDataParallel`` counts the parameter as used and waits for a gradient: there it contributes zeros, as DDP's
-    own unused parameters do.
-  * A weight that is read a second time in the same forward takes the inline path, as the second read of the reference.
-  * A weight written between the precomputation and its read is rolled back and re-evaluated inline.  The write is seen
+  * The reference evaluates an operator when -- and only when -- the layer's parameter is read (imitation.py:61-68).  A
+    tensor whose precomputed value was NOT consumed by the end of the root's forward -- a branch the forward skipped, an
+    exception half-way -- is rolled back to exactly the state it had before: running scale (from the backup
+    ``qs_multi_scale_update`` wrote), ``_n_updates``, the callback's ``t`` (host and device copy) and ``_quantized``.  The
+    forward hook that does this also runs when the forward raised.  Such a parameter receives NO gradient from its place in
+    the hand-out node (like the layer the reference never evaluated: ``.grad`` stays ``None``, an optimizer with weight decay
+    does not touch it) -- except under an initialised process group, where ``DistributedDataParallel`` counts the parameter as
+    used and waits for a gradient: there it contributes zeros, as DDP's own unused parameters do.
+  * A parameter that is read a second time in the same forward takes the inline path, as the second read of the reference.
+  * A parameter written between the precomputation and its read is rolled back and re-evaluated inline.  The write is seen
     through ``Tensor._version`` (every in-place operation); the one route that bypasses the counter is ``param.data``.  The
     place where user code runs between the two is a forward pre-hook of the layer itself: layers that carry one are not
     batched.  (A raw ``.data`` write to a layer's weight from OTHER code running inside the same forward, before that
     layer's read, is not visible -- switch ``batch_weights`` off for such a network.)
-  * Layers whose quantizer carries hooks, layers on the CPU, pruned or bias-quantized layers and per-channel quantizers
-    never take part; they keep their inline path.
+  * A bias that is read BEFORE its layer's weight (the reference would then have updated the bias with ``t``, not ``t + 1``)
+    rolls both back; they are evaluated inline in the order of the reads.
+  * Layers whose quantizer carries hooks, layers on the CPU, pruned layers (their quantizer's input is the pruned weight, which
+    the prune operator makes per read), group-wise quantizers and callbacks shared between layers never take part; they keep
+    their inline path.
 
-Only layers whose weight is read through exactly one tensor-wise Scaler / Decimal ``QuantizeLayer`` (no weight pruning,
-no bias quantizer, float32 parameter on the GPU) take part.  In evaluation mode the quantized weights are computed once
-and handed out again until a parameter or a scale changes (serving: no weight-side launch at all per request).
+In evaluation mode under ``torch.no_grad()`` the quantized tensors are computed once and handed out again until a parameter
+or a scale changes (serving: no weight-side launch at all per request).
 """
 from typing import List, Optional
 
@@ -46,30 +52,58 @@ from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantize
 from qsparse_amd.util import get_option, logging
 
 _ALIGN = 64   # elements between the starts of two outputs in the flat buffer (256 bytes)
-_READY = "_qs_ready_weight"        # layer.__dict__ key of a precomputed weight waiting for its read
+_READY = {"weight": "_qs_ready_weight", "bias": "_qs_ready_bias"}   # layer.__dict__ keys of precomputed tensors waiting for their read
 _ATTR = "_qs_weight_batcher"       # root.__dict__ key of the installed batcher
+_QUANT = {"weight": "quantize", "bias": "quantize_bias"}
 
 
-_GROUP = 8      # layers per hand-out node: their weight gradients are clamped together, by ONE launch, when the group's
+_GROUP = 8      # tensors per hand-out node: their gradients are clamped together, by ONE launch, when the group's
                 # earliest layer has finished its backward (small groups keep DDP's bucketed all-reduce overlapping)
 
 
+def _dense(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _geometry(t: torch.Tensor, channel_index: int):
+    """(outer, C, inner) of the CONTIGUOUS view of `t`'s memory around its channel dim, or None when there is none (the caller
+    then keeps the per-layer entry points, which copy).  Tensor-wise: (1, 1, numel) for any dense layout."""
+    if channel_index < 0:
+        return (1, 1, t.numel()) if _dense(t) else None
+    if channel_index >= t.dim() or t.numel() == 0:
+        return None
+    shape = tuple(t.shape)
+    C = shape[channel_index]
+    if t.is_contiguous():
+        outer = 1
+        for s in shape[:channel_index]:
+            outer *= s
+        inner = 1
+        for s in shape[channel_index + 1:]:
+            inner *= s
+    elif t.dim() == 4 and channel_index == 1 and t.is_contiguous(memory_format=torch.channels_last):
+        outer, inner = shape[0] * shape[2] * shape[3], 1        # [N][H][W][C] in memory
+    else:
+        return None
+    return (1, 1, t.numel()) if C == 1 else (outer, C, inner)
+
+
 class _GroupSte(torch.autograd.Function):
-    """hands out the precomputed quantized weights of a GROUP of consecutive layers through one autograd node whose
+    """hands out the precomputed quantized tensors of a GROUP of consecutive layers through one autograd node whose
     backward applies the quantizers' STE clamp (reference quantize.py:66-77, 120-131) to all of their gradients with one
     multi-tensor launch (qs_multi_ste_bwd) -- instead of one node, one Python backward and one 4 us launch per layer."""
 
     @staticmethod
     def forward(ctx, meta, dead, *tensors):
         k = len(meta)
-        ctx.meta, ctx.dead = meta, dead                     # per layer: (is_decimal, lo_mul, hi_mul, passthrough); rolled back?
+        ctx.meta, ctx.dead = meta, dead                     # per tensor: (is_decimal, lo_mul, hi_mul, passthrough, channel index); rolled back?
         ctx.shapes = [(w.shape, w.stride()) for w in tensors[:k]]
-        ctx.save_for_backward(*tensors[2 * k:])             # the steps (scale or decimal, one element each)
-        # a member whose weight is never read gets NO gradient, exactly like the layer the reference never evaluated
+        ctx.save_for_backward(*tensors[2 * k:])             # the steps (scales or decimals: one per channel)
+        # a member whose tensor is never read gets NO gradient, exactly like the layer the reference never evaluated
         # (zero_grad(set_to_none=True) + weight decay would otherwise start to move a parameter the forward did not use)
         ctx.set_materialize_grads(False)
         ys = tuple(y.view_as(y) for y in tensors[k:2 * k])
-        # a frozen weight (requires_grad=False: fine-tuning a head on a frozen backbone) hands out a quantized weight that
+        # a frozen parameter (requires_grad=False: fine-tuning a head on a frozen backbone) hands out a quantized tensor that
         # does not require grad either, as layer by layer -- its convolution then skips the weight-gradient pass altogether
         frozen = [ys[i] for i in range(k) if not ctx.needs_input_grad[2 + i]]
         if frozen:
@@ -94,11 +128,13 @@ class _GroupSte(torch.autograd.Function):
         for decimal in (False, True):
             idx = [i for i in range(k) if grads[i] is not None and ctx.needs_input_grad[2 + i] and meta[i][0] == decimal
                    and not meta[i][3]]
-            fast = [i for i in idx if grads[i].dtype == torch.float32 and grads[i].data_ptr() % 16 == 0
-                    and (grads[i].is_contiguous() or (grads[i].dim() == 4 and grads[i].is_contiguous(memory_format=torch.channels_last)))]
+            # the gradient's own memory view around the channel dim (a per-channel step needs the channel of every element)
+            geo = {i: (_geometry(grads[i], meta[i][4] if steps[i].numel() > 1 else -1)
+                       if (grads[i].dtype == torch.float32 and grads[i].data_ptr() % 16 == 0) else None) for i in idx}
+            fast = [i for i in idx if geo[i] is not None]
             for i in idx:
-                if i not in fast:                           # odd layouts / dtypes: the per-layer entry point
-                    out[i] = _hip.ste_bwd(grads[i], steps[i], decimal, -1, meta[i][1], meta[i][2], False, torch.float32)
+                if geo[i] is None:                          # odd layouts / dtypes: the per-layer entry point
+                    out[i] = _hip.ste_bwd(grads[i], steps[i], decimal, meta[i][4], meta[i][1], meta[i][2], False, torch.float32)
             if fast:
                 gs = [grads[i] for i in fast]
                 flat = torch.empty(sum((g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for g in gs), dtype=torch.float32, device=gs[0].device)
@@ -107,9 +143,12 @@ class _GroupSte(torch.autograd.Function):
                     outs.append(flat.as_strided(g.shape, g.stride(), flat.storage_offset() + off))     # the gradient's own (dense) layout
                     off += (g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
                 numels = [g.numel() for g in gs]
+                per_channel = any(geo[i][1] > 1 for i in fast)
                 _hip.multi_ste_bwd(len(fast), _hip.ptr_array(gs), _hip.ptr_array(outs), _hip.ptr_array([steps[i] for i in fast]),
                                    _hip.i64_array(numels), _hip.f32_array([meta[i][1] for i in fast]),
-                                   _hip.f32_array([meta[i][2] for i in fast]), decimal, gs[0].device, nbytes=8 * sum(numels))
+                                   _hip.f32_array([meta[i][2] for i in fast]), decimal, gs[0].device, nbytes=8 * sum(numels),
+                                   channels=_hip.i32_array([geo[i][1] for i in fast]) if per_channel else None,
+                                   inners=_hip.i64_array([geo[i][2] for i in fast]) if per_channel else None)
                 for i, o in zip(fast, outs):
                     out[i] = o
         for i in range(k):
@@ -118,23 +157,58 @@ class _GroupSte(torch.autograd.Function):
         return (None, None) + tuple(out) + (None,) * (2 * k)
 
 
-def _imitation_depth(layer: nn.Module) -> int:
-    """number of operators the layer's weight is read through (imitation.py stacks one subclass per operator); the
-    batcher's own hand-out subclass is not one of them"""
-    return sum(1 for cls in type(layer).__mro__
-               if isinstance(cls.__dict__.get("weight"), property) and "_qs_batcher_base" not in cls.__dict__)
+def _operators(layer: nn.Module) -> List[str]:
+    """the operators the layer's parameters are read through, outermost first (imitation.py stacks one subclass per operator;
+    the batcher's own hand-out subclass is not one of them)"""
+    ops = []
+    for cls in type(layer).__mro__:
+        name = cls.__dict__.get("_qs_imitation")
+        if name is not None:
+            ops.append(name)
+        elif isinstance(cls.__dict__.get("weight"), property) and "_qs_batcher_base" not in cls.__dict__:
+            ops.append("?")                  # a weight property of unknown origin (user code): hands off
+    return ops
+
+
+def _unit_ok(q, p) -> bool:
+    if not isinstance(q, QuantizeLayer) or p is None:
+        return False
+    qc = q.callback
+    return (type(qc) in (ScalerQuantizer, DecimalQuantizer) and qc.group_num <= 0 and q.batch_dimension == -1 and q.timeout > 0
+            and q.channelwise < p.dim())
 
 
 def _eligible(layer: nn.Module) -> bool:
-    q = getattr(layer, "quantize", None)
-    w = layer._parameters.get("weight") if hasattr(layer, "_parameters") else None
-    if not isinstance(q, QuantizeLayer) or w is None or _imitation_depth(layer) != 1:
+    """a layer whose weight is read through exactly one quantizer (tensor-wise or per channel) and nothing else"""
+    params = getattr(layer, "_parameters", None)
+    if params is None or _operators(layer) != ["quantize"]:
         return False
-    if isinstance(getattr(layer, "quantize_bias", None), QuantizeLayer) or hasattr(layer, "prune"):
+    if not _unit_ok(getattr(layer, "quantize", None), params.get("weight")):
         return False
-    qc = q.callback
-    return (type(qc) in (ScalerQuantizer, DecimalQuantizer) and qc.group_num <= 0 and q.channelwise < 0
-            and q.batch_dimension == -1 and q.timeout > 0)
+    qb = getattr(layer, "quantize_bias", None)
+    if isinstance(qb, QuantizeLayer) and params.get("bias") is not None:
+        # a bias quantizer takes part together with its weight's (one callback, one count `t`), or the layer stays inline
+        if not (_unit_ok(qb, params["bias"]) and qb.callback is layer.quantize.callback and qb.timeout == layer.quantize.timeout):
+            return False
+    return True
+
+
+def _callback_owners(model: nn.Module) -> dict:
+    """callback id -> number of distinct owners: an owner is a wrapped layer (its weight and bias quantizers count once) or a
+    free-standing QuantizeLayer (an activation operator)"""
+    inside, owners = set(), {}
+    for m in model.modules():
+        if isinstance(m, QuantizeLayer):
+            continue
+        subs = [m.__dict__.get("_modules", {}).get(k) for k in _QUANT.values()]
+        subs = [q for q in subs if isinstance(q, QuantizeLayer)]
+        inside.update(id(q) for q in subs)
+        for c in {id(q.callback) for q in subs if q.callback is not None}:
+            owners[c] = owners.get(c, 0) + 1
+    for m in model.modules():
+        if isinstance(m, QuantizeLayer) and id(m) not in inside and m.callback is not None:
+            owners[id(m.callback)] = owners.get(id(m.callback), 0) + 1
+    return owners
 
 
 def _batchable(model: nn.Module) -> List[nn.Module]:
@@ -142,12 +216,8 @@ def _batchable(model: nn.Module) -> List[nn.Module]:
     hand-built network may hand ONE callback object to several layers (the reference allows it: the callback's running-mean
     count `t` then advances once per layer read, in forward order) -- such layers keep the inline path, whose order of
     evaluation is the forward's own."""
-    layers = [m for m in model.modules() if _eligible(m)]
-    owners = {}
-    for m in model.modules():            # every QuantizeLayer of the tree counts, not only the eligible layers' own
-        if isinstance(m, QuantizeLayer) and m.callback is not None:
-            owners[id(m.callback)] = owners.get(id(m.callback), 0) + 1
-    return [m for m in layers if owners.get(id(m.quantize.callback), 0) == 1]
+    owners = _callback_owners(model)
+    return [m for m in model.modules() if _eligible(m) and owners.get(id(m.quantize.callback), 0) == 1]
 
 
 def _hooked(q: QuantizeLayer) -> bool:
@@ -159,7 +229,7 @@ def _hooked(q: QuantizeLayer) -> bool:
 
 
 class _LaunchPlan(dict):
-    """cached pointer arrays of the three launches (ctypes objects): never copied or pickled with the network"""
+    """cached launch table (ctypes + device memory): never copied or pickled with the network"""
 
     def __deepcopy__(self, memo):
         return _LaunchPlan()
@@ -168,33 +238,62 @@ class _LaunchPlan(dict):
         return (_LaunchPlan, ())
 
 
-class _Pending:
-    """what has to be undone if a precomputed layer's weight is never read"""
-    __slots__ = ("layer", "slot", "was_quantized", "t_dev", "version", "training", "dead", "index")
+class _Unit:
+    """one tensor of the multi-tensor launches: a layer's weight or bias with the QuantizeLayer it is read through"""
+    __slots__ = ("layer", "attr", "slot", "channels")
 
-    def __init__(self, layer, slot, was_quantized, t_dev, version, training):
-        self.layer, self.slot, self.was_quantized, self.t_dev, self.version, self.training = (layer, slot, was_quantized, t_dev,
-                                                                                             version, training)
-        self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this layer's place in them
+    def __init__(self, layer, attr, slot, channels):
+        self.layer, self.attr, self.slot, self.channels = layer, attr, slot, channels
+
+    @property
+    def q(self) -> QuantizeLayer:
+        return getattr(self.layer, _QUANT[self.attr])
+
+    @property
+    def param(self) -> torch.Tensor:
+        return self.layer._parameters[self.attr]
+
+
+class _Pending:
+    """what has to be undone if a precomputed tensor is never read"""
+    __slots__ = ("unit", "was_quantized", "t_dev", "version", "training", "dead", "index")
+
+    def __init__(self, unit, was_quantized, t_dev, version, training):
+        self.unit, self.was_quantized, self.t_dev, self.version, self.training = unit, was_quantized, t_dev, version, training
+        self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this tensor's place in them
 
 
 def _patched_class(base):
-    """subclass of `base` whose `weight` hands out a waiting precomputed tensor once, else reads like `base`.  The
-    property finds everything through the instance (nothing closes over a batcher), so a deep copy of the network keeps
+    """subclass of `base` whose `weight` / `bias` hand out a waiting precomputed tensor once, else read like `base`.  The
+    properties find everything through the instance (nothing closes over a batcher), so a deep copy of the network keeps
     working on its own."""
 
-    def read_weight(self_):
-        entry = self_.__dict__.pop(_READY, None)
-        if entry is not None:
-            y, pending, batcher = entry
-            w = self_._parameters["weight"]
-            if w._version == pending.version:
-                batcher._consumed(pending)
-                return y
-            batcher._rollback(pending)           # the parameter was written since the precomputation: evaluate inline
-        return base.weight.__get__(self_)
+    def reader(attr):
+        def read(self_):
+            entry = self_.__dict__.pop(_READY[attr], None)
+            if entry is not None:
+                y, pending, batcher = entry
+                waiting_weight = self_.__dict__.get(_READY["weight"]) if attr == "bias" else None
+                if waiting_weight is not None and waiting_weight[1].training:
+                    # the bias is read BEFORE the weight: the reference would update the bias statistics with t (not t + 1)
+                    # and the weight's with t + 1 -- undo both, the inline path follows the order of the reads
+                    batcher._rollback(waiting_weight[1])
+                    batcher._rollback(pending)
+                elif self_._parameters[attr]._version == pending.version:
+                    batcher._consumed(pending)
+                    return y
+                else:
+                    batcher._rollback(pending)       # the parameter was written since the precomputation: evaluate inline
+                    waiting_bias = self_.__dict__.get(_READY["bias"]) if attr == "weight" else None
+                    if waiting_bias is not None and waiting_bias[1].training:
+                        # ... and the bias after it: its precomputed update counted on the weight's having advanced the shared
+                        # count first, which the inline evaluation is about to do again
+                        batcher._rollback(waiting_bias[1])
+            return getattr(base, attr).__get__(self_)
+        return read
 
-    return type(base.__name__, (base,), {"weight": property(read_weight), "_qs_batcher_base": base})
+    return type(base.__name__, (base,), {"weight": property(reader("weight")), "bias": property(reader("bias")),
+                                         "_qs_batcher_base": base})
 
 
 class WeightBatcher:
@@ -205,6 +304,16 @@ class WeightBatcher:
                 old.remove()
         self.model = model
         self.layers: List[nn.Module] = _batchable(model)
+        self.units: List[_Unit] = []
+        total = 0
+        for layer in self.layers:
+            for attr in ("weight", "bias"):
+                q, p = getattr(layer, _QUANT[attr], None), layer._parameters.get(attr)
+                if isinstance(q, QuantizeLayer) and p is not None:
+                    C = 1 if q.channelwise < 0 else p.shape[q.channelwise]
+                    self.units.append(_Unit(layer, attr, total, C))
+                    total += C
+        self._channels = total
         self._pending: List[_Pending] = []
         self._amax = None
         self._decimals = None
@@ -248,7 +357,8 @@ class WeightBatcher:
             base = type(layer).__dict__.get("_qs_batcher_base")
             if base is not None:
                 layer.__class__ = base
-            layer.__dict__.pop(_READY, None)
+            for key in _READY.values():
+                layer.__dict__.pop(key, None)
         self.model.__dict__.pop(_ATTR, None)
 
     # ------------------------------------------------------------------------------------------
@@ -259,16 +369,17 @@ class WeightBatcher:
             pass
 
     def _rollback(self, p: _Pending):
-        """put the layer back where it was before `_precompute` advanced it (stream-ordered device writes, no sync)"""
+        """put the tensor's quantizer back where it was before `_precompute` advanced it (stream-ordered device writes, no sync)"""
         self._consumed(p)
-        p.layer.__dict__.pop(_READY, None)
+        u = p.unit
+        u.layer.__dict__.pop(_READY[u.attr], None)
         if p.dead is not None:
             p.dead[p.index] = True               # its place in the group's autograd node delivers no gradient
         if not p.training:
             return                               # evaluation-mode hand-outs change no state
-        q, qc = p.layer.quantize, p.layer.quantize.callback
+        q, qc = u.q, u.q.callback
         with torch.no_grad():
-            q.weight.data.view(-1).copy_(self._backup[p.slot:p.slot + 1])
+            q.weight.data.view(-1).copy_(self._backup[u.slot:u.slot + u.channels])
             q._steps.add(q._n_updates, -1)
             qc.t -= 1
             if p.t_dev is not None:
@@ -293,43 +404,48 @@ class WeightBatcher:
             self._rollback_all()
         if not get_option("batch_weights"):
             return
-        train, frozen = [], []          # layers that update statistics this step / that only quantize
-        for layer in self.layers:
-            q, w = layer.quantize, layer._parameters["weight"]
-            dense = w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))
-            if not (w.is_cuda and w.dtype == torch.float32 and dense and w.data_ptr() % 16 == 0):
-                continue                # (tensor-wise quantization does not care about the order of a dense tensor's elements)
-            if "_qs_batcher_base" not in type(layer).__dict__ or _hooked(q) or layer._forward_pre_hooks:
-                continue                # re-wrapped since (a further imitation); hooks that want to see the quantizer's calls;
-                                        # a pre-hook on the layer (code that runs between this precomputation and the read)
-            if not q.initted:
-                continue                # first read ever: the inline path creates the layer's state when (and if) it happens
-            if not (q.weight.is_cuda and q._n_updates.is_cuda):
-                continue
-            if w.is_inference() or q.weight.is_inference():
-                continue                # created under torch.inference_mode(): no version counter to see a write with
-            t = q._steps.read(q._n_updates)
-            if t < q.timeout:
-                continue                # identity phase: the inline path only counts
-            if q.training:
-                if t == q.timeout and get_option("log_during_train"):
-                    logging.warn(f"quantizing {q.name} with {q.bits} bits")
-                train.append(layer)
-            elif q._quantized:
-                frozen.append(layer)
+        train, frozen = [], []          # tensors that update statistics this step / that only quantize
+        skip_layer = None
+        for u in self.units:
+            layer = u.layer
+            if layer is skip_layer:
+                continue                # the weight does not take part this step: neither does its bias (shared count)
+            q, w = u.q, u.param
+            geo = _geometry(w, q.channelwise)
+            ok = (w.is_cuda and w.dtype == torch.float32 and geo is not None and w.data_ptr() % 4 == 0
+                  and (u.channels == 1 or geo[1] == u.channels))
+            # re-wrapped since (a further imitation); hooks that want to see the quantizer's calls; a pre-hook on the layer (code
+            # that runs between this precomputation and the read); first read ever (the inline path creates the layer's state
+            # when -- and if -- it happens); state on another device; tensors created under torch.inference_mode() (no
+            # version counter to see a write with)
+            ok = ok and "_qs_batcher_base" in type(layer).__dict__ and not _hooked(q) and not layer._forward_pre_hooks
+            ok = ok and q.initted and q.weight.is_cuda and q._n_updates.is_cuda and q.weight.numel() == u.channels
+            ok = ok and q.weight.is_contiguous() and not (w.is_inference() or q.weight.is_inference())
+            t = q._steps.read(q._n_updates) if ok else 0
+            took_part = False
+            if ok and t >= q.timeout:     # (below the timeout: identity phase, the inline path only counts)
+                if q.training:
+                    if t == q.timeout and get_option("log_during_train"):
+                        logging.warn(f"quantizing {q.name} with {q.bits} bits")
+                    train.append(u)
+                    took_part = True
+                elif q._quantized:
+                    frozen.append(u)
+                    took_part = True
+            if not took_part and u.attr == "weight":
+                skip_layer = layer
         if not train and not frozen:
             return
         todo = train + frozen
-        dev = todo[0]._parameters["weight"].device
-        if any(l._parameters["weight"].device != dev for l in todo):
+        weights = [u.param for u in todo]
+        dev = weights[0].device
+        if any(w.device != dev for w in weights):
             return
-        n_all = len(self.layers)
-        if self._amax is None or self._amax.device != dev or self._amax.shape[0] != n_all:
-            self._amax = torch.zeros(n_all, _hip.AMAX_LINE_STRIDE, dtype=torch.float32, device=dev)   # one line per layer
-            self._decimals = torch.zeros(n_all, dtype=torch.float32, device=dev)
-            self._backup = torch.zeros(n_all, dtype=torch.float32, device=dev)
-        slot = {id(l): i for i, l in enumerate(self.layers)}
-        weights = [l._parameters["weight"] for l in todo]
+        if self._amax is None or self._amax.device != dev:
+            self._amax = torch.zeros(self._channels, dtype=torch.float32, device=dev)
+            self._decimals = torch.zeros(self._channels, dtype=torch.float32, device=dev)
+            self._backup = torch.zeros(self._channels, dtype=torch.float32, device=dev)
+        sats = [u.q.callback.code_range(u.q.bits) for u in todo]
         # evaluation / serving: nothing changes between calls unless someone writes a parameter or a scale (both bump
         # `_version`), so the quantized weights of the previous call are handed out again without a launch
         eval_key = None
@@ -337,107 +453,103 @@ class WeightBatcher:
         # frozen statistics, manual SGD or EMA through `p.data.add_()` -- may write parameters by the one route the version
         # counter does not see, and would be handed stale weights silently; such loops pay the launch per forward)
         if not train and not torch.is_grad_enabled():
-            eval_key = tuple((id(l), w.data_ptr(), w._version, l.quantize.weight.data_ptr(), l.quantize.weight._version,
-                              tuple(w.stride()), l.quantize.callback.code_range(l.quantize.bits)) for l, w in zip(todo, weights))
+            eval_key = tuple((id(u.layer), u.attr, w.data_ptr(), w._version, u.q.weight.data_ptr(), u.q.weight._version,
+                              tuple(w.stride()), sat) for u, w, sat in zip(todo, weights, sats))
             if eval_key == self._eval_key:
-                self._hand_out(todo, weights, self._eval_outs, slot, {}, self._eval_decimals)
+                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals)
                 return
         self._eval_key = None
         undo = {}
         with torch.no_grad():
-            # everything that does not change from step to step -- the pointer arrays of the three launches, the layout of
-            # the flat output buffer -- is built once per (set of layers, parameter storage) and reused
-            sats = [l.quantize.callback.code_range(l.quantize.bits) for l in todo]
-            key = (len(train), get_option("graph_safe"), tuple(sats)) + tuple((id(l), w.data_ptr(), w.numel(), l.quantize.weight.data_ptr(),
-                                                                   l.quantize._n_updates.data_ptr()) for l, w in zip(todo, weights))
+            t_devs = [u.q.callback.device_t(dev) if i < len(train) else None for i, u in enumerate(todo)]
+            # everything that does not change from step to step -- the launch table, the layout of the flat output buffer --
+            # is built once per (set of tensors, parameter storage, state storage) and reused
+            key = (len(train), tuple(sats)) + tuple(
+                (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), u.q.weight.data_ptr(), u.q._n_updates.data_ptr(),
+                 None if td is None else td.data_ptr()) for u, w, td in zip(todo, weights, t_devs))
             plan = self._plan if self._plan is not None and self._plan.get("key") == key else None
             if plan is None:
-                offsets, total = [], 0
-                for w in weights:
-                    offsets.append(total)
-                    total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-                plan = _LaunchPlan(key=key, offsets=offsets, total=total, numels=[w.numel() for w in weights], keep=[])
-                if train:
-                    amax = [self._amax[slot[id(l)]] for l in train]
-                    decs = [self._decimals[slot[id(l)]:slot[id(l)] + 1] if not l.quantize.callback.use_float_scaler else None
-                            for l in train]
-                    backups = [self._backup[slot[id(l)]:slot[id(l)] + 1] for l in train]
-                    plan["keep"] += amax + decs + backups
-                    plan.update(w_ptrs=_hip.ptr_array(weights[:len(train)]), w_numels=_hip.i64_array(plan["numels"][:len(train)]),
-                                amax_ptrs=_hip.ptr_array(amax), scale_ptrs=_hip.ptr_array([l.quantize.weight.data for l in train]),
-                                dec_ptrs=_hip.ptr_array(decs), backup_ptrs=_hip.ptr_array(backups),
-                                bits=(_hip.c_int * len(train))(*[l.quantize.bits for l in train]),
-                                bump_ptrs=_hip.ptr_array([l.quantize._n_updates.data for l in train]),
-                                w_bytes=4 * sum(plan["numels"][:len(train)]))
-                groups = []
-                for decimal in (False, True):
-                    idx = [i for i, l in enumerate(todo) if (not l.quantize.callback.use_float_scaler) == decimal]
-                    if idx:
-                        params = [self._decimals[slot[id(todo[i])]:slot[id(todo[i])] + 1] if decimal else todo[i].quantize.weight.data
-                                  for i in idx]
-                        plan["keep"] += params
-                        # opt-in saturation per layer: (lo, hi) with lo <= hi, or the empty range (1, 0) for "none"
-                        los = _hip.i32_array([1 if sats[i] is None else sats[i][0] for i in idx]) if any(sats[i] for i in idx) else None
-                        his = _hip.i32_array([0 if sats[i] is None else sats[i][1] for i in idx]) if los is not None else None
-                        groups.append((decimal, idx, _hip.ptr_array([weights[i] for i in idx]), _hip.ptr_array(params),
-                                       _hip.i64_array([plan["numels"][i] for i in idx]), 8 * sum(plan["numels"][i] for i in idx),
-                                       los, his))
-                plan["groups"] = groups
-                self._plan = plan
+                plan = self._plan = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev)
+            table = plan["table"]
             if train:
-                graph_safe = get_option("graph_safe")
-                t_devs = [l.quantize.callback.device_t(dev) if graph_safe else None for l in train]
-                _hip.multi_absmax(len(train), plan["w_ptrs"], plan["w_numels"], plan["amax_ptrs"], dev, nbytes=plan["w_bytes"])
-                _hip.multi_scale_update(len(train), plan["amax_ptrs"], plan["scale_ptrs"], plan["dec_ptrs"],
-                                        _hip.i64_array([l.quantize.callback.t for l in train]),
-                                        _hip.ptr_array(t_devs) if graph_safe else None, plan["bits"], plan["bump_ptrs"], dev,
-                                        backup_ptrs=plan["backup_ptrs"])
-                for l, t_dev in zip(train, t_devs):
-                    q, qc = l.quantize, l.quantize.callback
-                    undo[id(l)] = _Pending(l, slot[id(l)], q._quantized, t_dev, l._parameters["weight"]._version, True)
+                _hip.multi_absmax(table, nbytes=plan["train_bytes"])
+                _hip.multi_scale_update(table)
+                for u, t_dev in zip(train, t_devs):
+                    q, qc = u.q, u.q.callback
+                    undo[(id(u.layer), u.attr)] = _Pending(u, q._quantized, t_dev, u.param._version, True)
                     qc._advance_t(t_dev, bumped_by_kernel=True)
                     q._quantized = True
                     q._steps.note_device_add(q._n_updates, 1)
-            if frozen:       # evaluation: the decimals of the frozen scales (the inline path recomputes them per call as well)
-                for l in frozen:
-                    qc = l.quantize.callback
-                    if not qc.use_float_scaler:
-                        self._decimals[slot[id(l)]:slot[id(l)] + 1] = _hip.decimal_from_scale(l.quantize.weight.data.view(-1))
+            for u in frozen:       # evaluation: the decimals of the frozen scales (the inline path recomputes them per call as well)
+                if not u.q.callback.use_float_scaler:
+                    self._decimals[u.slot:u.slot + u.channels] = _hip.decimal_from_scale(u.q.weight.data.view(-1))
             flat = torch.empty(plan["total"], dtype=torch.float32, device=dev)
-            base = flat.data_ptr()
             so = flat.storage_offset()
             outs = [flat.as_strided(w.shape, w.stride(), so + o) for o, w in zip(plan["offsets"], weights)]   # w's own layout
-            for decimal, idx, x_ptrs, param_ptrs, numels, nbytes, los, his in plan["groups"]:
-                y_ptrs = (_hip.ctypes.c_void_p * len(idx))(*[base + 4 * plan["offsets"][i] for i in idx])
-                _hip.multi_quant_fwd(len(idx), x_ptrs, y_ptrs, param_ptrs, numels, decimal, dev, nbytes=nbytes, code_lo=los,
-                                     code_hi=his)
+            for i, (u, w) in enumerate(zip(todo, weights)):
+                # the reference broadcasts the input against the parameter (`input / scaler`): a tensor-wise (1, 1) scale turns a
+                # 1-d bias into a (1, C) tensor (quantize.py `_reference_shape`; nn.Linear takes it, nn.Conv2d rejects it)
+                if u.q.weight.numel() == 1 and u.q.weight.dim() > w.dim():
+                    outs[i] = outs[i].view(torch.broadcast_shapes(tuple(w.shape), tuple(u.q.weight.shape)))
+            _hip.multi_quant_fwd(table, flat, advance=bool(train), nbytes=plan["all_bytes"])
             # a DecimalQuantizer's backward clamps with the decimal of ITS forward (the reference computes a fresh tensor per
             # call, quantize.py:312-325, and the Function saves that one, :41): the hand-out nodes get this step's values, not
             # the buffer the next precomputation overwrites (a ScalerQuantizer's saves the scale parameter itself, :108)
-            decimals = self._decimals.clone() if any(g[0] for g in plan["groups"]) else self._decimals
+            decimals = self._decimals.clone() if plan["any_decimal"] else self._decimals
         if eval_key is not None:
             self._eval_key, self._eval_outs, self._eval_decimals = eval_key, outs, decimals
-        self._hand_out(todo, weights, outs, slot, undo, decimals)
+        self._hand_out(todo, weights, outs, undo, decimals)
 
-    def _hand_out(self, todo, weights, outs, slot, undo, decimals):
-        """park every layer's quantized weight on the layer, `_GROUP` consecutive layers per autograd node (a node per layer
-        in evaluation mode under no_grad costs nothing either way)"""
+    def _build_plan(self, key, todo, weights, t_devs, sats, n_train, dev) -> _LaunchPlan:
+        offsets, total = [], 0
+        for w in weights:
+            offsets.append(total)
+            total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        rows, keep = [], []
+        trains_weight = {id(u.layer) for u in todo[:n_train] if u.attr == "weight"}
+        for i, (u, w, sat) in enumerate(zip(todo, weights, sats)):
+            q, qc = u.q, u.q.callback
+            outer, C, inner = _geometry(w, q.channelwise)
+            sl = slice(u.slot, u.slot + u.channels)
+            is_decimal = not qc.use_float_scaler
+            amax, dec, backup = self._amax[sl], self._decimals[sl], self._backup[sl]
+            keep += [amax, dec, backup, t_devs[i], q.weight, q._n_updates, w]
+            r = _hip.MultiRow()
+            r.x, r.scale = w.data_ptr(), q.weight.data_ptr()
+            r.amax, r.backup = amax.data_ptr(), backup.data_ptr()
+            r.decimal = dec.data_ptr() if is_decimal else None
+            r.t_dev = t_devs[i].data_ptr() if t_devs[i] is not None else None
+            r.bump = q._n_updates.data_ptr()
+            r.numel, r.y_off, r.outer, r.inner, r.C = w.numel(), offsets[i], outer, inner, C
+            r.train, r.is_decimal = int(i < n_train), int(is_decimal)
+            # the bias quantizer shares its weight quantizer's callback: when both update this step the bias sees t + 1
+            r.t_offset = int(u.attr == "bias" and i < n_train and id(u.layer) in trains_weight)
+            r.code_lo, r.code_hi = (1, 0) if sat is None else (int(sat[0]), int(sat[1]))
+            r.denom = float(2 ** (q.bits - 1))
+            rows.append(r)
+        return _LaunchPlan(key=key, offsets=offsets, total=total, keep=keep, table=_hip.MultiTable(rows, dev),
+                           train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
+                           any_decimal=any(not u.q.callback.use_float_scaler for u in todo))
+
+    def _hand_out(self, todo, weights, outs, undo, decimals):
+        """park every quantized tensor on its layer, `_GROUP` consecutive tensors per autograd node (a node per layer in
+        evaluation mode under no_grad costs nothing either way)"""
         for base in range(0, len(todo), _GROUP):
             group = todo[base:base + _GROUP]
             meta, steps = [], []
-            for l in group:
-                q, qc = l.quantize, l.quantize.callback
+            for u in group:
+                q, qc = u.q, u.q.callback
                 is_decimal = not qc.use_float_scaler
                 limit = 2.0 ** (q.bits - 1)
                 notch = 1 if qc.flip_axis else 0
-                meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough)))
-                steps.append(decimals[slot[id(l)]:slot[id(l)] + 1].view(1, 1) if is_decimal else q.weight.data)
+                meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise))
+                steps.append(decimals[u.slot:u.slot + u.channels].view(-1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)
             ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
-            for i, (l, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):
-                pending = undo.get(id(l))
+            for i, (u, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):
+                pending = undo.get((id(u.layer), u.attr))
                 if pending is None:
-                    pending = _Pending(l, slot[id(l)], l.quantize._quantized, None, w._version, False)
+                    pending = _Pending(u, u.q._quantized, None, w._version, False)
                 pending.dead, pending.index = dead, i
                 self._pending.append(pending)
-                l.__dict__[_READY] = (y, pending, self)
+                u.layer.__dict__[_READY[u.attr]] = (y, pending, self)

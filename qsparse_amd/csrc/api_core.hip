@@ -6,7 +6,42 @@
 #include "qs_reduce.h"
 #include "qs_multi.h"
 
+#include <mutex>
+
+// ---- interned activation descriptors (qs_activation) ----------------------------------------------------------------
+namespace {
+std::mutex g_act_mutex;
+ActSpec g_act_table[256] = {{QS_ACT_NONE, 0.f, 0.f}, {QS_ACT_RELU, 0.f, 0.f}};
+int g_act_count = 2;
+}  // namespace
+
+int qs_act_resolve(int pre_relu, ActSpec* out) {
+    if (pre_relu < 0) return QS_ERR_ARG;
+    if (pre_relu < 2) {          // the two built-in descriptors need no lock
+        *out = g_act_table[pre_relu];
+        return QS_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_act_mutex);
+    if (pre_relu >= g_act_count) return QS_ERR_ARG;
+    *out = g_act_table[pre_relu];
+    return QS_OK;
+}
+
 extern "C" {
+
+int qs_activation(int kind, float a, float b) {
+    if (kind == QS_ACT_NONE) return 0;
+    if (kind == QS_ACT_RELU) return 1;
+    if (kind != QS_ACT_HARDTANH && kind != QS_ACT_LEAKY) return QS_ERR_ARG;
+    if (kind == QS_ACT_HARDTANH && !(a <= b)) return QS_ERR_ARG;
+    if (kind == QS_ACT_LEAKY) b = 0.f;
+    std::lock_guard<std::mutex> lock(g_act_mutex);
+    for (int i = 2; i < g_act_count; ++i)
+        if (g_act_table[i].kind == kind && g_act_table[i].a == a && g_act_table[i].b == b) return i;
+    if (g_act_count >= 256) return QS_ERR_ARG;
+    g_act_table[g_act_count] = ActSpec{kind, a, b};
+    return g_act_count++;
+}
 
 int qs_version(void) { return QS_ABI_VERSION; }
 
@@ -74,7 +109,6 @@ static int pq_args(PqArgs* a, float* magnitude, int64_t C, int update_magnitude,
         return QS_ERR_ARG;
     a->gathered = gathered;
     a->world = gathered ? world : 1;
-    a->coherent = 0;
     a->magnitude = magnitude;
     a->C = C;
     a->update_magnitude = update_magnitude;
@@ -152,79 +186,42 @@ static int site_plan_ok(const qs_site_plan* p) {
     return p && p->N >= 1 && p->C >= 2 && p->H >= 1 && p->W >= 1 && (p->layout == 0 || p->layout == 1);
 }
 
-// first statistics stage of a live site step: mean over the batch per (c, h, w) + per-channel / per-element abs-max
-static int site_stage1(const qs_site_plan* p, const void* x, int pre_relu, qs_stream_t stream) {
-    if (!p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
-    const int64_t hw = p->H * p->W;
-    const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_RELU : 0);
-    if (p->layout == 0)
-        return qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride, hw,
-                           p->C, stream);
-    if (!p->amax_part) return QS_ERR_ARG;
-    return qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, p->amax_part, stream);
-}
-
 // the statistics launches of a live site step; `record` (nullable): the rank's exchange record, written by the last of them
 static int site_statistics(const qs_site_plan* p, const void* x, int pre_relu, float* record, qs_stream_t stream) {
-    int st = site_stage1(p, x, pre_relu, stream);
-    if (st) return st;
-    if (p->layout == 0)   // (the accumulator is complete when this launch starts: with `record` it is read for the record's second half)
+    if (!p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
+    const int64_t hw = p->H * p->W;
+    const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_ACT(pre_relu) : 0);
+    if (p->layout == 0) {
+        int st = qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride,
+                             hw, p->C, stream);
+        if (st) return st;
+        // (the accumulator is complete when this launch starts: with `record` it is read for the record's second half)
         return qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, nullptr, record ? p->chan_absmax : nullptr,
                              record ? p->absmax_stride : 1, record, stream);
+    }
+    if (!p->amax_part) return QS_ERR_ARG;
+    int st = qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, p->amax_part, stream);
+    if (st) return st;
     return qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, p->amax_part, p->chan_absmax, p->absmax_stride,
                          record, stream);
 }
 
-// qs_mean_last2 + qs_pq_select of a live site step as one launch (mean_last2_select_kernel); QS_SITE_FUSE_SELECT=0: off
-static bool site_fused_select_ok(const qs_site_plan* p) {
-    static const int on = env_int("QS_SITE_FUSE_SELECT", 1);
-    const size_t tile = (size_t)(p->H * p->W + p->W + 8) * sizeof(float);
-    return on && p->record && p->ticket && tile <= kLast2MaxLds && p->C <= 65536;
-}
-static int site_last2_select(const qs_site_plan* p, int flags, int64_t t_mag, int64_t k, int64_t t_q, qs_stream_t stream) {
-    PqArgs a;
-    int st = pq_args(&a, p->magnitude, p->C, 1, t_mag, (flags & QS_SITE_REFRESH) ? 1 : 0, k, p->mask, p->chan_absmax,
-                     p->absmax_stride, 1, t_q, p->bits, p->scale, p->prune_n_updates, p->quant_n_updates, p->callback_t,
-                     p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr, p->quantizer_t_dev, nullptr, 1);
-    if (st) return st;
-    if (!dt_ok(p->xdt)) return QS_ERR_DTYPE;
-    a.stat_dt = p->xdt;
-    a.coherent = 0;
-    static const int max_blocks_fused = env_int("QS_SITE_FUSE_BLOCKS", 256);   // one ticket each: same-address atomics serialise
-    const int blocks = (int)std::min<int64_t>(p->C, max_blocks_fused);
-    const size_t tile = (size_t)(p->H * p->W + p->W + 8) * sizeof(float);
-    const size_t lds = std::max(tile, sizeof(SelectShared) + 16 * sizeof(uint32_t) + 64);
-    return with_dtype(p->xdt, [&](auto X) {
-        constexpr int XD = decltype(X)::value;
-        hipLaunchKernelGGL((mean_last2_select_kernel<XD>), dim3(blocks), dim3(kBlock), lds, (hipStream_t)stream, p->stage,
-                           p->stage_mean, (int)p->C, (int)p->H, (int)p->W, p->layout == 1 ? (const uint32_t*)p->amax_part : nullptr,
-                           (const uint32_t*)p->chan_absmax, p->absmax_stride, p->record, p->ticket, a);
-        return launch_status();
-    });
-}
-
 int qs_site_stats(const qs_site_plan* p, const void* x, int flags, float* record, qs_stream_t stream) {
     if (!site_plan_ok(p) || !x || !record) return QS_ERR_ARG;
-    return site_statistics(p, x, (flags & QS_SITE_PRE_RELU) ? 1 : 0, record, stream);
+    return site_statistics(p, x, (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0, record, stream);
 }
 
 int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, qs_stream_t stream) {
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, qs_stream_t stream) {
     if (!site_plan_ok(p) || !x || !y) return QS_ERR_ARG;
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
-    const int pre_relu = (flags & QS_SITE_PRE_RELU) ? 1 : 0;
+    const int pre_relu = (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0;     // the folded activation's handle
     if (flags & QS_SITE_LIVE) {
         if (!p->magnitude || !p->chan_absmax || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
         if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
         if ((flags & QS_SITE_STATS_DONE) ? (!gathered || world < 1) : (gathered != nullptr)) return QS_ERR_ARG;
         int st;
-        if (!(flags & QS_SITE_STATS_DONE) && site_fused_select_ok(p)) {
-            st = site_stage1(p, x, pre_relu, stream);
-            if (st) return st;
-            st = site_last2_select(p, flags, t_mag, k, t_q, stream);
-            if (st) return st;
-        } else {
         if (!(flags & QS_SITE_STATS_DONE)) {
             st = site_statistics(p, x, pre_relu, nullptr, stream);
             if (st) return st;
@@ -234,13 +231,12 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
                           p->callback_t, p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr,
                           p->quantizer_t_dev, p->xdt, gathered, gathered ? world : 1, stream);
         if (st) return st;
-        }
     }
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, cm ? outer : 1, cm ? p->C : 1, cm ? inner : outer * p->C * inner,
                                p->xdt, p->ydt, QS_F32, p->saturate, p->code_lo, p->code_hi, pre_relu,
-                               (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out, imgdt, stream);
+                               (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out, imgdt, xback_out, stream);
 }
 
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
@@ -253,13 +249,13 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
     if (gate)
         return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt,
-                                     g2 ? 0 : elide, g2, g2dt, stream);
+                                     g2 ? 0 : elide, p->act > 0 ? p->act : 1, g2, g2dt, stream);
     return qs_quant_ste_bwd(g, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
 }
 
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     int saturate, int32_t code_lo, int32_t code_hi, qs_stream_t stream) {
+                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, qs_stream_t stream) {
     if (!x || (!y && update != QS_QSTEP_ABSMAX) || !scale || numel < 0 || update < 0 || update > QS_QSTEP_FINISH) return QS_ERR_ARG;
     if (numel == 0) return QS_OK;
     if (update != QS_QSTEP_APPLY) {
@@ -272,94 +268,83 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
         if (st) return st;
     }
     return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, saturate, code_lo, code_hi,
-                               pre_relu, 0, gate_out, nullptr, 0, stream);
+                               pre_relu, 0, gate_out, nullptr, 0, xback_out, stream);
 }
 
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
-int qs_multi_absmax(int n, const float* const* x, const int64_t* numel, float* const* amax, qs_stream_t stream) {
-    if (n < 0 || (n > 0 && (!x || !numel || !amax))) return QS_ERR_ARG;
-    for (int base = 0; base < n; base += kMultiMax) {
-        MultiTensors a{};
-        MultiUpdate u{};
-        a.n = u.n = std::min(kMultiMax, n - base);
-        int blocks = 0;
-        for (int i = 0; i < a.n; ++i) {
-            const int k = base + i;
-            if (!x[k] || !amax[k] || numel[k] < 0) return QS_ERR_ARG;
-            if (!aligned16(x[k])) return QS_ERR_ALIGN;
-            a.x[i] = x[k];
-            a.numel[i] = numel[k];
-            u.amax[i] = (uint32_t*)amax[k];
-            a.block0[i] = blocks;
-            const int64_t want = (numel[k] / 8 + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);   // ~4 groups per lane
-            blocks += (int)std::min<int64_t>(std::max<int64_t>(want, 1), 64);
+int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_blocks, int* channels) {
+    if (n < 0 || (n > 0 && !rows) || !absmax_blocks || !quant_blocks || !channels) return QS_ERR_ARG;
+    int64_t ab = 0, qb = 0, ch = 0;
+    for (int i = 0; i < n; ++i) {
+        qs_multi_row& r = rows[i];
+        if (!r.x || !r.scale || r.numel < 0 || r.C < 1 || r.outer < 1 || r.inner < 1) return QS_ERR_ARG;
+        if (r.outer * r.C * r.inner != r.numel && r.numel != 0) return QS_ERR_ARG;
+        if (r.C > 1 && (r.inner >= ((int64_t)1 << 31) || r.outer >= ((int64_t)1 << 31))) return QS_ERR_ARG;
+        if (r.train && (!r.amax || !r.t_dev || !(r.denom > 0.f))) return QS_ERR_ARG;
+        if (r.is_decimal && !r.decimal) return QS_ERR_ARG;
+        if ((((uintptr_t)r.x) & 3u) != 0) return QS_ERR_ALIGN;
+        r.absmax_block0 = (int32_t)ab;
+        r.row_splits = 1;
+        r.absmax_blocks = 0;
+        if (r.train && r.numel > 0) {
+            if (r.C == 1) {
+                const int64_t want = (r.numel / 8 + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);   // ~4 groups per lane
+                r.absmax_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(want, 1), 64);
+            } else {
+                const int64_t cols = (int64_t)r.C * r.inner;
+                const int cpb = r.outer > 1 ? kMultiTallCols : kMultiFlatCols;
+                const int64_t col_blocks = (cols + cpb - 1) / cpb;
+                // tall and narrow matrices (a 1x1 convolution's [Cout, Cin]): interleaved row sets on more workgroups
+                int splits = 1;
+                while (splits < 16 && r.outer / (splits * 2 * (kBlock / 64)) >= 64 && col_blocks * splits * 2 <= 512) splits *= 2;
+                r.row_splits = splits;
+                r.absmax_blocks = (int32_t)std::min<int64_t>(col_blocks * splits, 0x3fffffff);
+            }
         }
-        a.block0[a.n] = blocks;
-        hipLaunchKernelGGL(multi_absmax_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, a, u);
+        ab += r.absmax_blocks;
+        r.quant_block0 = (int32_t)qb;
+        qb += std::max<int64_t>((r.numel + 8 * kBlock - 1) / (8 * kBlock), 1);      // 8 elements per lane
+        r.chan0 = (int32_t)ch;
+        ch += r.C;
+        if (ab > 0x7fffffff || qb > 0x7fffffff || ch > 0x7fffffff) return QS_ERR_ARG;
     }
+    *absmax_blocks = (int)ab;
+    *quant_blocks = (int)qb;
+    *channels = (int)ch;
+    return QS_OK;
+}
+
+int qs_multi_absmax(const qs_multi_row* rows_dev, int n, int absmax_blocks, qs_stream_t stream) {
+    if (n < 0 || absmax_blocks < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
+    if (n == 0 || absmax_blocks == 0) return QS_OK;
+    hipLaunchKernelGGL(multi_absmax_kernel, dim3(absmax_blocks), dim3(kBlock), 0, (hipStream_t)stream, rows_dev, n);
     return launch_status();
 }
 
-int qs_multi_scale_update(int n, float* const* amax, float* const* scale, float* const* decimal, const int64_t* t,
-                          int64_t* const* t_dev, const int* bits, int32_t* const* bump, float* const* backup,
-                          qs_stream_t stream) {
-    if (n < 0 || (n > 0 && (!amax || !scale || !t || !bits))) return QS_ERR_ARG;
-    for (int base = 0; base < n; base += kMultiMax) {
-        MultiUpdate u{};
-        u.n = std::min(kMultiMax, n - base);
-        for (int i = 0; i < u.n; ++i) {
-            const int k = base + i;
-            if (!amax[k] || !scale[k] || t[k] < 0 || bits[k] < 1 || bits[k] > 31) return QS_ERR_ARG;
-            u.amax[i] = (uint32_t*)amax[k];
-            u.scale[i] = scale[k];
-            u.decimal[i] = decimal ? decimal[k] : nullptr;
-            u.t_dev[i] = t_dev ? t_dev[k] : nullptr;
-            u.bump[i] = bump ? bump[k] : nullptr;
-            u.backup[i] = backup ? backup[k] : nullptr;
-            u.t[i] = (float)t[k];
-            u.denom[i] = (float)((int64_t)1 << (bits[k] - 1));
-        }
-        hipLaunchKernelGGL(multi_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
-    }
+int qs_multi_scale_update(const qs_multi_row* rows_dev, int n, int channels, qs_stream_t stream) {
+    if (n < 0 || channels < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
+    if (n == 0 || channels == 0) return QS_OK;
+    hipLaunchKernelGGL(multi_scale_update_kernel, dim3((channels + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       rows_dev, n, channels);
     return launch_status();
 }
 
-int qs_multi_quant_fwd(int n, const float* const* x, float* const* y, float* const* param, const int64_t* numel,
-                       int decimal, const int32_t* code_lo, const int32_t* code_hi, qs_stream_t stream) {
-    if (n < 0 || (n > 0 && (!x || !y || !param || !numel)) || ((code_lo == nullptr) != (code_hi == nullptr))) return QS_ERR_ARG;
-    for (int base = 0; base < n; base += kMultiMax) {
-        MultiTensors a{};
-        a.n = std::min(kMultiMax, n - base);
-        int64_t blocks = 0;
-        for (int i = 0; i < a.n; ++i) {
-            const int k = base + i;
-            if (!x[k] || !y[k] || !param[k] || numel[k] < 0) return QS_ERR_ARG;
-            if (!aligned16(x[k]) || !aligned16(y[k])) return QS_ERR_ALIGN;
-            a.x[i] = x[k];
-            a.y[i] = y[k];
-            a.scale[i] = param[k];
-            a.numel[i] = numel[k];
-            a.lo[i] = code_lo ? code_lo[k] : 1;
-            a.hi[i] = code_lo ? code_hi[k] : 0;
-            a.block0[i] = (int32_t)blocks;
-            blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
-            if (blocks > 0x7fffffff) return QS_ERR_ARG;
-        }
-        a.block0[a.n] = (int32_t)blocks;
-        if (decimal)
-            hipLaunchKernelGGL((multi_quant_kernel<true>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL((multi_quant_kernel<false>), dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
-    }
+int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, float* ybase, int advance, qs_stream_t stream) {
+    if (n < 0 || quant_blocks < 0 || (n > 0 && (!rows_dev || !ybase))) return QS_ERR_ARG;
+    if (n == 0 || quant_blocks == 0) return QS_OK;
+    if (!aligned16(ybase)) return QS_ERR_ALIGN;
+    hipLaunchKernelGGL(multi_quant_kernel, dim3(quant_blocks), dim3(kBlock), 0, (hipStream_t)stream, rows_dev, n, ybase, advance);
     return launch_status();
 }
 
 int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
-                     const float* lo_mul, const float* hi_mul, int step_is_decimal, qs_stream_t stream) {
-    if (n < 0 || (n > 0 && (!g || !gx || !step || !numel || !lo_mul || !hi_mul))) return QS_ERR_ARG;
-    for (int base = 0; base < n; base += kMultiMax) {
+                     const int32_t* C, const int64_t* inner, const float* lo_mul, const float* hi_mul, int step_is_decimal,
+                     qs_stream_t stream) {
+    if (n < 0 || (n > 0 && (!g || !gx || !step || !numel || !lo_mul || !hi_mul)) || ((C == nullptr) != (inner == nullptr)))
+        return QS_ERR_ARG;
+    for (int base = 0; base < n; base += kMultiSteMax) {
         MultiSte a{};
-        a.n = std::min(kMultiMax, n - base);
+        a.n = std::min(kMultiSteMax, n - base);
         int64_t blocks = 0;
         for (int i = 0; i < a.n; ++i) {
             const int k = base + i;
@@ -369,10 +354,13 @@ int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* cons
             a.gx[i] = gx[k];
             a.step[i] = step[k];
             a.numel[i] = numel[k];
+            a.C[i] = C ? C[k] : 1;
+            if (a.C[i] < 1 || (a.C[i] > 1 && (inner[k] < 1 || inner[k] >= ((int64_t)1 << 31)))) return QS_ERR_ARG;
+            a.inner[i] = a.C[i] > 1 ? (int32_t)inner[k] : 1;
             a.lo_mul[i] = lo_mul[k];
             a.hi_mul[i] = hi_mul[k];
             a.block0[i] = (int32_t)blocks;
-            blocks += std::max<int64_t>((numel[k] / 8 + kBlock - 1) / kBlock, 1);
+            blocks += std::max<int64_t>((numel[k] + 8 * kBlock - 1) / (8 * kBlock), 1);
             if (blocks > 0x7fffffff) return QS_ERR_ARG;
         }
         a.block0[a.n] = (int32_t)blocks;

@@ -14,6 +14,11 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
     if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
     if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     if (absmax_out && (chan_div < 1 || C < 1 || absmax_stride < 1)) return QS_ERR_ARG;
+    // the folded activation: nn.ReLU, or the descriptor whose handle rides in the flags' upper bits (QS_MEAN_ACT)
+    ActSpec act;
+    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    const bool general_act = act.kind > QS_ACT_RELU;      // (takes the generic modes: every flag tested per element)
+    flags &= 0xff;
     const int64_t as = absmax_out ? absmax_stride : 1;
     hipStream_t s = (hipStream_t)stream;
     int64_t vcols = 0;
@@ -51,8 +56,8 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
                 const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
                 if (R == 1) {
-                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
-                                                    (flags == 0 && !am ? 3 : 0)));
+                    const int mode = (l0_flag || general_act) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                                                     (flags == 0 && !am ? 3 : 0)));
                     // few waves per CU: keep more rows in flight per wave instead (latency-, not bandwidth-bound)
                     // (2-byte inputs only: 32 fp32 rows of 8 columns do not fit the register file)
                     int depth = env_int("QS_MEAN_DEPTH", 0);
@@ -60,7 +65,7 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                     if (XD == QS_F32) depth = QS_MEAN_ROWS_IN_FLIGHT;
                     auto launch = [&](auto D, auto M) {
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, decltype(D)::value, decltype(M)::value>), dim3(blocks),
-                                           dim3(64), 0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes);
+                                           dim3(64), 0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes, act);
                     };
                     auto by_mode = [&](auto D) {
                         if (mode == 3) launch(D, IC<3>{});
@@ -78,12 +83,12 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 else {
                     const int64_t cd = chan_div > 0 ? chan_div : 1;
                     const bool rag = am && cd % 8 != 0;         // a lane's 8 columns may straddle two channels
-                    const int smode = (l0_flag || !am) ? 0 : (flags == QS_MEAN_ABS ? 1 :
+                    const int smode = (l0_flag || !am || general_act) ? 0 : (flags == QS_MEAN_ABS ? 1 :
                                       (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
                     auto launch = [&](auto RR, auto M, auto RG) {
                         constexpr int kR = decltype(RR)::value;
                         hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value, decltype(RG)::value>), dim3(blocks),
-                                           dim3(64 * kR), lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes);
+                                           dim3(64 * kR), lds, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, cd, Cc, lanes, act);
                     };
                     auto by_mode = [&](auto RR) {
                         if (smode == 1 && rag) launch(RR, IC<1>{}, std::true_type{});
@@ -101,7 +106,7 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                 const int64_t total = pre * (post - vcols);
                 hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
                                    0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1,
-                                   (uint32_t)(C > 0 ? C : 1));
+                                   (uint32_t)(C > 0 ? C : 1), act);
             }
             return launch_status();
         };
@@ -113,8 +118,12 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
                    const int32_t* l0_flag, float* amax_part, qs_stream_t stream) {
     if (!x || !out || n < 1 || hw < 1 || C < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
-    const int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
-                                                 (flags == 0 ? 3 : 0)));
+    ActSpec act;
+    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    flags &= 0xff;
+    int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
+                                           (flags == 0 ? 3 : 0)));
+    if (mode == 2 && act.kind > QS_ACT_RELU) mode = 4;     // |act(x)| of a folded activation other than nn.ReLU
     if (C % 8 != 0 || mode == 0 || (mode == 3 && amax_part) || !aligned16(x)) {
         // any channel count, the L0 variant, unaligned views: one lane per element of a sample, same summation order
         const int64_t total = hw * C;
@@ -124,10 +133,10 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
             const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
             if (odt == QS_F32)
                 hipLaunchKernelGGL((mean_cl_generic_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw,
-                                   C, flags, l0_flag, (uint32_t*)amax_part);
+                                   C, flags, l0_flag, (uint32_t*)amax_part, act);
             else
                 hipLaunchKernelGGL((mean_cl_generic_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw, C,
-                                   flags, l0_flag, (uint32_t*)amax_part);
+                                   flags, l0_flag, (uint32_t*)amax_part, act);
             return launch_status();
         });
     }
@@ -177,13 +186,13 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
                 constexpr int kM = decltype(M)::value;
                 if (!wg_main && main_groups > 0)
                     hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks1), dim3(64), 0, s, x, out, n, hw, C, am, lanes1,
-                                       main_groups);
+                                       main_groups, act);
                 if (wg_main || wg_tail) {
                     auto wg = [&](auto RR) {
                         constexpr int kR = decltype(RR)::value;
                         hipLaunchKernelGGL((mean_cl_wg_kernel<XD, OD, kR, kM>), dim3(wg_main_blocks + wg_tail_blocks), dim3(64 * kR),
                                            lds, s, x, out, n, hw, C, am, lanes, main_groups, wg_main_blocks, tail_groups,
-                                           (int)slots);
+                                           (int)slots, act);
                     };
                     if constexpr (XD != QS_F32) {
                         if (R == 16) wg(IC<16>{});
@@ -195,10 +204,11 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
                 }
                 if (!wg_tail && tail_groups > 0)
                     hipLaunchKernelGGL((mean_cl_tail_kernel<XD, OD, kM>), dim3(tail_blocks1), dim3(64), 0, s, x, out, n, hw, C,
-                                       am, main_groups, tail_groups);
+                                       am, main_groups, tail_groups, act);
             };
             if (mode == 1) launch(IC<1>{});
             else if (mode == 2) launch(IC<2>{});
+            else if (mode == 4) launch(IC<4>{});
             else launch(IC<3>{});
             return launch_status();
         };

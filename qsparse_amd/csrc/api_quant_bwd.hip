@@ -29,9 +29,11 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
 
 int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx, const float* step, int64_t nstep,
                           float step_host, int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask,
-                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, const void* g2, int g2dt,
-                          qs_stream_t stream) {
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, int act_handle, const void* g2,
+                          int g2dt, qs_stream_t stream) {
     if ((!g && !g2) || (!x && !gate) || !gx) return QS_ERR_ARG;
+    ActSpec act;
+    if (qs_act_resolve(act_handle > 0 ? act_handle : 1, &act) != QS_OK) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
     if (g2 && (!gate || gdt != QS_F32 || (g2dt != QS_BF16 && g2dt != QS_F16))) return QS_ERR_DTYPE;
     if ((g && !aligned16(g)) || (!gate && !aligned16(x)) || !aligned16(gx) || (g2 && !aligned16(g2))) return QS_ERR_ALIGN;
@@ -56,19 +58,19 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
             switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_SCALAR, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
                     break;
                 case CM_ROW:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ROW, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
                     break;
                 case CM_LAST:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_LAST, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
                     break;
                 default:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ELEM, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
                     break;
             }
             return launch_status();
@@ -86,27 +88,27 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
             switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx);
+                                       op, plan.geo, (int)ppc, g, second, gx, act);
                     break;
                 case CM_ROW:
                     if (el)
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx);
+                                           op, plan.geo, (int)ppc, g, second, gx, act);
                     else
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx);
+                                           op, plan.geo, (int)ppc, g, second, gx, act);
                     break;
                 case CM_LAST:
                     if (el)
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx);
+                                           op, plan.geo, (int)ppc, g, second, gx, act);
                     else
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx);
+                                           op, plan.geo, (int)ppc, g, second, gx, act);
                     break;
                 default:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx);
+                                       op, plan.geo, (int)ppc, g, second, gx, act);
                     break;
             }
             return launch_status();
@@ -120,6 +122,8 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
 int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const int64_t* sizes, const int64_t* mask_strides,
                   int dt, int pre_relu, int elide_masked, uint8_t* gate_out, qs_stream_t stream) {
     if (!x || !mask || !y || !sizes || !mask_strides || ndim < 1 || (gate_out && !pre_relu)) return QS_ERR_ARG;
+    ActSpec act;
+    if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
     if (!dt_ok(dt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y)) return QS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
@@ -164,11 +168,11 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
         EwPlan plan;
         int st = plan_ew(outer, C, inner, true, &plan, aligned8(mask));
         if (st) return st;
-        ChanMaskOp op{mask, pre_relu != 0};
+        ChanMaskOp op{mask, act, dt};
         return with_dtype(dt, [&](auto D) {
             constexpr int DD = decltype(D)::value;
             if (gate_out) {      // the folded ReLU's gate bitmap for the backward (GateOp, qs_elementwise.h)
-                GateOp<ChanMaskOp> gop{op, gate_out, elide_masked != 0, nullptr, QS_BF16};
+                GateOp<ChanMaskOp> gop{op, gate_out, elide_masked != 0, nullptr, QS_BF16, nullptr};
                 return launch_ew<GateOp<ChanMaskOp>, DD, DD>(gop, plan, true, x, y, nullptr, s);
             }
             return launch_ew<ChanMaskOp, DD, DD>(op, plan, true, x, y, nullptr, s, elide_masked != 0);

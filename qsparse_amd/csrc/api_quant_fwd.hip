@@ -6,13 +6,19 @@
 namespace {
 // the image of a quantizer's float32 output is written by the gate-recording widening kernels only (ew_widen_kernel<GateOp<..>>):
 // float32 output, no codes, a gate bitmap, and a geometry those kernels serve (launch_ew_impl's own conditions)
-bool image_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
-                    const uint8_t* gate_out, int xdt, int ydt, int imgdt, const void* image_out) {
-    if (!gate_out || codes || ydt != QS_F32 || (imgdt != QS_BF16 && imgdt != QS_F16) || !aligned16(image_out)) return false;
+// (the same kernels write relu(x) back: xback_out)
+bool widen_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
+                    const uint8_t* gate_out, int xdt, int ydt) {
+    if (!gate_out || codes || ydt != QS_F32) return false;
     EwPlan plan;
     if (plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask)) != QS_OK) return false;
     const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
     return ew_widen() >= (xdt == QS_F32 ? 2 : 1) && cm_w != CM_ELEM;
+}
+bool image_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
+                    const uint8_t* gate_out, int xdt, int ydt, int imgdt, const void* image_out) {
+    if ((imgdt != QS_BF16 && imgdt != QS_F16) || !aligned16(image_out)) return false;
+    return widen_route_ok(outer, C, inner, ppc, chan_mask, codes, gate_out, xdt, ydt);
 }
 }  // namespace
 
@@ -31,9 +37,14 @@ int qs_quant_image_ok(int64_t outer, int64_t C, int64_t inner, int per_channel_p
 int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* scale, int64_t nscale, float scale_host,
                         const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt, int ydt, int qdt,
                         int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked, uint8_t* gate_out,
-                        void* image_out, int imgdt, qs_stream_t stream) {
+                        void* image_out, int imgdt, void* xback_out, qs_stream_t stream) {
     if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
     if (image_out && !image_route_ok(outer, C, inner, nscale > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
+    ActSpec act;
+    if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
+    if (xback_out && (act.kind != QS_ACT_RELU || !aligned16(xback_out) ||
+                      !widen_route_ok(outer, C, inner, nscale > 1, chan_mask, codes, gate_out, xdt, ydt)))
+        return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -48,9 +59,9 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
-            ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
+            ScalerFwdOp<QD> op{scale, scale_host, chan_mask, saturate, code_lo, code_hi, act, xdt};
             if (gate_out) {
-                GateOp<ScalerFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt};
+                GateOp<ScalerFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt, xback_out};
                 return launch_ew<GateOp<ScalerFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
             }
             return launch_ew<ScalerFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);
@@ -63,9 +74,14 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
 int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* decimal, int64_t ndecimal,
                          float decimal_host, const uint8_t* chan_mask, int64_t outer, int64_t C, int64_t inner, int xdt,
                          int ydt, int qdt, int saturate, int32_t code_lo, int32_t code_hi, int pre_relu,
-                         int elide_masked, uint8_t* gate_out, void* image_out, int imgdt, qs_stream_t stream) {
+                         int elide_masked, uint8_t* gate_out, void* image_out, int imgdt, void* xback_out, qs_stream_t stream) {
     if (!x || !y || (gate_out && !pre_relu)) return QS_ERR_ARG;
     if (image_out && !image_route_ok(outer, C, inner, ndecimal > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
+    ActSpec act;
+    if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
+    if (xback_out && (act.kind != QS_ACT_RELU || !aligned16(xback_out) ||
+                      !widen_route_ok(outer, C, inner, ndecimal > 1, chan_mask, codes, gate_out, xdt, ydt)))
+        return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
     if (!(ydt == QS_F32 || ydt == xdt) || !(qdt == QS_F32 || qdt == xdt)) return QS_ERR_DTYPE;
     if (!aligned16(x) || !aligned16(y) || (codes && !aligned16(codes))) return QS_ERR_ALIGN;
@@ -80,9 +96,9 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
         constexpr int XD = decltype(X)::value;
         auto go = [&](auto Y, auto Q) {
             constexpr int YD = decltype(Y)::value, QD = decltype(Q)::value;
-            DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, pre_relu};
+            DecimalFwdOp<QD> op{decimal, decimal_host, chan_mask, saturate, code_lo, code_hi, act, xdt};
             if (gate_out) {
-                GateOp<DecimalFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt};
+                GateOp<DecimalFwdOp<QD>> gop{op, gate_out, elide_masked != 0 && chan_mask != nullptr, image_out, imgdt, xback_out};
                 return launch_ew<GateOp<DecimalFwdOp<QD>>, XD, YD>(gop, plan, ppc, x, y, codes, s);
             }
             return launch_ew<DecimalFwdOp<QD>, XD, YD>(op, plan, ppc, x, y, codes, s, elide_masked != 0);

@@ -8,7 +8,7 @@ extern "C" {
 
 // ------------------------------------------------------------------------------------------------
 static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, int per_channel, int64_t outer, int64_t C,
-                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false, int relu = 0, void* ws = nullptr,
+                       int64_t inner, int xdt, hipStream_t s, bool accumulate = false, ActSpec relu = ActSpec{0, 0.f, 0.f}, void* ws = nullptr,
                        size_t ws_bytes = 0, int lines = 1) {
     if (!x || !out_a || (minmax && !out_b)) return QS_ERR_ARG;
     if (!dt_ok(xdt)) return QS_ERR_DTYPE;
@@ -25,7 +25,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
     int64_t few_nblk = 0;
     if (per_channel && numel > 0 && vec_ptr && ws) {
         const int64_t cols = C * inner;
-        const bool rows_route = !minmax && inner % 8 == 0 && outer >= 16 && cols / 8 >= 64 * 1024;          // column walk
+        const bool rows_route = !minmax && inner % 8 == 0 && outer >= 16 && cols / 8 >= 64 * 1024 && relu.kind <= QS_ACT_RELU;   // column walk
         const bool long_rows = inner >= 64 && C < 65536 && !(inner < 512 && cols % 8 == 0);                     // reduce_rows
         if (!rows_route && !long_rows && cols % 8 == 0 && cols <= kFewColsMaxCols && cols / 8 <= kBlock) {
             const int64_t rows_per_iter = kBlock / (cols / 8);
@@ -54,7 +54,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                     if (grid > cap) grid = cap;
                     hipLaunchKernelGGL((reduce_all_kernel<XD, M, 512>), dim3(grid), dim3(512), 0, s, x, numel, omax, omin, relu,
                                        lines);
-                } else if (vec_ptr && inner % 8 == 0 && outer >= 16 && (C * inner) / 8 >= 64 * 1024) {
+                } else if (vec_ptr && inner % 8 == 0 && outer >= 16 && (C * inner) / 8 >= 64 * 1024 && relu.kind <= QS_ACT_RELU) {
                     // big tensors ([N, C, H*W] with >= 1024 waves of column groups): the column walk of the statistics
                     // kernel -- a lane keeps 8 adjacent columns and loops over N in registers, one atomic per wave and
                     // channel at the end -- streams at the statistics kernel's rate, where workgroups that hop from row
@@ -66,7 +66,7 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 6>), dim3(blocks), dim3(64), 0, s, x,
                                            (void*)omin, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
                                            inner, (uint32_t)C, lanes);
-                    else if (relu)
+                    else if (relu.kind)
                         hipLaunchKernelGGL((mean_outer_vec_kernel<XD, XD, QS_MEAN_ROWS_IN_FLIGHT, 5>), dim3(blocks), dim3(64), 0, s, x,
                                            (void*)nullptr, (int64_t)1, outer, post, post, 0, (const int32_t*)nullptr, omax, (int64_t)1,
                                            inner, (uint32_t)C, lanes);
@@ -125,14 +125,16 @@ static int reduce_impl(const void* x, float* out_a, float* out_b, bool minmax, i
 int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t C, int64_t inner, int xdt, int accumulate,
               int pre_relu, int out_lines, void* ws, size_t ws_bytes, qs_stream_t stream) {
     if (out_lines < 1 || out_lines > 64 || (out_lines > 1 && (per_channel || !accumulate))) return QS_ERR_ARG;
-    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0,
-                       pre_relu != 0, ws, ws_bytes, out_lines);
+    ActSpec act;
+    if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
+    return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0, act, ws,
+                       ws_bytes, out_lines);
 }
 
 int qs_minmax(const void* x, float* out_min, float* out_max, int per_channel, int64_t outer, int64_t C, int64_t inner,
               int xdt, int accumulate, void* ws, size_t ws_bytes, qs_stream_t stream) {
-    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0, 0,
-                       ws, ws_bytes);
+    return reduce_impl(x, out_min, out_max, true, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0,
+                       ActSpec{0, 0.f, 0.f}, ws, ws_bytes);
 }
 
 int qs_scale_update(float* absmax, int absmax_lines, float* weight, int64_t n, int64_t t, int64_t* t_dev, int advance_t_dev,

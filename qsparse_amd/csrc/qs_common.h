@@ -44,6 +44,46 @@ __device__ __forceinline__ float round_through(float v) {  // value after one ro
 // a diverged activation that the module-by-module path reports.
 __device__ __forceinline__ float relu_aten(float v) { return (v < 0.0f) ? 0.0f : v; }
 
+// ---- folded activations ----------------------------------------------------------------------------
+// convert() puts its operators behind whatever activation modules the user names (reference convert.py:214-218): nn.ReLU in
+// the BASELINE networks, nn.ReLU6 / nn.Hardtanh / nn.LeakyReLU in others.  A site's kernels absorb the activation -- its output
+// is never materialised -- when it is one of these: forward value, and the ONE bit per element its backward needs.
+//   QS_ACT_RELU      max(x, 0) as ATen's clamp_min;            backward  x <= 0 ? 0 : g            (threshold_backward)
+//   QS_ACT_HARDTANH  clamp(x, a, b) (nn.ReLU6: a = 0, b = 6);  backward  (x > a && x < b) ? g : 0   (hardtanh_backward)
+//   QS_ACT_LEAKY     x > 0 ? x : x * a, the product rounded to x's dtype;  backward  x > 0 ? g : g * a (leaky_relu_backward)
+struct ActSpec {
+    int kind;       // 0: none, else QS_ACT_*
+    float a, b;
+};
+__device__ __forceinline__ float round_to_dtype(float v, int dt) {   // value after one rounding to dtype `dt` (run-time)
+    if (dt == QS_F16) return round_through<QS_F16>(v);
+    if (dt == QS_BF16) return round_through<QS_BF16>(v);
+    return v;
+}
+// the activation's forward value; `dt`: dtype of the activation's input / output (ATen computes in float and casts back)
+__device__ __forceinline__ float act_apply(float v, const ActSpec& s, int dt) {
+    if (s.kind == QS_ACT_RELU) return relu_aten(v);
+    if (s.kind == QS_ACT_HARDTANH) {       // vec::clamp = minimum(b, maximum(a, x)): NaN passes, -0.0 survives a = +0.0
+        const float t = (v < s.a) ? s.a : v;
+        return (t > s.b) ? s.b : t;
+    }
+    if (s.kind == QS_ACT_LEAKY) return (v > 0.0f) ? v : round_to_dtype(v * s.a, dt);
+    return v;
+}
+// whether the activation's backward lets the gradient through unchanged at input v (the gate bit a forward records)
+__device__ __forceinline__ bool act_open(float v, const ActSpec& s) {
+    // (ATen's CPU hardtanh_backward treats a NaN input differently in its vector body -- (x > a) & (x < b): closed -- and in its
+    // scalar tail -- (x <= a || x >= b) ? 0 : g: open; the body's rule is the one followed here)
+    if (s.kind == QS_ACT_HARDTANH) return (v > s.a) && (v < s.b);
+    if (s.kind == QS_ACT_LEAKY) return v > 0.0f;
+    return !(v <= 0.0f);
+}
+// the gradient where the gate is closed: 0 for the rectifiers, g * slope (g in the gradient's dtype, the product rounded to
+// it) for the leaky one
+__device__ __forceinline__ float act_closed(float applied, const ActSpec& s, int dt) {
+    return (s.kind == QS_ACT_LEAKY) ? round_to_dtype(applied, dt) * s.a : 0.0f;
+}
+
 // ---- scalar element access ---------------------------------------------------------------------
 template <int DT>
 __device__ __forceinline__ float load1(const void* p, int64_t i) {

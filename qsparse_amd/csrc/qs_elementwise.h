@@ -74,7 +74,8 @@ struct ScalerFwdOp {
     const uint8_t* cmask;   // device, nullable: fused channel prune
     int saturate;
     int32_t lo, hi;
-    int pre_relu;           // folded preceding nn.ReLU: quantise max(x, 0)
+    ActSpec act;            // folded preceding activation (nn.ReLU: quantise max(x, 0)); act_dt: the dtype of its input
+    int act_dt;
     struct P {
         float s;
         float r;      // RN(1/s)
@@ -109,7 +110,7 @@ struct ScalerFwdOp {
         }
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
-        if (pre_relu) v = relu_aten(v);
+        if (act.kind) v = act_apply(v, act, act_dt);
         v = v * p.keep;                          // x * mask (exact; keeps the sign of zero)
         int32_t qi;                                   // round(x / s).int(): half-to-even (:109)
         if constexpr (QDT != QS_F32) qi = f32_to_i32_x86(quotient_rint(v, p));
@@ -129,7 +130,8 @@ struct DecimalFwdOp {
     const uint8_t* cmask;
     int saturate;
     int32_t lo, hi;
-    int pre_relu;
+    ActSpec act;
+    int act_dt;
     struct P {
         float toi, tof, keep;
     };
@@ -156,7 +158,7 @@ struct DecimalFwdOp {
         return p;
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
-        if (pre_relu) v = relu_aten(v);
+        if (act.kind) v = act_apply(v, act, act_dt);
         v = v * p.keep;
         float q = round_through<QDT>(v * p.toi);
         int32_t qi = f32_to_i32_x86(q);          // .int(): truncation toward zero (:55)
@@ -259,7 +261,8 @@ struct SteBwdOp {
 struct ChanMaskOp {
     static constexpr bool kHasMask = true;
     const uint8_t* cmask;
-    int relu;   // max(x, 0) * mask: a preceding nn.ReLU folded into the prune site
+    ActSpec act;   // act(x) * mask: a preceding activation folded into the prune site (nn.ReLU: max(x, 0) * mask)
+    int act_dt;
     struct P {
         float keep;
     };
@@ -276,7 +279,7 @@ struct ChanMaskOp {
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
         code = 0;
-        if (relu) v = relu_aten(v);   // ATen's CPU relu (clamp_min = max_ps(0, x)): -0.0 and NaN pass through
+        if (act.kind) v = act_apply(v, act, act_dt);   // (ATen's CPU relu, clamp_min = max_ps(0, x): -0.0 and NaN pass through)
         return v * p.keep;
     }
 };
@@ -297,6 +300,9 @@ struct GateOp : Base {
                         // a site gives the same bits with and without the bitmap (NaN / Inf on a pruned channel, quirk B15)
     void* image;        // nullable: the low-precision IMAGE of the float32 output -- RNE(y) in image_dt, the very cast autocast
     int image_dt;       // applies to y in front of a convolution -- written by the same pass (+2 B/elem instead of a 6 B/elem pass)
+    void* xback;        // nullable: relu(x) written back, in x's dtype, to wherever the caller says -- x's own storage for an
+                        // nn.ReLU(inplace=True) whose result other holders of x must see: the ReLU's forward pass costs one more
+                        // store in this kernel instead of a read + write pass of its own (widening kernels only)
     __device__ __forceinline__ float apply(float v, const typename Base::P& p, int32_t& code) const {
         if (zero_pruned && p.keep == 0.0f) v = 0.0f;
         return Base::apply(v, p, code);
@@ -315,12 +321,34 @@ __device__ __forceinline__ void image_store(void* img, int dt, int64_t e, const 
     if constexpr (N == 8) *(u32x4*)((uint16_t*)img + e) = u32x4{w[0], w[1], w[2], w[3]};
     else *(u32x2*)((uint16_t*)img + e) = u32x2{w[0], w[1]};
 }
+// relu(v[0..N)) (ATen's clamp_min: NaN and -0.0 pass) back in dtype DT at element e (a multiple of N): one store of N values
+template <int N, int DT>
+__device__ __forceinline__ void xback_store(void* xb, int64_t e, const float* v) {
+    if constexpr (DT == QS_F32) {
+        static_assert(N == 4, "fp32 inputs take the 4-elements-per-lane paths");
+        *(u32x4*)((float*)xb + e) = u32x4{__float_as_uint(relu_aten(v[0])), __float_as_uint(relu_aten(v[1])),
+                                          __float_as_uint(relu_aten(v[2])), __float_as_uint(relu_aten(v[3]))};
+    } else {
+        uint32_t w[N / 2];
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) {   // (the values are DT values already: the conversion is exact)
+            const float a = relu_aten(v[2 * j]), b = relu_aten(v[2 * j + 1]);
+            const uint32_t lo = (DT == QS_BF16) ? f32_to_bf16_bits(a) : f32_to_f16_bits(a);
+            const uint32_t hi = (DT == QS_BF16) ? f32_to_bf16_bits(b) : f32_to_f16_bits(b);
+            w[j] = lo | (hi << 16);
+        }
+        if constexpr (N == 8) *(u32x4*)((uint16_t*)xb + e) = u32x4{w[0], w[1], w[2], w[3]};
+        else *(u32x2*)((uint16_t*)xb + e) = u32x2{w[0], w[1]};
+    }
+}
 template <typename Op>
 struct OpGate {
     static constexpr bool value = false;
     __device__ __forceinline__ static uint8_t* ptr(const Op&) { return nullptr; }
     __device__ __forceinline__ static void* image(const Op&) { return nullptr; }
     __device__ __forceinline__ static int image_dt(const Op&) { return QS_BF16; }
+    __device__ __forceinline__ static void* xback(const Op&) { return nullptr; }
+    __device__ __forceinline__ static ActSpec act(const Op&) { return ActSpec{0, 0.f, 0.f}; }
 };
 template <typename Base>
 struct OpGate<GateOp<Base>> {
@@ -328,12 +356,19 @@ struct OpGate<GateOp<Base>> {
     __device__ __forceinline__ static uint8_t* ptr(const GateOp<Base>& op) { return op.gate; }
     __device__ __forceinline__ static void* image(const GateOp<Base>& op) { return op.image; }
     __device__ __forceinline__ static int image_dt(const GateOp<Base>& op) { return op.image_dt; }
+    __device__ __forceinline__ static void* xback(const GateOp<Base>& op) { return op.xback; }
+    __device__ __forceinline__ static ActSpec act(const GateOp<Base>& op) { return op.act; }
 };
 template <int N>
-__device__ __forceinline__ uint32_t gate_bits(const float* v) {
+__device__ __forceinline__ uint32_t gate_bits(const float* v, const ActSpec& act) {
     uint32_t b = 0u;
+    if (act.kind <= QS_ACT_RELU) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) b |= (v[j] <= 0.0f ? 0u : 1u) << j;
+        for (int j = 0; j < N; ++j) b |= (v[j] <= 0.0f ? 0u : 1u) << j;
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) b |= (act_open(v[j], act) ? 1u : 0u) << j;
+    }
     return b;
 }
 // the nibble of the neighbouring lane (lane ^ 1): quad_perm [1, 0, 3, 2]
@@ -477,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                     continue;
                 }
                 unpack8<XDT>(raw[u], v);
-                if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v);
+                if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v, OpGate<Op>::act(op));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], pp[u], q[j]);
                 store8<YDT, NT>(y, g, v);
@@ -499,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
             float v[8];
             int32_t q[8];
             if constexpr (!ELIDE) unpack8<XDT>(raw[u], v);
-            if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v);
+            if constexpr (GATE) OpGate<Op>::ptr(op)[g] = (uint8_t)gate_bits<8>(v, OpGate<Op>::act(op));
             if constexpr (CM == CM_SCALAR) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p_scalar, q[j]);
@@ -561,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
         typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
         int32_t qi;
         const float xe = load1<XDT>(x, e);
-        if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, !(xe <= 0.0f));
+        if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, act_open(xe, OpGate<Op>::act(op)));
         float r = op.apply(xe, p, qi);
         store1<YDT>(y, e, r);
         if (codes) codes[e] = qi;
@@ -612,7 +647,10 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
             const int64_t e = e_wave + lane * 8;
             float v[8];
             if constexpr (!ELIDE) unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
-            if constexpr (GATE) OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)gate_bits<8>(v);
+            if constexpr (GATE) {
+                OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)gate_bits<8>(v, OpGate<Op>::act(op));
+                if (void* xb = OpGate<Op>::xback(op)) xback_store<8, XDT>(xb, e, v);
+            }
             int32_t q;
             u32x4 a, b;
             if constexpr (CM == CM_LAST) {
@@ -746,9 +784,10 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                 }
             }
             if constexpr (GATE) {       // 4 elements = a nibble; the even lane stores the byte it shares with its neighbour
-                const uint32_t nib = gate_bits<4>(v);
+                const uint32_t nib = gate_bits<4>(v, OpGate<Op>::act(op));
                 const uint32_t other = gate_pair_swap(nib);      // both lanes of a pair are inside or outside the tensor together
                 if ((lane & 1) == 0) OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)(nib | (other << 4));
+                if (void* xb = OpGate<Op>::xback(op)) xback_store<4, XDT>(xb, e, v);
             }
             int32_t q;
             u32x4 out;
@@ -777,7 +816,10 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
         typename Op::P p = (CM == CM_SCALAR) ? p_scalar : op.channel_masked(PARAM_PER_CHANNEL ? it.c : 0u, it.c);
         int32_t qi;
         const float xe = load1<XDT>(x, e);
-        if constexpr (GATE) gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, !(xe <= 0.0f));
+        if constexpr (GATE) {
+            gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, act_open(xe, OpGate<Op>::act(op)));
+            if (void* xb = OpGate<Op>::xback(op)) store1<XDT>(xb, e, relu_aten(xe));
+        }
         y[e] = op.apply(xe, p, qi);
         if constexpr (GATE) {
             if (void* img = OpGate<Op>::image(op)) {
@@ -807,8 +849,14 @@ __device__ __forceinline__ void gate_to_floats(uint32_t bits, float* vx) {
 template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false, int G2DT = -1>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
-                                                              void* __restrict__ gx, const void* __restrict__ g2 = nullptr) {
+                                                              void* __restrict__ gx, ActSpec act, const void* __restrict__ g2 = nullptr) {
     static_assert(G2DT < 0 || (!ELIDE && GDT == QS_F32 && G2DT != QS_F32), "the second gradient is a 2-byte stream next to an fp32 one");
+    // the activation's backward at one element: `xv` is the activation's input -- or, with GATE, the recorded bit as 1.0 / 0.0;
+    // `applied` the clamped, masked gradient.  Open gate: it passes; closed: 0 (rectifiers) or applied * slope (leaky)
+    auto gated = [&](float xv, float applied) -> float {
+        const bool open = GATE ? (xv > 0.0f) : act_open(xv, act);
+        return open ? applied : act_closed(applied, act, XDT);
+    };
     const int64_t blk = geo.reverse ? (int64_t)(gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
     const int64_t grp = blk * kBlock + threadIdx.x;
     if constexpr (GDT == QS_F32 && XDT == QS_F32) {
@@ -863,8 +911,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                     if (op.cmask) mm = *(const uint32_t*)(op.cmask + last_dim_channel(e, geo.C));   // 4 consecutive channels
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f
-                                 : op.apply(__uint_as_float(rg4[j]), SteBwdOp::keep_of(p0, (mm >> (8 * j)) & 0xffu), dummy));
+                        out[j] = __float_as_uint(gated(__uint_as_float(rx4[j]), op.apply(__uint_as_float(rg4[j]), SteBwdOp::keep_of(p0, (mm >> (8 * j)) & 0xffu), dummy)));
                 } else if constexpr (CM == CM_ELEM) {
                     ChanIter it;
                     it.C = geo.C;
@@ -873,7 +920,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
-                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f : op.apply(__uint_as_float(rg4[j]), p, dummy));
+                        out[j] = __float_as_uint(gated(__uint_as_float(rx4[j]), op.apply(__uint_as_float(rg4[j]), p, dummy)));
                         it.next();
                     }
                 } else {
@@ -891,7 +938,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        out[j] = __float_as_uint((__uint_as_float(rx4[j]) <= 0.0f) ? 0.0f : op.apply(__uint_as_float(rg4[j]), p, dummy));
+                        out[j] = __float_as_uint(gated(__uint_as_float(rx4[j]), op.apply(__uint_as_float(rg4[j]), p, dummy)));
                 }
                 st16<NT>((u32x4*)((float*)gx + e), out);
             }
@@ -935,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         if constexpr (CM == CM_SCALAR) {
             const SteBwdOp::P p = op.channel(0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+            for (int j = 0; j < 8; ++j) vg[j] = gated(vx[j], op.apply(vg[j], p, dummy));
         } else if constexpr (CM == CM_ROW) {
             SteBwdOp::P p;
             if (geo.groups_per_row >= 64u) {         // wave-uniform look-up (WaveRows), dense too
@@ -949,7 +996,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 p = op.channel_masked(param_per_channel ? c : 0u, c);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+            for (int j = 0; j < 8; ++j) vg[j] = gated(vx[j], op.apply(vg[j], p, dummy));
         } else if constexpr (CM == CM_LAST) {
             const SteBwdOp::P p0 = op.channel(0);
             const uint32_t c0 = last_dim_channel(grp * 8, geo.C);
@@ -957,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
             if (op.cmask) mm = *(const u32x2*)(op.cmask + c0);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], SteBwdOp::keep_of(p0, (mm[j >> 2] >> (8 * (j & 3))) & 0xffu), dummy);
+                vg[j] = gated(vx[j], op.apply(vg[j], SteBwdOp::keep_of(p0, (mm[j >> 2] >> (8 * (j & 3))) & 0xffu), dummy));
         } else {
             ChanIter it;
             it.C = geo.C;
@@ -969,12 +1016,12 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 const SteBwdOp::P p0 = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
                 const SteBwdOp::P p1 = op.channel_masked(param_per_channel ? c1 : 0u, c1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], (uint32_t)j < left ? p0 : p1, dummy);
+                for (int j = 0; j < 8; ++j) vg[j] = gated(vx[j], op.apply(vg[j], (uint32_t)j < left ? p0 : p1, dummy));
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const SteBwdOp::P p = op.channel_masked(param_per_channel ? it.c : 0u, it.c);
-                    vg[j] = (vx[j] <= 0.0f) ? 0.0f : op.apply(vg[j], p, dummy);
+                    vg[j] = gated(vx[j], op.apply(vg[j], p, dummy));
                     it.next();
                 }
             }
@@ -997,7 +1044,7 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
             const float v2 = load1<G2DT>(g2, e);
             ge = g ? ge + v2 : v2;
         }
-        const float r = (xe <= 0.0f) ? 0.0f : op.apply(ge, p, dummy);
+        const float r = gated(xe, op.apply(ge, p, dummy));
         store1<XDT>(gx, e, r);
     }
 }

@@ -30,6 +30,10 @@
 
 using namespace qs;
 
+// folded activations: `pre_relu` arguments of the ABI are 0, 1 (nn.ReLU) or a qs_activation() handle; defined in api_core.hip
+// (one table for every translation unit).  Returns QS_OK and the descriptor, or QS_ERR_ARG for an unknown handle.
+int qs_act_resolve(int pre_relu, ActSpec* out);
+
 namespace {
 
 inline int env_int(const char* name, int dflt) {

@@ -1,165 +1,304 @@
 // Multi-tensor weight path: abs-max, running-scale update and quantization of MANY small fp32 tensors (the conv /
-// linear weights of a converted network) in three launches instead of three per tensor.  Per tensor these are 3-5 us
-// kernels over a few thousand to a few million elements; a ResNet-50 has 54 of them, i.e. ~160 launches per step.
-// The tensor list travels by value in the kernel arguments (<= kMultiMax tensors per launch, the host chunks longer
-// lists); `block0` is the exclusive prefix sum of the workgroups each tensor gets, a workgroup finds its tensor by
-// binary search.  Arithmetic is that of reduce_all_kernel / scale_update_kernel / ew_kernel<ScalerFwdOp|DecimalFwdOp>.
+// linear weights -- and biases -- of a converted network) in three launches instead of three per tensor.  Per tensor these
+// are 3-5 us kernels over a few thousand to a few million elements; a ResNet-50 has 54 of them, i.e. ~160 launches per step.
+//
+// The tensor list is a DEVICE-resident table of `qs_multi_row` descriptors (include/qsparse_hip.h) that the caller builds
+// once per set of layers and reuses every step -- any number of tensors per launch, nothing re-marshalled per step.  A
+// workgroup finds its tensor by binary search over the table's prefix sums of workgroups.  Tensor-wise AND per-channel
+// quantizers (the reference's default for weights is channelwise=1, quantize.py:524): a tensor is the contiguous
+// [outer, C, inner] view around its channel dim, C == 1 for tensor-wise.  Arithmetic is that of reduce_all_kernel /
+// reduce_rows_kernel, scale_update_kernel, decimal_from_scale_kernel and ew_kernel<ScalerFwdOp | DecimalFwdOp | SteBwdOp>.
 #pragma once
 #include "qs_elementwise.h"
 #include "qs_reduce.h"
 
 namespace qs {
 
-constexpr int kMultiMax = 48;
-
-struct MultiTensors {           // 48 * (8 + 8 + 8 + 8 + 4 + 4 + 4) + 8 = 2120 bytes of kernel arguments
-    const float* x[kMultiMax];
-    float* y[kMultiMax];        // quantized output (multi_quant_kernel only)
-    float* scale[kMultiMax];    // one-element running scale (QuantizeLayer.weight)
-    int64_t numel[kMultiMax];
-    int32_t block0[kMultiMax + 1];
-    int32_t lo[kMultiMax], hi[kMultiMax];   // code range of the opt-in saturation (multi_quant_kernel; lo > hi: none)
-    int32_t n;
-};
-
-struct MultiUpdate {            // 48 * (8 + 8 + 8 + 8 + 8 + 8 + 4 + 4) + 8 = 2696 bytes
-    uint32_t* amax[kMultiMax];  // one-element abs-max accumulators (max-accumulated, zero between steps)
-    float* scale[kMultiMax];
-    float* backup[kMultiMax];   // nullable: receives the scale this update replaces (for a caller that may have to undo it)
-    float* decimal[kMultiMax];  // nullable: receives rint(log2(1/scale)) for the decimal quantizer
-    int64_t* t_dev[kMultiMax];  // nullable: device-resident running-mean counter, read INSTEAD of t and incremented
-    int32_t* bump[kMultiMax];   // nullable: the layer's step counter, incremented
-    float t[kMultiMax];
-    float denom[kMultiMax];     // 2^(bits-1)
-    int32_t n;
-};
-
-__device__ __forceinline__ int multi_find(const int32_t* block0, int n, int b) {
+__device__ __forceinline__ int multi_find(const qs_multi_row* __restrict__ rows, int n, int b, int which) {
     int lo = 0, hi = n - 1;     // largest i with block0[i] <= b
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (block0[mid] <= b) lo = mid;
+        const int b0 = which ? rows[mid].quant_block0 : rows[mid].absmax_block0;
+        if (b0 <= b) lo = mid;
         else hi = mid - 1;
     }
     return lo;
 }
 
-// abs-max of every tensor; a tensor's workgroups stride over its 8-element groups, one atomic per workgroup
-static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(MultiTensors a, MultiUpdate u) {
-    const int i = multi_find(a.block0, a.n, blockIdx.x);
-    const int nb = a.block0[i + 1] - a.block0[i], b = blockIdx.x - a.block0[i];
-    const float* x = a.x[i];
-    const int64_t numel = a.numel[i], ngroups = numel / 8;
-    RedAcc<QS_F32, false> acc;
-    for (int64_t g = (int64_t)b * kBlock + threadIdx.x; g < ngroups; g += (int64_t)nb * kBlock) {
-        float v[8];
-        unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+constexpr int kMultiTallCols = 64;      // per-channel abs-max, outer > 1: adjacent columns per workgroup (one coalesced 256-byte row segment)
+constexpr int kMultiFlatCols = 2048;    // outer == 1 (the channel dim is the first one): elements per workgroup
+
+// abs-max of every tensor that updates its statistics this step (row.train != 0), max-accumulated into row.amax[c]
+// (zero between steps: multi_scale_update_kernel re-zeroes).
+//   tensor-wise (C == 1):  the tensor's workgroups stride over its 8-element groups, one atomic per workgroup.
+//   per channel:           the tensor is the matrix [outer, cols = C * inner].  outer > 1: a workgroup owns 64 adjacent columns
+//                          (and one of `row_splits` interleaved row sets), its four waves take every fourth row, lanes walk
+//                          their column (256 contiguous bytes per wave and row); outer == 1: 2048 consecutive elements.  The
+//                          columns' maxima are folded per channel in LDS and flushed with ONE atomic per channel touched --
+//                          same-line atomics serialise on this chip, so there must be few of them.
+static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(const qs_multi_row* __restrict__ rows, int n) {
+    const int i = multi_find(rows, n, blockIdx.x, 0);
+    const qs_multi_row r = rows[i];
+    const int b = blockIdx.x - r.absmax_block0;
+    const float* x = r.x;
+    uint32_t* amax = (uint32_t*)r.amax;
+    if (r.C == 1) {
+        const int nb = r.absmax_blocks;
+        const int64_t ngroups = r.numel / 8;
+        RedAcc<QS_F32, false> acc;
+        if ((((uintptr_t)x) & 15) == 0) {
+            for (int64_t g = (int64_t)b * kBlock + threadIdx.x; g < ngroups; g += (int64_t)nb * kBlock) {
+                float v[8];
+                unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc.add(v[j]);
+                for (int j = 0; j < 8; ++j) acc.add(v[j]);
+            }
+            if (b == 0 && ngroups * 8 + threadIdx.x < r.numel) acc.add(x[ngroups * 8 + threadIdx.x]);
+        } else {
+            for (int64_t e = (int64_t)b * kBlock + threadIdx.x; e < r.numel; e += (int64_t)nb * kBlock) acc.add(x[e]);
+        }
+        __shared__ uint32_t smx[kBlock / 64];
+        acc.wave_reduce();
+        if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = acc.mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = smx[0];
+            for (int w = 1; w < kBlock / 64; ++w) m = smx[w] > m ? smx[w] : m;
+            atomicMax(amax, m);
+        }
+        return;
     }
-    if (b == 0 && ngroups * 8 + threadIdx.x < numel) acc.add(x[ngroups * 8 + threadIdx.x]);
-    __shared__ uint32_t smx[kBlock / 64];
-    acc.wave_reduce();
-    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = acc.mx;
+    __shared__ uint32_t chan[kMultiFlatCols + 2];
+    const int64_t cols = (int64_t)r.C * r.inner;
+    const int cpb = r.outer > 1 ? kMultiTallCols : kMultiFlatCols;
+    const int splits = r.row_splits;
+    const int cb = b / splits, rs = b - cb * splits;
+    const int64_t col0 = (int64_t)cb * cpb;
+    const int64_t c_lo = col0 / r.inner;
+    for (int t = threadIdx.x; t < cpb + 2; t += kBlock) chan[t] = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t m = smx[0];
-        for (int w = 1; w < kBlock / 64; ++w) m = smx[w] > m ? smx[w] : m;
-        atomicMax(u.amax[i], m);
-    }
-}
-
-// one thread per tensor: the running mean of scale_update_kernel, the decimal of decimal_from_scale_kernel, counters
-static __global__ void multi_scale_update_kernel(MultiUpdate u) {
-    const int i = threadIdx.x;
-    if (i >= u.n) return;
-    float t = u.t[i];
-    if (u.t_dev[i]) t = (float)*u.t_dev[i];
-    const float nw = __uint_as_float(*u.amax[i]) / u.denom[i];                 // fp32 weights: no dtype rounding
-    const float old = *u.scale[i];
-    if (u.backup[i]) *u.backup[i] = old;
-    const float s = (t == 0.0f) ? nw : (t * old + nw) / (t + 1.0f);           // quantize.py:344-347
-    *u.scale[i] = s;
-    *u.amax[i] = 0u;
-    if (u.decimal[i]) {
-        float r = 1.0f / s;
-        if (r == __builtin_inff() || r == -__builtin_inff()) r = 1.0f;          // nan_to_num(posinf=1, neginf=1)
-        if (r != r) r = 0.0f;
-        *u.decimal[i] = rintf(log2f(r));
-    }
-    if (u.t_dev[i]) atomicAdd((unsigned long long*)u.t_dev[i], 1ull);
-    if (u.bump[i]) atomicAdd(u.bump[i], 1);
-}
-
-// y = Q(x) for every tensor: exact grid, 8 elements per lane; DECIMAL selects the truncating power-of-two quantizer
-// (its per-tensor parameter is then the decimal, not the scale)
-template <bool DECIMAL>
-__global__ __launch_bounds__(kBlock) void multi_quant_kernel(MultiTensors a) {
-    const int i = multi_find(a.block0, a.n, blockIdx.x);
-    const int64_t g = (int64_t)(blockIdx.x - a.block0[i]) * kBlock + threadIdx.x;
-    const float* x = a.x[i];
-    float* y = a.y[i];
-    const int64_t numel = a.numel[i], ngroups = numel / 8;
-    int32_t code;
-    if constexpr (DECIMAL) {
-        const DecimalFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, a.lo[i] <= a.hi[i], a.lo[i], a.hi[i], 0};
-        const auto p = op.channel(0);
-        if (g < ngroups) {
-            float v[8];
-            unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
-            store8<QS_F32, false>(y, g, v);
+    if (r.outer > 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int64_t j = col0 + lane;
+        if (j < cols) {
+            uint32_t m = 0u;
+            const float* col = x + j;
+            const int64_t stride = (int64_t)splits * (kBlock / 64);              // rows between two visits of this wave
+            int64_t row = (int64_t)rs * (kBlock / 64) + wave;
+            for (; row + 3 * stride < r.outer; row += 4 * stride) {             // four rows in flight
+                const uint32_t k0 = __float_as_uint(col[row * cols]) & 0x7fffffffu;
+                const uint32_t k1 = __float_as_uint(col[(row + stride) * cols]) & 0x7fffffffu;
+                const uint32_t k2 = __float_as_uint(col[(row + 2 * stride) * cols]) & 0x7fffffffu;
+                const uint32_t k3 = __float_as_uint(col[(row + 3 * stride) * cols]) & 0x7fffffffu;
+                const uint32_t a = k0 > k1 ? k0 : k1, c = k2 > k3 ? k2 : k3;
+                const uint32_t k = a > c ? a : c;
+                m = k > m ? k : m;
+            }
+            for (; row < r.outer; row += stride) {
+                const uint32_t k = __float_as_uint(col[row * cols]) & 0x7fffffffu;
+                m = k > m ? k : m;
+            }
+            atomicMax(&chan[(int)(j / r.inner - c_lo)], m);
         }
-        if (g == 0)
-            for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(x[e], p, code);
     } else {
-        const ScalerFwdOp<QS_F32> op{a.scale[i], 0.0f, nullptr, a.lo[i] <= a.hi[i], a.lo[i], a.hi[i], 0};
-        const auto p = op.channel(0);
-        if (g < ngroups) {
-            float v[8];
-            unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
-            store8<QS_F32, false>(y, g, v);
+        for (int t = threadIdx.x; t < cpb; t += kBlock) {
+            const int64_t j = col0 + t;
+            if (j < cols) atomicMax(&chan[(int)(j / r.inner - c_lo)], __float_as_uint(x[j]) & 0x7fffffffu);
         }
-        if (g == 0)
-            for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(x[e], p, code);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cpb + 2; t += kBlock) {
+        const int64_t c = c_lo + t;
+        if (c < r.C && chan[t] != 0u) atomicMax(amax + c, chan[t]);
     }
 }
 
-// gx = clamp(g, lo_mul * s, hi_mul * s) for every tensor (SteBwdOp's arithmetic, reference quantize.py:66-77, 120-131): the
-// STE backward of MANY weight quantizers in one launch -- gradients of a group of layers handed over together
-struct MultiSte {               // 48 * (8 + 8 + 8 + 8 + 4 + 4 + 4) + 8 = 2120 bytes
-    const float* g[kMultiMax];
-    float* gx[kMultiMax];
-    const float* step[kMultiMax];   // one-element scale, or decimal with DECIMAL
-    int64_t numel[kMultiMax];
-    int32_t block0[kMultiMax + 1];
-    float lo_mul[kMultiMax];
-    float hi_mul[kMultiMax];
+// one thread per (tensor, channel) of the table: the running mean of scale_update_kernel, the decimal of
+// decimal_from_scale_kernel, the backup a caller needs to undo the update.  t comes from row.t_dev (device-resident) plus
+// row.t_offset; the counters themselves are advanced by the launch that FOLLOWS in stream order (multi_quant_kernel with
+// advance != 0): every thread of this one has read them by then, whichever workgroup it ran in.
+static __global__ __launch_bounds__(kBlock) void multi_scale_update_kernel(const qs_multi_row* __restrict__ rows, int n,
+                                                                          int total_channels) {
+    const int item = blockIdx.x * kBlock + threadIdx.x;
+    if (item >= total_channels) return;
+    int lo = 0, hi = n - 1;     // the tensor this channel belongs to: largest i with chan0[i] <= item
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rows[mid].chan0 <= item) lo = mid;
+        else hi = mid - 1;
+    }
+    const qs_multi_row& r = rows[lo];
+    if (!r.train) return;
+    const int c = item - r.chan0;
+    uint32_t* amax = (uint32_t*)r.amax;
+    float* scale = r.scale;
+    const float t = (float)(*r.t_dev + r.t_offset);
+    const float nw = __uint_as_float(amax[c]) / r.denom;                   // fp32 weights: no dtype rounding (quantize.py:340)
+    const float old = scale[c];
+    if (r.backup) r.backup[c] = old;
+    const float s = (t == 0.0f) ? nw : (t * old + nw) / (t + 1.0f);       // quantize.py:344-347
+    scale[c] = s;
+    amax[c] = 0u;
+    if (r.decimal) {
+        float q = 1.0f / s;
+        if (q == __builtin_inff() || q == -__builtin_inff()) q = 1.0f;      // nan_to_num(posinf=1, neginf=1) (:316)
+        if (q != q) q = 0.0f;
+        r.decimal[c] = rintf(log2f(q));
+    }
+}
+
+// channel of element e of row r
+__device__ __forceinline__ uint32_t multi_channel(const qs_multi_row& r, int64_t e) {
+    return (uint32_t)((e / r.inner) % r.C);
+}
+
+// y = Q(x) for every tensor of the table: exact grid, 8 elements per lane; the per-tensor parameter is the scale (scaler
+// quantizer) or the decimal (row.is_decimal: the truncating power-of-two quantizer), one per channel
+static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_multi_row* __restrict__ rows, int n, float* ybase,
+                                                                   int advance) {
+    if (advance && blockIdx.x == 0) {
+        // the step counters of the rows that updated their statistics (see multi_scale_update_kernel).  A callback shared by
+        // a layer's weight and bias quantizers (reference quantize.py:548,559-571) appears in two rows with the same counter
+        // and t_offset 0 / 1: the weight's update saw t, the bias's t + 1, the counter moves by two.
+        for (int k = threadIdx.x; k < n; k += kBlock) {
+            if (!rows[k].train) continue;
+            atomicAdd((unsigned long long*)rows[k].t_dev, 1ull);
+            if (rows[k].bump) atomicAdd(rows[k].bump, 1);
+        }
+    }
+    const int i = multi_find(rows, n, blockIdx.x, 1);
+    const qs_multi_row r = rows[i];
+    const int64_t g = (int64_t)(blockIdx.x - r.quant_block0) * kBlock + threadIdx.x;
+    const float* x = r.x;
+    float* y = ybase + r.y_off;
+    const int64_t numel = r.numel, ngroups = numel / 8;
+    const int sat = r.code_lo <= r.code_hi;
+    const float* param = r.is_decimal ? r.decimal : r.scale;
+    const bool vec = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    int32_t code;
+    auto run = [&](auto op) {
+        if (r.C == 1) {
+            const auto p = op.channel(0);
+            if (vec) {
+                if (g < ngroups) {
+                    float v[8];
+                    unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
+                    store8<QS_F32, false>(y, g, v);
+                }
+                if (g == 0)
+                    for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(x[e], p, code);
+            } else {
+                for (int64_t e = g * 8; e < numel && e < g * 8 + 8; ++e) y[e] = op.apply(x[e], p, code);
+            }
+            return;
+        }
+        // per channel: the parameters are looked up again whenever the channel changes along the lane's 8 elements
+        const int64_t e0 = g * 8;
+        if (e0 >= numel) return;
+        uint32_t c = multi_channel(r, e0), rem = (uint32_t)(r.inner - e0 % r.inner);
+        auto p = op.channel(c);
+        if (vec && e0 + 8 <= numel) {
+            float v[8];
+            unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = op.apply(v[j], p, code);
+                if (--rem == 0) {
+                    rem = (uint32_t)r.inner;
+                    c = (c + 1 == (uint32_t)r.C) ? 0u : c + 1;
+                    p = op.channel(c);
+                }
+            }
+            store8<QS_F32, false>(y, g, v);
+        } else {
+            for (int64_t e = e0; e < numel && e < e0 + 8; ++e) {
+                y[e] = op.apply(x[e], p, code);
+                if (--rem == 0) {
+                    rem = (uint32_t)r.inner;
+                    c = (c + 1 == (uint32_t)r.C) ? 0u : c + 1;
+                    p = op.channel(c);
+                }
+            }
+        }
+    };
+    if (r.is_decimal) run(DecimalFwdOp<QS_F32>{param, 0.0f, nullptr, sat, r.code_lo, r.code_hi, ActSpec{0, 0.f, 0.f}, QS_F32});
+    else run(ScalerFwdOp<QS_F32>{param, 0.0f, nullptr, sat, r.code_lo, r.code_hi, ActSpec{0, 0.f, 0.f}, QS_F32});
+}
+
+// gx = clamp(g, lo_mul * s_c, hi_mul * s_c) for every tensor (SteBwdOp's arithmetic, reference quantize.py:66-77, 120-131): the
+// STE backward of a GROUP of weight quantizers in one launch -- gradients of a few layers handed over together.  The
+// gradients are fresh tensors every step, so this list travels by value in the kernel arguments.
+constexpr int kMultiSteMax = 32;
+struct MultiSte {
+    const float* g[kMultiSteMax];
+    float* gx[kMultiSteMax];
+    const float* step[kMultiSteMax];   // scale(s), or decimal(s) with is_decimal: one per channel
+    int64_t numel[kMultiSteMax];
+    int32_t block0[kMultiSteMax + 1];
+    int32_t C[kMultiSteMax], inner[kMultiSteMax];
+    float lo_mul[kMultiSteMax];
+    float hi_mul[kMultiSteMax];
     int32_t n;
 };
 
 template <bool DECIMAL>
 __global__ __launch_bounds__(kBlock) void multi_ste_kernel(MultiSte a) {
-    const int i = multi_find(a.block0, a.n, blockIdx.x);
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.block0[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const int i = lo;
     const int64_t g0 = (int64_t)(blockIdx.x - a.block0[i]) * kBlock + threadIdx.x;
     const float* g = a.g[i];
     float* gx = a.gx[i];
     const int64_t numel = a.numel[i], ngroups = numel / 8;
     const SteBwdOp op{a.step[i], 0.0f, DECIMAL ? 1 : 0, a.lo_mul[i], a.hi_mul[i], 0, nullptr};
-    const auto p = op.channel(0);
     int32_t code;
-    if (g0 < ngroups) {
+    const int C = a.C[i], inner = a.inner[i];
+    if (C == 1) {
+        const auto p = op.channel(0);
+        if (g0 < ngroups) {
+            float v[8];
+            unpack8<QS_F32>(load8_raw<QS_F32, false>(g, g0), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
+            store8<QS_F32, false>(gx, g0, v);
+        }
+        if (g0 == 0)
+            for (int64_t e = ngroups * 8; e < numel; ++e) gx[e] = op.apply(g[e], p, code);
+        return;
+    }
+    const int64_t e0 = g0 * 8;
+    if (e0 >= numel) return;
+    uint32_t c = (uint32_t)((e0 / inner) % C), rem = (uint32_t)(inner - e0 % inner);
+    auto p = op.channel(c);
+    if (e0 + 8 <= numel) {
         float v[8];
         unpack8<QS_F32>(load8_raw<QS_F32, false>(g, g0), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
+        for (int j = 0; j < 8; ++j) {
+            v[j] = op.apply(v[j], p, code);
+            if (--rem == 0) {
+                rem = (uint32_t)inner;
+                c = (c + 1 == (uint32_t)C) ? 0u : c + 1;
+                p = op.channel(c);
+            }
+        }
         store8<QS_F32, false>(gx, g0, v);
+    } else {
+        for (int64_t e = e0; e < numel; ++e) {
+            gx[e] = op.apply(g[e], p, code);
+            if (--rem == 0) {
+                rem = (uint32_t)inner;
+                c = (c + 1 == (uint32_t)C) ? 0u : c + 1;
+                p = op.channel(c);
+            }
+        }
     }
-    if (g0 == 0)
-        for (int64_t e = ngroups * 8; e < numel; ++e) gx[e] = op.apply(g[e], p, code);
 }
 
 }  // namespace qs

@@ -20,9 +20,9 @@ struct RedAcc {
     // and a minimum that ignored NaNs where the reference's rows.min() returns NaN; before that, key conversion + integer
     // min/max at ~9 ops made these kernels VALU-bound at 4.3 TB/s.)
     float fmx = -__builtin_inff(), fmn = __builtin_inff();
-    int relu = 0;   // abs-max of max(x, 0): the statistics of a folded nn.ReLU
+    ActSpec act = {0, 0.f, 0.f};   // abs-max of act(x): the statistics of a folded activation (nn.ReLU: max(x, 0))
     __device__ __forceinline__ void add(float v) {
-        if (relu) v = relu_aten(v);
+        if (act.kind) v = act_apply(v, act, DT);
         if constexpr (MINMAX) {
             fmx = __builtin_elementwise_maximum(fmx, v);
             fmn = __builtin_elementwise_minimum(fmn, v);
@@ -56,9 +56,9 @@ struct RedAcc {
 // halves their number at the same number of waves per CU.
 template <int DT, bool MINMAX, int BS>
 __global__ __launch_bounds__(BS) void reduce_all_kernel(const void* __restrict__ x, int64_t numel,
-                                                             uint32_t* out_max, uint32_t* out_min, int relu, int lines) {
+                                                             uint32_t* out_max, uint32_t* out_min, ActSpec relu, int lines) {
     RedAcc<DT, MINMAX> acc;
-    acc.relu = relu;
+    acc.act = relu;
     const int64_t ngroups = numel / 8;
     const int64_t stride = (int64_t)gridDim.x * BS;
     int64_t g = (int64_t)blockIdx.x * BS + threadIdx.x;
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(BS) void reduce_all_kernel(const void* __restrict__
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restrict__ x, int64_t outer, uint32_t C,
                                                               int64_t inner, int vec_ok, int64_t outer_per_block,
-                                                              uint32_t* out_max, uint32_t* out_min, int relu) {
+                                                              uint32_t* out_max, uint32_t* out_min, ActSpec relu) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc;
-    acc.relu = relu;
+    acc.act = relu;
     // short rows (<= 512 elements, e.g. 14x14 and 7x7 maps): a row is one vector load per lane, so a wave keeps FOUR rows
     // in flight instead of one (64x1024x14x14 bf16: 26 -> 23 us, tools/bench_reduce.py)
     const bool short_rows = vec_ok != 0 && inner <= 512;
@@ -249,13 +249,13 @@ __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const void* __restr
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
                                                               int64_t inner, int64_t outer_per_block,
-                                                              uint32_t* out_max, uint32_t* out_min, int relu) {
+                                                              uint32_t* out_max, uint32_t* out_min, ActSpec relu) {
     const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (col >= cols) return;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc;
-    acc.relu = relu;
+    acc.act = relu;
     for (int64_t o = o0; o < o1; ++o) acc.add(load1<DT>(x, o * cols + col));
     if (o1 > o0) acc.flush(out_max, out_min, (uint32_t)(col / inner));
 }
@@ -264,14 +264,14 @@ __global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const void* __restr
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_cols_vec_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
                                                                   int64_t inner, int64_t outer_per_block,
-                                                                  uint32_t* out_max, uint32_t* out_min, int relu) {
+                                                                  uint32_t* out_max, uint32_t* out_min, ActSpec relu) {
     const int64_t gcols = cols / 8;
     const int64_t gc = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t o0 = (int64_t)blockIdx.y * outer_per_block;
     const int64_t o1 = o0 + outer_per_block < outer ? o0 + outer_per_block : outer;
     RedAcc<DT, MINMAX> acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j].relu = relu;
+    for (int j = 0; j < 8; ++j) acc[j].act = relu;
     for (int64_t o = o0; o < o1 && gc < gcols; o += 8) {
         Raw8<DT> r[8];
 #pragma unroll
@@ -334,7 +334,7 @@ constexpr int kFewColsMaxCols = 512;
 template <int DT, bool MINMAX>
 __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __restrict__ x, int64_t outer, int64_t cols,
                                                                  uint32_t* __restrict__ part_max,
-                                                                 uint32_t* __restrict__ part_min, int relu) {
+                                                                 uint32_t* __restrict__ part_min, ActSpec relu) {
     __shared__ uint32_t lmx[kFewColsMaxCols], lmn[kFewColsMaxCols];
     const int gcols = (int)(cols / 8);
     const int rows_per_iter = kBlock / gcols;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void reduce_fewcols_kernel(const void* __re
     }
     RedAcc<DT, MINMAX> acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j].relu = relu;
+    for (int j = 0; j < 8; ++j) acc[j].act = relu;
     if (row_l < rows_per_iter) {
         for (int64_t o = o0 + row_l; o < o1; o += ostride) {
             constexpr int F = QS_FEWCOLS_INFLIGHT;
@@ -458,11 +458,6 @@ static __global__ void keys_to_float_kernel(uint32_t* mx, uint32_t* mn, int64_t 
 // The reference divides in the dtype of the statistic (`x.abs().max() / 2**(bits-1)` on an fp16 / bf16 tensor): the
 // quotient is rounded to that dtype before it enters the float32 running mean.  Exact for bf16 (same exponent range as
 // fp32) but not for fp16, where small maxima underflow into subnormals (max|x| = 1e-3, 8 bits: 7.8082e-6, not 7.8157e-6).
-__device__ __forceinline__ float round_to_dtype(float v, int dt) {
-    if (dt == QS_F16) return round_through<QS_F16>(v);
-    if (dt == QS_BF16) return round_through<QS_BF16>(v);
-    return v;
-}
 static __global__ void scale_update_kernel(float* absmax, float* weight, int64_t n, float t, float tp1, float denom,
                                     int64_t* t_dev, int advance, int clear, int32_t* bump, int stat_dt, int lines) {
     if (lines > 1) {
@@ -579,8 +574,8 @@ struct Cascade {  // 4-level cascade accumulator for ONE column
 };
 
 template <int DT>
-__device__ __forceinline__ float mean_prep(float v, int flags, int l0) {
-    if (flags & QS_MEAN_RELU) v = relu_aten(v);   // folded preceding nn.ReLU
+__device__ __forceinline__ float mean_prep(float v, int flags, int l0, const ActSpec& act) {
+    if (flags & QS_MEAN_RELU) v = act_apply(v, act, DT);   // folded preceding activation
     if (l0) return (v != 0.0f) ? 1.0f : 0.0f;       // (x != 0).float()  (sparse.py:86)
     return (flags & QS_MEAN_ABS) ? fabsf(v) : v;    // x.abs()           (sparse.py:87)
 }
@@ -693,7 +688,8 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                                                              int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                              int flags, const int32_t* __restrict__ l0_flag,
                                                              uint32_t* __restrict__ absmax, int64_t astride,
-                                                             int64_t chan_div, uint32_t C, int lanes) {
+                                                             int64_t chan_div, uint32_t C, int lanes,
+                                                             ActSpec act = ActSpec{QS_ACT_RELU, 0.f, 0.f}) {
     const int64_t gcols = vcols / 8;                 // column groups per slice
     const int64_t total = pre * gcols;
     const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
@@ -724,11 +720,11 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                     acc[j].add(v[j]);
                 } else if constexpr (MODE == 0) {
                     if (absmax) {
-                        const float av = (flags & QS_MEAN_RELU) ? relu_aten(v[j]) : v[j];
+                        const float av = (flags & QS_MEAN_RELU) ? act_apply(v[j], act, DT) : v[j];
                         const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
                         amax = k > amax ? k : amax;
                     }
-                    acc[j].add(mean_prep<DT>(v[j], flags, l0));
+                    acc[j].add(mean_prep<DT>(v[j], flags, l0, act));
                 } else if constexpr (MODE == 6) {   // min / max ONLY, no sum, no output: the column walk of a per-channel min/max
                     mm.add(v[j]);
                 } else if constexpr (MODE >= 4) {   // abs-max ONLY (4: |x|, 5: max(x, 0)): no sum, no output -- the column walk
@@ -837,10 +833,11 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 // maximum over n of the mean's operand (|x| or max(x, 0)) as a uint32 key; the following qs_mean_last2 launch, which
 // runs one workgroup per channel anyway, reduces it to the per-channel abs-max -- no atomics at all.
 // MODE 1: |x|, 2: max(x, 0), 3: x as it is (no abs-max).
+// MODE 4: |act(x)| for a folded activation other than nn.ReLU (its descriptor and the input dtype travel as arguments)
 template <int MODE>
-__device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am) {
+__device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am, const ActSpec& act, int dt) {
     if constexpr (MODE == 3) return v;
-    const float w = (MODE == 2) ? relu_aten(v) : v;
+    const float w = (MODE == 4) ? act_apply(v, act, dt) : ((MODE == 2) ? relu_aten(v) : v);
     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
     am = k > am ? k : am;
     return __uint_as_float(k);
@@ -850,7 +847,7 @@ __device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am) {
 template <int DT, int ODT, int MODE>
 __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
                                                       int64_t hw, int64_t C, uint32_t* __restrict__ amax_part, int lanes,
-                                                      int64_t ngroups) {
+                                                      int64_t ngroups, ActSpec act) {
     const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
     const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
     if ((int)threadIdx.x >= lanes || t >= ngroups) return;
@@ -866,7 +863,7 @@ __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x,
         float v[8];
         unpack8<DT>(r, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j].add(mean_cl_prep<MODE>(v[j], amax[j]));
+        for (int j = 0; j < 8; ++j) acc[j].add(mean_cl_prep<MODE>(v[j], amax[j], act, DT));
     };
     int64_t i = 0;
     while (i + step <= n) {
@@ -908,7 +905,7 @@ template <int DT, int ODT, int R, int MODE>
 __global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
                                                              int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
                                                              int lanes, int64_t main_groups, int main_blocks,
-                                                             int64_t tail_groups, int slots) {
+                                                             int64_t tail_groups, int slots, ActSpec act) {
     extern __shared__ __attribute__((aligned(16))) float cl_slot_sums[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
@@ -943,7 +940,7 @@ __global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restri
                     float w[8];
                     unpack8<DT>(r[u], w);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += mean_cl_prep<MODE>(w[k], amax[k]);
+                    for (int k = 0; k < 8; ++k) acc[k] += mean_cl_prep<MODE>(w[k], amax[k], act, DT);
                 }
             }
 #pragma unroll
@@ -960,7 +957,7 @@ __global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restri
         float w[8];
         unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), w);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) add(k, mean_cl_prep<MODE>(w[k], amax[k]));
+        for (int k = 0; k < 8; ++k) add(k, mean_cl_prep<MODE>(w[k], amax[k], act, DT));
     };
     float res[8];
     if (!tail) {
@@ -1022,7 +1019,7 @@ __global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restri
 template <int DT, int ODT, int MODE>
 __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
                                                            int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
-                                                           int64_t first_group, int64_t ngroups) {
+                                                           int64_t first_group, int64_t ngroups, ActSpec act) {
     const int64_t groups = hw * C / 8;
     const int64_t tt = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (tt >= ngroups) return;
@@ -1040,7 +1037,7 @@ __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict
         float v[8];
         unpack8<DT>(r, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j].add(mean_cl_prep<MODE>(v[j], amax[j]));
+        for (int j = 0; j < 8; ++j) a[j].add(mean_cl_prep<MODE>(v[j], amax[j], act, DT));
     };
     int64_t e = 0;                                      // elements consumed per interleaved sum
     while (e + step <= n4) {
@@ -1074,7 +1071,7 @@ __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict
         float v[8];
         unpack8<DT>(load8_raw<DT, false>(x, t + i * groups), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) p[0][j] += mean_cl_prep<MODE>(v[j], amax[j]);
+        for (int j = 0; j < 8; ++j) p[0][j] += mean_cl_prep<MODE>(v[j], amax[j], act, DT);
     }
     const float fn = (float)n;
 #pragma unroll
@@ -1095,7 +1092,7 @@ template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                   int64_t n, int64_t hw, int64_t C, int flags,
                                                                   const int32_t* __restrict__ l0_flag,
-                                                                  uint32_t* __restrict__ amax_part) {
+                                                                  uint32_t* __restrict__ amax_part, ActSpec act) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= hw * C) return;
     const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
@@ -1105,11 +1102,11 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, i * sample + t);
         if (amax_part) {
-            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v) : v;
+            const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }
-        return mean_prep<DT>(v, flags, l0);
+        return mean_prep<DT>(v, flags, l0, act);
     };
     const float s = (pos < (hw / 4) * 4) ? sum_multi_row(n, get) : sum_row_sum(n, get);
     const int64_t o = c * hw + pos;                       // the result is NCHW-contiguous, as ATen's is
@@ -1135,7 +1132,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
                                                                    int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                                    int flags, const int32_t* __restrict__ l0_flag,
                                                                    uint32_t* __restrict__ absmax, int64_t astride,
-                                                                   int64_t chan_div, uint32_t C, int lanes) {
+                                                                   int64_t chan_div, uint32_t C, int lanes, ActSpec act) {
     extern __shared__ __attribute__((aligned(16))) float chunk_sums[];   // [nchunks][8][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gcols = vcols / 8, total = pre * gcols;
@@ -1157,7 +1154,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
     auto track = [&](const float (&v)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v[j]) : v[j];
+            const float av = (flags & QS_MEAN_RELU) ? act_apply(v[j], act, DT) : v[j];
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             if (j < first_col_next) amax0 = k > amax0 ? k : amax0;
             else amax1 = k > amax1 ? k : amax1;
@@ -1179,7 +1176,7 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
         } else {
             if (absmax) track(v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) add(k, mean_prep<DT>(v[k], flags, l0));
+            for (int k = 0; k < 8; ++k) add(k, mean_prep<DT>(v[k], flags, l0, act));
         }
     };
 
@@ -1237,7 +1234,7 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
                                                                int64_t pre, int64_t n, int64_t post, int64_t col0,
                                                                int flags, const int32_t* __restrict__ l0_flag,
                                                                uint32_t* __restrict__ absmax, int64_t astride,
-                                                               int64_t chan_div, uint32_t C) {
+                                                               int64_t chan_div, uint32_t C, ActSpec act) {
     const int64_t ncols = post - col0;
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= pre * ncols) return;
@@ -1248,11 +1245,11 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, base + i * post);
         if (absmax) {
-            const float av = (flags & QS_MEAN_RELU) ? relu_aten(v) : v;
+            const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }
-        return mean_prep<DT>(v, flags, l0);
+        return mean_prep<DT>(v, flags, l0, act);
     };
     float s;
     if (post == 1) {
@@ -1476,31 +1473,19 @@ struct PqArgs {
     // in rank order, instead of reading `stage` / `chan_absmax` (which is then only re-zeroed)
     const float* gathered;
     int world;
-    int coherent;               // `gathered` was written by OTHER workgroups of this very launch (mean_last2_select_kernel): read it
-                                // with agent-scope (sc1) loads
 };
-
-// a float another workgroup of the same launch published with an agent-scope store (see mean_last2_select_kernel)
-__device__ __forceinline__ float load_published(const float* p) {
-    return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void publish(float* p, float v) {
-    __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // channel i's importance / abs-max key: the local statistics, or the rank-ordered combination of every rank's record
 // (same arithmetic as stats_combine_kernel: fp32 sum in rank order divided by the world size; maximum of the keys)
 template <int SDT>
 __device__ __forceinline__ float pq_stage_value(const PqArgs& a, const void* stage, int64_t i) {
     if (!a.gathered) return load1<SDT>(stage, i);
-    if (a.coherent) return load_published(a.gathered + i);   // this rank's own record: the value mean_last2 stored in `stage`
     float sum = 0.f;
     for (int r = 0; r < a.world; ++r) sum += a.gathered[(int64_t)r * 2 * a.C + i];
     return sum / (float)a.world;
 }
 __device__ __forceinline__ uint32_t pq_amax_key(const PqArgs& a, int64_t i) {
     if (!a.gathered) return a.chan_absmax[i * a.amax_stride];
-    if (a.coherent) return __float_as_uint(load_published(a.gathered + a.C + i));
     uint32_t mx = 0u;
     for (int r = 0; r < a.world; ++r) {
         const uint32_t k = __float_as_uint(a.gathered[(int64_t)r * 2 * a.C + a.C + i]);
@@ -1643,110 +1628,6 @@ __global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const voi
 // (rounded to ODT) -> out [pre].  One workgroup per `pre` slice, tile held in LDS as fp32; both stages
 // add in ATen's order (outer rule over H, inner rule over W; see the block comment above).
 // =================================================================================================
-// maximum of slice p of the per-element maxima mean_cl_kernel left (valid in thread 0; all threads of the workgroup call it)
-__device__ __forceinline__ uint32_t last2_slice_max(const uint32_t* __restrict__ amax_part, int64_t p, int hw) {
-    __shared__ uint32_t wmax[kBlock / 64];
-    uint32_t m = 0u;
-    if ((hw & 3) == 0 && (((uintptr_t)amax_part) & 15) == 0) {
-        const uint4* part4 = reinterpret_cast<const uint4*>(amax_part + p * hw);
-        const int n4 = hw >> 2;
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * kBlock) {
-            uint4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = (i0 + u * kBlock < n4) ? part4[i0 + u * kBlock] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t a = q[u].x > q[u].y ? q[u].x : q[u].y, b = q[u].z > q[u].w ? q[u].z : q[u].w;
-                const uint32_t k = a > b ? a : b;
-                m = k > m ? k : m;
-            }
-        }
-    } else {
-        for (int i = threadIdx.x; i < hw; i += kBlock) {
-            const uint32_t k = amax_part[p * hw + i];
-            m = k > m ? k : m;
-        }
-    }
-    m = wave_max_u32(m);
-    __syncthreads();                                   // (wmax may still be read by thread 0 of the previous slice)
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int w = 1; w < kBlock / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
-    return m;
-}
-
-// mean over H (rounded to DT) then over W of slice p of x [pre, H, W]: the unrounded mean, valid in thread 0
-template <int DT>
-__device__ __forceinline__ float last2_slice_mean(const void* __restrict__ x, int64_t p, int H, int W, float* tile) {
-    float* colmean = tile + (size_t)H * W;
-    const int hw = H * W;
-    load_tile_f32<DT>(x, p, hw, tile);
-    __syncthreads();
-    const int mr_cols = (W >= 8) ? (W / 32) * 32 : (W / 4) * 4;
-    for (int col = threadIdx.x; col < W; col += kBlock) {
-        auto get = [&](int64_t i) { return tile[i * W + col]; };
-        const float s = (col < mr_cols) ? sum_multi_row(H, get) : sum_row_sum(H, get);
-        colmean[col] = round_through<DT>(s / (float)H);
-    }
-    __syncthreads();
-    const float s = inner_sum_lds(colmean, W, colmean + W);
-    return s / (float)W;
-}
-
-// =================================================================================================
-// qs_mean_last2 and qs_pq_select in ONE launch (the composite site call, no exchange between ranks): the workgroups reduce
-// their channels' tiles as mean_last2_kernel does and PUBLISH the two numbers the select needs per channel -- importance and
-// abs-max -- into the 2C-float record with agent-scope (write-through) stores; each then draws a ticket, and the workgroup
-// that draws the last one runs the select on the record.  Nobody waits for anybody: no grid barrier, no residency
-// requirement.  Hand-off as the CDNA4 guide prescribes: sc1 payload stores, s_waitcnt vmcnt(0) in the storing lane, an
-// agent-scope ticket; the last arriver issues ONE agent acquire (one lane, then __syncthreads) and reads the record with
-// agent-scope loads.  The abs-max accumulator is NOT written here (a plain store from a producer's XCD could land after the
-// select's re-zeroing store from another XCD): in the channels_last route the slice maximum goes into the record only.
-// ticket: one zero-initialised word per site, left zero by the last arriver.
-// =================================================================================================
-template <int DT>
-__global__ __launch_bounds__(kBlock) void mean_last2_select_kernel(const void* __restrict__ x, void* __restrict__ out, int C,
-                                                                    int H, int W, const uint32_t* __restrict__ amax_part,
-                                                                    const uint32_t* chan_absmax, int64_t astride,
-                                                                    float* record, uint32_t* ticket, PqArgs a0) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // max(H*W + W + 8 floats, SelectShared + 16 words)
-    const int hw = H * W;
-    for (int p = blockIdx.x; p < C; p += gridDim.x) {
-        uint32_t m = 0u;
-        if (amax_part) m = last2_slice_max(amax_part, p, hw);
-        const float mean = last2_slice_mean<DT>(x, p, H, W, tile);
-        if (threadIdx.x == 0) {
-            const uint32_t old = chan_absmax[(int64_t)p * astride];       // NCHW route: complete since the previous launch
-            m = m > old ? m : old;
-            store1<DT>(out, p, mean);
-            publish(record + p, round_through<DT>(mean));
-            publish(record + C + p, __uint_as_float(m));
-        }
-        __syncthreads();                                                   // the tile is reused by the next slice
-    }
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the storing lane drains its write-through stores
-        const uint32_t prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = prev == gridDim.x - 1;
-        if (last) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-    __syncthreads();
-    if (!last) return;
-    PqArgs a = pq_live_counters(a0);
-    a.gathered = record;
-    a.world = 1;
-    a.coherent = 1;
-    SelectShared& sh = *reinterpret_cast<SelectShared*>(tile);
-    uint32_t* sh_max = reinterpret_cast<uint32_t*>(tile) + (sizeof(SelectShared) + 3) / 4;
-    if (a.C <= kRankMax) pq_select_small<QS_F32, kRankMax / kBlock>(a, nullptr, sh, sh_max);
-    else pq_select_body<QS_F32>(a, nullptr, sh, sh_max);
-}
-
 template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_last2_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                              int H, int W, const uint32_t* __restrict__ amax_part,

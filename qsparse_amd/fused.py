@@ -64,9 +64,6 @@ def _arm_accumulators(q: QuantizeLayer):
             buf = d.get(key)
             if buf is not None:
                 buf.zero_()
-        plan = d.get("_qs_site_plan")
-        if plan is not None and plan.key is not None:
-            plan.keep[6].zero_()           # the arrival ticket of the fused last-two-stages + select launch
     d[_ARMED] = True
 
 
@@ -115,7 +112,8 @@ class _FusedApply(torch.autograd.Function):
         # decimal computed at THIS forward for a DecimalQuantizer (a fresh tensor, quantize.py:312-325 -> :41)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
         res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
-                             pre_relu=pre_relu, want_gate=want_gate, saturate=saturate)
+                             pre_relu=pre_relu, want_gate=want_gate, saturate=saturate,
+                             xback=_hip.owned_relu_cell() if (want_gate and h.data_ptr() % 16 == 0) else None)
         # the bitmap travels through save_for_backward like any saved activation (released with the graph, visible to
         # saved-tensor hooks); only its description -- shape, dtype, layout -- stays on ctx
         if want_gate:
@@ -152,7 +150,7 @@ class _FusedApply(torch.autograd.Function):
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
     __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused",
-                 "xbuf")
+                 "xbuf", "widen_nomask")
 
     def __init__(self):
         self.key = None
@@ -202,10 +200,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     stage = torch.empty(C * H * W, dtype=h.dtype, device=h.device)
     part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
-    # scratch of the fused last-two-stages + select launch: the per-channel record its workgroups publish, the arrival ticket
-    record = torch.empty(2 * C, dtype=torch.float32, device=h.device)
-    ticket = torch.zeros(1, dtype=torch.int32, device=h.device)
-    plan.keep = (acc, stage, part, stage_mean, t_q_dev, record, ticket) + state
+    plan.keep = (acc, stage, part, stage_mean, t_q_dev) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
     c.layout, c.xdt, c.ydt, c.bits = int(cl), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
@@ -216,10 +211,11 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
     c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
-    c.record, c.ticket = record.data_ptr(), ticket.data_ptr()
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
+    # (the same kernels write an owned in-place ReLU's result back into x; without the mask the launch is tensor-wise)
+    plan.widen_nomask = bool(_hip.load().qs_quant_image_ok(1, 1, outer * C * inner, 0, 0, 1, _hip.dt(h)))
     plan.c, plan.ref = c, ctypes.byref(c)
     q.__dict__["_qs_site_plan"] = plan
     return plan
@@ -309,13 +305,20 @@ class _SiteStep(torch.autograd.Function):
         # the image comes out of the forward kernel itself when the gate-recording kernels serve this geometry with the mask
         # (forward-only calls -- evaluation, serving -- let them record a bitmap nobody reads: 1/8 B/elem for a 6 B/elem pass)
         fused_image = bool(make_image and (flags & _hip.SITE_PRE_RELU) and plan.image_fused and not (flags & _hip.SITE_NO_MASK))
-        bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if (want_gate or fused_image) else None
+        # an owned nn.ReLU(inplace=True) in front of this site has not touched x yet: the apply kernel writes relu(x) back into
+        # x's own storage when it is one of the gate-recording widening kernels (forward-only calls record a bitmap nobody reads)
+        cell = _hip.owned_relu_cell() if (flags & _hip.SITE_PRE_RELU) else None
+        xback = bool(cell is not None and plan.out_dtype == torch.float32
+                     and (plan.widen_nomask if (flags & _hip.SITE_NO_MASK) else plan.image_fused))
+        bits_t = torch.empty((h.numel() + 7) // 8, dtype=torch.uint8, device=h.device) if (want_gate or fused_image or xback) else None
         if want_gate:
             _hip.note_gate(bits_t)
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
         if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None):
             flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic (see _hip.elide_mode)
-        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world)
+        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world, xback=xback)
+        if xback:
+            cell["done"] = True
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
@@ -563,7 +566,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
 class _OwnedRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cell):
-        x.relu_()
+        if not cell.get("defer"):        # deferred: the site's apply kernel (or `_with_owned_relu` after it) rectifies x
+            x.relu_()
         ctx.mark_dirty(x)
         ctx.cell = cell
         ctx.layout = (x.shape, x.stride())   # (x itself is NOT kept for the backward, unlike ATen's in-place ReLU)
@@ -608,7 +612,12 @@ def _foldable_relu(act, x) -> int:
 def _with_owned_relu(x: torch.Tensor, site):
     """x <- relu(x) in place, then `site(h)` on the alias the fused site reads (with `pre_relu`: max(h, 0) == h, its gate bits
     are h > 0); the bitmap the site records is also what `_OwnedRelu`'s rare route gates with"""
-    cell = {}
+    # The ReLU is DEFERRED: x keeps its raw values while the site runs -- every one of its kernels takes `pre_relu` and reads
+    # max(x, 0) -- and the site's apply kernel, which loads every element of x anyway, stores relu(x) back into x's storage
+    # (xback_out of qs_quant_scaler_fwd: +2 / +4 B/elem instead of ATen's 4 / 8 B/elem read + write pass).  A site whose route
+    # has no such kernel leaves x raw; the ATen pass below then runs after it -- same tensor contents either way, and in
+    # stream order before anything else can read x.
+    cell = {"defer": x.data_ptr() % 16 == 0}
     h = _Tap.apply(_OwnedRelu.apply(x, cell), cell)
     outer = getattr(_hip._gate_sink, "cell", None)
     _hip._gate_sink.cell = cell
@@ -616,6 +625,10 @@ def _with_owned_relu(x: torch.Tensor, site):
         y = site(h)
     finally:
         _hip._gate_sink.cell = outer
+        if cell.get("defer") and not cell.get("done"):
+            with torch.no_grad():
+                x.relu_()
+            cell["done"] = True
     if "bits" not in cell and torch.is_grad_enabled() and h.requires_grad:
         cell["h"] = h.detach()               # a site that recorded no gate this step (quantizer idle ...) kept x itself anyway
     return y

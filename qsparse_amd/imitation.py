@@ -38,6 +38,8 @@ def imitate(human: nn.Module, name: str, thing: Callable, bias_thing: Optional[C
     def read_bias(self):
         return getattr(self, name + "_bias")(inherited(self, "bias"))
 
-    patched = type(base.__name__, (base,), {"weight": property(read_weight), "bias": property(read_bias)})
+    # `_qs_imitation`: which operator this subclass reads through (outermost first along the MRO) -- the multi-tensor weight
+    # path (batch.py) needs the order of a layer's operators to know what a quantizer's input is
+    patched = type(base.__name__, (base,), {"weight": property(read_weight), "bias": property(read_bias), "_qs_imitation": name})
     human.__class__ = patched
     return human

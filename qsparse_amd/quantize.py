@@ -531,10 +531,16 @@ class _QuantStep(torch.autograd.Function):
     def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None):
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
-        gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if want_gate else None
+        # an owned nn.ReLU(inplace=True) in front of this quantizer: the apply kernel writes relu(x) back into x itself
+        cell = _hip.owned_relu_cell() if pre_relu else None
+        xback = bool(cell is not None and out_dtype == torch.float32
+                     and _hip.load().qs_quant_image_ok(1, 1, x.numel(), 0, 0, 1, _hip.dt(x)))
+        gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if (want_gate or xback) else None
         if want_gate:
             _hip.note_gate(gate_bits)
-        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update, saturate)
+        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update, saturate, xback=xback)
+        if xback:
+            cell["done"] = True
         ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.channels_last = x.dim() in (4, 5) and not x.is_contiguous()

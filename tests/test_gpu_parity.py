@@ -388,12 +388,12 @@ def test_abi_rejects_bad_arguments_loudly():
         quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
     lib = _hip.load()
     y = torch.empty(64, device=DEV)
-    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None)
+    st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None)
     assert st == -3 and b"aligned" in lib.qs_status_string(st)
-    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None) == -1
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 7, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None) == -1
     # an image without a gate bitmap (or from a geometry the gate-recording kernels do not serve) is rejected, nothing enqueued
     img = torch.empty(64, device=DEV, dtype=torch.bfloat16)
-    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 64, 0, 0, 0, 0, 0, 0, 1, 0, None, img.data_ptr(), 1, None) == -2
+    assert lib.qs_quant_scaler_fwd(y.data_ptr(), y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 64, 0, 0, 0, 0, 0, 0, 1, 0, None, img.data_ptr(), 1, None, None) == -2
     # odd storage offsets are re-packed by the binding instead of failing
     base = torch.randn(1001, device=DEV)
     assert same(quantize_with_scaler(base[1:], 8, 0.1).cpu(), O.scaler_fwd(base[1:].cpu(), 8, 0.1))
@@ -533,7 +533,7 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
                                 scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
-                                       1, 0, 0, 0, 0, 0, 0, 1, None, None, 0, stream) == 0
+                                       1, 0, 0, 0, 0, 0, 0, 1, None, None, 0, None, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
                                     N, C, H * W, 0, 1, 0, stream) == 0
 
@@ -1023,48 +1023,106 @@ def test_fp16_scale_quotient_is_rounded_to_fp16_and_relu_keeps_negative_zero():
 
 
 def test_multi_tensor_weight_kernels_match_the_per_tensor_ones():
-    """qs_multi_absmax / qs_multi_scale_update / qs_multi_quant_fwd over 60 tensors (more than one launch's worth of 48,
-    ragged sizes included) against qs_absmax / qs_scale_update / qs_quant_*_fwd per tensor."""
-    sizes = [1, 5, 8, 9, 63, 64, 100, 1000, 4096, 36864, 147456, 65, 12345] * 5
-    sizes = sizes[:60]
-    ws = [(torch.randn(n, generator=gen(300 + i)) * (0.05 + 0.01 * i)) for i, n in enumerate(sizes)]
-    wd = [w.to(DEV) for w in ws]
-    n = len(wd)
+    """qs_multi_absmax / qs_multi_scale_update / qs_multi_quant_fwd / qs_multi_ste_bwd over one device-resident table of 70
+    tensors -- tensor-wise and per channel along the first, a middle and the last dim, ragged sizes, 4-byte aligned starts,
+    rows that only quantize, a saturating row, a weight / bias pair sharing one counter -- against qs_absmax / qs_scale_update
+    / qs_quant_*_fwd / qs_quant_ste_bwd one tensor at a time."""
+    shapes = [(1,), (5,), (8,), (9,), (63,), (64,), (100,), (1000,), (4096,), (36864,), (147456,), (65,), (12345,)] * 3
+    # (shape, channel dim): conv weights along dim 1 and 0, linear weights along dim 1 (the last), a bias along dim 0,
+    # 1x1 convolutions (tall and narrow), a single-channel dim, a 3-d tensor along its middle dim
+    per_channel = [((64, 32, 3, 3), 1), ((64, 32, 3, 3), 0), ((10, 512), 1), ((48,), 0), ((2048, 96, 1, 1), 1), ((7, 5, 3), 1),
+                   ((16, 1, 5, 5), 1), ((3, 700), 1), ((700, 3), 1), ((513, 257), 0), ((4, 9, 1, 1), 1), ((128, 64, 1, 1), 0),
+                   ((33, 17, 2), 2), ((1, 40), 1), ((40, 1), 0)]
+    specs = [(sh, -1) for sh in shapes] + per_channel * 2
+    specs = specs[:70]
+    n = len(specs)
+    pool = torch.empty(sum(int(np.prod(sh)) + 16 for sh, _ in specs), device=DEV)      # tensors carved at 4-byte aligned starts
+    wd, off = [], 0
+    for i, (sh, ci) in enumerate(specs):
+        numel = int(np.prod(sh))
+        start = off + (i % 4)                                     # only every fourth tensor is 16-byte aligned
+        w = pool[start:start + numel].view(sh)
+        w.copy_((torch.randn(sh, generator=gen(300 + i)) * (0.05 + 0.01 * i)).to(DEV))
+        wd.append(w)
+        off = start + numel + 8
     bits = [2 + (i % 7) for i in range(n)]
     ts = [i % 4 for i in range(n)]
-    scales0 = [torch.rand(1, 1, generator=gen(400 + i)) * 0.1 for i in range(n)]
+    geo = [(1, 1, w.numel()) if ci < 0 or w.shape[ci] == 1 else
+           (int(np.prod(w.shape[:ci])), w.shape[ci], int(np.prod(w.shape[ci + 1:]))) for w, (sh, ci) in zip(wd, specs)]
+    chans = [g[1] for g in geo]
+    train = [i % 9 != 4 for i in range(n)]                        # some rows only quantize (evaluation hand-outs)
+    sat = {11: (-3, 2), 40: (0, 7)}                                # two saturating rows
     for decimal in (False, True):
-        # reference: one tensor at a time
-        ref_scales, ref_y = [], []
-        for w, b, t, s0 in zip(wd, bits, ts, scales0):
-            s = s0.clone().to(DEV)
-            _hip.scale_update(_hip.absmax(w, -1), s.view(-1), t, b)
+        scales0 = [torch.rand(c, 1, generator=gen(400 + i)) * 0.1 + 0.01 for i, c in enumerate(chans)]
+        # reference: one tensor at a time through the per-tensor entry points
+        ref_scales, ref_y, ref_gx = [], [], []
+        for i, (w, (sh, ci)) in enumerate(zip(wd, specs)):
+            ci_eff = ci if chans[i] > 1 else -1
+            s = scales0[i].clone().to(DEV)
+            wc = w.contiguous().clone()                           # (16-byte aligned copy for the per-tensor entry points)
+            if train[i]:
+                t = ts[50] + 1 if i == 51 else ts[i]              # row 51 plays the bias of row 50: shared counter, t + 1
+                _hip.scale_update(_hip.absmax(wc, ci_eff), s.view(-1), t, bits[i])
             ref_scales.append(s)
-            if decimal:
-                y, _ = _hip.quant_fwd("decimal", w, _hip.decimal_from_scale(s.view(-1)).view(1, 1), -1, torch.float32)
-            else:
-                y, _ = _hip.quant_fwd("scaler", w, s, -1, torch.float32)
+            param = _hip.decimal_from_scale(s.view(-1)).view(-1, 1) if decimal else s
+            y, _ = _hip.quant_fwd("decimal" if decimal else "scaler", wc, param if chans[i] > 1 else param.view(1, 1), ci_eff,
+                                  torch.float32, saturate=sat.get(i))
             ref_y.append(y)
-        amax = torch.zeros(n, 32, device=DEV)
+            g = torch.randn(sh, generator=gen(500 + i)).to(DEV)
+            ref_gx.append(_hip.ste_bwd(g, param if chans[i] > 1 else param.view(1, 1), decimal, ci_eff, -4.0, 3.0, False, torch.float32))
+        total_c = sum(chans)
+        amax, decs, backup = (torch.zeros(total_c, device=DEV) for _ in range(3))
         scales = [s0.clone().to(DEV) for s0 in scales0]
-        decs = torch.zeros(n, device=DEV)
+        t_devs = [torch.tensor([ts[i]], dtype=torch.int64, device=DEV) for i in range(n)]
+        t_devs[51] = t_devs[50]                                   # the shared counter
+        ts_before = [int(t.item()) for t in t_devs]
         bumps = torch.zeros(n, dtype=torch.int32, device=DEV)
-        numels = _hip.i64_array(sizes)
-        _hip.multi_absmax(n, _hip.ptr_array(wd), numels, _hip.ptr_array([amax[i] for i in range(n)]), wd[0].device)
-        _hip.multi_scale_update(n, _hip.ptr_array([amax[i] for i in range(n)]), _hip.ptr_array(scales),
-                                _hip.ptr_array([decs[i:i + 1] for i in range(n)]), _hip.i64_array(ts), _hip.ptr_array([None] * n),
-                                (_hip.c_int * n)(*bits), _hip.ptr_array([bumps[i:i + 1] for i in range(n)]), wd[0].device)
-        flat = torch.empty(sum((s + 63) // 64 * 64 for s in sizes), device=DEV)
-        outs, o = [], 0
-        for s in sizes:
-            outs.append(flat[o:o + s])
-            o += (s + 63) // 64 * 64
-        params = [decs[i:i + 1] for i in range(n)] if decimal else scales
-        _hip.multi_quant_fwd(n, _hip.ptr_array(wd), _hip.ptr_array(outs), _hip.ptr_array(params), numels, decimal, wd[0].device)
+        rows, offs, o, c0 = [], [], 0, 0
+        for i, w in enumerate(wd):
+            r = _hip.MultiRow()
+            sl = slice(c0, c0 + chans[i])
+            r.x, r.scale, r.amax, r.backup = w.data_ptr(), scales[i].data_ptr(), amax[sl].data_ptr(), backup[sl].data_ptr()
+            r.decimal = decs[sl].data_ptr() if decimal else None
+            r.t_dev, r.bump = t_devs[i].data_ptr(), bumps[i:i + 1].data_ptr()
+            r.numel, r.y_off = w.numel(), o
+            r.outer, r.C, r.inner = geo[i]
+            r.train, r.is_decimal, r.t_offset = int(train[i]), int(decimal), int(i == 51)
+            r.code_lo, r.code_hi = sat.get(i, (1, 0))
+            r.denom = float(2 ** (bits[i] - 1))
+            rows.append(r)
+            offs.append(o)
+            o += (w.numel() + 63) // 64 * 64
+            c0 += chans[i]
+        table = _hip.MultiTable(rows, wd[0].device)
+        assert table.channels == total_c
+        flat = torch.empty(o, device=DEV)
+        _hip.multi_absmax(table)
+        _hip.multi_scale_update(table)
+        if decimal:      # rows that do not train keep their scale: their decimals come from the caller
+            for i in range(n):
+                if not train[i]:
+                    decs[sum(chans[:i]):sum(chans[:i + 1])] = _hip.decimal_from_scale(scales[i].view(-1))
+        _hip.multi_quant_fwd(table, flat, advance=True)
+        for i, w in enumerate(wd):
+            assert torch.equal(scales[i], ref_scales[i]), (decimal, i, specs[i])
+            assert torch.equal(flat[offs[i]:offs[i] + w.numel()].view(w.shape), ref_y[i]), (decimal, i, specs[i])
+            sl = slice(sum(chans[:i]), sum(chans[:i + 1]))
+            if train[i]:
+                assert torch.equal(backup[sl], scales0[i].view(-1).to(DEV)), i           # what the update replaced
+        assert not amax.any()
+        assert bumps.tolist() == [int(tr) for tr in train]
         for i in range(n):
-            assert torch.equal(scales[i], ref_scales[i]), (decimal, i)
-            assert torch.equal(outs[i], ref_y[i]), (decimal, i, sizes[i])
-        assert not amax.any() and bool((bumps == 1).all())
+            moved = int(t_devs[i].item()) - ts_before[i]
+            assert moved == (2 if i in (50, 51) else int(train[i])), (i, moved)
+        # the grouped STE backward, per channel where the step is
+        gs = [torch.randn(sh, generator=gen(500 + i)).to(DEV) for i, (sh, _) in enumerate(specs)]
+        gx = [torch.empty_like(g) for g in gs]
+        steps = [(decs[sum(chans[:i]):sum(chans[:i + 1])] if decimal else scales[i]) for i in range(n)]
+        _hip.multi_ste_bwd(n, _hip.ptr_array(gs), _hip.ptr_array(gx), _hip.ptr_array(steps), _hip.i64_array([g.numel() for g in gs]),
+                           _hip.f32_array([-4.0] * n), _hip.f32_array([3.0] * n), decimal, wd[0].device,
+                           channels=_hip.i32_array(chans), inners=_hip.i64_array([g[2] for g in geo]))
+        for i in range(n):
+            assert torch.equal(gx[i], ref_gx[i]), (decimal, i, specs[i])
 
 
 @pytest.mark.parametrize("C", [48, 300, 2500])
@@ -1224,8 +1282,11 @@ def test_folded_relu_propagates_nan_like_the_module_by_module_path():
                                   qs.quantize(bits=4, channelwise=-1, timeout=1)),
             lambda: nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)))):
         runs = []
-        for fold in (True, False):
-            qs.set_qsparse_options(fold_relu=fold)
+        # (fold, elide_pruned): the folded site records the ReLU gate, loads every element and follows the reference on a NaN of
+        # a PRUNED channel in the default mode too; the unfolded NCHW pair elides by default (a pruned NaN gives f32(0) * s,
+        # the documented deviation), so its reference run is the strict mode
+        for fold, mode in ((True, "forward"), (False, "off"), (True, "off")):
+            qs.set_qsparse_options(fold_relu=fold, elide_pruned=mode)
             site = fuse_prune_quantize_pairs(make().to(DEV).train())
             outs = []
             for s in range(4):
@@ -1238,10 +1299,10 @@ def test_folded_relu_propagates_nan_like_the_module_by_module_path():
                 y.backward(torch.ones_like(y))
                 outs.append((y.detach().cpu(), xg.grad.cpu()))
             runs.append(outs)
-        qs.set_qsparse_options(fold_relu=True)
-        for s, ((ya, ga), (yb, gb)) in enumerate(zip(*runs)):
-            assert same(ya, yb) and same(ga, gb), s
-        if si != 1:     # (in the pair a NaN channel has NaN magnitude, is pruned, and never reaches the output or the scale)
+        qs.set_qsparse_options(fold_relu=True, elide_pruned="forward")
+        for s, ((ya, ga), (yb, gb), (yc, gc)) in enumerate(zip(*runs)):
+            assert same(ya, yb) and same(ga, gb) and same(ya, yc) and same(ga, gc), s
+        if si != 1:     # (in the pair a NaN channel has NaN magnitude, is pruned, and never reaches the scale)
             assert bool(runs[0][2][0].isnan().any())      # the NaN is visible in the step that received it
 
 

@@ -150,3 +150,71 @@ def test_a_view_keeps_atens_own_inplace_route():
         y = net(base[:, :4])                                  # in-place ReLU on a view: ATen's view bookkeeping
         assert "_OwnedReluBackward" not in _graph_names(y.grad_fn)
         y.sum().backward()
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,quantizer", [("pair", "scaler"), ("relu_q", "scaler"), ("pair", "decimal"), ("relu_p", "scaler")])
+def test_the_apply_kernel_writes_relu_back_itself(kind, quantizer, dtype, channels_last, monkeypatch):
+    """the in-place ReLU's FORWARD is not a pass of its own either.  The site's apply kernel loads every
+    element of x anyway and stores relu(x) back into x's storage (`xback_out`, include/qsparse_hip.h): ATen's `relu_` is not
+    called for the quantizing sites, in training (gate recorded) and in evaluation / no-grad forwards alike; x's storage holds
+    exactly what the reference's CPU `relu_` leaves there -- NaN and -0.0 pass, -inf becomes +0 -- and the site's output and
+    gradient are those of the module-by-module route.  (The prune-only site has no such kernel: it keeps ATen's pass.)"""
+    calls = []
+    real = torch.Tensor.relu_
+    monkeypatch.setattr(torch.Tensor, "relu_", lambda t: (calls.append(1), real(t))[1])
+    net, plain = _site(kind, True, quantizer), _site(kind, True, quantizer)
+    g = torch.Generator().manual_seed(3)
+    special = torch.tensor([-0.0, float("nan"), float("-inf"), float("inf"), -1.5, 2.5, -1e-30, 0.0])
+    for step in range(6):
+        train = step < 4
+        net.train(train), plain.train(train)
+        x0 = torch.randn(6, 16, 6, 8, generator=g).to(dtype)
+        if step == 2:         # training step: finite specials only (a NaN / Inf would poison the running statistics for good)
+            x0.view(-1)[7:15] = torch.tensor([-0.0, -1.5, 2.5, -1e-30, 0.0, -3.0, 1e-30, 4.0]).to(dtype)
+        if step == 5:         # evaluation: statistics are frozen
+            x0.view(-1)[7:15] = special.to(dtype)
+        xa = x0.clone().cuda()
+        if channels_last:
+            xa = xa.contiguous(memory_format=torch.channels_last)
+        xb = xa.clone()
+        xa.requires_grad_(train), xb.requires_grad_(train)
+        del calls[:]
+        qs.set_qsparse_options(fold_relu=True)
+        with torch.set_grad_enabled(train):
+            ha = xa * 1.0
+            ya = net(ha)
+        n_owned = len(calls)
+        qs.set_qsparse_options(fold_relu=False)
+        try:
+            with torch.set_grad_enabled(train):
+                hb = xb * 1.0
+                yb = plain(hb)
+        finally:
+            qs.set_qsparse_options(fold_relu=True)
+        active = step >= 1                                      # (step 0: the operators are not active yet, nothing is folded)
+        # the composite route (Scaler sites) writes back in training and in no-grad forwards; the fine-grained route (Decimal)
+        # where it records a gate, i.e. in training; the prune-only site never
+        kernel_wrote = active and kind != "relu_p" and (quantizer == "scaler" or train)
+        if active:
+            assert n_owned == (0 if kernel_wrote else 1), (step, n_owned)
+        got = ha.detach().cpu().contiguous()
+        bits = torch.int16 if dtype == torch.bfloat16 else torch.int32
+        if kernel_wrote:
+            want = torch.relu_(x0.clone())                      # the reference's own in-place ReLU, on the CPU (-0.0 stays -0.0)
+        else:
+            want = hb.detach().cpu().contiguous()               # ATen's pass on the device (module by module: the same kernel)
+        nan = want.isnan()                                      # (a NaN stays a NaN; its payload is ATen's business)
+        assert torch.equal(got.isnan(), nan) and torch.equal(got.view(bits)[~nan], want.view(bits)[~nan]), step
+        if step != 5:
+            assert torch.equal(ya, yb), step
+            if train:
+                ga, = torch.autograd.grad(ya.sum(), xa)
+                gb, = torch.autograd.grad(yb.sum(), xb)
+                assert torch.equal(ga, gb), step
+        else:       # NaN / Inf inputs: same values where the module-by-module route is finite, NaN where it is NaN
+            a, b = ya.detach().float(), yb.detach().float()
+            assert bool(((a == b) | (a.isnan() & b.isnan())).all()), step
+    for (ka, va), (kb, vb) in zip(net.state_dict().items(), plain.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka

@@ -253,5 +253,5 @@ def test_gate_needs_pre_relu():
     y = torch.empty_like(x)
     gate = torch.empty(8, dtype=torch.uint8, device=DEV)
     st = lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, None, 1, 0.5, None, 1, 1, 64, 0, 0, 0, 0, 0, 0, 0, 0,
-                                 gate.data_ptr(), None, 0, None)
+                                 gate.data_ptr(), None, 0, None, None)
     assert st == -2                            # QS_ERR_ARG: nothing enqueued

@@ -206,7 +206,9 @@ def test_weight_batcher_saturates_like_the_inline_path(quantizer):
         s = float(s_batched[k])
         step = s if quantizer is ScalerQuantizer else 2.0 ** -round(torch.log2(torch.tensor(1 / s)).item())
         codes = (w / step).round()
-        assert float(codes.max()) <= 7 and float(codes.min()) >= -8 and float(codes.max()) == 7
+        assert float(codes.max()) <= 7 and float(codes.min()) >= -8
+        if quantizer is ScalerQuantizer:         # (a power-of-two step may leave the largest element below the top code)
+            assert float(codes.max()) == 7
 
 
 @pytest.mark.parametrize("dev", DEVICES)

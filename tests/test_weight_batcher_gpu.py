@@ -56,11 +56,21 @@ def _state(model):
     return out
 
 
-def _build(quantizer="scaler", timeout=2):
+# quantizer configurations the scenarios run with: name -> (callback kind, channelwise, bias_bits).  "default" is the
+# reference's own default for quantize(): per channel along dim 1 (quantize.py:524); "bias" adds bias quantizers, which share
+# their layer's callback and its running-mean count t (quantize.py:548,559-571)
+KINDS = {"scaler": ("scaler", -1, -1), "decimal": ("decimal", -1, -1), "default": ("scaler", 1, -1),
+         "decimal_dim0_bias": ("decimal", 0, 6), "scaler_dim1_bias": ("scaler", 1, 8)}
+
+
+def _build(quantizer="scaler", timeout=2, channels_last=False):
+    kind, channelwise, bias_bits = KINDS[quantizer]
     torch.manual_seed(0)
-    cb = qs.DecimalQuantizer() if quantizer == "decimal" else None
-    model = qs.convert(Branchy(), qs.quantize(bits=4, channelwise=-1, timeout=timeout, callback=cb),
+    cb = qs.DecimalQuantizer() if kind == "decimal" else None
+    model = qs.convert(Branchy(), qs.quantize(bits=4, channelwise=channelwise, timeout=timeout, callback=cb, bias_bits=bias_bits),
                        weight_layers=[nn.Conv2d, nn.Linear], log=False).cuda().train()
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
     return model, torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
 
 
@@ -72,6 +82,9 @@ def _scenario(script, quantizer="scaler"):
         try:
             model, opt = _build(quantizer)
             assert (model.__dict__.get("_qs_weight_batcher") is not None) == batched
+            if batched:      # every layer takes part, with its bias when that is quantized
+                wb = model.__dict__["_qs_weight_batcher"]
+                assert len(wb.layers) == 5 and len(wb.units) == (10 if KINDS[quantizer][2] > 0 else 5)
             g = torch.Generator().manual_seed(3)
             trace, loose = [], []
 
@@ -96,9 +109,11 @@ def _scenario(script, quantizer="scaler"):
             script(model, step)
             torch.cuda.synchronize()
             model.eval()
-            for name, m in model.named_modules():       # the weight every layer would compute with now
+            for name, m in model.named_modules():       # the weight (and bias) every layer would compute with now
                 if isinstance(getattr(m, "quantize", None), QuantizeLayer):
                     trace.append(m.weight.detach().clone())
+                    if isinstance(getattr(m, "quantize_bias", None), QuantizeLayer):
+                        trace.append(m.bias.detach().clone())
             results.append((trace, _state(model), loose))
         finally:
             qs.set_qsparse_options(batch_weights=True)
@@ -113,7 +128,7 @@ def _scenario(script, quantizer="scaler"):
     return sa
 
 
-@pytest.mark.parametrize("quantizer", ["scaler", "decimal"])
+@pytest.mark.parametrize("quantizer", list(KINDS))
 def test_a_branch_the_forward_skips_is_rolled_back(quantizer):
     def script(model, step):
         for i in range(9):
@@ -123,10 +138,14 @@ def test_a_branch_the_forward_skips_is_rolled_back(quantizer):
     state = _scenario(script, quantizer)
     # the two branches really advanced differently (6 vs 3 reads, minus the 2 identity steps each saw)
     assert state["left.quantize._n_updates"].item() == 6 and state["right.quantize._n_updates"].item() == 3
-    assert state["left.quantize.<t>"].item() == 4 and state["right.quantize.<t>"].item() == 1
+    per_read = 2 if KINDS[quantizer][2] > 0 else 1       # a bias quantizer advances the shared count once more per forward
+    assert state["left.quantize.<t>"].item() == 4 * per_read and state["right.quantize.<t>"].item() == 1 * per_read
+    if per_read == 2:
+        assert state["left.quantize_bias._n_updates"].item() == 6 and state["left.quantize_bias.<t>"].item() == 8
 
 
-def test_an_exception_in_the_forward_rolls_back_what_was_not_read():
+@pytest.mark.parametrize("quantizer", ["scaler", "default", "decimal_dim0_bias"])
+def test_an_exception_in_the_forward_rolls_back_what_was_not_read(quantizer):
     def script(model, step):
         for i in range(8):
             model.fail = i in (3, 5)
@@ -139,11 +158,12 @@ def test_an_exception_in_the_forward_rolls_back_what_was_not_read():
             else:
                 step()
 
-    state = _scenario(script)
+    state = _scenario(script, quantizer)
     assert state["stem.quantize._n_updates"].item() == 8 and state["head.quantize._n_updates"].item() == 6
 
 
-def test_eval_train_switches_and_forwards_without_backward():
+@pytest.mark.parametrize("quantizer", ["scaler", "default", "scaler_dim1_bias", "decimal_dim0_bias"])
+def test_eval_train_switches_and_forwards_without_backward(quantizer):
     def script(model, step):
         for i in range(12):
             if i in (4, 5, 9):
@@ -154,10 +174,11 @@ def test_eval_train_switches_and_forwards_without_backward():
             else:
                 step(backward=i != 7)
 
-    _scenario(script)
+    _scenario(script, quantizer)
 
 
-def test_a_layer_read_twice_and_a_weight_written_before_its_read():
+@pytest.mark.parametrize("quantizer", ["scaler", "default", "decimal_dim0_bias"])
+def test_a_layer_read_twice_and_a_weight_written_before_its_read(quantizer):
     def script(model, step):
         model.twice = True
         bump = []
@@ -180,7 +201,7 @@ def test_a_layer_read_twice_and_a_weight_written_before_its_read():
             h.remove()
         step()
 
-    state = _scenario(script)
+    state = _scenario(script, quantizer)
     assert state["shared.quantize._n_updates"].item() == 16       # two reads per forward, both counted
 
 
@@ -339,3 +360,104 @@ def test_a_frozen_weight_hands_out_a_weight_that_does_not_require_grad():
         assert torch.equal(a, b)
     for k in res[0][3]:
         assert torch.equal(res[0][3][k], res[1][3][k]), k
+
+
+class BiasFirst(nn.Module):
+    """a layer whose forward reads the bias BEFORE the weight (a fused bias-activation kernel would): the reference then updates
+    the bias statistics with the callback's count t and the weight's with t + 1 -- the other way round from nn.Conv2d"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 6)
+        self.b = nn.Linear(6, 4)
+        self.bias_first = True
+
+    def forward(self, x):
+        h = torch.relu(self.a(x))
+        if self.bias_first:
+            bias = self.b.bias
+            return F.linear(h, self.b.weight) + bias
+        return self.b(h)
+
+
+@pytest.mark.parametrize("kind", ["scaler", "decimal"])
+def test_a_bias_read_before_its_weight_follows_the_order_of_the_reads(kind):
+    results = []
+    for batched in (True, False):
+        qs.set_qsparse_options(batch_weights=batched)
+        try:
+            torch.manual_seed(0)
+            cb = qs.DecimalQuantizer() if kind == "decimal" else None
+            model = qs.convert(BiasFirst(), qs.quantize(bits=6, channelwise=0, timeout=1, bias_bits=6, callback=cb),
+                               weight_layers=[nn.Linear], log=False).cuda().train()
+            g = torch.Generator().manual_seed(5)
+            outs = []
+            for i in range(8):
+                model.bias_first = i not in (5, 6)
+                x = torch.randn(3, 6, generator=g).cuda()
+                y = model(x)
+                y.sum().backward()
+                with torch.no_grad():
+                    for prm in model.parameters():
+                        if prm.requires_grad:
+                            prm.add_(torch.randn(prm.shape, generator=g).cuda() * 0.05)
+                            prm.grad = None
+                outs.append(y.detach().clone())
+            results.append((outs, _state(model)))
+        finally:
+            qs.set_qsparse_options(batch_weights=True)
+    (oa, sa), (ob, sb) = results
+    for a, b in zip(oa, ob):
+        assert torch.equal(a, b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_reference_default_quantize_on_every_resnet50_weight_vs_the_oracle_in_a_handful_of_launches(channels_last, monkeypatch):
+    """a user who writes `convert(model, quantize(bits=8), weight_layers=[...])` gets the reference's DEFAULT,
+    a per-channel quantizer along dim 1 (quantize.py:524).  All 54 weights of a ResNet-50 take the multi-tensor path: three
+    launches per forward (any number of tensors: the descriptor table lives on the device) and one per eight layers in the
+    backward; every running scale follows the oracle's QuantizeSim fed with the raw parameter of that step, the effective
+    weights equal its output, contiguous and channels_last (memory view [Cout*kh*kw, Cin, 1]) alike."""
+    from examples.models import resnet50
+    from oracle import qs_oracle as O
+    from qsparse_amd import _hip
+    torch.manual_seed(0)
+    model = qs.convert(resnet50(10, False, width=16), qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear],
+                       log=False).cuda().train()
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    wb = model.__dict__["_qs_weight_batcher"]
+    layers = {name: m for name, m in model.named_modules() if isinstance(getattr(m, "quantize", None), QuantizeLayer)}
+    assert len(layers) == 54 and len(wb.units) == 54 and all(m.quantize.channelwise == 1 for m in layers.values())
+    sims = {name: O.QuantizeSim("scaler", 8, 1, 1, batch_dimension=-1) for name in layers}
+    calls = []
+    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_ste_bwd", "absmax", "scale_update", "quant_fwd", "ste_bwd"):
+        real = getattr(_hip, fn)
+        monkeypatch.setattr(_hip, fn, (lambda real, fn: (lambda *a, **k: (calls.append(fn), real(*a, **k))[1]))(real, fn))
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    g = torch.Generator().manual_seed(2)
+    for step in range(5):
+        raw = {name: m._parameters["weight"].detach().cpu().contiguous().clone() for name, m in layers.items()}
+        x = torch.randn(4, 3, 64, 64, generator=g).cuda()
+        if channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        del calls[:]
+        opt.zero_grad()
+        model(x).square().mean().backward()
+        if step >= 1:       # (step 0 is the identity step of timeout=1: nothing to launch)
+            assert calls.count("multi_absmax") == 1 and calls.count("multi_scale_update") == 1 and calls.count("multi_quant_fwd") == 1
+            assert calls.count("multi_ste_bwd") == 7 and not {"absmax", "scale_update", "quant_fwd", "ste_bwd"} & set(calls), calls
+        opt.step()
+        for name, m in layers.items():
+            sims[name].step(raw[name], True)
+            if sims[name].weight is not None and m.quantize.initted:
+                assert torch.equal(m.quantize.weight.detach().cpu(), sims[name].weight), (step, name)
+            assert m.quantize._n_updates.item() == sims[name].n_updates and m.quantize.callback.t == sims[name].shared["t"]
+    model.eval()
+    with torch.no_grad():
+        model(x)                                   # evaluation hand-out (batched)
+        for name, m in layers.items():
+            w = m._parameters["weight"].detach().cpu().contiguous()
+            assert torch.equal(m.weight.detach().cpu().contiguous(), sims[name].apply(w, False)), name

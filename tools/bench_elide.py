@@ -75,7 +75,7 @@ def main():
                     if kernel == "fwd":
                         def fn():
                             assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(),
-                                                           outer, Cc, inner, 1, 0, 0, 0, 0, 0, 0, elide, None, None, 0, None) == 0
+                                                           outer, Cc, inner, 1, 0, 0, 0, 0, 0, 0, elide, None, None, 0, None, None) == 0
                         rd, wr = 2, 4
                     else:
                         def fn():

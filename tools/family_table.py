@@ -34,7 +34,7 @@ def main():
     qs_rows = [r for r in rows if "qs::" in r["Kernel_Name"]]
     steps = meta["steps"]
     # launches per step as the TRACE has them: the event log behind `launches_per_step` keeps to the fine-grained entry
-    # points, a real step may fuse launches (qs_site_fwd's last-two-stages + select kernel).  The K steady-state steps are
+    # points, a real step may go through composite entry points that launch differently.  The K steady-state steps are
     # identical, so the per-step count is the smallest period of the kernel-name sequence at the end of the trace.
     names = [r["Kernel_Name"].split("(")[0] for r in qs_rows]
     per_step = meta["launches_per_step"]

@@ -22,7 +22,7 @@ stage = torch.empty(C * H * W, device=dev, dtype=torch.bfloat16)
 amax = torch.zeros(C, device=dev)
 big = torch.empty(300 * 1024 * 1024, device=dev, dtype=torch.uint8)
 
-def fwd(): lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE, None, None, 0, None)
+def fwd(): lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE, None, None, 0, None, None)
 def bwd(): lib.qs_quant_ste_bwd(gout.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(), N, C, H * W, 0, 1, 0, None)
 def stats(): lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, None)
 def readg(): lib.qs_absmax(gout.data_ptr(), amax.data_ptr(), 0, 1, 1, numel, 0, 0, 0, 1, None, 0, None)

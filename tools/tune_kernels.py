@@ -65,7 +65,7 @@ def run_variant(path):
 
     def fwd():
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C,
-                                       H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE_FWD, None, None, 0, None) == 0
+                                       H * W, 1, 0, 0, 0, 0, 0, 0, ELIDE_FWD, None, None, 0, None, None) == 0
 
     def bwd():
         assert lib.qs_quant_ste_bwd(gout.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0,
