@@ -110,8 +110,9 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
 int qs_quant_image_ok(int64_t outer, int64_t C, int64_t inner, int per_channel_param, int has_mask, int mask_aligned8, int xdt);
 
 /* xback_out (nullable; same kernels and conditions as image_out -- gate_out, ydt == QS_F32, codes == NULL, a geometry for which
- * qs_quant_image_ok answers 1): the same pass also stores relu(x) in xdt at xback_out[e] -- ATen's clamp_min(x, 0), NaN and -0.0
- * pass.  With xback_out == x this IS the forward of an nn.ReLU(inplace=True) standing in front of the operator (what
+ * qs_quant_image_ok answers 1): the same pass also stores act(x) in xdt at xback_out[e] -- nn.ReLU: ATen's clamp_min(x, 0), NaN
+ * and -0.0 pass; any other folded activation likewise.  With xback_out == x this IS the forward of an nn.ReLU(inplace=True) /
+ * nn.ReLU6(inplace=True) standing in front of the operator (what
  * torchvision-style networks carry where the reference's convert() puts its operators, qsparse/convert.py:199-229): other
  * holders of x see relu(x) as they must, at the price of one more store (+2 / +4 B/elem) instead of ATen's read + write pass
  * (4 / 8 B/elem).  Every lane reads the elements it rewrites before it rewrites them; no other lane touches them. */

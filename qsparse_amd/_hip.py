@@ -40,7 +40,8 @@ SIGNATURES = {
     "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P, _P]),
     "qs_quant_decimal_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P, _P]),
     "qs_quant_image_ok": (c_int, [_L, _L, _L, _I, _I, _I, _I]),
-    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _P, _I, _P]),
+    "qs_quant_ste_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P, _L, _L, _L, _I, _I, _I, _I, _P, _I, _P]),
+    "qs_activation": (c_int, [_I, _F, _F]),
     "qs_quant_line_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _L, _I, _I, _P]),
     "qs_quant_ste_bwd": (c_int, [_P, _P, _P, _L, _F, _I, _F, _F, _I, _P, _L, _L, _L, _I, _I, _I, _P]),
     "qs_absmax": (c_int, [_P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _P, c_size_t, _P]),
@@ -80,7 +81,7 @@ class SitePlanStruct(ctypes.Structure):
                 ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
-                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32)]
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32)]
 
 
 class MultiRow(ctypes.Structure):
@@ -323,6 +324,74 @@ def note_gate(bits: torch.Tensor):
         cell["bits"] = bits
 
 
+ACT_RELU, ACT_HARDTANH, ACT_LEAKY = 1, 2, 3
+_act_handles = {}
+
+
+def activation(kind: int, a: float = 0.0, b: float = 0.0) -> int:
+    """handle of a folded activation (qs_activation): what the `pre_relu` arguments below take besides False / True"""
+    key = (kind, float(a), float(b))
+    h = _act_handles.get(key)
+    if h is None:
+        h = load().qs_activation(kind, float(a), float(b))
+        if h < 0:
+            _check(h, "qs_activation")
+        _act_handles[key] = h
+    return h
+
+
+def act_spec(handle: int):
+    """(kind, a, b) of a handle made by `activation` (1: nn.ReLU)"""
+    if handle == 1:
+        return (ACT_RELU, 0.0, 0.0)
+    for key, h in _act_handles.items():
+        if h == handle:
+            return key
+    raise KeyError(handle)
+
+
+def act_torch(pre_relu, x: torch.Tensor) -> torch.Tensor:
+    """the folded activation as an ATen expression (out of place): the routes that have to materialise it after all"""
+    kind, a, b = act_spec(_act(pre_relu))
+    if kind == ACT_RELU:
+        return torch.relu(x)
+    if kind == ACT_HARDTANH:
+        return torch.nn.functional.hardtanh(x, a, b)
+    return torch.nn.functional.leaky_relu(x, a)
+
+
+def act_torch_(pre_relu, x: torch.Tensor) -> torch.Tensor:
+    """... and in place"""
+    kind, a, b = act_spec(_act(pre_relu))
+    if kind == ACT_RELU:
+        return x.relu_()
+    if kind == ACT_HARDTANH:
+        return torch.nn.functional.hardtanh_(x, a, b)
+    return torch.nn.functional.leaky_relu_(x, a)
+
+
+def act_gate_of(pre_relu, h: torch.Tensor) -> torch.Tensor:
+    """the backward's gate (True: the gradient passes unchanged) from the activation's INPUT or -- the rectifiers and a leaky
+    ReLU with a positive slope map both to the same side -- its output"""
+    kind, a, b = act_spec(_act(pre_relu))
+    if kind == ACT_HARDTANH:
+        return (h > a) & (h < b)
+    if kind == ACT_LEAKY:
+        return h > 0
+    return ~(h <= 0)
+
+
+def mean_flags(take_abs: bool, pre_relu=False, l0: bool = False) -> int:
+    """flags of qs_mean_dim / qs_mean_dim_cl; a folded activation other than nn.ReLU rides as QS_MEAN_ACT(handle)"""
+    h = _act(pre_relu)
+    return (MEAN_ABS if take_abs else 0) | (MEAN_L0 if l0 else 0) | ((MEAN_RELU | ((h << 8) if h > 1 else 0)) if h else 0)
+
+
+def _act(pre_relu) -> int:
+    """`pre_relu` as the ABI takes it: 0 (no folded activation), 1 (nn.ReLU; also True) or a qs_activation() handle"""
+    return int(pre_relu) if pre_relu else 0
+
+
 def owned_relu_cell():
     """the cell of the owned in-place ReLU whose site is being evaluated on this thread (fused.py::_with_owned_relu), or None.
     cell["defer"]: the ReLU has NOT been applied to x yet -- the site's apply kernel may write relu(x) back itself (xback_out of
@@ -393,7 +462,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
         xb = x                 # relu(x) lands in x's own storage (x IS the in-place ReLU's tensor, addressed in memory order)
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None, xb):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, int(bool(pre_relu)), _elide_fwd(x is not like, gate is not None) if cm is not None else 0,
+                _DT[qdtype], sat, lo, hi, _act(pre_relu), _elide_fwd(x is not like, gate is not None) if cm is not None else 0,
                 _ptr(gate.bits) if gate is not None else None, None, 0, _ptr(xb), _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     if xb is not None:
@@ -442,7 +511,7 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
 
 def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
                  chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1, gate: Optional[ReluGate] = None,
-                 g2: Optional[torch.Tensor] = None):
+                 g2: Optional[torch.Tensor] = None, act=1):
     """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate.  With `gate` (the
     bitmap `quant_fwd(want_gate=True)` recorded) x is not needed.  `g2` (with `gate`; bf16 / fp16): a second gradient that
     is added to the float32 `g` in float32 before the clamp; `g` may then be None."""
@@ -482,7 +551,7 @@ def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, ste
             st = lib.qs_quant_ste_relu_bwd(_ptr(gm), None, _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host,
                                            int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner,
                                            F32 if gm is None else dt(gm), _DT[gate.dtype],
-                                           _elide_all() if (cm is not None and g2m is None) else 0, _ptr(g2m),
+                                           _elide_all() if (cm is not None and g2m is None) else 0, _act(act) or 1, _ptr(g2m),
                                            0 if g2m is None else dt(g2m), _stream(refm))
         _check(st, "qs_quant_ste_relu_bwd")
         return gx
@@ -506,7 +575,7 @@ def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, ste
     with _timed("quant_ste_relu_bwd", g, x, gx):
         st = lib.qs_quant_ste_relu_bwd(_ptr(g), _ptr(x), None, _ptr(gx), _ptr(pt), n, host, int(bool(step_is_decimal)),
                                        float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner, dt(g), dt(x),
-                                       _elide_all() if cm is not None else 0, None, 0, _stream(g))
+                                       _elide_all() if cm is not None else 0, _act(act) or 1, None, 0, _stream(g))
     _check(st, "qs_quant_ste_relu_bwd")
     return gx
 
@@ -557,7 +626,7 @@ def absmax(x: torch.Tensor, channel_index: int, accumulate_into: Optional[torch.
     ws, ws_bytes = _reduce_workspace(x, channel_index, outer, C, inner)
     with _timed("absmax", x):
         st = lib.qs_absmax(_ptr(x), _ptr(out), int(channel_index >= 0), outer, C, inner, dt(x),
-                           int(accumulate_into is not None), int(bool(pre_relu)), lines, _ptr(ws), ws_bytes, _stream(x))
+                           int(accumulate_into is not None), _act(pre_relu), lines, _ptr(ws), ws_bytes, _stream(x))
     _check(st, "qs_absmax")
     return out
 
@@ -767,7 +836,7 @@ def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False, want
     sizes = (c_int64 * nd)(*x.shape)
     mstr = (c_int64 * nd)(*[0 if m.shape[d] == 1 else m.stride(d) for d in range(nd)])
     with _timed("mask_apply", x, y, gate.bits if gate is not None else None):
-        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), int(bool(pre_relu)), _elide_all(),
+        st = lib.qs_mask_apply(_ptr(x), _ptr(m), _ptr(y), nd, sizes, mstr, dt(x), _act(pre_relu), _elide_all(),
                                _ptr(gate.bits) if gate is not None else None, _stream(x))
     _check(st, "qs_mask_apply")
     return (y, gate) if want_gate else y
@@ -837,7 +906,7 @@ def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Te
                                  None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
                                  x.numel(), _DT[x.dtype], _DT[(y if y is not None else x).dtype], int(bits), int(t),
                                  None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
-                                 int(bool(pre_relu)), int(update), sat, lo, hi, x.data_ptr() if xback else None, _stream(x))
+                                 _act(pre_relu), int(update), sat, lo, hi, x.data_ptr() if xback else None, _stream(x))
     if st:
         _check(st, "qs_quantize_step")
 

@@ -42,7 +42,7 @@ int qs_quant_scaler_fwd(const void* x, void* y, int32_t* codes, const float* sca
     if (image_out && !image_route_ok(outer, C, inner, nscale > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
     ActSpec act;
     if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
-    if (xback_out && (act.kind != QS_ACT_RELU || !aligned16(xback_out) ||
+    if (xback_out && (act.kind == QS_ACT_NONE || !aligned16(xback_out) ||
                       !widen_route_ok(outer, C, inner, nscale > 1, chan_mask, codes, gate_out, xdt, ydt)))
         return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;
@@ -79,7 +79,7 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes, const float* de
     if (image_out && !image_route_ok(outer, C, inner, ndecimal > 1, chan_mask, codes, gate_out, xdt, ydt, imgdt, image_out)) return QS_ERR_ARG;
     ActSpec act;
     if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
-    if (xback_out && (act.kind != QS_ACT_RELU || !aligned16(xback_out) ||
+    if (xback_out && (act.kind == QS_ACT_NONE || !aligned16(xback_out) ||
                       !widen_route_ok(outer, C, inner, ndecimal > 1, chan_mask, codes, gate_out, xdt, ydt)))
         return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(ydt) || !dt_ok(qdt)) return QS_ERR_DTYPE;

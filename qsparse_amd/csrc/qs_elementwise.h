@@ -321,18 +321,18 @@ __device__ __forceinline__ void image_store(void* img, int dt, int64_t e, const 
     if constexpr (N == 8) *(u32x4*)((uint16_t*)img + e) = u32x4{w[0], w[1], w[2], w[3]};
     else *(u32x2*)((uint16_t*)img + e) = u32x2{w[0], w[1]};
 }
-// relu(v[0..N)) (ATen's clamp_min: NaN and -0.0 pass) back in dtype DT at element e (a multiple of N): one store of N values
+// act(v[0..N)) (nn.ReLU: ATen's clamp_min, NaN and -0.0 pass) back in dtype DT at element e (a multiple of N): one store of N
 template <int N, int DT>
-__device__ __forceinline__ void xback_store(void* xb, int64_t e, const float* v) {
+__device__ __forceinline__ void xback_store(void* xb, int64_t e, const float* v, const ActSpec& act) {
     if constexpr (DT == QS_F32) {
         static_assert(N == 4, "fp32 inputs take the 4-elements-per-lane paths");
-        *(u32x4*)((float*)xb + e) = u32x4{__float_as_uint(relu_aten(v[0])), __float_as_uint(relu_aten(v[1])),
-                                          __float_as_uint(relu_aten(v[2])), __float_as_uint(relu_aten(v[3]))};
+        *(u32x4*)((float*)xb + e) = u32x4{__float_as_uint(act_apply(v[0], act, DT)), __float_as_uint(act_apply(v[1], act, DT)),
+                                          __float_as_uint(act_apply(v[2], act, DT)), __float_as_uint(act_apply(v[3], act, DT))};
     } else {
         uint32_t w[N / 2];
 #pragma unroll
         for (int j = 0; j < N / 2; ++j) {   // (the values are DT values already: the conversion is exact)
-            const float a = relu_aten(v[2 * j]), b = relu_aten(v[2 * j + 1]);
+            const float a = act_apply(v[2 * j], act, DT), b = act_apply(v[2 * j + 1], act, DT);
             const uint32_t lo = (DT == QS_BF16) ? f32_to_bf16_bits(a) : f32_to_f16_bits(a);
             const uint32_t hi = (DT == QS_BF16) ? f32_to_bf16_bits(b) : f32_to_f16_bits(b);
             w[j] = lo | (hi << 16);
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
             if constexpr (!ELIDE) unpack8<XDT>(load8_raw<XDT, NT>(x, e / 8), v);
             if constexpr (GATE) {
                 OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)gate_bits<8>(v, OpGate<Op>::act(op));
-                if (void* xb = OpGate<Op>::xback(op)) xback_store<8, XDT>(xb, e, v);
+                if (void* xb = OpGate<Op>::xback(op)) xback_store<8, XDT>(xb, e, v, OpGate<Op>::act(op));
             }
             int32_t q;
             u32x4 a, b;
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                 const uint32_t nib = gate_bits<4>(v, OpGate<Op>::act(op));
                 const uint32_t other = gate_pair_swap(nib);      // both lanes of a pair are inside or outside the tensor together
                 if ((lane & 1) == 0) OpGate<Op>::ptr(op)[e >> 3] = (uint8_t)(nib | (other << 4));
-                if (void* xb = OpGate<Op>::xback(op)) xback_store<4, XDT>(xb, e, v);
+                if (void* xb = OpGate<Op>::xback(op)) xback_store<4, XDT>(xb, e, v, OpGate<Op>::act(op));
             }
             int32_t q;
             u32x4 out;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
         const float xe = load1<XDT>(x, e);
         if constexpr (GATE) {
             gate_store_tail(OpGate<Op>::ptr(op), geo.ngroups, act_open(xe, OpGate<Op>::act(op)));
-            if (void* xb = OpGate<Op>::xback(op)) store1<XDT>(xb, e, relu_aten(xe));
+            if (void* xb = OpGate<Op>::xback(op)) store1<XDT>(xb, e, act_apply(xe, OpGate<Op>::act(op), XDT));
         }
         y[e] = op.apply(xe, p, qi);
         if constexpr (GATE) {

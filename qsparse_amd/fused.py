@@ -134,7 +134,7 @@ class _FusedApply(torch.autograd.Function):
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
-                                   limit - 1 + ctx.notch, mask_c, gate=gate)
+                                   limit - 1 + ctx.notch, mask_c, gate=gate, act=ctx.pre_relu)
             return (gx,) + (None,) * 8
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
@@ -164,7 +164,7 @@ class _SitePlan:
         return (_SitePlan, ())
 
 
-def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
+def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     """the cached plan of this site for inputs like `h`, or None when the site is not one the composite call covers
     (4-d NCHW / channels_last activation with a batch of at least two, tensor-wise ScalerQuantizer, state on h's device)"""
     cb, qc = p.callback, q.callback
@@ -189,7 +189,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     t_q_dev = qc.device_t(h.device) if graph_safe else None
     out_dtype = _out_dtype(h)
     sat = qc.code_range(q.bits)
-    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat) + tuple(t.data_ptr() for t in state) + \
+    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat, act) + tuple(t.data_ptr() for t in state) + \
         ((t_q_dev.data_ptr(),) if t_q_dev is not None else ())
     plan = q.__dict__.get("_qs_site_plan")
     if plan is not None and plan.key == key:
@@ -211,6 +211,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor):
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
     c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
+    c.act = int(act) or 1                # the activation QS_SITE_PRE_RELU folds at this site (1: nn.ReLU)
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
@@ -320,6 +321,7 @@ class _SiteStep(torch.autograd.Function):
         if xback:
             cell["done"] = True
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
+        ctx.act = plan.c.act
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
@@ -363,16 +365,17 @@ class _SiteStep(torch.autograd.Function):
         scale = scale.detach()
         if pre_relu:
             gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
-            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, False, lo_mul, hi_mul, mask, gate=gate)
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, False, lo_mul, hi_mul, mask, gate=gate, act=ctx.act)
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
         return (gx,) + (None,) * (n_in - 1)
 
 
-def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
-    """one training / evaluation step of ``q(p(h))`` on a GPU tensor -- or of ``q(p(relu(h)))`` with ``pre_relu``
-    (the caller guarantees that the quantizer is active this step, so the ReLU is applied inside the kernels)."""
+def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu=False) -> torch.Tensor:
+    """one training / evaluation step of ``q(p(h))`` on a GPU tensor -- or of ``q(p(act(h)))`` with ``pre_relu``: True for a
+    folded nn.ReLU, or the handle of another folded activation (``_fold_handle``; the caller guarantees that the quantizer is
+    active this step, so the activation is applied inside the kernels)."""
     cb, qc = p.callback, q.callback
     C = h.shape[1]
 
@@ -428,7 +431,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     world = qdist.stats_world_size()
     exchange = qdist.exchange_active(world)      # (only a live step has statistics to exchange)
     if (live or idle) and not _hip.logging_events():
-        site = _site_plan(p, q, h)
+        site = _site_plan(p, q, h, int(pre_relu) or 1)
     if site is not None and live:        # the counters ride in the select launch, as on the fine-grained route (the flags
         bump_p = bump_q = bump_t = True   # below only ask WHETHER they did)
         select_bumped_tq = bool(get_option("graph_safe"))
@@ -526,9 +529,9 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
 
     # ---- apply: one read of h, one write ----
     if not prune_on and not quant_on:
-        return torch.relu(h) if pre_relu else h
+        return _hip.act_torch(pre_relu, h) if pre_relu else h
     if pre_relu and not quant_on:      # cannot happen when the caller checked q.is_active(); stay correct anyway
-        h, pre_relu = torch.relu(h), False
+        h, pre_relu = _hip.act_torch(pre_relu, h), False
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
     if site is not None:
         flags = ((_hip.SITE_LIVE if live else 0) | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
@@ -567,7 +570,7 @@ class _OwnedRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cell):
         if not cell.get("defer"):        # deferred: the site's apply kernel (or `_with_owned_relu` after it) rectifies x
-            x.relu_()
+            _hip.act_torch_(cell["act"], x)
         ctx.mark_dirty(x)
         ctx.cell = cell
         ctx.layout = (x.shape, x.stride())   # (x itself is NOT kept for the backward, unlike ATen's in-place ReLU)
@@ -580,8 +583,10 @@ class _OwnedRelu(torch.autograd.Function):
         if g is None or g is gated:
             return g, None
         # the rare route: the gate as the site recorded it (or, where the site recorded none, from the tensor itself)
-        open_ = (_hip.unpack_gate(cell["bits"], *ctx.layout) if "bits" in cell else ~(cell["h"] <= 0))
-        return torch.where(open_, g, torch.zeros((), dtype=g.dtype, device=g.device)), None      # threshold_backward: NaN passes
+        open_ = (_hip.unpack_gate(cell["bits"], *ctx.layout) if "bits" in cell else _hip.act_gate_of(cell["act"], cell["h"]))
+        kind, slope, _ = _hip.act_spec(cell["act"])
+        closed = g * slope if kind == _hip.ACT_LEAKY else torch.zeros((), dtype=g.dtype, device=g.device)
+        return torch.where(open_, g, closed), None      # (threshold_backward: NaN passes)
 
 
 class _Tap(torch.autograd.Function):
@@ -596,20 +601,41 @@ class _Tap(torch.autograd.Function):
         return g, None
 
 
-def _foldable_relu(act, x) -> int:
-    """0: not a ReLU the kernels can absorb; 1: out-of-place nn.ReLU; 2: nn.ReLU(inplace=True) on a tensor the library may own
-    (a leaf that requires grad raises in the plain module -- let it; in-place on views stays with ATen's view bookkeeping)"""
-    if type(act) is not nn.ReLU or not get_option("fold_relu"):
-        return 0
-    if not act.inplace:
+_FOLDABLE = (nn.ReLU, nn.ReLU6, nn.Hardtanh, nn.LeakyReLU)
+
+
+def _fold_handle(act) -> int:
+    """what the kernels' `pre_relu` arguments take for this activation module: 1 for nn.ReLU, a `_hip.activation` handle for
+    nn.ReLU6 / nn.Hardtanh (clamp to [a, b]; backward 0 outside (a, b)) and nn.LeakyReLU (slope > 0); 0: not foldable"""
+    t = type(act)
+    if t is nn.ReLU:
         return 1
-    if (not isinstance(x, torch.Tensor) or not x.is_cuda or x._is_view() or (x.is_leaf and x.requires_grad)
-            or not get_option("relu_gate")):
-        return 0
-    return 2
+    if t in (nn.ReLU6, nn.Hardtanh):       # (nn.ReLU6 is a Hardtanh with min_val = 0, max_val = 6)
+        return _hip.activation(_hip.ACT_HARDTANH, float(act.min_val), float(act.max_val))
+    if t is nn.LeakyReLU and act.negative_slope > 0:
+        return _hip.activation(_hip.ACT_LEAKY, float(act.negative_slope))
+    return 0
 
 
-def _with_owned_relu(x: torch.Tensor, site):
+def _foldable_relu(act, x):
+    """(fold, handle).  fold 0: not an activation the kernels can absorb; 1: out of place; 2: ``inplace=True`` on a tensor the
+    library may own (a leaf that requires grad raises in the plain module -- let it; in-place on views stays with ATen's view
+    bookkeeping).  handle: see `_fold_handle`."""
+    if type(act) not in _FOLDABLE or not get_option("fold_relu") or not isinstance(x, torch.Tensor) or not x.is_cuda:
+        return 0, 0
+    handle = _fold_handle(act)
+    if not handle:
+        return 0, 0
+    if not act.inplace:
+        return 1, handle
+    if x._is_view() or (x.is_leaf and x.requires_grad) or not get_option("relu_gate"):
+        return 0, 0
+    if handle != 1 and type(act) is nn.LeakyReLU and x.data_ptr() % 16:
+        return 0, 0          # (not idempotent: it can only be folded when the kernel -- not ATen beforehand -- applies it)
+    return 2, handle
+
+
+def _with_owned_relu(x: torch.Tensor, site, act: int = 1):
     """x <- relu(x) in place, then `site(h)` on the alias the fused site reads (with `pre_relu`: max(h, 0) == h, its gate bits
     are h > 0); the bitmap the site records is also what `_OwnedRelu`'s rare route gates with"""
     # The ReLU is DEFERRED: x keeps its raw values while the site runs -- every one of its kernels takes `pre_relu` and reads
@@ -617,7 +643,7 @@ def _with_owned_relu(x: torch.Tensor, site):
     # (xback_out of qs_quant_scaler_fwd: +2 / +4 B/elem instead of ATen's 4 / 8 B/elem read + write pass).  A site whose route
     # has no such kernel leaves x raw; the ATen pass below then runs after it -- same tensor contents either way, and in
     # stream order before anything else can read x.
-    cell = {"defer": x.data_ptr() % 16 == 0}
+    cell = {"defer": x.data_ptr() % 16 == 0, "act": act}
     h = _Tap.apply(_OwnedRelu.apply(x, cell), cell)
     outer = getattr(_hip._gate_sink, "cell", None)
     _hip._gate_sink.cell = cell
@@ -627,7 +653,7 @@ def _with_owned_relu(x: torch.Tensor, site):
         _hip._gate_sink.cell = outer
         if cell.get("defer") and not cell.get("done"):
             with torch.no_grad():
-                x.relu_()
+                _hip.act_torch_(act, x)
             cell["done"] = True
     if "bits" not in cell and torch.is_grad_enabled() and h.requires_grad:
         cell["h"] = h.detach()               # a site that recorded no gate this step (quantizer idle ...) kept x itself anyway
@@ -656,11 +682,11 @@ class FusedPruneQuantize(nn.Sequential):
         # a plain, out-of-place nn.ReLU in front of an active quantizer is folded into the kernels: relu(x) is
         # never materialised (statistics, apply and backward read x itself); the gate of its backward rides in
         # the fused backward kernel
-        fold = _foldable_relu(act, x)
+        fold, handle = _foldable_relu(act, x)
         if fold and q.is_active() and isinstance(x, torch.Tensor) and _eligible(p, q, x):
             if fold == 2:
-                return _with_owned_relu(x, lambda h: fused_prune_quantize(p, q, h, pre_relu=True))
-            return fused_prune_quantize(p, q, x, pre_relu=True)
+                return _with_owned_relu(x, lambda h: fused_prune_quantize(p, q, h, pre_relu=handle), handle)
+            return fused_prune_quantize(p, q, x, pre_relu=handle)
         h = act(x)
         if _eligible(p, q, h):
             return fused_prune_quantize(p, q, h)
@@ -678,13 +704,13 @@ def _quantizer_foldable(q: QuantizeLayer, x) -> bool:
             and not qc.backward_passthrough and q.batch_dimension == 0)
 
 
-def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
+def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor, act: int = 1) -> torch.Tensor:
     """one step of ``q(relu(x))`` for an ACTIVE tensor-wise Scaler/Decimal quantizer without materialising
     relu(x): abs-max of max(x, 0) (qs_absmax pre_relu), running scale, y = Q(max(x, 0)), and a backward that
     applies the ReLU gate and the STE clamp in one pass.  Bookkeeping as QuantizeLayer.forward
     (reference quantize.py:482-517)."""
     qc = q.callback
-    y = q.single_call_step(x, q._steps.read(q._n_updates), pre_relu=True)
+    y = q.single_call_step(x, q._steps.read(q._n_updates), pre_relu=act)
     if y is not None:
         return y
     if q.training:
@@ -693,7 +719,7 @@ def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
             logging.warn(f"quantizing {q.name} with {q.bits} bits")
         qc.__dict__["_bumped_step_counter"] = False
         new_weight = qc.optimize(x.detach(), q.bits, q.weight, batched=True, channel_index=-1, step_counter=q._n_updates,
-                                 pre_relu=True)
+                                 pre_relu=act)
         if new_weight is not None and new_weight is not q.weight:
             q.weight.data[:] = new_weight
         q._quantized = True
@@ -702,7 +728,7 @@ def fused_relu_quantize(q: QuantizeLayer, x: torch.Tensor) -> torch.Tensor:
         else:
             q._steps.add(q._n_updates, 1)
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
-    return _FusedApply.apply(x, None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0, True, True, qc.code_range(q.bits))
+    return _FusedApply.apply(x, None, q.weight.data, kind, q.bits, 1 if qc.flip_axis else 0, True, act, qc.code_range(q.bits))
 
 
 class FusedActQuantize(nn.Sequential):
@@ -713,9 +739,11 @@ class FusedActQuantize(nn.Sequential):
 
     def forward(self, x):
         act, q = self[0], self[1]
-        fold = _foldable_relu(act, x)
+        fold, handle = _foldable_relu(act, x)
         if fold and q.is_active() and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback):
-            return _with_owned_relu(x, lambda h: fused_relu_quantize(q, h)) if fold == 2 else fused_relu_quantize(q, x)
+            if fold == 2:
+                return _with_owned_relu(x, lambda h: fused_relu_quantize(q, h, handle), handle)
+            return fused_relu_quantize(q, x, handle)
         return q(act(x))
 
 
@@ -730,12 +758,12 @@ class FusedActPrune(nn.Sequential):
 
     def forward(self, x):
         act, p = self[0], self[1]
-        fold = _foldable_relu(act, x)
+        fold, handle = _foldable_relu(act, x)
         if (fold and isinstance(x, torch.Tensor)
                 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and p.is_active()
                 and type(p.callback) is MagnitudePruningCallback and not p.callback.l0
                 and not p.callback.use_gradient and len(p.dimensions) == 1 and not _hooked(act, p.callback)):
-            return _with_owned_relu(x, lambda h: p(h, pre_relu=True)) if fold == 2 else p(x, pre_relu=True)
+            return _with_owned_relu(x, lambda h: p(h, pre_relu=handle), handle) if fold == 2 else p(x, pre_relu=handle)
         return p(act(x))
 
 
@@ -743,7 +771,7 @@ FusedActPrune.__name__ = "Sequential"
 
 
 def _is_act_prune(m: nn.Module) -> bool:
-    return len(m) == 2 and type(m[0]) is nn.ReLU and isinstance(m[1], PruneLayer)
+    return len(m) == 2 and type(m[0]) in _FOLDABLE and isinstance(m[1], PruneLayer)
 
 
 def _is_pair(m: nn.Module) -> bool:
@@ -755,7 +783,7 @@ def _is_pair(m: nn.Module) -> bool:
 
 
 def _is_act_quantize(m: nn.Module) -> bool:
-    return len(m) == 2 and type(m[0]) is nn.ReLU and isinstance(m[1], QuantizeLayer)
+    return len(m) == 2 and type(m[0]) in _FOLDABLE and isinstance(m[1], QuantizeLayer)
 
 
 def fuse_prune_quantize_pairs(model: nn.Module) -> nn.Module:

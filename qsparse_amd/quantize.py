@@ -388,7 +388,7 @@ class DecimalQuantizer(BaseQuantizer):
                 if buf is None:     # tensor-wise: 16 partial accumulators on lines of their own (see _hip.absmax)
                     buf = bufs[key] = (_hip.tensor_amax_accumulator(x.device) if channel_index < 0 else
                                        torch.zeros(n_stat, dtype=torch.float32, device=x.device))
-                stat = _hip.absmax(x, channel_index, accumulate_into=buf, pre_relu=bool(kwargs.get("pre_relu", False)))
+                stat = _hip.absmax(x, channel_index, accumulate_into=buf, pre_relu=kwargs.get("pre_relu", False))
                 if batched:      # activations differ per rank; weights and biases (batched=False) are identical under DDP
                     stat = qdist.allreduce_max_(stat)
                 if weight is None:
@@ -554,7 +554,8 @@ class _QuantStep(torch.autograd.Function):
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(second, ctx.x_shape, ctx.x_dtype, ctx.channels_last) if ctx.has_gate else None
-            gx = _hip.ste_relu_bwd(g, None if gate is not None else second, scale, False, lo_mul, hi_mul, None, gate=gate)
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else second, scale, False, lo_mul, hi_mul, None, gate=gate,
+                                   act=ctx.pre_relu)
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)

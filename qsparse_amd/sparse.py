@@ -27,19 +27,20 @@ class _MaskApply(torch.autograd.Function):
     dim only, with the ReLU's gate in the backward (a folded nn.ReLU; relu(x) is never materialised)."""
 
     @staticmethod
-    def forward(ctx, x, mask, relu_dim=-1):
-        ctx.relu_dim = relu_dim
+    def forward(ctx, x, mask, relu_dim=-1, act=1):
+        """``act``: what ``pre_relu`` stands for -- 1 (nn.ReLU) or the handle of another folded activation"""
+        ctx.relu_dim, ctx.act = relu_dim, act
         ctx.gate_meta = None
         if relu_dim >= 0:
             if ctx.needs_input_grad[0] and get_option("relu_gate"):
                 # the backward needs one bit of x per element (x <= 0): recorded by this pass, x itself is not kept; the
                 # bitmap is a saved tensor like any other (released with the graph, visible to saved-tensor hooks)
-                y, gate = _hip.mask_apply(x, mask, pre_relu=True, want_gate=True)
+                y, gate = _hip.mask_apply(x, mask, pre_relu=act, want_gate=True)
                 ctx.gate_meta = (gate.shape, gate.dtype, gate.channels_last)
                 ctx.save_for_backward(mask, gate.bits)
                 return y
             ctx.save_for_backward(mask, x)
-            return _hip.mask_apply(x, mask, pre_relu=True)
+            return _hip.mask_apply(x, mask, pre_relu=act)
         ctx.save_for_backward(mask)
         return _hip.mask_apply(x, mask)
 
@@ -50,11 +51,12 @@ class _MaskApply(torch.autograd.Function):
             if ctx.gate_meta is not None:
                 mask, bits = ctx.saved_tensors
                 return _hip.ste_relu_bwd(grad, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim,
-                                         gate=_hip.ReluGate.from_saved(bits, *ctx.gate_meta)), None, None
+                                         gate=_hip.ReluGate.from_saved(bits, *ctx.gate_meta), act=ctx.act), None, None, None
             mask, x = ctx.saved_tensors
-            return _hip.ste_relu_bwd(grad, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim), None, None
+            return _hip.ste_relu_bwd(grad, x, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=ctx.relu_dim,
+                                     act=ctx.act), None, None, None
         (mask,) = ctx.saved_tensors
-        return _hip.mask_apply(grad, mask), None, None
+        return _hip.mask_apply(grad, mask), None, None, None
 
 
 def _channel_dim(mask: torch.Tensor) -> int:
@@ -63,13 +65,14 @@ def _channel_dim(mask: torch.Tensor) -> int:
     return dims[0] if len(dims) == 1 else -1
 
 
-def apply_mask(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
+def apply_mask(x: torch.Tensor, mask: torch.Tensor, pre_relu=False) -> torch.Tensor:
+    """``pre_relu``: False, True (a folded nn.ReLU) or the handle of another folded activation (``_hip.activation``)"""
     if x.is_cuda:
         if pre_relu:
             d = _channel_dim(mask)
             if d < 0 or mask.shape[d] != x.shape[d]:
-                return _MaskApply.apply(torch.relu(x), mask.detach())
-            return _MaskApply.apply(x, mask.detach(), d)
+                return _MaskApply.apply(_hip.act_torch(pre_relu, x), mask.detach())
+            return _MaskApply.apply(x, mask.detach(), d, int(pre_relu))
         return _MaskApply.apply(x, mask.detach())
     return (torch.relu(x) if pre_relu else x) * mask
 
@@ -80,8 +83,8 @@ def _importance(x: torch.Tensor, shape, l0: bool = False, pre_relu: bool = False
     if pre_relu:
         dims = _reduction_plan(x.shape, shape)
         if x.is_cuda and dims and not l0:
-            return _staged_mean_hip(x, dims, take_abs=True, pre_relu=True)
-        x = torch.relu(x)
+            return _staged_mean_hip(x, dims, take_abs=True, pre_relu=pre_relu)
+        x = _hip.act_torch(pre_relu, x) if x.is_cuda else torch.relu(x)
     if x.is_cuda:
         dims = _reduction_plan(x.shape, shape)
         flag = _hip.l0_flag(x) if l0 else None
@@ -258,7 +261,7 @@ class MagnitudePruningCallback(nn.Module):
         if self._single_launch_select(x, mask):
             return self._forward_single_launch(x, sparsity, mask, name, t, step_counter, pre_relu)
         if pre_relu:
-            x = torch.relu(x)
+            x = _hip.act_torch(pre_relu, x) if x.is_cuda else torch.relu(x)
         if t < self.stop_mask_refresh:
             self.receive_input(x)
         if self.refresh_due(t, sparsity):
@@ -372,7 +375,7 @@ class PruneLayer(nn.Module):
         if not self.training or self.mask.numel() == 1:
             return apply_mask(x, self.mask, pre_relu)
         if pre_relu and not (n >= self.start and x.is_cuda and type(self.callback) is MagnitudePruningCallback):
-            x, pre_relu = torch.relu(x), False
+            x, pre_relu = (_hip.act_torch(pre_relu, x) if x.is_cuda else torch.relu(x)), False
         if n >= self.start:
             if n == self.start and get_option("log_during_train"):
                 logging.warning(f"Start pruning at {self.name} @ {n}")

@@ -130,9 +130,9 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
             N, C, H, W = x.shape
-            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0)
+            flags = _hip.mean_flags(take_abs, pre_relu)
             fusable = (dims == [0, 2, 3] and l0_flag is None and (H * W + W) * 4 <= _hip.LAST2_MAX_TILE_BYTES
-                       and flags in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU)
+                       and (flags & 0xff) in (0, _hip.MEAN_ABS, _hip.MEAN_ABS | _hip.MEAN_RELU)
                        and not (flags == 0 and absmax_out is not None))
             if fusable:       # stages 2 + 3 in one launch, which also folds the per-element maxima per channel
                 stage, part = _hip.mean_dim_cl(xm, x.dtype, flags, absmax_out is not None)
@@ -141,8 +141,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
                 acc = absmax_out if absmax_out is not None else (record_absmax if rec is not None else None)
                 return _hip.mean_last2(stage, C, H, W, x.dtype, part, acc, rec).view(1, C, 1, 1)
             if absmax_out is None:
-                if l0_flag is not None:
-                    flags |= _hip.MEAN_L0
+                flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
                 stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
                 cur, dims, first = stage.view(1, C, H, W), dims[1:], False
     elif x.dim() == 5 and dims and dims[0] == 0 and x.shape[0] > 1 and absmax_out is None:
@@ -150,7 +149,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         # batch reduction of the [N, C, 1, D*H*W] channels_last tensor its memory also is; NCDHW-contiguous result)
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
-            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
             stage, _ = _hip.mean_dim_cl(xm, torch.float32 if l0_flag is not None else x.dtype, flags, False, l0_flag=l0_flag)
             cur, dims, first = stage.view((1,) + tuple(x.shape[1:])), dims[1:], False
     if cur is None and x.dim() == 4 and dims and dims[0] == 2 and absmax_out is None:
@@ -162,7 +161,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
             N, C, H, W = x.shape
-            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
             odt = torch.float32 if l0_flag is not None else x.dtype
             rows = [_hip.mean_dim_cl(xm[i].view(H, 1, W, C), odt, flags, False, l0_flag=l0_flag)[0] for i in range(N)]
             cur = (rows[0] if N == 1 else torch.cat(rows)).view(N, C, 1, W)
@@ -174,7 +173,7 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         xm, _, like = _hip.mem_view(x, 1)
         if xm is not like:
             N, C, H, W = x.shape
-            flags = (_hip.MEAN_ABS if take_abs else 0) | (_hip.MEAN_RELU if pre_relu else 0) | (_hip.MEAN_L0 if l0_flag is not None else 0)
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
             kw = {"l0_flag": l0_flag} if l0_flag is not None else {}
             cur = _hip.mean_dim(xm.reshape(N * H * W, C), N * H * W, C, 1, torch.float32 if l0_flag is not None else x.dtype,
                                 flags, **kw).view(N, 1, H, W)
@@ -204,12 +203,8 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         flags = 0
         kw = {}
         if first:
-            if take_abs:
-                flags |= _hip.MEAN_ABS
-            if pre_relu:
-                flags |= _hip.MEAN_RELU
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
             if l0_flag is not None:
-                flags |= _hip.MEAN_L0
                 kw["l0_flag"] = l0_flag
             if absmax_out is not None:
                 cd = absmax_channel_dim
@@ -222,8 +217,8 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         shape[d] = 1
         cur = cur.view(shape)
         first = False
-    if first and take_abs:  # nothing to reduce: importance is |x| itself (|max(x, 0)| under a folded ReLU)
-        cur = torch.relu(cur) if pre_relu else cur.abs()
+    if first and take_abs:  # nothing to reduce: importance is |x| itself (|act(x)| under a folded activation)
+        cur = _hip.act_torch(pre_relu, cur).abs() if pre_relu else cur.abs()
     return cur
 
 
