@@ -96,6 +96,13 @@ def main():
     print(f"{'kernel':100s} {'family':10s} {'ms/step':>8s} {'calls/step':>10s} {'avg us':>8s}")
     for k, (us, n, f) in sorted(ker.items(), key=lambda kv: -kv[1][0]):
         print(f"{k[:100]:100s} {f:10s} {us / 1e3 / steps:8.3f} {n / steps:10.1f} {us / n:8.1f}")
+    # the last step launch by launch: a streaming launch's work-items x 8 elements is (within a workgroup) its tensor's size
+    print("\nlast step, launch by launch (grid = work-items):")
+    print(f"{'kernel':100s} {'grid':>12s} {'us':>8s}")
+    for r in tail[-per_step:]:
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        grid = r.get("Grid_Size_X", r.get("Grid_Size", "?"))
+        print(f"{r['Kernel_Name'].split('(')[0][:100]:100s} {grid:>12s} {us:8.1f}")
 
 
 if __name__ == "__main__":
