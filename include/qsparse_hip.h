@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 11
+#define QS_ABI_VERSION 12
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -343,7 +343,8 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
  * arithmetic: they call the entry points above with the arguments the plan describes, in that order, on `stream`.
  *
  * The plan names what does not change from step to step: the geometry of x as the kernels address it (NCHW-contiguous:
- * layout 0, x = [N][C][H*W]; dense channels_last: layout 1, x = [N][H*W][C]), dtypes, the layer state (running
+ * layout 0, x = [N][C][H*W]; dense channels_last: layout 1, x = [N][H*W][C]; a 2-d activation [N][C] -- nn.Linear's output:
+ * layout 2 with H = W = 1, whose statistics are ONE qs_mean_dim launch, no qs_mean_last2), dtypes, the layer state (running
  * magnitude, mask, running scale, step counters -- all device pointers, the objects PruneLayer / QuantizeLayer /
  * MagnitudePruningCallback hold, reference sparse.py:58-122, quantize.py:327-349, 473-518) and the caller's workspaces
  * (stage: C*H*W elements of xdt; amax_part: C*H*W floats, channels_last only; chan_absmax: C * absmax_stride floats,
@@ -351,7 +352,7 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
  * when a pointer or a shape changes. */
 typedef struct qs_site_plan {
     int64_t N, C, H, W;
-    int32_t layout;              /* 0: NCHW-contiguous, 1: channels_last (NHWC in memory) */
+    int32_t layout;              /* 0: NCHW-contiguous, 1: channels_last (NHWC in memory), 2: [N][C] (H = W = 1) */
     int32_t xdt, ydt;            /* input dtype; output dtype (QS_F32: the reference's promotion, or xdt) */
     int32_t bits;                /* of the quantizer */
     float* magnitude;            /* [C]  MagnitudePruningCallback.magnitude */
@@ -359,7 +360,7 @@ typedef struct qs_site_plan {
     float* scale;                /* [1]  QuantizeLayer.weight */
     float* chan_absmax;          /* [C * absmax_stride] scratch accumulator */
     int64_t absmax_stride;
-    void* stage;                 /* [C*H*W] xdt scratch: first-stage means */
+    void* stage;                 /* [C*H*W] xdt scratch: first-stage means (unused, nullable, for layout 2) */
     float* amax_part;            /* [C*H*W] scratch (layout 1), NULL for layout 0 */
     void* stage_mean;            /* [C] xdt scratch: the importance of this step */
     int32_t* prune_n_updates;    /* nullable: PruneLayer._n_updates, incremented by the select */
@@ -385,9 +386,13 @@ typedef struct qs_site_plan {
 /* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
  * gate_out, image_out / imgdt, xback_out: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference
  * sparse.py:88, quantize.py:344), k: threshold rank (util.py:115-116).  gathered / world: nullable / 1; the all-gathered
- * records of qs_site_stats (see there and qs_pq_select). */
+ * records of qs_site_stats (see there and qs_pq_select).
+ * decimal: NULL for a ScalerQuantizer; else the site's quantizer is a DecimalQuantizer (reference quantize.py:275-367, same
+ * running scale, power-of-two step): device float[1] of THIS call, which receives qs_decimal_from_scale(plan->scale) after the
+ * select (one more launch) and is what qs_quant_decimal_fwd applies -- and what qs_site_bwd of this forward must be given. */
 int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, qs_stream_t stream);
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, float* decimal,
+                qs_stream_t stream);
 
 /* The statistics half of a live qs_site_fwd on its own -- qs_mean_dim | qs_mean_dim_cl, then qs_mean_last2, which also writes
  * this rank's exchange record (record: device float[2*C] = importance | per-channel abs-max, qs_stats_pack's layout) -- for a
@@ -399,9 +404,10 @@ int qs_site_stats(const qs_site_plan* plan, const void* x, int flags, float* rec
 
 /* gx = gate * clamp(g) * mask in xdt (qs_quant_ste_relu_bwd with the bitmap when `gate` is given, qs_quant_ste_bwd
  * otherwise); g has dtype gdt, the geometry of the plan.  lo_mul / hi_mul as there.  g2 / g2dt: the second gradient of
- * qs_quant_ste_relu_bwd (needs `gate`; g may then be NULL). */
+ * qs_quant_ste_relu_bwd (needs `gate`; g may then be NULL).  decimal: NULL (the clamp follows plan->scale) or the float[1] its
+ * forward call filled (DecimalQuantizer: the clamp follows 2^-decimal). */
 int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
-                float hi_mul, const void* g2, int g2dt, qs_stream_t stream);
+                float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream);
 
 /* A lone tensor-wise ScalerQuantizer step -- QuantizeLayer.forward in training (reference quantize.py:473-518 with
  * optimize :327-349 and ScalerQuantization.forward :100-117) -- from ONE call: with `update` != 0

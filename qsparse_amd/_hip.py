@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 11          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 12          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -64,9 +64,9 @@ SIGNATURES = {
     "qs_multi_quant_fwd": (c_int, [_P, _I, _I, _P, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
-    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P]),
+    "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
     "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
-    "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P]),
+    "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P, _P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
@@ -913,13 +913,15 @@ def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Te
 
 def site_fwd(plan_ref, x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], flags: int, t_mag: int, k: int,
              t_q: int, image: Optional[torch.Tensor] = None, gathered: Optional[torch.Tensor] = None, world: int = 1,
-             xback: bool = False):
+             xback: bool = False, decimal: Optional[torch.Tensor] = None):
     """image: optional bf16 / fp16 tensor of y's shape and layout that receives RNE(y) from the same pass (see qs_quant_image_ok);
     gathered (with SITE_STATS_DONE in flags): the all-gathered [world, 2C] records of `site_stats`; xback: the apply kernel also
-    writes relu(x) back into x (an owned nn.ReLU(inplace=True), see qs_quant_scaler_fwd xback_out)"""
+    writes relu(x) back into x (an owned nn.ReLU(inplace=True), see qs_quant_scaler_fwd xback_out); decimal: float32 [1] of this
+    call when the site's quantizer is a DecimalQuantizer (receives the power-of-two step; hand it to `site_bwd`)"""
     st = load().qs_site_fwd(plan_ref, x.data_ptr(), y.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(), flags,
                             t_mag, k, t_q, None if image is None else image.data_ptr(), 0 if image is None else _DT[image.dtype],
-                            None if gathered is None else gathered.data_ptr(), world, x.data_ptr() if xback else None, _stream(x))
+                            None if gathered is None else gathered.data_ptr(), world, x.data_ptr() if xback else None,
+                            None if decimal is None else decimal.data_ptr(), _stream(x))
     if st:
         _check(st, "qs_site_fwd")
 
@@ -932,11 +934,12 @@ def site_stats(plan_ref, x: torch.Tensor, flags: int, record: torch.Tensor):
 
 
 def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
-             hi_mul: float, g2: Optional[torch.Tensor] = None):
+             hi_mul: float, g2: Optional[torch.Tensor] = None, decimal: Optional[torch.Tensor] = None):
     """g2: a second, 2-byte gradient added to g in float32 (g may then be None), see qs_quant_ste_relu_bwd"""
     st = load().qs_site_bwd(plan_ref, None if g is None else g.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
                             gx.data_ptr(), F32 if g is None else _DT[g.dtype], flags, lo_mul, hi_mul,
-                            None if g2 is None else g2.data_ptr(), 0 if g2 is None else _DT[g2.dtype], _stream(gx))
+                            None if g2 is None else g2.data_ptr(), 0 if g2 is None else _DT[g2.dtype],
+                            None if decimal is None else decimal.data_ptr(), _stream(gx))
     if st:
         _check(st, "qs_site_bwd")
 

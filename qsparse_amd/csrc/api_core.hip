@@ -183,14 +183,21 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
 
 // ---- one activation site per call: the fine-grained entry points in sequence (no arithmetic of its own) --------------
 static int site_plan_ok(const qs_site_plan* p) {
-    return p && p->N >= 1 && p->C >= 2 && p->H >= 1 && p->W >= 1 && (p->layout == 0 || p->layout == 1);
+    if (!p || p->N < 1 || p->C < 2 || p->H < 1 || p->W < 1) return 0;
+    return p->layout == 0 || p->layout == 1 || (p->layout == 2 && p->H == 1 && p->W == 1);
 }
 
 // the statistics launches of a live site step; `record` (nullable): the rank's exchange record, written by the last of them
 static int site_statistics(const qs_site_plan* p, const void* x, int pre_relu, float* record, qs_stream_t stream) {
-    if (!p->chan_absmax || !p->stage || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
+    if (!p->chan_absmax || !p->stage_mean || p->absmax_stride < 1 || (p->layout != 2 && !p->stage)) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
     const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_ACT(pre_relu) : 0);
+    if (p->layout == 2) {      // [N][C]: one stage, the per-channel abs-max rides in it; the record is a launch of its own
+        int st = qs_mean_dim(x, p->stage_mean, 1, p->N, p->C, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride, 1,
+                             p->C, stream);
+        if (st || !record) return st;
+        return qs_stats_pack(p->stage_mean, p->xdt, p->chan_absmax, p->absmax_stride, p->C, record, stream);
+    }
     if (p->layout == 0) {
         int st = qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride,
                              hw, p->C, stream);
@@ -212,7 +219,8 @@ int qs_site_stats(const qs_site_plan* p, const void* x, int flags, float* record
 }
 
 int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
-                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, qs_stream_t stream) {
+                int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, float* decimal,
+                qs_stream_t stream) {
     if (!site_plan_ok(p) || !x || !y) return QS_ERR_ARG;
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
@@ -234,23 +242,32 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     }
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
-    return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, cm ? outer : 1, cm ? p->C : 1, cm ? inner : outer * p->C * inner,
-                               p->xdt, p->ydt, QS_F32, p->saturate, p->code_lo, p->code_hi, pre_relu,
-                               (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0, gate_out, image_out, imgdt, xback_out, stream);
+    const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
+    const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
+    if (decimal) {             // DecimalQuantizer: the power-of-two step of THIS call's scale (quantize.py:316)
+        int st = qs_decimal_from_scale(p->scale, decimal, 1, stream);
+        if (st) return st;
+        return qs_quant_decimal_fwd(x, y, nullptr, decimal, 1, 0.0f, cm, o, c, in, p->xdt, p->ydt, QS_F32, p->saturate, p->code_lo,
+                                    p->code_hi, pre_relu, elide, gate_out, image_out, imgdt, xback_out, stream);
+    }
+    return qs_quant_scaler_fwd(x, y, nullptr, p->scale, 1, 0.0f, cm, o, c, in, p->xdt, p->ydt, QS_F32, p->saturate, p->code_lo,
+                               p->code_hi, pre_relu, elide, gate_out, image_out, imgdt, xback_out, stream);
 }
 
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
-                float hi_mul, const void* g2, int g2dt, qs_stream_t stream) {
+                float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream) {
     if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate)) return QS_ERR_ARG;
+    const float* step = decimal ? decimal : p->scale;
+    const int is_decimal = decimal ? 1 : 0;
     const int64_t hw = p->H * p->W;
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
     if (gate)
-        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt,
+        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, step, 1, 0.0f, is_decimal, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt,
                                      g2 ? 0 : elide, p->act > 0 ? p->act : 1, g2, g2dt, stream);
-    return qs_quant_ste_bwd(g, gx, p->scale, 1, 0.0f, 0, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
+    return qs_quant_ste_bwd(g, gx, step, 1, 0.0f, is_decimal, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
 }
 
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,

@@ -150,7 +150,7 @@ class _FusedApply(torch.autograd.Function):
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
     __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused",
-                 "xbuf", "widen_nomask")
+                 "xbuf", "widen_nomask", "decimal")
 
     def __init__(self):
         self.key = None
@@ -166,15 +166,17 @@ class _SitePlan:
 
 def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     """the cached plan of this site for inputs like `h`, or None when the site is not one the composite call covers
-    (4-d NCHW / channels_last activation with a batch of at least two, tensor-wise ScalerQuantizer, state on h's device)"""
+    (4-d NCHW / channels_last or 2-d [N, C] activation with a batch of at least two, tensor-wise Scaler / Decimal quantizer,
+    state on h's device)"""
     cb, qc = p.callback, q.callback
-    if h.dim() != 4 or h.shape[0] < 2 or type(qc) is not ScalerQuantizer or not hasattr(cb, "magnitude"):
+    if h.dim() not in (2, 4) or h.shape[0] < 2 or type(qc) not in (ScalerQuantizer, DecimalQuantizer) or not hasattr(cb, "magnitude"):
         return None
-    N, C, H, W = h.shape
-    if H < 2 or W < 2:
+    flat = h.dim() == 2
+    N, C, H, W = (h.shape[0], h.shape[1], 1, 1) if flat else h.shape
+    if not flat and (H < 2 or W < 2):
         return None                      # (an extent of 1 is not reduced -- and turns its neighbour into an inner reduction)
     cl = not h.is_contiguous()
-    if cl and not h.is_contiguous(memory_format=torch.channels_last):
+    if cl and (flat or not h.is_contiguous(memory_format=torch.channels_last)):
         return None
     if h.data_ptr() % 16 or (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES:
         return None
@@ -189,24 +191,25 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     t_q_dev = qc.device_t(h.device) if graph_safe else None
     out_dtype = _out_dtype(h)
     sat = qc.code_range(q.bits)
-    key = (N, C, H, W, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat, act) + tuple(t.data_ptr() for t in state) + \
+    key = (N, C, H, W, flat, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat, act, type(qc)) + tuple(t.data_ptr() for t in state) + \
         ((t_q_dev.data_ptr(),) if t_q_dev is not None else ())
     plan = q.__dict__.get("_qs_site_plan")
     if plan is not None and plan.key == key:
         return plan
     plan = _SitePlan()
     plan.key, plan.out_dtype, plan.channels_last, plan.xdt = key, out_dtype, cl, h.dtype
+    plan.decimal = type(qc) is DecimalQuantizer
     acc = _absmax_accumulator(q, C, h.device)
-    stage = torch.empty(C * H * W, dtype=h.dtype, device=h.device)
+    stage = None if flat else torch.empty(C * H * W, dtype=h.dtype, device=h.device)
     part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
     plan.keep = (acc, stage, part, stage_mean, t_q_dev) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
-    c.layout, c.xdt, c.ydt, c.bits = int(cl), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
+    c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
     c.magnitude, c.mask, c.scale = cb.magnitude.data_ptr(), p.mask.data_ptr(), q.weight.data_ptr()
     c.chan_absmax, c.absmax_stride = acc.data_ptr(), _hip.amax_stride(acc)
-    c.stage, c.amax_part, c.stage_mean = stage.data_ptr(), (part.data_ptr() if cl else None), stage_mean.data_ptr()
+    c.stage, c.amax_part, c.stage_mean = (None if flat else stage.data_ptr()), (part.data_ptr() if cl else None), stage_mean.data_ptr()
     c.prune_n_updates, c.quant_n_updates, c.callback_t = p._n_updates.data_ptr(), q._n_updates.data_ptr(), cb.t.data_ptr()
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)
@@ -317,11 +320,14 @@ class _SiteStep(torch.autograd.Function):
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
         if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None):
             flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic (see _hip.elide_mode)
-        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world, xback=xback)
+        # a DecimalQuantizer's power-of-two step of THIS call (the backward clamps with it; two forwards may precede a backward)
+        dec = torch.empty(1, dtype=torch.float32, device=h.device) if plan.decimal else None
+        _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world, xback=xback,
+                      decimal=dec)
         if xback:
             cell["done"] = True
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
-        ctx.act = plan.c.act
+        ctx.act, ctx.dec = plan.c.act, dec
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
@@ -351,7 +357,7 @@ class _SiteStep(torch.autograd.Function):
             if (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
                     and _hip.elide_mode != "all" and not _hip.logging_events()):
                 gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g16.device, memory_format=fmt)
-                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16)
+                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec)
                 return (gx,) + (None,) * (n_in - 1)
             g = g16.float() if g is None else g + g16.float()          # autograd's own accumulation, then the usual routes
         fast = (dense(g) and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype)
@@ -359,16 +365,17 @@ class _SiteStep(torch.autograd.Function):
         if fast:
             gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g.device, memory_format=fmt)
             bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
-            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul)
+            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul, decimal=ctx.dec)
             return (gx,) + (None,) * (n_in - 1)
         mask = mask_c.detach().view(-1) if mask_c.numel() else None      # (the layers' own parameters were saved, not aliases)
-        scale = scale.detach()
+        is_dec = ctx.dec is not None
+        scale = ctx.dec if is_dec else scale.detach()
         if pre_relu:
             gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
-            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, False, lo_mul, hi_mul, mask, gate=gate, act=ctx.act)
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, is_dec, lo_mul, hi_mul, mask, gate=gate, act=ctx.act)
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
-            gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
+            gx = _hip.ste_bwd(g, scale, is_dec, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
         return (gx,) + (None,) * (n_in - 1)
 
 

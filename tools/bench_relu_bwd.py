@@ -26,7 +26,11 @@ def t_us(fn, iters=30):
     return ts[len(ts) // 2] * 1e3
 
 
-for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7), (256, 256, 56, 56), (256, 1024, 14, 14)):
+SHAPES = ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7), (256, 256, 56, 56), (256, 1024, 14, 14))
+if "--b256" in sys.argv:      # the bf16 sites inside ResNet-50's bottlenecks at batch 256 (and the fp32 ones behind the residual adds)
+    SHAPES = ((256, 64, 112, 112), (256, 64, 56, 56), (256, 128, 56, 56), (256, 128, 28, 28), (256, 256, 28, 28), (256, 256, 14, 14),
+              (256, 512, 14, 14), (256, 512, 7, 7), (256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7))
+for shape in SHAPES:
     for xdt in (torch.float32, torch.bfloat16):
         for cl in (False, True):
             C = shape[1]
@@ -69,6 +73,9 @@ for shape in ((64, 256, 56, 56), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 204
             usf = t_us(fwd)
             nbf = n * (4 + eb)
             usg, usfg = t_us(run_gate), t_us(fwd_gate)
+            os.environ["QS_RELU_BWD_U"] = "2"            # two groups per lane in the narrowing gate kernels (A/B)
+            usg2 = t_us(run_gate)
+            os.environ["QS_RELU_BWD_U"] = "1"
             print(f"{str(shape):20s} x {str(xdt)[6:]:8s} {'channels_last' if cl else 'nchw':13s} bwd {us:7.1f} us {nbytes / us / 1e3:6.0f} GB/s"
                   f"   fwd {usf:7.1f} us {nbf / usf / 1e3:6.0f} GB/s   | gate: bwd {usg:7.1f} us {n * (4.125 + eb) / usg / 1e3:6.0f} GB/s"
-                  f"   fwd {usfg:7.1f} us {n * (4.125 + eb) / usfg / 1e3:6.0f} GB/s", flush=True)
+                  f"   fwd {usfg:7.1f} us {n * (4.125 + eb) / usfg / 1e3:6.0f} GB/s   | U=2 gate bwd {usg2:7.1f} us", flush=True)

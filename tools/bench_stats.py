@@ -41,10 +41,13 @@ def main():
     noabs = "--noabs" in sys.argv
     stride = 1 if "--dense" in sys.argv else 32     # abs-max accumulator: dense float[C] or one 128-byte line per channel
     channels_last = "--cl" in sys.argv
+    tile_sweep = "--tile" in sys.argv            # channels_last one-wave kernel: linear columns (0) vs tiles of 8 / 4 lanes per position (QS_CL_TILE)
     depth_sweep = "--depth" in sys.argv          # sweep the rows in flight per wave (QS_MEAN_DEPTH) of the unsplit kernel instead
     # cells: R (waves per workgroup, 0 = the host's own choice) or R:lanes (channels_last: QS_CL_LANES)
     splits = [s for s in sys.argv[1:] if s.replace(":", "").isdigit()] or (["0", "16", "32"] if depth_sweep else ["0", "1", "2", "4", "8"])
-    print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{('D=' if depth_sweep else 'R=') + str(r):>14s}" for r in splits))
+    if tile_sweep:
+        splits = ["0", "8", "4"]
+    print(f"{'shape':24s} {'dtype':6s} " + " ".join(f"{('T=' if tile_sweep else 'D=' if depth_sweep else 'R=') + str(r):>14s}" for r in splits))
     for shp in (B256 if "--b256" in sys.argv else SHAPES):
         N, C, H, W = shp
         for dtype, code, nbytes in ((torch.bfloat16, 1, 2), (torch.float32, 0, 4)):
@@ -59,7 +62,9 @@ def main():
             for cell in splits:
                 r = int(cell.split(":")[0])
                 os.environ["QS_CL_LANES"] = cell.split(":")[1] if ":" in cell else "0"
-                if depth_sweep:
+                if tile_sweep:
+                    os.environ["QS_MEAN_SPLIT"], os.environ["QS_CL_TILE"] = "0", str(r)
+                elif depth_sweep:
                     os.environ["QS_MEAN_SPLIT"], os.environ["QS_MEAN_DEPTH"] = ("1" if r else "0"), str(r)
                 else:
                     os.environ["QS_MEAN_SPLIT"] = str(r)
@@ -77,7 +82,7 @@ def main():
                 us = t_us(stats_cl if channels_last else stats)
                 cells.append(f"{us:6.1f}us {x.numel() * nbytes / us / 1e3:5.0f}GB/s"[:14].rjust(14))
             print(f"{str(shp):24s} {str(dtype)[6:]:6s} " + " ".join(cells), flush=True)
-    os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = os.environ["QS_CL_LANES"] = "0"
+    os.environ["QS_MEAN_SPLIT"] = os.environ["QS_MEAN_DEPTH"] = os.environ["QS_CL_LANES"] = os.environ["QS_CL_TILE"] = "0"
 
 
 if __name__ == "__main__":
