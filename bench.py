@@ -756,6 +756,23 @@ def main():
             torch.cuda.synchronize()
             variants[other] = (time.perf_counter() - tv) / k * 1e3
         qs.set_qsparse_options(elide_pruned=mode)
+        # the steady state of the reference's own recipe (devise_layerwise_pruning_schedule, sparse.py:343-359): the mask
+        # froze when the callback's t passed stop_mask_refresh, the scale still follows the data every step
+        cb = pair[0][1].callback
+        stop = cb.stop_mask_refresh
+        cb.stop_mask_refresh = 0
+        try:
+            for _ in range(5):
+                step()
+            k = max(min(args.steps // 2, 60), 1)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            variants["frozen_mask"] = (time.perf_counter() - tv) / k * 1e3
+        finally:
+            cb.stop_mask_refresh = stop
 
     numel = x.numel()
     if rank == 0:
@@ -804,7 +821,9 @@ def main():
                 m: {"ms_per_step": round(ms, 4), "Gelem/s": round(numel / ms / 1e6, 1),
                     "note": {"off": "dense: every element loaded, 14 B/elem (round-1 record)",
                              "forward": "apply forward skips pruned channels; bit-identical for finite inputs (library default)",
-                             "all": "backward elided as well: +0.0 where the reference has -0.0 (opt-in)"}[m]}
+                             "all": "backward elided as well: +0.0 where the reference has -0.0 (opt-in)",
+                             "frozen_mask": "default mode after stop_mask_refresh (the layerwise recipe's steady state): mask fixed, "
+                                            "scale live -- statistics are the per-channel abs-max alone"}[m]}
                 for m, ms in variants.items()}
         if world > 1 or force_exchange:
             out["config"]["exchange"] = ("one all-gather of a 2C-float record per step over " +

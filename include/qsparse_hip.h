@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 12
+#define QS_ABI_VERSION 13
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -372,6 +372,9 @@ typedef struct qs_site_plan {
     int32_t saturate;            /* != 0: codes are clamped to [code_lo, code_hi] (qs_quant_scaler_fwd's opt-in saturation) */
     int32_t code_lo, code_hi;
     int32_t act;                 /* the activation QS_SITE_PRE_RELU folds: 0 / 1 nn.ReLU, else a qs_activation() handle */
+    float* absmax_dense;         /* nullable: [C] scratch accumulator of QS_SITE_SCALE_ONLY steps (zero on entry, re-zeroed by the select) */
+    void* reduce_ws;             /* nullable: qs_absmax's `ws` for this geometry (QS_SITE_SCALE_ONLY steps) */
+    int64_t reduce_ws_bytes;
 } qs_site_plan;
 
 /* flags of qs_site_fwd */
@@ -382,6 +385,10 @@ typedef struct qs_site_plan {
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
 #define QS_SITE_STATS_DONE 32 /* with QS_SITE_LIVE: the statistics launches were already enqueued by qs_site_stats (a data-parallel
                                  step: the caller exchanged the record in between); qs_site_fwd starts at the select */
+#define QS_SITE_SCALE_ONLY 64 /* with QS_SITE_LIVE: the mask is frozen (MagnitudePruningCallback.t passed stop_mask_refresh,
+                                 sparse.py:107-116 -- the steady state of devise_layerwise_pruning_schedule recipes, :343-359):
+                                 magnitude and mask stay, the statistics are qs_absmax per channel into plan->absmax_dense
+                                 and the select updates the scale (max over the kept channels) and the counters */
 
 /* y = Q(relu?(x) * mask); with QS_SITE_LIVE preceded by statistics + select exactly as the four calls above.
  * gate_out, image_out / imgdt, xback_out: nullable, see qs_quant_scaler_fwd.  t_mag / t_q: the running-mean counters of this step (reference

@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 12          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 13          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -81,7 +81,8 @@ class SitePlanStruct(ctypes.Structure):
                 ("absmax_stride", c_int64), ("stage", c_void_p), ("amax_part", c_void_p), ("stage_mean", c_void_p),
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
-                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32)]
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32),
+                ("absmax_dense", c_void_p), ("reduce_ws", c_void_p), ("reduce_ws_bytes", c_int64)]
 
 
 class MultiRow(ctypes.Structure):
@@ -93,7 +94,7 @@ class MultiRow(ctypes.Structure):
                 ("absmax_block0", c_int32), ("absmax_blocks", c_int32), ("quant_block0", c_int32), ("chan0", c_int32)]
 
 
-SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE = 1, 2, 4, 8, 16, 32
+SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE, SITE_SCALE_ONLY = 1, 2, 4, 8, 16, 32, 64
 QSTEP_APPLY, QSTEP_ALL, QSTEP_ABSMAX, QSTEP_FINISH = 0, 1, 2, 3
 
 _lib = None
@@ -586,11 +587,16 @@ def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, ste
 WS_REDUCE = 2
 
 
+def reduce_workspace_bytes(channel_index: int, outer: int, C: int, inner: int) -> int:
+    """bytes of scratch the two-stage per-channel reduction over few columns wants for this geometry (0: it never takes that route)"""
+    if channel_index < 0 or inner >= 64 or outer < 256:
+        return 0
+    return int(load().qs_workspace_bytes(WS_REDUCE, C * inner))
+
+
 def _reduce_workspace(x: torch.Tensor, channel_index: int, outer: int, C: int, inner: int):
     """scratch for the two-stage per-channel reduction over few columns (channels_last activations, 2-d inputs)"""
-    if channel_index < 0 or inner >= 64 or outer < 256:
-        return None, 0
-    nbytes = load().qs_workspace_bytes(WS_REDUCE, C * inner)
+    nbytes = reduce_workspace_bytes(channel_index, outer, C, inner)
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=x.device), nbytes

@@ -226,8 +226,19 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     const int64_t hw = p->H * p->W;
     const int pre_relu = (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0;     // the folded activation's handle
     if (flags & QS_SITE_LIVE) {
-        if (!p->magnitude || !p->chan_absmax || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
         if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
+        if (flags & QS_SITE_SCALE_ONLY) {      // frozen mask: per-channel abs-max, then the select's scale half alone
+            if (!p->absmax_dense || gathered || (flags & (QS_SITE_REFRESH | QS_SITE_STATS_DONE))) return QS_ERR_ARG;
+            const int64_t so = p->layout == 0 ? p->N : p->N * hw, si = p->layout == 0 ? hw : 1;
+            int st = qs_absmax(x, p->absmax_dense, 1, so, p->C, si, p->xdt, 1, pre_relu, 1, p->reduce_ws,
+                               (size_t)p->reduce_ws_bytes, stream);
+            if (st) return st;
+            st = qs_pq_select(p->magnitude, nullptr, p->xdt, p->C, 0, t_mag, 0, 0, p->mask, p->absmax_dense, 1, 1, t_q, p->bits,
+                              p->scale, p->prune_n_updates, p->quant_n_updates, p->callback_t, p->quantizer_t_dev, nullptr,
+                              p->quantizer_t_dev, p->xdt, nullptr, 1, stream);
+            if (st) return st;
+        } else {
+        if (!p->magnitude || !p->chan_absmax || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
         if ((flags & QS_SITE_STATS_DONE) ? (!gathered || world < 1) : (gathered != nullptr)) return QS_ERR_ARG;
         int st;
         if (!(flags & QS_SITE_STATS_DONE)) {
@@ -239,6 +250,7 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
                           p->callback_t, p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr,
                           p->quantizer_t_dev, p->xdt, gathered, gathered ? world : 1, stream);
         if (st) return st;
+        }
     }
     const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;

@@ -203,7 +203,12 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     stage = None if flat else torch.empty(C * H * W, dtype=h.dtype, device=h.device)
     part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
-    plan.keep = (acc, stage, part, stage_mean, t_q_dev) + state
+    # a frozen-mask step (QS_SITE_SCALE_ONLY): dense [C] abs-max accumulator + the reduction's scratch for this geometry
+    dense = _absmax_accumulator_dense(q, C, h.device)
+    so, si = (N * H * W, 1) if (cl or flat) else (N, H * W)
+    ws_bytes = _hip.reduce_workspace_bytes(1, so, C, si)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device) if ws_bytes else None
+    plan.keep = (acc, stage, part, stage_mean, t_q_dev, dense, ws) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
     c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
@@ -215,6 +220,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     c.callback_t_from_device = int(graph_safe)
     c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
     c.act = int(act) or 1                # the activation QS_SITE_PRE_RELU folds at this site (1: nn.ReLU)
+    c.absmax_dense, c.reduce_ws, c.reduce_ws_bytes = dense.data_ptr(), (ws.data_ptr() if ws is not None else None), ws_bytes
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
@@ -437,19 +443,23 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     idle = not (update_mag or refresh or update_scale) and quant_on
     world = qdist.stats_world_size()
     exchange = qdist.exchange_active(world)      # (only a live step has statistics to exchange)
-    if (live or idle) and not _hip.logging_events():
+    # the mask is frozen (the callback's t passed stop_mask_refresh: the steady state of the reference's layerwise recipe,
+    # sparse.py:343-359) and the scale still follows the data: abs-max per channel, the select's scale half, apply
+    frozen = (update_scale and not (update_mag or refresh) and prune_on and p_counts and q_counts and n >= p.start
+              and not exchange)
+    if (live or idle or frozen) and not _hip.logging_events():
         site = _site_plan(p, q, h, int(pre_relu) or 1)
-    if site is not None and live:        # the counters ride in the select launch, as on the fine-grained route (the flags
-        bump_p = bump_q = bump_t = True   # below only ask WHETHER they did)
+    if site is not None and (live or frozen):   # the counters ride in the select launch, as on the fine-grained route (the
+        bump_p = bump_q = bump_t = True          # flags below only ask WHETHER they did)
         select_bumped_tq = bool(get_option("graph_safe"))
     site_gathered = None
     with torch.no_grad():
         hd = h.detach() if site is None else None
         stage = chan_absmax = record = None
         if site is not None:
-            if live:
+            if live or frozen:
                 _arm_accumulators(q)
-                if exchange:
+                if exchange and live:
                     # data-parallel step, two calls around ONE collective: the statistics launches (the last of them writes
                     # this rank's record), the all-gather, and -- in `_SiteStep` below -- select + apply on the gathered records
                     rec, site_gathered = _exchange_buffers(site, C, world, h.device)
@@ -541,7 +551,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         h, pre_relu = _hip.act_torch(pre_relu, h), False
     kind = "scaler" if isinstance(qc, ScalerQuantizer) else "decimal"
     if site is not None:
-        flags = ((_hip.SITE_LIVE if live else 0) | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
+        flags = ((_hip.SITE_LIVE if (live or frozen) else 0) | (_hip.SITE_SCALE_ONLY if frozen else 0)
+                 | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
                  | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0) | (0 if prune_on else _hip.SITE_NO_MASK))
         if site.image_made and not site.image_used:
             site.image_ok = False        # nobody took the last image (the consumer is not an autocast matmul / convolution): stop making them
@@ -551,7 +562,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             flags |= _hip.SITE_STATS_DONE
         out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
                               p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world)
-        if live:
+        if live or frozen:
             _disarm_accumulators(q)
         if type(out) is tuple:
             y, img = out

@@ -46,7 +46,7 @@ def test_single_gpu_line_with_roofline_variants_and_cpu_baseline():
     assert len(lines) == 1, lines
     rec = json.loads(lines[0])
     _check(rec, 1, 24)
-    assert rec["config"]["elide_pruned"] == "forward" and set(rec["config"]["variants"]) == {"off", "all"}
+    assert rec["config"]["elide_pruned"] == "forward" and set(rec["config"]["variants"]) == {"off", "all", "frozen_mask"}
     # (orderings of TIMES are only checked where the byte counts differ by a wide margin -- 9.5 against 14 B/elem -- and between
     #  figures taken back to back; the 24 timed headline steps of this short run can fall into the clock ramp of a cold GPU)
     v = rec["config"]["variants"]

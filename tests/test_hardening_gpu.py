@@ -66,7 +66,8 @@ def _check_twins(disturbed, twin, first, last, **kw):
 
 @pytest.mark.parametrize("quantizer,shape", [(DecimalQuantizer, (8, 16, 12, 12)), (ScalerQuantizer, (24, 16))])
 def test_failing_select_on_the_fine_grained_route_leaves_no_stale_statistics(monkeypatch, quantizer, shape):
-    """Decimal sites and 2-d activations take the fine-grained route: statistics launch(es), then `qs_pq_select`"""
+    """the fine-grained route (sites the composite call does not cover; forced here): statistics launch(es), then `qs_pq_select`"""
+    monkeypatch.setattr(fused, "_site_plan", lambda *a, **k: None)
     disturbed, twin = _pair(quantizer), _pair(quantizer)
     _check_twins(disturbed, twin, 0, 4, shape=shape)
     real = _hip.pq_select

@@ -194,9 +194,9 @@ def test_the_apply_kernel_writes_relu_back_itself(kind, quantizer, dtype, channe
         finally:
             qs.set_qsparse_options(fold_relu=True)
         active = step >= 1                                      # (step 0: the operators are not active yet, nothing is folded)
-        # the composite route (Scaler sites) writes back in training and in no-grad forwards; the fine-grained route (Decimal)
-        # where it records a gate, i.e. in training; the prune-only site never
-        kernel_wrote = active and kind != "relu_p" and (quantizer == "scaler" or train)
+        # the composite route (prune -> quantize pairs, the lone Scaler quantizer) writes back in training and in no-grad forwards;
+        # the fine-grained route where it records a gate, i.e. in training; the prune-only site never
+        kernel_wrote = active and kind != "relu_p" and (quantizer == "scaler" or kind == "pair" or train)
         if active:
             assert n_owned == (0 if kernel_wrote else 1), (step, n_owned)
         got = ha.detach().cpu().contiguous()

@@ -23,10 +23,14 @@ START, INTERVAL, REPS, TIMEOUT = 2, 2, 2, 3
 STEPS = 9
 
 
-def make_site(kind, relu, device):
+FREEZE = dict(mask_refresh_interval=1, stop_mask_refresh=3)      # the mask freezes three steps after pruning started
+
+
+def make_site(kind, relu, device, frozen=False):
     from qsparse_amd.fused import FusedPruneQuantize
     cb = qs.ScalerQuantizer() if kind == "scaler" else qs.DecimalQuantizer()
-    p = qs.prune(sparsity=0.5, start=START, interval=INTERVAL, repetition=REPS, dimensions={1})
+    p = qs.prune(sparsity=0.5, start=START, interval=INTERVAL, repetition=1 if frozen else REPS, dimensions={1},
+                 callback=qs.MagnitudePruningCallback(**FREEZE) if frozen else None)
     q = qs.quantize(bits=4, timeout=TIMEOUT, channelwise=-1, callback=cb)
     return FusedPruneQuantize(nn.Sequential(nn.ReLU() if relu else nn.Identity(), p), q).to(device), p, q
 
@@ -65,16 +69,29 @@ CASES = [
     ("scaler", (64, 1000), torch.float32, False, False),
     ("decimal", (5, 36), torch.float16, False, True),
 ]
+# the recipe's steady state: mask frozen (stop_mask_refresh passed), the scale still follows the data (QS_SITE_SCALE_ONLY)
+FROZEN_CASES = [
+    ("scaler", (6, 16, 10, 12), torch.float32, False, True),
+    ("scaler", (6, 16, 10, 12), torch.bfloat16, True, True),
+    ("decimal", (4, 24, 7, 7), torch.bfloat16, False, False),
+    ("scaler", (300, 64, 4, 4), torch.bfloat16, True, True),        # channels_last, many rows: the two-stage reduction's workspace
+    ("scaler", (300, 40), torch.float32, False, True),              # 2-d, many rows
+    ("decimal", (17, 40), torch.float16, False, False),
+]
 
 
-@pytest.mark.parametrize("kind,shape,dtype,channels_last,relu", CASES)
-def test_composite_site_equals_oracle_and_fine_grained(kind, shape, dtype, channels_last, relu, monkeypatch):
+@pytest.mark.parametrize("kind,shape,dtype,channels_last,relu,frozen",
+                         [c + (False,) for c in CASES] + [c + (True,) for c in FROZEN_CASES])
+def test_composite_site_equals_oracle_and_fine_grained(kind, shape, dtype, channels_last, relu, frozen, monkeypatch):
     dev = torch.device("cuda:0")
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     fwd_calls, bwd_calls = Counter(monkeypatch, "site_fwd"), Counter(monkeypatch, "site_bwd")
-    site, p, q = make_site(kind, relu, dev)
-    fine, pf, qf = make_site(kind, relu, dev)
-    psim = O.PruneSim(0.5, [1], START, INTERVAL, REPS, False)
+    site, p, q = make_site(kind, relu, dev, frozen)
+    fine, pf, qf = make_site(kind, relu, dev, frozen)
+    psim = O.PruneSim(0.5, [1], START, INTERVAL, 1 if frozen else REPS, False, **(FREEZE if frozen else {}))
+    flags_seen = []
+    real_site_fwd = _hip.site_fwd
+    monkeypatch.setattr(_hip, "site_fwd", lambda *a, **k: (flags_seen.append(a[4]), real_site_fwd(*a, **k))[1])
     qsim = O.QuantizeSim(kind, 4, -1, TIMEOUT)
     real_plan = fused._site_plan
     for step in range(STEPS):
@@ -112,6 +129,8 @@ def test_composite_site_equals_oracle_and_fine_grained(kind, shape, dtype, chann
             assert ql._n_updates.item() == qsim.n_updates and ql.callback.t == qsim.shared["t"], ("quantizer counters", tag)
     # live steps (quantizer and pruning both active, training) and the evaluation step went through the composite calls
     assert fwd_calls.n >= STEPS - TIMEOUT - 1 and bwd_calls.n >= STEPS - TIMEOUT - 1, (fwd_calls.n, bwd_calls.n)
+    scale_only = sum(1 for f in flags_seen if f & _hip.SITE_SCALE_ONLY)
+    assert (scale_only >= 2) if frozen else (scale_only == 0), flags_seen
 
 
 def test_two_forwards_of_a_decimal_site_keep_their_own_step():
@@ -134,5 +153,5 @@ def test_two_forwards_of_a_decimal_site_keep_their_own_step():
     for xd, y, gr, dec, _ in xs:
         (gx,) = torch.autograd.grad(y, xd, gr)
         clamped = O.ste_bwd(gr.cpu(), 4, 2.0 ** -dec)           # the gradient VALUES are clamped (quantize.py:120-131)
-        keep = p.mask.detach().cpu().view(1, -1, 1, 1).to(torch.bool) & (xd.detach().cpu() > 0)
-        assert same(gx.cpu(), torch.where(keep, clamped, torch.zeros_like(clamped)))
+        masked = clamped * p.mask.detach().cpu().view(1, -1, 1, 1).to(clamped.dtype)      # g * mask: a signed zero on pruned channels
+        assert same(gx.cpu(), torch.where(xd.detach().cpu() > 0, masked, torch.zeros_like(masked)))
