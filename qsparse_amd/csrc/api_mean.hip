@@ -173,7 +173,9 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
     const bool wg_tail = wg_ok && tail_groups > 0;
     const int lanes1 = mean_lanes(main_groups > 0 ? main_groups : 1);
     const int blocks1 = (int)((main_groups + lanes1 - 1) / lanes1);
-    const int wg_main_blocks = wg_main ? (int)((main_groups + lanes - 1) / lanes) : 0;
+    const int xcd_wg = env_int("QS_CL_XCD_WG", 1);     // XCD-contiguous order of the main workgroups (0: linear)
+    int wg_main_blocks = wg_main ? (int)((main_groups + lanes - 1) / lanes) : 0;
+    if (xcd_wg) wg_main_blocks = (wg_main_blocks + 7) / 8 * 8;
     const int wg_tail_blocks = wg_tail ? (int)((tail_groups + lanes - 1) / lanes) : 0;
     const int tail_blocks1 = (int)((tail_groups + 63) / 64);
     hipStream_t s = (hipStream_t)stream;
@@ -184,15 +186,18 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
             uint32_t* am = (uint32_t*)amax_part;
             auto launch = [&](auto M) {
                 constexpr int kM = decltype(M)::value;
-                if (!wg_main && main_groups > 0)
-                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(blocks1), dim3(64), 0, s, x, out, n, hw, C, am, lanes1,
-                                       main_groups, act);
+                if (!wg_main && main_groups > 0) {
+                    // XCD-contiguous wave order (see the kernel); QS_CL_XCD=0 restores the linear order
+                    const int xcd_per = env_int("QS_CL_XCD", 1) ? (blocks1 + 7) / 8 : 0;
+                    hipLaunchKernelGGL((mean_cl_kernel<XD, OD, kM>), dim3(xcd_per ? 8 * xcd_per : blocks1), dim3(64), 0, s, x, out, n,
+                                       hw, C, am, lanes1, main_groups, act, xcd_per);
+                }
                 if (wg_main || wg_tail) {
                     auto wg = [&](auto RR) {
                         constexpr int kR = decltype(RR)::value;
                         hipLaunchKernelGGL((mean_cl_wg_kernel<XD, OD, kR, kM>), dim3(wg_main_blocks + wg_tail_blocks), dim3(64 * kR),
                                            lds, s, x, out, n, hw, C, am, lanes, main_groups, wg_main_blocks, tail_groups,
-                                           (int)slots, act);
+                                           (int)slots, act, xcd_wg);
                     };
                     if constexpr (XD != QS_F32) {
                         if (R == 16) wg(IC<16>{});

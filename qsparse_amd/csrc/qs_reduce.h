@@ -847,9 +847,14 @@ __device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am, const ActSp
 template <int DT, int ODT, int MODE>
 __global__ __launch_bounds__(64) void mean_cl_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
                                                       int64_t hw, int64_t C, uint32_t* __restrict__ amax_part, int lanes,
-                                                      int64_t ngroups, ActSpec act) {
+                                                      int64_t ngroups, ActSpec act, int xcd_per) {
     const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
-    const int64_t t = (int64_t)blockIdx.x * lanes + threadIdx.x;
+    // xcd_per > 0: the launch has 8 * xcd_per workgroups and workgroup b (dispatched to XCD b % 8) takes the wave
+    // (b % 8) * xcd_per + b / 8 -- every XCD owns one contiguous eighth of the columns, so the single means and abs-max keys
+    // that neighbouring waves store into the same output lines (H*W apart per lane, adjacent across waves) meet in ONE L2 and
+    // leave it as full lines instead of as partial writes from eight L2s (a speed choice only: placement is not a contract)
+    const int64_t b = xcd_per > 0 ? (int64_t)(blockIdx.x & 7u) * xcd_per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t t = b * lanes + threadIdx.x;
     if ((int)threadIdx.x >= lanes || t >= ngroups) return;
     const int64_t col0 = t * 8;
     const int64_t pos = col0 / C, c0 = col0 - pos * C;
@@ -905,12 +910,14 @@ template <int DT, int ODT, int R, int MODE>
 __global__ __launch_bounds__(64 * R) void mean_cl_wg_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n,
                                                              int64_t hw, int64_t C, uint32_t* __restrict__ amax_part,
                                                              int lanes, int64_t main_groups, int main_blocks,
-                                                             int64_t tail_groups, int slots, ActSpec act) {
+                                                             int64_t tail_groups, int slots, ActSpec act, int xcd) {
     extern __shared__ __attribute__((aligned(16))) float cl_slot_sums[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t groups = hw * C / 8;                 // 16-byte groups per row of x
     const bool tail = (int)blockIdx.x >= main_blocks;
-    const int64_t local = (int64_t)(tail ? (int)blockIdx.x - main_blocks : (int)blockIdx.x) * lanes + lane;
+    // xcd != 0 (main_blocks is then a multiple of 8): XCD-contiguous order of the main workgroups, as in mean_cl_kernel
+    const int mb = (!tail && xcd) ? (int)(blockIdx.x & 7u) * (main_blocks >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t local = (int64_t)(tail ? (int)blockIdx.x - main_blocks : mb) * lanes + lane;
     const bool active = lane < lanes && local < (tail ? tail_groups : main_groups);
     const int64_t t = (tail ? main_groups : 0) + local;   // the group of every row this lane owns
     const int64_t items = tail ? n / 4 : n;            // items per cascade

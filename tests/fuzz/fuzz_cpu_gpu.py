@@ -45,7 +45,7 @@ def make_quantizer(rng):
 
 def build(rng):
     """returns (description, module factory, input shape, dtype)"""
-    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear"])
+    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear", "site", "site", "site"])
     dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
     if what in ("conv", "linear"):
         dtype = torch.float32
@@ -80,6 +80,41 @@ def build(rng):
             return qs.MagnitudePruningCallback(mask_refresh_interval=2, stop_mask_refresh=4)
         return qs.MagnitudePruningCallback()
 
+    if what == "site":
+        # a `convert`-built activation site (reference convert.py:199-229): activation module -> PruneLayer -> QuantizeLayer, the
+        # activation folded into the kernels on the GPU (nn.ReLU / ReLU6 / Hardtanh / LeakyReLU, in place or not), composite or
+        # fine-grained route, optional code saturation, masks that freeze (policy "refresh")
+        act = rng.choice(["relu", "relu", "relu6", "hardtanh", "leaky", "identity"])
+        inplace = act != "identity" and rng.random() < 0.35
+        if act == "leaky" and dtype == torch.float16:
+            # ATen's own fp16 leaky_relu_backward differs between its CPU and GPU kernels (a subnormal product on a rounding tie,
+            # -0.0 * slope; tools/_leaky_check.py) -- and it is ATen's kernel wherever a site is not fused (Adaptive quantizer, ...)
+            dtype = torch.bfloat16
+            desc["dtype"] = "bfloat16"
+        site = rng.choice(["pair", "pair", "act_q", "act_p"])
+        saturate = kind != "adaptive" and rng.random() < 0.25
+        if saturate:
+            qcb.saturate = True
+        flat = rng.random() < 0.2                # a 2-d activation (behind an nn.Linear)
+        if flat:
+            shape = shape[:2]
+        cb = pcb()
+        desc.update(act=act, inplace=inplace, site=site, saturate=saturate, shape=shape)
+        make_act = {"relu": lambda: nn.ReLU(inplace=inplace), "relu6": lambda: nn.ReLU6(inplace=inplace),
+                    "hardtanh": lambda: nn.Hardtanh(-0.75, 1.5, inplace=inplace), "leaky": lambda: nn.LeakyReLU(0.1, inplace=inplace),
+                    "identity": lambda: nn.Identity()}[act]
+
+        def site_factory():
+            net = nn.Sequential(make_act())
+            types = [type(net[0])]
+            if site in ("pair", "act_p"):
+                net = qs.convert(net, qs.prune(sparsity=sparsity, dimensions={1}, start=start, interval=interval, repetition=rep,
+                                               callback=copy.deepcopy(cb)), activation_layers=types, log=False)
+            if site in ("pair", "act_q"):
+                net = qs.convert(net, qs.quantize(bits=bits, channelwise=-1, timeout=timeout, callback=copy.deepcopy(qcb)),
+                                 activation_layers=types, log=False)
+            return net
+        return desc, site_factory, shape, dtype
     if what == "act_q":
         cw = rng.choice([-1, -1, 1])
         if cw == 1 and kind != "adaptive":
@@ -229,7 +264,8 @@ def one_functional(rng, idx, dry=False):
 ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
 
 
-def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False):
+def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False,
+        site=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -267,23 +303,25 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
                 if p.grad is not None:
                     outs.append(("grad:" + name, p.grad.cpu()))
             continue
-        x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
+        x = (torch.randn(shape, generator=g) * (3.0 if site else 1.5)).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -0.5]).to(dtype)
+        if site and x.numel() >= 8:             # the boundary values of the activations' gates
+            x.view(-1)[2:8] = torch.tensor([6.0, -0.75, 1.5, 7.5, -3.0, 1e-30]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (see tests/fuzz/fuzz_parity.py)
         if channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         xd = x.to(device).requires_grad_(True)
-        y = m(xd)
+        y = m(xd.clone() if site else xd)       # (an in-place activation needs a non-leaf input, as behind a convolution)
         if twin and m.training:         # a second forward before the first one's backward
             x2 = (x.detach().float() * 4).to(dtype).to(device).requires_grad_(True)
-            y2 = m(x2)
+            y2 = m(x2.clone() if site else x2)
             y2.backward((torch.randn(y2.shape, generator=g) * 3).to(y2.dtype).to(device))
             outs.append(("y2", y2.detach().cpu()))
             outs.append(("gx2", x2.grad.cpu()))
         gout = torch.randn(y.shape, generator=g).to(y.dtype)
         if channels_last and gout.dim() == 4:
             gout = gout.contiguous(memory_format=torch.channels_last)
-        outs.append(("layout", torch.tensor(y.stride())))
+        outs.append(("layout", torch.tensor([st for st, n in zip(y.stride(), y.shape) if n > 1])))     # (the stride of an extent-1 dim means nothing)
         for p in m.parameters():
             p.grad = None
         y.backward(gout.to(device))
@@ -299,7 +337,7 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
 
 def one_case(rng, idx, dry=False):
     desc, factory, shape, dtype = build(rng)
-    steps = rng.choice([3, 5, 6])
+    steps = rng.choice([3, 5, 6]) if desc["what"] != "site" else rng.choice([6, 8, 10])
     eval_from = rng.choice([steps, steps - 1])
     channels_last = rng.random() < 0.4
     if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact whenever the batch dim is reduced first
@@ -318,7 +356,7 @@ def one_case(rng, idx, dry=False):
     for device in ("cpu", "cuda"):
         try:
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher, twin)
+                                  channels_last, batcher, twin, desc['what'] == 'site')
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
     a, b = results["cpu"], results["cuda"]
@@ -332,6 +370,10 @@ def one_case(rng, idx, dry=False):
         if ka == kb and ka.startswith(("gx", "grad:")) and va.shape == vb.shape and torch.equal(va, vb):
             continue   # gradients clamped to [-0, +0] by a zero scale: ATen's own vector body and scalar tail disagree on the sign
         if ka != kb or not same(va, vb):
+            if VERBOSE and va.shape == vb.shape and va.is_floating_point():
+                bad = ((va.float() != vb.float()) | (torch.signbit(va) != torch.signbit(vb))).view(-1).nonzero().view(-1)
+                print(f"   {ka}: {bad.numel()} mismatching elements; first (index, cpu, gpu):",
+                      [(i, float(va.reshape(-1)[i]), float(vb.reshape(-1)[i])) for i in bad[:6].tolist()], flush=True)
             return dict(desc, mismatch=(ka, kb), cpu=(tuple(va.shape), str(va.dtype)), gpu=(tuple(vb.shape), str(vb.dtype)),
                         max_abs=float((va.float() - vb.float()).abs().max()) if va.shape == vb.shape and va.numel() else None)
     return "ok"
