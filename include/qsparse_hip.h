@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 13
+#define QS_ABI_VERSION 14
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -455,7 +455,17 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
  *                          the rows that trained -- *t_dev (quantizer callback's t, quantize.py:348) and *bump (the layer's
  *                          `_n_updates`, :515) -- are incremented here, i.e. after every thread of the preceding
  *                          qs_multi_scale_update has read them (stream order).  A callback shared by a layer's weight and
- *                          bias quantizers (:548,559-571) is two rows with the same t_dev and t_offset 0 / 1. */
+ *                          bias quantizers (:548,559-571) is two rows with the same t_dev and t_offset 0 / 1.
+ * A PRUNED weight -- quantize(prune(conv)): the quantizer's input is weight * mask (sparse.py:263 through imitation.py:61-68) --
+ * is a row with `mask` set: every x[e] above reads x[e] * mask[.] (the product itself, so that a non-finite weight under a
+ * pruned position behaves as in the reference).  mask_C == 0: one mask byte per element; else the mask varies along one run of
+ * dims: byte (e / mask_inner) % mask_C.  Steps on which the prune operator only applies its mask take part (before `start`
+ * without a mask; after the schedule with a frozen or a still-averaging full-shape magnitude); its counters -- prune_n_updates
+ * (PruneLayer._n_updates, sparse.py:272) and prune_t (MagnitudePruningCallback.t, :117) -- are incremented next to the
+ * quantizer's where non-NULL.
+ *   qs_multi_magnitude     rows with magnitude != NULL (full-shape masks): t = *prune_t;
+ *                          mag_backup[e] <- magnitude[e]; magnitude[e] <- (t*magnitude[e] + |x[e]|)/(t+1)   (sparse.py:82-89);
+ *                          launched BEFORE qs_multi_quant_fwd (which advances prune_t) */
 typedef struct qs_multi_row {
     const float* x;              /* the tensor, 4-byte aligned (16-byte aligned tensors take the vector paths) */
     float* scale;                /* [C] running scale (QuantizeLayer.weight) */
@@ -472,6 +482,14 @@ typedef struct qs_multi_row {
     int32_t t_offset;            /* added to *t_dev (1 for the bias quantizer that shares its weight quantizer's callback) */
     int32_t code_lo, code_hi;    /* code_lo > code_hi: no saturation */
     float denom;                 /* 2^(bits-1) */
+    const uint8_t* mask;         /* nullable: the prune operator's mask (bool bytes) */
+    int64_t mask_inner;          /* see above (ignored with mask_C == 0) */
+    int32_t mask_C;              /* 0: one mask byte per element */
+    int32_t reserved0;
+    int32_t* prune_n_updates;    /* nullable */
+    int64_t* prune_t;            /* nullable (required with magnitude) */
+    float* magnitude;            /* nullable: [numel] running magnitude, updated by qs_multi_magnitude */
+    float* mag_backup;           /* [numel] with magnitude: what the update replaced */
     /* derived by qs_multi_plan: */
     int32_t row_splits, absmax_block0, absmax_blocks, quant_block0, chan0;
 } qs_multi_row;
@@ -481,14 +499,17 @@ int qs_multi_plan(qs_multi_row* rows_host, int n, int* absmax_blocks, int* quant
 int qs_multi_absmax(const qs_multi_row* rows_dev, int n, int absmax_blocks, qs_stream_t stream);
 int qs_multi_scale_update(const qs_multi_row* rows_dev, int n, int channels, qs_stream_t stream);
 int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, float* ybase, int advance, qs_stream_t stream);
+int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs_stream_t stream);
 /*   qs_multi_ste_bwd:       gx[i][e] = clamp(g[i][e], lo_mul[i] * s, hi_mul[i] * s) with s = step[i][c] (or 2^-step[i][c] with
  *                           step_is_decimal), c the channel of e in the contiguous [*, C[i], inner[i]] view the gradient has
  *                           (C == NULL: tensor-wise, one step per tensor): qs_quant_ste_bwd's arithmetic (quantize.py:66-77,
  *                           120-131) for the gradients of a GROUP of weight quantizers that are handed over together.  The
- *                           gradients are fresh tensors every step: HOST arrays of length n of device pointers / values. */
+ *                           gradients are fresh tensors every step: HOST arrays of length n of device pointers / values.
+ *                           mask / mask_C / mask_inner (each array nullable, entries nullable / 0): the pruned weight's
+ *                           backward, gx = clamp(g) * mask (the product: a signed zero under a pruned position, sparse.py:263). */
 int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
                      const int32_t* C, const int64_t* inner, const float* lo_mul, const float* hi_mul, int step_is_decimal,
-                     qs_stream_t stream);
+                     const uint8_t* const* mask, const int32_t* mask_C, const int64_t* mask_inner, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

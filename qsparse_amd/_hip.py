@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 13          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 14          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -62,7 +62,8 @@ SIGNATURES = {
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
     "qs_multi_scale_update": (c_int, [_P, _I, _I, _P]),
     "qs_multi_quant_fwd": (c_int, [_P, _I, _I, _P, _I, _P]),
-    "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qs_multi_magnitude": (c_int, [_P, _I, _I, _P]),
+    "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
     "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
@@ -90,7 +91,10 @@ class MultiRow(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("scale", c_void_p), ("amax", c_void_p), ("decimal", c_void_p), ("backup", c_void_p),
                 ("t_dev", c_void_p), ("bump", c_void_p), ("numel", c_int64), ("y_off", c_int64), ("outer", c_int64),
                 ("inner", c_int64), ("C", c_int32), ("train", c_int32), ("is_decimal", c_int32), ("t_offset", c_int32),
-                ("code_lo", c_int32), ("code_hi", c_int32), ("denom", c_float), ("row_splits", c_int32),
+                ("code_lo", c_int32), ("code_hi", c_int32), ("denom", c_float),
+                ("mask", c_void_p), ("mask_inner", c_int64), ("mask_C", c_int32), ("reserved0", c_int32),
+                ("prune_n_updates", c_void_p), ("prune_t", c_void_p), ("magnitude", c_void_p), ("mag_backup", c_void_p),
+                ("row_splits", c_int32),
                 ("absmax_block0", c_int32), ("absmax_blocks", c_int32), ("quant_block0", c_int32), ("chan0", c_int32)]
 
 
@@ -351,14 +355,46 @@ def act_spec(handle: int):
     raise KeyError(handle)
 
 
-def act_torch(pre_relu, x: torch.Tensor) -> torch.Tensor:
-    """the folded activation as an ATen expression (out of place): the routes that have to materialise it after all"""
-    kind, a, b = act_spec(_act(pre_relu))
+class _ActivationFromOutput(torch.autograd.Function):
+    """an out-of-place activation whose backward keeps its OUTPUT instead of its input (threshold_backward /
+    hardtanh_backward / leaky_relu_backward all decide on the side of the rectified value just as well): for an input whose
+    storage is about to be overwritten, see `act_torch`"""
+
+    @staticmethod
+    def forward(ctx, h, act):
+        ctx.act = act
+        y = _act_aten(act, h)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        kind, slope, _ = act_spec(ctx.act)
+        closed = g * slope if kind == ACT_LEAKY else torch.zeros((), dtype=g.dtype, device=g.device)
+        return torch.where(act_gate_of(ctx.act, y), g, closed), None
+
+
+def _act_aten(act: int, x: torch.Tensor) -> torch.Tensor:
+    kind, a, b = act_spec(act)
     if kind == ACT_RELU:
         return torch.relu(x)
     if kind == ACT_HARDTANH:
         return torch.nn.functional.hardtanh(x, a, b)
     return torch.nn.functional.leaky_relu(x, a)
+
+
+def act_torch(pre_relu, x: torch.Tensor) -> torch.Tensor:
+    """the folded activation as an ATen expression (out of place): the routes that have to materialise it after all"""
+    cell = owned_relu_cell()
+    if (cell is not None and cell.get("x") is not None and torch.is_grad_enabled() and x.requires_grad
+            and x.data_ptr() == cell["x"].data_ptr() and x.shape == cell["x"].shape):
+        # an owned in-place activation is still pending on this very storage (fused.py::_with_owned_relu deferred it to the site's
+        # apply kernel; the ATen in-place pass runs after the site when no kernel did it).  ATen's own out-of-place activation
+        # would keep this raw alias for its backward, and the pending pass would then overwrite it ("modified by an inplace
+        # operation"): record a node that keeps its output instead.
+        return _ActivationFromOutput.apply(x, _act(pre_relu))
+    return _act_aten(_act(pre_relu), x)
 
 
 def act_torch_(pre_relu, x: torch.Tensor) -> torch.Tensor:
@@ -1023,11 +1059,19 @@ def f32_array(values):
     return (c_float * len(values))(*[float(v) for v in values])
 
 
+def multi_magnitude(table: MultiTable, nbytes: int = 0):
+    """the running magnitudes of the table's pruned weights (rows with `magnitude`), before `multi_quant_fwd` advances their count"""
+    with _timed("multi_magnitude", int(nbytes)):
+        st = load().qs_multi_magnitude(table.dev.data_ptr(), table.n, table.quant_blocks, _device_stream(table.device))
+    _check(st, "qs_multi_magnitude")
+
+
 def multi_ste_bwd(n: int, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, decimal: bool, device, nbytes: int = 0,
-                  channels=None, inners=None):
+                  channels=None, inners=None, masks=None, mask_channels=None, mask_inners=None):
     """channels / inners (`i32_array` / `i64_array`, both or neither): per-channel steps -- gradient i is the contiguous
-    [*, channels[i], inners[i]] view; None: one step per tensor"""
+    [*, channels[i], inners[i]] view; None: one step per tensor.  masks (`ptr_array`, entries may be NULL) with mask_channels /
+    mask_inners: the pruned weights' masks, gx = clamp(g) * mask"""
     with _timed("multi_ste_bwd", int(nbytes)):
         st = load().qs_multi_ste_bwd(n, g_ptrs, gx_ptrs, step_ptrs, numels, channels, inners, lo_muls, hi_muls, int(bool(decimal)),
-                                     _device_stream(device))
+                                     masks, mask_channels, mask_inners, _device_stream(device))
     _check(st, "qs_multi_ste_bwd")

@@ -33,9 +33,16 @@ undoes it).  It is safe by construction for anything a forward pass may do:
     layer's read, is not visible -- switch ``batch_weights`` off for such a network.)
   * A bias that is read BEFORE its layer's weight (the reference would then have updated the bias with ``t``, not ``t + 1``)
     rolls both back; they are evaluated inline in the order of the reads.
-  * Layers whose quantizer carries hooks, layers on the CPU, pruned layers (their quantizer's input is the pruned weight, which
-    the prune operator makes per read), group-wise quantizers and callbacks shared between layers never take part; they keep
-    their inline path.
+  * A PRUNED weight -- ``quantize(prune(conv))``: the quantizer's input is ``weight * mask`` (sparse.py:263) -- takes part on
+    every step on which its prune operator only applies the mask: before ``start`` (no mask yet, the layer only counts), after
+    the schedule while nothing refreshes (a frozen mask, or ``running_average=False``: the steady state of the reference's
+    layerwise recipe, sparse.py:343-359), with a full-shape mask also while the running magnitude is still averaged (one more
+    launch, ``qs_multi_magnitude``), and in evaluation.  The kernels multiply by the mask themselves and advance the prune
+    operator's counters; a step that changes the sparsity or rebuilds the mask keeps the inline path (and so does a mask over
+    a channel subset whose magnitude is still averaged: a staged mean per layer).  Rolled back like the quantizer's state
+    (the magnitudes from the backup the launch wrote).
+  * Layers whose operators carry hooks, layers on the CPU, group-wise quantizers, callbacks shared between layers, pruning
+    callbacks other than ``MagnitudePruningCallback`` (or ranking by gradient / L0) never take part; they keep their inline path.
 
 In evaluation mode under ``torch.no_grad()`` the quantized tensors are computed once and handed out again until a parameter
 or a scale changes (serving: no weight-side launch at all per request).
@@ -48,7 +55,9 @@ import torch.nn as nn
 from torch.nn.modules import module as _m
 
 from qsparse_amd import _hip
+from qsparse_amd import distributed as qdist
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
+from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer
 from qsparse_amd.util import get_option, logging
 
 _ALIGN = 64   # elements between the starts of two outputs in the flat buffer (256 bytes)
@@ -96,7 +105,7 @@ class _GroupSte(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, dead, *tensors):
         k = len(meta)
-        ctx.meta, ctx.dead = meta, dead                     # per tensor: (is_decimal, lo_mul, hi_mul, passthrough, channel index); rolled back?
+        ctx.meta, ctx.dead = meta, dead                     # per tensor: (is_decimal, lo_mul, hi_mul, passthrough, channel index, mask); rolled back?
         ctx.shapes = [(w.shape, w.stride()) for w in tensors[:k]]
         ctx.save_for_backward(*tensors[2 * k:])             # the steps (scales or decimals: one per channel)
         # a member whose tensor is never read gets NO gradient, exactly like the layer the reference never evaluated
@@ -135,6 +144,8 @@ class _GroupSte(torch.autograd.Function):
             for i in idx:
                 if geo[i] is None:                          # odd layouts / dtypes: the per-layer entry point
                     out[i] = _hip.ste_bwd(grads[i], steps[i], decimal, meta[i][4], meta[i][1], meta[i][2], False, torch.float32)
+                    if meta[i][5] is not None:              # a pruned weight: the backward of `weight * mask` (sparse.py:263)
+                        out[i] = out[i] * meta[i][5][0]
             if fast:
                 gs = [grads[i] for i in fast]
                 flat = torch.empty(sum((g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for g in gs), dtype=torch.float32, device=gs[0].device)
@@ -144,16 +155,26 @@ class _GroupSte(torch.autograd.Function):
                     off += (g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
                 numels = [g.numel() for g in gs]
                 per_channel = any(geo[i][1] > 1 for i in fast)
+                # pruned weights: the gradient has the weight's own (contiguous) layout, which is what the mask geometry describes;
+                # any other layout multiplies afterwards
+                mk = {i: meta[i][5] for i in fast if meta[i][5] is not None}
+                in_kernel = {i for i in mk if grads[i].is_contiguous()}
                 _hip.multi_ste_bwd(len(fast), _hip.ptr_array(gs), _hip.ptr_array(outs), _hip.ptr_array([steps[i] for i in fast]),
                                    _hip.i64_array(numels), _hip.f32_array([meta[i][1] for i in fast]),
                                    _hip.f32_array([meta[i][2] for i in fast]), decimal, gs[0].device, nbytes=8 * sum(numels),
                                    channels=_hip.i32_array([geo[i][1] for i in fast]) if per_channel else None,
-                                   inners=_hip.i64_array([geo[i][2] for i in fast]) if per_channel else None)
+                                   inners=_hip.i64_array([geo[i][2] for i in fast]) if per_channel else None,
+                                   masks=_hip.ptr_array([mk[i][0] if i in in_kernel else None for i in fast]) if in_kernel else None,
+                                   mask_channels=_hip.i32_array([mk[i][1] if i in in_kernel else 0 for i in fast]) if in_kernel else None,
+                                   mask_inners=_hip.i64_array([mk[i][2] if i in in_kernel else 1 for i in fast]) if in_kernel else None)
+                for i in mk:
+                    if i not in in_kernel:
+                        outs[fast.index(i)] = outs[fast.index(i)] * mk[i][0]
                 for i, o in zip(fast, outs):
                     out[i] = o
         for i in range(k):
             if out[i] is None and grads[i] is not None and meta[i][3]:
-                out[i] = grads[i]                           # backward_passthrough
+                out[i] = grads[i] if meta[i][5] is None else grads[i] * meta[i][5][0]      # backward_passthrough
         return (None, None) + tuple(out) + (None,) * (2 * k)
 
 
@@ -178,10 +199,43 @@ def _unit_ok(q, p) -> bool:
             and q.channelwise < p.dim())
 
 
+def _prune_ok(p) -> bool:
+    """a prune operator whose idle steps the kernels can stand in for: the stock magnitude policy, ranking by value"""
+    if not isinstance(p, PruneLayer):
+        return False
+    cb = p.callback
+    return type(cb) is MagnitudePruningCallback and not cb.use_gradient and not cb.l0 and cb.forward_hook is None
+
+
+def _mask_geometry(shape, mask_shape):
+    """(mask_C, mask_inner) of a broadcast mask over a CONTIGUOUS tensor: (0, 1) for a full-shape mask, else the mask varies
+    along one run of dims -- its byte for element e is (e // mask_inner) % mask_C; None when it does not (or has one element)"""
+    shape, mask_shape = tuple(shape), tuple(mask_shape)
+    if len(shape) != len(mask_shape) or any(m not in (1, s) for m, s in zip(mask_shape, shape)):
+        return None
+    varying = [d for d, (m, s) in enumerate(zip(mask_shape, shape)) if m == s and s > 1]
+    if not varying:
+        return None
+    if len(varying) == sum(1 for s in shape if s > 1):
+        return (0, 1)
+    lo, hi = varying[0], varying[-1]
+    if any(shape[d] > 1 and mask_shape[d] == 1 for d in range(lo, hi + 1)):
+        return None
+    C = 1
+    for d in range(lo, hi + 1):
+        C *= shape[d]
+    inner = 1
+    for s in shape[hi + 1:]:
+        inner *= s
+    return (C, inner)
+
+
 def _eligible(layer: nn.Module) -> bool:
-    """a layer whose weight is read through exactly one quantizer (tensor-wise or per channel) and nothing else"""
+    """a layer whose weight is read through exactly one quantizer (tensor-wise or per channel) -- and, underneath it, at most a
+    prune operator"""
     params = getattr(layer, "_parameters", None)
-    if params is None or _operators(layer) != ["quantize"]:
+    ops = _operators(layer) if params is not None else None
+    if ops != ["quantize"] and not (ops == ["quantize", "prune"] and _prune_ok(getattr(layer, "prune", None))):
         return False
     if not _unit_ok(getattr(layer, "quantize", None), params.get("weight")):
         return False
@@ -217,7 +271,15 @@ def _batchable(model: nn.Module) -> List[nn.Module]:
     count `t` then advances once per layer read, in forward order) -- such layers keep the inline path, whose order of
     evaluation is the forward's own."""
     owners = _callback_owners(model)
-    return [m for m in model.modules() if _eligible(m) and owners.get(id(m.quantize.callback), 0) == 1]
+    prune_owners = {}                 # a pruning callback shared between layers: one `t`, one magnitude -- inline as well
+    for m in model.modules():
+        if isinstance(m, PruneLayer) and m.callback is not None:
+            prune_owners[id(m.callback)] = prune_owners.get(id(m.callback), 0) + 1
+
+    def own_prune(m):
+        p = m.__dict__.get("_modules", {}).get("prune")
+        return not isinstance(p, PruneLayer) or prune_owners.get(id(p.callback), 0) == 1
+    return [m for m in model.modules() if _eligible(m) and owners.get(id(m.quantize.callback), 0) == 1 and own_prune(m)]
 
 
 def _hooked(q: QuantizeLayer) -> bool:
@@ -226,6 +288,47 @@ def _hooked(q: QuantizeLayer) -> bool:
     if _m._global_forward_hooks or _m._global_forward_pre_hooks:
         return True
     return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (q, q.callback))
+
+
+def _hooked_prune(p: PruneLayer) -> bool:
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (p, p.callback))
+
+
+def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
+    """what the prune operator underneath a weight's quantizer would do on this read, if that is something the multi-tensor
+    kernels can do in its place -- None otherwise (the inline path then runs the operator itself).  Reads state, changes none.
+    Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude)."""
+    if not _prune_ok(p) or _hooked_prune(p) or not p.initted or p.training != training or not w.is_contiguous():
+        return None
+    mask = p.mask
+    if (not mask.is_cuda or mask.device != w.device or mask.dtype != torch.bool or not mask.is_contiguous() or mask.is_inference()
+            or not p._n_updates.is_cuda or mask.numel() == 1):
+        return None
+    geo = _mask_geometry(w.shape, mask.shape)
+    if geo is None:
+        return None
+    if not training:                              # PruneLayer.forward in evaluation: weight * mask, nothing else
+        return (geo, False, False, False)
+    n = p._steps.read(p._n_updates)
+    if n in p.schedules:
+        return None                               # the sparsity changes on this read
+    if n < p.start:
+        return (None, True, False, False)         # not pruning yet: the layer only counts
+    cb = p.callback
+    if not cb.initted or not cb.t.is_cuda or cb.t.device != w.device:
+        return None
+    t = cb._t_host.read(cb.t)
+    if cb.refresh_due(t, p.current_sparsity()):
+        return None                               # the mask is rebuilt on this read
+    average = t < cb.stop_mask_refresh and cb.running_average
+    if average:
+        # the running magnitude of a full-shape mask is element-wise; over a channel subset it is a staged mean per layer, and
+        # under a process group the reference path averages it over the ranks: both stay inline
+        mag = getattr(cb, "magnitude", None)
+        if (geo != (0, 1) or mag is None or not mag.is_cuda or mag.dtype != torch.float32 or not mag.is_contiguous()
+                or mag.numel() != w.numel() or qdist.exchange_active(qdist.stats_world_size())):
+            return None
+    return (geo, True, True, average)
 
 
 class _LaunchPlan(dict):
@@ -253,14 +356,23 @@ class _Unit:
     def param(self) -> torch.Tensor:
         return self.layer._parameters[self.attr]
 
+    @property
+    def p(self) -> Optional[PruneLayer]:
+        """the prune operator underneath the weight's quantizer, if there is one"""
+        if self.attr != "weight":
+            return None
+        p = self.layer.__dict__.get("_modules", {}).get("prune")
+        return p if isinstance(p, PruneLayer) else None
+
 
 class _Pending:
     """what has to be undone if a precomputed tensor is never read"""
-    __slots__ = ("unit", "was_quantized", "t_dev", "version", "training", "dead", "index")
+    __slots__ = ("unit", "was_quantized", "t_dev", "version", "training", "dead", "index", "prune")
 
-    def __init__(self, unit, was_quantized, t_dev, version, training):
+    def __init__(self, unit, was_quantized, t_dev, version, training, prune=None):
         self.unit, self.was_quantized, self.t_dev, self.version, self.training = unit, was_quantized, t_dev, version, training
         self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this tensor's place in them
+        self.prune = prune                  # (counted n_updates, counted t, magnitude backup or None) of a pruned weight
 
 
 def _patched_class(base):
@@ -385,6 +497,15 @@ class WeightBatcher:
             if p.t_dev is not None:
                 p.t_dev.sub_(1)
                 qc.__dict__["_t_dev_value"] = qc.t
+            if p.prune is not None:          # the prune operator underneath: its counters and its running magnitude
+                pl = u.p
+                counted_n, counted_t, mag_backup = p.prune
+                if counted_n:
+                    pl._steps.add(pl._n_updates, -1)
+                if counted_t:
+                    pl.callback._t_host.add(pl.callback.t, -1)
+                if mag_backup is not None:
+                    pl.callback.magnitude.data.view(-1).copy_(mag_backup)
         q._quantized = p.was_quantized
 
     def _rollback_all(self):
@@ -405,6 +526,7 @@ class WeightBatcher:
         if not get_option("batch_weights"):
             return
         train, frozen = [], []          # tensors that update statistics this step / that only quantize
+        prune_steps = {}                # id(layer) -> what its prune operator does on this read (`_prune_step`)
         skip_layer = None
         for u in self.units:
             layer = u.layer
@@ -423,6 +545,11 @@ class WeightBatcher:
             ok = ok and q.weight.is_contiguous() and not (w.is_inference() or q.weight.is_inference())
             t = q._steps.read(q._n_updates) if ok else 0
             took_part = False
+            pl = u.p
+            if ok and pl is not None and t >= q.timeout and (q.training or q._quantized):
+                # a pruned weight: only on the steps its prune operator leaves to the kernels (see `_prune_step`)
+                prune_steps[id(layer)] = _prune_step(pl, w, q.training)
+                ok = prune_steps[id(layer)] is not None
             if ok and t >= q.timeout:     # (below the timeout: identity phase, the inline path only counts)
                 if q.training:
                     if t == q.timeout and get_option("log_during_train"):
@@ -454,9 +581,10 @@ class WeightBatcher:
         # counter does not see, and would be handed stale weights silently; such loops pay the launch per forward)
         if not train and not torch.is_grad_enabled():
             eval_key = tuple((id(u.layer), u.attr, w.data_ptr(), w._version, u.q.weight.data_ptr(), u.q.weight._version,
-                              tuple(w.stride()), sat) for u, w, sat in zip(todo, weights, sats))
+                              tuple(w.stride()), sat) + ((u.p.mask.data_ptr(), u.p.mask._version) if u.p is not None else ())
+                             for u, w, sat in zip(todo, weights, sats))
             if eval_key == self._eval_key:
-                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals)
+                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals, prune_steps)
                 return
         self._eval_key = None
         undo = {}
@@ -464,22 +592,37 @@ class WeightBatcher:
             t_devs = [u.q.callback.device_t(dev) if i < len(train) else None for i, u in enumerate(todo)]
             # everything that does not change from step to step -- the launch table, the layout of the flat output buffer --
             # is built once per (set of tensors, parameter storage, state storage) and reused
+            # (pruned weights: the mask and what the prune operator does this step are part of the table)
+            psteps = [prune_steps.get(id(u.layer)) if u.attr == "weight" else None for u in todo]
             key = (len(train), tuple(sats)) + tuple(
                 (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), u.q.weight.data_ptr(), u.q._n_updates.data_ptr(),
-                 None if td is None else td.data_ptr()) for u, w, td in zip(todo, weights, t_devs))
+                 None if td is None else td.data_ptr())
+                + ((ps, u.p.mask.data_ptr(), u.p._n_updates.data_ptr(), u.p.callback.t.data_ptr(),
+                    u.p.callback.magnitude.data_ptr() if ps[3] else None) if ps is not None else ())
+                for u, w, td, ps in zip(todo, weights, t_devs, psteps))
             plan = self._plan if self._plan is not None and self._plan.get("key") == key else None
             if plan is None:
-                plan = self._plan = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev)
+                plan = self._plan = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev, psteps)
             table = plan["table"]
             if train:
                 _hip.multi_absmax(table, nbytes=plan["train_bytes"])
                 _hip.multi_scale_update(table)
-                for u, t_dev in zip(train, t_devs):
+                for i, (u, t_dev) in enumerate(zip(train, t_devs)):
                     q, qc = u.q, u.q.callback
-                    undo[(id(u.layer), u.attr)] = _Pending(u, q._quantized, t_dev, u.param._version, True)
+                    ps, prune_undo = psteps[i], None
+                    if ps is not None:          # the prune operator's own bookkeeping of this read (sparse.py:117,272)
+                        pl = u.p
+                        if ps[1]:
+                            pl._steps.note_device_add(pl._n_updates, 1)
+                        if ps[2]:
+                            pl.callback._t_host.note_device_add(pl.callback.t, 1)
+                        prune_undo = (ps[1], ps[2], plan["mag_backups"].get(i))
+                    undo[(id(u.layer), u.attr)] = _Pending(u, q._quantized, t_dev, u.param._version, True, prune_undo)
                     qc._advance_t(t_dev, bumped_by_kernel=True)
                     q._quantized = True
                     q._steps.note_device_add(q._n_updates, 1)
+                if plan["mag_backups"]:
+                    _hip.multi_magnitude(table, nbytes=plan["mag_bytes"])
             for u in frozen:       # evaluation: the decimals of the frozen scales (the inline path recomputes them per call as well)
                 if not u.q.callback.use_float_scaler:
                     self._decimals[u.slot:u.slot + u.channels] = _hip.decimal_from_scale(u.q.weight.data.view(-1))
@@ -491,21 +634,22 @@ class WeightBatcher:
                 # 1-d bias into a (1, C) tensor (quantize.py `_reference_shape`; nn.Linear takes it, nn.Conv2d rejects it)
                 if u.q.weight.numel() == 1 and u.q.weight.dim() > w.dim():
                     outs[i] = outs[i].view(torch.broadcast_shapes(tuple(w.shape), tuple(u.q.weight.shape)))
-            _hip.multi_quant_fwd(table, flat, advance=bool(train), nbytes=plan["all_bytes"])
+            _hip.multi_quant_fwd(table, flat, advance=bool(train), nbytes=plan["all_bytes"])      # (prune counters ride with train rows)
             # a DecimalQuantizer's backward clamps with the decimal of ITS forward (the reference computes a fresh tensor per
             # call, quantize.py:312-325, and the Function saves that one, :41): the hand-out nodes get this step's values, not
             # the buffer the next precomputation overwrites (a ScalerQuantizer's saves the scale parameter itself, :108)
             decimals = self._decimals.clone() if plan["any_decimal"] else self._decimals
         if eval_key is not None:
             self._eval_key, self._eval_outs, self._eval_decimals = eval_key, outs, decimals
-        self._hand_out(todo, weights, outs, undo, decimals)
+        self._hand_out(todo, weights, outs, undo, decimals, prune_steps)
 
-    def _build_plan(self, key, todo, weights, t_devs, sats, n_train, dev) -> _LaunchPlan:
+    def _build_plan(self, key, todo, weights, t_devs, sats, n_train, dev, psteps) -> _LaunchPlan:
         offsets, total = [], 0
         for w in weights:
             offsets.append(total)
             total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         rows, keep = [], []
+        mag_backups, mag_bytes = {}, 0
         trains_weight = {id(u.layer) for u in todo[:n_train] if u.attr == "weight"}
         for i, (u, w, sat) in enumerate(zip(todo, weights, sats)):
             q, qc = u.q, u.q.callback
@@ -526,12 +670,32 @@ class WeightBatcher:
             r.t_offset = int(u.attr == "bias" and i < n_train and id(u.layer) in trains_weight)
             r.code_lo, r.code_hi = (1, 0) if sat is None else (int(sat[0]), int(sat[1]))
             r.denom = float(2 ** (q.bits - 1))
+            ps = psteps[i]
+            if ps is not None:                   # a pruned weight (see `_prune_step`)
+                pl = u.p
+                geo, counts_n, counts_t, averages = ps
+                if geo is not None:
+                    r.mask, r.mask_C, r.mask_inner = pl.mask.data_ptr(), geo[0], geo[1]
+                    keep.append(pl.mask)
+                if counts_n:
+                    r.prune_n_updates = pl._n_updates.data_ptr()
+                    keep.append(pl._n_updates)
+                if counts_t:
+                    r.prune_t = pl.callback.t.data_ptr()
+                    keep.append(pl.callback.t)
+                if averages:
+                    backup = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+                    r.magnitude, r.mag_backup = pl.callback.magnitude.data_ptr(), backup.data_ptr()
+                    keep += [pl.callback.magnitude, backup]
+                    mag_backups[i] = backup
+                    mag_bytes += 16 * w.numel()
             rows.append(r)
         return _LaunchPlan(key=key, offsets=offsets, total=total, keep=keep, table=_hip.MultiTable(rows, dev),
+                           mag_backups=mag_backups, mag_bytes=mag_bytes,
                            train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
                            any_decimal=any(not u.q.callback.use_float_scaler for u in todo))
 
-    def _hand_out(self, todo, weights, outs, undo, decimals):
+    def _hand_out(self, todo, weights, outs, undo, decimals, prune_steps=None):
         """park every quantized tensor on its layer, `_GROUP` consecutive tensors per autograd node (a node per layer in
         evaluation mode under no_grad costs nothing either way)"""
         for base in range(0, len(todo), _GROUP):
@@ -542,7 +706,9 @@ class WeightBatcher:
                 is_decimal = not qc.use_float_scaler
                 limit = 2.0 ** (q.bits - 1)
                 notch = 1 if qc.flip_axis else 0
-                meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise))
+                ps = prune_steps.get(id(u.layer)) if (prune_steps and u.attr == "weight") else None
+                mask = (u.p.mask, ps[0][0], ps[0][1]) if (ps is not None and ps[0] is not None) else None
+                meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise, mask))
                 steps.append(decimals[u.slot:u.slot + u.channels].view(-1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)
             ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)

@@ -311,6 +311,8 @@ int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_bloc
         if (r.C > 1 && (r.inner >= ((int64_t)1 << 31) || r.outer >= ((int64_t)1 << 31))) return QS_ERR_ARG;
         if (r.train && (!r.amax || !r.t_dev || !(r.denom > 0.f))) return QS_ERR_ARG;
         if (r.is_decimal && !r.decimal) return QS_ERR_ARG;
+        if (r.mask && r.mask_C != 0 && (r.mask_C < 1 || r.mask_inner < 1)) return QS_ERR_ARG;
+        if (r.magnitude && (!r.mag_backup || !r.prune_t)) return QS_ERR_ARG;
         if ((((uintptr_t)r.x) & 3u) != 0) return QS_ERR_ALIGN;
         r.absmax_block0 = (int32_t)ab;
         r.row_splits = 1;
@@ -366,9 +368,16 @@ int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, fl
     return launch_status();
 }
 
+int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs_stream_t stream) {
+    if (n < 0 || quant_blocks < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
+    if (n == 0 || quant_blocks == 0) return QS_OK;
+    hipLaunchKernelGGL(multi_magnitude_kernel, dim3(quant_blocks), dim3(kBlock), 0, (hipStream_t)stream, rows_dev, n);
+    return launch_status();
+}
+
 int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
                      const int32_t* C, const int64_t* inner, const float* lo_mul, const float* hi_mul, int step_is_decimal,
-                     qs_stream_t stream) {
+                     const uint8_t* const* mask, const int32_t* mask_C, const int64_t* mask_inner, qs_stream_t stream) {
     if (n < 0 || (n > 0 && (!g || !gx || !step || !numel || !lo_mul || !hi_mul)) || ((C == nullptr) != (inner == nullptr)))
         return QS_ERR_ARG;
     for (int base = 0; base < n; base += kMultiSteMax) {
@@ -388,6 +397,10 @@ int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* cons
             a.inner[i] = a.C[i] > 1 ? (int32_t)inner[k] : 1;
             a.lo_mul[i] = lo_mul[k];
             a.hi_mul[i] = hi_mul[k];
+            a.mask[i] = mask ? mask[k] : nullptr;
+            a.mask_C[i] = (a.mask[i] && mask_C) ? mask_C[k] : 0;
+            a.mask_inner[i] = (a.mask[i] && mask_inner) ? mask_inner[k] : 1;
+            if (a.mask[i] && a.mask_C[i] != 0 && (a.mask_C[i] < 1 || a.mask_inner[i] < 1)) return QS_ERR_ARG;
             a.block0[i] = (int32_t)blocks;
             blocks += std::max<int64_t>((numel[k] + 8 * kBlock - 1) / (8 * kBlock), 1);
             if (blocks > 0x7fffffff) return QS_ERR_ARG;

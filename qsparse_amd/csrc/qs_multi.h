@@ -25,6 +25,12 @@ __device__ __forceinline__ int multi_find(const qs_multi_row* __restrict__ rows,
     return lo;
 }
 
+// the prune operator's mask at element e of a row (1.0f / 0.0f: the quantizer's input is the PRODUCT x * mask, sparse.py:263)
+__device__ __forceinline__ float multi_mask_at(const uint8_t* __restrict__ mask, int32_t mask_C, int64_t mask_inner, int64_t e) {
+    const int64_t i = mask_C == 0 ? e : (e / mask_inner) % mask_C;
+    return mask[i] ? 1.0f : 0.0f;
+}
+
 constexpr int kMultiTallCols = 64;      // per-channel abs-max, outer > 1: adjacent columns per workgroup (one coalesced 256-byte row segment)
 constexpr int kMultiFlatCols = 2048;    // outer == 1 (the channel dim is the first one): elements per workgroup
 
@@ -50,12 +56,20 @@ static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(const qs_mu
             for (int64_t g = (int64_t)b * kBlock + threadIdx.x; g < ngroups; g += (int64_t)nb * kBlock) {
                 float v[8];
                 unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+                if (r.mask) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= multi_mask_at(r.mask, r.mask_C, r.mask_inner, g * 8 + j);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc.add(v[j]);
             }
-            if (b == 0 && ngroups * 8 + threadIdx.x < r.numel) acc.add(x[ngroups * 8 + threadIdx.x]);
+            if (b == 0 && ngroups * 8 + threadIdx.x < r.numel) {
+                const int64_t e = ngroups * 8 + threadIdx.x;
+                acc.add(r.mask ? x[e] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, e) : x[e]);
+            }
         } else {
-            for (int64_t e = (int64_t)b * kBlock + threadIdx.x; e < r.numel; e += (int64_t)nb * kBlock) acc.add(x[e]);
+            for (int64_t e = (int64_t)b * kBlock + threadIdx.x; e < r.numel; e += (int64_t)nb * kBlock)
+                acc.add(r.mask ? x[e] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, e) : x[e]);
         }
         __shared__ uint32_t smx[kBlock / 64];
         acc.wave_reduce();
@@ -85,6 +99,13 @@ static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(const qs_mu
             const float* col = x + j;
             const int64_t stride = (int64_t)splits * (kBlock / 64);              // rows between two visits of this wave
             int64_t row = (int64_t)rs * (kBlock / 64) + wave;
+            if (r.mask) {       // a pruned weight: |x * mask|
+                for (; row < r.outer; row += stride) {
+                    const float v = col[row * cols] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, row * cols + j);
+                    const uint32_t k = __float_as_uint(v) & 0x7fffffffu;
+                    m = k > m ? k : m;
+                }
+            }
             for (; row + 3 * stride < r.outer; row += 4 * stride) {             // four rows in flight
                 const uint32_t k0 = __float_as_uint(col[row * cols]) & 0x7fffffffu;
                 const uint32_t k1 = __float_as_uint(col[(row + stride) * cols]) & 0x7fffffffu;
@@ -103,7 +124,10 @@ static __global__ __launch_bounds__(kBlock) void multi_absmax_kernel(const qs_mu
     } else {
         for (int t = threadIdx.x; t < cpb; t += kBlock) {
             const int64_t j = col0 + t;
-            if (j < cols) atomicMax(&chan[(int)(j / r.inner - c_lo)], __float_as_uint(x[j]) & 0x7fffffffu);
+            if (j < cols) {
+                const float v = r.mask ? x[j] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, j) : x[j];
+                atomicMax(&chan[(int)(j / r.inner - c_lo)], __float_as_uint(v) & 0x7fffffffu);
+            }
         }
     }
     __syncthreads();
@@ -161,6 +185,9 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
         // a layer's weight and bias quantizers (reference quantize.py:548,559-571) appears in two rows with the same counter
         // and t_offset 0 / 1: the weight's update saw t, the bias's t + 1, the counter moves by two.
         for (int k = threadIdx.x; k < n; k += kBlock) {
+            // (the prune operator's counters of a pruned weight: every training read counts, sparse.py:117,272)
+            if (rows[k].prune_n_updates) atomicAdd(rows[k].prune_n_updates, 1);
+            if (rows[k].prune_t) atomicAdd((unsigned long long*)rows[k].prune_t, 1ull);
             if (!rows[k].train) continue;
             atomicAdd((unsigned long long*)rows[k].t_dev, 1ull);
             if (rows[k].bump) atomicAdd(rows[k].bump, 1);
@@ -176,21 +203,30 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
     const float* param = r.is_decimal ? r.decimal : r.scale;
     const bool vec = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
     int32_t code;
+    // the quantizer's input at element e: x[e], or x[e] * mask for a pruned weight
+    auto in1 = [&](int64_t e) -> float { return r.mask ? x[e] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, e) : x[e]; };
+    auto in8 = [&](int64_t grp, float (&v)[8]) {
+        unpack8<QS_F32>(load8_raw<QS_F32, false>(x, grp), v);
+        if (r.mask) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= multi_mask_at(r.mask, r.mask_C, r.mask_inner, grp * 8 + j);
+        }
+    };
     auto run = [&](auto op) {
         if (r.C == 1) {
             const auto p = op.channel(0);
             if (vec) {
                 if (g < ngroups) {
                     float v[8];
-                    unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+                    in8(g, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
                     store8<QS_F32, false>(y, g, v);
                 }
                 if (g == 0)
-                    for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(x[e], p, code);
+                    for (int64_t e = ngroups * 8; e < numel; ++e) y[e] = op.apply(in1(e), p, code);
             } else {
-                for (int64_t e = g * 8; e < numel && e < g * 8 + 8; ++e) y[e] = op.apply(x[e], p, code);
+                for (int64_t e = g * 8; e < numel && e < g * 8 + 8; ++e) y[e] = op.apply(in1(e), p, code);
             }
             return;
         }
@@ -201,7 +237,7 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
         auto p = op.channel(c);
         if (vec && e0 + 8 <= numel) {
             float v[8];
-            unpack8<QS_F32>(load8_raw<QS_F32, false>(x, g), v);
+            in8(g, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v[j] = op.apply(v[j], p, code);
@@ -214,7 +250,7 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
             store8<QS_F32, false>(y, g, v);
         } else {
             for (int64_t e = e0; e < numel && e < e0 + 8; ++e) {
-                y[e] = op.apply(x[e], p, code);
+                y[e] = op.apply(in1(e), p, code);
                 if (--rem == 0) {
                     rem = (uint32_t)r.inner;
                     c = (c + 1 == (uint32_t)r.C) ? 0u : c + 1;
@@ -225,6 +261,23 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
     };
     if (r.is_decimal) run(DecimalFwdOp<QS_F32>{param, 0.0f, nullptr, sat, r.code_lo, r.code_hi, ActSpec{0, 0.f, 0.f}, QS_F32});
     else run(ScalerFwdOp<QS_F32>{param, 0.0f, nullptr, sat, r.code_lo, r.code_hi, ActSpec{0, 0.f, 0.f}, QS_F32});
+}
+
+// the running magnitude of the pruned weights with a full-shape mask (MagnitudePruningCallback.update_magnitude, reference
+// sparse.py:82-89: magnitude <- (t * magnitude + |x|) / (t + 1), every operation rounded to fp32), rows with magnitude != NULL;
+// the replaced values go to mag_backup (a caller that evaluated the layer ahead of time restores them if the forward never
+// reads the weight).  Same workgroup partition as multi_quant_kernel; t is read from prune_t, which that kernel advances.
+static __global__ __launch_bounds__(kBlock) void multi_magnitude_kernel(const qs_multi_row* __restrict__ rows, int n) {
+    const int i = multi_find(rows, n, blockIdx.x, 1);
+    const qs_multi_row r = rows[i];
+    if (!r.magnitude) return;
+    const float t = (float)*r.prune_t, tp1 = (float)(*r.prune_t + 1);
+    const int64_t e0 = ((int64_t)(blockIdx.x - r.quant_block0) * kBlock + threadIdx.x) * 8;
+    for (int64_t e = e0; e < r.numel && e < e0 + 8; ++e) {
+        const float old = r.magnitude[e];
+        r.mag_backup[e] = old;
+        r.magnitude[e] = (t * old + fabsf(r.x[e])) / tp1;
+    }
 }
 
 // gx = clamp(g, lo_mul * s_c, hi_mul * s_c) for every tensor (SteBwdOp's arithmetic, reference quantize.py:66-77, 120-131): the
@@ -240,6 +293,9 @@ struct MultiSte {
     int32_t C[kMultiSteMax], inner[kMultiSteMax];
     float lo_mul[kMultiSteMax];
     float hi_mul[kMultiSteMax];
+    const uint8_t* mask[kMultiSteMax];   // nullable: gx = clamp(g) * mask (the pruned weight's backward)
+    int64_t mask_inner[kMultiSteMax];
+    int32_t mask_C[kMultiSteMax];
     int32_t n;
 };
 
@@ -259,6 +315,9 @@ __global__ __launch_bounds__(kBlock) void multi_ste_kernel(MultiSte a) {
     const SteBwdOp op{a.step[i], 0.0f, DECIMAL ? 1 : 0, a.lo_mul[i], a.hi_mul[i], 0, nullptr};
     int32_t code;
     const int C = a.C[i], inner = a.inner[i];
+    const uint8_t* mask = a.mask[i];
+    const int32_t mC = a.mask_C[i];
+    const int64_t mI = a.mask_inner[i];
     if (C == 1) {
         const auto p = op.channel(0);
         if (g0 < ngroups) {
@@ -266,10 +325,17 @@ __global__ __launch_bounds__(kBlock) void multi_ste_kernel(MultiSte a) {
             unpack8<QS_F32>(load8_raw<QS_F32, false>(g, g0), v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = op.apply(v[j], p, code);
+            if (mask) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= multi_mask_at(mask, mC, mI, g0 * 8 + j);
+            }
             store8<QS_F32, false>(gx, g0, v);
         }
         if (g0 == 0)
-            for (int64_t e = ngroups * 8; e < numel; ++e) gx[e] = op.apply(g[e], p, code);
+            for (int64_t e = ngroups * 8; e < numel; ++e) {
+                const float v = op.apply(g[e], p, code);
+                gx[e] = mask ? v * multi_mask_at(mask, mC, mI, e) : v;
+            }
         return;
     }
     const int64_t e0 = g0 * 8;
@@ -288,10 +354,15 @@ __global__ __launch_bounds__(kBlock) void multi_ste_kernel(MultiSte a) {
                 p = op.channel(c);
             }
         }
+        if (mask) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= multi_mask_at(mask, mC, mI, e0 + j);
+        }
         store8<QS_F32, false>(gx, g0, v);
     } else {
         for (int64_t e = e0; e < numel; ++e) {
-            gx[e] = op.apply(g[e], p, code);
+            const float ve = op.apply(g[e], p, code);
+            gx[e] = mask ? ve * multi_mask_at(mask, mC, mI, e) : ve;
             if (--rem == 0) {
                 rem = (uint32_t)inner;
                 c = (c + 1 == (uint32_t)C) ? 0u : c + 1;

@@ -661,7 +661,7 @@ def _with_owned_relu(x: torch.Tensor, site, act: int = 1):
     # (xback_out of qs_quant_scaler_fwd: +2 / +4 B/elem instead of ATen's 4 / 8 B/elem read + write pass).  A site whose route
     # has no such kernel leaves x raw; the ATen pass below then runs after it -- same tensor contents either way, and in
     # stream order before anything else can read x.
-    cell = {"defer": x.data_ptr() % 16 == 0, "act": act}
+    cell = {"defer": x.data_ptr() % 16 == 0, "act": act, "x": x}
     h = _Tap.apply(_OwnedRelu.apply(x, cell), cell)
     outer = getattr(_hip._gate_sink, "cell", None)
     _hip._gate_sink.cell = cell
@@ -669,6 +669,7 @@ def _with_owned_relu(x: torch.Tensor, site, act: int = 1):
         y = site(h)
     finally:
         _hip._gate_sink.cell = outer
+        cell.pop("x", None)                  # (only `_hip.act_torch`, inside the site, looks at it: no cycle through x's own graph)
         if cell.get("defer") and not cell.get("done"):
             with torch.no_grad():
                 _hip.act_torch_(act, x)

@@ -234,3 +234,33 @@ def test_mobilenet_style_network_sites_vs_oracle(channels_last):
     assert all(s.steps == 8 for s in sites) and len(log) >= 8 * 9
     kept = [float(s.p.mask.float().mean()) for s in sites if s.p is not None]
     assert all(0.4 <= k <= 0.8 for k in kept), kept
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["relu", "relu6", "leaky"])
+@pytest.mark.parametrize("policy", ["no_avg", "uniform", "dims01"])
+def test_inplace_activation_in_front_of_a_site_that_materialises_it_after_all(policy, act, dtype):
+    """An owned in-place activation is deferred to the site's kernels (`fused.py::_with_owned_relu`).  A prune operator whose
+    policy the kernels do not cover -- no running average, the uniform policy, masks over two dims -- applies the activation
+    through ATen instead, on the alias: the deferred in-place pass must happen BEFORE that node records its input (found by
+    tests/fuzz/fuzz_cpu_gpu.py: "modified by an inplace operation" in the backward).  Compared with the CPU path."""
+    def build():
+        cb = {"no_avg": lambda: qs.MagnitudePruningCallback(running_average=False),
+              "uniform": lambda: qs.UniformPruningCallback(),
+              "dims01": lambda: qs.MagnitudePruningCallback()}[policy]()
+        net = nn.Sequential(ACTS[act](True))
+        return qs.convert(net, qs.prune(sparsity=0.4, start=1, interval=1, repetition=2, dimensions={0, 1} if policy == "dims01" else {1},
+                                        callback=cb), activation_layers=[type(net[0])], log=False)
+    import numpy as np
+    g = gen(21)
+    data = [((torch.randn(4, 8, 6, 6, generator=g) * 3).to(dtype), torch.randn(4, 8, 6, 6, generator=g)) for _ in range(6)]
+    np.random.seed(5)
+    cpu, cpu_state = _run(build(), "cpu", data, torch.contiguous_format, True)
+    np.random.seed(5)
+    gpu, gpu_state = _run(build(), "cuda", data, torch.contiguous_format, True)
+    for step, ((ya, ga, ha), (yb, gb, hb)) in enumerate(zip(cpu, gpu)):
+        assert torch.equal(ya.float(), yb.float()) and ya.dtype == yb.dtype, ("output", step)
+        assert torch.equal(ga.float(), gb.float()) and ga.dtype == gb.dtype, ("input gradient", step)
+        assert torch.equal(ha.float(), hb.float()), ("the modified tensor", step)
+    for k in cpu_state:
+        assert same(cpu_state[k], gpu_state[k]), k
