@@ -819,8 +819,14 @@ def l0_flag(x: torch.Tensor) -> torch.Tensor:
 
 
 def running_mean(state: torch.Tensor, new: torch.Tensor, t: int, t_dev: Optional[torch.Tensor] = None):
-    assert state.dtype == torch.float32 and state.is_contiguous() and new.numel() == state.numel()
-    new = new.contiguous()
+    assert state.dtype == torch.float32 and new.numel() == state.numel()
+    if state.is_contiguous():
+        new = new.contiguous()
+    else:
+        # a dense state in another memory order (a full-shape magnitude laid out channels_last like its weight): element-wise all
+        # the same, once `new` sits in memory the same way
+        assert state.dim() == 4 and state.is_contiguous(memory_format=torch.channels_last) and new.shape == state.shape
+        new = new.contiguous(memory_format=torch.channels_last)
     with _timed("running_mean"):
         st = load().qs_running_mean(_ptr(state), _ptr(new), dt(new), state.numel(), int(t), _ptr(t_dev), _stream(state))
     _check(st, "qs_running_mean")
@@ -843,12 +849,17 @@ def kth_value(imp: torch.Tensor, k: int) -> torch.Tensor:
 
 
 def mask_ge(imp: torch.Tensor, thr: torch.Tensor, out_mask: torch.Tensor):
-    """out_mask (bool, contiguous, same numel) <- imp >= thr, in place."""
+    """out_mask (bool, same shape or same numel) <- imp >= thr, in place."""
     imp = imp.detach().to(torch.float32).contiguous()
-    assert out_mask.dtype == torch.bool and out_mask.is_contiguous() and out_mask.numel() == imp.numel()
+    assert out_mask.dtype == torch.bool and out_mask.numel() == imp.numel()
+    # a mask that is not contiguous (a full-shape 4-d mask after `model.to(memory_format=torch.channels_last)`): the kernel
+    # writes the logical order `imp.contiguous()` has, the copy puts it into the mask's own layout
+    target = out_mask if out_mask.is_contiguous() else torch.empty(out_mask.shape, dtype=torch.bool, device=out_mask.device)
     with _timed("mask_ge", imp, out_mask):
-        st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(out_mask), imp.numel(), _stream(imp))
+        st = load().qs_mask_ge(_ptr(imp), _ptr(thr), _ptr(target), imp.numel(), _stream(imp))
     _check(st, "qs_mask_ge")
+    if target is not out_mask:
+        out_mask.copy_(target)
 
 
 def mask_apply(x: torch.Tensor, mask: torch.Tensor, pre_relu: bool = False, want_gate: bool = False):

@@ -155,10 +155,10 @@ class _GroupSte(torch.autograd.Function):
                     off += (g.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
                 numels = [g.numel() for g in gs]
                 per_channel = any(geo[i][1] > 1 for i in fast)
-                # pruned weights: the gradient has the weight's own (contiguous) layout, which is what the mask geometry describes;
-                # any other layout multiplies afterwards
+                # pruned weights: a gradient laid out like the weight (the rule) is what the mask geometry describes; any other layout
+                # multiplies afterwards
                 mk = {i: meta[i][5] for i in fast if meta[i][5] is not None}
-                in_kernel = {i for i in mk if grads[i].is_contiguous()}
+                in_kernel = {i for i in mk if _strides(grads[i]) == mk[i][3]}
                 _hip.multi_ste_bwd(len(fast), _hip.ptr_array(gs), _hip.ptr_array(outs), _hip.ptr_array([steps[i] for i in fast]),
                                    _hip.i64_array(numels), _hip.f32_array([meta[i][1] for i in fast]),
                                    _hip.f32_array([meta[i][2] for i in fast]), decimal, gs[0].device, nbytes=8 * sum(numels),
@@ -207,26 +207,48 @@ def _prune_ok(p) -> bool:
     return type(cb) is MagnitudePruningCallback and not cb.use_gradient and not cb.l0 and cb.forward_hook is None
 
 
-def _mask_geometry(shape, mask_shape):
-    """(mask_C, mask_inner) of a broadcast mask over a CONTIGUOUS tensor: (0, 1) for a full-shape mask, else the mask varies
-    along one run of dims -- its byte for element e is (e // mask_inner) % mask_C; None when it does not (or has one element)"""
-    shape, mask_shape = tuple(shape), tuple(mask_shape)
-    if len(shape) != len(mask_shape) or any(m not in (1, s) for m, s in zip(mask_shape, shape)):
+def _strides(t: torch.Tensor):
+    """strides that matter: those of the dims with more than one element"""
+    return tuple(st for st, n in zip(t.stride(), t.shape) if n > 1)
+
+
+def _mask_geometry(w: torch.Tensor, mask: torch.Tensor):
+    """(mask_C, mask_inner) of a broadcast mask over a dense weight, in the weight's MEMORY order (contiguous, or channels_last
+    as `model.to(memory_format=torch.channels_last)` leaves 4-d parameters -- masks and magnitudes included): (0, 1) for a
+    full-shape mask laid out like the weight, else the mask varies along one run of dims of that order -- its byte for the
+    element at memory offset e is (e // mask_inner) % mask_C; None when it does not (or has one element)"""
+    if w.dim() != mask.dim() or any(m not in (1, s) for m, s in zip(mask.shape, w.shape)):
         return None
-    varying = [d for d, (m, s) in enumerate(zip(mask_shape, shape)) if m == s and s > 1]
+    if w.is_contiguous():
+        order = list(range(w.dim()))
+    elif w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last):
+        order = [0, 2, 3, 1]
+    else:
+        return None
+    shape = [w.shape[d] for d in order]
+    mshape = [mask.shape[d] for d in order]
+    varying = [i for i, (m, s) in enumerate(zip(mshape, shape)) if m == s and s > 1]
     if not varying:
         return None
     if len(varying) == sum(1 for s in shape if s > 1):
-        return (0, 1)
+        # full shape: the mask must sit in memory exactly like the weight
+        return (0, 1) if _strides(mask) == _strides(w) else None
     lo, hi = varying[0], varying[-1]
-    if any(shape[d] > 1 and mask_shape[d] == 1 for d in range(lo, hi + 1)):
+    if any(shape[i] > 1 and mshape[i] == 1 for i in range(lo, hi + 1)):
         return None
+    # the mask's own bytes along that run must be consecutive in the same order
+    run = [order[i] for i in range(lo, hi + 1) if shape[i] > 1]
+    expect = 1
+    for d in reversed(run):
+        if mask.stride(d) != expect:
+            return None
+        expect *= mask.shape[d]
     C = 1
-    for d in range(lo, hi + 1):
-        C *= shape[d]
+    for i in range(lo, hi + 1):
+        C *= shape[i]
     inner = 1
-    for s in shape[hi + 1:]:
-        inner *= s
+    for sdim in shape[hi + 1:]:
+        inner *= sdim
     return (C, inner)
 
 
@@ -298,13 +320,13 @@ def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     """what the prune operator underneath a weight's quantizer would do on this read, if that is something the multi-tensor
     kernels can do in its place -- None otherwise (the inline path then runs the operator itself).  Reads state, changes none.
     Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude)."""
-    if not _prune_ok(p) or _hooked_prune(p) or not p.initted or p.training != training or not w.is_contiguous():
+    if not _prune_ok(p) or _hooked_prune(p) or not p.initted or p.training != training:
         return None
     mask = p.mask
-    if (not mask.is_cuda or mask.device != w.device or mask.dtype != torch.bool or not mask.is_contiguous() or mask.is_inference()
+    if (not mask.is_cuda or mask.device != w.device or mask.dtype != torch.bool or mask.is_inference()
             or not p._n_updates.is_cuda or mask.numel() == 1):
         return None
-    geo = _mask_geometry(w.shape, mask.shape)
+    geo = _mask_geometry(w, mask)
     if geo is None:
         return None
     if not training:                              # PruneLayer.forward in evaluation: weight * mask, nothing else
@@ -325,8 +347,8 @@ def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
         # the running magnitude of a full-shape mask is element-wise; over a channel subset it is a staged mean per layer, and
         # under a process group the reference path averages it over the ranks: both stay inline
         mag = getattr(cb, "magnitude", None)
-        if (geo != (0, 1) or mag is None or not mag.is_cuda or mag.dtype != torch.float32 or not mag.is_contiguous()
-                or mag.numel() != w.numel() or qdist.exchange_active(qdist.stats_world_size())):
+        if (geo != (0, 1) or mag is None or not mag.is_cuda or mag.dtype != torch.float32 or mag.shape != w.shape
+                or _strides(mag) != _strides(w) or qdist.exchange_active(qdist.stats_world_size())):
             return None
     return (geo, True, True, average)
 
@@ -505,7 +527,7 @@ class WeightBatcher:
                 if counted_t:
                     pl.callback._t_host.add(pl.callback.t, -1)
                 if mag_backup is not None:
-                    pl.callback.magnitude.data.view(-1).copy_(mag_backup)
+                    pl.callback.magnitude.data.copy_(mag_backup)      # (same shape and strides: element by element)
         q._quantized = p.was_quantized
 
     def _rollback_all(self):
@@ -684,7 +706,7 @@ class WeightBatcher:
                     r.prune_t = pl.callback.t.data_ptr()
                     keep.append(pl.callback.t)
                 if averages:
-                    backup = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+                    backup = torch.empty_like(pl.callback.magnitude)        # the magnitude's (= the weight's) own memory layout
                     r.magnitude, r.mag_backup = pl.callback.magnitude.data_ptr(), backup.data_ptr()
                     keep += [pl.callback.magnitude, backup]
                     mag_backups[i] = backup
@@ -707,7 +729,7 @@ class WeightBatcher:
                 limit = 2.0 ** (q.bits - 1)
                 notch = 1 if qc.flip_axis else 0
                 ps = prune_steps.get(id(u.layer)) if (prune_steps and u.attr == "weight") else None
-                mask = (u.p.mask, ps[0][0], ps[0][1]) if (ps is not None and ps[0] is not None) else None
+                mask = (u.p.mask, ps[0][0], ps[0][1], _strides(u.param)) if (ps is not None and ps[0] is not None) else None
                 meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise, mask))
                 steps.append(decimals[u.slot:u.slot + u.channels].view(-1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)

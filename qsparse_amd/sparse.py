@@ -146,8 +146,7 @@ class MagnitudePruningCallback(nn.Module):
 
     def initialize(self, mask: torch.Tensor):
         if self.running_average:
-            self.magnitude = nn.Parameter(torch.zeros(*mask.shape, device=mask.device, dtype=torch.float),
-                                          requires_grad=False)
+            self.magnitude = nn.Parameter(torch.zeros_like(mask, dtype=torch.float), requires_grad=False)     # (the mask's layout)
 
     def update_magnitude(self, x):
         """magnitude <- (t*magnitude + mean|x|) / (t+1)   (reference sparse.py:82-89)"""
@@ -336,7 +335,14 @@ class PruneLayer(nn.Module):
     def _lazy_init(self, x: torch.Tensor):
         assert len(x.shape) > 1
         mask_shape = [s if i in self.dimensions else 1 for i, s in enumerate(x.shape)]
-        self.mask = nn.Parameter(torch.ones(*mask_shape, dtype=torch.bool, device=x.device), requires_grad=False)
+        mask = torch.ones(*mask_shape, dtype=torch.bool, device=x.device)
+        if (x.dim() == 4 and tuple(mask_shape) == tuple(x.shape) and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            # a full-shape mask of a channels_last tensor (the weight of a network moved with `.to(memory_format=...)`) is laid out
+            # like that tensor: same values, same shape -- and x * mask, the running magnitude and the multi-tensor weight
+            # kernels then walk both in one memory order
+            mask = mask.contiguous(memory_format=torch.channels_last)
+        self.mask = nn.Parameter(mask, requires_grad=False)
         if self.mask.numel() == 1:
             logging.warn(f"the mask shape of {self.name} is {tuple(self.mask.shape)}, which is not prunable")
         self._n_updates = state_parameter(torch.zeros(1, dtype=torch.int, device=x.device))

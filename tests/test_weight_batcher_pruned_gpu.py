@@ -38,7 +38,7 @@ PRUNES = {
 QUANTS = {"scaler": ("scaler", -1, -1), "default": ("scaler", 1, -1), "decimal_dim0_bias": ("decimal", 0, 6)}
 
 
-def _build(prune, quantizer):
+def _build(prune, quantizer, channels_last=False):
     dims, cbkw = PRUNES[prune]
     kind, channelwise, bias_bits = QUANTS[quantizer]
     torch.manual_seed(0)
@@ -48,15 +48,17 @@ def _build(prune, quantizer):
     model = qs.convert(model, qs.quantize(bits=4, channelwise=channelwise, timeout=2, bias_bits=bias_bits,
                                           callback=qs.DecimalQuantizer() if kind == "decimal" else None),
                        weight_layers=[nn.Conv2d, nn.Linear], log=False).cuda().train()
+    if channels_last:        # (before the first forward: the full-shape masks and magnitudes are then created in the weights' layout)
+        model = model.to(memory_format=torch.channels_last)
     return model
 
 
-def _scenario(script, prune, quantizer, calls=None):
+def _scenario(script, prune, quantizer, calls=None, channels_last=False):
     results = []
     for batched in (True, False):
         qs.set_qsparse_options(batch_weights=batched)
         try:
-            model = _build(prune, quantizer)
+            model = _build(prune, quantizer, channels_last)
             if batched:
                 wb = model.__dict__["_qs_weight_batcher"]
                 assert len(wb.layers) == 5 and all(u.p is not None for u in wb.units if u.attr == "weight")
@@ -65,6 +67,8 @@ def _scenario(script, prune, quantizer, calls=None):
 
             def step(train=True, backward=True):
                 x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+                if channels_last:
+                    x = x.contiguous(memory_format=torch.channels_last)
                 y = torch.randint(0, 5, (4,), generator=g).cuda()
                 if not train:
                     with torch.no_grad():
@@ -108,9 +112,10 @@ def _scenario(script, prune, quantizer, calls=None):
     return sa
 
 
+@pytest.mark.parametrize("channels_last", [False, True])
 @pytest.mark.parametrize("quantizer", list(QUANTS))
 @pytest.mark.parametrize("prune", list(PRUNES))
-def test_pruned_layers_follow_the_layer_by_layer_state_through_the_whole_schedule(prune, quantizer):
+def test_pruned_layers_follow_the_layer_by_layer_state_through_the_whole_schedule(prune, quantizer, channels_last):
     def script(model, step):
         for i in range(16):
             model.route = "left" if i % 3 else "right"          # the skipped branch is rolled back (counters, magnitudes)
@@ -122,7 +127,7 @@ def test_pruned_layers_follow_the_layer_by_layer_state_through_the_whole_schedul
             else:
                 step(backward=i != 9)
 
-    state = _scenario(script, prune, quantizer)
+    state = _scenario(script, prune, quantizer, channels_last=channels_last)
     # the masks did prune, and the two branches advanced differently
     assert 0.3 < 1.0 - state["stem.prune.mask"].float().mean().item() < 0.7
     assert state["left.prune._n_updates"].item() > state["right.prune._n_updates"].item() > 0
@@ -151,7 +156,8 @@ def test_an_exception_and_a_weight_written_before_its_read(prune):
     _scenario(script, prune, "default")
 
 
-def test_the_multi_tensor_kernels_really_take_the_pruned_layers(monkeypatch):
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_the_multi_tensor_kernels_really_take_the_pruned_layers(channels_last, monkeypatch):
     """call counts: on a read the prune operators leave to the kernels there is no per-layer weight-side call at all; the
     averaging reads of the full-shape masks add ONE qs_multi_magnitude launch"""
     calls = []
@@ -159,11 +165,13 @@ def test_the_multi_tensor_kernels_really_take_the_pruned_layers(monkeypatch):
                "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value"):
         real = getattr(_hip, fn)
         monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (calls.append(name), f(*a, **k))[1]))(fn, real))
-    model = _build("full_avg", "scaler")
+    model = _build("full_avg", "scaler", channels_last)
     g = torch.Generator().manual_seed(5)
     per_step = []
     for i in range(14):
         x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+        if channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         for prm in model.parameters():
             prm.grad = None
         del calls[:]
@@ -208,3 +216,28 @@ def test_serving_hands_out_cached_pruned_weights_and_sees_a_new_mask():
     finally:
         qs.set_qsparse_options(batch_weights=True)
     assert not torch.equal(y1, y3) and torch.equal(y3, y4)
+
+
+def test_a_network_moved_to_channels_last_after_its_masks_exist_keeps_training():
+    """`model.to(memory_format=torch.channels_last)` also converts the 4-d full-shape masks and magnitudes that already exist: the
+    mask rebuild (`qs_mask_ge` writes a contiguous order) and the running magnitude then meet non-contiguous state"""
+    results = []
+    for move in (False, True):
+        model = _build("full_avg", "scaler")
+        g = torch.Generator().manual_seed(11)
+        for i in range(10):
+            if move and i == 4:
+                model = model.to(memory_format=torch.channels_last)
+                assert not model.left.prune.mask.is_contiguous()
+            x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+            for prm in model.parameters():
+                prm.grad = None
+            model(x).sum().backward()
+            with torch.no_grad():
+                for prm in model.parameters():
+                    if prm.requires_grad:
+                        prm.add_(torch.randn(prm.shape, generator=g).cuda() * 0.02)
+        results.append(_state(model))
+    a, b = results
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
