@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 14
+#define QS_ABI_VERSION 15
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -465,7 +465,13 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
  * quantizer's where non-NULL.
  *   qs_multi_magnitude     rows with magnitude != NULL (full-shape masks): t = *prune_t;
  *                          mag_backup[e] <- magnitude[e]; magnitude[e] <- (t*magnitude[e] + |x[e]|)/(t+1)   (sparse.py:82-89);
- *                          launched BEFORE qs_multi_quant_fwd (which advances prune_t) */
+ *                          launched BEFORE qs_multi_quant_fwd (which advances prune_t)
+ *   qs_multi_mask_refresh  rows with refresh != 0 (full-shape masks): the mask rebuild of MagnitudePruningCallback
+ *                          (sparse.py:58-66 -> util.py:103-117): thr = the select_k-th smallest importance (importance =
+ *                          `importance` when non-NULL -- the running magnitude, after qs_multi_magnitude -- else |x|), by the
+ *                          4-pass radix select of qs_kth_value run for all rows at once (select_state: 258 uint32 of scratch
+ *                          per row, zero before the first use); mask_backup[e] <- mask[e]; mask[e] <- importance[e] >= thr.
+ *                          Nine launches for the whole table; BEFORE qs_multi_absmax (the quantizer sees the new mask). */
 typedef struct qs_multi_row {
     const float* x;              /* the tensor, 4-byte aligned (16-byte aligned tensors take the vector paths) */
     float* scale;                /* [C] running scale (QuantizeLayer.weight) */
@@ -490,16 +496,23 @@ typedef struct qs_multi_row {
     int64_t* prune_t;            /* nullable (required with magnitude) */
     float* magnitude;            /* nullable: [numel] running magnitude, updated by qs_multi_magnitude */
     float* mag_backup;           /* [numel] with magnitude: what the update replaced */
+    int32_t refresh;             /* != 0: qs_multi_mask_refresh rebuilds this row's (full-shape, writable) mask */
+    uint32_t select_k;           /* rank of the threshold element, ascending (util.py:115-116) */
+    const float* importance;     /* nullable: [numel] importance to rank by (NULL: |x|) */
+    uint32_t* select_state;      /* [258] scratch of the radix select */
+    uint8_t* mask_backup;        /* [numel]: what the rebuild replaced */
     /* derived by qs_multi_plan: */
-    int32_t row_splits, absmax_block0, absmax_blocks, quant_block0, chan0;
+    int32_t row_splits, absmax_block0, absmax_blocks, quant_block0, chan0, hist_block0, hist_blocks, reserved1;
 } qs_multi_row;
 
 /* fills the derived fields of a HOST table in place and returns the launch totals; QS_ERR_ARG for an inconsistent row */
-int qs_multi_plan(qs_multi_row* rows_host, int n, int* absmax_blocks, int* quant_blocks, int* channels);
+int qs_multi_plan(qs_multi_row* rows_host, int n, int* absmax_blocks, int* quant_blocks, int* channels, int* hist_blocks_out);
 int qs_multi_absmax(const qs_multi_row* rows_dev, int n, int absmax_blocks, qs_stream_t stream);
 int qs_multi_scale_update(const qs_multi_row* rows_dev, int n, int channels, qs_stream_t stream);
 int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, float* ybase, int advance, qs_stream_t stream);
 int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs_stream_t stream);
+/* hist_blocks: the total qs_multi_plan returned through *hist_blocks_out (0: no row refreshes) */
+int qs_multi_mask_refresh(const qs_multi_row* rows_dev, int n, int hist_blocks, int quant_blocks, qs_stream_t stream);
 /*   qs_multi_ste_bwd:       gx[i][e] = clamp(g[i][e], lo_mul[i] * s, hi_mul[i] * s) with s = step[i][c] (or 2^-step[i][c] with
  *                           step_is_decimal), c the channel of e in the contiguous [*, C[i], inner[i]] view the gradient has
  *                           (C == NULL: tensor-wise, one step per tensor): qs_quant_ste_bwd's arithmetic (quantize.py:66-77,

@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 14          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 15          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -58,11 +58,12 @@ SIGNATURES = {
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
-    "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P]),
+    "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
     "qs_multi_scale_update": (c_int, [_P, _I, _I, _P]),
     "qs_multi_quant_fwd": (c_int, [_P, _I, _I, _P, _I, _P]),
     "qs_multi_magnitude": (c_int, [_P, _I, _I, _P]),
+    "qs_multi_mask_refresh": (c_int, [_P, _I, _I, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
@@ -94,8 +95,11 @@ class MultiRow(ctypes.Structure):
                 ("code_lo", c_int32), ("code_hi", c_int32), ("denom", c_float),
                 ("mask", c_void_p), ("mask_inner", c_int64), ("mask_C", c_int32), ("reserved0", c_int32),
                 ("prune_n_updates", c_void_p), ("prune_t", c_void_p), ("magnitude", c_void_p), ("mag_backup", c_void_p),
+                ("refresh", c_int32), ("select_k", ctypes.c_uint32), ("importance", c_void_p), ("select_state", c_void_p),
+                ("mask_backup", c_void_p),
                 ("row_splits", c_int32),
-                ("absmax_block0", c_int32), ("absmax_blocks", c_int32), ("quant_block0", c_int32), ("chan0", c_int32)]
+                ("absmax_block0", c_int32), ("absmax_blocks", c_int32), ("quant_block0", c_int32), ("chan0", c_int32),
+                ("hist_block0", c_int32), ("hist_blocks", c_int32), ("reserved1", c_int32)]
 
 
 SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE, SITE_SCALE_ONLY = 1, 2, 4, 8, 16, 32, 64
@@ -1027,9 +1031,10 @@ class MultiTable:
     def __init__(self, rows, device):
         self.n = len(rows)
         self.host = (MultiRow * self.n)(*rows)
-        ab, qb, ch = c_int(0), c_int(0), c_int(0)
-        _check(load().qs_multi_plan(self.host, self.n, ctypes.byref(ab), ctypes.byref(qb), ctypes.byref(ch)), "qs_multi_plan")
-        self.absmax_blocks, self.quant_blocks, self.channels = ab.value, qb.value, ch.value
+        ab, qb, ch, hb = c_int(0), c_int(0), c_int(0), c_int(0)
+        _check(load().qs_multi_plan(self.host, self.n, ctypes.byref(ab), ctypes.byref(qb), ctypes.byref(ch), ctypes.byref(hb)),
+               "qs_multi_plan")
+        self.absmax_blocks, self.quant_blocks, self.channels, self.hist_blocks = ab.value, qb.value, ch.value, hb.value
         self.device = device
         self.dev = None
         self.upload()
@@ -1075,6 +1080,14 @@ def multi_magnitude(table: MultiTable, nbytes: int = 0):
     with _timed("multi_magnitude", int(nbytes)):
         st = load().qs_multi_magnitude(table.dev.data_ptr(), table.n, table.quant_blocks, _device_stream(table.device))
     _check(st, "qs_multi_magnitude")
+
+
+def multi_mask_refresh(table: MultiTable, nbytes: int = 0):
+    """the mask rebuild of the table's pruned weights that are due (rows with `refresh`): radix select + mask, nine launches"""
+    with _timed("multi_mask_refresh", int(nbytes)):
+        st = load().qs_multi_mask_refresh(table.dev.data_ptr(), table.n, table.hist_blocks, table.quant_blocks,
+                                          _device_stream(table.device))
+    _check(st, "qs_multi_mask_refresh")
 
 
 def multi_ste_bwd(n: int, g_ptrs, gx_ptrs, step_ptrs, numels, lo_muls, hi_muls, decimal: bool, device, nbytes: int = 0,

@@ -33,14 +33,15 @@ undoes it).  It is safe by construction for anything a forward pass may do:
     layer's read, is not visible -- switch ``batch_weights`` off for such a network.)
   * A bias that is read BEFORE its layer's weight (the reference would then have updated the bias with ``t``, not ``t + 1``)
     rolls both back; they are evaluated inline in the order of the reads.
-  * A PRUNED weight -- ``quantize(prune(conv))``: the quantizer's input is ``weight * mask`` (sparse.py:263) -- takes part on
-    every step on which its prune operator only applies the mask: before ``start`` (no mask yet, the layer only counts), after
-    the schedule while nothing refreshes (a frozen mask, or ``running_average=False``: the steady state of the reference's
-    layerwise recipe, sparse.py:343-359), with a full-shape mask also while the running magnitude is still averaged (one more
-    launch, ``qs_multi_magnitude``), and in evaluation.  The kernels multiply by the mask themselves and advance the prune
-    operator's counters; a step that changes the sparsity or rebuilds the mask keeps the inline path (and so does a mask over
-    a channel subset whose magnitude is still averaged: a staged mean per layer).  Rolled back like the quantizer's state
-    (the magnitudes from the backup the launch wrote).
+  * A PRUNED weight -- ``quantize(prune(conv))``: the quantizer's input is ``weight * mask`` (sparse.py:263) -- takes part too:
+    the kernels multiply by the mask themselves, forward and backward, and advance the prune operator's counters.  With a
+    full-shape (unstructured) mask every read but the few that change the sparsity: the running magnitude is averaged by
+    ``qs_multi_magnitude`` and the mask rebuilt by ``qs_multi_mask_refresh`` (the radix select + mask of the callback, for all
+    layers at once) whenever the callback would -- with the stock ``MagnitudePruningCallback()`` that is every read.  With a
+    mask over a channel subset (``prune()``'s default ``dimensions={1}``: a staged mean per layer) the reads on which the
+    operator only applies its mask: before ``start``, between rebuilds, after ``stop_mask_refresh`` (the steady state of the
+    reference's layerwise recipe, sparse.py:343-359), in evaluation.  Everything is rolled back like the quantizer's state
+    (magnitudes and masks from the backups the launches wrote).
   * Layers whose operators carry hooks, layers on the CPU, group-wise quantizers, callbacks shared between layers, pruning
     callbacks other than ``MagnitudePruningCallback`` (or ranking by gradient / L0) never take part; they keep their inline path.
 
@@ -58,7 +59,7 @@ from qsparse_amd import _hip
 from qsparse_amd import distributed as qdist
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
 from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer
-from qsparse_amd.util import get_option, logging
+from qsparse_amd.util import get_option, logging, threshold_rank
 
 _ALIGN = 64   # elements between the starts of two outputs in the flat buffer (256 bytes)
 _READY = {"weight": "_qs_ready_weight", "bias": "_qs_ready_bias"}   # layer.__dict__ keys of precomputed tensors waiting for their read
@@ -319,7 +320,7 @@ def _hooked_prune(p: PruneLayer) -> bool:
 def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     """what the prune operator underneath a weight's quantizer would do on this read, if that is something the multi-tensor
     kernels can do in its place -- None otherwise (the inline path then runs the operator itself).  Reads state, changes none.
-    Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude)."""
+    Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude, threshold rank of a mask rebuild or None)."""
     if not _prune_ok(p) or _hooked_prune(p) or not p.initted or p.training != training:
         return None
     mask = p.mask
@@ -330,27 +331,36 @@ def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     if geo is None:
         return None
     if not training:                              # PruneLayer.forward in evaluation: weight * mask, nothing else
-        return (geo, False, False, False)
+        return (geo, False, False, False, None)
     n = p._steps.read(p._n_updates)
     if n in p.schedules:
         return None                               # the sparsity changes on this read
     if n < p.start:
-        return (None, True, False, False)         # not pruning yet: the layer only counts
+        return (None, True, False, False, None)   # not pruning yet: the layer only counts
     cb = p.callback
     if not cb.initted or not cb.t.is_cuda or cb.t.device != w.device:
         return None
     t = cb._t_host.read(cb.t)
-    if cb.refresh_due(t, p.current_sparsity()):
-        return None                               # the mask is rebuilt on this read
+    sparsity = p.current_sparsity()
+    refresh = cb.refresh_due(t, sparsity)
     average = t < cb.stop_mask_refresh and cb.running_average
-    if average:
+    mag = getattr(cb, "magnitude", None)
+    if average or (refresh and cb.running_average):
         # the running magnitude of a full-shape mask is element-wise; over a channel subset it is a staged mean per layer, and
         # under a process group the reference path averages it over the ranks: both stay inline
-        mag = getattr(cb, "magnitude", None)
         if (geo != (0, 1) or mag is None or not mag.is_cuda or mag.dtype != torch.float32 or mag.shape != w.shape
                 or _strides(mag) != _strides(w) or qdist.exchange_active(qdist.stats_world_size())):
             return None
-    return (geo, True, True, average)
+    k = None
+    if refresh:
+        # the mask is rebuilt on this read (sparse.py:58-66): for a full-shape mask a radix select over the element-wise importance
+        # -- the running magnitude, or |weight| without a running average -- which the kernels run for all such layers at once
+        n_el = w.numel()
+        k = threshold_rank(sparsity, n_el)
+        if (geo != (0, 1) or k >= n_el or n_el >= 2 ** 32 or _strides(mask) != _strides(w)
+                or (not cb.running_average and qdist.exchange_active(qdist.stats_world_size()))):
+            return None                           # (k >= n: the inline path raises the reference's IndexError)
+    return (geo, True, True, average, k)
 
 
 class _LaunchPlan(dict):
@@ -394,7 +404,7 @@ class _Pending:
     def __init__(self, unit, was_quantized, t_dev, version, training, prune=None):
         self.unit, self.was_quantized, self.t_dev, self.version, self.training = unit, was_quantized, t_dev, version, training
         self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this tensor's place in them
-        self.prune = prune                  # (counted n_updates, counted t, magnitude backup or None) of a pruned weight
+        self.prune = prune                  # (counted n_updates, counted t, magnitude backup, mask backup) of a pruned weight
 
 
 def _patched_class(base):
@@ -521,13 +531,15 @@ class WeightBatcher:
                 qc.__dict__["_t_dev_value"] = qc.t
             if p.prune is not None:          # the prune operator underneath: its counters and its running magnitude
                 pl = u.p
-                counted_n, counted_t, mag_backup = p.prune
+                counted_n, counted_t, mag_backup, mask_backup = p.prune
                 if counted_n:
                     pl._steps.add(pl._n_updates, -1)
                 if counted_t:
                     pl.callback._t_host.add(pl.callback.t, -1)
                 if mag_backup is not None:
                     pl.callback.magnitude.data.copy_(mag_backup)      # (same shape and strides: element by element)
+                if mask_backup is not None:
+                    pl.mask.data.copy_(mask_backup)
         q._quantized = p.was_quantized
 
     def _rollback_all(self):
@@ -620,13 +632,25 @@ class WeightBatcher:
                 (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), u.q.weight.data_ptr(), u.q._n_updates.data_ptr(),
                  None if td is None else td.data_ptr())
                 + ((ps, u.p.mask.data_ptr(), u.p._n_updates.data_ptr(), u.p.callback.t.data_ptr(),
-                    u.p.callback.magnitude.data_ptr() if ps[3] else None) if ps is not None else ())
+                    u.p.callback.magnitude.data_ptr() if (ps[3] or (ps[4] is not None and u.p.callback.running_average)) else None)
+                   if ps is not None else ())
                 for u, w, td, ps in zip(todo, weights, t_devs, psteps))
-            plan = self._plan if self._plan is not None and self._plan.get("key") == key else None
+            plans = self._plan if isinstance(self._plan, _LaunchPlan) else _LaunchPlan()     # (key -> table; never copied)
+            plan = plans.get(key)
             if plan is None:
-                plan = self._plan = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev, psteps)
+                # (a handful of tables: reads that rebuild masks alternate with reads that do not, training with evaluation)
+                if len(plans) >= 4:
+                    plans.pop(next(iter(plans)))
+                plan = plans[key] = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev, psteps)
+                self._plan = plans
             table = plan["table"]
             if train:
+                # the prune operators first, as on every read (sparse.py:99-122): running magnitudes, then the masks that are due
+                # -- the quantizers' abs-max below sees weight * (new) mask
+                if plan["mag_backups"]:
+                    _hip.multi_magnitude(table, nbytes=plan["mag_bytes"])
+                if plan["mask_backups"]:
+                    _hip.multi_mask_refresh(table, nbytes=plan["refresh_bytes"])
                 _hip.multi_absmax(table, nbytes=plan["train_bytes"])
                 _hip.multi_scale_update(table)
                 for i, (u, t_dev) in enumerate(zip(train, t_devs)):
@@ -638,13 +662,11 @@ class WeightBatcher:
                             pl._steps.note_device_add(pl._n_updates, 1)
                         if ps[2]:
                             pl.callback._t_host.note_device_add(pl.callback.t, 1)
-                        prune_undo = (ps[1], ps[2], plan["mag_backups"].get(i))
+                        prune_undo = (ps[1], ps[2], plan["mag_backups"].get(i), plan["mask_backups"].get(i))
                     undo[(id(u.layer), u.attr)] = _Pending(u, q._quantized, t_dev, u.param._version, True, prune_undo)
                     qc._advance_t(t_dev, bumped_by_kernel=True)
                     q._quantized = True
                     q._steps.note_device_add(q._n_updates, 1)
-                if plan["mag_backups"]:
-                    _hip.multi_magnitude(table, nbytes=plan["mag_bytes"])
             for u in frozen:       # evaluation: the decimals of the frozen scales (the inline path recomputes them per call as well)
                 if not u.q.callback.use_float_scaler:
                     self._decimals[u.slot:u.slot + u.channels] = _hip.decimal_from_scale(u.q.weight.data.view(-1))
@@ -672,6 +694,7 @@ class WeightBatcher:
             total += (w.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         rows, keep = [], []
         mag_backups, mag_bytes = {}, 0
+        mask_backups, refresh_bytes = {}, 0
         trains_weight = {id(u.layer) for u in todo[:n_train] if u.attr == "weight"}
         for i, (u, w, sat) in enumerate(zip(todo, weights, sats)):
             q, qc = u.q, u.q.callback
@@ -695,7 +718,7 @@ class WeightBatcher:
             ps = psteps[i]
             if ps is not None:                   # a pruned weight (see `_prune_step`)
                 pl = u.p
-                geo, counts_n, counts_t, averages = ps
+                geo, counts_n, counts_t, averages, rank = ps
                 if geo is not None:
                     r.mask, r.mask_C, r.mask_inner = pl.mask.data_ptr(), geo[0], geo[1]
                     keep.append(pl.mask)
@@ -711,9 +734,19 @@ class WeightBatcher:
                     keep += [pl.callback.magnitude, backup]
                     mag_backups[i] = backup
                     mag_bytes += 16 * w.numel()
+                if rank is not None:             # this read rebuilds the mask
+                    cb = pl.callback
+                    state = torch.zeros(258, dtype=torch.int32, device=dev)
+                    mbackup = torch.empty_like(pl.mask)
+                    r.refresh, r.select_k = 1, int(rank)
+                    r.importance = cb.magnitude.data_ptr() if cb.running_average else None
+                    r.select_state, r.mask_backup = state.data_ptr(), mbackup.data_ptr()
+                    keep += [state, mbackup] + ([cb.magnitude] if cb.running_average else [])
+                    mask_backups[i] = mbackup
+                    refresh_bytes += (4 * 4 + 6) * w.numel()
             rows.append(r)
         return _LaunchPlan(key=key, offsets=offsets, total=total, keep=keep, table=_hip.MultiTable(rows, dev),
-                           mag_backups=mag_backups, mag_bytes=mag_bytes,
+                           mag_backups=mag_backups, mag_bytes=mag_bytes, mask_backups=mask_backups, refresh_bytes=refresh_bytes,
                            train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
                            any_decimal=any(not u.q.callback.use_float_scaler for u in todo))
 

@@ -301,9 +301,9 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
 }
 
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------
-int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_blocks, int* channels) {
-    if (n < 0 || (n > 0 && !rows) || !absmax_blocks || !quant_blocks || !channels) return QS_ERR_ARG;
-    int64_t ab = 0, qb = 0, ch = 0;
+int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_blocks, int* channels, int* hist_blocks_out) {
+    if (n < 0 || (n > 0 && !rows) || !absmax_blocks || !quant_blocks || !channels || !hist_blocks_out) return QS_ERR_ARG;
+    int64_t ab = 0, qb = 0, ch = 0, hb = 0;
     for (int i = 0; i < n; ++i) {
         qs_multi_row& r = rows[i];
         if (!r.x || !r.scale || r.numel < 0 || r.C < 1 || r.outer < 1 || r.inner < 1) return QS_ERR_ARG;
@@ -313,6 +313,9 @@ int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_bloc
         if (r.is_decimal && !r.decimal) return QS_ERR_ARG;
         if (r.mask && r.mask_C != 0 && (r.mask_C < 1 || r.mask_inner < 1)) return QS_ERR_ARG;
         if (r.magnitude && (!r.mag_backup || !r.prune_t)) return QS_ERR_ARG;
+        if (r.refresh && (!r.mask || r.mask_C != 0 || !r.select_state || !r.mask_backup || r.numel < 1 ||
+                          r.numel >= ((int64_t)1 << 32) || (int64_t)r.select_k >= r.numel))
+            return QS_ERR_ARG;
         if ((((uintptr_t)r.x) & 3u) != 0) return QS_ERR_ALIGN;
         r.absmax_block0 = (int32_t)ab;
         r.row_splits = 1;
@@ -337,11 +340,19 @@ int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_bloc
         qb += std::max<int64_t>((r.numel + 8 * kBlock - 1) / (8 * kBlock), 1);      // 8 elements per lane
         r.chan0 = (int32_t)ch;
         ch += r.C;
-        if (ab > 0x7fffffff || qb > 0x7fffffff || ch > 0x7fffffff) return QS_ERR_ARG;
+        r.hist_block0 = (int32_t)hb;
+        r.hist_blocks = 0;
+        if (r.refresh) {                  // ~32 elements per lane, at most 256 workgroups per tensor
+            const int64_t want = (r.numel + (int64_t)kBlock * 32 - 1) / ((int64_t)kBlock * 32);
+            r.hist_blocks = (int32_t)std::min<int64_t>(std::max<int64_t>(want, 1), 256);
+        }
+        hb += r.hist_blocks;
+        if (ab > 0x7fffffff || qb > 0x7fffffff || ch > 0x7fffffff || hb > 0x7fffffff) return QS_ERR_ARG;
     }
     *absmax_blocks = (int)ab;
     *quant_blocks = (int)qb;
     *channels = (int)ch;
+    *hist_blocks_out = (int)hb;
     return QS_OK;
 }
 
@@ -372,6 +383,18 @@ int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs
     if (n < 0 || quant_blocks < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
     if (n == 0 || quant_blocks == 0) return QS_OK;
     hipLaunchKernelGGL(multi_magnitude_kernel, dim3(quant_blocks), dim3(kBlock), 0, (hipStream_t)stream, rows_dev, n);
+    return launch_status();
+}
+
+int qs_multi_mask_refresh(const qs_multi_row* rows_dev, int n, int hist_blocks, int quant_blocks, qs_stream_t stream) {
+    if (n < 0 || hist_blocks < 0 || quant_blocks < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
+    if (n == 0 || hist_blocks == 0) return QS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    for (int pass = 3; pass >= 0; --pass) {
+        hipLaunchKernelGGL(multi_select_hist_kernel, dim3(hist_blocks), dim3(kBlock), 0, s, rows_dev, n, pass);
+        hipLaunchKernelGGL(multi_select_scan_kernel, dim3(n), dim3(256), 0, s, rows_dev, pass);
+    }
+    hipLaunchKernelGGL(multi_mask_ge_kernel, dim3(quant_blocks), dim3(kBlock), 0, s, rows_dev, n);
     return launch_status();
 }
 

@@ -280,6 +280,80 @@ static __global__ __launch_bounds__(kBlock) void multi_magnitude_kernel(const qs
     }
 }
 
+// ---- mask rebuild of the pruned weights with a full-shape mask (rows with refresh != 0) -----------------------------------------
+// the radix select of qs_kth_value (select_hist_kernel / select_scan_kernel: 4 passes over order-preserving keys, most significant
+// byte first) for every such row at once, then mask <- importance >= threshold.  A row's SelectState needs no initialisation
+// launch: the first pass ignores what the previous step left (prefix and k are taken as 0 and row.select_k), the scan re-zeroes
+// the histogram after every pass.
+__device__ __forceinline__ int multi_find_hist(const qs_multi_row* __restrict__ rows, int n, int b) {
+    int lo = 0, hi = n - 1;     // largest i with hist_block0[i] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rows[mid].hist_block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float multi_importance(const qs_multi_row& r, int64_t e) {
+    return r.importance ? r.importance[e] : fabsf(r.x[e]);
+}
+
+static __global__ __launch_bounds__(kBlock) void multi_select_hist_kernel(const qs_multi_row* __restrict__ rows, int n, int pass) {
+    const int i = multi_find_hist(rows, n, blockIdx.x);
+    const qs_multi_row r = rows[i];
+    if (!r.refresh || r.hist_blocks == 0) return;
+    SelectState* st = (SelectState*)r.select_state;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = (pass == 3) ? 0u : st->prefix;
+    const int shift = 8 * pass;
+    const uint32_t himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
+    const int64_t stride = (int64_t)r.hist_blocks * kBlock;
+    for (int64_t e = (int64_t)(blockIdx.x - r.hist_block0) * kBlock + threadIdx.x; e < r.numel; e += stride) {
+        const uint32_t k = f32_to_key(multi_importance(r, e));
+        if ((k & himask) == (prefix & himask)) atomicAdd(&h[(k >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// one workgroup of 256 threads per row: pick the bin holding rank k, descend (select_scan_kernel)
+static __global__ __launch_bounds__(256) void multi_select_scan_kernel(const qs_multi_row* __restrict__ rows, int pass) {
+    const qs_multi_row& r = rows[blockIdx.x];
+    if (!r.refresh) return;
+    SelectState* st = (SelectState*)r.select_state;
+    if (threadIdx.x == 0) {
+        uint32_t k = (pass == 3) ? r.select_k : st->k, cum = 0;
+        int b = 0;
+        for (; b < 256; ++b) {
+            const uint32_t c = st->hist[b];
+            if (cum + c > k) break;
+            cum += c;
+        }
+        if (b == 256) b = 255;
+        st->k = k - cum;
+        st->prefix = ((pass == 3) ? 0u : st->prefix) | (((uint32_t)b) << (8 * pass));
+    }
+    __syncthreads();
+    st->hist[threadIdx.x] = 0;
+}
+
+// mask <- importance >= threshold (mask_ge_kernel), the replaced bytes to mask_backup; the workgroup partition of multi_quant_kernel
+static __global__ __launch_bounds__(kBlock) void multi_mask_ge_kernel(const qs_multi_row* __restrict__ rows, int n) {
+    const int i = multi_find(rows, n, blockIdx.x, 1);
+    const qs_multi_row r = rows[i];
+    if (!r.refresh) return;
+    const float t = key_to_f32(((const SelectState*)r.select_state)->prefix);
+    uint8_t* mask = (uint8_t*)r.mask;
+    const int64_t e0 = ((int64_t)(blockIdx.x - r.quant_block0) * kBlock + threadIdx.x) * 8;
+    for (int64_t e = e0; e < r.numel && e < e0 + 8; ++e) {
+        r.mask_backup[e] = mask[e];
+        mask[e] = multi_importance(r, e) >= t ? 1 : 0;
+    }
+}
+
 // gx = clamp(g, lo_mul * s_c, hi_mul * s_c) for every tensor (SteBwdOp's arithmetic, reference quantize.py:66-77, 120-131): the
 // STE backward of a GROUP of weight quantizers in one launch -- gradients of a few layers handed over together.  The
 // gradients are fresh tensors every step, so this list travels by value in the kernel arguments.

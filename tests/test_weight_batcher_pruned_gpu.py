@@ -34,6 +34,11 @@ PRUNES = {
     "subset_noavg": ({0, 1}, dict(running_average=False, mask_refresh_interval=2, stop_mask_refresh=4)),
     # per-input-channel masks (prune()'s default dimensions) whose magnitude is a staged mean: inline until frozen
     "channel_avg": ({1}, dict(mask_refresh_interval=4, stop_mask_refresh=6)),
+    # the stock callback as it comes (MagnitudePruningCallback()): the running magnitude is averaged and the mask rebuilt from
+    # it on EVERY read, for good -- qs_multi_magnitude + qs_multi_mask_refresh per step for all layers
+    "full_default": ({0, 1, 2, 3}, dict()),
+    # no running average: the mask is rebuilt from |weight| itself on every second read
+    "full_noavg_refresh": ({0, 1, 2, 3}, dict(running_average=False, mask_refresh_interval=2)),
 }
 QUANTS = {"scaler": ("scaler", -1, -1), "default": ("scaler", 1, -1), "decimal_dim0_bias": ("decimal", 0, 6)}
 
@@ -134,7 +139,7 @@ def test_pruned_layers_follow_the_layer_by_layer_state_through_the_whole_schedul
     assert state["left.prune.callback.t"].item() > state["right.prune.callback.t"].item()
 
 
-@pytest.mark.parametrize("prune", ["full_avg", "subset_noavg"])
+@pytest.mark.parametrize("prune", ["full_avg", "subset_noavg", "full_default"])
 def test_an_exception_and_a_weight_written_before_its_read(prune):
     def script(model, step):
         for i in range(12):
@@ -161,8 +166,8 @@ def test_the_multi_tensor_kernels_really_take_the_pruned_layers(channels_last, m
     """call counts: on a read the prune operators leave to the kernels there is no per-layer weight-side call at all; the
     averaging reads of the full-shape masks add ONE qs_multi_magnitude launch"""
     calls = []
-    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_magnitude", "multi_ste_bwd", "absmax", "scale_update",
-               "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value"):
+    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_magnitude", "multi_mask_refresh", "multi_ste_bwd", "absmax",
+               "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge"):
         real = getattr(_hip, fn)
         monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (calls.append(name), f(*a, **k))[1]))(fn, real))
     model = _build("full_avg", "scaler", channels_last)
@@ -178,11 +183,13 @@ def test_the_multi_tensor_kernels_really_take_the_pruned_layers(channels_last, m
         model.route = "left"
         model(x).sum().backward()
         per_step.append(list(calls))
-    inline = {"absmax", "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value"}
+    inline = {"absmax", "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge"}
     taken = [i for i, c in enumerate(per_step) if "multi_quant_fwd" in c and not inline & set(c)]
     averaging = [i for i in taken if "multi_magnitude" in per_step[i]]
-    # reads 0-1: the quantizers' identity phase (inline); 2 and 4: the sparsity changes; callback reads 3 and 6 rebuild the mask
-    assert len(taken) >= 6 and len(averaging) >= 2 and taken[-1] == 13 and 13 not in averaging, (taken, averaging)
+    rebuilding = [i for i in taken if "multi_mask_refresh" in per_step[i]]
+    # reads 0-1: the quantizers' identity phase (inline); 2 and 4: the sparsity changes (inline); the callback's reads 3 and 6 --
+    # steps 5 and 8 -- rebuild the mask; from its read 8 on the mask is frozen
+    assert taken == [3, 5, 6, 7, 8, 9, 10, 11, 12, 13] and averaging == [3, 5, 6, 7, 8, 9] and rebuilding == [5, 8], (taken, averaging, rebuilding)
     for i in taken:
         c = per_step[i]
         assert c.count("multi_quant_fwd") == 1 and c.count("multi_absmax") == 1 and c.count("multi_scale_update") == 1
@@ -241,3 +248,25 @@ def test_a_network_moved_to_channels_last_after_its_masks_exist_keeps_training()
     a, b = results
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_the_stock_callback_rebuilds_every_mask_on_every_read_in_a_handful_of_launches(monkeypatch):
+    """`MagnitudePruningCallback()` as it comes: after `start`, every read averages the magnitude and re-ranks it.  Layer by layer
+    that is a radix select (nine launches), a mask launch, a running mean and a mask apply per layer and read; here one
+    qs_multi_magnitude + one qs_multi_mask_refresh for the whole network"""
+    calls = []
+    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_magnitude", "multi_mask_refresh", "absmax",
+               "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge"):
+        real = getattr(_hip, fn)
+        monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (calls.append(name), f(*a, **k))[1]))(fn, real))
+    model = _build("full_default", "default")
+    g = torch.Generator().manual_seed(5)
+    for i in range(10):
+        for prm in model.parameters():
+            prm.grad = None
+        del calls[:]
+        model(torch.randn(4, 3, 10, 10, generator=g).cuda()).sum().backward()
+        if i >= 6:          # past the schedule (the sparsity changed on reads 2 and 4)
+            assert sorted(calls) == ["multi_absmax", "multi_magnitude", "multi_mask_refresh", "multi_quant_fwd", "multi_scale_update"], (i, calls)
+    sparsity = 1.0 - model.left.prune.mask.float().mean().item()
+    assert abs(sparsity - 0.5) < 0.02

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A ResNet whose WEIGHTS are pruned and quantized -- convert(prune(...), weight_layers) then convert(quantize(...), weight_layers),
 the reference's way of stacking operators on a layer (qsparse/convert.py:199-229, imitation.py:61-68) -- in the steady state of a
-frozen-mask recipe (`stop_mask_refresh` passed): step time with the multi-tensor weight path taking the pruned layers
+frozen-mask recipe (`stop_mask_refresh` passed) and with the stock callback (every read averages the magnitude and rebuilds the
+mask): step time with the multi-tensor weight path taking the pruned layers
 (`batch_weights=True`, default) and layer by layer.  Development tool:
 
     python3 tools/bench_pruned_weights.py [resnet50|resnet18] [batch] [steps]"""
@@ -20,12 +21,13 @@ from examples.models import resnet18, resnet50
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
 
 
-def build(arch, batched, dims):
+def build(arch, batched, dims, stock=False):
     qs.set_qsparse_options(batch_weights=batched)
     torch.manual_seed(0)
     net = (resnet50 if arch == "resnet50" else resnet18)(num_classes=1000 if arch == "resnet50" else 10)
     net = qs.convert(net, qs.prune(sparsity=0.5, dimensions=dims, start=1, interval=1, repetition=1,
-                                   callback=qs.MagnitudePruningCallback(mask_refresh_interval=1, stop_mask_refresh=2)),
+                                   callback=qs.MagnitudePruningCallback() if stock else
+                                   qs.MagnitudePruningCallback(mask_refresh_interval=1, stop_mask_refresh=2)),
                      weight_layers=[nn.Conv2d, nn.Linear], log=False)
     net = qs.convert(net, qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
     return net.cuda().to(memory_format=torch.channels_last).train()
@@ -38,10 +40,11 @@ def main():
     size = 224 if arch == "resnet50" else 32
     x = torch.randn(batch, 3, size, size, device="cuda").contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 10, (batch,), device="cuda")
-    for dims, name in (({0, 1, 2, 3}, "unstructured masks"), ({1}, "per-input-channel masks")):
+    for dims, name, stock in (({0, 1, 2, 3}, "unstructured masks, frozen", False), ({1}, "per-input-channel masks, frozen", False),
+                              ({0, 1, 2, 3}, "unstructured masks, the stock callback: magnitude averaged and mask rebuilt on every read", True)):
         row = {}
         for batched in (True, False):
-            net = build(arch, batched, dims)
+            net = build(arch, batched, dims, stock)
             opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
 
             def step():
@@ -63,7 +66,7 @@ def main():
                 wb = net.__dict__.get("_qs_weight_batcher")
                 row["layers taken"] = 0 if wb is None else len(wb.layers)
         qs.set_qsparse_options(batch_weights=True)
-        print(f"{arch} batch {batch}, weights pruned 50 % ({name}, frozen) + quantized 8-bit per channel, ms/step: {row}", flush=True)
+        print(f"{arch} batch {batch}, weights pruned 50 % ({name}) + quantized 8-bit per channel, ms/step: {row}", flush=True)
 
 
 if __name__ == "__main__":
