@@ -18,7 +18,6 @@ import qsparse_amd as qs
 from oracle import qs_oracle as O
 from qsparse_amd import _hip
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
-from qsparse_amd.sparse import PruneLayer
 
 pytestmark = pytest.mark.gpu
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
