@@ -176,3 +176,50 @@ def test_config2_size_other_quantizers_equal_the_oracle_on_the_full_tensor(kind)
         assert _bits_equal(gx, gx_ref.to(DEV)), ("input gradient", kind, s)
         assert _bits_equal(q.weight.detach().cpu(), qsim.weight), ("state", kind, s)
         del y, gx, y_ref, gx_ref
+
+
+def test_headline_pair_decimal_relu6_frozen_mask_on_the_full_tensor():
+    """The composite routes added in round 4, at full size in one go: a DecimalQuantizer site (the power-of-two step of each
+    forward, reference quantize.py:275-367), a folded nn.ReLU6 (hardtanh(0, 6), gate of `hardtanh_backward`), and the
+    frozen-mask steps of a layerwise recipe (`stop_mask_refresh` passed: `QS_SITE_SCALE_ONLY`, sparse.py:107-116), channels_last,
+    against the oracle with ATen's own activation on the CPU."""
+    import torch.nn.functional as F
+    steps, stop = 5, 2
+    cbkw = dict(mask_refresh_interval=1, stop_mask_refresh=stop)
+    ps = O.PruneSim(0.75, [1], 0, 1, 1, False, **cbkw)
+    qsim = O.QuantizeSim("decimal", 4, -1, 1)
+    pair = nn.Sequential(nn.Sequential(nn.ReLU6(), qs.prune(sparsity=0.75, dimensions={1}, start=0, interval=1, repetition=1,
+                                                             callback=qs.MagnitudePruningCallback(**cbkw))),
+                         qs.quantize(bits=4, channelwise=-1, timeout=1, callback=qs.DecimalQuantizer())).to(DEV).train()
+    fuse_prune_quantize_pairs(pair)
+    p, q = pair[0][1], pair[1]
+    assert torch.get_num_threads() == 1
+    flags = []
+    from qsparse_amd import _hip
+    real = _hip.site_fwd
+    _hip.site_fwd = lambda *a, **k: (flags.append(a[4]), real(*a, **k))[1]
+    try:
+        for s in range(steps):
+            x, gout = _inputs(HEADLINE, s, True, True)
+            x = (x.float() * 2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)      # (so that the upper bound 6 is reached)
+            xc, gc = x.cpu(), gout.cpu()
+            h = F.hardtanh(xc, 0.0, 6.0)
+            n_before = ps.n_updates
+            y_ref = qsim.step(ps.step(h, True).contiguous(), True)
+            gx_ref = ps.grad(qsim.grad(gc.contiguous().to(y_ref.dtype), torch.bfloat16), n_before >= ps.start)
+            xcc = xc.contiguous()
+            gx_ref = torch.where((xcc > 0) & (xcc < 6), gx_ref, torch.zeros_like(gx_ref))              # hardtanh_backward
+            x.requires_grad_(True)
+            y = pair(x)
+            (gx,) = torch.autograd.grad(y, x, gout.to(y.dtype))
+            assert _bits_equal(y.detach(), y_ref.to(DEV)), ("output", s)
+            assert _bits_equal(gx, gx_ref.to(DEV)), ("input gradient", s)
+            assert _bits_equal(p.mask.detach().cpu(), ps.mask) and _bits_equal(p.callback.magnitude.detach().cpu(), ps.magnitude), s
+            assert _bits_equal(q.weight.detach().cpu(), qsim.weight), ("scale", s)
+            assert (p._n_updates.item(), p.callback.t.item(), q._n_updates.item(), q.callback.t) == \
+                (ps.n_updates, ps.t, qsim.n_updates, qsim.shared["t"]), ("counters", s)
+            del y, gx, x, gout, xc, gc, h, y_ref, gx_ref, xcc
+    finally:
+        _hip.site_fwd = real
+    # the last steps ran the frozen-mask composite, the ones before the live one
+    assert sum(1 for f in flags if f & _hip.SITE_SCALE_ONLY) >= 2 and sum(1 for f in flags if not f & _hip.SITE_SCALE_ONLY) >= 1, flags
