@@ -83,6 +83,12 @@ def main():
             a = casts.setdefault(k, [0.0, 0])
             a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             a[1] += 1
+            # parameter-sized launches (weights forward, weight gradients backward: at most a few hundred thousand work-items;
+            # the smallest activation of these networks has millions) apart from the activation-sized ones
+            if int(r.get("Grid_Size_X", r.get("Grid_Size", 1 << 30))) <= 800_000:
+                b = casts.setdefault(k + ", parameter-sized launches among them", [0.0, 0])
+                b[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                b[1] += 1
     for r in rows:      # ATen's own ReLU passes (networks with in-place ReLU modules, or fold_relu=False)
         name = r["Kernel_Name"]
         if int(r["Start_Timestamp"]) >= t_first and "qs::" not in name and ("threshold" in name or "clamp" in name or "relu" in name.lower()):
