@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 15
+#define QS_ABI_VERSION 16
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -491,7 +491,10 @@ typedef struct qs_multi_row {
     const uint8_t* mask;         /* nullable: the prune operator's mask (bool bytes) */
     int64_t mask_inner;          /* see above (ignored with mask_C == 0) */
     int32_t mask_C;              /* 0: one mask byte per element */
-    int32_t reserved0;
+    int32_t kind;                /* 0: a weight / bias row.  1: a MASK-LEVEL row -- the importance of a pruned weight whose mask
+                                    varies along a subset of dims (x: [numel] float, the staged mean of |weight| that
+                                    qs_multi_stage_mean produced this step; numel = the mask's): it takes part in
+                                    qs_multi_magnitude and qs_multi_mask_refresh only (scale may be NULL, nothing is quantized) */
     int32_t* prune_n_updates;    /* nullable */
     int64_t* prune_t;            /* nullable (required with magnitude) */
     float* magnitude;            /* nullable: [numel] running magnitude, updated by qs_multi_magnitude */
@@ -511,6 +514,23 @@ int qs_multi_absmax(const qs_multi_row* rows_dev, int n, int absmax_blocks, qs_s
 int qs_multi_scale_update(const qs_multi_row* rows_dev, int n, int channels, qs_stream_t stream);
 int qs_multi_quant_fwd(const qs_multi_row* rows_dev, int n, int quant_blocks, float* ybase, int advance, qs_stream_t stream);
 int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs_stream_t stream);
+/* The importance of pruned weights whose mask varies along a SUBSET of dims (prune()'s default dimensions={1}: one mask entry
+ * per input channel) is squeeze_tensor_to_shape(|weight|, mask.shape) (reference util.py:79-99 via sparse.py:82-89): one mean per
+ * reduced dim, ascending, each rounded to float32.  qs_multi_stage_mean runs ONE such stage for a list of tensors: entry i
+ * averages the middle dim of the contiguous [pre, n, post] tensor x into out [pre, 1, post] (layout 0; |x| first with take_abs),
+ * or -- layout 1, the first stage of a channels_last weight -- the leading dim of x = [n][hw = pre][C = post] in memory into the
+ * NCHW-contiguous out [C][hw], in ATen's CPU summation order for that case (the orders of qs_mean_dim / qs_mean_dim_cl, one
+ * lane per output element).  The caller launches it once per stage level; qs_multi_stage_plan fills block0 of a HOST table. */
+typedef struct qs_multi_stage {
+    const float* x;
+    float* out;
+    int64_t pre, n, post;
+    int32_t take_abs, layout;
+    int32_t block0, reserved;     /* derived */
+} qs_multi_stage;
+int qs_multi_stage_plan(qs_multi_stage* stages_host, int n, int* blocks);
+int qs_multi_stage_mean(const qs_multi_stage* stages_dev, int n, int blocks, qs_stream_t stream);
+
 /* hist_blocks: the total qs_multi_plan returned through *hist_blocks_out (0: no row refreshes) */
 int qs_multi_mask_refresh(const qs_multi_row* rows_dev, int n, int hist_blocks, int quant_blocks, qs_stream_t stream);
 /*   qs_multi_ste_bwd:       gx[i][e] = clamp(g[i][e], lo_mul[i] * s, hi_mul[i] * s) with s = step[i][c] (or 2^-step[i][c] with

@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 15          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 16          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -64,6 +64,8 @@ SIGNATURES = {
     "qs_multi_quant_fwd": (c_int, [_P, _I, _I, _P, _I, _P]),
     "qs_multi_magnitude": (c_int, [_P, _I, _I, _P]),
     "qs_multi_mask_refresh": (c_int, [_P, _I, _I, _I, _P]),
+    "qs_multi_stage_plan": (c_int, [_P, _I, _P]),
+    "qs_multi_stage_mean": (c_int, [_P, _I, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
@@ -93,7 +95,7 @@ class MultiRow(ctypes.Structure):
                 ("t_dev", c_void_p), ("bump", c_void_p), ("numel", c_int64), ("y_off", c_int64), ("outer", c_int64),
                 ("inner", c_int64), ("C", c_int32), ("train", c_int32), ("is_decimal", c_int32), ("t_offset", c_int32),
                 ("code_lo", c_int32), ("code_hi", c_int32), ("denom", c_float),
-                ("mask", c_void_p), ("mask_inner", c_int64), ("mask_C", c_int32), ("reserved0", c_int32),
+                ("mask", c_void_p), ("mask_inner", c_int64), ("mask_C", c_int32), ("kind", c_int32),
                 ("prune_n_updates", c_void_p), ("prune_t", c_void_p), ("magnitude", c_void_p), ("mag_backup", c_void_p),
                 ("refresh", c_int32), ("select_k", ctypes.c_uint32), ("importance", c_void_p), ("select_state", c_void_p),
                 ("mask_backup", c_void_p),
@@ -1046,6 +1048,33 @@ class MultiTable:
 
     def __deepcopy__(self, memo):
         raise TypeError("a launch table holds raw device pointers: rebuild it, never copy it")
+
+
+class MultiStage(ctypes.Structure):
+    """`qs_multi_stage` of include/qsparse_hip.h, field for field"""
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("pre", c_int64), ("n", c_int64), ("post", c_int64),
+                ("take_abs", c_int32), ("layout", c_int32), ("block0", c_int32), ("reserved", c_int32)]
+
+
+class StageTable:
+    """one level of the staged means of a list of tensors (`qs_multi_stage_mean`): host array -> plan -> device copy"""
+
+    def __init__(self, stages, device):
+        self.n = len(stages)
+        self.host = (MultiStage * self.n)(*stages)
+        blocks = c_int(0)
+        _check(load().qs_multi_stage_plan(self.host, self.n, ctypes.byref(blocks)), "qs_multi_stage_plan")
+        self.blocks, self.device = blocks.value, device
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+
+    def __deepcopy__(self, memo):
+        raise TypeError("a launch table holds raw device pointers: rebuild it, never copy it")
+
+
+def multi_stage_mean(table: StageTable, nbytes: int = 0):
+    with _timed("multi_stage_mean", int(nbytes)):
+        st = load().qs_multi_stage_mean(table.dev.data_ptr(), table.n, table.blocks, _device_stream(table.device))
+    _check(st, "qs_multi_stage_mean")
 
 
 def multi_absmax(table: MultiTable, nbytes: int = 0):

@@ -33,15 +33,16 @@ undoes it).  It is safe by construction for anything a forward pass may do:
     layer's read, is not visible -- switch ``batch_weights`` off for such a network.)
   * A bias that is read BEFORE its layer's weight (the reference would then have updated the bias with ``t``, not ``t + 1``)
     rolls both back; they are evaluated inline in the order of the reads.
-  * A PRUNED weight -- ``quantize(prune(conv))``: the quantizer's input is ``weight * mask`` (sparse.py:263) -- takes part too:
-    the kernels multiply by the mask themselves, forward and backward, and advance the prune operator's counters.  With a
-    full-shape (unstructured) mask every read but the few that change the sparsity: the running magnitude is averaged by
-    ``qs_multi_magnitude`` and the mask rebuilt by ``qs_multi_mask_refresh`` (the radix select + mask of the callback, for all
-    layers at once) whenever the callback would -- with the stock ``MagnitudePruningCallback()`` that is every read.  With a
-    mask over a channel subset (``prune()``'s default ``dimensions={1}``: a staged mean per layer) the reads on which the
-    operator only applies its mask: before ``start``, between rebuilds, after ``stop_mask_refresh`` (the steady state of the
-    reference's layerwise recipe, sparse.py:343-359), in evaluation.  Everything is rolled back like the quantizer's state
-    (magnitudes and masks from the backups the launches wrote).
+  * A PRUNED weight -- ``quantize(prune(conv))``: the quantizer's input is ``weight * mask`` (sparse.py:263) -- takes part too,
+    with its whole prune operator: the kernels multiply by the mask themselves, forward and backward, advance the operator's
+    counters, compute the importance -- ``|weight|`` element by element for a full-shape mask, the staged mean
+    ``squeeze_tensor_to_shape(|weight|, mask.shape)`` for a mask over a subset of dims (``prune()``'s default: one entry per input
+    channel; ``qs_multi_stage_mean``, one launch per stage level for all layers) --, average the running magnitude
+    (``qs_multi_magnitude``) and rebuild the mask (``qs_multi_mask_refresh``: the callback's radix select + mask for all layers at
+    once) whenever the callback would -- with the stock ``MagnitudePruningCallback()`` that is every read.  Only the few reads
+    that change the sparsity stay per layer (and, per layer, a channels_last weight whose first reduced dim is not dim 0: its
+    staged mean has an order of its own).  Everything is rolled back like the quantizer's state (magnitudes and masks from the
+    backups the launches wrote).
   * Layers whose operators carry hooks, layers on the CPU, group-wise quantizers, callbacks shared between layers, pruning
     callbacks other than ``MagnitudePruningCallback`` (or ranking by gradient / L0) never take part; they keep their inline path.
 
@@ -59,7 +60,7 @@ from qsparse_amd import _hip
 from qsparse_amd import distributed as qdist
 from qsparse_amd.quantize import DecimalQuantizer, QuantizeLayer, ScalerQuantizer
 from qsparse_amd.sparse import MagnitudePruningCallback, PruneLayer
-from qsparse_amd.util import get_option, logging, threshold_rank
+from qsparse_amd.util import _reduction_plan, get_option, logging, threshold_rank
 
 _ALIGN = 64   # elements between the starts of two outputs in the flat buffer (256 bytes)
 _READY = {"weight": "_qs_ready_weight", "bias": "_qs_ready_bias"}   # layer.__dict__ keys of precomputed tensors waiting for their read
@@ -253,6 +254,38 @@ def _mask_geometry(w: torch.Tensor, mask: torch.Tensor):
     return (C, inner)
 
 
+def _stage_plan(w: torch.Tensor, mask: torch.Tensor):
+    """the stages of squeeze_tensor_to_shape(|w|, mask.shape) (reference util.py:79-99: one keepdim mean per reduced dim,
+    ascending) as (layout, pre, n, post) tuples for `qs_multi_stage_mean`, or None for a layout it does not serve.  A contiguous
+    weight: every stage is the mean over the middle dim of a contiguous [pre, n, post] tensor.  A channels_last weight whose
+    first reduced dim is dim 0: ATen reduces the NHWC memory directly into an NCHW-contiguous result (layout 1), the later stages
+    are contiguous ones (the route of `util._staged_mean_hip`)."""
+    try:
+        dims = _reduction_plan(w.shape, mask.shape)
+    except (AssertionError, ValueError):
+        return None
+    if not dims:
+        return None
+    shape = list(w.shape)
+    stages = []
+    if not w.is_contiguous():
+        if not (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last) and dims[0] == 0 and shape[0] > 1):
+            return None
+        stages.append((1, shape[2] * shape[3], shape[0], shape[1]))          # x = [n][hw][C] in memory -> [C][hw]
+        shape[0] = 1
+        dims = dims[1:]
+    for d in dims:
+        pre = 1
+        for sdim in shape[:d]:
+            pre *= sdim
+        post = 1
+        for sdim in shape[d + 1:]:
+            post *= sdim
+        stages.append((0, pre, shape[d], post))
+        shape[d] = 1
+    return tuple(stages)
+
+
 def _eligible(layer: nn.Module) -> bool:
     """a layer whose weight is read through exactly one quantizer (tensor-wise or per channel) -- and, underneath it, at most a
     prune operator"""
@@ -320,7 +353,8 @@ def _hooked_prune(p: PruneLayer) -> bool:
 def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     """what the prune operator underneath a weight's quantizer would do on this read, if that is something the multi-tensor
     kernels can do in its place -- None otherwise (the inline path then runs the operator itself).  Reads state, changes none.
-    Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude, threshold rank of a mask rebuild or None)."""
+    Returns (mask_geometry or None, counts n_updates, counts t, averages magnitude, threshold rank of a mask rebuild or None,
+    stages of the importance's staged mean or None)."""
     if not _prune_ok(p) or _hooked_prune(p) or not p.initted or p.training != training:
         return None
     mask = p.mask
@@ -331,12 +365,12 @@ def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     if geo is None:
         return None
     if not training:                              # PruneLayer.forward in evaluation: weight * mask, nothing else
-        return (geo, False, False, False, None)
+        return (geo, False, False, False, None, None)
     n = p._steps.read(p._n_updates)
     if n in p.schedules:
         return None                               # the sparsity changes on this read
     if n < p.start:
-        return (None, True, False, False, None)   # not pruning yet: the layer only counts
+        return (None, True, False, False, None, None)   # not pruning yet: the layer only counts
     cb = p.callback
     if not cb.initted or not cb.t.is_cuda or cb.t.device != w.device:
         return None
@@ -344,23 +378,33 @@ def _prune_step(p: PruneLayer, w: torch.Tensor, training: bool):
     sparsity = p.current_sparsity()
     refresh = cb.refresh_due(t, sparsity)
     average = t < cb.stop_mask_refresh and cb.running_average
+    if not (average or refresh):
+        return (geo, True, True, False, None, None)
+    # this read averages the running magnitude and / or rebuilds the mask (sparse.py:82-89, 58-66): the importance is
+    # squeeze_tensor_to_shape(|weight|, mask.shape) -- element-wise for a full-shape mask, a staged mean otherwise -- which the
+    # kernels compute for all such layers at once.  Under a process group the reference path averages it over the ranks: inline.
+    if qdist.exchange_active(qdist.stats_world_size()):
+        return None
     mag = getattr(cb, "magnitude", None)
-    if average or (refresh and cb.running_average):
-        # the running magnitude of a full-shape mask is element-wise; over a channel subset it is a staged mean per layer, and
-        # under a process group the reference path averages it over the ranks: both stay inline
-        if (geo != (0, 1) or mag is None or not mag.is_cuda or mag.dtype != torch.float32 or mag.shape != w.shape
-                or _strides(mag) != _strides(w) or qdist.exchange_active(qdist.stats_world_size())):
+    stages = None
+    if geo == (0, 1):
+        if _strides(mask) != _strides(w):
             return None
+        mag_ok = mag is not None and mag.shape == w.shape and _strides(mag) == _strides(w)
+    else:
+        stages = _stage_plan(w, mask)
+        if stages is None or not mask.is_contiguous():
+            return None
+        mag_ok = mag is not None and mag.shape == mask.shape and mag.is_contiguous()
+    if cb.running_average and not (mag_ok and mag.is_cuda and mag.dtype == torch.float32):
+        return None
     k = None
     if refresh:
-        # the mask is rebuilt on this read (sparse.py:58-66): for a full-shape mask a radix select over the element-wise importance
-        # -- the running magnitude, or |weight| without a running average -- which the kernels run for all such layers at once
-        n_el = w.numel()
+        n_el = mask.numel()
         k = threshold_rank(sparsity, n_el)
-        if (geo != (0, 1) or k >= n_el or n_el >= 2 ** 32 or _strides(mask) != _strides(w)
-                or (not cb.running_average and qdist.exchange_active(qdist.stats_world_size()))):
+        if k >= n_el or n_el >= 2 ** 32:
             return None                           # (k >= n: the inline path raises the reference's IndexError)
-    return (geo, True, True, average, k)
+    return (geo, True, True, average, k, stages)
 
 
 class _LaunchPlan(dict):
@@ -632,7 +676,7 @@ class WeightBatcher:
                 (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), u.q.weight.data_ptr(), u.q._n_updates.data_ptr(),
                  None if td is None else td.data_ptr())
                 + ((ps, u.p.mask.data_ptr(), u.p._n_updates.data_ptr(), u.p.callback.t.data_ptr(),
-                    u.p.callback.magnitude.data_ptr() if (ps[3] or (ps[4] is not None and u.p.callback.running_average)) else None)
+                    u.p.callback.magnitude.data_ptr() if ((ps[3] or ps[4] is not None) and u.p.callback.running_average) else None)
                    if ps is not None else ())
                 for u, w, td, ps in zip(todo, weights, t_devs, psteps))
             plans = self._plan if isinstance(self._plan, _LaunchPlan) else _LaunchPlan()     # (key -> table; never copied)
@@ -647,6 +691,8 @@ class WeightBatcher:
             if train:
                 # the prune operators first, as on every read (sparse.py:99-122): running magnitudes, then the masks that are due
                 # -- the quantizers' abs-max below sees weight * (new) mask
+                for stage_table in plan["stage_tables"]:       # importances that are staged means, one launch per stage level
+                    _hip.multi_stage_mean(stage_table, nbytes=plan["stage_bytes"])
                 if plan["mag_backups"]:
                     _hip.multi_magnitude(table, nbytes=plan["mag_bytes"])
                 if plan["mask_backups"]:
@@ -695,6 +741,7 @@ class WeightBatcher:
         rows, keep = [], []
         mag_backups, mag_bytes = {}, 0
         mask_backups, refresh_bytes = {}, 0
+        levels, mask_rows, stage_bytes = {}, [], 0       # staged-mean launch tables per stage level; mask-level rows; bytes read
         trains_weight = {id(u.layer) for u in todo[:n_train] if u.attr == "weight"}
         for i, (u, w, sat) in enumerate(zip(todo, weights, sats)):
             q, qc = u.q, u.q.callback
@@ -718,7 +765,7 @@ class WeightBatcher:
             ps = psteps[i]
             if ps is not None:                   # a pruned weight (see `_prune_step`)
                 pl = u.p
-                geo, counts_n, counts_t, averages, rank = ps
+                geo, counts_n, counts_t, averages, rank, stages = ps
                 if geo is not None:
                     r.mask, r.mask_C, r.mask_inner = pl.mask.data_ptr(), geo[0], geo[1]
                     keep.append(pl.mask)
@@ -728,24 +775,49 @@ class WeightBatcher:
                 if counts_t:
                     r.prune_t = pl.callback.t.data_ptr()
                     keep.append(pl.callback.t)
+                # who averages / re-ranks: the weight's own row (full-shape mask: the importance is |weight| element by element) or a
+                # mask-level row whose x is the staged mean this step's stage launches leave in `imp`
+                target, n_imp = r, w.numel()
+                if stages is not None:
+                    cur, n_imp = w, pl.mask.numel()
+                    for level, (layout, pre, n_red, post) in enumerate(stages):
+                        out = torch.empty(pre * post, dtype=torch.float32, device=dev)
+                        st = _hip.MultiStage()
+                        st.x, st.out, st.pre, st.n, st.post = cur.data_ptr(), out.data_ptr(), pre, n_red, post
+                        st.take_abs, st.layout = int(level == 0), layout
+                        levels.setdefault(level, []).append(st)
+                        keep += [cur, out]
+                        stage_bytes += 4 * pre * n_red * post
+                        cur = out
+                    target = _hip.MultiRow()
+                    target.kind, target.x = 1, cur.data_ptr()
+                    target.numel, target.outer, target.C, target.inner = n_imp, 1, 1, n_imp
+                    target.code_lo, target.code_hi, target.denom = 1, 0, 1.0
+                    target.prune_t = pl.callback.t.data_ptr()         # (read by the running mean; advanced through the weight's row)
+                    mask_rows.append(target)
                 if averages:
-                    backup = torch.empty_like(pl.callback.magnitude)        # the magnitude's (= the weight's) own memory layout
-                    r.magnitude, r.mag_backup = pl.callback.magnitude.data_ptr(), backup.data_ptr()
+                    backup = torch.empty_like(pl.callback.magnitude)        # the magnitude's own memory layout
+                    target.magnitude, target.mag_backup = pl.callback.magnitude.data_ptr(), backup.data_ptr()
                     keep += [pl.callback.magnitude, backup]
                     mag_backups[i] = backup
-                    mag_bytes += 16 * w.numel()
+                    mag_bytes += 16 * n_imp
                 if rank is not None:             # this read rebuilds the mask
                     cb = pl.callback
                     state = torch.zeros(258, dtype=torch.int32, device=dev)
                     mbackup = torch.empty_like(pl.mask)
-                    r.refresh, r.select_k = 1, int(rank)
-                    r.importance = cb.magnitude.data_ptr() if cb.running_average else None
-                    r.select_state, r.mask_backup = state.data_ptr(), mbackup.data_ptr()
-                    keep += [state, mbackup] + ([cb.magnitude] if cb.running_average else [])
+                    target.refresh, target.select_k = 1, int(rank)
+                    target.importance = cb.magnitude.data_ptr() if cb.running_average else None
+                    target.select_state, target.mask_backup = state.data_ptr(), mbackup.data_ptr()
+                    if target is not r:
+                        target.mask, target.mask_C, target.mask_inner = pl.mask.data_ptr(), 0, 1
+                    keep += [state, mbackup, pl.mask] + ([cb.magnitude] if cb.running_average else [])
                     mask_backups[i] = mbackup
-                    refresh_bytes += (4 * 4 + 6) * w.numel()
+                    refresh_bytes += (4 * 4 + 6) * n_imp
             rows.append(r)
+        rows += mask_rows                                 # (after the tensors: `offsets` and the callers index rows by unit)
+        stage_tables = [_hip.StageTable(levels[k], dev) for k in sorted(levels)]
         return _LaunchPlan(key=key, offsets=offsets, total=total, keep=keep, table=_hip.MultiTable(rows, dev),
+                           stage_tables=stage_tables, stage_bytes=stage_bytes,
                            mag_backups=mag_backups, mag_bytes=mag_bytes, mask_backups=mask_backups, refresh_bytes=refresh_bytes,
                            train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
                            any_decimal=any(not u.q.callback.use_float_scaler for u in todo))

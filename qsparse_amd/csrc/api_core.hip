@@ -306,7 +306,8 @@ int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_bloc
     int64_t ab = 0, qb = 0, ch = 0, hb = 0;
     for (int i = 0; i < n; ++i) {
         qs_multi_row& r = rows[i];
-        if (!r.x || !r.scale || r.numel < 0 || r.C < 1 || r.outer < 1 || r.inner < 1) return QS_ERR_ARG;
+        if (!r.x || (!r.scale && r.kind == 0) || r.numel < 0 || r.C < 1 || r.outer < 1 || r.inner < 1) return QS_ERR_ARG;
+        if (r.kind != 0 && (r.kind != 1 || r.train)) return QS_ERR_ARG;
         if (r.outer * r.C * r.inner != r.numel && r.numel != 0) return QS_ERR_ARG;
         if (r.C > 1 && (r.inner >= ((int64_t)1 << 31) || r.outer >= ((int64_t)1 << 31))) return QS_ERR_ARG;
         if (r.train && (!r.amax || !r.t_dev || !(r.denom > 0.f))) return QS_ERR_ARG;
@@ -383,6 +384,27 @@ int qs_multi_magnitude(const qs_multi_row* rows_dev, int n, int quant_blocks, qs
     if (n < 0 || quant_blocks < 0 || (n > 0 && !rows_dev)) return QS_ERR_ARG;
     if (n == 0 || quant_blocks == 0) return QS_OK;
     hipLaunchKernelGGL(multi_magnitude_kernel, dim3(quant_blocks), dim3(kBlock), 0, (hipStream_t)stream, rows_dev, n);
+    return launch_status();
+}
+
+int qs_multi_stage_plan(qs_multi_stage* stages, int n, int* blocks) {
+    if (n < 0 || (n > 0 && !stages) || !blocks) return QS_ERR_ARG;
+    int64_t b = 0;
+    for (int i = 0; i < n; ++i) {
+        qs_multi_stage& st = stages[i];
+        if (!st.x || !st.out || st.pre < 1 || st.n < 1 || st.post < 1 || (st.layout != 0 && st.layout != 1)) return QS_ERR_ARG;
+        st.block0 = (int32_t)b;
+        b += (st.pre * st.post + kBlock - 1) / kBlock;
+        if (b > 0x7fffffff) return QS_ERR_ARG;
+    }
+    *blocks = (int)b;
+    return QS_OK;
+}
+
+int qs_multi_stage_mean(const qs_multi_stage* stages_dev, int n, int blocks, qs_stream_t stream) {
+    if (n < 0 || blocks < 0 || (n > 0 && !stages_dev)) return QS_ERR_ARG;
+    if (n == 0 || blocks == 0) return QS_OK;
+    hipLaunchKernelGGL(multi_stage_mean_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, stages_dev, n);
     return launch_status();
 }
 

@@ -186,8 +186,9 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
         // and t_offset 0 / 1: the weight's update saw t, the bias's t + 1, the counter moves by two.
         for (int k = threadIdx.x; k < n; k += kBlock) {
             // (the prune operator's counters of a pruned weight: every training read counts, sparse.py:117,272)
-            if (rows[k].prune_n_updates) atomicAdd(rows[k].prune_n_updates, 1);
-            if (rows[k].prune_t) atomicAdd((unsigned long long*)rows[k].prune_t, 1ull);
+            // (a mask-level row names the same count only to READ it in multi_magnitude_kernel)
+            if (rows[k].prune_n_updates && rows[k].kind == 0) atomicAdd(rows[k].prune_n_updates, 1);
+            if (rows[k].prune_t && rows[k].kind == 0) atomicAdd((unsigned long long*)rows[k].prune_t, 1ull);
             if (!rows[k].train) continue;
             atomicAdd((unsigned long long*)rows[k].t_dev, 1ull);
             if (rows[k].bump) atomicAdd(rows[k].bump, 1);
@@ -195,6 +196,7 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
     }
     const int i = multi_find(rows, n, blockIdx.x, 1);
     const qs_multi_row r = rows[i];
+    if (r.kind != 0) return;                // a mask-level row: nothing to quantize
     const int64_t g = (int64_t)(blockIdx.x - r.quant_block0) * kBlock + threadIdx.x;
     const float* x = r.x;
     float* y = ybase + r.y_off;
@@ -278,6 +280,61 @@ static __global__ __launch_bounds__(kBlock) void multi_magnitude_kernel(const qs
         r.mag_backup[e] = old;
         r.magnitude[e] = (t * old + fabsf(r.x[e])) / tp1;
     }
+}
+
+// ---- one stage of the staged mean (importance of pruned weights whose mask varies along a subset of dims) for a list of tensors --
+// one lane per output element, ATen's CPU summation order: mean_generic_kernel (layout 0) / mean_cl_generic_kernel (layout 1)
+static __global__ __launch_bounds__(kBlock) void multi_stage_mean_kernel(const qs_multi_stage* __restrict__ stages, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (stages[mid].block0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const qs_multi_stage st = stages[lo];
+    const int64_t t = (int64_t)(blockIdx.x - st.block0) * kBlock + threadIdx.x;
+    if (t >= st.pre * st.post) return;
+    const float* x = st.x;
+    const float fn = (float)st.n;
+    if (st.layout == 1) {
+        // x: [n][hw][C] in memory, t = pos * C + c; out [C][hw]
+        const int64_t hw = st.pre, C = st.post;
+        const int64_t pos = t / C, c = t - pos * C;
+        const int64_t sample = hw * C;
+        auto get = [&](int64_t i) {
+            const float v = x[i * sample + t];
+            return st.take_abs ? fabsf(v) : v;
+        };
+        const float s = (pos < (hw / 4) * 4) ? sum_multi_row(st.n, get) : sum_row_sum(st.n, get);
+        st.out[c * hw + pos] = s / fn;
+        return;
+    }
+    const int64_t p = t / st.post, col = t - p * st.post;
+    const int64_t base = p * st.n * st.post + col;
+    auto get = [&](int64_t i) {
+        const float v = x[base + i * st.post];
+        return st.take_abs ? fabsf(v) : v;
+    };
+    float s;
+    if (st.post == 1) {
+        if (st.n >= 8) {   // vectorized inner sum: 8 lanes, row-sum order over n/8 vectors
+            const int64_t nv = st.n / 8;
+            float lanes[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lanes[k] = sum_row_sum(nv, [&](int64_t i) { return get(8 * i + k); });
+            float fin = 0.f;
+            for (int64_t i = nv * 8; i < st.n; ++i) fin += get(i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fin += lanes[k];
+            s = fin;
+        } else {
+            s = sum_row_sum(st.n, get);
+        }
+    } else {
+        const int64_t mr_cols = (st.post >= 8) ? (st.post / 32) * 32 : (st.post / 4) * 4;
+        s = (col < mr_cols) ? sum_multi_row(st.n, get) : sum_row_sum(st.n, get);
+    }
+    st.out[p * st.post + col] = s / fn;
 }
 
 // ---- mask rebuild of the pruned weights with a full-shape mask (rows with refresh != 0) -----------------------------------------

@@ -39,6 +39,12 @@ PRUNES = {
     "full_default": ({0, 1, 2, 3}, dict()),
     # no running average: the mask is rebuilt from |weight| itself on every second read
     "full_noavg_refresh": ({0, 1, 2, 3}, dict(running_average=False, mask_refresh_interval=2)),
+    # prune()'s defaults altogether -- `convert(model, prune(sparsity), weight_layers=[...])`: one mask entry per input channel,
+    # the stock callback: the importance is a staged mean of |weight| (qs_multi_stage_mean), averaged and re-ranked on every read
+    "channel_default": ({1}, dict()),
+    # masks over output x input channels, and per output channel; without a running average
+    "subset_default": ({0, 1}, dict()),
+    "rows_noavg": ({0}, dict(running_average=False, mask_refresh_interval=2)),
 }
 QUANTS = {"scaler": ("scaler", -1, -1), "default": ("scaler", 1, -1), "decimal_dim0_bias": ("decimal", 0, 6)}
 
@@ -139,7 +145,7 @@ def test_pruned_layers_follow_the_layer_by_layer_state_through_the_whole_schedul
     assert state["left.prune.callback.t"].item() > state["right.prune.callback.t"].item()
 
 
-@pytest.mark.parametrize("prune", ["full_avg", "subset_noavg", "full_default"])
+@pytest.mark.parametrize("prune", ["full_avg", "subset_noavg", "full_default", "channel_default"])
 def test_an_exception_and_a_weight_written_before_its_read(prune):
     def script(model, step):
         for i in range(12):
@@ -250,23 +256,29 @@ def test_a_network_moved_to_channels_last_after_its_masks_exist_keeps_training()
         assert torch.equal(a[k], b[k]), k
 
 
-def test_the_stock_callback_rebuilds_every_mask_on_every_read_in_a_handful_of_launches(monkeypatch):
+@pytest.mark.parametrize("prune,channels_last", [("full_default", False), ("channel_default", False), ("channel_default", True)])
+def test_the_stock_callback_rebuilds_every_mask_on_every_read_in_a_handful_of_launches(prune, channels_last, monkeypatch):
     """`MagnitudePruningCallback()` as it comes: after `start`, every read averages the magnitude and re-ranks it.  Layer by layer
     that is a radix select (nine launches), a mask launch, a running mean and a mask apply per layer and read; here one
     qs_multi_magnitude + one qs_multi_mask_refresh for the whole network"""
     calls = []
-    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_magnitude", "multi_mask_refresh", "absmax",
-               "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge"):
+    for fn in ("multi_absmax", "multi_scale_update", "multi_quant_fwd", "multi_magnitude", "multi_mask_refresh", "multi_stage_mean",
+               "absmax", "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge", "mean_dim",
+               "mean_last2", "mean_dim_cl", "pq_select"):
         real = getattr(_hip, fn)
         monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (calls.append(name), f(*a, **k))[1]))(fn, real))
-    model = _build("full_default", "default")
+    model = _build(prune, "default", channels_last)
     g = torch.Generator().manual_seed(5)
     for i in range(10):
         for prm in model.parameters():
             prm.grad = None
         del calls[:]
-        model(torch.randn(4, 3, 10, 10, generator=g).cuda()).sum().backward()
+        x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+        model(x.contiguous(memory_format=torch.channels_last) if channels_last else x).sum().backward()
         if i >= 6:          # past the schedule (the sparsity changed on reads 2 and 4)
-            assert sorted(calls) == ["multi_absmax", "multi_magnitude", "multi_mask_refresh", "multi_quant_fwd", "multi_scale_update"], (i, calls)
+            want = ["multi_absmax", "multi_magnitude", "multi_mask_refresh", "multi_quant_fwd", "multi_scale_update"]
+            if prune == "channel_default":      # the staged means: dim 0, then kh, then kw -- three stage levels for the 3 x 3 kernels
+                want += ["multi_stage_mean"] * 3
+            assert sorted(calls) == sorted(want), (i, calls)
     sparsity = 1.0 - model.left.prune.mask.float().mean().item()
     assert abs(sparsity - 0.5) < 0.02

@@ -41,7 +41,8 @@ def main():
     x = torch.randn(batch, 3, size, size, device="cuda").contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 10, (batch,), device="cuda")
     for dims, name, stock in (({0, 1, 2, 3}, "unstructured masks, frozen", False), ({1}, "per-input-channel masks, frozen", False),
-                              ({0, 1, 2, 3}, "unstructured masks, the stock callback: magnitude averaged and mask rebuilt on every read", True)):
+                              ({0, 1, 2, 3}, "unstructured masks, the stock callback: magnitude averaged and mask rebuilt on every read", True),
+                              ({1}, "per-input-channel masks, the stock callback -- prune()'s defaults", True)):
         row = {}
         for batched in (True, False):
             net = build(arch, batched, dims, stock)
