@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 16
+#define QS_ABI_VERSION 17
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -494,7 +494,11 @@ typedef struct qs_multi_row {
     int32_t kind;                /* 0: a weight / bias row.  1: a MASK-LEVEL row -- the importance of a pruned weight whose mask
                                     varies along a subset of dims (x: [numel] float, the staged mean of |weight| that
                                     qs_multi_stage_mean produced this step; numel = the mask's): it takes part in
-                                    qs_multi_magnitude and qs_multi_mask_refresh only (scale may be NULL, nothing is quantized) */
+                                    qs_multi_magnitude and qs_multi_mask_refresh only (scale may be NULL, nothing is quantized).
+                                    2: a weight that is NOT quantized on this read -- prune(conv) without a quantizer, or a
+                                    quantizer still in its identity phase (quantize.py:496-517: it only counts): y = x * mask
+                                    (x where mask == NULL), `bump` (nullable: the idle quantizer's `_n_updates`) incremented,
+                                    scale may be NULL */
     int32_t* prune_n_updates;    /* nullable */
     int64_t* prune_t;            /* nullable (required with magnitude) */
     float* magnitude;            /* nullable: [numel] running magnitude, updated by qs_multi_magnitude */

@@ -42,7 +42,9 @@ undoes it).  It is safe by construction for anything a forward pass may do:
     once) whenever the callback would -- with the stock ``MagnitudePruningCallback()`` that is every read.  Only the few reads
     that change the sparsity stay per layer (and, per layer, a channels_last weight whose first reduced dim is not dim 0: its
     staged mean has an order of its own).  Everything is rolled back like the quantizer's state (magnitudes and masks from the
-    backups the launches wrote).
+    backups the launches wrote).  A pruned weight WITHOUT a quantizer (``convert(model, prune(...), weight_layers=[...])`` alone)
+    and one whose quantizer is still in its identity phase (it only counts the read, quantize.py:496-517) take part the same
+    way: the table row hands out ``weight * mask``.
   * Layers whose operators carry hooks, layers on the CPU, group-wise quantizers, callbacks shared between layers, pruning
     callbacks other than ``MagnitudePruningCallback`` (or ranking by gradient / L0) never take part; they keep their inline path.
 
@@ -291,6 +293,9 @@ def _eligible(layer: nn.Module) -> bool:
     prune operator"""
     params = getattr(layer, "_parameters", None)
     ops = _operators(layer) if params is not None else None
+    if ops == ["prune"]:             # a pruned weight without a quantizer: the prune operator alone
+        w = params.get("weight")
+        return _prune_ok(getattr(layer, "prune", None)) and w is not None and w.dim() > 1
     if ops != ["quantize"] and not (ops == ["quantize", "prune"] and _prune_ok(getattr(layer, "prune", None))):
         return False
     if not _unit_ok(getattr(layer, "quantize", None), params.get("weight")):
@@ -335,7 +340,10 @@ def _batchable(model: nn.Module) -> List[nn.Module]:
     def own_prune(m):
         p = m.__dict__.get("_modules", {}).get("prune")
         return not isinstance(p, PruneLayer) or prune_owners.get(id(p.callback), 0) == 1
-    return [m for m in model.modules() if _eligible(m) and owners.get(id(m.quantize.callback), 0) == 1 and own_prune(m)]
+    def own_quantizer(m):
+        q = m.__dict__.get("_modules", {}).get("quantize")
+        return not isinstance(q, QuantizeLayer) or owners.get(id(q.callback), 0) == 1
+    return [m for m in model.modules() if _eligible(m) and own_quantizer(m) and own_prune(m)]
 
 
 def _hooked(q: QuantizeLayer) -> bool:
@@ -425,8 +433,9 @@ class _Unit:
         self.layer, self.attr, self.slot, self.channels = layer, attr, slot, channels
 
     @property
-    def q(self) -> QuantizeLayer:
-        return getattr(self.layer, _QUANT[self.attr])
+    def q(self) -> Optional[QuantizeLayer]:
+        q = self.layer.__dict__.get("_modules", {}).get(_QUANT[self.attr])
+        return q if isinstance(q, QuantizeLayer) else None       # (None: a pruned weight without a quantizer)
 
     @property
     def param(self) -> torch.Tensor:
@@ -443,12 +452,13 @@ class _Unit:
 
 class _Pending:
     """what has to be undone if a precomputed tensor is never read"""
-    __slots__ = ("unit", "was_quantized", "t_dev", "version", "training", "dead", "index", "prune")
+    __slots__ = ("unit", "was_quantized", "t_dev", "version", "training", "dead", "index", "prune", "plain")
 
-    def __init__(self, unit, was_quantized, t_dev, version, training, prune=None):
+    def __init__(self, unit, was_quantized, t_dev, version, training, prune=None, plain=None):
         self.unit, self.was_quantized, self.t_dev, self.version, self.training = unit, was_quantized, t_dev, version, training
         self.dead, self.index = None, 0     # the hand-out group's "rolled back" flags and this tensor's place in them
         self.prune = prune                  # (counted n_updates, counted t, magnitude backup, mask backup) of a pruned weight
+        self.plain = plain                  # not quantized on this read: None, or whether an idle quantizer counted the read
 
 
 def _patched_class(base):
@@ -501,6 +511,8 @@ class WeightBatcher:
                     C = 1 if q.channelwise < 0 else p.shape[q.channelwise]
                     self.units.append(_Unit(layer, attr, total, C))
                     total += C
+                elif attr == "weight" and p is not None and not isinstance(getattr(layer, "quantize", None), QuantizeLayer):
+                    self.units.append(_Unit(layer, attr, total, 0))       # prune only: no scale, no channel slot
         self._channels = total
         self._pending: List[_Pending] = []
         self._amax = None
@@ -565,14 +577,19 @@ class WeightBatcher:
             p.dead[p.index] = True               # its place in the group's autograd node delivers no gradient
         if not p.training:
             return                               # evaluation-mode hand-outs change no state
-        q, qc = u.q, u.q.callback
+        q = u.q
         with torch.no_grad():
-            q.weight.data.view(-1).copy_(self._backup[u.slot:u.slot + u.channels])
-            q._steps.add(q._n_updates, -1)
-            qc.t -= 1
-            if p.t_dev is not None:
-                p.t_dev.sub_(1)
-                qc.__dict__["_t_dev_value"] = qc.t
+            if p.plain is not None:              # not quantized on that read: at most an idle quantizer counted it
+                if p.plain:
+                    q._steps.add(q._n_updates, -1)
+            else:
+                qc = q.callback
+                q.weight.data.view(-1).copy_(self._backup[u.slot:u.slot + u.channels])
+                q._steps.add(q._n_updates, -1)
+                qc.t -= 1
+                if p.t_dev is not None:
+                    p.t_dev.sub_(1)
+                    qc.__dict__["_t_dev_value"] = qc.t
             if p.prune is not None:          # the prune operator underneath: its counters and its running magnitude
                 pl = u.p
                 counted_n, counted_t, mag_backup, mask_backup = p.prune
@@ -584,7 +601,8 @@ class WeightBatcher:
                     pl.callback.magnitude.data.copy_(mag_backup)      # (same shape and strides: element by element)
                 if mask_backup is not None:
                     pl.mask.data.copy_(mask_backup)
-        q._quantized = p.was_quantized
+        if p.plain is None:
+            q._quantized = p.was_quantized
 
     def _rollback_all(self):
         for p in list(self._pending):
@@ -604,6 +622,7 @@ class WeightBatcher:
         if not get_option("batch_weights"):
             return
         train, frozen = [], []          # tensors that update statistics this step / that only quantize
+        plain = {}                      # unit -> whether an idle quantizer counts the read: pruned weights that are NOT quantized now
         prune_steps = {}                # id(layer) -> what its prune operator does on this read (`_prune_step`)
         skip_layer = None
         for u in self.units:
@@ -611,6 +630,15 @@ class WeightBatcher:
             if layer is skip_layer:
                 continue                # the weight does not take part this step: neither does its bias (shared count)
             q, w = u.q, u.param
+            if q is None:               # prune(conv) without a quantizer: the prune operator alone, y = weight * mask
+                pl = u.p
+                ok = (pl is not None and w.is_cuda and w.dtype == torch.float32 and _dense(w) and w.data_ptr() % 4 == 0
+                      and "_qs_batcher_base" in type(layer).__dict__ and not layer._forward_pre_hooks and not w.is_inference())
+                ps = _prune_step(pl, w, pl.training) if ok else None
+                if ps is not None:
+                    prune_steps[id(layer)] = ps
+                    plain[u] = False
+                continue
             geo = _geometry(w, q.channelwise)
             ok = (w.is_cuda and w.dtype == torch.float32 and geo is not None and w.data_ptr() % 4 == 0
                   and (u.channels == 1 or geo[1] == u.channels))
@@ -624,7 +652,16 @@ class WeightBatcher:
             t = q._steps.read(q._n_updates) if ok else 0
             took_part = False
             pl = u.p
-            if ok and pl is not None and t >= q.timeout and (q.training or q._quantized):
+            if ok and pl is not None and (t < q.timeout or not (q.training or q._quantized)):
+                # the quantizer above a pruned weight is in its identity phase (it only counts the read, quantize.py:496-517): the
+                # prune operator alone -- its bias quantizer, if any, stays inline this step
+                ps = _prune_step(pl, w, q.training)
+                if ps is not None:
+                    prune_steps[id(layer)] = ps
+                    plain[u] = bool(q.training)
+                skip_layer = layer
+                continue
+            if ok and pl is not None:
                 # a pruned weight: only on the steps its prune operator leaves to the kernels (see `_prune_step`)
                 prune_steps[id(layer)] = _prune_step(pl, w, q.training)
                 ok = prune_steps[id(layer)] is not None
@@ -639,42 +676,45 @@ class WeightBatcher:
                     took_part = True
             if not took_part and u.attr == "weight":
                 skip_layer = layer
-        if not train and not frozen:
+        if not train and not frozen and not plain:
             return
-        todo = train + frozen
+        todo = train + frozen + list(plain)
+        plain_training = any(u.p.training for u in plain)
         weights = [u.param for u in todo]
         dev = weights[0].device
         if any(w.device != dev for w in weights):
             return
         if self._amax is None or self._amax.device != dev:
-            self._amax = torch.zeros(self._channels, dtype=torch.float32, device=dev)
-            self._decimals = torch.zeros(self._channels, dtype=torch.float32, device=dev)
-            self._backup = torch.zeros(self._channels, dtype=torch.float32, device=dev)
-        sats = [u.q.callback.code_range(u.q.bits) for u in todo]
+            self._amax = torch.zeros(max(self._channels, 1), dtype=torch.float32, device=dev)
+            self._decimals = torch.zeros(max(self._channels, 1), dtype=torch.float32, device=dev)
+            self._backup = torch.zeros(max(self._channels, 1), dtype=torch.float32, device=dev)
+        sats = [None if u in plain else u.q.callback.code_range(u.q.bits) for u in todo]
         # evaluation / serving: nothing changes between calls unless someone writes a parameter or a scale (both bump
         # `_version`), so the quantized weights of the previous call are handed out again without a launch
         eval_key = None
         # (only under no_grad / inference_mode: a loop that runs the network in eval() WITH gradients -- fine-tuning with
         # frozen statistics, manual SGD or EMA through `p.data.add_()` -- may write parameters by the one route the version
         # counter does not see, and would be handed stale weights silently; such loops pay the launch per forward)
-        if not train and not torch.is_grad_enabled():
-            eval_key = tuple((id(u.layer), u.attr, w.data_ptr(), w._version, u.q.weight.data_ptr(), u.q.weight._version,
-                              tuple(w.stride()), sat) + ((u.p.mask.data_ptr(), u.p.mask._version) if u.p is not None else ())
+        if not train and not plain_training and not torch.is_grad_enabled():
+            eval_key = tuple((id(u.layer), u.attr, w.data_ptr(), w._version, tuple(w.stride()), sat)
+                             + ((u.q.weight.data_ptr(), u.q.weight._version) if u not in plain else ())
+                             + ((u.p.mask.data_ptr(), u.p.mask._version) if u.p is not None else ())
                              for u, w, sat in zip(todo, weights, sats))
             if eval_key == self._eval_key:
-                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals, prune_steps)
+                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals, prune_steps, plain)
                 return
         self._eval_key = None
         undo = {}
         with torch.no_grad():
-            t_devs = [u.q.callback.device_t(dev) if i < len(train) else None for i, u in enumerate(todo)]
+            t_devs = [u.q.callback.device_t(dev) if i < len(train) else None for i, u in enumerate(todo)]       # (train units come first)
             # everything that does not change from step to step -- the launch table, the layout of the flat output buffer --
             # is built once per (set of tensors, parameter storage, state storage) and reused
             # (pruned weights: the mask and what the prune operator does this step are part of the table)
             psteps = [prune_steps.get(id(u.layer)) if u.attr == "weight" else None for u in todo]
             key = (len(train), tuple(sats)) + tuple(
-                (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), u.q.weight.data_ptr(), u.q._n_updates.data_ptr(),
-                 None if td is None else td.data_ptr())
+                (id(u.layer), u.attr, w.data_ptr(), tuple(w.stride()), None if td is None else td.data_ptr())
+                + ((u.q.weight.data_ptr(), u.q._n_updates.data_ptr()) if u not in plain
+                   else ("plain", u.q._n_updates.data_ptr() if plain[u] else None))
                 + ((ps, u.p.mask.data_ptr(), u.p._n_updates.data_ptr(), u.p.callback.t.data_ptr(),
                     u.p.callback.magnitude.data_ptr() if ((ps[3] or ps[4] is not None) and u.p.callback.running_average) else None)
                    if ps is not None else ())
@@ -685,10 +725,10 @@ class WeightBatcher:
                 # (a handful of tables: reads that rebuild masks alternate with reads that do not, training with evaluation)
                 if len(plans) >= 4:
                     plans.pop(next(iter(plans)))
-                plan = plans[key] = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev, psteps)
+                plan = plans[key] = self._build_plan(key, todo, weights, t_devs, sats, len(train), dev, psteps, plain)
                 self._plan = plans
             table = plan["table"]
-            if train:
+            if train or plain_training:
                 # the prune operators first, as on every read (sparse.py:99-122): running magnitudes, then the masks that are due
                 # -- the quantizers' abs-max below sees weight * (new) mask
                 for stage_table in plan["stage_tables"]:       # importances that are staged means, one launch per stage level
@@ -697,8 +737,21 @@ class WeightBatcher:
                     _hip.multi_magnitude(table, nbytes=plan["mag_bytes"])
                 if plan["mask_backups"]:
                     _hip.multi_mask_refresh(table, nbytes=plan["refresh_bytes"])
-                _hip.multi_absmax(table, nbytes=plan["train_bytes"])
-                _hip.multi_scale_update(table)
+                if train:
+                    _hip.multi_absmax(table, nbytes=plan["train_bytes"])
+                    _hip.multi_scale_update(table)
+                for i, u in enumerate(todo):
+                    if u in plain and u.p.training:      # not quantized on this read: the prune operator's bookkeeping, an idle quantizer's count
+                        ps, pl = psteps[i], u.p
+                        if ps[1]:
+                            pl._steps.note_device_add(pl._n_updates, 1)
+                        if ps[2]:
+                            pl.callback._t_host.note_device_add(pl.callback.t, 1)
+                        if plain[u]:
+                            u.q._steps.note_device_add(u.q._n_updates, 1)
+                        undo[(id(u.layer), u.attr)] = _Pending(u, None, None, u.param._version, True,
+                                                                (ps[1], ps[2], plan["mag_backups"].get(i), plan["mask_backups"].get(i)),
+                                                                plain=plain[u])
                 for i, (u, t_dev) in enumerate(zip(train, t_devs)):
                     q, qc = u.q, u.q.callback
                     ps, prune_undo = psteps[i], None
@@ -722,18 +775,18 @@ class WeightBatcher:
             for i, (u, w) in enumerate(zip(todo, weights)):
                 # the reference broadcasts the input against the parameter (`input / scaler`): a tensor-wise (1, 1) scale turns a
                 # 1-d bias into a (1, C) tensor (quantize.py `_reference_shape`; nn.Linear takes it, nn.Conv2d rejects it)
-                if u.q.weight.numel() == 1 and u.q.weight.dim() > w.dim():
+                if u not in plain and u.q.weight.numel() == 1 and u.q.weight.dim() > w.dim():
                     outs[i] = outs[i].view(torch.broadcast_shapes(tuple(w.shape), tuple(u.q.weight.shape)))
-            _hip.multi_quant_fwd(table, flat, advance=bool(train), nbytes=plan["all_bytes"])      # (prune counters ride with train rows)
+            _hip.multi_quant_fwd(table, flat, advance=bool(train) or plain_training, nbytes=plan["all_bytes"])
             # a DecimalQuantizer's backward clamps with the decimal of ITS forward (the reference computes a fresh tensor per
             # call, quantize.py:312-325, and the Function saves that one, :41): the hand-out nodes get this step's values, not
             # the buffer the next precomputation overwrites (a ScalerQuantizer's saves the scale parameter itself, :108)
             decimals = self._decimals.clone() if plan["any_decimal"] else self._decimals
         if eval_key is not None:
             self._eval_key, self._eval_outs, self._eval_decimals = eval_key, outs, decimals
-        self._hand_out(todo, weights, outs, undo, decimals, prune_steps)
+        self._hand_out(todo, weights, outs, undo, decimals, prune_steps, plain)
 
-    def _build_plan(self, key, todo, weights, t_devs, sats, n_train, dev, psteps) -> _LaunchPlan:
+    def _build_plan(self, key, todo, weights, t_devs, sats, n_train, dev, psteps, plain) -> _LaunchPlan:
         offsets, total = [], 0
         for w in weights:
             offsets.append(total)
@@ -744,24 +797,33 @@ class WeightBatcher:
         levels, mask_rows, stage_bytes = {}, [], 0       # staged-mean launch tables per stage level; mask-level rows; bytes read
         trains_weight = {id(u.layer) for u in todo[:n_train] if u.attr == "weight"}
         for i, (u, w, sat) in enumerate(zip(todo, weights, sats)):
-            q, qc = u.q, u.q.callback
-            outer, C, inner = _geometry(w, q.channelwise)
-            sl = slice(u.slot, u.slot + u.channels)
-            is_decimal = not qc.use_float_scaler
-            amax, dec, backup = self._amax[sl], self._decimals[sl], self._backup[sl]
-            keep += [amax, dec, backup, t_devs[i], q.weight, q._n_updates, w]
             r = _hip.MultiRow()
-            r.x, r.scale = w.data_ptr(), q.weight.data_ptr()
-            r.amax, r.backup = amax.data_ptr(), backup.data_ptr()
-            r.decimal = dec.data_ptr() if is_decimal else None
-            r.t_dev = t_devs[i].data_ptr() if t_devs[i] is not None else None
-            r.bump = q._n_updates.data_ptr()
-            r.numel, r.y_off, r.outer, r.inner, r.C = w.numel(), offsets[i], outer, inner, C
-            r.train, r.is_decimal = int(i < n_train), int(is_decimal)
-            # the bias quantizer shares its weight quantizer's callback: when both update this step the bias sees t + 1
-            r.t_offset = int(u.attr == "bias" and i < n_train and id(u.layer) in trains_weight)
-            r.code_lo, r.code_hi = (1, 0) if sat is None else (int(sat[0]), int(sat[1]))
-            r.denom = float(2 ** (q.bits - 1))
+            if u in plain:               # not quantized on this read (kind 2): y = weight * mask, an idle quantizer counts
+                keep.append(w)
+                r.kind, r.x = 2, w.data_ptr()
+                r.numel, r.y_off, r.outer, r.inner, r.C = w.numel(), offsets[i], 1, max(w.numel(), 1), 1
+                r.code_lo, r.code_hi, r.denom = 1, 0, 1.0
+                if plain[u]:
+                    r.bump = u.q._n_updates.data_ptr()
+                    keep.append(u.q._n_updates)
+            else:
+                q, qc = u.q, u.q.callback
+                outer, C, inner = _geometry(w, q.channelwise)
+                sl = slice(u.slot, u.slot + u.channels)
+                is_decimal = not qc.use_float_scaler
+                amax, dec, backup = self._amax[sl], self._decimals[sl], self._backup[sl]
+                keep += [amax, dec, backup, t_devs[i], q.weight, q._n_updates, w]
+                r.x, r.scale = w.data_ptr(), q.weight.data_ptr()
+                r.amax, r.backup = amax.data_ptr(), backup.data_ptr()
+                r.decimal = dec.data_ptr() if is_decimal else None
+                r.t_dev = t_devs[i].data_ptr() if t_devs[i] is not None else None
+                r.bump = q._n_updates.data_ptr()
+                r.numel, r.y_off, r.outer, r.inner, r.C = w.numel(), offsets[i], outer, inner, C
+                r.train, r.is_decimal = int(i < n_train), int(is_decimal)
+                # the bias quantizer shares its weight quantizer's callback: when both update this step the bias sees t + 1
+                r.t_offset = int(u.attr == "bias" and i < n_train and id(u.layer) in trains_weight)
+                r.code_lo, r.code_hi = (1, 0) if sat is None else (int(sat[0]), int(sat[1]))
+                r.denom = float(2 ** (q.bits - 1))
             ps = psteps[i]
             if ps is not None:                   # a pruned weight (see `_prune_step`)
                 pl = u.p
@@ -820,21 +882,25 @@ class WeightBatcher:
                            stage_tables=stage_tables, stage_bytes=stage_bytes,
                            mag_backups=mag_backups, mag_bytes=mag_bytes, mask_backups=mask_backups, refresh_bytes=refresh_bytes,
                            train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
-                           any_decimal=any(not u.q.callback.use_float_scaler for u in todo))
+                           any_decimal=any(u not in plain and not u.q.callback.use_float_scaler for u in todo))
 
-    def _hand_out(self, todo, weights, outs, undo, decimals, prune_steps=None):
+    def _hand_out(self, todo, weights, outs, undo, decimals, prune_steps=None, plain=()):
         """park every quantized tensor on its layer, `_GROUP` consecutive tensors per autograd node (a node per layer in
         evaluation mode under no_grad costs nothing either way)"""
         for base in range(0, len(todo), _GROUP):
             group = todo[base:base + _GROUP]
             meta, steps = [], []
             for u in group:
+                ps = prune_steps.get(id(u.layer)) if (prune_steps and u.attr == "weight") else None
+                mask = (u.p.mask, ps[0][0], ps[0][1], _strides(u.param)) if (ps is not None and ps[0] is not None) else None
+                if u in plain:      # not quantized on this read: the gradient passes (times the mask: the backward of weight * mask)
+                    meta.append((False, 0.0, 0.0, True, -1, mask))
+                    steps.append(decimals[:1])
+                    continue
                 q, qc = u.q, u.q.callback
                 is_decimal = not qc.use_float_scaler
                 limit = 2.0 ** (q.bits - 1)
                 notch = 1 if qc.flip_axis else 0
-                ps = prune_steps.get(id(u.layer)) if (prune_steps and u.attr == "weight") else None
-                mask = (u.p.mask, ps[0][0], ps[0][1], _strides(u.param)) if (ps is not None and ps[0] is not None) else None
                 meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise, mask))
                 steps.append(decimals[u.slot:u.slot + u.channels].view(-1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)
@@ -842,7 +908,8 @@ class WeightBatcher:
             for i, (u, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):
                 pending = undo.get((id(u.layer), u.attr))
                 if pending is None:
-                    pending = _Pending(u, u.q._quantized, None, w._version, False)
+                    pending = _Pending(u, None if u in plain else u.q._quantized, None, w._version, False,
+                                       plain=(False if u in plain else None))
                 pending.dead, pending.index = dead, i
                 self._pending.append(pending)
                 u.layer.__dict__[_READY[u.attr]] = (y, pending, self)

@@ -307,7 +307,7 @@ int qs_multi_plan(qs_multi_row* rows, int n, int* absmax_blocks, int* quant_bloc
     for (int i = 0; i < n; ++i) {
         qs_multi_row& r = rows[i];
         if (!r.x || (!r.scale && r.kind == 0) || r.numel < 0 || r.C < 1 || r.outer < 1 || r.inner < 1) return QS_ERR_ARG;
-        if (r.kind != 0 && (r.kind != 1 || r.train)) return QS_ERR_ARG;
+        if (r.kind != 0 && ((r.kind != 1 && r.kind != 2) || r.train)) return QS_ERR_ARG;
         if (r.outer * r.C * r.inner != r.numel && r.numel != 0) return QS_ERR_ARG;
         if (r.C > 1 && (r.inner >= ((int64_t)1 << 31) || r.outer >= ((int64_t)1 << 31))) return QS_ERR_ARG;
         if (r.train && (!r.amax || !r.t_dev || !(r.denom > 0.f))) return QS_ERR_ARG;

@@ -187,8 +187,10 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
         for (int k = threadIdx.x; k < n; k += kBlock) {
             // (the prune operator's counters of a pruned weight: every training read counts, sparse.py:117,272)
             // (a mask-level row names the same count only to READ it in multi_magnitude_kernel)
-            if (rows[k].prune_n_updates && rows[k].kind == 0) atomicAdd(rows[k].prune_n_updates, 1);
-            if (rows[k].prune_t && rows[k].kind == 0) atomicAdd((unsigned long long*)rows[k].prune_t, 1ull);
+            if (rows[k].prune_n_updates && rows[k].kind != 1) atomicAdd(rows[k].prune_n_updates, 1);
+            if (rows[k].prune_t && rows[k].kind != 1) atomicAdd((unsigned long long*)rows[k].prune_t, 1ull);
+            // (kind 2: the quantizer underneath is in its identity phase -- or absent: it only counts the read, quantize.py:515)
+            if (rows[k].kind == 2 && rows[k].bump) atomicAdd(rows[k].bump, 1);
             if (!rows[k].train) continue;
             atomicAdd((unsigned long long*)rows[k].t_dev, 1ull);
             if (rows[k].bump) atomicAdd(rows[k].bump, 1);
@@ -196,10 +198,15 @@ static __global__ __launch_bounds__(kBlock) void multi_quant_kernel(const qs_mul
     }
     const int i = multi_find(rows, n, blockIdx.x, 1);
     const qs_multi_row r = rows[i];
-    if (r.kind != 0) return;                // a mask-level row: nothing to quantize
+    if (r.kind == 1) return;                // a mask-level row: nothing to quantize
     const int64_t g = (int64_t)(blockIdx.x - r.quant_block0) * kBlock + threadIdx.x;
     const float* x = r.x;
     float* y = ybase + r.y_off;
+    if (r.kind == 2) {                      // no quantization (a prune-only weight, or a quantizer in its identity phase): y = x * mask
+        for (int64_t e = g * 8; e < r.numel && e < g * 8 + 8; ++e)
+            y[e] = r.mask ? x[e] * multi_mask_at(r.mask, r.mask_C, r.mask_inner, e) : x[e];
+        return;
+    }
     const int64_t numel = r.numel, ngroups = numel / 8;
     const int sat = r.code_lo <= r.code_hi;
     const float* param = r.is_decimal ? r.decimal : r.scale;

@@ -46,19 +46,24 @@ PRUNES = {
     "subset_default": ({0, 1}, dict()),
     "rows_noavg": ({0}, dict(running_average=False, mask_refresh_interval=2)),
 }
-QUANTS = {"scaler": ("scaler", -1, -1), "default": ("scaler", 1, -1), "decimal_dim0_bias": ("decimal", 0, 6)}
+# name -> (callback kind, channelwise, bias_bits, timeout); "none": the prune operator alone (no quantizer on the layers); "late":
+# the quantizers stay in their identity phase for the first seven reads (they only count, quantize.py:496-517)
+QUANTS = {"scaler": ("scaler", -1, -1, 2), "default": ("scaler", 1, -1, 2), "decimal_dim0_bias": ("decimal", 0, 6, 2),
+          "none": None, "late": ("scaler", 1, 8, 7)}
 
 
 def _build(prune, quantizer, channels_last=False):
     dims, cbkw = PRUNES[prune]
-    kind, channelwise, bias_bits = QUANTS[quantizer]
     torch.manual_seed(0)
     model = qs.convert(Branchy(), qs.prune(sparsity=0.5, dimensions=dims, start=2, interval=2, repetition=2,
                                            callback=qs.MagnitudePruningCallback(**cbkw)),
                        weight_layers=[nn.Conv2d, nn.Linear], log=False)
-    model = qs.convert(model, qs.quantize(bits=4, channelwise=channelwise, timeout=2, bias_bits=bias_bits,
-                                          callback=qs.DecimalQuantizer() if kind == "decimal" else None),
-                       weight_layers=[nn.Conv2d, nn.Linear], log=False).cuda().train()
+    if QUANTS[quantizer] is not None:
+        kind, channelwise, bias_bits, timeout = QUANTS[quantizer]
+        model = qs.convert(model, qs.quantize(bits=4, channelwise=channelwise, timeout=timeout, bias_bits=bias_bits,
+                                              callback=qs.DecimalQuantizer() if kind == "decimal" else None),
+                           weight_layers=[nn.Conv2d, nn.Linear], log=False)
+    model = model.cuda().train()
     if channels_last:        # (before the first forward: the full-shape masks and magnitudes are then created in the weights' layout)
         model = model.to(memory_format=torch.channels_last)
     return model
@@ -105,7 +110,7 @@ def _scenario(script, prune, quantizer, calls=None, channels_last=False):
             model.eval()
             trace = []
             for name, m in model.named_modules():       # the weight (and bias) every layer would compute with now
-                if isinstance(getattr(m, "quantize", None), QuantizeLayer):
+                if isinstance(getattr(m, "quantize", None), QuantizeLayer) or isinstance(getattr(m, "prune", None), PruneLayer):
                     trace.append(m.weight.detach().clone())
                     if isinstance(getattr(m, "quantize_bias", None), QuantizeLayer):
                         trace.append(m.bias.detach().clone())
@@ -193,10 +198,12 @@ def test_the_multi_tensor_kernels_really_take_the_pruned_layers(channels_last, m
     taken = [i for i, c in enumerate(per_step) if "multi_quant_fwd" in c and not inline & set(c)]
     averaging = [i for i in taken if "multi_magnitude" in per_step[i]]
     rebuilding = [i for i in taken if "multi_mask_refresh" in per_step[i]]
-    # reads 0-1: the quantizers' identity phase (inline); 2 and 4: the sparsity changes (inline); the callback's reads 3 and 6 --
-    # steps 5 and 8 -- rebuild the mask; from its read 8 on the mask is frozen
-    assert taken == [3, 5, 6, 7, 8, 9, 10, 11, 12, 13] and averaging == [3, 5, 6, 7, 8, 9] and rebuilding == [5, 8], (taken, averaging, rebuilding)
-    for i in taken:
+    # read 0 creates the layers' state (inline); read 1: quantizers in their identity phase, pruning not started -- the layers only
+    # count, from the table; 2 and 4: the sparsity changes (inline); the callback's reads 3 and 6 -- steps 5 and 8 -- rebuild the
+    # mask; from its read 8 on the mask is frozen
+    assert taken == [1, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13] and averaging == [3, 5, 6, 7, 8, 9] and rebuilding == [5, 8], (taken, averaging, rebuilding)
+    assert per_step[1].count("multi_quant_fwd") == 1 and "multi_absmax" not in per_step[1]      # (nothing to quantize yet)
+    for i in taken[1:]:
         c = per_step[i]
         assert c.count("multi_quant_fwd") == 1 and c.count("multi_absmax") == 1 and c.count("multi_scale_update") == 1
         assert c.count("multi_ste_bwd") == 1, c          # four layers on the route: one hand-out group
@@ -282,3 +289,28 @@ def test_the_stock_callback_rebuilds_every_mask_on_every_read_in_a_handful_of_la
             assert sorted(calls) == sorted(want), (i, calls)
     sparsity = 1.0 - model.left.prune.mask.float().mean().item()
     assert abs(sparsity - 0.5) < 0.02
+
+
+@pytest.mark.parametrize("prune", ["channel_default", "full_default"])
+def test_prune_only_layers_and_idle_quantizers_take_no_per_layer_launch(prune, monkeypatch):
+    """`convert(model, prune(...), weight_layers=[...])` without any quantizer -- and the same network with quantizers that are
+    still in their identity phase: the prune operators of all layers run from the table, nothing per layer"""
+    calls = []
+    per_layer = ("absmax", "scale_update", "quant_fwd", "ste_bwd", "mask_apply", "running_mean", "kth_value", "mask_ge", "mean_dim",
+                 "mean_last2", "mean_dim_cl", "pq_select")
+    for fn in per_layer + ("multi_quant_fwd", "multi_absmax"):
+        real = getattr(_hip, fn)
+        monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (calls.append(name), f(*a, **k))[1]))(fn, real))
+    for quantizer in ("none", "late"):
+        model = _build(prune, quantizer)
+        g = torch.Generator().manual_seed(5)
+        for i in range(7):
+            for prm in model.parameters():
+                prm.grad = None
+            del calls[:]
+            model(torch.randn(4, 3, 10, 10, generator=g).cuda()).sum().backward()
+            if i >= 5:      # past the pruning schedule; "late": the quantizers only count (their bias quantizers, inline, too)
+                assert "multi_quant_fwd" in calls and "multi_absmax" not in calls and not set(per_layer) & set(calls), (quantizer, i, calls)
+        assert abs(1.0 - model.left.prune.mask.float().mean().item() - 0.5) < 0.02
+        if quantizer == "late":
+            assert model.left.quantize._n_updates.item() == 7 and not model.left.quantize._quantized

@@ -21,7 +21,7 @@ from examples.models import resnet18, resnet50
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
 
 
-def build(arch, batched, dims, stock=False):
+def build(arch, batched, dims, stock=False, quantized=True):
     qs.set_qsparse_options(batch_weights=batched)
     torch.manual_seed(0)
     net = (resnet50 if arch == "resnet50" else resnet18)(num_classes=1000 if arch == "resnet50" else 10)
@@ -29,7 +29,8 @@ def build(arch, batched, dims, stock=False):
                                    callback=qs.MagnitudePruningCallback() if stock else
                                    qs.MagnitudePruningCallback(mask_refresh_interval=1, stop_mask_refresh=2)),
                      weight_layers=[nn.Conv2d, nn.Linear], log=False)
-    net = qs.convert(net, qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
+    if quantized:
+        net = qs.convert(net, qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
     return net.cuda().to(memory_format=torch.channels_last).train()
 
 
@@ -40,12 +41,14 @@ def main():
     size = 224 if arch == "resnet50" else 32
     x = torch.randn(batch, 3, size, size, device="cuda").contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 10, (batch,), device="cuda")
-    for dims, name, stock in (({0, 1, 2, 3}, "unstructured masks, frozen", False), ({1}, "per-input-channel masks, frozen", False),
-                              ({0, 1, 2, 3}, "unstructured masks, the stock callback: magnitude averaged and mask rebuilt on every read", True),
-                              ({1}, "per-input-channel masks, the stock callback -- prune()'s defaults", True)):
+    for dims, name, stock, quantized in (
+            ({0, 1, 2, 3}, "unstructured masks, frozen", False, True), ({1}, "per-input-channel masks, frozen", False, True),
+            ({0, 1, 2, 3}, "unstructured masks, the stock callback: magnitude averaged and mask rebuilt on every read", True, True),
+            ({1}, "per-input-channel masks, the stock callback -- prune()'s defaults", True, True),
+            ({1}, "per-input-channel masks, the stock callback, NO quantizer: convert(model, prune(0.5), weight_layers=[...]) alone", True, False)):
         row = {}
         for batched in (True, False):
-            net = build(arch, batched, dims, stock)
+            net = build(arch, batched, dims, stock, quantized)
             opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
 
             def step():
@@ -67,7 +70,7 @@ def main():
                 wb = net.__dict__.get("_qs_weight_batcher")
                 row["layers taken"] = 0 if wb is None else len(wb.layers)
         qs.set_qsparse_options(batch_weights=True)
-        print(f"{arch} batch {batch}, weights pruned 50 % ({name}) + quantized 8-bit per channel, ms/step: {row}", flush=True)
+        print(f"{arch} batch {batch}, weights pruned 50 % ({name})" + (" + quantized 8-bit per channel" if quantized else "") + f", ms/step: {row}", flush=True)
 
 
 if __name__ == "__main__":
