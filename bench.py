@@ -513,10 +513,57 @@ def host_overhead(device, steps=300):
     return out
 
 
+def weights_pruned_config(device):
+    """the weight side on its own: every Conv2d / Linear weight of a ResNet read through prune() with its defaults
+    (one mask entry per input channel, the stock MagnitudePruningCallback: running magnitude averaged and mask rebuilt on every
+    read) and through quantize() with its defaults (8 bits, per channel) -- `convert(model, prune(0.5), weight_layers=...)` then
+    `convert(model, quantize(), weight_layers=...)`, reference convert.py:199-229 / imitation.py:61-68 -- training step time with
+    the multi-tensor weight path (default) and layer by layer, next to the plain network"""
+    import qsparse_amd as qs
+    from examples.models import resnet18, resnet50
+
+    out = {"recipe": "convert(prune(sparsity=0.5), weight_layers=[Conv2d, Linear]); convert(quantize(bits=8), weight_layers=[...]); "
+                     "channels_last, bf16 autocast, SGD momentum 0.9; ms per training step in steady state"}
+    for arch, ctor, batch, size, classes, steps in (("resnet18", resnet18, 128, 32, 10, 20), ("resnet50", resnet50, 64, 224, 1000, 8)):
+        x = torch.randn(batch, 3, size, size, device=device).contiguous(memory_format=torch.channels_last)
+        y = torch.randint(0, classes, (batch,), device=device)
+        row = {}
+        for mode in ("plain", "multi_tensor", "layer_by_layer"):
+            qs.set_qsparse_options(batch_weights=mode != "layer_by_layer")
+            try:
+                torch.manual_seed(0)
+                net = ctor(num_classes=classes)
+                if mode != "plain":
+                    net = qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
+                    net = qs.convert(net, qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
+                net = net.to(device).to(memory_format=torch.channels_last).train()
+                opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+
+                def step(_=0):
+                    opt.zero_grad(set_to_none=True)
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        loss = F.cross_entropy(net(x), y)
+                    loss.backward()
+                    opt.step()
+
+                for _ in range(6):
+                    step()
+                row[mode + "_ms"] = round(_timed_loop(step, steps), 3)
+                del net, opt
+            finally:
+                qs.set_qsparse_options(batch_weights=True)
+            torch.cuda.empty_cache()
+        row["multi_tensor_over_plain"] = round(row["multi_tensor_ms"] / row["plain_ms"], 4)
+        row["layer_by_layer_over_plain"] = round(row["layer_by_layer_ms"] / row["plain_ms"], 4)
+        out[f"{arch}_b{batch}"] = row
+    return out
+
+
 def extra_configs(device, only=None):
     """configs 2-4 of BASELINE.json; a failure in one of them is recorded, it never costs the headline line"""
     out = {}
     for name, fn in (("host_overhead_per_site", lambda: host_overhead(device)),
+                     ("weights_pruned_quantized", lambda: weights_pruned_config(device)),
                      ("config2_quantize8_256x64x56x56", lambda: config2(device)),
                      ("config3_resnet18_cifar_b128", lambda: resnet_config("resnet18", 128, device, 10)),
                      ("config4_resnet50_imagenet_b256", lambda: resnet_config("resnet50", 256, device, 5))):
