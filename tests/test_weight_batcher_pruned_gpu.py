@@ -314,3 +314,47 @@ def test_prune_only_layers_and_idle_quantizers_take_no_per_layer_launch(prune, m
         assert abs(1.0 - model.left.prune.mask.float().mean().item() - 0.5) < 0.02
         if quantizer == "late":
             assert model.left.quantize._n_updates.item() == 7 and not model.left.quantize._quantized
+
+
+@pytest.mark.parametrize("prune", ["full_default", "channel_default", "subset_noavg"])
+def test_non_finite_weights_under_and_outside_the_mask_behave_as_layer_by_layer(prune):
+    """NaN / Inf in a weight: `weight * mask` is NaN under a pruned position too (Inf * 0), the abs-max, the running magnitude
+    and the mask rebuild see them -- the table's kernels form the same products as the per-layer path (bit for bit, NaN == NaN)"""
+    def same_nan(a, b):
+        if a.dtype.is_floating_point:
+            return a.shape == b.shape and bool(((a == b) | (a.isnan() & b.isnan())).all())
+        return torch.equal(a, b)
+
+    results = []
+    for batched in (True, False):
+        qs.set_qsparse_options(batch_weights=batched)
+        try:
+            model = _build(prune, "default")
+            g = torch.Generator().manual_seed(9)
+            outs = []
+            for i in range(9):
+                if i == 6:          # past the schedule: poison a few weights of two layers, under and outside their masks
+                    with torch.no_grad():
+                        for layer, vals in ((model.left, [float("inf"), float("-inf"), float("nan")]), (model.shared, [float("inf")])):
+                            w = layer._parameters["weight"]
+                            m = layer.prune.mask.expand_as(w)
+                            pruned, kept = (~m).nonzero()[:3], m.nonzero()[:3]
+                            for k, v in enumerate(vals):
+                                w[tuple(pruned[k % len(pruned)])] = v
+                                w[tuple(kept[k % len(kept)])] = v
+                x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+                for prm in model.parameters():
+                    prm.grad = None
+                out = model(x)
+                out.sum().backward()
+                outs.append(out.detach().clone())
+            model.eval()
+            outs += [m.weight.detach().clone() for m in (model.stem, model.left, model.shared, model.head)]
+            results.append((outs, _state(model)))
+        finally:
+            qs.set_qsparse_options(batch_weights=True)
+    (oa, sa), (ob, sb) = results
+    for k in sa:
+        assert same_nan(sa[k], sb[k]), k
+    for i, (a, b) in enumerate(zip(oa[-4:], ob[-4:])):
+        assert same_nan(a, b), ("effective weight", i)
