@@ -16,6 +16,9 @@ _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics"
              "saturate": False}
 
 
+_options_epoch = [0]       # bumped by every set_options call: cached per-site decisions that depend on an option are keyed on it
+
+
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
@@ -54,6 +57,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     110-116, so its tensor's largest element maps to code ``+2^(bits-1)``, one above the range).  Per quantizer:
     ``ScalerQuantizer(saturate=True)`` / ``quantize_with_scaler(..., saturate=True)``; ``None`` there follows this option.
     With it every code fits its bit width, so ``export_integer(...)`` yields int8 / packed int4 tensors directly."""
+    _options_epoch[0] += 1
     if elide_pruned is not None:
         if elide_pruned not in ("off", "forward", "all"):
             raise ValueError(f"elide_pruned must be 'off', 'forward' or 'all', got {elide_pruned!r}")
