@@ -20,6 +20,7 @@ The same idea one operator at a time: ``FusedActQuantize`` and ``FusedActPrune``
 quantize / prune site (``Sequential(act, op)``), see the classes below.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -703,6 +704,7 @@ def _hooked(*modules) -> bool:
 # the host mirrors notice) takes the full path, which re-arms when it finds the steady state again.
 # ----------------------------------------------------------------------------------------------------------------------
 _MISS = object()
+_FAST_PATH = os.environ.get("QS_NO_FAST_PATH", "0") != "1"      # (development switch for A/B measurements)
 
 
 def _no_fast():
@@ -743,6 +745,8 @@ class _FastPair:
         inner, q = seq[0], seq[1]
         act, p = inner[0], inner[1]
         cb, qc = p.callback, q.callback
+        if not _FAST_PATH:
+            return None
         if type(act) is nn.Identity:
             fold, handle = 0, 0
         elif not fold:
