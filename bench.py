@@ -520,11 +520,13 @@ def weights_pruned_config(device):
     `convert(model, quantize(), weight_layers=...)`, reference convert.py:199-229 / imitation.py:61-68 -- training step time with
     the multi-tensor weight path (default) and layer by layer, next to the plain network"""
     import qsparse_amd as qs
-    from examples.models import resnet18, resnet50
+    from examples.models import resnet18
 
     out = {"recipe": "convert(prune(sparsity=0.5), weight_layers=[Conv2d, Linear]); convert(quantize(bits=8), weight_layers=[...]); "
                      "channels_last, bf16 autocast, SGD momentum 0.9; ms per training step in steady state"}
-    for arch, ctor, batch, size, classes, steps in (("resnet18", resnet18, 128, 32, 10, 20), ("resnet50", resnet50, 64, 224, 1000, 8)):
+    # (ResNet-18 only: the ResNet-50 figures -- 17.4 / 22.6 / 16.6 ms at batch 64 -- come from tools/bench_pruned_weights.py; new
+    #  convolution shapes in the middle of this process have cost MIOpen seconds per step on some boxes)
+    for arch, ctor, batch, size, classes, steps in (("resnet18", resnet18, 128, 32, 10, 20),):
         x = torch.randn(batch, 3, size, size, device=device).contiguous(memory_format=torch.channels_last)
         y = torch.randint(0, classes, (batch,), device=device)
         row = {}
