@@ -49,7 +49,7 @@ def one_case(rng, idx):
     start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2, 3])
     timeout = rng.choice([1, 2, 3])
     fold = rng.random() < 0.7
-    steps = rng.choice([4, 6, 8])
+    steps = rng.choice([4, 6, 8, 12, 16])      # (the long ones reach the steady state: the pair's fast path, fused.py)
     eval_from = rng.choice([steps, steps, steps - 1, steps - 2])
     channels_last = rng.random() < 0.35
     preserve = rng.random() < 0.2
