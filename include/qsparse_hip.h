@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 17
+#define QS_ABI_VERSION 18
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -385,6 +385,11 @@ typedef struct qs_site_plan {
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
 #define QS_SITE_STATS_DONE 32 /* with QS_SITE_LIVE: the statistics launches were already enqueued by qs_site_stats (a data-parallel
                                  step: the caller exchanged the record in between); qs_site_fwd starts at the select */
+#define QS_SITE_NO_QUANT 128  /* the site is a PruneLayer ALONE (reference sparse.py:215-273 behind an activation, convert.py:214-218;
+                                 plan->scale and the quantizer fields are unused): with QS_SITE_LIVE the statistics are the staged
+                                 mean alone (no abs-max), with QS_SITE_LIVE or QS_SITE_REFRESH the select updates magnitude / mask /
+                                 the prune counters, and the apply is y = act?(x) * mask in x's dtype (qs_mask_apply); qs_site_bwd
+                                 with the flag: gx = gate * g * mask (qs_quant_ste_relu_bwd without a clamp) or g * mask */
 #define QS_SITE_SCALE_ONLY 64 /* with QS_SITE_LIVE: the mask is frozen (MagnitudePruningCallback.t passed stop_mask_refresh,
                                  sparse.py:107-116 -- the steady state of devise_layerwise_pruning_schedule recipes, :343-359):
                                  magnitude and mask stay, the statistics are qs_absmax per channel into plan->absmax_dense

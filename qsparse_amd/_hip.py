@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 17          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 18          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -104,7 +104,7 @@ class MultiRow(ctypes.Structure):
                 ("hist_block0", c_int32), ("hist_blocks", c_int32), ("reserved1", c_int32)]
 
 
-SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE, SITE_SCALE_ONLY = 1, 2, 4, 8, 16, 32, 64
+SITE_LIVE, SITE_REFRESH, SITE_PRE_RELU, SITE_ELIDE, SITE_NO_MASK, SITE_STATS_DONE, SITE_SCALE_ONLY, SITE_NO_QUANT = 1, 2, 4, 8, 16, 32, 64, 128
 QSTEP_APPLY, QSTEP_ALL, QSTEP_ABSMAX, QSTEP_FINISH = 0, 1, 2, 3
 
 _lib = None

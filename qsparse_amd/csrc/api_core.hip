@@ -213,6 +213,52 @@ static int site_statistics(const qs_site_plan* p, const void* x, int pre_relu, f
                          record, stream);
 }
 
+// a PruneLayer alone (QS_SITE_NO_QUANT): geometry of plan as qs_mask_apply wants it
+static int site_mask_apply(const qs_site_plan* p, const void* x, void* y, int dt, int pre_relu, int elide, uint8_t* gate_out,
+                           qs_stream_t stream) {
+    const int64_t hw = p->H * p->W;
+    int64_t sizes[3], strides[3];
+    int nd;
+    if (p->layout == 0) {
+        sizes[0] = p->N, sizes[1] = p->C, sizes[2] = hw;
+        strides[0] = 0, strides[1] = 1, strides[2] = 0;
+        nd = 3;
+    } else {
+        sizes[0] = p->N * hw, sizes[1] = p->C;
+        strides[0] = 0, strides[1] = 1;
+        nd = 2;
+    }
+    return qs_mask_apply(x, p->mask, y, nd, sizes, strides, dt, pre_relu, elide, gate_out, stream);
+}
+
+static int site_prune_only_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out, int flags, int64_t t_mag, int64_t k,
+                               int pre_relu, qs_stream_t stream) {
+    if (!p->mask || !p->magnitude || (flags & (QS_SITE_STATS_DONE | QS_SITE_SCALE_ONLY | QS_SITE_NO_MASK))) return QS_ERR_ARG;
+    const int64_t hw = p->H * p->W;
+    const int update = (flags & QS_SITE_LIVE) ? 1 : 0, refresh = (flags & QS_SITE_REFRESH) ? 1 : 0;
+    if (update) {           // the staged mean of |act?(x)| alone: no abs-max rides along
+        if (!p->stage_mean || (p->layout != 2 && !p->stage)) return QS_ERR_ARG;
+        const int mflags = QS_MEAN_ABS | (pre_relu ? QS_MEAN_ACT(pre_relu) : 0);
+        int st;
+        if (p->layout == 2) {
+            st = qs_mean_dim(x, p->stage_mean, 1, p->N, p->C, p->xdt, p->xdt, mflags, nullptr, nullptr, 1, 1, p->C, stream);
+        } else {
+            st = p->layout == 0 ? qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, nullptr, 1, hw, p->C, stream)
+                                : qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, nullptr, stream);
+            if (st) return st;
+            st = qs_mean_last2(p->stage, p->stage_mean, p->C, p->H, p->W, p->xdt, p->xdt, nullptr, nullptr, 1, nullptr, stream);
+        }
+        if (st) return st;
+    }
+    if (update || refresh) {
+        int st = qs_pq_select(p->magnitude, update ? p->stage_mean : nullptr, p->xdt, p->C, update, t_mag, refresh, k, p->mask, nullptr, 1,
+                              0, 0, 8, nullptr, p->prune_n_updates, nullptr, p->callback_t, nullptr,
+                              (update && p->callback_t_from_device) ? p->callback_t : nullptr, nullptr, p->xdt, nullptr, 1, stream);
+        if (st) return st;
+    }
+    return site_mask_apply(p, x, y, p->xdt, pre_relu, (flags & QS_SITE_ELIDE) ? 1 : 0, gate_out, stream);
+}
+
 int qs_site_stats(const qs_site_plan* p, const void* x, int flags, float* record, qs_stream_t stream) {
     if (!site_plan_ok(p) || !x || !record) return QS_ERR_ARG;
     return site_statistics(p, x, (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0, record, stream);
@@ -222,9 +268,13 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
                 int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, float* decimal,
                 qs_stream_t stream) {
     if (!site_plan_ok(p) || !x || !y) return QS_ERR_ARG;
+    const int pre_relu = (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0;     // the folded activation's handle
+    if (flags & QS_SITE_NO_QUANT) {
+        if (image_out || xback_out || decimal || gathered) return QS_ERR_ARG;
+        return site_prune_only_fwd(p, x, y, gate_out, flags, t_mag, k, pre_relu, stream);
+    }
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
-    const int pre_relu = (flags & QS_SITE_PRE_RELU) ? (p->act > 0 ? p->act : 1) : 0;     // the folded activation's handle
     if (flags & QS_SITE_LIVE) {
         if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
         if (flags & QS_SITE_SCALE_ONLY) {      // frozen mask: per-channel abs-max, then the select's scale half alone
@@ -269,6 +319,16 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
 int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
                 float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream) {
     if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate)) return QS_ERR_ARG;
+    if (flags & QS_SITE_NO_QUANT) {          // a PruneLayer alone: the backward of act?(x) * mask
+        if (!g || !p->mask || g2 || decimal) return QS_ERR_ARG;
+        const int64_t hw0 = p->H * p->W;
+        const int64_t po = p->layout == 0 ? p->N : p->N * hw0, pi = p->layout == 0 ? hw0 : 1;
+        const int el = (flags & QS_SITE_ELIDE) ? 1 : 0;
+        if (gate)
+            return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, nullptr, 1, 1.0f, 0, -__builtin_inff(), __builtin_inff(), p->mask, po, p->C,
+                                         pi, gdt, p->xdt, el, p->act > 0 ? p->act : 1, nullptr, 0, stream);
+        return site_mask_apply(p, g, gx, gdt, 0, el, nullptr, stream);
+    }
     const float* step = decimal ? decimal : p->scale;
     const int is_decimal = decimal ? 1 : 0;
     const int64_t hw = p->H * p->W;

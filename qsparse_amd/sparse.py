@@ -59,6 +59,101 @@ class _MaskApply(torch.autograd.Function):
         return _hip.mask_apply(grad, mask), None, None, None
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# One FFI call per training step of a PruneLayer alone (`qs_site_fwd` / `qs_site_bwd` with QS_SITE_NO_QUANT): the staged mean,
+# the select (running magnitude, mask, counters) and the mask apply of `MagnitudePruningCallback._forward_single_launch` issued
+# from one ctypes call with a cached plan instead of three or four -- the same launches, the same arithmetic.
+# ----------------------------------------------------------------------------------------------------------------------
+class _PrunePlan:
+    __slots__ = ("key", "c", "ref", "keep", "channels_last")
+
+    def __init__(self):
+        self.key = None
+
+    def __deepcopy__(self, memo):        # raw pointers never travel
+        return _PrunePlan()
+
+    def __reduce__(self):
+        return (_PrunePlan, ())
+
+
+def _prune_plan(cb, x: torch.Tensor, mask: torch.Tensor, step_counter, act: int):
+    """the cached `qs_site_plan` of a prune-only site for inputs like `x`, or None when the composite does not cover it (then the
+    fine-grained launches run): 4-d NCHW / channels_last or 2-d activation with a batch of at least two, a channel mask, state on
+    x's device"""
+    if x.dim() not in (2, 4) or x.shape[0] < 2 or step_counter is None or not hasattr(cb, "magnitude"):
+        return None
+    flat = x.dim() == 2
+    N, C, H, W = (x.shape[0], x.shape[1], 1, 1) if flat else x.shape
+    if mask.numel() != C or _channel_dim(mask) != 1 or (not flat and (H < 2 or W < 2)):
+        return None
+    cl = not x.is_contiguous()
+    if cl and (flat or not x.is_contiguous(memory_format=torch.channels_last) or C % 8):
+        return None
+    if x.data_ptr() % 16 or (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return None
+    state = (cb.magnitude, mask, step_counter, cb.t)
+    if any((not t.is_cuda) or t.device != x.device for t in state) or cb.magnitude.numel() != C:
+        return None
+    graph_safe = bool(get_option("graph_safe"))
+    key = (N, C, H, W, flat, x.dtype, cl, x.device, graph_safe, act) + tuple(t.data_ptr() for t in state)
+    plan = cb.__dict__.get("_qs_prune_plan")
+    if plan is not None and plan.key == key:
+        return plan
+    plan = _PrunePlan()
+    plan.key, plan.channels_last = key, cl
+    stage = None if flat else torch.empty(C * H * W, dtype=x.dtype, device=x.device)
+    stage_mean = torch.empty(C, dtype=x.dtype, device=x.device)
+    plan.keep = (stage, stage_mean) + state
+    c = _hip.SitePlanStruct()
+    c.N, c.C, c.H, c.W = N, C, H, W
+    c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(x), _hip.dt(x), 8
+    c.magnitude, c.mask = cb.magnitude.data_ptr(), mask.data_ptr()
+    c.stage, c.stage_mean = (None if flat else stage.data_ptr()), stage_mean.data_ptr()
+    c.absmax_stride = 1
+    c.prune_n_updates, c.callback_t = step_counter.data_ptr(), cb.t.data_ptr()
+    c.callback_t_from_device = int(graph_safe)
+    c.act = int(act) or 1
+    plan.c, plan.ref = c, __import__("ctypes").byref(c)
+    cb.__dict__["_qs_prune_plan"] = plan
+    return plan
+
+
+class _PruneSiteStep(torch.autograd.Function):
+    """a PruneLayer's training step through qs_site_fwd / qs_site_bwd (QS_SITE_NO_QUANT); same results as `_importance` +
+    `qs_pq_select` + `_MaskApply`"""
+
+    @staticmethod
+    def forward(ctx, x, plan, flags, t_mag, k, mask):
+        want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0])
+        y = torch.empty_like(x)
+        bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if want_gate else None
+        if want_gate:
+            _hip.note_gate(bits)
+        _hip.site_fwd(plan.ref, x, y, bits, flags, t_mag, k, 0)
+        ctx.plan, ctx.has_gate = plan, want_gate
+        ctx.x_meta = (x.shape, x.dtype, x.stride())
+        ctx.save_for_backward(mask, bits if want_gate else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, bits = ctx.saved_tensors
+        plan = ctx.plan
+        shape, dtype, strides = ctx.x_meta
+        if (g.shape == shape and g.dtype == dtype and g.stride() == strides and g.data_ptr() % 16 == 0 and not _hip.logging_events()):
+            gx = torch.empty_like(g)
+            flags = _hip.SITE_NO_QUANT | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
+            _hip.site_bwd(plan.ref, g, bits if ctx.has_gate else None, gx, flags, 0.0, 0.0)
+            return gx, None, None, None, None, None
+        if ctx.has_gate:
+            inf = float("inf")
+            gate = _hip.ReluGate.from_saved(bits, shape, dtype, plan.channels_last)
+            return (_hip.ste_relu_bwd(g, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=1, gate=gate, act=plan.c.act),
+                    None, None, None, None, None)
+        return _hip.mask_apply(g, mask), None, None, None, None, None
+
+
 def _channel_dim(mask: torch.Tensor) -> int:
     """the single dim along which ``mask`` varies, or -1"""
     dims = [d for d, s in enumerate(mask.shape) if s != 1]
@@ -222,6 +317,26 @@ class MagnitudePruningCallback(nn.Module):
         refresh = self.refresh_due(t, sparsity)
         self.__dict__["_bumped_step_counter"] = False
         t_on_dev = self.t.is_cuda and self.t.device == x.device
+        if ((update or refresh) and t_on_dev and not self.l0 and not _hip.logging_events()
+                and (not pre_relu or get_option("relu_gate") or not (torch.is_grad_enabled() and x.requires_grad))
+                and not qdist.exchange_active(qdist.stats_world_size())):
+            # one call into the library for the whole step (statistics, select, mask apply): qs_site_fwd(QS_SITE_NO_QUANT)
+            plan = _prune_plan(self, x, mask, step_counter, int(pre_relu) or 1)
+            if plan is not None:
+                k = 0
+                if refresh:
+                    k = threshold_rank(sparsity, mask.numel())
+                    if k >= mask.numel():
+                        raise IndexError(f"index {k} is out of bounds for dimension 0 with size {mask.numel()}")
+                flags = (_hip.SITE_NO_QUANT | (_hip.SITE_LIVE if update else 0) | (_hip.SITE_REFRESH if refresh else 0)
+                         | (_hip.SITE_PRE_RELU if pre_relu else 0) | (_hip.SITE_ELIDE if _hip._elide_all() else 0))
+                # (x * mask keeps the sign of x on a pruned channel: only elide_pruned="all" may skip those loads, as `mask_apply`)
+                out = _PruneSiteStep.apply(x, plan, flags, t, k, mask)
+                self.__dict__["_bumped_step_counter"] = True
+                self._t_host.note_device_add(self.t, 1)
+                if self.forward_hook is not None:
+                    self.forward_hook(mask, name)
+                return out
         if update or refresh:
             with torch.no_grad():
                 imp = k = None
