@@ -32,7 +32,8 @@ def _worker(rank, world, port, sync, out):
         shard = full[rank * 4:(rank + 1) * 4] * (1.0 + 0.5 * rank)     # ranks see different data
         q(p(shard))
         a(shard)
-    out.put((rank, p.mask.clone(), p.callback.magnitude.clone(), q.weight.clone(), a.weight.clone()))
+    # by value (numpy): a tensor travels as a file descriptor the parent fetches from THIS process, which may have exited by then
+    out.put((rank,) + tuple(t.detach().numpy().copy() for t in (p.mask, p.callback.magnitude, q.weight, a.weight)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -48,7 +49,7 @@ def _run(sync):
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    return res
+    return [(r[0],) + tuple(torch.from_numpy(a) for a in r[1:]) for r in res]
 
 
 def test_statistics_exchange_keeps_ranks_identical():
