@@ -12,8 +12,8 @@ One "step" = one pass of the hot path over one batch of synthetic input, everyth
     apply   (read x, write y)   y = dequant(round(x*mask / s))         bf16 -> fp32
     bwd     (read g, write gx)  gx = clamp(g) * mask                    fp32 -> bf16
 Algorithmic bytes: 14 B/elem for the dense step (2 + 6 + 6), 6 B/elem for each apply kernel.  The
-library's default (`elide_pruned="forward"`, bit-identical for finite inputs) does not load the x of pruned channels
-in the apply forward, so its forward moves (2 * kept + 4) B/elem: every byte count below is the mask-aware one for the
+library's default (`elide_pruned="forward"`, bit-identical for every input: the select marks the pruned channels that
+hold a NaN / Inf and those are loaded) does not load the x of pruned channels in the apply forward, so its forward moves (2 * kept + 4) B/elem: every byte count below is the mask-aware one for the
 mode that ran, and `config.variants` carries the dense step ("off") and the fully elided one ("all") next to it.
 
 Rank 0 prints ONE JSON line.  With N > 1 every rank processes its own batch shard (weak scaling) and the C-sized
@@ -379,9 +379,9 @@ def resnet_config(arch, batch, device, steps):
         # float32 output and takes that convolution's bf16 gradient as it is (fused.py "Autocast image") -- same values as
         # the default path, no fp32 <-> bf16 cast passes around the site; opt-in because the site's output is a Tensor subclass
         opt_in_run("value_identical_opt_in", "autocast_image=True (value-identical)", True, autocast_image=True)
-        # the strict-reference mode for non-finite values on pruned channels.  Since round 4 the default elides only where a
-        # pruned channel is a skippable row (NCHW, no gate recording), so in this channels_last training step "off" and the
-        # default run the same kernels: the figure is the evidence that nothing is paid for following the reference there
+        # every element loaded.  The default elides only where a pruned channel is a skippable row (NCHW, no gate recording; exact
+        # for non-finite inputs as well since ABI v19), so in this channels_last training step "off" and the default run the
+        # same kernels: the figure is the evidence of that
         opt_in_run("elide_off", "elide_pruned='off' (every element loaded; the channels_last default already does)", False,
                    elide_pruned="off")
     finally:
@@ -869,7 +869,7 @@ def main():
             out["config"]["variants"] = {
                 m: {"ms_per_step": round(ms, 4), "Gelem/s": round(numel / ms / 1e6, 1),
                     "note": {"off": "dense: every element loaded, 14 B/elem (round-1 record)",
-                             "forward": "apply forward skips pruned channels; bit-identical for finite inputs (library default)",
+                             "forward": "apply forward skips pruned channels whose values are all finite this step; bit-identical for every input (library default)",
                              "all": "backward elided as well: +0.0 where the reference has -0.0 (opt-in)",
                              "frozen_mask": "default mode after stop_mask_refresh (the layerwise recipe's steady state): mask fixed, "
                                             "scale live -- statistics are the per-channel abs-max alone"}[m]}

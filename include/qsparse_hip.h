@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 18
+#define QS_ABI_VERSION 19
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -81,7 +81,10 @@ size_t qs_workspace_bytes(int op, int64_t n);
  * (qsparse/convert.py:214-218) folded into the same pass.
  * elide_masked != 0 (with chan_mask): the x of a pruned channel is not loaded at all -- it only ever meets `* 0`
  * (sparse.py:116) -- and the quantizer is applied to +0.0 instead: bit-identical to the loading path for every finite
- * x; a NaN / Inf on a pruned channel yields f32(0)*s instead of the reference's f32(INT_MIN)*s.
+ * x; a NaN / Inf on a pruned channel yields f32(0)*s instead of the reference's f32(INT_MIN)*s.  chan_mask bytes are then
+ * read as an ELISION MASK: 1 kept, 0 pruned and skipped, 2 pruned but LOADED (a zero factor like 0, so NaN / Inf come out as in
+ * the reference) -- qs_pq_select's elide_mask_out marks 2 the pruned channels whose abs-max of this step is not finite, which
+ * makes the eliding call bit-identical to the loading one for every x.
  * gate_out (nullable; needs pre_relu != 0; ceil(numel / 8) bytes): the folded ReLU's gate for the backward, one BIT per
  * element in memory order -- bit (e & 7) of gate_out[e >> 3] = !(x[e] <= 0), ATen's threshold_backward -- so that
  * qs_quant_ste_relu_bwd reads one bit instead of x per element and x need not be kept.  Every element is loaded then;
@@ -312,14 +315,19 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  * gathered (nullable, device float[world][2*C]): the all-gathered qs_stats_pack records of a data-parallel run.  When
  * given, channel c's importance is (sum over ranks, in rank order, of gathered[r][c]) / world and its abs-max the
  * maximum over ranks of gathered[r][C + c] -- what qs_stats_combine computes -- read INSTEAD of stage_mean and
- * chan_absmax (which, when non-NULL, is still zeroed). */
+ * chan_absmax (which, when non-NULL, is still zeroed).
+ * elide_mask_out (nullable, with update_scale): [C] bytes for a forward that skips the loads of pruned channels -- 1 for a kept
+ * channel, 0 for a pruned channel whose abs-max this step is finite (x * 0 is a zero whatever x is: its loads may be skipped), 2
+ * for a pruned channel that holds a NaN / Inf (x * 0 is NaN there and rounds to INT_MIN, quantize.py:109 on CPU: it must be
+ * loaded).  Passed as the forward's chan_mask together with elide_masked, elision is bit-identical to the loading path for EVERY
+ * input. */
 int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  int update_magnitude, int64_t t_mag,
                  int refresh_mask, int64_t k, uint8_t* mask,
                  float* chan_absmax, int64_t chan_absmax_stride, int update_scale, int64_t t_q, int bits, float* scale,
                  int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
-                 qs_stream_t stream);
+                 uint8_t* elide_mask_out, qs_stream_t stream);
 
 /* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
 
@@ -372,6 +380,9 @@ typedef struct qs_site_plan {
     int32_t saturate;            /* != 0: codes are clamped to [code_lo, code_hi] (qs_quant_scaler_fwd's opt-in saturation) */
     int32_t code_lo, code_hi;
     int32_t act;                 /* the activation QS_SITE_PRE_RELU folds: 0 / 1 nn.ReLU, else a qs_activation() handle */
+    uint8_t* elide_mask;         /* nullable: [C] scratch, qs_pq_select's elide_mask_out: the chan_mask of an eliding forward on the
+                                    steps that have statistics (QS_SITE_LIVE), exact for every x; without it, and on steps without
+                                    statistics, QS_SITE_ELIDE elides through the mask itself (exact for finite x only) */
     float* absmax_dense;         /* nullable: [C] scratch accumulator of QS_SITE_SCALE_ONLY steps (zero on entry, re-zeroed by the select) */
     void* reduce_ws;             /* nullable: qs_absmax's `ws` for this geometry (QS_SITE_SCALE_ONLY steps) */
     int64_t reduce_ws_bytes;
@@ -381,7 +392,7 @@ typedef struct qs_site_plan {
 #define QS_SITE_LIVE 1        /* training step with live statistics: magnitude and scale are updated (else: apply only) */
 #define QS_SITE_REFRESH 2     /* rebuild the mask from the running magnitude, threshold rank k */
 #define QS_SITE_PRE_RELU 4    /* x is the input of a folded activation (plan->act; nn.ReLU by default) */
-#define QS_SITE_ELIDE 8       /* elide_masked of qs_quant_scaler_fwd */
+#define QS_SITE_ELIDE 8       /* elide_masked of qs_quant_scaler_fwd (through plan->elide_mask on QS_SITE_LIVE steps) */
 #define QS_SITE_NO_MASK 16    /* apply without the channel mask (pruning not started) -- only without QS_SITE_LIVE */
 #define QS_SITE_STATS_DONE 32 /* with QS_SITE_LIVE: the statistics launches were already enqueued by qs_site_stats (a data-parallel
                                  step: the caller exchanged the record in between); qs_site_fwd starts at the select */

@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 18          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 19          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -55,7 +55,7 @@ SIGNATURES = {
     "qs_kth_value": (c_int, [_P, _L, _L, _P, _P, c_size_t, _P]),
     "qs_mask_ge": (c_int, [_P, _P, _P, _L, _P]),
     "qs_mask_apply": (c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
-    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
@@ -86,7 +86,7 @@ class SitePlanStruct(ctypes.Structure):
                 ("prune_n_updates", c_void_p), ("quant_n_updates", c_void_p), ("callback_t", c_void_p),
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
                 ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32),
-                ("absmax_dense", c_void_p), ("reduce_ws", c_void_p), ("reduce_ws_bytes", c_int64)]
+                ("elide_mask", c_void_p), ("absmax_dense", c_void_p), ("reduce_ws", c_void_p), ("reduce_ws_bytes", c_int64)]
 
 
 class MultiRow(ctypes.Structure):
@@ -110,20 +110,26 @@ QSTEP_APPLY, QSTEP_ALL, QSTEP_ABSMAX, QSTEP_FINISH = 0, 1, 2, 3
 _lib = None
 
 # Mask-aware traffic elision (set through set_qsparse_options(elide_pruned=...), see qs_elementwise.h):
-#   "forward" (default)  quantizer forward kernels that carry a channel mask skip the loads of pruned channels WHERE THAT
-#                        SAVES TRAFFIC -- an NCHW activation (a pruned channel is a whole row) in a forward that records no
-#                        ReLU gate -- bit-identical for finite inputs.  A channels_last forward (a pruned channel is a
-#                        2-byte column: nothing to skip) and a gate-recording forward (it loads every element anyway) run
-#                        the loading arithmetic, i.e. the reference's own on non-finite inputs as well
-#   "all"                every kernel that carries a channel mask, the backward and mask-apply kernels included: +0.0 where
-#                        the reference has -0.0, f32(0)*s where it has f32(INT_MIN)*s for a NaN / Inf on a pruned channel (opt-in)
-#   "off"                every element is loaded (NaN / Inf on pruned channels behave as in the reference, quirk B15)
+#   "forward" (default)  the quantizer forward of a prune -> quantize site skips the loads of pruned channels where that saves
+#                        traffic AND is exact for every input: an NCHW activation (a pruned channel is a whole row), a forward
+#                        that records no ReLU gate, on a step whose statistics pass has seen the input -- the select then
+#                        writes an ELISION MASK (1 kept, 0 pruned and finite, 2 pruned with a NaN / Inf in the channel) and
+#                        only the channels marked 0 are skipped: x * 0 is a zero there whatever x is, and a NaN / Inf on a
+#                        pruned channel still comes out as the reference's f32(INT_MIN) * s (quirk B15).  Everything else --
+#                        steps without statistics (evaluation, idle steps), channels_last (a pruned channel is a 2-byte
+#                        column: nothing to skip), gate-recording forwards (they load every element anyway), backwards, mask
+#                        applies -- runs the loading arithmetic
+#   "all"                every kernel that carries a channel mask, the backward and mask-apply kernels and the forwards of
+#                        steps without statistics included: +0.0 where the reference has -0.0, f32(0)*s where it has
+#                        f32(INT_MIN)*s for a NaN / Inf on a pruned channel (opt-in)
+#   "off"                every element is loaded
 elide_mode = "forward"
 
 
-def _elide_fwd(channels_last: bool = False, records_gate: bool = False) -> int:
+def _elide_fwd(channels_last: bool = False, records_gate: bool = False, exact: bool = False) -> int:
+    """`exact`: the kernel is handed the select's elision mask of THIS step instead of the mask"""
     if elide_mode == "forward":
-        return int(not (channels_last or records_gate))
+        return int(exact and not (channels_last or records_gate))
     return int(elide_mode == "all")
 
 
@@ -475,8 +481,10 @@ class ReluGate:
 def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: torch.dtype,
               chan_mask: Optional[torch.Tensor] = None, mask_channel_index: Optional[int] = None,
               want_codes: bool = False, out_dtype: torch.dtype = torch.float32, saturate=None, pre_relu: bool = False,
-              want_gate: bool = False, xback: Optional[dict] = None):
+              want_gate: bool = False, xback: Optional[dict] = None, elision_mask: bool = False):
     """kind in {'scaler','decimal'}; returns (y, codes|None).  pre_relu: quantise max(x, 0) (folded nn.ReLU).
+    elision_mask: `chan_mask` is the uint8 elision mask `pq_select(..., elide_mask=)` wrote from THIS x's statistics (1 kept,
+    0 pruned and finite, 2 pruned with a NaN / Inf) -- skipping the loads of its 0 channels is exact (see `elide_mode`).
     want_gate (with pre_relu): returns (y, codes|None, ReluGate) -- the ReLU's gate as one bit per element, recorded by
     the same pass, for `ste_relu_bwd(gate=...)`.
     xback (with want_gate): the cell of an owned in-place ReLU (fused.py::_with_owned_relu) -- when this launch is one that can
@@ -505,7 +513,7 @@ def quant_fwd(kind: str, x: torch.Tensor, param, channel_index: int, qdtype: tor
         xb = x                 # relu(x) lands in x's own storage (x IS the in-place ReLU's tensor, addressed in memory order)
     with _timed(f"quant_{kind}_fwd" + ("+mask" if cm is not None else ""), x, y, codes, gate.bits if gate is not None else None, xb):
         st = fn(_ptr(x), _ptr(y), _ptr(codes), _ptr(pt), n, host, _ptr(cm), outer, C, inner, dt(x), _DT[out_dtype],
-                _DT[qdtype], sat, lo, hi, _act(pre_relu), _elide_fwd(x is not like, gate is not None) if cm is not None else 0,
+                _DT[qdtype], sat, lo, hi, _act(pre_relu), _elide_fwd(x is not like, gate is not None, elision_mask) if cm is not None else 0,
                 _ptr(gate.bits) if gate is not None else None, None, 0, _ptr(xb), _stream(x))
     _check(st, f"qs_quant_{kind}_fwd")
     if xb is not None:
@@ -907,13 +915,14 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
               bump_b: Optional[torch.Tensor] = None, bump_c: Optional[torch.Tensor] = None,
               bump_d: Optional[torch.Tensor] = None, t_mag_dev: Optional[torch.Tensor] = None,
               t_q_dev: Optional[torch.Tensor] = None, stat_dtype: torch.dtype = torch.float32,
-              gathered: Optional[torch.Tensor] = None, world: int = 1):
+              gathered: Optional[torch.Tensor] = None, world: int = 1, elide_mask: Optional[torch.Tensor] = None):
     """bump_a / bump_b: int32 one-element counters; bump_c / bump_d: int64 one-element counters; t_*_dev: device
     int64 counters read instead of the by-value t_mag / t_q (each optional).  `gathered`: the all-gathered
     [world, 2C] float32 records of `stats_pack`, combined in rank order by the kernel itself."""
     C = magnitude.numel()
     sdt = dt(stage_mean) if stage_mean is not None else F32
     assert gathered is None or (gathered.dtype == torch.float32 and gathered.numel() == world * 2 * C)
+    assert elide_mask is None or (elide_mask.dtype == torch.uint8 and elide_mask.numel() == C and elide_mask.is_contiguous())
     for b32 in (bump_a, bump_b):
         assert b32 is None or b32.dtype == torch.int32
     for b64 in (bump_c, bump_d, t_mag_dev, t_q_dev):
@@ -924,7 +933,7 @@ def pq_select(magnitude: torch.Tensor, stage_mean: Optional[torch.Tensor], updat
                                  int(update_scale), int(t_q),
                                  int(bits), _ptr(scale), _ptr(bump_a), _ptr(bump_b), _ptr(bump_c), _ptr(bump_d),
                                  _ptr(t_mag_dev), _ptr(t_q_dev), _DT.get(stat_dtype, F32), _ptr(gathered), int(world),
-                                 _stream(magnitude))
+                                 _ptr(elide_mask), _stream(magnitude))
     _check(st, "qs_pq_select")
 
 

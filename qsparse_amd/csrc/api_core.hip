@@ -140,12 +140,13 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C, i
                  int64_t t_q, int bits,
                  float* scale, int32_t* bump_i32_a, int32_t* bump_i32_b, int64_t* bump_i64_a, int64_t* bump_i64_b,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
-                 qs_stream_t stream) {
+                 uint8_t* elide_mask_out, qs_stream_t stream) {
     PqArgs a;
     int st = pq_args(&a, magnitude, C, update_magnitude, t_mag, refresh_mask, k, mask, chan_absmax, chan_absmax_stride, update_scale, t_q, bits,
                      scale, bump_i32_a, bump_i32_b, bump_i64_a, bump_i64_b, t_mag_dev, t_q_dev, gathered, world);
     if (st == QS_OK && update_scale && !dt_ok(stat_dt)) st = QS_ERR_DTYPE;
     a.stat_dt = stat_dt;
+    a.elide_mask = update_scale ? elide_mask_out : nullptr;
     if (st) return st;
     if (update_magnitude && !stage_mean && !gathered) return QS_ERR_ARG;
     if (gathered) sdt = QS_F32;      // the records are float32; `stage_mean` is not read
@@ -253,7 +254,7 @@ static int site_prune_only_fwd(const qs_site_plan* p, const void* x, void* y, ui
     if (update || refresh) {
         int st = qs_pq_select(p->magnitude, update ? p->stage_mean : nullptr, p->xdt, p->C, update, t_mag, refresh, k, p->mask, nullptr, 1,
                               0, 0, 8, nullptr, p->prune_n_updates, nullptr, p->callback_t, nullptr,
-                              (update && p->callback_t_from_device) ? p->callback_t : nullptr, nullptr, p->xdt, nullptr, 1, stream);
+                              (update && p->callback_t_from_device) ? p->callback_t : nullptr, nullptr, p->xdt, nullptr, 1, nullptr, stream);
         if (st) return st;
     }
     return site_mask_apply(p, x, y, p->xdt, pre_relu, (flags & QS_SITE_ELIDE) ? 1 : 0, gate_out, stream);
@@ -285,7 +286,7 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
             if (st) return st;
             st = qs_pq_select(p->magnitude, nullptr, p->xdt, p->C, 0, t_mag, 0, 0, p->mask, p->absmax_dense, 1, 1, t_q, p->bits,
                               p->scale, p->prune_n_updates, p->quant_n_updates, p->callback_t, p->quantizer_t_dev, nullptr,
-                              p->quantizer_t_dev, p->xdt, nullptr, 1, stream);
+                              p->quantizer_t_dev, p->xdt, nullptr, 1, p->elide_mask, stream);
             if (st) return st;
         } else {
         if (!p->magnitude || !p->chan_absmax || !p->stage_mean || p->absmax_stride < 1) return QS_ERR_ARG;
@@ -298,7 +299,7 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
         st = qs_pq_select(p->magnitude, p->stage_mean, p->xdt, p->C, 1, t_mag, (flags & QS_SITE_REFRESH) ? 1 : 0, k, p->mask,
                           p->chan_absmax, p->absmax_stride, 1, t_q, p->bits, p->scale, p->prune_n_updates, p->quant_n_updates,
                           p->callback_t, p->quantizer_t_dev, p->callback_t_from_device ? p->callback_t : nullptr,
-                          p->quantizer_t_dev, p->xdt, gathered, gathered ? world : 1, stream);
+                          p->quantizer_t_dev, p->xdt, gathered, gathered ? world : 1, p->elide_mask, stream);
         if (st) return st;
         }
     }
@@ -306,6 +307,9 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
+    // a step with statistics elides through the select's elision mask: pruned channels that hold a NaN / Inf are loaded, so the
+    // result is the loading path's for every input; an eliding step without statistics (the caller's choice) has only the mask
+    if (elide && (flags & QS_SITE_LIVE) && p->elide_mask) cm = p->elide_mask;
     if (decimal) {             // DecimalQuantizer: the power-of-two step of THIS call's scale (quantize.py:316)
         int st = qs_decimal_from_scale(p->scale, decimal, 1, stream);
         if (st) return st;

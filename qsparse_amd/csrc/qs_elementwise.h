@@ -65,6 +65,15 @@ __device__ __forceinline__ float guarded_reciprocal(float s) {
     return r;
 }
 
+// The channel mask byte a quantizer forward sees is the PruneLayer's mask (0 / 1) -- or, where the forward may skip the loads of
+// pruned channels, the ELISION MASK the select wrote next to it: 1 kept, 0 pruned and finite (its loads may be skipped: the
+// product x * 0 is a zero whatever x is), 2 pruned but this step's statistics saw a NaN / Inf in the channel (x * 0 is NaN there,
+// reference quirk B15: it must be loaded).  `keep` carries all three: 1.0, +0.0 (skippable) and -0.0 (a zero factor like any other
+// -- the product's zero may take the other sign, the code it rounds to is 0 either way -- but not skippable).
+__device__ __forceinline__ float keep_from_byte(uint32_t m) { return m == 1u ? 1.0f : (m ? -0.0f : 0.0f); }
+template <typename P>
+__device__ __forceinline__ bool needs_load(const P& p) { return __float_as_uint(p.keep) != 0u; }
+
 // ScalerQuantization.forward  (reference qsparse/quantize.py:100-117)
 template <int QDT>
 struct ScalerFwdOp {
@@ -90,12 +99,12 @@ struct ScalerFwdOp {
     }
     __device__ __forceinline__ P channel_masked(uint32_t c_scale, uint32_t c_mask) const {
         P p = channel(c_scale);
-        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        if (cmask) p.keep = keep_from_byte(cmask[c_mask]);
         return p;
     }
     __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
-        p.keep = m ? 1.0f : 0.0f;
+        p.keep = keep_from_byte(m);
         return p;
     }
     // rint(RN(v / s)) without dividing in the common case.  t = RN(v * RN(1/s)) differs from RN(v/s) by at
@@ -149,12 +158,12 @@ struct DecimalFwdOp {
     }
     __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
         P p = channel(c_par);
-        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        if (cmask) p.keep = keep_from_byte(cmask[c_mask]);
         return p;
     }
     __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
-        p.keep = m ? 1.0f : 0.0f;
+        p.keep = keep_from_byte(m);
         return p;
     }
     __device__ __forceinline__ float apply(float v, const P& p, int32_t& code) const {
@@ -227,23 +236,29 @@ struct SteBwdOp {
     struct P {
         float lo, hi, keep;
     };
+    // A NaN bound (a scale that a NaN / Inf input has turned into NaN) makes ATen's tensor-bound clamp return NaN for EVERY g,
+    // and NaN * mask stays NaN: the factor `keep` carries it, so the per-element arithmetic is the same two instructions
+    __device__ __forceinline__ static float factor(const P& p, uint32_t m) {
+        const float f = m ? 1.0f : 0.0f;
+        return (p.lo != p.lo) ? p.lo : ((p.hi != p.hi) ? p.hi : f);
+    }
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         float s = step ? step[c] : step_host;
         if (step_is_decimal) s = DecimalFwdOp<QS_F32>::pow2(-s);
-        p.lo = lo_mul * s;
-        p.hi = hi_mul * s;
-        p.keep = 1.0f;
+        p.lo = passthrough ? -__builtin_inff() : lo_mul * s;
+        p.hi = passthrough ? __builtin_inff() : hi_mul * s;
+        p.keep = factor(p, 1u);
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
         P p = channel(c_par);
-        if (cmask) p.keep = cmask[c_mask] ? 1.0f : 0.0f;
+        if (cmask) p.keep = factor(p, cmask[c_mask]);
         return p;
     }
     __host__ __device__ __forceinline__ const uint8_t* mask_ptr() const { return cmask; }
     __device__ __forceinline__ static P keep_of(P p, uint32_t m) {
-        p.keep = m ? 1.0f : 0.0f;
+        p.keep = factor(p, m);
         return p;
     }
     __device__ __forceinline__ float apply(float g, const P& p, int32_t& code) const {
@@ -304,7 +319,7 @@ struct GateOp : Base {
                         // nn.ReLU(inplace=True) whose result other holders of x must see: the ReLU's forward pass costs one more
                         // store in this kernel instead of a read + write pass of its own (widening kernels only)
     __device__ __forceinline__ float apply(float v, const typename Base::P& p, int32_t& code) const {
-        if (zero_pruned && p.keep == 0.0f) v = 0.0f;
+        if (zero_pruned && !needs_load(p)) v = 0.0f;
         return Base::apply(v, p, code);
     }
 };
@@ -412,7 +427,7 @@ __device__ __forceinline__ uint32_t last_dim_channel(int64_t e, uint32_t C) {
 // and for ops without a mask (their P has no `keep`)
 template <bool ELIDE, typename P>
 __device__ __forceinline__ bool lane_pruned(const P& p) {
-    if constexpr (ELIDE) return p.keep == 0.0f;
+    if constexpr (ELIDE) return !needs_load(p);
     else return false;
 }
 
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(Op op, EwGeom geo, const voi
                     const typename Op::P p1 = op.channel_masked(PARAM_PER_CHANNEL ? c1 : 0u, c1);      // unconditional: no divergent branch
                     if constexpr (ELIDE) {
                         raw[u] = zero_raw8<XDT>();
-                        if (p0.keep != 0.0f || (left < 8u && p1.keep != 0.0f)) raw[u] = load8_raw<XDT, NT>(x, g);
+                        if (needs_load(p0) || (left < 8u && needs_load(p1))) raw[u] = load8_raw<XDT, NT>(x, g);
                         unpack8<XDT>(raw[u], v);
                     }
 #pragma unroll
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                         p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
                     }
                     Raw8<XDT> r = zero_raw8<XDT>();
-                    if (p.keep != 0.0f) r = load8_raw<XDT, NT>(x, e / 8);
+                    if (needs_load(p)) r = load8_raw<XDT, NT>(x, e / 8);
                     unpack8<XDT>(r, v);
                 } else if constexpr (CM == CM_ROW) {
                     if (geo.groups_per_row >= 64u) {        // the dense kernel takes the wave-uniform look-up as well
@@ -745,7 +760,7 @@ __global__ __launch_bounds__(kWidenBlock) void ew_widen_kernel(Op op, EwGeom geo
                 if constexpr (CM == CM_ROW) {
                     const uint32_t c = (uint32_t)((uint64_t)e / geo.inner) % geo.C;
                     p = op.channel_masked(PARAM_PER_CHANNEL ? c : 0u, c);
-                    need = p.keep != 0.0f;
+                    need = needs_load(p);
                 } else {
                     const uint8_t* mp = op.mask_ptr();
                     if (mp) mm = *(const uint32_t*)(mp + last_dim_channel(e, geo.C));

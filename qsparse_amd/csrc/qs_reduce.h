@@ -1465,6 +1465,8 @@ struct PqArgs {
     uint8_t* mask;
     uint32_t* chan_absmax;
     int64_t amax_stride;        // elements between consecutive channels of chan_absmax
+    uint8_t* elide_mask;        // nullable, with update_scale: [C] bytes for the forward's load elision -- 1 kept, 0 pruned and every
+                                // value of the channel finite this step, 2 pruned with a NaN / Inf (see keep_from_byte)
     int update_scale;
     float t_q, t_q1, denom;
     float* scale;
@@ -1501,6 +1503,14 @@ __device__ __forceinline__ uint32_t pq_amax_key(const PqArgs& a, int64_t i) {
     return mx;
 }
 
+// what a channel contributes to max|x * mask| (quantize.py:340 on the product of sparse.py:263), given its abs-max key of |x|:
+// a kept channel its own maximum; a pruned one 0 -- unless it holds a NaN / Inf, whose product with the mask's 0 is a NaN that
+// the reference's x.abs().max() propagates into the scale (an Inf gives the default NaN, a NaN keeps its payload)
+__device__ __forceinline__ uint32_t pq_scale_key(uint32_t am, bool kept) {
+    if (kept) return am;
+    return am > 0x7f800000u ? am : (am == 0x7f800000u ? 0x7fc00000u : 0u);
+}
+
 __device__ __forceinline__ PqArgs pq_live_counters(PqArgs a) {
     if (a.t_mag_dev) {
         a.t_mag = (float)*a.t_mag_dev;
@@ -1534,7 +1544,10 @@ __device__ __forceinline__ void pq_select_body(const PqArgs& a, const void* stag
         uint32_t m = 0u;
         for (int64_t i = tid; i < a.C; i += nthreads) {
             const uint32_t am = pq_amax_key(a, i);
-            if (a.mask[i]) m = am > m ? am : m;
+            const bool kept = a.mask[i] != 0;
+            const uint32_t sk = pq_scale_key(am, kept);
+            m = sk > m ? sk : m;
+            if (a.elide_mask) a.elide_mask[i] = kept ? 1 : (am >= 0x7f800000u ? 2 : 0);
             if (a.chan_absmax) a.chan_absmax[i * a.amax_stride] = 0u;   // leave the accumulator clean for the next statistics pass
         }
         m = wave_max_u32(m);
@@ -1594,7 +1607,9 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
             if (a.update_magnitude) a.magnitude[i] = mag[it];
             if (a.refresh_mask) a.mask[i] = keep[it];
             if (a.update_scale) {
-                if (keep[it]) m = amax[it] > m ? amax[it] : m;
+                const uint32_t sk = pq_scale_key(amax[it], keep[it] != 0);
+                m = sk > m ? sk : m;
+                if (a.elide_mask) a.elide_mask[i] = keep[it] ? 1 : (amax[it] >= 0x7f800000u ? 2 : 0);
                 if (a.chan_absmax) a.chan_absmax[i * a.amax_stride] = 0u;
             }
         }

@@ -209,7 +209,8 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     so, si = (N * H * W, 1) if (cl or flat) else (N, H * W)
     ws_bytes = _hip.reduce_workspace_bytes(1, so, C, si)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device) if ws_bytes else None
-    plan.keep = (acc, stage, part, stage_mean, t_q_dev, dense, ws) + state
+    elide = torch.empty(C, dtype=torch.uint8, device=h.device)     # the select's elision mask (see _hip.elide_mode)
+    plan.keep = (acc, stage, part, stage_mean, t_q_dev, dense, ws, elide) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
     c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
@@ -221,6 +222,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     c.callback_t_from_device = int(graph_safe)
     c.saturate, c.code_lo, c.code_hi = (0, 0, 0) if sat is None else (1, sat[0], sat[1])
     c.act = int(act) or 1                # the activation QS_SITE_PRE_RELU folds at this site (1: nn.ReLU)
+    c.elide_mask = elide.data_ptr()
     c.absmax_dense, c.reduce_ws, c.reduce_ws_bytes = dense.data_ptr(), (ws.data_ptr() if ws is not None else None), ws_bytes
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
     outer, inner = (N * H * W, 1) if cl else (N, H * W)
@@ -325,8 +327,8 @@ class _SiteStep(torch.autograd.Function):
         if want_gate:
             _hip.note_gate(bits_t)
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
-        if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None):
-            flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic (see _hip.elide_mode)
+        if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None, bool(flags & _hip.SITE_LIVE)):
+            flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic and is exact (see _hip.elide_mode)
         # a DecimalQuantizer's power-of-two step of THIS call (the backward clamps with it; two forwards may precede a backward)
         dec = torch.empty(1, dtype=torch.float32, device=h.device) if plan.decimal else None
         _hip.site_fwd(plan.ref, h, y, bits_t, flags, t_mag, k, t_q, image=img, gathered=gathered, world=world, xback=xback,

@@ -265,7 +265,7 @@ ENGAGED = [0]      # cases in which the multi-tensor weight path actually took t
 
 
 def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False,
-        site=False):
+        site=False, nonfinite=None):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -308,6 +308,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         if site and x.numel() >= 8:             # the boundary values of the activations' gates
             x.view(-1)[2:8] = torch.tensor([6.0, -0.75, 1.5, 7.5, -3.0, 1e-30]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (see tests/fuzz/fuzz_parity.py)
+        if nonfinite is not None and s >= nonfinite[1]:     # a NaN / Inf somewhere -- on a kept or a pruned channel, whichever
+            x.view(-1)[(seed * 7919 + s * 31) % x.numel()] = nonfinite[0]
         if channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         xd = x.to(device).requires_grad_(True)
@@ -347,7 +349,13 @@ def one_case(rng, idx, dry=False):
         channels_last = channels_last and len(shape) == 4 and (not reduced or reduced[0] != 3)
     batcher = rng.random() < 0.6
     twin = rng.random() < 0.25
-    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin)
+    nonfinite = None
+    if desc["what"] == "site" and rng.random() < 0.3:
+        # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
+        # act_open -- so the clamping activations get infinities only)
+        values = [float("inf"), float("-inf")] + ([] if desc["act"] in ("relu6", "hardtanh") else [float("nan")] * 2)
+        nonfinite = (rng.choice(values), rng.choice([steps - 3, steps - 2, steps - 1]))
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite)
     if dry:
         return None
     if VERBOSE:
@@ -356,7 +364,7 @@ def one_case(rng, idx, dry=False):
     for device in ("cpu", "cuda"):
         try:
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher, twin, desc['what'] == 'site')
+                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
     a, b = results["cpu"], results["cuda"]

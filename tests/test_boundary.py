@@ -44,7 +44,7 @@ def test_argument_validation_without_a_gpu():
     assert lib.qs_quant_scaler_fwd(16, 32, None, None, 1, 0.1, None, 1, 1, 8, 5, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None) == -1
     assert lib.qs_quant_scaler_fwd(20, 32, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None) == -3
     assert lib.qs_kth_value(16, 10, 10, 32, None, 0, None) == -2          # k out of range
-    assert lib.qs_pq_select(16, None, 0, 70000, 0, 0, 0, 0, 32, None, 1, 0, 0, 4, None, None, None, None, None, None, None, 0, None, 1, None) == -2
+    assert lib.qs_pq_select(16, None, 0, 70000, 0, 0, 0, 0, 32, None, 1, 0, 0, 4, None, None, None, None, None, None, None, 0, None, 1, None, None) == -2
 
 
 def test_product_never_imports_the_oracle_or_the_reference():

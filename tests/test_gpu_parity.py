@@ -531,7 +531,7 @@ def test_abi_calls_are_graph_capturable():
         assert lib.qs_mean_dim(x.data_ptr(), stage1.data_ptr(), 1, N, C * H * W, 1, 1, 1, None, amax.data_ptr(), 1, H * W, C, stream) == 0
         assert lib.qs_mean_last2(stage1.data_ptr(), imp.data_ptr(), C, H, W, 1, 1, None, None, 1, None, stream) == 0
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 0, 1, 16, mask.data_ptr(), amax.data_ptr(), 1, 1, 0, 4,
-                                scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, stream) == 0
+                                scale.data_ptr(), None, None, None, None, None, None, 1, None, 1, None, stream) == 0
         assert lib.qs_quant_scaler_fwd(x.data_ptr(), y.data_ptr(), None, scale.data_ptr(), 1, 0.0, mask.data_ptr(), N, C, H * W,
                                        1, 0, 0, 0, 0, 0, 0, 1, None, None, 0, None, stream) == 0
         assert lib.qs_quant_ste_bwd(g.data_ptr(), gx.data_ptr(), scale.data_ptr(), 1, 0.0, 0, -8.0, 7.0, 0, mask.data_ptr(),
@@ -1282,10 +1282,9 @@ def test_folded_relu_propagates_nan_like_the_module_by_module_path():
                                   qs.quantize(bits=4, channelwise=-1, timeout=1)),
             lambda: nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)))):
         runs = []
-        # (fold, elide_pruned): the folded site records the ReLU gate, loads every element and follows the reference on a NaN of
-        # a PRUNED channel in the default mode too; the unfolded NCHW pair elides by default (a pruned NaN gives f32(0) * s,
-        # the documented deviation), so its reference run is the strict mode
-        for fold, mode in ((True, "forward"), (False, "off"), (True, "off")):
+        # (fold, elide_pruned): the default mode is exact -- the folded site records the ReLU gate and loads every element, the
+        # unfolded NCHW pair elides through the select's elision mask, which has a pruned NaN channel loaded -- so all four agree
+        for fold, mode in ((True, "forward"), (False, "off"), (True, "off"), (False, "forward")):
             qs.set_qsparse_options(fold_relu=fold, elide_pruned=mode)
             site = fuse_prune_quantize_pairs(make().to(DEV).train())
             outs = []
@@ -1300,8 +1299,8 @@ def test_folded_relu_propagates_nan_like_the_module_by_module_path():
                 outs.append((y.detach().cpu(), xg.grad.cpu()))
             runs.append(outs)
         qs.set_qsparse_options(fold_relu=True, elide_pruned="forward")
-        for s, ((ya, ga), (yb, gb), (yc, gc)) in enumerate(zip(*runs)):
-            assert same(ya, yb) and same(ga, gb) and same(ya, yc) and same(ga, gc), s
+        for s, ((ya, ga), (yb, gb), (yc, gc), (yd, gd)) in enumerate(zip(*runs)):
+            assert same(ya, yb) and same(ga, gb) and same(ya, yc) and same(ga, gc) and same(ya, yd) and same(ga, gd), s
         if si != 1:     # (in the pair a NaN channel has NaN magnitude, is pruned, and never reaches the scale)
             assert bool(runs[0][2][0].isnan().any())      # the NaN is visible in the step that received it
 

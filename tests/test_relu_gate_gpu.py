@@ -82,7 +82,7 @@ def test_recording_forward_and_bitmap(dtype, kind):
                     mask = (torch.rand(C, generator=gen(si + 7)) < 0.5).to(DEV) if masked else None
                     param = torch.tensor([0.37], device=DEV) if kind == "scaler" else torch.tensor([2.0], device=DEV)
                     tag = (shape, layout, masked, str(out_dtype))
-                    for mode in ("off", "forward"):     # NaN / Inf on a pruned channel: INT_MIN * s when loaded, Q(+0) when elided --
+                    for mode in ("off", "forward", "all"):  # NaN / Inf on a pruned channel: INT_MIN * s when loaded, Q(+0) when elided --
                         qs.set_qsparse_options(elide_pruned=mode)       # the recording forward follows the mode it is called in
                         y0, _ = _hip.quant_fwd(kind, x, param, -1, torch.float32, chan_mask=mask, mask_channel_index=1,
                                                out_dtype=out_dtype, pre_relu=True)
@@ -90,7 +90,7 @@ def test_recording_forward_and_bitmap(dtype, kind):
                                                      out_dtype=out_dtype, pre_relu=True, want_gate=True)
                         assert y1.dtype == y0.dtype and y1.stride() == y0.stride(), (tag, mode)
                         a, b = y0.cpu(), y1.cpu()
-                        if mode == "forward" and masked:
+                        if mode == "all" and masked:
                             # an eliding kernel skips a pruned NaN / Inf or not depending on the lane geometry (documented:
                             # bit-identical for finite x); the recording kernel always counts it as +0.0
                             ok = (mask.view([1, -1] + [1] * (x.dim() - 2)) | torch.isfinite(x)).cpu()

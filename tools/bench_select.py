@@ -30,7 +30,7 @@ def one():
 
         def select():
             assert lib.qs_pq_select(mag.data_ptr(), stage.data_ptr(), 1, C, 0, 3, 1, k, mk.data_ptr(), amax.data_ptr(), 1, 1, 3,
-                                    4, sc.data_ptr(), None, None, None, None, None, None, 1, None, 1, None) == 0
+                                    4, sc.data_ptr(), None, None, None, None, None, None, 1, None, 1, None, None) == 0
 
         select()
         torch.cuda.synchronize()

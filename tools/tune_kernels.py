@@ -94,7 +94,7 @@ def run_variant(path):
 
     def select():
         assert lib.qs_pq_select(mag.data_ptr(), imp.data_ptr(), 1, C, 1, 3, 1, 191, mk.data_ptr(), amax.data_ptr(), 1, 1, 3, 4,
-                                sc.data_ptr(), None, None, None, None, None, None, 1, None, 1, None) == 0
+                                sc.data_ptr(), None, None, None, None, None, None, 1, None, 1, None, None) == 0
 
     out = {}
     for name, fn, bpe in (("fwd", fwd, 6), ("bwd", bwd, 6), ("stats", stats, 2), ("read_all", read_all, 2),
