@@ -72,6 +72,15 @@ def _disarm_accumulators(q: QuantizeLayer):
     q.__dict__[_ARMED] = False
 
 
+def _elision_mask(q, C: int, device) -> torch.Tensor:
+    """[C] bytes the select fills for the apply kernel of the same step (fine-grained route; the composite's is in its plan)"""
+    buf = q.__dict__.get("_qs_elision")
+    if buf is None or buf.numel() != C or buf.device != device:
+        buf = torch.empty(C, dtype=torch.uint8, device=device)
+        q.__dict__["_qs_elision"] = buf
+    return buf
+
+
 def _absmax_accumulator_dense(q: QuantizeLayer, C: int, device) -> torch.Tensor:
     """persistent dense [C] accumulator for the abs-max passes that run on their own (no statistics stage to ride on):
     zero on entry because the select re-zeroes it, so the reduction needs no initialisation launch."""
@@ -95,7 +104,8 @@ class _FusedApply(torch.autograd.Function):
     """y = Q(relu?(x) * mask) forward, gx = gate * clamp(g) * mask backward, each one pass over the tensor."""
 
     @staticmethod
-    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False, saturate=None):
+    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False, saturate=None, elision=None):
+        # elision: the elision mask the select wrote from THIS input's statistics (see _hip.elide_mode), or None
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
         ctx.pre_relu = pre_relu
         ctx.has_mask = mask_c is not None
@@ -112,7 +122,8 @@ class _FusedApply(torch.autograd.Function):
         # ScalerQuantizer (quantize.py:108 -- a later statistics update is seen by an earlier forward's backward), the
         # decimal computed at THIS forward for a DecimalQuantizer (a fresh tensor, quantize.py:312-325 -> :41)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
-        res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c, mask_channel_index=1, out_dtype=out_dtype,
+        res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c if elision is None else elision,
+                             mask_channel_index=1, out_dtype=out_dtype, elision_mask=elision is not None,
                              pre_relu=pre_relu, want_gate=want_gate, saturate=saturate,
                              xback=_hip.owned_relu_cell() if (want_gate and h.data_ptr() % 16 == 0) else None)
         # the bitmap travels through save_for_backward like any saved activation (released with the graph, visible to
@@ -130,17 +141,17 @@ class _FusedApply(torch.autograd.Function):
         mask_c, step, x = ctx.saved_tensors
         mask_c = mask_c if ctx.has_mask else None
         if not ctx.quant_on:
-            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 8
+            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 9
         limit = 2.0 ** (ctx.bits - 1)
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
                                    limit - 1 + ctx.notch, mask_c, gate=gate, act=ctx.pre_relu)
-            return (gx,) + (None,) * 8
+            return (gx,) + (None,) * 9
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
                           out_dtype, chan_mask=mask_c, mask_channel_index=1)
-        return (gx,) + (None,) * 8
+        return (gx,) + (None,) * 9
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -439,6 +450,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     q_counts = q.timeout > 0 and q.training
     bump_p = bump_q = bump_t = None
     select_bumped_tq = False
+    elision = None          # the select's elision mask of THIS step, when it wrote one (fine-grained route)
     # one FFI call for the whole site (qs_site_fwd) when this is a live steady-state step -- magnitude, mask policy and
     # scale all updated from this input -- or a pure apply step (evaluation, frozen statistics) of a plain 4-d site
     site = None
@@ -516,10 +528,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 if get_option("graph_safe"):   # running-mean counters come from device memory (hipGraph replay)
                     t_mag_dev = on_dev(cb.t) if update_mag else None
                     t_q_dev = qc.device_t(h.device) if update_scale else None
+                if update_scale and h.dim() == 4 and h.is_contiguous() and _hip.elide_mode != "off":
+                    elision = _elision_mask(q, C, h.device)      # (an NCHW forward may skip rows: see _hip.elide_mode)
                 _hip.pq_select(mag, stage, update_mag, t_mag, refresh, k, p.mask.data.view(-1), chan_absmax,
                                update_scale, t_q, q.bits, q.weight.data, bump_a=bump_p, bump_b=bump_q, bump_c=bump_t,
                                bump_d=t_q_dev, t_mag_dev=t_mag_dev, t_q_dev=t_q_dev, stat_dtype=h.dtype,
-                               gathered=gathered, world=world if gathered is not None else 1)
+                               gathered=gathered, world=world if gathered is not None else 1, elide_mask=elision)
                 _disarm_accumulators(q)
                 select_bumped_tq = t_q_dev is not None
         if update_scale:
@@ -578,7 +592,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             return dual
         return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
-                             1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits))
+                             1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits),
+                             elision if (prune_on and quant_on) else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
