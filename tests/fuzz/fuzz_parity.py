@@ -57,24 +57,41 @@ def one_case(rng, idx):
     elide = rng.choice(["forward", "forward", "off", "all"])      # mask-aware load elision (qs_elementwise.h)
     gate = rng.random() < 0.75             # the folded ReLU's gate as a bitmap (backward without x)
     inplace = rng.random() < 0.3           # nn.ReLU(inplace=True) in front of the site (torchvision-style networks)
+    # a NaN / Inf / -Inf in the input from some step on, on a kept or pruned channel as it falls (quirk B15 and what follows from
+    # it: a NaN scale, NaN clamp bounds); the opt-in "all" mode is exact for finite inputs only
+    nonfinite = None
+    if elide != "all" and rng.random() < 0.25:
+        nonfinite = (rng.choice([float("nan"), float("inf"), float("-inf")]), rng.choice([steps - 3, steps - 2, steps - 1]))
     if DRY:
         return None
     return run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx,
-                    channels_last, preserve, graph_safe, elide, gate, inplace)
+                    channels_last, preserve, graph_safe, elide, gate, inplace, nonfinite)
+
+
+def same_up_to_nan_payload(a, b):
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if not a.is_floating_point():
+        return same(a, b)
+    it = {2: torch.int16, 4: torch.int32}[a.element_size()]
+    return bool(((a.contiguous().view(it) == b.contiguous().view(it)) | (a.isnan() & b.isnan())).all())
 
 
 def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep, timeout, fold, steps, eval_from, idx=0,
-             channels_last=False, preserve=False, graph_safe=False, elide="forward", gate=True, inplace=False):
+             channels_last=False, preserve=False, graph_safe=False, elide="forward", gate=True, inplace=False, nonfinite=None):
     """one activation site on DEV against the oracle; returns "ok", None (configuration not applicable) or a dict
     describing the first mismatch"""
     global LAST
     desc = LAST = dict(i=idx, shape=shape, dtype=str(dtype)[6:], site=site_kind, kind=kind, bits=bits, sparsity=sparsity, start=start,
                        interval=interval, rep=rep, timeout=timeout, fold=fold, steps=steps, eval_from=eval_from,
-                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide, gate=gate, inplace=inplace)
+                       channels_last=channels_last, preserve=preserve, graph_safe=graph_safe, elide=elide, gate=gate, inplace=inplace,
+                       nonfinite=nonfinite)
     if len(shape) < 2 or shape[1] < 2:
         return None
     if VERBOSE:
         print(desc, flush=True)
+    # bit for bit -- with a non-finite input, up to the payload and sign of NaNs (x86 and the GPU produce different default NaNs)
+    eq = same if nonfinite is None else same_up_to_nan_payload
     k = max(int(sparsity * shape[1] - 1), 0) + 1
     if k >= shape[1]:
         return None
@@ -102,6 +119,8 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
         x = (torch.randn(shape, generator=g) * chan).to(dtype)
         x.view(-1)[:2] = torch.tensor([0.0, -1e-3]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (fp16 underflow): torch's own CPU and GPU ReLU disagree on its sign
+        if nonfinite is not None and s >= nonfinite[1]:
+            x.view(-1)[(idx * 7919 + s * 31) % x.numel()] = nonfinite[0]
         # channels_last statistics are bit-exact whenever the batch dim is reduced first (any channel count, any batch);
         # channels_last_3d (5-d) with a batch of at least two
         cl = channels_last and (len(shape) == 4 or (len(shape) == 5 and shape[0] > 1))
@@ -136,7 +155,7 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
                 return a.dtype == b.dtype and a.shape == b.shape and bool(((a.float() == b.float()) | (a.isnan() & b.isnan())).all())
             ok = same_num(y.detach().cpu(), y_ref) and same_num(xg.grad.cpu(), gr.to(dtype))     # (y: an inactive quantizer leaves x*mask)
         else:
-            ok = same(y.detach().cpu(), y_ref) and same(xg.grad.cpu(), gr.to(dtype))
+            ok = eq(y.detach().cpu(), y_ref) and eq(xg.grad.cpu(), gr.to(dtype))
         if VERBOSE and not same(y.detach().cpu(), y_ref) and y.shape == y_ref.shape:
             bad = (y.detach().cpu().view(-1).view(torch.int16 if y.element_size() == 2 else torch.int32)
                    != y_ref.contiguous().view(-1).view(torch.int16 if y_ref.element_size() == 2 else torch.int32)).nonzero().view(-1)[:6]
@@ -154,14 +173,14 @@ def run_site(shape, dtype, site_kind, kind, bits, sparsity, start, interval, rep
                   if qsim else None, flush=True)
         if ps:
             pl = site[0][1] if has_q else site[1]
-            ok = ok and same(pl.mask.cpu(), ps.mask) and int(pl._n_updates) == ps.n_updates
+            ok = ok and eq(pl.mask.cpu(), ps.mask) and int(pl._n_updates) == ps.n_updates
             if ps.magnitude is not None:
-                ok = ok and same(pl.callback.magnitude.cpu(), ps.magnitude) and int(pl.callback.t) == ps.t
+                ok = ok and eq(pl.callback.magnitude.cpu(), ps.magnitude) and int(pl.callback.t) == ps.t
         if qsim:
             ql = site[1]
-            ok = ok and int(ql._n_updates) == qsim.n_updates and (qsim.weight is None or same(ql.weight.detach().cpu(), qsim.weight))
+            ok = ok and int(ql._n_updates) == qsim.n_updates and (qsim.weight is None or eq(ql.weight.detach().cpu(), qsim.weight))
         if inplace and has_relu:    # x's own storage holds relu(x) afterwards, whichever route the site took
-            ok = ok and same(xin.detach().cpu(), torch.relu(x))
+            ok = ok and eq(xin.detach().cpu(), torch.relu(x))
         if not ok:
             return dict(desc, failed_step=s)
     return "ok"
