@@ -282,20 +282,24 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             # itself (whose CPU and GPU algorithms round differently)
             for p in m.parameters():
                 p.grad = None
+            if nonfinite is not None and s == nonfinite[1]:      # a diverged weight: a NaN / Inf in the raw parameter from here on
+                raw = m._parameters["weight"]
+                with torch.no_grad():
+                    raw.view(-1)[(seed * 7919) % raw.numel()] = nonfinite[0]
             if wb is not None:
                 wb._precompute(m, ())       # what the forward pre-hook does
             w = m.weight
             gw = torch.randn(w.shape, generator=g)
-            outs.append(("w", w.detach().cpu()))
+            outs.append(("w", w.detach().cpu().clone()))
             if twin and m.training:     # a second read before the first one's backward (siamese recipes): the statistics move on,
                 w2 = m.weight           # each read's backward clamps with what the reference's Function saved for it
-                outs.append(("w2", w2.detach().cpu()))
+                outs.append(("w2", w2.detach().cpu().clone()))
                 (w2 * 1.0).backward(torch.randn(w2.shape, generator=g).to(device) * 3, retain_graph=True)
             b = m.bias
             if b is not None and b.requires_grad:
                 (w * 1.0).backward(gw.to(device), retain_graph=True)
                 gb = torch.randn(b.shape, generator=g)
-                outs.append(("b", b.detach().cpu()))
+                outs.append(("b", b.detach().cpu().clone()))
                 b.backward(gb.to(device))
             else:
                 w.backward(gw.to(device))
@@ -350,6 +354,8 @@ def one_case(rng, idx, dry=False):
     batcher = rng.random() < 0.6
     twin = rng.random() < 0.25
     nonfinite = None
+    if desc["what"] in ("conv", "linear") and rng.random() < 0.25:
+        nonfinite = (rng.choice([float("nan"), float("inf"), float("-inf")]), rng.choice([steps - 2, steps - 1]))
     if desc["what"] == "site" and rng.random() < 0.3:
         # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
         # act_open -- so the clamping activations get infinities only)
