@@ -206,29 +206,32 @@ def test_elision_mask_marks_the_pruned_channels_that_must_be_loaded(kind):
         assert same(out["exact"], ref), pre_relu
 
 
-def _site(act, **cbkw):
+def _site(act, kind="scaler", **cbkw):
     return nn.Sequential(nn.Sequential(nn.ReLU() if act else nn.Identity(),
                                        qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1,
                                                 callback=qs.MagnitudePruningCallback(**cbkw))),
-                         qs.quantize(bits=4, channelwise=-1, timeout=1))
+                         qs.quantize(bits=4, channelwise=-1, timeout=1,
+                                     callback=qs.ScalerQuantizer() if kind == "scaler" else qs.DecimalQuantizer()))
 
 
 @pytest.mark.parametrize("frozen", [True, False], ids=["frozen_mask", "refreshing_mask"])
 @pytest.mark.parametrize("act", [False, True], ids=["identity", "relu"])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_default_mode_is_exact_on_a_site_with_non_finite_values_on_pruned_channels(act, dtype, frozen):
+@pytest.mark.parametrize("dtype,kind", [(torch.bfloat16, "scaler"), (torch.float32, "scaler"), (torch.bfloat16, "decimal")])
+def test_default_mode_is_exact_on_a_site_with_non_finite_values_on_pruned_channels(act, dtype, kind, frozen):
     """the default elision changed NaN / Inf on PRUNED channels of an NCHW site.  A whole convert-style
     (ReLU ->) prune -> quantize site meets NaN / Inf / -Inf on pruned channels: the fused pair (composite route) == the
     module-by-module GPU path == the CPU path (the reference's own torch arithmetic), in both layouts, with and without autograd:
       * evaluation (no statistics: every element is loaded): f32(INT_MIN) * s at the NaN, quirk B15;
       * training with a live scale: x * 0 is NaN there and the reference's x.abs().max() carries it into the scale -- the
         select, which takes the maximum over kept channels, accounts for it (`pq_scale_key`) -- and marks the channel in the
-        elision mask, so the eliding apply kernel loads it."""
+        elision mask, so the eliding apply kernel loads it.  (With a ScalerQuantizer every output is NaN then; a
+        DecimalQuantizer turns the NaN scale into a step of 2^inf, q * inf, and the loaded NaN shows as -inf = INT_MIN * inf
+        where a skipped one would give 0 * inf = NaN: the elision mask is what keeps that element right.)"""
     import copy
     assert qs.get_qsparse_option("elide_pruned") == "forward"
     cbkw = {"stop_mask_refresh": 3} if frozen else {}
-    fused, plain, cpu = (fuse_prune_quantize_pairs(_site(act, **cbkw).to(DEV)).train(), _site(act, **cbkw).to(DEV).train(),
-                         _site(act, **cbkw).train())
+    fused, plain, cpu = (fuse_prune_quantize_pairs(_site(act, kind, **cbkw).to(DEV)).train(), _site(act, kind, **cbkw).to(DEV).train(),
+                         _site(act, kind, **cbkw).train())
 
     def batch(step):
         return (torch.randn(4, 16, 8, 8, generator=gen(300 + step)) * torch.linspace(0.25, 4, 16).view(1, -1, 1, 1)).to(dtype)
@@ -264,8 +267,12 @@ def test_default_mode_is_exact_on_a_site_with_non_finite_values_on_pruned_channe
                         assert same(m[1].weight.cpu(), sites[2][1].weight) and same(m[0][1].mask.cpu(), sites[2][0][1].mask), tag
                     w = float(sites[2][1].weight)
                     if training:
-                        assert w != w and bool(ys[0].isnan().all()), tag          # the reference's scale is NaN from here on
-                    else:
+                        assert w != w, tag                                        # the reference's scale is NaN from here on
+                        if kind == "scaler":
+                            assert bool(ys[0].isnan().all()), tag
+                        else:
+                            assert ys[0][0, pruned[0], 0, 0].item() == float("-inf"), tag
+                    elif kind == "scaler":
                         assert w == w and ys[0][0, pruned[0], 0, 0].item() == float(-2 ** 31) * w, tag
                     if training and rep == 0 and not cl and not grad:      # this step elided: what the select wrote for the apply kernel
                         em = sites[0][1].__dict__["_qs_site_plan"].keep[7].cpu().tolist()
