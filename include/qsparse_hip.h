@@ -303,7 +303,9 @@ int qs_mask_apply(const void* x, const uint8_t* mask, void* y, int ndim, const i
  * Sequential(PruneLayer(dims={1}), QuantizeLayer(channelwise=-1)) built by convert(), convert.py:214-218):
  *   magnitude  <- (t_mag*magnitude + f32(stage_mean))/(t_mag+1)       if update_magnitude   (sparse.py:89)
  *   mask       <- magnitude >= sort(magnitude)[k]                      if refresh_mask       (util.py:113-117)
- *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340)
+ *   absmax_all <- max over channels with mask != 0 of chan_absmax      (== max|x*mask|, quantize.py:329-340; a pruned
+ *                 channel whose chan_absmax is Inf / NaN contributes a NaN: its x * 0 is NaN in the product the reference
+ *                 takes x.abs().max() of, so the scale turns NaN there too)
  *   scale      <- t_q == 0 ? new : (t_q*scale + new)/(t_q+1), new = absmax_all/2^(bits-1)  if update_scale
  * stage_mean is the last squeeze stage's output ([C] in dtype sdt).  Single workgroup; C <= 65536.
  * chan_absmax[c * chan_absmax_stride] (stride as for qs_mean_dim's absmax_out, >= 1) is zeroed after use when
