@@ -361,7 +361,11 @@ def one_case(rng, idx, dry=False):
         # act_open -- so the clamping activations get infinities only)
         values = [float("inf"), float("-inf")] + ([] if desc["act"] in ("relu6", "hardtanh") else [float("nan")] * 2)
         nonfinite = (rng.choice(values), rng.choice([steps - 3, steps - 2, steps - 1]))
-    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite)
+    # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
+    routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
+                  graph_safe=rng.random() < 0.2)
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite,
+                routes=routes)
     if dry:
         return None
     if VERBOSE:
@@ -369,10 +373,14 @@ def one_case(rng, idx, dry=False):
     results = {}
     for device in ("cpu", "cuda"):
         try:
+            if device == "cuda":
+                qs.set_qsparse_options(**routes)
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
                                   channels_last, batcher, twin, desc['what'] == 'site', nonfinite)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
+        finally:
+            qs.set_qsparse_options(fold_relu=True, relu_gate=True, elide_pruned="forward", graph_safe=False)
     a, b = results["cpu"], results["cuda"]
     if isinstance(a, tuple) or isinstance(b, tuple):
         if isinstance(a, tuple) and isinstance(b, tuple) and a[1] == b[1]:
