@@ -261,6 +261,8 @@ def one_functional(rng, idx, dry=False):
     return "ok"
 
 
+EXCHANGE = bool(os.environ.get("QS_FUZZ_EXCHANGE"))      # run inside a one-rank RCCL process group
+COLLECTIVES = [0]
 ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
 
 
@@ -364,6 +366,8 @@ def one_case(rng, idx, dry=False):
     # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
                   graph_safe=rng.random() < 0.2)
+    if EXCHANGE and rng.random() < 0.6:     # the statistics exchange of a data-parallel run, live on a one-rank group (same values)
+        routes["sync_statistics"] = "always"
     desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite,
                 routes=routes)
     if dry:
@@ -381,6 +385,7 @@ def one_case(rng, idx, dry=False):
             results[device] = ("raised", type(e).__name__)
         finally:
             qs.set_qsparse_options(fold_relu=True, relu_gate=True, elide_pruned="forward", graph_safe=False)
+            qs.set_qsparse_options(sync_statistics=False) if EXCHANGE else None
     a, b = results["cpu"], results["cuda"]
     if isinstance(a, tuple) or isinstance(b, tuple):
         if isinstance(a, tuple) and isinstance(b, tuple) and a[1] == b[1]:
@@ -407,6 +412,15 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    if EXCHANGE:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29711", rank=0, world_size=1)
+        for name in ("all_gather_into_tensor", "all_reduce"):       # how many collectives the cases really issued
+            def counted(*a, _f=getattr(dist, name), **k):
+                COLLECTIVES[0] += 1
+                return _f(*a, **k)
+            setattr(dist, name, counted)
+        qs.set_qsparse_options(sync_statistics=False)     # (the CPU runs: no collective on CPU tensors through RCCL)
     only = os.environ.get("QS_FUZZ_ONLY")
     ran = fails = 0
     mode = os.environ.get("QS_FUZZ_MODE", "modules")
@@ -418,7 +432,8 @@ def main():
         if r != "ok":
             fails += 1
             print("FAIL", r, flush=True)
-    print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed}); weight batcher engaged in {ENGAGED[0]}")
+    print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed}); weight batcher engaged in {ENGAGED[0]}"
+          + (f"; {COLLECTIVES[0]} collectives on the one-rank group" if EXCHANGE else ""))
     sys.exit(1 if fails else 0)
 
 
