@@ -262,12 +262,14 @@ def one_functional(rng, idx, dry=False):
 
 
 EXCHANGE = bool(os.environ.get("QS_FUZZ_EXCHANGE"))      # run inside a one-rank RCCL process group
+GRAPH = bool(os.environ.get("QS_FUZZ_GRAPH"))            # steady-state steps of the site cases replayed from a hipGraph
+GRAPHED = [0]
 COLLECTIVES = [0]
 ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
 
 
 def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False,
-        site=False, nonfinite=None):
+        site=False, nonfinite=None, graph=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -277,8 +279,13 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         ENGAGED[0] += 1
     g = torch.Generator().manual_seed(seed)
     outs = []
+    captured = None         # (graph, static x, static gradient, static y): whole steps replayed from a hipGraph (graphs.py)
+    y_dtype = None
     for s in range(steps):
         m.train(s < eval_from)
+        if captured is not None and not m.training:
+            qs.graphs.resync_host_state(m)      # back to eager: the host mirrors re-read the device state
+            captured = None
         if weight_mode:
             # read the layer's weight (and bias) through its operators, as its forward does, without the convolution
             # itself (whose CPU and GPU algorithms round differently)
@@ -318,8 +325,31 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             x.view(-1)[(seed * 7919 + s * 31) % x.numel()] = nonfinite[0]
         if channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
+        if (graph and device == "cuda" and captured is None and m.training and not twin and s >= 2 and y_dtype is not None
+                and qs.graphs.steady_state(m)):
+            sx = torch.empty_like(x.to(device)).requires_grad_(True)
+            sg = torch.empty_like(sx, dtype=y_dtype).detach()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                sy = m(sx.clone() if site else sx)
+                sy.backward(sg)
+            captured = (gr, sx, sg, sy)
+            GRAPHED[0] += 1
+        if captured is not None:        # this step is a replay of the captured one on this step's data
+            gr, sx, sg, sy = captured
+            gout = torch.randn(sy.shape, generator=g).to(sy.dtype)
+            with torch.no_grad():
+                sx.copy_(x.to(device))
+                sg.copy_(gout.to(device))
+            gr.replay()
+            outs.append(("layout", torch.tensor([st for st, n in zip(sy.stride(), sy.shape) if n > 1])))
+            outs.append(("y", sy.detach().cpu().clone()))
+            outs.append(("gx", sx.grad.cpu().clone()))
+            continue
         xd = x.to(device).requires_grad_(True)
         y = m(xd.clone() if site else xd)       # (an in-place activation needs a non-leaf input, as behind a convolution)
+        y_dtype = y.dtype
         if twin and m.training:         # a second forward before the first one's backward
             x2 = (x.detach().float() * 4).to(dtype).to(device).requires_grad_(True)
             y2 = m(x2.clone() if site else x2)
@@ -338,6 +368,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         for name, p in m.named_parameters():
             if p.grad is not None:
                 outs.append(("grad:" + name, p.grad.cpu()))
+    if captured is not None:
+        qs.graphs.resync_host_state(m)
     for k, v in m.state_dict().items():
         outs.append(("state:" + k, v.detach().cpu()))
     return outs
@@ -366,6 +398,9 @@ def one_case(rng, idx, dry=False):
     # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
                   graph_safe=rng.random() < 0.2)
+    graph = GRAPH and desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.7
+    if graph:
+        routes["graph_safe"] = True
     if EXCHANGE and rng.random() < 0.6:     # the statistics exchange of a data-parallel run, live on a one-rank group (same values)
         routes["sync_statistics"] = "always"
     desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite,
@@ -380,7 +415,7 @@ def one_case(rng, idx, dry=False):
             if device == "cuda":
                 qs.set_qsparse_options(**routes)
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite)
+                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite, graph)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
         finally:
@@ -433,7 +468,8 @@ def main():
             fails += 1
             print("FAIL", r, flush=True)
     print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed}); weight batcher engaged in {ENGAGED[0]}"
-          + (f"; {COLLECTIVES[0]} collectives on the one-rank group" if EXCHANGE else ""))
+          + (f"; {COLLECTIVES[0]} collectives on the one-rank group" if EXCHANGE else "")
+          + (f"; {GRAPHED[0]} cases captured into a hipGraph" if GRAPH else ""))
     sys.exit(1 if fails else 0)
 
 
