@@ -51,3 +51,15 @@ def test_functional_api_cpu_path_against_hip_path():
     rng = random.Random(2026)
     bad = [r for r in (fz.one_functional(rng, i) for i in range(250)) if r not in ("ok", None)]
     assert not bad, bad[:3]
+
+
+def test_modules_with_steady_state_steps_replayed_from_a_hipgraph():
+    """the same module cases; the activation sites that reach a steady state capture a whole step (forward + backward) into a
+    hipGraph and replay it on each further step's data (`QS_FUZZ_GRAPH` of the tool)"""
+    fz = _load("fuzz_cpu_gpu")
+    fz.GRAPH = True
+    fz.GRAPHED[0] = 0
+    rng = random.Random(2027)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(120)) if r not in ("ok", None)]
+    assert not bad, bad[:3]
+    assert fz.GRAPHED[0] >= 10, fz.GRAPHED[0]
