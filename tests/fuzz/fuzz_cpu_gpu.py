@@ -390,10 +390,10 @@ def one_case(rng, idx, dry=False):
     nonfinite = None
     if desc["what"] in ("conv", "linear") and rng.random() < 0.25:
         nonfinite = (rng.choice([float("nan"), float("inf"), float("-inf")]), rng.choice([steps - 2, steps - 1]))
-    if desc["what"] == "site" and rng.random() < 0.3:
+    if desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.3:
         # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
         # act_open -- so the clamping activations get infinities only)
-        values = [float("inf"), float("-inf")] + ([] if desc["act"] in ("relu6", "hardtanh") else [float("nan")] * 2)
+        values = [float("inf"), float("-inf")] + ([] if desc.get("act") in ("relu6", "hardtanh") else [float("nan")] * 2)
         nonfinite = (rng.choice(values), rng.choice([steps - 3, steps - 2, steps - 1]))
     # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
