@@ -70,7 +70,14 @@ __device__ __forceinline__ float guarded_reciprocal(float s) {
 // product x * 0 is a zero whatever x is), 2 pruned but this step's statistics saw a NaN / Inf in the channel (x * 0 is NaN there,
 // reference quirk B15: it must be loaded).  `keep` carries all three: 1.0, +0.0 (skippable) and -0.0 (a zero factor like any other
 // -- the product's zero may take the other sign, the code it rounds to is 0 either way -- but not skippable).
-__device__ __forceinline__ float keep_from_byte(uint32_t m) { return m == 1u ? 1.0f : (m ? -0.0f : 0.0f); }
+// Decoded arithmetically -- (-f) * (f - 2) for f = float(m) is +0.0, 1.0, -0.0 at m = 0, 1, 2 -- so that the per-element decode
+// of the channels-last kernels is a byte-to-float conversion (v_cvt_f32_ubyteN, straight from the packed word), an add and a
+// multiply instead of two compare / select pairs (measured in ResNet-50: the apply forward family 2.88 -> see DESIGN).  Mask
+// bytes are 0 / 1 (torch.bool) or 0 / 1 / 2 (the elision mask); nothing else is defined.
+__device__ __forceinline__ float keep_from_byte(uint32_t m) {
+    const float f = (float)m;
+    return (-f) * (f - 2.0f);
+}
 template <typename P>
 __device__ __forceinline__ bool needs_load(const P& p) { return __float_as_uint(p.keep) != 0u; }
 
@@ -234,21 +241,21 @@ struct SteBwdOp {
     int passthrough;
     const uint8_t* cmask;
     struct P {
-        float lo, hi, keep;
+        float lo, hi, keep, k1;
     };
     // A NaN bound (a scale that a NaN / Inf input has turned into NaN) makes ATen's tensor-bound clamp return NaN for EVERY g,
-    // and NaN * mask stays NaN: the factor `keep` carries it, so the per-element arithmetic is the same two instructions
-    __device__ __forceinline__ static float factor(const P& p, uint32_t m) {
-        const float f = m ? 1.0f : 0.0f;
-        return (p.lo != p.lo) ? p.lo : ((p.hi != p.hi) ? p.hi : f);
-    }
+    // and NaN * mask stays NaN: the factor `keep` = float(mask byte) * k1 carries it (k1 = 1.0, or that NaN: 0 * NaN and
+    // 1 * NaN are both NaN), so the per-element arithmetic stays a clamp and a multiply and the per-element mask decode of the
+    // channels-last kernels is a byte-to-float conversion and a multiply.  Mask bytes are 0 / 1 (torch.bool).
+    __device__ __forceinline__ static float factor(const P& p, uint32_t m) { return (float)m * p.k1; }
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         float s = step ? step[c] : step_host;
         if (step_is_decimal) s = DecimalFwdOp<QS_F32>::pow2(-s);
         p.lo = passthrough ? -__builtin_inff() : lo_mul * s;
         p.hi = passthrough ? __builtin_inff() : hi_mul * s;
-        p.keep = factor(p, 1u);
+        p.k1 = (p.lo != p.lo) ? p.lo : ((p.hi != p.hi) ? p.hi : 1.0f);
+        p.keep = p.k1;
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
