@@ -72,7 +72,7 @@ __device__ __forceinline__ float guarded_reciprocal(float s) {
 // -- the product's zero may take the other sign, the code it rounds to is 0 either way -- but not skippable).
 // Decoded arithmetically -- (-f) * (f - 2) for f = float(m) is +0.0, 1.0, -0.0 at m = 0, 1, 2 -- so that the per-element decode
 // of the channels-last kernels is a byte-to-float conversion (v_cvt_f32_ubyteN, straight from the packed word), an add and a
-// multiply instead of two compare / select pairs (measured in ResNet-50: the apply forward family 2.88 -> see DESIGN).  Mask
+// multiply instead of two compare / select pairs (ResNet-50, batch 256: the apply forward family 2.88 -> 2.80 ms per step).  Mask
 // bytes are 0 / 1 (torch.bool) or 0 / 1 / 2 (the elision mask); nothing else is defined.
 __device__ __forceinline__ float keep_from_byte(uint32_t m) {
     const float f = (float)m;
