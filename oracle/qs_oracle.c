@@ -86,6 +86,8 @@ void qo_ste_bwd(const float* g, const float* step, int64_t nstep, float lo_mul, 
         const float lo = lo_mul * s, hi = hi_mul * s;
         float v = g[e] < lo ? lo : g[e];
         v = v > hi ? hi : v;
+        /* a NaN bound (a NaN scale): ATen's clamp with tensor bounds returns NaN for every g, and a NaN g passes through */
+        if (lo != lo) v = lo; else if (hi != hi) v = hi;
         if (mask) v = v * (mask[c] ? 1.0f : 0.0f);
         gx[e] = v;
     }
