@@ -75,7 +75,7 @@ void qo_line_fwd(const float* x, const float* lines, int64_t nlines, int bits, i
 }
 
 /* Scaler/DecimalQuantization.backward, qsparse/quantize.py:66-77,120-131: gradient VALUES clamped into
- * [lo_mul*s, hi_mul*s] (the masked assignment at :76/:130 is a no-op); optional channel mask = the
+ * [lo_mul*s, hi_mul*s] (the masked assignment at :76/:130 compares the tensor with itself: NaNs -> 0); optional channel mask = the
  * PruneLayer backward g * mask. */
 void qo_ste_bwd(const float* g, const float* step, int64_t nstep, float lo_mul, float hi_mul, const uint8_t* mask,
                 int64_t outer, int64_t C, int64_t inner, float* gx) {
@@ -86,8 +86,9 @@ void qo_ste_bwd(const float* g, const float* step, int64_t nstep, float lo_mul, 
         const float lo = lo_mul * s, hi = hi_mul * s;
         float v = g[e] < lo ? lo : g[e];
         v = v > hi ? hi : v;
-        /* a NaN bound (a NaN scale): ATen's clamp with tensor bounds returns NaN for every g, and a NaN g passes through */
-        if (lo != lo) v = lo; else if (hi != hi) v = hi;
+        /* a NaN bound (a NaN scale): ATen's clamp with tensor bounds returns NaN for every g, and a NaN g stays NaN -- then the
+         * masked assignment at :76/:130, which compares the clamped tensor with ITSELF, turns exactly those NaNs into +0.0 */
+        if (lo != lo || hi != hi || v != v) v = 0.0f;
         if (mask) v = v * (mask[c] ? 1.0f : 0.0f);
         gx[e] = v;
     }

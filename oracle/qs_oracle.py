@@ -69,8 +69,8 @@ def ste_bounds(bits: int, step, flip_axis: bool = False):
 def ste_bwd(g: torch.Tensor, bits: int, step, channel_index: int = -1, flip_axis: bool = False,
             backward_passthrough: bool = False, x_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """backward of the scaler / decimal quantizers (quantize.py:66-77, 120-131): the incoming
-    gradient VALUES are clamped to the interval above (line :76/:130 is a no-op because `v` aliases
-    `grad_output`); autograd then casts the result to the forward input's dtype.
+    gradient VALUES are clamped to the interval above (line :76/:130 zeroes nothing but NaNs because `v` aliases
+    `grad_output`: pinned by fixture F17); autograd then casts the result to the forward input's dtype.
     `step` is the scaler (ScalerQuantization) or 2**-decimal (DecimalQuantization)."""
     if backward_passthrough:
         out = g
@@ -80,6 +80,7 @@ def ste_bwd(g: torch.Tensor, bits: int, step, channel_index: int = -1, flip_axis
             s = torch.tensor(s)
         lo, hi = ste_bounds(bits, s, flip_axis)
         out = g.clone().clamp_(lo, hi)
+        out[out != out] = 0          # :76/:130 -- `v` IS grad_output, so `v != grad_output` is true for NaNs only: they become 0
     return out if x_dtype is None else out.to(x_dtype)
 
 

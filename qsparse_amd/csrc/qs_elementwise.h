@@ -241,21 +241,22 @@ struct SteBwdOp {
     int passthrough;
     const uint8_t* cmask;
     struct P {
-        float lo, hi, keep, k1;
+        float lo, hi, keep;
     };
-    // A NaN bound (a scale that a NaN / Inf input has turned into NaN) makes ATen's tensor-bound clamp return NaN for EVERY g,
-    // and NaN * mask stays NaN: the factor `keep` = float(mask byte) * k1 carries it (k1 = 1.0, or that NaN: 0 * NaN and
-    // 1 * NaN are both NaN), so the per-element arithmetic stays a clamp and a multiply and the per-element mask decode of the
-    // channels-last kernels is a byte-to-float conversion and a multiply.  Mask bytes are 0 / 1 (torch.bool).
-    __device__ __forceinline__ static float factor(const P& p, uint32_t m) { return (float)m * p.k1; }
+    // The reference clamps in place and then runs `v[v != grad_output] = 0` with v BEING grad_output (quantize.py:72-76,
+    // 126-130): the comparison is true for NaNs only, so a NaN gradient becomes +0.0 -- and so does every element once a NaN
+    // scale (a NaN / Inf input reached it) has made the bounds NaN, since ATen's tensor-bound clamp returns NaN then (fixture
+    // F17).  NaN bounds are replaced by [+0.0, +0.0] here, per channel: clamp(g, +0, +0) is +0.0 for every g that is not NaN.
+    // Mask bytes are 0 / 1 (torch.bool): the factor is a byte-to-float conversion.
+    __device__ __forceinline__ static float factor(const P&, uint32_t m) { return (float)m; }
     __device__ __forceinline__ P channel(uint32_t c) const {
         P p;
         float s = step ? step[c] : step_host;
         if (step_is_decimal) s = DecimalFwdOp<QS_F32>::pow2(-s);
         p.lo = passthrough ? -__builtin_inff() : lo_mul * s;
         p.hi = passthrough ? __builtin_inff() : hi_mul * s;
-        p.k1 = (p.lo != p.lo) ? p.lo : ((p.hi != p.hi) ? p.hi : 1.0f);
-        p.keep = p.k1;
+        if (p.lo != p.lo || p.hi != p.hi) p.lo = p.hi = 0.0f;
+        p.keep = 1.0f;
         return p;
     }
     __device__ __forceinline__ P channel_masked(uint32_t c_par, uint32_t c_mask) const {
@@ -272,7 +273,7 @@ struct SteBwdOp {
         float v = g;
         if (!passthrough) {
             v = fminf(fmaxf(g, p.lo), p.hi);             // clamp_(lo, hi) == min(max(g, lo), hi)
-            if (g != g) v = g;
+            if (g != g) v = 0.0f;                        // clamp keeps a NaN; `v[v != v] = 0` then zeroes it
         }
         code = 0;
         return v * p.keep;                               // g * mask keeps the sign of zero

@@ -106,8 +106,11 @@ class _SteFunction(torch.autograd.Function):
         s = torch.pow(2.0, -step) if step_is_decimal else step
         if s.numel() > 1:
             s = _on_channel(s, grad_output.dim(), ctx.channel_index, grad_output.shape[ctx.channel_index])
-        # values are clamped; nothing is zeroed (the reference's masked assignment is a no-op)
-        return (torch.clamp(grad_output, lo_mul * s, hi_mul * s),) + (None,) * 8
+        # values are clamped; the reference's masked assignment `v[v != grad_output] = 0` compares v with ITSELF (clamp_ returned
+        # grad_output), so it zeroes nothing but NaNs: a NaN gradient, and every element once a NaN scale made the bounds NaN
+        out = torch.clamp(grad_output, lo_mul * s, hi_mul * s)
+        out[out != out] = 0
+        return (out,) + (None,) * 8
 
 
 class ScalerQuantization(_SteFunction):

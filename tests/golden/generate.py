@@ -26,6 +26,9 @@ Reference entry points exercised (file:line in /root/reference):
   F14 counters written through ``.data``       qsparse/quantize.py:495, qsparse/sparse.py:251-269,104-118
   F15 MagnitudePruningCallback(use_gradient=True)  qsparse/sparse.py:69-80 (tensor hook -> update_magnitude(grad), :82-89)
   F16 the MNIST --pq recipe with devise_layerwise_pruning_schedule  examples/mnist.py:17-44,193-199; qsparse/sparse.py:343-359
+  F17 the prune->quantize pair with NaN / Inf / -Inf on PRUNED channels  qsparse/sparse.py:263 (x * mask: NaN there),
+      qsparse/quantize.py:109 (.int() of NaN: INT_MIN), :329-347 (x.abs().max() carries the NaN into a live scale),
+      :126-130 (clamp with NaN bounds), :316 (nan_to_num in the decimal)
 """
 import io
 import json
@@ -877,6 +880,51 @@ F16_CASES = (dict(name="fractional", E=7, steps=50, prune=dict(sparsity=0.75, di
              dict(name="weights", E=10, steps=60, prune=dict(sparsity=0.5, interval=4), where="weights", seed=14))
 
 
+# --------------------------------------------------------------------------------------------
+# F17: the pair of F10 meeting non-finite values on pruned channels -- in evaluation with a finite scale (quirk B15:
+# f32(INT_MIN) * s) and in training with a live scale (the scale turns NaN; the backward's clamp bounds with it)
+# --------------------------------------------------------------------------------------------
+def f17():
+    store, cases = {}, []
+    shape, C = (4, 16, 4, 4), 16
+    specs = ((torch.bfloat16, "scaler", None, 8), (torch.bfloat16, "scaler", 3, 5), (torch.float32, "scaler", None, 6),
+             (torch.bfloat16, "decimal", 3, 5), (torch.float32, "decimal", None, 8), (torch.float32, "scaler", 3, 8))
+    for idx, (dt, kind, stop, inject_from) in enumerate(specs):
+        with quiet():
+            cb = MagnitudePruningCallback() if stop is None else MagnitudePruningCallback(stop_mask_refresh=stop)
+            pl = prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2, callback=cb)
+            ql = quantize(bits=4, channelwise=-1, timeout=1, callback=ScalerQuantizer() if kind == "scaler" else DecimalQuantizer())
+        pl.train(), ql.train()
+        steps = 8                    # the last one (index 8) in evaluation
+        k = f"c{idx}_"
+        for s in range(steps + 1):
+            if s == steps:
+                pl.eval(), ql.eval()
+            x = (torch.randn(shape, generator=gen(9100 + 17 * idx + s)) * torch.linspace(0.25, 4, C).view(1, -1, 1, 1)).to(dt)
+            if s >= inject_from:
+                pruned = (~pl.mask.view(-1)).nonzero().view(-1).tolist()
+                assert len(pruned) >= 3
+                for j, c in enumerate(pruned[:3]):
+                    x[j, c, j, j] = (float("nan"), float("inf"), float("-inf"))[j]
+            x.requires_grad_(True)
+            with quiet():
+                y = ql(pl(x))
+            gout = torch.randn(shape, generator=gen(9500 + 17 * idx + s)).to(y.dtype)
+            y.backward(gout.clone())
+            put(store, k + f"s{s}_x", x)
+            put(store, k + f"s{s}_gout", gout)
+            put(store, k + f"s{s}_y", y)
+            put(store, k + f"s{s}_gx", x.grad)
+            put(store, k + f"s{s}_mask", pl.mask)
+            if hasattr(pl.callback, "magnitude"):
+                put(store, k + f"s{s}_magnitude", pl.callback.magnitude)
+            put(store, k + f"s{s}_scale", ql.weight)
+        cases.append(dict(id=idx, dtype=str(dt).replace("torch.", ""), shape=list(shape), kind=kind, bits=4, sparsity=0.5,
+                          start=1, interval=1, repetition=2, timeout=1, stop_mask_refresh=stop, inject_from=inject_from,
+                          total_steps=steps + 1))
+    save("f17_pair_non_finite", store, dict(cases=cases))
+
+
 def f16_recipe(ns, case):
     """the recipe of examples/mnist.py:193-199 against the namespace `ns` (the reference here; tests/test_host_golden.py
     carries the same lines against the package)"""
@@ -982,3 +1030,4 @@ if __name__ == "__main__":
     f14()
     f15()
     f16()
+    f17()

@@ -80,6 +80,14 @@ def test_golden_f10_pair(fused):
     H.run_f10(DEV, fused)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_golden_f17_pair_with_non_finite_values_on_pruned_channels(fused):
+    """the REFERENCE's recorded outputs for NaN / Inf / -Inf on pruned channels (f32(INT_MIN) * s in evaluation, a NaN scale
+    and NaN clamp bounds once a live scale has seen them), module by module and through the fused pair (composite route,
+    default elision)"""
+    H.run_f17(DEV, fused)
+
+
 def test_golden_f13_uniform_pruning_callback():
     H.run_f13(DEV)
 

@@ -326,6 +326,42 @@ def run_f10(dev, fused):
                 assert same(pl.callback.magnitude.detach().cpu(), g.get(k + f"s{s}_magnitude")), (c, s)
 
 
+def run_f17(dev, fused):
+    """fixture F17: the pair meeting NaN / Inf / -Inf on pruned channels, against the reference's recorded outputs"""
+    from golden_io import same_up_to_nan_payload as eq
+    g = Golden("f17_pair_non_finite")
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        stop = c["stop_mask_refresh"]
+        cb = qs.MagnitudePruningCallback() if stop is None else qs.MagnitudePruningCallback(stop_mask_refresh=stop)
+        pl = qs.prune(sparsity=c["sparsity"], dimensions={1}, start=c["start"], interval=c["interval"],
+                      repetition=c["repetition"], callback=cb)
+        ql = qs.quantize(bits=c["bits"], channelwise=-1, timeout=c["timeout"],
+                         callback=qs.ScalerQuantizer() if c["kind"] == "scaler" else qs.DecimalQuantizer())
+        pair = nn.Sequential(nn.Sequential(nn.Identity(), pl), ql)
+        if fused:
+            from qsparse_amd.fused import fuse_prune_quantize_pairs
+            fuse_prune_quantize_pairs(pair)
+        pair.to(dev).train()
+        for s in range(c["total_steps"]):
+            if s == c["total_steps"] - 1:
+                pair.eval()
+            x = g.get(k + f"s{s}_x").to(dev).requires_grad_(True)
+            y = pair(x)
+            y.backward(g.get(k + f"s{s}_gout").to(dev).clone())
+            assert eq(y.detach().cpu(), g.get(k + f"s{s}_y")), (c, s)
+            assert eq(x.grad.cpu(), g.get(k + f"s{s}_gx")), (c, s)
+            assert same(pl.mask.detach().cpu(), g.get(k + f"s{s}_mask")), (c, s)
+            assert eq(ql.weight.detach().cpu(), g.get(k + f"s{s}_scale")), (c, s)
+            if g.has(k + f"s{s}_magnitude"):
+                assert eq(pl.callback.magnitude.detach().cpu(), g.get(k + f"s{s}_magnitude")), (c, s)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_f17_pair_non_finite(fused):
+    run_f17(DEV, fused)
+
+
 def test_f16_mnist_recipe_with_layerwise_schedule():
     run_f16(DEV)
 

@@ -176,6 +176,42 @@ def test_f7_conv_weight_pruning():
             assert same(sim.mask, g.get(k + f"s{s}_mask")), (c, s)
 
 
+def test_f17_pair_with_non_finite_values_on_pruned_channels():
+    """the reference's own outputs for NaN / Inf / -Inf on pruned channels: f32(INT_MIN) * s in evaluation (quirk B15), a NaN
+    scale once a live scale has seen them (x * mask is NaN there), NaN clamp bounds in the backward from then on"""
+    from golden_io import same_up_to_nan_payload as eq
+    g = Golden("f17_pair_non_finite")
+    seen_nan_scale = seen_int_min = 0
+    for c in g.cases:
+        k = f"c{c['id']}_"
+        stop = c["stop_mask_refresh"]
+        ps = O.PruneSim(c["sparsity"], [1], c["start"], c["interval"], c["repetition"], False,
+                        **({} if stop is None else {"stop_mask_refresh": stop}))
+        qs = O.QuantizeSim(c["kind"], c["bits"], -1, c["timeout"])
+        for s in range(c["total_steps"]):
+            training = s < c["total_steps"] - 1
+            x = g.get(k + f"s{s}_x")
+            n_before = ps.n_updates
+            h = ps.step(x, training)
+            y = qs.step(h, training)
+            want = g.get(k + f"s{s}_y")
+            assert eq(y, want), (c, s)
+            assert same(ps.mask, g.get(k + f"s{s}_mask")), (c, s)
+            assert eq(qs.weight, g.get(k + f"s{s}_scale")), (c, s)
+            if g.has(k + f"s{s}_magnitude"):
+                assert eq(ps.magnitude, g.get(k + f"s{s}_magnitude")), (c, s)
+            gh = qs.grad(g.get(k + f"s{s}_gout"), h.dtype)
+            gx = ps.grad(gh, (not training) or n_before >= c["start"])
+            assert eq(gx, g.get(k + f"s{s}_gx")), (c, s)
+            if s >= c["inject_from"]:
+                scale = g.get(k + f"s{s}_scale")
+                seen_nan_scale += int(bool(scale.isnan().any()))
+                if not bool(scale.isnan().any()) and c["kind"] == "scaler":
+                    assert float((want.float() == float(-2 ** 31) * float(scale)).sum()) >= 2, (c, s)      # NaN and Inf
+                    seen_int_min += 1
+    assert seen_nan_scale >= 3 and seen_int_min >= 2
+
+
 def test_f10_prune_quant_pair():
     g = Golden("f10_prune_quant_pair")
     for c in g.cases:
