@@ -134,6 +134,8 @@ int qs_quant_line_fwd(const void* x, void* y, int32_t* codes, const float* lines
 
 /* ScalerQuantization.backward / DecimalQuantization.backward, qsparse/quantize.py:66-77,120-131:
  *   gx = cast(gxdt, min(max(g, lo_mul*step_c), hi_mul*step_c))     (passthrough != 0: gx = cast(g))
+ * and +0.0 where that clamp is NaN -- a NaN g, or any g once step_c is NaN: the reference's `v[v != grad_output] = 0` (:76,
+ * :130) compares the clamped tensor with itself, i.e. zeroes exactly the NaNs (fixture F17).
  * step_c = scale (step_is_decimal == 0) or 2^-d (step_is_decimal != 0);  lo_mul = -2^(bits-1)+notch,
  * hi_mul = 2^(bits-1)-1+notch.  chan_mask (nullable) fuses the PruneLayer backward g*mask
  * (autograd MulBackward0 of qsparse/sparse.py:116).  g and gx may alias.
