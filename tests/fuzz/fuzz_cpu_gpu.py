@@ -20,6 +20,7 @@ import qsparse_amd as qs
 from golden_io import same
 
 VERBOSE = bool(os.environ.get("QS_FUZZ_ONLY"))
+FORCE_WHAT = os.environ.get("QS_FUZZ_WHAT")      # e.g. "net": every case is of that kind (campaigns aimed at one route)
 _same_bits = same
 
 
@@ -36,6 +37,27 @@ def same(a, b):
     return _same_bits(torch.where(na, torch.zeros_like(a), a), torch.where(nb, torch.zeros_like(b), b))
 
 
+class WeightReader(nn.Module):
+    """a network whose forward only READS its layers' parameters through their operators (as Conv2d.forward / Linear.forward
+    do: weight, then bias) -- the convolutions themselves round differently on the two devices and are not what is under test.
+    `skip`: a layer this forward does not reach (a branch not taken: the multi-tensor path rolls that layer back)."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, skip=-1):
+        read = []
+        for i, layer in enumerate(self.layers):
+            if i == skip:
+                continue
+            read.append(("w%d" % i, layer.weight))
+            b = layer.bias
+            if b is not None:
+                read.append(("b%d" % i, b))
+        return read
+
+
 def make_quantizer(rng):
     kind = rng.choice(["scaler", "decimal", "adaptive"])
     kw = dict(flip_axis=rng.random() < 0.2, backward_passthrough=rng.random() < 0.15)
@@ -45,9 +67,11 @@ def make_quantizer(rng):
 
 def build(rng):
     """returns (description, module factory, input shape, dtype)"""
-    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear", "site", "site", "site"])
+    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear", "site", "site", "site", "net", "net"])
+    if FORCE_WHAT:
+        what = FORCE_WHAT
     dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
-    if what in ("conv", "linear"):
+    if what in ("conv", "linear", "net"):
         dtype = torch.float32
     n = rng.choice([1, 2, 4, 8, 16, 17, 48, 64, 130, 256, 300])
     c = rng.choice([2, 4, 6, 16, 33, 64, 96, 256])
@@ -80,6 +104,36 @@ def build(rng):
             return qs.MagnitudePruningCallback(mask_refresh_interval=2, stop_mask_refresh=4)
         return qs.MagnitudePruningCallback()
 
+    if what == "net":
+        # `convert(model, prune(...), weight_layers=[Conv2d, Linear])` -- then, mostly, `convert(model, quantize(...), ...)` -- over a
+        # small network (reference convert.py:120-197 wraps every layer; imitation.py:61-68 reads through the operators): on the GPU
+        # the DEFAULT route of such a network is the multi-tensor table (batch.py: qs_multi_stage_mean / magnitude / mask_refresh /
+        # absmax / scale_update / quant_fwd / ste_bwd), installed by convert itself
+        dims = rng.choice([{0, 1, 2, 3}, {0, 1, 2, 3}, {1}, {1}, {0}, {0, 1}])
+        policy = rng.choice(["default", "default", "no_avg", "refresh", "no_avg_refresh", "freeze"])
+        cbkw = {"default": {}, "no_avg": dict(running_average=False), "refresh": dict(mask_refresh_interval=2, stop_mask_refresh=4),
+                "no_avg_refresh": dict(running_average=False, mask_refresh_interval=2),
+                "freeze": dict(running_average=False, mask_refresh_interval=2, stop_mask_refresh=3)}[policy]
+        with_quant = rng.random() < 0.75
+        cw = rng.choice([-1, 0, 1, 1])
+        bias_bits = rng.choice([-1, -1, 8])
+        c1, c2, c3 = rng.choice([4, 8, 12, 33]), rng.choice([4, 8, 16]), rng.choice([3, 8, 10])
+        c0 = min(c, 33)
+        desc.update(dimensions=sorted(dims), policy=policy, with_quant=with_quant, channelwise=cw, bias_bits=bias_bits,
+                    widths=(c0, c1, c2, c3))
+
+        def net_factory():
+            torch.manual_seed(1234)
+            net = WeightReader([nn.Conv2d(c0, c1, 3, padding=1), nn.Conv2d(c1, c2, 3, bias=False), nn.Conv2d(c2, c2, 1),
+                                nn.Conv2d(c2, c2, (1, 3)), nn.Linear(c2, c3)])
+            net = qs.convert(net, qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
+                                           callback=qs.MagnitudePruningCallback(**cbkw)),
+                             weight_layers=[nn.Conv2d, nn.Linear], log=False)
+            if with_quant:
+                net = qs.convert(net, qs.quantize(bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb), bias_bits=bias_bits),
+                                 weight_layers=[nn.Conv2d, nn.Linear], log=False)
+            return net
+        return desc, net_factory, (1,), dtype
     if what == "site":
         # a `convert`-built activation site (reference convert.py:199-229): activation module -> PruneLayer -> QuantizeLayer, the
         # activation folded into the kernels on the GPU (nn.ReLU / ReLU6 / Hardtanh / LeakyReLU, in place or not), composite or
@@ -279,6 +333,37 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         ENGAGED[0] += 1
     g = torch.Generator().manual_seed(seed)
     outs = []
+    if isinstance(m, WeightReader):
+        if channels_last:        # (before the first forward: full-shape masks and magnitudes are created in their weight's layout)
+            m = m.to(memory_format=torch.channels_last)
+        if device == "cuda" and len(getattr(m.__dict__.get("_qs_weight_batcher"), "layers", ())) > 0:
+            ENGAGED[0] += 1
+        for s in range(steps):
+            m.train(s < eval_from)
+            for p in m.parameters():
+                p.grad = None
+            if nonfinite is not None and s == nonfinite[1]:      # a diverged weight: a NaN / Inf in a raw parameter from here on
+                raw = m.layers[seed % len(m.layers)]._parameters["weight"]
+                with torch.no_grad():
+                    raw.view(-1)[(seed * 7919) % raw.numel()] = nonfinite[0]
+            skip = (seed + s) % len(m.layers) if s % 3 == 1 else -1
+            read = m(skip)
+            grads = [torch.randn(t.shape, generator=g) * 3 for _, t in read]
+            for k, t in read:
+                outs.append((k, t.detach().cpu().clone()))
+            live = [(t, gr.to(device)) for (_, t), gr in zip(read, grads) if t.requires_grad]
+            if live and m.training:
+                torch.autograd.backward([t for t, _ in live], [gr for _, gr in live])
+            for name, p in m.named_parameters():
+                if p.grad is not None:
+                    outs.append(("grad:" + name, p.grad.cpu().contiguous()))
+            with torch.no_grad():                # seeded pseudo-update of the raw parameters (identical on both devices)
+                for name, p in m.named_parameters():
+                    if p.requires_grad:
+                        p.add_((torch.randn(p.shape, generator=g) * 0.05).to(device))
+        for k, v in m.state_dict().items():
+            outs.append(("state:" + k, v.detach().cpu().contiguous()))
+        return outs
     captured = None         # (graph, static x, static gradient, static y): whole steps replayed from a hipGraph (graphs.py)
     y_dtype = None
     for s in range(steps):
@@ -388,7 +473,7 @@ def one_case(rng, idx, dry=False):
     batcher = rng.random() < 0.6
     twin = rng.random() < 0.25
     nonfinite = None
-    if desc["what"] in ("conv", "linear") and rng.random() < 0.25:
+    if desc["what"] in ("conv", "linear", "net") and rng.random() < 0.25:
         nonfinite = (rng.choice([float("nan"), float("inf"), float("-inf")]), rng.choice([steps - 2, steps - 1]))
     if desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.3:
         # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
@@ -398,6 +483,12 @@ def one_case(rng, idx, dry=False):
     # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
                   graph_safe=rng.random() < 0.2)
+    if desc["what"] == "net":
+        steps = rng.choice([6, 8, 10])
+        eval_from = rng.choice([steps, steps - 1])
+        routes["batch_weights"] = batcher = rng.random() < 0.85      # (off: the same network layer by layer)
+        if nonfinite is not None:
+            nonfinite = (nonfinite[0], rng.choice([steps - 3, steps - 2]))
     graph = GRAPH and desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.7
     if graph:
         routes["graph_safe"] = True
@@ -419,7 +510,7 @@ def one_case(rng, idx, dry=False):
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
         finally:
-            qs.set_qsparse_options(fold_relu=True, relu_gate=True, elide_pruned="forward", graph_safe=False)
+            qs.set_qsparse_options(fold_relu=True, relu_gate=True, elide_pruned="forward", graph_safe=False, batch_weights=True)
             qs.set_qsparse_options(sync_statistics=False) if EXCHANGE else None
     a, b = results["cpu"], results["cuda"]
     if isinstance(a, tuple) or isinstance(b, tuple):

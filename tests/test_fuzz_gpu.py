@@ -46,6 +46,19 @@ def test_modules_cpu_path_against_hip_path():
     assert not bad, bad[:3]
 
 
+def test_converted_weight_networks_cpu_path_against_hip_path():
+    """`convert(model, prune(...), weight_layers=[...])` (+ `convert(model, quantize(...), ...)`) networks only: the multi-tensor
+    pruned-weight route (qs_multi_stage_mean / magnitude / mask_refresh) against the CPU path -- which tests/fuzz/fuzz_reference.py
+    holds against the real reference on the same cases"""
+    fz = _load("fuzz_cpu_gpu")
+    fz.FORCE_WHAT = "net"
+    fz.ENGAGED[0] = 0
+    rng = random.Random(2028)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(100)) if r not in ("ok", None)]
+    assert not bad, bad[:3]
+    assert fz.ENGAGED[0] >= 60, fz.ENGAGED[0]
+
+
 def test_functional_api_cpu_path_against_hip_path():
     fz = _load("fuzz_cpu_gpu")
     rng = random.Random(2026)

@@ -1,0 +1,299 @@
+"""The multi-tensor PRUNED-weight path against the ORACLE (VERDICT r04 "next" item 1).
+
+`convert(model, prune(...), weight_layers=[Conv2d, Linear])` -- optionally followed by `convert(model, quantize(...), ...)` --
+makes every layer read `quantize(prune(weight))` (reference imitation.py:61-68): PruneLayer.forward (sparse.py:215-273) counts
+the read, `MagnitudePruningCallback` (sparse.py:82-122) averages the importance `squeeze_tensor_to_shape(|w|, mask.shape)`
+(util.py:92-99) into its running magnitude and rebuilds the mask (util.py:113-117) when its refresh policy says so -- the
+`running_average=False` weight recipe of sparse.py:343-359 ranks `|w|` itself -- and returns `weight * mask`; the quantizer
+(quantize.py:473-518) sees that product.  On the GPU the DEFAULT route for all of this is the multi-tensor table of
+`qsparse_amd/batch.py` (`qs_multi_stage_mean`, `qs_multi_magnitude`, `qs_multi_mask_refresh`, `qs_multi_absmax`,
+`qs_multi_scale_update`, `qs_multi_quant_fwd`, `qs_multi_ste_bwd`).
+
+Here every layer of the network gets an oracle twin (`oracle.PruneSim` + `oracle.QuantizeSim`, which restate the reference and
+are pinned to fixtures recorded from it).  Per training step the raw parameters are copied to the CPU BEFORE the forward; the
+tensors each layer really computed with (recorded where `Conv2d.forward` / `Linear.forward` read `self.weight` / `self.bias`)
+are compared bit for bit with what the twins make of those raw parameters, and so are -- for EVERY layer, read or not (a
+skipped branch is rolled back) -- mask, running magnitude, `_cur_sparsity`, `_n_updates`, the callbacks' `t`, the scales, and
+the gradient that reaches the raw weight (STE clamp times mask).  Full-width ResNet-50 (54 layers, masks of up to 2.36 M
+entries) and the `Branchy` net (branches that are skipped), contiguous and channels_last, through the whole schedule."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import qsparse_amd as qs
+from examples.models import resnet50
+from golden_io import same
+from oracle import qs_oracle as O
+from qsparse_amd.quantize import QuantizeLayer
+from qsparse_amd.sparse import PruneLayer
+from test_weight_batcher_gpu import Branchy
+from test_weight_batcher_pruned_gpu import PRUNES, QUANTS
+
+qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+
+MULTI = ("multi_quant_fwd", "multi_absmax", "multi_scale_update", "multi_magnitude", "multi_mask_refresh", "multi_stage_mean",
+         "multi_ste_bwd")
+PER_LAYER = ("kth_value", "mask_ge", "running_mean", "mean_dim", "mean_dim_cl", "mean_last2", "pq_select", "mask_apply")
+CALLS = {}
+SCHED = dict(sparsity=0.5, start=2, interval=2, repetition=2)
+BITS = 4
+
+
+def build(net, prune, quantizer, device, channels_last):
+    dims, cbkw = PRUNES[prune]
+    torch.manual_seed(0)
+    model = qs.convert(net(), qs.prune(dimensions=dims, callback=qs.MagnitudePruningCallback(**cbkw), **SCHED),
+                       weight_layers=[nn.Conv2d, nn.Linear], log=False)
+    if QUANTS[quantizer] is not None:
+        kind, channelwise, bias_bits, timeout = QUANTS[quantizer]
+        model = qs.convert(model, qs.quantize(bits=BITS, channelwise=channelwise, timeout=timeout, bias_bits=bias_bits,
+                                              callback=qs.DecimalQuantizer() if kind == "decimal" else None),
+                           weight_layers=[nn.Conv2d, nn.Linear], log=False)
+    model = model.to(device).train()
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    return model
+
+
+class WeightTwin:
+    """oracle twin of one wrapped layer: prune operator, weight quantizer, bias quantizer (sharing the weight quantizer's count
+    `t`, quantize.py:548,559-571)"""
+
+    def __init__(self, name, layer, prune, quantizer):
+        dims, cbkw = PRUNES[prune]
+        self.name, self.layer = name, layer
+        w = layer._parameters["weight"]
+        self.psim = O.PruneSim(SCHED["sparsity"], [d for d in dims if d < w.dim()], SCHED["start"], SCHED["interval"],
+                               SCHED["repetition"], False, **cbkw)
+        self.qsim = self.bsim = None
+        if QUANTS[quantizer] is not None:
+            kind, channelwise, bias_bits, timeout = QUANTS[quantizer]
+            shared = {"t": 0}
+            self.qsim = O.QuantizeSim(kind, BITS, channelwise, timeout, batch_dimension=-1, shared=shared)
+            if bias_bits > 0 and layer._parameters.get("bias") is not None:
+                self.bsim = O.QuantizeSim(kind, bias_bits, 0 if channelwise >= 0 else -1, timeout, batch_dimension=-1, shared=shared)
+        self.raw_w = self.raw_b = None
+        self.reads = 0
+        self.grad_eff = None         # gradient w.r.t. the tensor the layer computed with (captured by a tensor hook)
+        self.active = False
+
+    def snapshot(self):
+        """the raw parameters as the coming forward will read them (strides kept: a channels_last weight stays channels_last)"""
+        self.raw_w = self.layer._parameters["weight"].detach().cpu()
+        b = self.layer._parameters.get("bias")
+        self.raw_b = None if b is None else b.detach().cpu()
+        self.grad_eff = None
+        self.read_this_step = False
+
+    def read(self, w, b, training):
+        """the layer's forward read its parameters: step the twins on the raw values, compare what the layer got"""
+        tag = (self.name, self.reads)
+        assert not self.read_this_step, ("a second read in one forward is not part of this harness", tag)
+        self.read_this_step = True
+        n_before = self.psim.n_updates
+        h = self.psim.step(self.raw_w, training)
+        self.active = (not training) or self.psim.mask.numel() == 1 or n_before >= self.psim.start
+        y = self.qsim.step(h.contiguous(), training) if self.qsim is not None else h
+        got = w.detach().cpu()
+        assert got.dtype == y.dtype and same(got.contiguous(), y.contiguous()), ("effective weight", tag)
+        if b is not None:
+            yb = self.bsim.step(self.raw_b, training) if self.bsim is not None else self.raw_b
+            assert same(b.detach().cpu(), yb), ("effective bias", tag)
+        if training and w.requires_grad:
+            # (the hand-out node of the multi-tensor path leaves the gradients of unused members undefined: a hook can see None)
+            w.register_hook(lambda g: setattr(self, "grad_eff", g.detach().cpu()) if g is not None else None)
+        self.reads += 1
+
+    def check_state(self, step):
+        """after the root's forward: the layer's whole state against the twins' -- whether or not it was read on this step"""
+        tag = (self.name, step, "read" if self.read_this_step else "not read")
+        p, ps = self.layer.prune, self.psim
+        assert isinstance(p, PruneLayer)
+        if ps.mask is None:
+            assert not p.initted or p._n_updates.item() == 0, ("untouched prune operator", tag)
+        else:
+            assert same(p.mask.detach().cpu().contiguous(), ps.mask.contiguous()), ("mask", tag)
+            assert p._n_updates.item() == ps.n_updates, ("prune _n_updates", tag, p._n_updates.item(), ps.n_updates)
+            assert p._cur_sparsity.item() == ps.cur_sparsity, ("_cur_sparsity", tag)
+            t = p.callback.t
+            assert (t.item() if isinstance(t, torch.Tensor) else int(t)) == ps.t, ("callback t", tag)
+            if ps.magnitude is not None:
+                assert same(p.callback.magnitude.detach().cpu().contiguous(), ps.magnitude.contiguous()), ("magnitude", tag)
+        for q, sim, what in ((getattr(self.layer, "quantize", None), self.qsim, "weight"),
+                             (getattr(self.layer, "quantize_bias", None), self.bsim, "bias")):
+            if sim is None:
+                continue
+            assert isinstance(q, QuantizeLayer)
+            if "_n_updates" not in q._parameters:        # never read so far: the layer creates its state on its first read
+                assert sim.n_updates == 0 and not sim.quantized, (what + " untouched quantizer", tag)
+                continue
+            assert q._n_updates.item() == sim.n_updates, (what + " quantizer _n_updates", tag)
+            assert bool(q._quantized) == sim.quantized, (what + " quantizer _quantized", tag)
+            assert int(q.callback.t) == sim.shared["t"], (what + " quantizer t", tag)
+            if sim.weight is not None and sim.n_updates > 0:
+                assert same(q.weight.detach().cpu(), sim.weight), (what + " scale", tag)
+
+    def check_grad(self, step):
+        """after the backward: the raw weight's gradient = mask * STE-clamp(gradient of the effective weight)"""
+        raw = self.layer._parameters["weight"]
+        if not self.read_this_step or self.grad_eff is None:
+            return
+        g = self.grad_eff.contiguous()
+        gin = self.qsim.grad(g, g.dtype) if self.qsim is not None else g
+        gin = self.psim.grad(gin, self.active)
+        assert raw.grad is not None, ("no gradient", self.name, step)
+        got = raw.grad.detach().cpu().contiguous()
+        assert got.dtype == gin.dtype and same(got, gin.contiguous()), ("raw weight gradient", self.name, step)
+
+
+class Recorder:
+    """records the parameter reads of every Conv2d / Linear forward (same reads, same order as the stock forwards: weight, then
+    bias) and forwards them to the layers' twins"""
+
+    def __init__(self, monkeypatch, twins):
+        self.by_layer = {id(t.layer): t for t in twins}
+        rec = self
+
+        def conv_forward(self, input):
+            w, b = self.weight, self.bias
+            rec.seen(self, w, b)
+            return self._conv_forward(input, w, b)
+
+        def linear_forward(self, input):
+            w, b = self.weight, self.bias
+            rec.seen(self, w, b)
+            return F.linear(input, w, b)
+
+        monkeypatch.setattr(nn.Conv2d, "forward", conv_forward)
+        monkeypatch.setattr(nn.Linear, "forward", linear_forward)
+
+    def seen(self, layer, w, b):
+        twin = self.by_layer.get(id(layer))
+        if twin is not None:
+            twin.read(w, b, layer.training)
+
+
+def run(monkeypatch, net, shape, classes, prune, quantizer, device, channels_last, steps, script=None, expect_batched=None):
+    model = build(net, prune, quantizer, device, channels_last)
+    twins = [WeightTwin(name, m, prune, quantizer) for name, m in model.named_modules()
+             if isinstance(getattr(m, "prune", None), PruneLayer) and "weight" in getattr(m, "_parameters", {})]
+    if expect_batched is not None:
+        wb = model.__dict__["_qs_weight_batcher"]
+        assert len(wb.layers) == expect_batched == len(twins), (len(wb.layers), len(twins))
+    Recorder(monkeypatch, twins)
+    if device == "cuda":                     # which entry points served the run (the multi-tensor ones must have, see the tests)
+        from qsparse_amd import _hip
+        for fn in MULTI + PER_LAYER:
+            real = getattr(_hip, fn)
+            monkeypatch.setattr(_hip, fn, (lambda name, f: (lambda *a, **k: (CALLS.__setitem__(name, CALLS.get(name, 0) + 1), f(*a, **k))[1]))(fn, real))
+    CALLS.clear()
+    g = torch.Generator().manual_seed(3)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                 # the staged mean's bits are ATen's with ONE intra-op thread
+    try:
+        for s in range(steps):
+            mode = script(model, s) if script is not None else "train"
+            model.train(mode != "eval")
+            x = torch.randn(shape, generator=g).to(device)
+            if channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            y = torch.randint(0, classes, (shape[0],), generator=g).to(device)
+            for prm in model.parameters():
+                prm.grad = None
+            for t in twins:
+                t.snapshot()
+            if mode == "eval":
+                with torch.no_grad():
+                    model(x)
+                for t in twins:
+                    t.check_state(s)
+                continue
+            out = model(x)
+            for t in twins:
+                t.check_state(s)
+            if mode == "train":
+                F.cross_entropy(out.float(), y).backward()
+                for t in twins:
+                    t.check_grad(s)
+            with torch.no_grad():                # seeded pseudo-update: the parameters keep moving whatever the convolutions round to
+                for prm in model.parameters():
+                    if prm.requires_grad:
+                        prm.add_(torch.randn(prm.shape, generator=g).to(device) * 0.02)
+    finally:
+        torch.set_num_threads(threads)
+    return model, twins
+
+
+def branchy_script(model, s):
+    model.route = "left" if s % 3 else "right"          # the skipped branch is rolled back (counters, magnitudes, masks)
+    if s in (6, 11):
+        return "eval"
+    return "forward_only" if s == 9 else "train"
+
+
+def _branchy_checks(model, twins):
+    by = {t.name: t for t in twins}
+    assert by["left"].reads > by["right"].reads > 0 and by["stem"].reads == 16
+    assert 0.3 < 1.0 - by["stem"].psim.mask.float().mean().item() < 0.7          # the masks did prune
+
+
+def test_harness_on_the_cpu_path(monkeypatch):
+    """the harness itself on the package's CPU path (no GPU needed): every prune policy, two quantizer set-ups"""
+    for prune in PRUNES:
+        for quantizer in ("default", "decimal_dim0_bias", "none"):
+            with monkeypatch.context() as mp:
+                model, twins = run(mp, Branchy, (4, 3, 10, 10), 5, prune, quantizer, "cpu", False, 16, branchy_script)
+                _branchy_checks(model, twins)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("quantizer", list(QUANTS))
+@pytest.mark.parametrize("prune", list(PRUNES))
+def test_branchy_pruned_weights_vs_oracle(monkeypatch, prune, quantizer, channels_last):
+    model, twins = run(monkeypatch, Branchy, (4, 3, 10, 10), 5, prune, quantizer, "cuda", channels_last, 16, branchy_script,
+                       expect_batched=5)
+    _branchy_checks(model, twins)
+    _served_by_the_table(prune, quantizer, steps=16)
+
+
+def _served_by_the_table(prune, quantizer, steps):
+    """the run above really went through the multi-tensor entry points: one hand-out launch per forward; with a policy that
+    averages / re-ranks on every read, one qs_multi_magnitude / qs_multi_mask_refresh per forward past the schedule -- and the
+    per-layer select only on the two reads that change the sparsity"""
+    dims, cbkw = PRUNES[prune]
+    assert CALLS.get("multi_quant_fwd", 0) >= steps - 3, CALLS
+    if not cbkw:                                    # the stock callback: every read past `start` re-ranks
+        assert CALLS.get("multi_mask_refresh", 0) >= steps - 8, CALLS
+        if dims != {0, 1, 2, 3}:
+            assert CALLS.get("multi_stage_mean", 0) >= steps - 8, CALLS
+    if cbkw.get("running_average", True):
+        assert CALLS.get("multi_magnitude", 0) >= 3, CALLS
+    if QUANTS[quantizer] is not None and QUANTS[quantizer][3] < steps - 2:
+        assert CALLS.get("multi_absmax", 0) >= 3 and CALLS.get("multi_ste_bwd", 0) >= 3, CALLS
+
+
+RN50_CASES = [("full_default", "default", False), ("full_default", "default", True), ("channel_default", "default", False),
+              ("channel_default", "default", True), ("channel_default", "none", False), ("subset_noavg", "decimal_dim0_bias", False),
+              ("full_avg", "scaler", True), ("rows_noavg", "late", False)]
+
+
+def test_resnet50_harness_on_the_cpu_path_miniature(monkeypatch):
+    run(monkeypatch, lambda: resnet50(10, False, 8), (2, 3, 32, 32), 10, "channel_default", "default", "cpu", False, 7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prune,quantizer,channels_last", RN50_CASES)
+def test_resnet50_full_width_pruned_weights_vs_oracle(monkeypatch, prune, quantizer, channels_last):
+    """BASELINE config 4's network at its real width: 53 convolutions + the classifier, masks of up to 2,359,296 entries
+    (`full_*`), per-input-channel / per-filter / per-(filter, channel) masks whose importance is a staged mean; small images
+    (the weights are what is under test)"""
+    model, twins = run(monkeypatch, lambda: resnet50(1000, False, 64), (2, 3, 64, 64), 1000, prune, quantizer, "cuda", channels_last, 8,
+                       expect_batched=54)
+    assert len(twins) == 54 and all(t.reads == 8 for t in twins)
+    _served_by_the_table(prune, quantizer, steps=8)
+    if PRUNES[prune][0] == {0, 1, 2, 3}:
+        assert max(t.psim.mask.numel() for t in twins) == 2359296
+    sparsity = [1.0 - t.psim.mask.float().mean().item() for t in twins if t.psim.mask.numel() >= 64]
+    assert all(0.4 < s < 0.6 for s in sparsity), sparsity
