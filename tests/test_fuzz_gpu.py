@@ -56,7 +56,7 @@ def test_converted_weight_networks_cpu_path_against_hip_path():
     rng = random.Random(2028)
     bad = [r for r in (fz.one_case(rng, i) for i in range(100)) if r not in ("ok", None)]
     assert not bad, bad[:3]
-    assert fz.ENGAGED[0] >= 60, fz.ENGAGED[0]
+    assert fz.ENGAGED[0] >= 30, fz.ENGAGED[0]     # (Adaptive quantizers and timeout=0 layers keep the inline path)
 
 
 def test_functional_api_cpu_path_against_hip_path():
