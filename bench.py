@@ -116,11 +116,12 @@ def cpu_baseline(batch=None, reps=3, threads=None):
     multi = _cpu_steps(batch, reps, cores)
     single = _cpu_steps(min(32, batch), 2, 1)
     what = "the headline tensor itself" if batch == SHAPE[0] else f"a {batch}-sample slice of the headline tensor"
-    return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
+    return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": "port",
             "value_1thread": round(single, 4),
-            "sample": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on {what} "
-                      f"({batch}x256x56x56 bf16), min of {reps} after 2 warm-up steps ({cores} threads); "
-                      f"{min(32, batch)}x256x56x56, best of 2 (1 thread); torch {torch.__version__} CPU"}
+            "sample": f"{batch}x256x56x56 bf16 ({what}), oracle PruneSim->QuantizeSim train fwd+bwd, min of {reps}, {cores} thr",
+            "sample_detail": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on {what} "
+                             f"({batch}x256x56x56 bf16), min of {reps} after 2 warm-up steps ({cores} threads of {os.cpu_count()} "
+                             f"host cores); {min(32, batch)}x256x56x56, best of 2 (1 thread); torch {torch.__version__} CPU"}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -589,6 +590,38 @@ def extra_configs(device, only=None):
     return out
 
 
+def config5_warm(device, rank):
+    """rank-local, collective-free warm-up of config 5: one training step of the plain and of the converted ResNet-50 at the
+    config's batch, so that MIOpen's algorithm search and kernel compilation (69.6 s on a fresh box at N = 1, more with eight
+    ranks tuning side by side) happen BEFORE the deadline of the collective phase is armed.  The statistics exchange is
+    switched off here -- nothing in this function may wait for another rank."""
+    import qsparse_amd as qs
+    from examples.models import convert_pq, resnet50
+
+    batch = int(os.environ.get("QS_BENCH_DDP_BATCH", "256"))
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    x = torch.randn((batch, 3, 224, 224), generator=g, device=device).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 1000, (batch,), generator=g, device=device)
+    before = qs.get_qsparse_option("sync_statistics")
+    qs.set_qsparse_options(sync_statistics=False)
+    try:
+        for pq in (False, True):
+            torch.manual_seed(0)
+            model = resnet50(1000, False)
+            if pq:
+                model = convert_pq(model, sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+            model = model.to(device).to(memory_format=torch.channels_last).train()
+            for _ in range(3 if pq else 2):        # (inactive -> live -> steady: every kernel variant the timed steps use)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = F.cross_entropy(model(x).float(), y)
+                loss.backward()
+            torch.cuda.synchronize()
+            del model, loss
+            torch.cuda.empty_cache()
+    finally:
+        qs.set_qsparse_options(sync_statistics=before)
+
+
 def config5(device, world, rank, steps=5):
     """BASELINE config 5 (N > 1 only): full-width ResNet-50 on synthetic ImageNet-shape data, 4-bit weights and
     activations + 75 % channel pruning (the --pq recipe), bf16 autocast, channels_last, one process per GPU under
@@ -782,10 +815,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     events = {kname: [a.elapsed_time(b) for a, b in pairs] for kname, pairs in events.items()}
+    ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if world > 1 or force_exchange:       # "did the collective library see N ranks": an all-reduce of ones, in the record
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
 
     # the other two elision modes, outside the timed region, on rank 0's clock (continuity with round 1: "off" is the
     # dense 14 B/elem step; "all" also elides the backward, which then writes +0.0 for the reference's -0.0)
@@ -855,17 +893,27 @@ def main():
             "value": round(value, 3), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "prune(0.75,dims={1})->quantize(4-bit,tensor-wise) train fwd+bwd, live mask+scale "
-                                   "statistics every step, 256x256x56x56 bf16 in / fp32 out / fp32 grad in / bf16 grad out "
-                                   "per GPU (SURVEY 8d scope ii)",
+            # (the driver's parser keeps flat scalar keys and the first 128 characters of a string: shape first, short)
+            "config": {"workload": "256x256x56x56 bf16 per GPU: prune(0.75,{1})->quantize(4b) train fwd+bwd, live mask+scale",
+                       "shape": "x".join(str(d) for d in SHAPE), "io_dtypes": "bf16 x, f32 y, f32 grad_y, bf16 grad_x",
                        "shape_per_gpu": list(SHAPE), "fused": True, "elide_pruned": mode,
                        "kept_channel_fraction": round(kept, 4),
+                       "step_bytes_per_elem": round(step_bpe, 4), "dense_step_bytes_per_elem": 14.0,
                        "algorithmic_bytes_per_elem": {"step": round(step_bpe, 4), "stats": 2.0, "apply_fwd": round(fwd_bpe, 4),
                                                       "apply_bwd": round(bwd_bpe, 4), "dense_step": 14.0},
                        "step_frac_of_hbm_peak": round(step_bpe * numel / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roof,
         }
+        for kname, rec in kern.items():            # flat copies of the per-kernel figures (nested objects do not survive the parser)
+            roof[kname + "_ms"], roof[kname + "_frac"], roof[kname + "_bytes_per_elem"] = rec["ms"], rec["frac"], rec["bytes_per_elem"]
         if variants:
+            cfg = out["config"]
+            for m, key in (("off", "dense"), ("all", "elide_all"), ("forward", "elide_forward"), ("frozen_mask", "frozen_mask")):
+                if m in variants:
+                    cfg[key + "_ms_per_step"] = round(variants[m], 4)
+                    cfg[key + "_gelem_s"] = round(numel / variants[m] / 1e6, 1)
+            if "off" in variants:       # the dense step, 14 B/elem: the figure comparable with BASELINE.md's byte accounting
+                cfg["dense_frac_of_hbm_peak"] = round(14.0 * numel / (variants["off"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             out["config"]["variants"] = {
                 m: {"ms_per_step": round(ms, 4), "Gelem/s": round(numel / ms / 1e6, 1),
                     "note": {"off": "dense: every element loaded, 14 B/elem (round-1 record)",
@@ -875,6 +923,8 @@ def main():
                                             "scale live -- statistics are the per-channel abs-max alone"}[m]}
                 for m, ms in variants.items()}
         if world > 1 or force_exchange:
+            out["config"]["ranks_seen"] = ranks_seen
+            out["config"]["backend"] = dist.get_backend()
             out["config"]["exchange"] = ("one all-gather of a 2C-float record per step over " +
                                          ("gloo (shared GPU, development)" if share_gpu else "RCCL") +
                                          (" in a ONE-rank group (QS_BENCH_FORCE_EXCHANGE)" if force_exchange else ""))
@@ -895,7 +945,9 @@ def main():
         del pair, x, gout
         torch.cuda.empty_cache()
         limit = float(os.environ.get("QS_BENCH_DDP_TIMEOUT", "480"))
+        warm_limit = float(os.environ.get("QS_BENCH_DDP_WARM_TIMEOUT", "600"))
         t5 = time.perf_counter()
+        phase = ["warm-up (MIOpen search, rank-local)", warm_limit]
 
         def bark():
             # a rank failed or hung inside a collective: the headline (measured before config 5 started) is still written,
@@ -903,18 +955,31 @@ def main():
             with emit_lock:
                 if rank == 0 and "configs" not in out:
                     out["degraded"] = True
-                    out["configs"] = {"config5_resnet50_ddp": {"error": f"did not finish within {limit:.0f} s (a rank failed "
-                                                                        f"or hung); the headline record is unaffected"}}
+                    out["configs"] = {"config5_resnet50_ddp": {"error": f"{phase[0]} did not finish within {phase[1]:.0f} s (a rank "
+                                                                        f"failed or hung); the headline record is unaffected"}}
             emit()
             os._exit(3)
 
-        watchdog = threading.Timer(limit, bark)
+        watchdog = threading.Timer(warm_limit, bark)
         watchdog.daemon = True
         watchdog.start()
+        warm_s = None
         try:
+            # phase 1, no collectives: every rank tunes and compiles on its own; the deadline of the collective phase is armed
+            # only when all ranks are through (the barrier is inside phase 1's deadline)
+            config5_warm(device, rank)
+            torch.cuda.synchronize()
+            dist.barrier()
+            warm_s = round(time.perf_counter() - t5, 1)
+            watchdog.cancel()
+            phase[:] = ["the DDP phase", limit]
+            watchdog = threading.Timer(limit, bark)
+            watchdog.daemon = True
+            watchdog.start()
             rec5 = config5(device, world, rank)
         except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
             rec5 = {"error": f"{type(e).__name__}: {e}"[:400]}
+        rec5["warmup_seconds"] = warm_s
         rec5["bench_seconds"] = round(time.perf_counter() - t5, 1)
         if rank == 0:
             with emit_lock:

@@ -343,28 +343,41 @@ def note_gate(bits: torch.Tensor):
 
 ACT_RELU, ACT_HARDTANH, ACT_LEAKY = 1, 2, 3
 _act_handles = {}
+_act_specs = {}          # handle -> (kind, a, b)
 
 
 def activation(kind: int, a: float = 0.0, b: float = 0.0) -> int:
     """handle of a folded activation (qs_activation): what the `pre_relu` arguments below take besides False / True"""
     key = (kind, float(a), float(b))
     h = _act_handles.get(key)
+    if h == 0:
+        raise QsparseHipError(f"qs_activation{key}: the library could not intern this descriptor earlier in this process")
     if h is None:
         h = load().qs_activation(kind, float(a), float(b))
         if h < 0:
             _check(h, "qs_activation")
         _act_handles[key] = h
+        _act_specs[h] = key
     return h
+
+
+def try_activation(kind: int, a: float = 0.0, b: float = 0.0) -> int:
+    """`activation`, or 0 -- "not foldable" -- where the library cannot intern the descriptor (its 256-entry table is full,
+    NaN parameters): the site then runs the activation module by itself, q(p(act(x))), instead of failing the forward"""
+    if _act_handles.get((kind, float(a), float(b))) == 0:
+        return 0
+    try:
+        return activation(kind, a, b)
+    except QsparseHipError:
+        _act_handles[(kind, float(a), float(b))] = 0
+        return 0
 
 
 def act_spec(handle: int):
     """(kind, a, b) of a handle made by `activation` (1: nn.ReLU)"""
     if handle == 1:
         return (ACT_RELU, 0.0, 0.0)
-    for key, h in _act_handles.items():
-        if h == handle:
-            return key
-    raise KeyError(handle)
+    return _act_specs[handle]
 
 
 class _ActivationFromOutput(torch.autograd.Function):
@@ -1034,10 +1047,22 @@ def _device_stream(device):
     return _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
 
 
+def _upload_table(host, n, device) -> torch.Tensor:
+    """device copy of a launch table (a few KB).  A blocking copy from pageable memory: it happens once per launch plan (a plan
+    is built when a set of layers, their mode or their due operators change), never in a steady-state step.  It cannot be part of
+    a hipGraph capture -- a plan that has to be built while the stream is capturing is refused with a clear message instead of
+    the capture error of the copy itself (run one eager step in that mode first: graphs.GraphedStep does)."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise QsparseHipError("the weight path has to build a launch table, which cannot happen inside a hipGraph capture: run one "
+                              "eager step in this mode (training / evaluation, same set of due operators) before capturing")
+    raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8) if n else torch.zeros(0, dtype=torch.uint8)
+    return raw.to(device)
+
+
 class MultiTable:
     """a `qs_multi_row` table: the host copy (a ctypes array the caller fills), the derived launch totals and the device
-    copy the kernels read.  Built once per set of layers; `set_train` rewrites the one per-step field and re-uploads (a few KB,
-    asynchronously) only when it changed."""
+    copy the kernels read.  Built once per set of layers; `set_train` rewrites the one per-step field and re-uploads (a few KB)
+    only when it changed."""
 
     def __init__(self, rows, device):
         self.n = len(rows)
@@ -1051,9 +1076,7 @@ class MultiTable:
         self.upload()
 
     def upload(self):
-        raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8) if self.n else torch.zeros(0, dtype=torch.uint8)
-        # pinned staging + non_blocking copy: stream-ordered with the launches that read the table
-        self.dev = raw.to(self.device, non_blocking=False)
+        self.dev = _upload_table(self.host, self.n, self.device)
 
     def __deepcopy__(self, memo):
         raise TypeError("a launch table holds raw device pointers: rebuild it, never copy it")
@@ -1074,7 +1097,7 @@ class StageTable:
         blocks = c_int(0)
         _check(load().qs_multi_stage_plan(self.host, self.n, ctypes.byref(blocks)), "qs_multi_stage_plan")
         self.blocks, self.device = blocks.value, device
-        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+        self.dev = _upload_table(self.host, self.n, device)
 
     def __deepcopy__(self, memo):
         raise TypeError("a launch table holds raw device pointers: rebuild it, never copy it")

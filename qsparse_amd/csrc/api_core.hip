@@ -276,6 +276,22 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
     }
     if (!p->mask || !p->scale) return QS_ERR_ARG;
     const int64_t hw = p->H * p->W;
+    // the apply launch's operands, fixed by the plan and the flags alone: validated BEFORE the statistics and select launches
+    // advance magnitude, mask, scale and counters -- a routing the apply kernels do not serve must not leave the state one step
+    // ahead of a call that failed
+    const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
+    const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
+    const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
+    const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
+    // a step with statistics elides through the select's elision mask: pruned channels that hold a NaN / Inf are loaded, so the
+    // result is the loading path's for every input; an eliding step without statistics (the caller's choice) has only the mask
+    if (elide && (flags & QS_SITE_LIVE) && p->elide_mask) cm = p->elide_mask;
+    if (image_out || xback_out) {
+        if (!gate_out || p->ydt != QS_F32 || (xback_out && (!pre_relu || (((uintptr_t)xback_out) & 15u))) ||
+            (image_out && ((imgdt != QS_BF16 && imgdt != QS_F16) || (((uintptr_t)image_out) & 15u))) ||
+            !qs_quant_image_ok(o, c, in, 0, cm != nullptr, (((uintptr_t)cm) & 7u) == 0, p->xdt))
+            return QS_ERR_ARG;
+    }
     if (flags & QS_SITE_LIVE) {
         if (flags & QS_SITE_NO_MASK) return QS_ERR_ARG;
         if (flags & QS_SITE_SCALE_ONLY) {      // frozen mask: per-channel abs-max, then the select's scale half alone
@@ -303,13 +319,6 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
         if (st) return st;
         }
     }
-    const uint8_t* cm = (flags & QS_SITE_NO_MASK) ? nullptr : p->mask;
-    const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
-    const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
-    const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
-    // a step with statistics elides through the select's elision mask: pruned channels that hold a NaN / Inf are loaded, so the
-    // result is the loading path's for every input; an eliding step without statistics (the caller's choice) has only the mask
-    if (elide && (flags & QS_SITE_LIVE) && p->elide_mask) cm = p->elide_mask;
     if (decimal) {             // DecimalQuantizer: the power-of-two step of THIS call's scale (quantize.py:316)
         int st = qs_decimal_from_scale(p->scale, decimal, 1, stream);
         if (st) return st;

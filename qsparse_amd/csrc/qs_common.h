@@ -64,8 +64,12 @@ __device__ __forceinline__ float round_to_dtype(float v, int dt) {   // value af
 __device__ __forceinline__ float act_apply(float v, const ActSpec& s, int dt) {
     if (s.kind == QS_ACT_RELU) return relu_aten(v);
     if (s.kind == QS_ACT_HARDTANH) {       // vec::clamp = minimum(b, maximum(a, x)): NaN passes, -0.0 survives a = +0.0
-        const float t = (v < s.a) ? s.a : v;
-        return (t > s.b) ? s.b : t;
+        // ATen's clamp converts its scalar bounds to the tensor's dtype first (clamp_scalar_kernel: min.to<scalar_t>()): a bound
+        // that bf16 / fp16 cannot represent (0.1, 0.7) saturates at its ROUNDED value, which is what the statistics, the mask
+        // product and the quotient then see.  (hardtanh_backward compares with the unrounded float bounds: act_open below.)
+        const float a = round_to_dtype(s.a, dt), b = round_to_dtype(s.b, dt);
+        const float t = (v < a) ? a : v;
+        return (t > b) ? b : t;
     }
     if (s.kind == QS_ACT_LEAKY) return (v > 0.0f) ? v : round_to_dtype(v * s.a, dt);
     return v;

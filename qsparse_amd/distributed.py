@@ -57,16 +57,28 @@ def allreduce_min_(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor
     return t
 
 
+# `ProcessGroup._allgather_base` is what all_gather_into_tensor itself ends in on the torch versions this package was measured
+# with (2.10); anything else takes the public call
+_PRIVATE_ALLGATHER = tuple(int(v) for v in torch.__version__.split("+")[0].split(".")[:2] if v.isdigit()) in ((2, 9), (2, 10), (2, 11))
+
+
 def all_gather_records(gathered: torch.Tensor, record: torch.Tensor):
     """the one collective of a data-parallel site step: every rank's 2C-float record into `gathered` ([world * 2C], rank
     order).  RCCL over xGMI is point-to-point and a 2 KB all-gather is latency-bound at any world size: ONE collective per
     site is what matters (the records hold importance and abs-max together)."""
-    pg = dist.group.WORLD
-    base = getattr(pg, "_allgather_base", None)
-    if base is None:
-        dist.all_gather_into_tensor(gathered, record)
-    else:       # the process group's own entry point: the public wrapper's argument checks cost ~7 us per call, seventeen times a step
-        base(gathered, record).wait()
+    global _PRIVATE_ALLGATHER
+    if _PRIVATE_ALLGATHER:
+        # the process group's own entry point: the public wrapper's argument checks cost ~7 us per call, seventeen times a step.
+        # A private name: any surprise (another torch, a wrapped or fake process group, a changed signature) switches to the
+        # public call for good -- BEFORE anything was exchanged, so the step's statistics are still those of this rank alone
+        try:
+            work = dist.group.WORLD._allgather_base(gathered, record)
+        except (TypeError, AttributeError, NotImplementedError, RuntimeError):
+            _PRIVATE_ALLGATHER = False
+        else:
+            work.wait()
+            return
+    dist.all_gather_into_tensor(gathered, record)
 
 
 def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int,

@@ -650,9 +650,9 @@ def _fold_handle(act) -> int:
     if t is nn.ReLU:
         return 1
     if t in (nn.ReLU6, nn.Hardtanh):       # (nn.ReLU6 is a Hardtanh with min_val = 0, max_val = 6)
-        return _hip.activation(_hip.ACT_HARDTANH, float(act.min_val), float(act.max_val))
+        return _hip.try_activation(_hip.ACT_HARDTANH, float(act.min_val), float(act.max_val))
     if t is nn.LeakyReLU and act.negative_slope > 0:
-        return _hip.activation(_hip.ACT_LEAKY, float(act.negative_slope))
+        return _hip.try_activation(_hip.ACT_LEAKY, float(act.negative_slope))
     return 0
 
 

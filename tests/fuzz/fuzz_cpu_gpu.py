@@ -138,7 +138,7 @@ def build(rng):
         # a `convert`-built activation site (reference convert.py:199-229): activation module -> PruneLayer -> QuantizeLayer, the
         # activation folded into the kernels on the GPU (nn.ReLU / ReLU6 / Hardtanh / LeakyReLU, in place or not), composite or
         # fine-grained route, optional code saturation, masks that freeze (policy "refresh")
-        act = rng.choice(["relu", "relu", "relu6", "hardtanh", "leaky", "identity"])
+        act = rng.choice(["relu", "relu", "relu6", "hardtanh", "hardtanh_odd", "leaky", "identity"])
         inplace = act != "identity" and rng.random() < 0.35
         if act == "leaky" and dtype == torch.float16:
             # ATen's own fp16 leaky_relu_backward differs between its CPU and GPU kernels (a subnormal product on a rounding tie,
@@ -155,7 +155,9 @@ def build(rng):
         cb = pcb()
         desc.update(act=act, inplace=inplace, site=site, saturate=saturate, shape=shape)
         make_act = {"relu": lambda: nn.ReLU(inplace=inplace), "relu6": lambda: nn.ReLU6(inplace=inplace),
-                    "hardtanh": lambda: nn.Hardtanh(-0.75, 1.5, inplace=inplace), "leaky": lambda: nn.LeakyReLU(0.1, inplace=inplace),
+                    "hardtanh": lambda: nn.Hardtanh(-0.75, 1.5, inplace=inplace),
+                    "hardtanh_odd": lambda: nn.Hardtanh(0.1, 0.7, inplace=inplace),       # bounds bf16 / fp16 cannot represent
+                    "leaky": lambda: nn.LeakyReLU(0.1, inplace=inplace),
                     "identity": lambda: nn.Identity()}[act]
 
         def site_factory():
@@ -405,6 +407,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         x.view(-1)[:2] = torch.tensor([0.0, -0.5]).to(dtype)
         if site and x.numel() >= 8:             # the boundary values of the activations' gates
             x.view(-1)[2:8] = torch.tensor([6.0, -0.75, 1.5, 7.5, -3.0, 1e-30]).to(dtype)
+            if x.numel() >= 12:
+                x.view(-1)[8:12] = torch.tensor([0.1, 0.7, 0.69921875, 0.10009765625]).to(dtype)
         x[x == 0] = 0.0             # no -0.0 (see tests/fuzz/fuzz_parity.py)
         if nonfinite is not None and s >= nonfinite[1]:     # a NaN / Inf somewhere -- on a kept or a pruned channel, whichever
             x.view(-1)[(seed * 7919 + s * 31) % x.numel()] = nonfinite[0]
@@ -478,7 +482,7 @@ def one_case(rng, idx, dry=False):
     if desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.3:
         # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
         # act_open -- so the clamping activations get infinities only)
-        values = [float("inf"), float("-inf")] + ([] if desc.get("act") in ("relu6", "hardtanh") else [float("nan")] * 2)
+        values = [float("inf"), float("-inf")] + ([] if desc.get("act") in ("relu6", "hardtanh", "hardtanh_odd") else [float("nan")] * 2)
         nonfinite = (rng.choice(values), rng.choice([steps - 3, steps - 2, steps - 1]))
     # route switches of the HIP path (the CPU path has none of these routes: the results must not depend on them)
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),

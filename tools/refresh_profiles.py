@@ -4,6 +4,8 @@
   rNN_bench_default.json                 the JSON record of a plain `python3 bench.py`
   rNN_bench_kernel_stats.csv             rocprofv3 --kernel-trace --stats summary of the same command
   rNN_bench_step_timeline.txt            the last three headline steps of that trace, kernel by kernel
+  rNN_headline_kernel_stats.csv          the same summary for `python3 bench.py --no-configs --no-variants --no-cpu-baseline`:
+                                         headline kernels only, so the averages are the roofline's per-launch durations
   rNN_configN_kernel_stats.csv           the same summary for `python3 bench.py --configs-only configN` (N = 2, 3, 4)
   rNN_pmc_<COUNTER>_counter_collection.csv   rocprofv3 --pmc <COUNTER> rows of the library's kernels (one pass per counter)
   rNN_pmc_traffic.json                   HBM bytes per launch of the three streaming kernels, corrected as
@@ -23,7 +25,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 MODE_ALL = len(sys.argv) > 2 and sys.argv[2] == "all"
 MODE_GATE = len(sys.argv) > 2 and sys.argv[2] == "gate"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
@@ -88,6 +90,14 @@ def main():
                     f"vgpr={x.get('VGPR_Count', '?')}\n")
             prev_end = e
     shutil.rmtree(d)
+
+    # 2a. the headline alone (no configs, no variants, no CPU baseline): every row of this summary is a headline kernel, so its
+    #     averages ARE the per-launch durations the roofline quotes (the summary of the plain command mixes in configs 2-4)
+    d = os.path.join(OUT, "stats_headline")
+    if sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+           "python3", BENCH, "--no-configs", "--no-variants", "--no-cpu-baseline"]).returncode == 0:
+        shutil.copy(find(os.path.join(d, "**", "*kernel_stats.csv")), os.path.join(OUT, f"{TAG}_headline_kernel_stats.csv"))
+    shutil.rmtree(d, ignore_errors=True)
 
     # 2b. per-config kernel stats (BASELINE configs 2-4), each from its own command
     for cfg in ("config2", "config3", "config4"):
