@@ -619,7 +619,9 @@ def config5_warm(device, rank):
             del model, loss
             torch.cuda.empty_cache()
     finally:
-        qs.set_qsparse_options(sync_statistics=before)
+        from qsparse_amd import util as _u
+        _u._options_["sync_statistics"] = before      # (None = auto is the default; set_qsparse_options(None) would leave False)
+        _u._options_epoch[0] += 1
 
 
 def config5(device, world, rank, steps=5):

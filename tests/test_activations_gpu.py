@@ -53,7 +53,9 @@ def _run(net, dev, data, fmt, inplace):
         if step == len(data) - 1:
             net.eval()
         x0 = x.detach().clone().to(dev).contiguous(memory_format=fmt).requires_grad_(True)
-        h = x0 * 1.0 if inplace else x0              # (an in-place activation needs a non-leaf input, as behind a convolution)
+        # (an in-place activation needs a non-leaf input, as behind a convolution.  A clone, not `x0 * 1.0`: ATen's own fp16 GPU
+        # multiply is compiled to v_fma_mixlo_f16(g, 1.0, +0) and returns +0.0 for a -0.0 gradient -- the CPU's keeps the sign)
+        h = x0.clone() if inplace else x0
         y = net(h)
         y.backward(g.to(dev).to(y.dtype))
         outs.append((y.detach().cpu(), x0.grad.detach().cpu(), h.detach().cpu()))
