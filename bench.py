@@ -371,22 +371,25 @@ def resnet_config(arch, batch, device, steps):
             except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
                 rec = {"options": label, "error": f"{type(e).__name__}: {e}"[:300]}
             finally:
-                qs.set_qsparse_options(preserve_dtype=False, elide_pruned="forward", autocast_image=False)
+                qs.set_qsparse_options(preserve_dtype=False, elide_pruned="forward", autocast_image=True)
                 torch.cuda.empty_cache()
             out[key] = rec
 
         opt_in_run("opt_in_extensions", "preserve_dtype=True, elide_pruned='all'", True, preserve_dtype=True, elide_pruned="all")
-        # the value-identical opt-in: under autocast every fused site hands its first convolution the bf16 image of its
-        # float32 output and takes that convolution's bf16 gradient as it is (fused.py "Autocast image") -- same values as
-        # the default path, no fp32 <-> bf16 cast passes around the site; opt-in because the site's output is a Tensor subclass
-        opt_in_run("value_identical_opt_in", "autocast_image=True (value-identical)", True, autocast_image=True)
+        # the default WITHOUT the autocast image (round 4's default; `set_qsparse_options(autocast_image=False)`): every fused
+        # site returns a plain float32 tensor and its first convolution casts it (fp32 -> bf16 forward, bf16 -> fp32 backward:
+        # two 6 B/elem passes per site).  Since round 5 the site hands that convolution the bf16 image itself and takes its
+        # bf16 gradient as it is (fused.py "Autocast image"): same values, and everything that can observe the output's
+        # gradient sees the whole one
+        opt_in_run("autocast_image_off", "autocast_image=False (plain float32 tensor out of every site: round 4's default)", True,
+                   autocast_image=False)
         # every element loaded.  The default elides only where a pruned channel is a skippable row (NCHW, no gate recording; exact
         # for non-finite inputs as well since ABI v19), so in this channels_last training step "off" and the default run the
         # same kernels: the figure is the evidence of that
         opt_in_run("elide_off", "elide_pruned='off' (every element loaded; the channels_last default already does)", False,
                    elide_pruned="off")
     finally:
-        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward", autocast_image=False)
+        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, elide_pruned="forward", autocast_image=True)
         torch.cuda.empty_cache()
     return out
 

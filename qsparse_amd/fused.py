@@ -271,15 +271,98 @@ _IMAGE_CONSUMERS = _image_consumers()
 _GRADIENT_OBSERVERS = frozenset([torch.Tensor.register_hook, torch.Tensor.retain_grad])
 
 
+def _whole(g, g16):
+    """autograd's own accumulation of the two gradient streams of a site's output: float32 consumers + the image's consumer"""
+    if g16 is None:
+        return g
+    return g16.float() if g is None else g + g16.float()
+
+
+def _late_hook(dual, fn):
+    """`register_hook` on a site's output AFTER its image was taken: the hook must see the WHOLE gradient of the output, of which
+    the image consumer's share never passes through the tensor -- so it runs as a pre-hook of the site's backward node, which
+    holds both streams.  A hook that only looks (returns None) leaves the fast route untouched; one that returns a
+    replacement turns the step into the plain one: (replacement, no second stream)."""
+    node = dual.__dict__["_qs_node"]
+
+    def pre(grads):
+        g, g16 = grads
+        full = _whole(g, g16)
+        if full is None:
+            return None
+        r = fn(full)
+        if r is None:
+            return None
+        if g is None:
+            raise RuntimeError("a gradient hook registered on a site's output after its autocast image was consumed cannot REPLACE a "
+                               "gradient that only the image's consumer delivers: register the hook before the consumer runs, or "
+                               "set_qsparse_options(autocast_image=False)")
+        return (r, None)
+
+    return node.register_prehook(pre)
+
+
+def _late_retain_grad(dual):
+    import weakref
+    torch.Tensor.retain_grad(dual)
+    ref, node = weakref.ref(dual), dual.__dict__["_qs_node"]
+
+    def pre(grads):
+        d = ref()
+        if d is not None and grads[1] is not None:
+            with torch.no_grad():
+                d.grad = _whole(grads[0], grads[1])      # (the tensor's own retain-grad hook has stored the float32 share by now)
+        return None
+
+    node.register_prehook(pre)
+
+
+def _grad_through_duals(args, kwargs):
+    """`torch.autograd.grad(outputs, inputs, ...)` with a site's output among `inputs` after its image was taken: differentiate
+    with respect to the image as well and add the two shares (float32 accumulation, as autograd itself would)"""
+    kwargs = dict(kwargs or {})
+    args = list(args)
+    inputs = kwargs.pop("inputs") if "inputs" in kwargs else args.pop(1)
+    outputs = kwargs.pop("outputs") if "outputs" in kwargs else args.pop(0)
+    single = isinstance(inputs, torch.Tensor)
+    ins = [inputs] if single else list(inputs)
+    extra = [(i, t.__dict__["_qs_image_taken"]) for i, t in enumerate(ins)
+             if type(t) is AutocastImageTensor and t.__dict__.get("_qs_image_taken") is not None]
+    if not extra:
+        return torch.autograd.grad(outputs, inputs, *args, **kwargs)
+    allow_unused = kwargs.pop("allow_unused", None)
+    materialize = kwargs.pop("materialize_grads", False)
+    res = list(torch.autograd.grad(outputs, ins + [img for _, img in extra], *args, allow_unused=True, **kwargs))
+    shares = res[len(ins):]
+    res = res[:len(ins)]
+    for (i, _), g16 in zip(extra, shares):
+        res[i] = _whole(res[i], g16)
+    for i, r in enumerate(res):
+        if r is None:
+            if materialize:
+                res[i] = torch.zeros_like(ins[i].as_subclass(torch.Tensor))
+            elif not allow_unused:
+                raise RuntimeError("One of the differentiated Tensors appears to not have been used in the graph. Set allow_unused=True "
+                                   "if this is the desired behavior.")
+    return tuple(res)
+
+
 class AutocastImageTensor(torch.Tensor):
-    """float32 output of a quantize site that also carries its low-precision image for ONE autocast consumer"""
+    """float32 output of a quantize site that also carries its low-precision image for ONE autocast consumer.  Everything that
+    can OBSERVE the output's gradient sees the whole gradient: `register_hook` / `retain_grad` before the image is taken cancel
+    it; after it was taken they, and `torch.autograd.grad(..., inputs=[output])`, combine the two streams (`_late_hook`)."""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         with torch._C.DisableTorchFunctionSubclass():
             if func in _GRADIENT_OBSERVERS and args and type(args[0]) is cls:
-                # someone wants to SEE this tensor's gradient: it must be the whole one, so no consumer may bypass it
-                args[0].__dict__.pop("_qs_image", None)
+                # someone wants to SEE this tensor's gradient: it must be the whole one
+                d = args[0].__dict__
+                if d.pop("_qs_image", None) is None and d.get("_qs_image_taken") is not None and d.get("_qs_node") is not None:
+                    # ... and a consumer has already bypassed the tensor: observe at the site's backward node instead
+                    if func is torch.Tensor.retain_grad:
+                        return _late_retain_grad(args[0])
+                    return _late_hook(args[0], *args[1:], **(kwargs or {}))
             elif func in _IMAGE_CONSUMERS and args and type(args[0]) is cls:
                 held = args[0].__dict__.get("_qs_image")
                 if held is not None:
@@ -287,13 +370,35 @@ class AutocastImageTensor(torch.Tensor):
                     if (args[0]._version == version and torch.is_autocast_enabled("cuda")
                             and torch.get_autocast_dtype("cuda") == img.dtype):
                         del args[0].__dict__["_qs_image"]       # one consumer only: a second one casts for itself, as before
+                        if img.requires_grad:
+                            args[0].__dict__["_qs_image_taken"] = img
                         plan.image_used = True
                         args = (img,) + tuple(args[1:])
+            elif func is torch.autograd.grad:
+                return _grad_through_duals(args, kwargs)
             return func(*args, **(kwargs or {}))
 
     def __repr__(self):
         with torch._C.DisableTorchFunctionSubclass():
             return torch.Tensor.__repr__(self.as_subclass(torch.Tensor))
+
+    # copies and pickles are plain tensors: the image (and the site plan behind it) belongs to THIS forward pass
+    def __deepcopy__(self, memo):
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__deepcopy__(memo)
+
+    def __reduce_ex__(self, proto):
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
+
+
+def _as_dual(y, img, plan):
+    """the site's float32 output as the subclass that carries its image to the first autocast consumer"""
+    plan.image_made = True
+    dual = y.as_subclass(AutocastImageTensor)
+    dual.__dict__["_qs_image"] = (img, y._version, plan)
+    dual.__dict__["_qs_node"] = y.grad_fn        # the site's backward node: both gradient streams arrive there (None: no grad)
+    return dual
 
 
 def _image_dtype(plan, training_needs_gate: bool):
@@ -581,15 +686,10 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                               p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world)
         if live or frozen:
             _disarm_accumulators(q)
-        # (what `_FastPair.arm` looks at: a steady-state step of the composite route, no exchange, no image)
-        q.__dict__["_qs_last_route"] = (("live" if live else "frozen") if ((live or frozen) and site_gathered is None
-                                                                         and image_dtype is None) else None)
+        # (what `_FastPair.arm` looks at: a steady-state step of the composite route, no exchange)
+        q.__dict__["_qs_last_route"] = ("live" if live else "frozen") if ((live or frozen) and site_gathered is None) else None
         if type(out) is tuple:
-            y, img = out
-            site.image_made = True
-            dual = y.as_subclass(AutocastImageTensor)
-            dual.__dict__["_qs_image"] = (img, y._version, site)
-            return dual
+            return _as_dual(out[0], out[1], site)
         return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
                              1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits),
@@ -768,7 +868,7 @@ class _FastPair:
             fold, handle = 0, 0
         elif not fold:
             return None
-        if get_option("autocast_image") or get_option("log_during_train") or not (seq.training and inner.training):
+        if get_option("log_during_train") or not (seq.training and inner.training):
             return None
         if q.__dict__.get("_qs_last_route") not in ("live", "frozen") or not p.initted or not q.initted or not cb.initted:
             return None
@@ -862,9 +962,14 @@ class _FastPair:
             q._steps.note_device_add(state[4], 1)
             flags = (_hip.SITE_LIVE | (0 if live else _hip.SITE_SCALE_ONLY) | (_hip.SITE_REFRESH if refresh else 0)
                      | (_hip.SITE_PRE_RELU if pre_relu else 0) | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0))
+            if plan.image_made and not plan.image_used:
+                plan.image_ok = False        # nobody took the last image: stop making them (as the full path)
             plan.image_made = plan.image_used = False
-            out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], None, None, 1)
+            image_dtype = _image_dtype(plan, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
+            out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1)
             _disarm_accumulators(q)
+            if type(out) is tuple:
+                return _as_dual(out[0], out[1], plan)
             return out
 
         if self.fold == 2:

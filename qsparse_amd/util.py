@@ -12,7 +12,7 @@ import torch.nn as nn
 from qsparse_amd import _hip
 
 _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
-             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": False,
+             "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": True,
              "saturate": False}
 
 

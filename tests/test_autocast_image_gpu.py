@@ -1,4 +1,4 @@
-"""The `autocast_image` extension (qsparse_amd/fused.py): under torch.autocast a fused ReLU -> prune -> quantize site hands
+"""The autocast image (qsparse_amd/fused.py; the DEFAULT since round 5, `set_qsparse_options(autocast_image=False)` opts out): under torch.autocast a fused ReLU -> prune -> quantize site hands
 its first convolution / linear consumer the bf16 image of its float32 output and takes that consumer's bf16 gradient as it
 is.  The claim is that every VALUE stays the reference's (quantize.py:109-131 + autocast's casts + autograd's float32
 accumulation); what is checked:
@@ -114,7 +114,7 @@ def test_sites_with_real_consumers_are_value_identical(cl, residual, second, sha
                 net.zero_grad()
             runs.append((trace, net.seen, net.site[0][1].mask.clone(), net.site[1].weight.clone()))
         finally:
-            qs.set_qsparse_options(autocast_image=False)
+            qs.set_qsparse_options(autocast_image=True)
     (ta, seen_a, ma, sa), (tb, seen_b, mb, sb) = runs
     assert all(t is torch.Tensor for t in seen_a)
     assert seen_b[0] is torch.Tensor and all(t is AutocastImageTensor for t in seen_b[2:])      # from the first ACTIVE step on
@@ -189,7 +189,7 @@ def test_the_image_is_taken_once_and_only_when_it_is_still_valid():
             qs.set_qsparse_options(autocast_image=False)
             assert torch.equal(a, F.linear(site(x), w))
     finally:
-        qs.set_qsparse_options(autocast_image=False)
+        qs.set_qsparse_options(autocast_image=True)
 
 
 def test_whole_step_graph_capture_with_the_image_equals_eager():
@@ -220,8 +220,168 @@ def test_whole_step_graph_capture_with_the_image_equals_eager():
                 step.finish()
             outs.append((trace, net.site[0][1].mask.clone(), net.site[1].weight.clone()))
     finally:
-        qs.set_qsparse_options(autocast_image=False, graph_safe=False)
+        qs.set_qsparse_options(autocast_image=True, graph_safe=False)
     (ta, ma, sa), (tb, mb, sb) = outs
     for i, (a, b) in enumerate(zip(ta, tb)):
         assert same(a.cpu(), b.cpu()), i
     assert torch.equal(ma, mb) and torch.equal(sa, sb)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Default since round 5.  What made it opt-in before -- something that observes the output's gradient AFTER the consumer took the
+# image saw only the float32 consumers' share -- is closed: late `register_hook` / `retain_grad` and `torch.autograd.grad(...,
+# inputs=[output])` see the whole gradient.  Every scenario below runs with the image (the default) and without it and compares
+# what the USER observes bit for bit: outputs, hook arguments, retained gradients, input and weight gradients.
+# ----------------------------------------------------------------------------------------------------------------------
+def _pair():
+    return fuse_prune_quantize_pairs(nn.Sequential(
+        nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+        qs.quantize(bits=4, channelwise=-1, timeout=1)))
+
+
+class Block(nn.Module):
+    """a site in front of a convolution, with every kind of second consumer a network may have"""
+
+    def __init__(self, mode):
+        super().__init__()
+        self.site = _pair()
+        torch.manual_seed(7)
+        self.conv = nn.Conv2d(16, 16, 1, bias=False)
+        self.lin = nn.Linear(8, 6, bias=False)
+        self.mode = mode
+        self.observed = []
+        self.kinds = []
+
+    def forward(self, x):
+        y = self.site(x)
+        self.kinds.append(type(y))
+        m = self.mode
+        if m == "hook_before":
+            y.register_hook(lambda g: self.observed.append(g.clone()))
+        if m == "inplace_before":                   # an in-place consumer in front of the convolution: the image is stale
+            y = F.hardtanh_(y, -1.0, 1.0)
+        z = self.lin(y) if m == "linear" else self.conv(y)
+        if m == "hook_after":
+            y.register_hook(lambda g: self.observed.append(g.clone()))
+        if m == "hook_after_replacing":
+            y.register_hook(lambda g: g * 2.0)
+        if m == "retain_after":
+            y.retain_grad()
+            self.retained = y
+        if m == "grad_wrt_output":
+            self.held = y
+        out = z.float().mean((2, 3)) if z.dim() == 4 else z.float()
+        if m in ("residual", "hook_after", "hook_after_replacing", "retain_after", "grad_wrt_output"):
+            out = out + (y * 0.25).mean((2, 3))[:, :out.shape[1]] if out.dim() == 2 else out
+        if m == "cat":
+            out = out + torch.cat([y, y * 2.0], 1).mean((2, 3))[:, :16]
+        if m == "view":
+            out = out + y.flatten(1)[:, :16] + y[:, :, 0, 0]
+        if m == "second_conv":
+            out = out + self.conv(y).float().mean((2, 3))
+        return out
+
+
+MODES = ["plain", "linear", "residual", "cat", "view", "second_conv", "hook_before", "hook_after", "hook_after_replacing", "retain_after",
+         "grad_wrt_output", "inplace_before"]
+
+
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("mode", MODES)
+def test_everything_observable_is_the_same_with_and_without_the_image(mode, cl):
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            net = Block(mode).to(DEV).train()
+            trace = []
+            for s in range(5):
+                x = (torch.randn(6, 16, 8, 8, generator=gen(40 + s)) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16().to(DEV)
+                if cl:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                x.requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = net(x)
+                loss = (out * torch.linspace(-1, 1, out.shape[1], device=DEV)).sum()
+                if mode == "grad_wrt_output":
+                    gy, gx = torch.autograd.grad(loss, [net.held, x])
+                    trace += [gy.as_subclass(torch.Tensor).clone(), gx.clone()]
+                    continue
+                loss.backward()
+                trace += [out.detach().clone(), x.grad.clone(), (net.lin if mode == "linear" else net.conv).weight.grad.clone()]
+                if mode == "retain_after":
+                    trace.append(net.retained.grad.as_subclass(torch.Tensor).clone())
+                net.zero_grad()
+            runs.append((trace, net.observed, net.kinds))
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    (ta, oa, ka), (tb, ob, kb) = runs
+    assert len(ta) == len(tb) and len(oa) == len(ob)
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
+    for i, (a, b) in enumerate(zip(oa, ob)):
+        assert a.dtype == b.dtype == torch.float32 and same(a.cpu(), b.cpu()), ("gradient seen by the hook", i)
+    if mode.startswith("hook") and mode != "hook_after_replacing":
+        assert len(ob) == 5 and all(float(g.abs().sum()) > 0 for g in ob[1:])
+    assert all(k is torch.Tensor for k in ka) and AutocastImageTensor in kb          # the image route really ran
+
+
+def test_the_image_is_the_default_and_takes_the_steady_state_fast_path():
+    """library defaults: under autocast a training site returns the subclass, also from `_FastPair` (the steady-state fast path);
+    outside autocast and with the option off a plain tensor"""
+    assert qs.get_qsparse_option("autocast_image") is True
+    site = _pair().to(DEV).train()
+    conv = nn.Conv2d(16, 16, 1, bias=False).to(DEV)
+    kinds, fast = [], []
+    for s in range(8):
+        x = torch.randn(4, 16, 8, 8, generator=gen(s)).bfloat16().to(DEV).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = site(x)
+            kinds.append(type(y))
+            fast.append(site.__dict__.get("_qs_fast") is not None)
+            conv(y).float().sum().backward()
+    assert kinds[-1] is AutocastImageTensor and fast[-1] and fast[-2]
+    assert type(site(torch.randn(4, 16, 8, 8, device=DEV).bfloat16())) is torch.Tensor      # no autocast: nothing to hand over
+
+
+def test_copies_and_pickles_of_the_output_are_plain_tensors():
+    import copy
+    import pickle
+    site = _pair().to(DEV).train()
+    for s in range(4):
+        x = torch.randn(4, 16, 8, 8, generator=gen(s)).bfloat16().to(DEV)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = site(x)
+    assert type(y) is AutocastImageTensor
+    for z in (copy.deepcopy(y.detach()), pickle.loads(pickle.dumps(y.detach())), y.detach().clone(), y + 0):
+        assert type(z) is torch.Tensor and torch.equal(z, y.as_subclass(torch.Tensor))
+    net = nn.Sequential(site, nn.Conv2d(16, 4, 1)).to(DEV)
+    twin = copy.deepcopy(net)                       # a network holding a site deep-copies and keeps working
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(net(x), twin(x))
+
+
+def test_under_distributed_data_parallel_the_gradients_are_those_of_the_plain_route():
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        grads = []
+        for image in (False, True):
+            qs.set_qsparse_options(autocast_image=image)
+            torch.manual_seed(3)
+            net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1), _pair(), nn.Conv2d(16, 8, 3, padding=1), nn.Flatten(), nn.Linear(8 * 64, 5))
+            net = nn.parallel.DistributedDataParallel(net.to(DEV).train(), device_ids=[0])
+            for s in range(4):
+                x = torch.randn(4, 3, 8, 8, generator=gen(s)).to(DEV)
+                net.zero_grad()
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    net(x).float().sum().backward()
+            grads.append([p.grad.clone() for p in net.parameters() if p.grad is not None])
+        for a, b in zip(*grads):
+            assert torch.allclose(a, b, rtol=2e-2, atol=1e-3)      # (the convolutions' own algorithm choice may differ between runs)
+    finally:
+        qs.set_qsparse_options(autocast_image=True)
+        dist.destroy_process_group()

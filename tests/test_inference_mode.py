@@ -73,4 +73,4 @@ def test_inference_mode_on_the_gpu(image):
     try:
         _run("cuda", autocast=image)
     finally:
-        qs.set_qsparse_options(autocast_image=False)
+        qs.set_qsparse_options(autocast_image=True)       # (the default)
