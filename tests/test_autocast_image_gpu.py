@@ -258,8 +258,8 @@ class Block(nn.Module):
         m = self.mode
         if m == "hook_before":
             y.register_hook(lambda g: self.observed.append(g.clone()))
-        if m == "inplace_before":                   # an in-place consumer in front of the convolution: the image is stale
-            y = F.hardtanh_(y, -1.0, 1.0)
+        if m == "inplace_before" and len(self.kinds) > 1:      # an in-place consumer in front of the convolution: the image is stale
+            y = F.hardtanh_(y, -1.0, 1.0)                        # (not on step 0: the idle site's output is nn.ReLU's, which autograd keeps)
         z = self.lin(y) if m == "linear" else self.conv(y)
         if m == "hook_after":
             y.register_hook(lambda g: self.observed.append(g.clone()))
@@ -320,7 +320,7 @@ def test_everything_observable_is_the_same_with_and_without_the_image(mode, cl):
     for i, (a, b) in enumerate(zip(ta, tb)):
         assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
     for i, (a, b) in enumerate(zip(oa, ob)):
-        assert a.dtype == b.dtype == torch.float32 and same(a.cpu(), b.cpu()), ("gradient seen by the hook", i)
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("gradient seen by the hook", i)      # (step 0: operators idle, bf16 passes through)
     if mode.startswith("hook") and mode != "hook_after_replacing":
         assert len(ob) == 5 and all(float(g.abs().sum()) > 0 for g in ob[1:])
     assert all(k is torch.Tensor for k in ka) and AutocastImageTensor in kb          # the image route really ran
@@ -348,10 +348,13 @@ def test_copies_and_pickles_of_the_output_are_plain_tensors():
     import copy
     import pickle
     site = _pair().to(DEV).train()
+    conv = nn.Conv2d(16, 4, 1).to(DEV)
     for s in range(4):
         x = torch.randn(4, 16, 8, 8, generator=gen(s)).bfloat16().to(DEV)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = site(x)
+            if s < 3:
+                conv(y)          # (a site whose images nobody takes stops making them)
     assert type(y) is AutocastImageTensor
     for z in (copy.deepcopy(y.detach()), pickle.loads(pickle.dumps(y.detach())), y.detach().clone(), y + 0):
         assert type(z) is torch.Tensor and torch.equal(z, y.as_subclass(torch.Tensor))
