@@ -199,6 +199,17 @@ def library_kernel_accounting(step, reps=3):
     for _ in range(reps):
         step()
     per = _hip.stop_event_log(with_bytes=True)
+    # the event log takes the fine-grained entry points, which make no autocast image: what the image route (the default under
+    # autocast) moves differently -- the image written by the forward, the 2-byte gradient read by the backward instead of
+    # (or besides) the float32 one -- is counted by the composite site step itself over the same number of ordinary steps
+    _hip.image_byte_delta = {"apply_fwd": 0, "apply_bwd": 0}
+    try:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        image_delta = {k: v // reps for k, v in _hip.image_byte_delta.items()}
+    finally:
+        _hip.image_byte_delta = None
     # what an event pair costs by itself: the pair brackets the launch's dispatch latency as well as its execution, which
     # back-to-back launches overlap; an EMPTY pair on the same (busy) stream measures that floor
     torch.cuda.synchronize()
@@ -226,6 +237,9 @@ def library_kernel_accounting(step, reps=3):
         f["bytes"] += sum(nb for _, nb in launches) // reps
         f["launches"] += len(launches) // reps
         by_kernel[k] = round(sum(ms for ms, _ in launches) / reps, 3)
+    for fam, delta in image_delta.items():
+        if fam in fams:
+            fams[fam]["bytes"] += delta
     total_ms = sum(f["ms"] for f in fams.values())
     total_net = sum(f["net"] for f in fams.values())
     total_bytes = sum(f["bytes"] for f in fams.values())
@@ -242,6 +256,7 @@ def library_kernel_accounting(step, reps=3):
         rec["families"][name] = {"ms": round(f["ms"], 3), "ms_net": round(f["net"], 3), "launches": f["launches"],
                                  "GB": round(f["bytes"] / 1e9, 3), "frac_of_hbm_peak": frac(f["bytes"], f["ms"]),
                                  "frac_net": frac(f["bytes"], f["net"])}
+    rec["autocast_image_bytes_per_step"] = image_delta
     rec["note"] = ("HIP event pairs around every library launch; `ms` is the raw sum (what `frac_of_hbm_peak` uses), `*_net` subtracts "
                    "the cost of an empty event pair from every launch (the pair also brackets dispatch latency that back-to-back "
                    "launches overlap; rocprofv3 kernel durations, profiles/r04_config*_family_table.txt, are the reference). "

@@ -341,6 +341,11 @@ def note_gate(bits: torch.Tensor):
         cell["bits"] = bits
 
 
+# development aid for the byte accounting of bench.py / tools/profile_config.py: the event log (above) takes the fine-grained
+# entry points, which make no autocast image; with this dict set, the composite site step adds what the image route moves
+# DIFFERENTLY from the fine-grained one (forward: the image written; backward: the 2-byte gradient read, the float32 one not)
+image_byte_delta = None         # None, or {"apply_fwd": bytes, "apply_bwd": bytes}
+
 ACT_RELU, ACT_HARDTANH, ACT_LEAKY = 1, 2, 3
 _act_handles = {}
 _act_specs = {}          # handle -> (kind, a, b)

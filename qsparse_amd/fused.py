@@ -451,6 +451,8 @@ class _SiteStep(torch.autograd.Function):
                       decimal=dec)
         if xback:
             cell["done"] = True
+        if _hip.image_byte_delta is not None and img is not None:
+            _hip.image_byte_delta["apply_fwd"] += img.numel() * img.element_size()
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
         ctx.act, ctx.dec = plan.c.act, dec
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
@@ -482,6 +484,8 @@ class _SiteStep(torch.autograd.Function):
             if (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
                     and _hip.elide_mode != "all" and not _hip.logging_events()):
                 gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g16.device, memory_format=fmt)
+                if _hip.image_byte_delta is not None:
+                    _hip.image_byte_delta["apply_bwd"] += g16.numel() * g16.element_size() - (g16.numel() * 4 if g is None else 0)
                 _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec)
                 return (gx,) + (None,) * (n_in - 1)
             g = g16.float() if g is None else g + g16.float()          # autograd's own accumulation, then the usual routes

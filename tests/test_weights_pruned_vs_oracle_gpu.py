@@ -255,15 +255,20 @@ def test_branchy_pruned_weights_vs_oracle(monkeypatch, prune, quantizer, channel
     model, twins = run(monkeypatch, Branchy, (4, 3, 10, 10), 5, prune, quantizer, "cuda", channels_last, 16, branchy_script,
                        expect_batched=5)
     _branchy_checks(model, twins)
-    _served_by_the_table(prune, quantizer, steps=16)
+    _served_by_the_table(prune, quantizer, 16, channels_last)
 
 
-def _served_by_the_table(prune, quantizer, steps):
+def _served_by_the_table(prune, quantizer, steps, channels_last=False):
     """the run above really went through the multi-tensor entry points: one hand-out launch per forward; with a policy that
     averages / re-ranks on every read, one qs_multi_magnitude / qs_multi_mask_refresh per forward past the schedule -- and the
     per-layer select only on the two reads that change the sparsity"""
     dims, cbkw = PRUNES[prune]
     assert CALLS.get("multi_quant_fwd", 0) >= steps - 3, CALLS
+    if channels_last and 0 in dims and dims != {0, 1, 2, 3}:
+        # a channels_last weight whose first REDUCED dim is not dim 0 (masks that keep dim 0): ATen's staged mean of such a tensor
+        # has an order of its own, which only the per-layer kernels restate -- the averaging / re-ranking reads stay per layer
+        # (DESIGN section 9), the others go through the table; parity is what `run` checked either way
+        return
     if not cbkw:                                    # the stock callback: every read past `start` re-ranks
         assert CALLS.get("multi_mask_refresh", 0) >= steps - 8, CALLS
         if dims != {0, 1, 2, 3}:
@@ -292,7 +297,7 @@ def test_resnet50_full_width_pruned_weights_vs_oracle(monkeypatch, prune, quanti
     model, twins = run(monkeypatch, lambda: resnet50(1000, False, 64), (2, 3, 64, 64), 1000, prune, quantizer, "cuda", channels_last, 8,
                        expect_batched=54)
     assert len(twins) == 54 and all(t.reads == 8 for t in twins)
-    _served_by_the_table(prune, quantizer, steps=8)
+    _served_by_the_table(prune, quantizer, 8, channels_last)
     if PRUNES[prune][0] == {0, 1, 2, 3}:
         assert max(t.psim.mask.numel() for t in twins) == 2359296
     sparsity = [1.0 - t.psim.mask.float().mean().item() for t in twins if t.psim.mask.numel() >= 64]

@@ -60,8 +60,7 @@ def main():
     # wall time of the K steps: first launch of the window to the end of the last kernel of the trace
     t0 = int(tail[0]["Start_Timestamp"])
     t1 = max(int(r["End_Timestamp"]) for r in rows)
-    opts = "autocast_image=True (bytes are those of the DEFAULT mode: the backward reads 2 instead of 4 B/elem of gradient here)" \
-        if meta.get("autocast_image") else "default options"
+    opts = "default options (autocast image on: its bytes are counted)" if meta.get("autocast_image") else "autocast_image=False"
     print(f"{meta['arch']} batch {meta['batch']}, channels_last, bf16 autocast, {opts}: last {steps} steps of the trace, "
           f"{meta['launches_per_step']} library launches per step; step wall time ~{(t1 - t0) / 1e6 / steps:.2f} ms")
     print("(durations: rocprofv3 --kernel-trace; bytes: every data operand of a launch once, dense, in the dtype/layout the site saw)\n")

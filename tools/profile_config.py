@@ -27,7 +27,7 @@ def main():
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     dev = torch.device("cuda", 0)
-    image = os.environ.get("QS_PROFILE_IMAGE", "0") == "1"          # the value-identical opt-in (fused.py "Autocast image")
+    image = os.environ.get("QS_PROFILE_IMAGE", "1") == "1"          # the autocast image (fused.py): the default since round 5
     qs.set_qsparse_options(log_on_created=False, log_during_train=False, autocast_image=image,
                            batch_weights=os.environ.get("QS_PROFILE_NO_BATCHER", "0") != "1",
                            fold_relu=os.environ.get("QS_PROFILE_NO_FOLD", "0") != "1")
