@@ -233,6 +233,18 @@ def _check(status: int, what: str):
         raise QsparseHipError(f"{what}: {msg.decode() if msg else status} (status {status})")
 
 
+HIP_DTYPES = frozenset((torch.float32, torch.bfloat16, torch.float16))
+
+
+def on_hip(t: torch.Tensor) -> bool:
+    """whether the operators on this tensor run as HIP kernels: a GPU tensor of a dtype the kernels are written for.  A GPU
+    tensor of another dtype (float64, integers -- the reference is dtype-agnostic ATen, quantize.py:109-117, sparse.py:116)
+    evaluates the package's own ATen expression ON THE DEVICE: the code the CPU path runs, which restates the reference line
+    by line (type promotion included: a float64 input is divided in float64 and still comes out as float32).  Never the
+    oracle, never a host round trip."""
+    return t.is_cuda and t.dtype in HIP_DTYPES
+
+
 def dt(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]

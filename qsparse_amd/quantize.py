@@ -99,7 +99,7 @@ class _SteFunction(torch.autograd.Function):
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         (step,) = ctx.saved_tensors
-        if grad_output.is_cuda:
+        if _hip.on_hip(grad_output) and ctx.x_dtype in _hip.HIP_DTYPES:
             out_dtype = ctx.x_dtype if grad_output.dtype == torch.float32 else grad_output.dtype
             gx = _hip.ste_bwd(grad_output, step, step_is_decimal, ctx.channel_index, lo_mul, hi_mul, False, out_dtype)
             return (gx,) + (None,) * 8
@@ -128,7 +128,7 @@ class ScalerQuantization(_SteFunction):
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
         ctx.save_for_backward(ensure_tensor(scaler).detach())
         sat = code_range(bits, ctx.notch, use_uint, saturate)
-        if input.is_cuda:
+        if _hip.on_hip(input):
             qd = _quotient_dtype(input, scaler)
             _gpu_dtype_guard(input, qd)
             if isinstance(scaler, torch.Tensor) and scaler.numel() > 1:
@@ -160,7 +160,7 @@ class DecimalQuantization(_SteFunction):
         ctx.bits, ctx.channel_index, ctx.x_dtype = bits, channel_index, input.dtype
         ctx.save_for_backward(ensure_tensor(decimal).detach().float())
         sat = code_range(bits, ctx.notch, use_uint, saturate)
-        if input.is_cuda:
+        if _hip.on_hip(input):
             qd = _quotient_dtype(input, decimal.float() if isinstance(decimal, torch.Tensor) else 1.0)
             _gpu_dtype_guard(input, qd)
             if isinstance(decimal, torch.Tensor) and decimal.numel() > 1:
@@ -194,7 +194,7 @@ class LineQuantization(torch.autograd.Function):
         if channel_index >= 0:
             assert x.shape[channel_index] == lines.shape[0]
         assert lines.shape[1] == 2
-        if x.is_cuda:
+        if _hip.on_hip(x):
             if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or lines.dtype != torch.float32:
                 raise _hip.QsparseHipError(f"HIP line quantizer: unsupported dtypes {x.dtype} / {lines.dtype}")
             if return_codes:
@@ -379,7 +379,7 @@ class DecimalQuantizer(BaseQuantizer):
                     "channel-wise Scaler/Decimal quantization of a batched activation is not supported by the "
                     f"reference (shape {tuple(x.shape)}, channelwise={channel_index}); use channelwise=-1 or "
                     "AdaptiveQuantizer")
-            if x.is_cuda:
+            if _hip.on_hip(x):
                 # three launches per step: abs-max accumulated into a persistent zeroed buffer, running-mean update
                 # (which also clears that buffer and bumps the layer's step counter), quantization
                 n_stat = wshape[0]
@@ -490,7 +490,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
 
     def optimize(self, x, bits, weight=None, channel_index=-1, batched=False, **kwargs):
         with torch.no_grad():
-            if x.is_cuda:
+            if _hip.on_hip(x):
                 # nothing to exchange between the reduction and the update (one process, or a weight): ONE reduction launch
                 # into persistent key buffers, which the running-mean launch converts and resets -- two launches instead of
                 # four (key initialisation, reduction, key -> float, running mean)
@@ -682,7 +682,7 @@ class QuantizeLayer(nn.Module):
                 if t == self.timeout and get_option("log_during_train"):
                     logging.warn(f"quantizing {self.name} with {self.bits} bits")
                 extra = {}
-                if x.is_cuda and type(self.callback) in (DecimalQuantizer, ScalerQuantizer):
+                if _hip.on_hip(x) and type(self.callback) in (DecimalQuantizer, ScalerQuantizer):
                     self.callback.__dict__["_bumped_step_counter"] = False
                     extra["step_counter"] = self._n_updates   # bumped inside the running-mean kernel
                 new_weight = self.callback.optimize(x, self.bits, self.weight, batched=self.batch_dimension == 0,

@@ -162,7 +162,7 @@ def _channel_dim(mask: torch.Tensor) -> int:
 
 def apply_mask(x: torch.Tensor, mask: torch.Tensor, pre_relu=False) -> torch.Tensor:
     """``pre_relu``: False, True (a folded nn.ReLU) or the handle of another folded activation (``_hip.activation``)"""
-    if x.is_cuda:
+    if _hip.on_hip(x):
         if pre_relu:
             d = _channel_dim(mask)
             if d < 0 or mask.shape[d] != x.shape[d]:
@@ -177,10 +177,10 @@ def _importance(x: torch.Tensor, shape, l0: bool = False, pre_relu: bool = False
     over ``x`` on the GPU (reference sparse.py:85-87).  ``pre_relu``: the importance of max(x, 0)."""
     if pre_relu:
         dims = _reduction_plan(x.shape, shape)
-        if x.is_cuda and dims and not l0:
+        if _hip.on_hip(x) and dims and not l0:
             return _staged_mean_hip(x, dims, take_abs=True, pre_relu=pre_relu)
         x = _hip.act_torch(pre_relu, x) if x.is_cuda else torch.relu(x)
-    if x.is_cuda:
+    if _hip.on_hip(x):
         dims = _reduction_plan(x.shape, shape)
         flag = _hip.l0_flag(x) if l0 else None
         if l0 and not dims:   # nothing to reduce: materialise (x != 0).float() or |x| via the flag
@@ -250,7 +250,7 @@ class MagnitudePruningCallback(nn.Module):
         with torch.no_grad():
             t = self._t_host.read(self.t)
             imp = qdist.allreduce_mean(_importance(x.detach(), self.magnitude.shape, self.l0))
-            if x.is_cuda:
+            if _hip.on_hip(x):
                 t_dev = self.t.data if (get_option("graph_safe") and self.t.is_cuda) else None
                 _hip.running_mean(self.magnitude.data, imp, t, t_dev=t_dev)
             else:
@@ -272,7 +272,7 @@ class MagnitudePruningCallback(nn.Module):
         with torch.no_grad():
             importance = self.magnitude if self.running_average else qdist.allreduce_mean(
                 _importance(x.detach(), mask.shape))
-            if x.is_cuda:
+            if _hip.on_hip(x) and importance.dtype in _hip.HIP_DTYPES:
                 imp = importance.detach().to(torch.float32).contiguous()
                 n = imp.numel()
                 k = threshold_rank(sparsity, n)
@@ -306,7 +306,7 @@ class MagnitudePruningCallback(nn.Module):
         """GPU tensors, running-average magnitudes of at most 65536 mask entries, no overridden policy methods:
         running mean + k-th value + mask (+ step counters) are then ONE launch (qs_pq_select)."""
         cls = type(self)
-        return (x.is_cuda and self.running_average and not self.use_gradient and 2 <= mask.numel() <= 65536
+        return (_hip.on_hip(x) and self.running_average and not self.use_gradient and 2 <= mask.numel() <= 65536
                 and mask.is_cuda and mask.is_contiguous() and hasattr(self, "magnitude")
                 and cls.update_magnitude is MagnitudePruningCallback.update_magnitude
                 and cls.receive_input is MagnitudePruningCallback.receive_input
@@ -495,13 +495,13 @@ class PruneLayer(nn.Module):
         n = self.advance_schedule()
         if not self.training or self.mask.numel() == 1:
             return apply_mask(x, self.mask, pre_relu)
-        if pre_relu and not (n >= self.start and x.is_cuda and type(self.callback) is MagnitudePruningCallback):
+        if pre_relu and not (n >= self.start and _hip.on_hip(x) and type(self.callback) is MagnitudePruningCallback):
             x, pre_relu = (_hip.act_torch(pre_relu, x) if x.is_cuda else torch.relu(x)), False
         if n >= self.start:
             if n == self.start and get_option("log_during_train"):
                 logging.warning(f"Start pruning at {self.name} @ {n}")
             cb = self.callback
-            if x.is_cuda and type(cb) is MagnitudePruningCallback:
+            if _hip.on_hip(x) and type(cb) is MagnitudePruningCallback:
                 # the layer's step counter rides along in the callback's select launch when there is one
                 cb.__dict__["_bumped_step_counter"] = False
                 out = cb(x, self.current_sparsity(), mask=self.mask, name=self.name, step_counter=self._n_updates,

@@ -230,7 +230,7 @@ def squeeze_tensor_to_shape(x: torch.Tensor, shape: List[int]) -> torch.Tensor:
     """average ``x`` down to ``shape`` one dim at a time (reference util.py:79-99): every stage
     accumulates in fp32 and rounds to ``x``'s dtype, exactly like ``Tensor.mean`` on CPU."""
     dims = _reduction_plan(x.shape, shape)
-    if x.is_cuda:
+    if _hip.on_hip(x):
         return _staged_mean_hip(x, dims, take_abs=False)
     for i in dims:
         x = x.mean(i, keepdim=True)
@@ -252,7 +252,7 @@ def calculate_mask_given_importance(importance: torch.Tensor, sparsity: float) -
     k = threshold_rank(sparsity, n)
     if k >= n:
         raise IndexError(f"index {k} is out of bounds for dimension 0 with size {n}")
-    if importance.is_cuda:
+    if _hip.on_hip(importance):
         imp = importance.detach().to(torch.float32).contiguous()
         thr = _hip.kth_value(imp, k)
         mask = torch.empty(importance.shape, dtype=torch.bool, device=importance.device)
