@@ -43,6 +43,16 @@ def _quotient_dtype(x: torch.Tensor, param) -> torch.dtype:
     return torch.result_type(x, param)
 
 
+def _int32(t: torch.Tensor) -> torch.Tensor:
+    """``t.int()`` as the reference's CPU evaluates it: x86's cvttss2si / cvttsd2si return INT32_MIN for a NaN, an infinity and
+    anything outside the int32 range, which the HIP kernels restate.  ATen's device cast saturates instead, so a
+    GPU tensor that takes the ATen expression (float64, integers: `_hip.on_hip`) spells the rule out; on the CPU it is the cast."""
+    if not t.is_cuda or not t.is_floating_point():
+        return t.int()
+    ok = (t > -2147483649.0) & (t < 2147483648.0)          # (a NaN compares false)
+    return torch.where(ok, t, torch.full_like(t, -2147483648.0)).int()
+
+
 def _out_dtype(x: torch.Tensor) -> torch.dtype:
     """float32 like the reference (type promotion), or the input dtype with the ``preserve_dtype`` extension"""
     if get_option("preserve_dtype") and x.dtype in (torch.bfloat16, torch.float16):
@@ -138,7 +148,7 @@ class ScalerQuantization(_SteFunction):
                                       want_codes=return_codes, saturate=sat)
             return _with_codes(ctx, _reference_shape(y, input, scaler), codes, return_codes)
         s = _on_channel(scaler, input.dim(), channel_index, input.shape[channel_index])
-        codes = torch.round(input / s).int()
+        codes = _int32(torch.round(input / s))
         if sat is not None:      # (the reference's own line with the assignment it lacks; off by default: see module docstring)
             codes = codes.clamp(sat[0], sat[1])
         return _with_codes(ctx, (codes.float() * s).to(_out_dtype(input)), codes, return_codes)
@@ -171,7 +181,7 @@ class DecimalQuantization(_SteFunction):
             return _with_codes(ctx, _reference_shape(y, input, decimal), codes, return_codes)
         to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
         to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
-        codes = (input * to_int).int()
+        codes = _int32(input * to_int)
         if sat is not None:
             codes = codes.clamp(sat[0], sat[1])
         return _with_codes(ctx, (codes.float() * to_float).to(_out_dtype(input)), codes, return_codes)

@@ -29,7 +29,7 @@ def _both(make, xs, grads=True):
         m = make().to(dev).train()
         rec = []
         for x in xs:
-            xd = x.to(dev)
+            xd = x.detach().clone().to(dev)
             if grads and xd.is_floating_point():
                 xd.requires_grad_(True)
             y = m(xd)
@@ -52,7 +52,9 @@ def test_float64_activations_through_every_quantizer(kind, channelwise):
     assert len(a) == len(b)
     for i, (u, v) in enumerate(zip(a, b)):
         assert u.dtype == v.dtype and same(u, v), i
-    assert a[2].dtype == torch.float32 and a[3].dtype == torch.float64        # float32 out of a float64 input; float64 gradient
+    # Scaler / Decimal: float32 out of a float64 input (`q.float() * scaler`, quantize.py:117), float64 gradient; the line
+    # quantizer keeps the input's dtype (quantize.py:160-181)
+    assert a[2].dtype == (torch.float64 if kind == "adaptive" else torch.float32) and a[3].dtype == torch.float64
 
 
 @pytest.mark.parametrize("dims", [{1}, {0, 1}, {1, 2, 3}])
@@ -64,7 +66,7 @@ def test_float64_activations_through_the_prune_layer(dims, policy):
                                   callback=qs.MagnitudePruningCallback(**policy)), xs)
     for i, (u, v) in enumerate(zip(a, b)):
         assert u.dtype == v.dtype and same(u, v), i
-    assert a[-4].dtype == torch.float64 and (a[-4] == 0).any()               # pruned float64 output
+    assert a[12].dtype == torch.float64 and (a[12] == 0).any()               # the last step's output: float64, pruned
 
 
 def test_integer_activations():
@@ -72,20 +74,34 @@ def test_integer_activations():
     a, b = _both(lambda: qs.quantize(bits=4, channelwise=-1, timeout=1), xs, grads=False)
     for i, (u, v) in enumerate(zip(a, b)):
         assert u.dtype == v.dtype and same(u, v), i
-    a, b = _both(lambda: qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1), xs, grads=False)
-    for i, (u, v) in enumerate(zip(a, b)):
-        assert u.dtype == v.dtype and same(u, v), i
+    # a prune layer averages |x| (util.py:97): ATen has no integer mean -- the reference raises, on either device, and so does this
+    for dev in ("cpu", "cuda"):
+        p = qs.prune(sparsity=0.5, dimensions={1}, start=0, interval=1, repetition=1).to(dev).train()
+        with pytest.raises(RuntimeError, match="mean"):
+            p(xs[0].to(dev))
+    # ... while a frozen / evaluating one only multiplies (sparse.py:263)
+    for dev in ("cpu", "cuda"):
+        p = qs.prune(sparsity=0.5, dimensions={1}, start=0, interval=1, repetition=1).to(dev).train()
+        p(xs[0].float().to(dev))
+        p(xs[1].float().to(dev))
+        p.eval()
+        y = p(xs[2].to(dev))
+        assert y.dtype == torch.int32 and torch.equal(y.cpu(), xs[2] * p.mask.cpu())
 
 
 def test_a_double_precision_network_trains_on_the_gpu():
-    """`model.double()`: weights, activations, masks -- a converted network as a whole; state and effective weights against the
-    CPU run (the convolutions themselves round differently on the two devices: the parameters move by a seeded pseudo-update)"""
+    """`model.double()` with the operators that keep their input's dtype -- pruned weights and activations (`x * mask`), the line
+    quantizer on activations (the Scaler / Decimal quantizers return float32, which a float64 convolution refuses in the
+    reference as here): state and effective weights against the CPU run (the convolutions themselves round differently on the
+    two devices: the parameters move by a seeded pseudo-update)"""
     def build():
         torch.manual_seed(0)
         net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(), nn.Flatten(),
                             nn.Linear(8 * 36, 5))
-        net = qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=1), weight_layers=[nn.Conv2d], log=False)
-        net = qs.convert(net, qs.quantize(bits=8, timeout=1), weight_layers=[nn.Conv2d, nn.Linear], log=False)
+        net = qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=1), weight_layers=[nn.Conv2d],
+                         activation_layers=[nn.ReLU], log=False)
+        net = qs.convert(net, qs.quantize(bits=8, timeout=1, channelwise=-1, callback=qs.AdaptiveQuantizer()), activation_layers=[nn.ReLU],
+                         log=False)
         return net.double()
 
     results = []
@@ -104,20 +120,21 @@ def test_a_double_precision_network_trains_on_the_gpu():
                         prm.add_((torch.randn(prm.shape, generator=g, dtype=torch.float64) * 0.02).to(dev))
         net.eval()
         eff = [m.weight.detach().cpu() for m in net.modules() if isinstance(m, (nn.Conv2d, nn.Linear))]
-        results.append((eff, {k: v.detach().cpu() for k, v in net.state_dict().items()}))
+        results.append((eff, {k: v.detach().cpu() for k, v in net.state_dict().items() if "mask" in k or "_n_updates" in k or k.endswith(".t")}))
     (ea, sa), (eb, sb) = results
     for i, (u, v) in enumerate(zip(ea, eb)):
-        assert u.dtype == v.dtype and same(u, v), ("effective weight", i)
-    for k in sa:
-        assert same(sa[k], sb[k]), k
+        assert u.dtype == v.dtype == torch.float64 and same(u, v), ("effective weight", i)
+    for k in sa:                    # (the WEIGHT masks depend on the parameters alone; the activations' on convolution outputs, which
+        if ".prune." in k:          # the two devices round differently)
+            assert same(sa[k], sb[k]), k
 
 
 def test_supported_dtypes_still_take_the_kernels(monkeypatch):
     calls = []
-    real = _hip.quant_fwd
-    monkeypatch.setattr(_hip, "quant_fwd", lambda *a, **k: (calls.append(a[1].dtype), real(*a, **k))[1])
+    real = _hip.quantize_step
+    monkeypatch.setattr(_hip, "quantize_step", lambda *a, **k: (calls.append(a[0].dtype), real(*a, **k))[1])
     for dtype in (torch.float32, torch.bfloat16, torch.float16, torch.float64):
-        q = qs.quantize(bits=8, channelwise=-1, timeout=0 + 1).cuda().train()
+        q = qs.quantize(bits=8, channelwise=-1, timeout=1).cuda().train()
         for s in range(3):
             q(torch.randn(4, 8, 4, 4, generator=gen(s)).to(dtype).cuda())
     assert torch.float64 not in calls and {torch.float32, torch.bfloat16, torch.float16} <= set(calls)
