@@ -461,3 +461,64 @@ def test_reference_default_quantize_on_every_resnet50_weight_vs_the_oracle_in_a_
         for name, m in layers.items():
             w = m._parameters["weight"].detach().cpu().contiguous()
             assert torch.equal(m.weight.detach().cpu().contiguous(), sims[name].apply(w, False)), name
+
+
+@pytest.mark.parametrize("quantizer", ["scaler", "decimal_dim0_bias", "default"])
+def test_the_steady_state_fast_path_of_the_weight_path_equals_the_full_one(quantizer, monkeypatch):
+    """once every tensor is quantized on every read the precomputation only compares identities and re-issues the cached launch
+    table (`_Steady`): a run with it and a twin without (QS_NO_FAST_PATH) through route switches (roll-backs), an evaluation
+    step, a hook that comes and goes, a configuration attribute and a parameter re-assigned -- bit for bit; and it did engage"""
+    results, armed = [], []
+    for fast in (True, False):
+        if not fast:
+            monkeypatch.setenv("QS_NO_FAST_PATH", "1")
+        model, opt = _build(quantizer)
+        wb = model.__dict__["_qs_weight_batcher"]
+        g = torch.Generator().manual_seed(3)
+        trace = []
+        handle = None
+        for i in range(20):
+            model.route = "left" if i % 3 else "right"
+            if i == 8:
+                handle = model.left.quantize.register_forward_hook(lambda m, a, o: None)
+            if i == 10:
+                handle.remove()
+            if i == 12:
+                model.shared.quantize.bits = 6
+            if i == 15:
+                with torch.no_grad():
+                    model.head._parameters["weight"] = nn.Parameter(model.head._parameters["weight"].detach().clone() * 1.5)
+            x = torch.randn(4, 3, 10, 10, generator=g).cuda()
+            if i == 6:
+                model.eval()
+                with torch.no_grad():
+                    trace.append(model(x).detach().clone())
+                model.train()
+                continue
+            if fast:
+                armed.append((i, wb._steady is not None))
+            for prm in model.parameters():
+                prm.grad = None
+            out = model(x)
+            out.sum().backward()
+            trace.append(out.detach().clone())
+            with torch.no_grad():
+                for prm in model.parameters():
+                    if prm.requires_grad:
+                        prm.add_(torch.randn(prm.shape, generator=g).cuda() * 0.02)
+        model.eval()
+        trace += [m.weight.detach().clone() for m in (model.stem, model.left, model.right, model.shared, model.head)]
+        results.append((trace, _state(model)))
+    (ta, sa), (tb, sb) = results
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for i, (a, b) in enumerate(zip(ta[-5:], tb[-5:])):
+        assert torch.equal(a, b), ("effective weight", i)
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), ("output", i)
+    armed = dict(armed)
+    # armed in the plain stretches; not on the first steps (timeouts: the skipped branch's layer sits AT its timeout for a
+    # while), not after the evaluation step, not while the hook is there; a changed attribute / a re-assigned parameter is
+    # noticed by the step that meets it, whose full path re-arms
+    assert armed[5] and not armed[7] and not armed[9] and not armed[10] and all(armed[i] for i in (11, 13, 14, 16, 17, 18, 19)), \
+        "".join("1" if v else "0" for _, v in sorted(armed.items()))
