@@ -189,7 +189,7 @@ FAMILIES = (("apply_fwd", ("quant_scaler_fwd", "quant_decimal_fwd", "quant_line_
             ("statistics", ("mean_dim", "mean_last2", "absmax", "minmax", "l0_flag", "multi_absmax", "kth_value", "mask_ge")))
 
 
-def library_kernel_accounting(step, reps=3):
+def library_kernel_accounting(step, reps=3, add_image_bytes=False):
     """`reps` training steps with a HIP event pair around every launch of the library: per kernel family the time per
     step, the algorithmic bytes per step and the fraction of the 8 TB/s roofline they amount to; overall the same with
     the C-sized launches' time in the denominator as well (they move nothing, so they only cost)."""
@@ -237,9 +237,12 @@ def library_kernel_accounting(step, reps=3):
         f["bytes"] += sum(nb for _, nb in launches) // reps
         f["launches"] += len(launches) // reps
         by_kernel[k] = round(sum(ms for ms, _ in launches) / reps, 3)
-    for fam, delta in image_delta.items():
-        if fam in fams:
-            fams[fam]["bytes"] += delta
+    # `add_image_bytes`: for callers that set these bytes against durations of ORDINARY steps (tools/profile_config.py: rocprofv3
+    # times the image route's kernels).  The event pairs below time the fine-grained route, whose bytes are counted as they are.
+    if add_image_bytes:
+        for fam, delta in image_delta.items():
+            if fam in fams:
+                fams[fam]["bytes"] += delta
     total_ms = sum(f["ms"] for f in fams.values())
     total_net = sum(f["net"] for f in fams.values())
     total_bytes = sum(f["bytes"] for f in fams.values())
@@ -256,7 +259,9 @@ def library_kernel_accounting(step, reps=3):
         rec["families"][name] = {"ms": round(f["ms"], 3), "ms_net": round(f["net"], 3), "launches": f["launches"],
                                  "GB": round(f["bytes"] / 1e9, 3), "frac_of_hbm_peak": frac(f["bytes"], f["ms"]),
                                  "frac_net": frac(f["bytes"], f["net"])}
-    rec["autocast_image_bytes_per_step"] = image_delta
+    rec["autocast_image_bytes_per_step"] = dict(image_delta, included=bool(add_image_bytes),
+                                                note="what an ordinary step (autocast image, the default) moves on top of the fine-grained "
+                                                     "route timed here: the image written by the forward, the 2-byte gradient read by the backward")
     rec["note"] = ("HIP event pairs around every library launch; `ms` is the raw sum (what `frac_of_hbm_peak` uses), `*_net` subtracts "
                    "the cost of an empty event pair from every launch (the pair also brackets dispatch latency that back-to-back "
                    "launches overlap; rocprofv3 kernel durations, profiles/r04_config*_family_table.txt, are the reference). "

@@ -56,7 +56,7 @@ def main():
 
     for _ in range(8):
         step()
-    acct = bench.library_kernel_accounting(step, reps=1)
+    acct = bench.library_kernel_accounting(step, reps=1, add_image_bytes=image)
     torch.cuda.synchronize()
     for _ in range(steps):
         step()
