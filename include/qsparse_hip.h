@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 19
+#define QS_ABI_VERSION 20
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -251,6 +251,14 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
  * per-channel abs-max without atomics. */
 int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
                    const int32_t* l0_flag, float* amax_part, qs_stream_t stream);
+
+/* The ONE stage of squeeze_tensor_to_shape (qsparse/util.py:92-99) for a channels_last activation x[N][H][W][C] whose first --
+ * and then only -- reduced dim is W (a mask that keeps N, C and H; `prune(dimensions={0, 1, 2})`, qsparse/sparse.py:228-249):
+ * mean over W -> out[N][C][H], NCHW-contiguous like Tensor.mean(3, keepdim=True) of such a tensor, in ATen's summation order
+ * for it (scalar inner sum: four interleaved cascade sums over w, then ((p0 + p1) + p2) + p3; NOT the vectorised order of the
+ * contiguous NCHW row).  flags / l0_flag as for qs_mean_dim.  (ABI v20) */
+int qs_mean_cl_w(const void* x, void* out, int64_t N, int64_t H, int64_t W, int64_t C, int xdt, int odt, int flags,
+                 const int32_t* l0_flag, qs_stream_t stream);
 
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].

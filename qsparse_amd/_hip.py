@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 19          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 20          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
+    "qs_mean_cl_w": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
     "qs_multi_scale_update": (c_int, [_P, _I, _I, _P]),
@@ -850,6 +851,18 @@ def mean_dim_cl(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, want_a
                                    _ptr(part), _stream(x_nhwc))
     _check(st, "qs_mean_dim_cl")
     return out, part
+
+
+def mean_cl_w(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, l0_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """the one squeeze stage of a channels_last activation, given as its contiguous [N, H, W, C] view, whose first reduced dim
+    is W: mean over W -> [N, C, H] (NCHW order) in ATen's order for that layout (qs_mean_cl_w)"""
+    N, H, W, C = x_nhwc.shape
+    out = torch.empty(N * C * H, dtype=out_dtype, device=x_nhwc.device)
+    with _timed("mean_dim", x_nhwc, out):
+        st = load().qs_mean_cl_w(_ptr(x_nhwc), _ptr(out), N, H, W, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(l0_flag),
+                                 _stream(x_nhwc))
+    _check(st, "qs_mean_cl_w")
+    return out
 
 
 def l0_flag(x: torch.Tensor) -> torch.Tensor:

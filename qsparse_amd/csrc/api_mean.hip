@@ -221,6 +221,28 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
     });
 }
 
+int qs_mean_cl_w(const void* x, void* out, int64_t N, int64_t H, int64_t W, int64_t C, int xdt, int odt, int flags,
+                 const int32_t* l0_flag, qs_stream_t stream) {
+    if (!x || !out || N < 1 || H < 1 || W < 1 || C < 1) return QS_ERR_ARG;
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    ActSpec act;
+    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    flags &= 0xff;
+    const int64_t total = N * H * C;
+    if ((total + kBlock - 1) / kBlock > 0x7fffffff) return QS_ERR_ARG;
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+        if (odt == QS_F32)
+            hipLaunchKernelGGL((mean_cl_w_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, N * H, H, W, C, flags,
+                               l0_flag, act);
+        else
+            hipLaunchKernelGGL((mean_cl_w_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, N * H, H, W, C, flags,
+                               l0_flag, act);
+        return launch_status();
+    });
+}
+
 int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, const float* amax_part,
                   float* absmax_out, int64_t absmax_stride, float* record, qs_stream_t stream) {
     if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;

@@ -1121,6 +1121,27 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
     if (amax_part) amax_part[o] = amax;
 }
 
+// ---- channels_last activation whose FIRST reduced dim is W (a mask that keeps N, C and H: `prune(dimensions={0, 1, 2})`) ------
+// x: [N][H][W][C] in memory.  ATen's TensorIterator puts the reduced dim (W, C elements apart) innermost and H next; with
+// in_stride[0] < in_stride[1] its sum kernel takes scalar_inner_sum (SumKernel.cpp), i.e. row_sum per output: four interleaved
+// cascade sums over w (w feeds sum w % 4), the W % 4 last elements added to the first, then ((p0 + p1) + p2) + p3 -- NOT the
+// vectorised inner sum it uses for the contiguous NCHW row (checked against Tensor.mean(3) on the CPU, tests/test_aten_contract.py).
+// One lane per output (n, h, c), in memory order (a wave's loads are contiguous); the result is NCHW-contiguous [N][C][H] like
+// ATen's.  Until ABI v20 such inputs were copied to NCHW and summed in THAT order (a last float32 bit).
+template <int DT, int ODT>
+__global__ __launch_bounds__(kBlock) void mean_cl_w_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t NH,
+                                                            int64_t H, int64_t W, int64_t C, int flags,
+                                                            const int32_t* __restrict__ l0_flag, ActSpec act) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // t = p * C + c,  p = n * H + h
+    if (t >= NH * C) return;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int64_t p = t / C, c = t - p * C;
+    auto get = [&](int64_t i) { return mean_prep<DT>(load1<DT>(x, (p * W + i) * C + c), flags, l0, act); };
+    const float s = sum_row_sum(W, get);
+    const int64_t n = p / H, h = p - n * H;
+    store1<ODT>(out, (n * C + c) * H + h, s / (float)W);
+}
+
 // ---- the same stage for tensors with FEW columns: rows split over R waves of one workgroup -------------------
 // With C*H*W small (late ResNet stages, small batches of small maps) one wave per 512 columns leaves most CUs
 // with one or two waves and the kernel becomes latency-bound.  Here the R waves of a workgroup own the SAME

@@ -182,6 +182,16 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
             cur = _hip.mean_dim(xm.reshape(N * H * W, C), N * H * W, C, 1, torch.float32 if l0_flag is not None else x.dtype,
                                 flags, **kw).view(N, 1, H, W)
             dims, first = dims[1:], False
+    if cur is None and x.dim() == 4 and dims and dims[0] == 3 and x.shape[2] > 1 and x.shape[3] > 1 and absmax_out is None:
+        # channels_last activation whose first (and then only) reduced dim is W -- a mask that keeps N, C and H: ATen sums the
+        # strided rows with its scalar inner loop (row-sum order), not in the vectorised order of the contiguous NCHW row:
+        # qs_mean_cl_w on the memory view, no copy (identity pinned in tests/test_aten_contract.py)
+        xm, _, like = _hip.mem_view(x, 1)
+        if xm is not like:
+            N, C, H, W = x.shape
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
+            cur = _hip.mean_cl_w(xm, torch.float32 if l0_flag is not None else x.dtype, flags, l0_flag).view(N, C, H, 1)
+            dims, first = dims[1:], False
     if cur is None:
         cur = _hip.dense(x)
     shape = list(cur.shape)

@@ -181,7 +181,7 @@ def build(rng):
         desc.update(channelwise=cw, shape=shape)
         return desc, (lambda: qs.quantize(bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb))), shape, dtype
     if what == "act_p":
-        dims = rng.choice([{1}, {1}, {0, 1}, {2, 3}, {1, 2, 3}, {0, 1, 2, 3}, {0}])
+        dims = rng.choice([{1}, {1}, {0, 1}, {2, 3}, {1, 2, 3}, {0, 1, 2, 3}, {0}, {0, 1, 2}])
         desc.update(dimensions=sorted(dims))
         cb = pcb()
         return desc, (lambda: qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
@@ -472,11 +472,12 @@ def one_case(rng, idx, dry=False):
     steps = rng.choice([3, 5, 6]) if desc["what"] != "site" else rng.choice([6, 8, 10])
     eval_from = rng.choice([steps, steps - 1])
     channels_last = rng.random() < 0.4
-    if desc["what"] in ("act_p", "act_pq"):   # statistics of channels_last inputs: bit-exact whenever the batch dim is reduced first
-        # ... or, with the batch dim kept (per-sample masks, every batch of one), C or H leads the reduced dims; a reduction that
-        # STARTS with W of an NHWC tensor is the one order not reproduced (it takes the NCHW copy: a last float32 bit)
+    if desc["what"] in ("act_p", "act_pq"):
+        # statistics of channels_last inputs follow ATen's own order for that layout whichever dim leads the reduced ones (N: the
+        # multi-row / row-sum split; C or H with the batch dim kept; W: the scalar inner sum, qs_mean_cl_w since ABI v20).  The one
+        # layout left to its NCHW copy: W leading with H == 1, where "channels_last" strides say nothing about the order
         reduced = [d for d in range(len(shape)) if d not in desc.get("dimensions", [1]) and shape[d] > 1]
-        channels_last = channels_last and len(shape) == 4 and (not reduced or reduced[0] != 3)
+        channels_last = channels_last and len(shape) == 4 and (not reduced or reduced[0] != 3 or shape[2] > 1)
     batcher = rng.random() < 0.6
     twin = rng.random() < 0.25
     nonfinite = None

@@ -62,3 +62,57 @@ def test_aten_reduces_h_of_a_channels_last_sample_like_the_batch_of_its_rows():
         assert not torch.equal(x.mean(1, keepdim=True), x.contiguous().mean(1, keepdim=True))
     finally:
         torch.set_num_threads(before)
+
+
+def test_aten_reduces_w_of_a_channels_last_tensor_in_row_sum_order():
+    """`x.mean(3, keepdim=True)` of a channels_last tensor (a mask that keeps N, C and H): ATen's scalar inner sum -- four
+    interleaved cascade sums over w, the W % 4 last elements added to the first, ((p0 + p1) + p2) + p3 -- which is what
+    qs_mean_cl_w restates (qsparse_amd/csrc/qs_reduce.h); NOT the order of the contiguous NCHW row"""
+    import numpy as np
+
+    def multi_row(v):
+        n = v.shape[0]
+        lp = max(4, (0 if n <= 1 else (n - 1).bit_length()) // 4)
+        step, lmask = 1 << lp, (1 << lp) - 1
+        a = [np.zeros(v.shape[1], np.float32) for _ in range(4)]
+        i = 0
+        while i + step <= n:
+            for j in range(step):
+                a[0] = a[0] + v[i + j]
+            i += step
+            a[1] = a[1] + a[0]
+            a[0] = np.zeros_like(a[0])
+            if (i & (lmask << lp)) == 0:
+                a[2] = a[2] + a[1]
+                a[1] = np.zeros_like(a[1])
+                if (i & (lmask << (2 * lp))) == 0:
+                    a[3] = a[3] + a[2]
+                    a[2] = np.zeros_like(a[2])
+        while i < n:
+            a[0] = a[0] + v[i]
+            i += 1
+        return ((a[0] + a[1]) + a[2]) + a[3]
+
+    def row_sum(v):
+        n4 = v.shape[0] // 4
+        p = [multi_row(v[k:n4 * 4:4]) if n4 else np.zeros(v.shape[1], np.float32) for k in range(4)]
+        for i in range(n4 * 4, v.shape[0]):
+            p[0] = p[0] + v[i]
+        return ((p[0] + p[1]) + p[2]) + p[3]
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        g = torch.Generator().manual_seed(0)
+        differs_from_nchw = 0
+        for N, C, H, W in [(2, 8, 5, 7), (4, 16, 14, 14), (3, 24, 7, 56), (2, 64, 28, 28), (8, 3, 9, 33), (1, 8, 5, 17), (2, 5, 3, 100),
+                           (2, 8, 4, 300), (2, 8, 3, 3), (2, 16, 2, 9)]:
+            x = (torch.randn(N, C, H, W, generator=g) * 3).contiguous(memory_format=torch.channels_last)
+            a = x.abs().mean(3, keepdim=True)
+            v = x.abs().permute(3, 0, 2, 1).contiguous().view(W, -1).numpy()          # [W, N*H*C]
+            b = torch.from_numpy((row_sum(v) / np.float32(W)).astype(np.float32)).view(N, H, C).permute(0, 2, 1).unsqueeze(-1)
+            assert torch.equal(a, b.contiguous()), (N, C, H, W)
+            differs_from_nchw += int(not torch.equal(a, x.abs().contiguous().mean(3, keepdim=True)))
+        assert differs_from_nchw >= 3          # (which is why the NCHW copy's order was a deviation)
+    finally:
+        torch.set_num_threads(threads)

@@ -1414,3 +1414,36 @@ def test_minmax_key_accumulation_equals_the_float_route():
                     _hip.lines_update(mn, mx, lb, t + 1)
                     assert same(la.cpu(), lb.cpu()), (shape, ci, dtype, cl, t)
                     assert bool((keys[0] == -1).all()) and not keys[1].any(), (shape, ci, dtype, cl, t)     # neutral again
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_channels_last_reduction_that_starts_with_w_follows_atens_order(dtype):
+    """a mask that keeps N, C and H (`prune(dimensions={0, 1, 2})`): squeeze_tensor_to_shape reduces W alone, which ATen sums
+    in row-sum order for a channels_last tensor (reference util.py:92-99 on such an input; qs_mean_cl_w, ABI v20)"""
+    import qsparse_amd as qs
+    from qsparse_amd.util import squeeze_tensor_to_shape
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        g = torch.Generator().manual_seed(2)
+        for N, C, H, W in [(2, 8, 5, 7), (4, 16, 14, 14), (3, 24, 7, 56), (2, 64, 28, 28), (8, 3, 9, 33), (2, 5, 3, 100), (2, 8, 4, 300),
+                           (2, 16, 2, 9), (1, 8, 5, 17)]:
+            x = (torch.randn(N, C, H, W, generator=g) * 3).to(dtype).contiguous(memory_format=torch.channels_last)
+            want = squeeze_tensor_to_shape(x, [N, C, H, 1])
+            got = squeeze_tensor_to_shape(x.cuda(), [N, C, H, 1])
+            assert got.dtype == want.dtype and torch.equal(got.cpu(), want), (N, C, H, W)
+        # the prune layer end to end: importance, running magnitude, mask
+        outs = []
+        for dev in ("cpu", "cuda"):
+            p = qs.prune(sparsity=0.5, dimensions={0, 1, 2}, start=1, interval=1, repetition=2).to(dev).train()
+            gg = torch.Generator().manual_seed(3)
+            rec = []
+            for _ in range(5):
+                x = (torch.randn(4, 8, 6, 10, generator=gg) * 2).to(dtype).contiguous(memory_format=torch.channels_last).to(dev)
+                rec.append(p(x).cpu())
+            outs.append(rec + [p.mask.cpu(), p.callback.magnitude.cpu()])
+        for i, (a, b) in enumerate(zip(*outs)):
+            assert torch.equal(a, b), i
+    finally:
+        torch.set_num_threads(threads)
