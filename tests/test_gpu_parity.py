@@ -391,9 +391,13 @@ def test_l0_and_unstructured_and_2d_vs_oracle():
 
 
 def test_abi_rejects_bad_arguments_loudly():
+    # a dtype the kernels are not written for never reaches them: the binding refuses it ...
     x = torch.randn(64, device=DEV, dtype=torch.float64)
     with pytest.raises(_hip.QsparseHipError):
-        quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
+        _hip.dt(x)
+    # ... and the operators evaluate such a tensor with the package's ATen expression on the device (tests/test_other_dtypes_gpu.py)
+    y64 = quantize_with_scaler(x, 8, torch.tensor([[0.1]], device=DEV))
+    assert y64.dtype == torch.float32 and same(y64.cpu(), quantize_with_scaler(x.cpu(), 8, torch.tensor([[0.1]])))
     lib = _hip.load()
     y = torch.empty(64, device=DEV)
     st = lib.qs_quant_scaler_fwd(y.data_ptr() + 4, y.data_ptr(), None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None)
