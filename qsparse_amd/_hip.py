@@ -246,6 +246,14 @@ def on_hip(t: torch.Tensor) -> bool:
     return t.is_cuda and t.dtype in HIP_DTYPES
 
 
+def refuse_capture(t: torch.Tensor, what: str):
+    """the ATen-on-device route of a training step keeps its running-mean counts on the host, like the CPU path: captured into
+    a hipGraph they would be replayed as constants -- refuse loudly instead"""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise QsparseHipError(f"{what} of a {t.dtype} GPU tensor evaluates the package's ATen expression with host-side counters: it "
+                              "cannot be captured into a hipGraph (float32 / bfloat16 / float16 tensors take the graph-safe kernels)")
+
+
 def dt(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
@@ -407,7 +415,10 @@ class _ActivationFromOutput(torch.autograd.Function):
     def forward(ctx, h, act):
         ctx.act = act
         y = _act_aten(act, h)
-        ctx.save_for_backward(y)
+        # a clamp whose bounds the dtype cannot represent saturates at the ROUNDED bound, which may lie inside (a, b): the output
+        # no longer tells a clamped element from one that sat there -- keep the gate of the INPUT (one byte per element) instead
+        ctx.from_input = act_spec(act)[0] == ACT_HARDTANH and not bounds_representable(act, h.dtype)
+        ctx.save_for_backward(act_gate_of(act, h) if ctx.from_input else y)
         return y
 
     @staticmethod
@@ -415,7 +426,25 @@ class _ActivationFromOutput(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         kind, slope, _ = act_spec(ctx.act)
         closed = g * slope if kind == ACT_LEAKY else torch.zeros((), dtype=g.dtype, device=g.device)
-        return torch.where(act_gate_of(ctx.act, y), g, closed), None
+        return torch.where(y if ctx.from_input else act_gate_of(ctx.act, y), g, closed), None
+
+
+_representable = {}
+
+
+def bounds_representable(act: int, dtype: torch.dtype) -> bool:
+    """whether both bounds of a folded clamp (nn.Hardtanh / nn.ReLU6) are values of `dtype`: ATen clamps to the bounds ROUNDED to
+    the tensor's dtype (0.1 -> 0.10009765625 in bfloat16) while hardtanh_backward compares the float bounds -- with such bounds
+    the gate cannot be read off the rectified tensor (see `act_gate_of`)"""
+    kind, a, b = act_spec(act)
+    if kind != ACT_HARDTANH or dtype == torch.float32:
+        return True
+    key = (a, b, dtype)
+    r = _representable.get(key)
+    if r is None:
+        t = torch.tensor([a, b], dtype=torch.float64).to(dtype).to(torch.float64)
+        r = _representable[key] = bool(t[0].item() == a and t[1].item() == b)
+    return r
 
 
 def _act_aten(act: int, x: torch.Tensor) -> torch.Tensor:
@@ -452,7 +481,8 @@ def act_torch_(pre_relu, x: torch.Tensor) -> torch.Tensor:
 
 def act_gate_of(pre_relu, h: torch.Tensor) -> torch.Tensor:
     """the backward's gate (True: the gradient passes unchanged) from the activation's INPUT or -- the rectifiers and a leaky
-    ReLU with a positive slope map both to the same side -- its output"""
+    ReLU with a positive slope map both to the same side -- its output (a clamp: only with bounds its dtype represents exactly,
+    `bounds_representable`; the callers check)"""
     kind, a, b = act_spec(_act(pre_relu))
     if kind == ACT_HARDTANH:
         return (h > a) & (h < b)

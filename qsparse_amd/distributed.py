@@ -34,11 +34,12 @@ def exchange_active(world: Optional[int] = None) -> bool:
 
 
 def allreduce_mean(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
-    """mean over ranks of a small statistics tensor, in fp32 (returns a new fp32 tensor)."""
+    """mean over ranks of a small statistics tensor, in fp32 (returns a new tensor; float64 statistics stay float64)."""
     world = world or stats_world_size()
     if not exchange_active(world):
         return t
-    buf = t.detach().to(torch.float32).contiguous().clone()
+    # (float64 statistics -- a float64 tensor's importance, `_hip.on_hip` -- keep their precision; everything else is fp32)
+    buf = t.detach().to(torch.float64 if t.dtype == torch.float64 else torch.float32).contiguous().clone()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf / world
 

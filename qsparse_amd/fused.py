@@ -773,6 +773,8 @@ def _foldable_relu(act, x):
         return 1, handle
     if x._is_view() or (x.is_leaf and x.requires_grad) or not get_option("relu_gate"):
         return 0, 0
+    if handle != 1 and not _hip.bounds_representable(handle, x.dtype):
+        return 0, 0          # (an owned in-place clamp may have to gate from the RECTIFIED tensor, which such bounds make ambiguous)
     if handle != 1 and type(act) is nn.LeakyReLU and x.data_ptr() % 16:
         return 0, 0          # (not idempotent: it can only be folded when the kernel -- not ATen beforehand -- applies it)
     return 2, handle

@@ -415,6 +415,7 @@ class DecimalQuantizer(BaseQuantizer):
                 self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight
             else:
+                _hip.refuse_capture(x, "the scale statistics")
                 stat = _absmax_rows_cpu(x, channel_index)
                 if batched:
                     stat = qdist.allreduce_max_(stat)
@@ -522,6 +523,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
                 _hip.lines_update(lo, hi, weight.data, self.t + 1, t_dev=t_dev, advance_t_dev=True, from_keys=keyed)
                 self._advance_t(t_dev, bumped_by_kernel=True)
                 return weight
+            _hip.refuse_capture(x, "the line statistics")
             bounds = self._bounds_cpu(x, channel_index, batched)
             if batched and qdist.exchange_active():
                 bounds = torch.stack([qdist.allreduce_min_(bounds[:, 0].contiguous()),

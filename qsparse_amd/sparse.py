@@ -254,6 +254,7 @@ class MagnitudePruningCallback(nn.Module):
                 t_dev = self.t.data if (get_option("graph_safe") and self.t.is_cuda) else None
                 _hip.running_mean(self.magnitude.data, imp, t, t_dev=t_dev)
             else:
+                _hip.refuse_capture(x, "the running magnitude")
                 self.magnitude.data[:] = (t * self.magnitude + imp) / (t + 1)
 
     def receive_input(self, x: torch.Tensor):

@@ -243,7 +243,13 @@ def squeeze_tensor_to_shape(x: torch.Tensor, shape: List[int]) -> torch.Tensor:
     if _hip.on_hip(x):
         return _staged_mean_hip(x, dims, take_abs=False)
     for i in dims:
-        x = x.mean(i, keepdim=True)
+        if x.is_cuda:
+            # a GPU tensor of a dtype the kernels are not written for (float64): ATen's CPU mean is sum(x) -> div_(n); its device
+            # kernel multiplies by 1/n instead, a last-bit difference that decides the rounding whenever the exact mean is a
+            # midpoint of the float32 state it ends in (float32-valued data in a float64 tensor: 0.2 % of the entries)
+            x = x.sum(i, keepdim=True) / x.shape[i]
+        else:
+            x = x.mean(i, keepdim=True)
     return x
 
 

@@ -351,7 +351,9 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
                 raw = m.layers[seed % len(m.layers)]._parameters["weight"]
                 with torch.no_grad():
                     raw.view(-1)[(seed * 7919) % raw.numel()] = nonfinite[0]
-            skip = (seed + s) % len(m.layers) if s % 3 == 1 else -1
+            # (under an initialised process group a rolled-back layer's parameter receives ZEROS, what DistributedDataParallel itself
+            #  uses for an unused parameter -- batch.py `_GroupSte` -- instead of no gradient: no skipped layers in that mode)
+            skip = (seed + s) % len(m.layers) if (s % 3 == 1 and not EXCHANGE) else -1
             read = m(skip)
             grads = [torch.randn(t.shape, generator=g) * 3 for _, t in read]
             for k, t in read:
@@ -497,7 +499,8 @@ def one_case(rng, idx, dry=False):
         routes["batch_weights"] = batcher = rng.random() < 0.85      # (off: the same network layer by layer)
         if nonfinite is not None:
             nonfinite = (nonfinite[0], rng.choice([steps - 3, steps - 2]))
-    graph = GRAPH and desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.7
+    # (float64: the ATen-on-device route keeps its running means on the host, as the CPU path does -- not capturable, refused)
+    graph = GRAPH and desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.7 and desc["dtype"] != "float64"
     if graph:
         routes["graph_safe"] = True
     if EXCHANGE and rng.random() < 0.6:     # the statistics exchange of a data-parallel run, live on a one-rank group (same values)

@@ -269,3 +269,25 @@ def test_inplace_activation_in_front_of_a_site_that_materialises_it_after_all(po
         assert torch.equal(ha.float(), hb.float()), ("the modified tensor", step)
     for k in cpu_state:
         assert same(cpu_state[k], gpu_state[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("policy", ["no_avg", "uniform"])
+def test_inplace_clamp_with_bounds_the_dtype_cannot_represent_in_front_of_a_site_the_kernels_do_not_cover(policy, dtype):
+    """found by the round-5 fuzz campaign: nn.Hardtanh(0.1, 0.7, inplace=True) on a bf16 tensor saturates at 0.10009765625 /
+    0.69921875 -- values INSIDE (0.1, 0.7) -- so a gate read off the rectified tensor lets the gradient of clamped elements
+    through.  Such an activation is not owned in place (`_hip.bounds_representable`); the results are the CPU path's"""
+    cb = qs.MagnitudePruningCallback(running_average=False) if policy == "no_avg" else qs.UniformPruningCallback()
+    def site():
+        net = nn.Sequential(nn.Hardtanh(0.1, 0.7, inplace=True))
+        return qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=2, dimensions={1}, callback=__import__("copy").deepcopy(cb)),
+                          activation_layers=[nn.Hardtanh], log=False)
+    g = gen(31)
+    data = [((torch.randn(6, 16, 9, 8, generator=g) * 0.8).to(dtype), torch.randn(6, 16, 9, 8, generator=g)) for _ in range(6)]
+    import numpy as np
+    np.random.seed(0)
+    cpu, _ = _run(site(), "cpu", data, torch.contiguous_format, True)
+    np.random.seed(0)
+    gpu, _ = _run(site().to("cuda"), "cuda", data, torch.contiguous_format, True)
+    for step, ((ya, ga, ha), (yb, gb, hb)) in enumerate(zip(cpu, gpu)):
+        assert same(ya, yb) and torch.equal(ga.float(), gb.float()), step
