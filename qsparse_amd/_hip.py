@@ -246,6 +246,16 @@ def on_hip(t: torch.Tensor) -> bool:
     return t.is_cuda and t.dtype in HIP_DTYPES
 
 
+def true_div(a: torch.Tensor, n) -> torch.Tensor:
+    """``a / n`` for a Python number ``n`` as ATen's CPU kernels evaluate it: a correctly rounded division.  On the device ATen
+    turns a division by a host scalar into a multiplication by its reciprocal (BinaryDivTrueKernel.cu: "compute a *
+    reciprocal(b)"), one more rounding -- which the GPU tensors that take the ATen expression (`on_hip`) must not see: there the
+    divisor is made a device tensor, for which ATen divides."""
+    if not a.is_cuda:
+        return a / n
+    return a / torch.full((), n, dtype=a.dtype if a.is_floating_point() else torch.get_default_dtype(), device=a.device)
+
+
 def refuse_capture(t: torch.Tensor, what: str):
     """the ATen-on-device route of a training step keeps its running-mean counts on the host, like the CPU path: captured into
     a hipGraph they would be replayed as constants -- refuse loudly instead"""

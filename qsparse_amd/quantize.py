@@ -423,7 +423,7 @@ class DecimalQuantizer(BaseQuantizer):
                 if self.t == 0:
                     weight = new_weight
                 else:
-                    weight.data[:] = (self.t * weight + new_weight) / (self.t + 1)
+                    weight.data[:] = _hip.true_div(self.t * weight + new_weight, self.t + 1)
         self.t += 1
         return weight
 
@@ -436,11 +436,15 @@ class DecimalQuantizer(BaseQuantizer):
             logging.danger(f"clustering {len(scaler)} channels into {self.group_num} groups")
             labels = AgglomerativeClustering(n_clusters=self.group_num).fit(scaler.detach().cpu().numpy()).labels_
             self.groups = nn.Parameter(torch.from_numpy(labels).to(scaler.device), requires_grad=False)
-        shared = torch.clone(scaler)
+        # the group means on the host copy of the (C-sized) scales: the reference's own ATen CPU arithmetic, bit for bit -- the
+        # device's mean kernel sums in another order and multiplies by 1/k -- and one round trip instead of a boolean-index sync
+        # per group
+        shared = scaler.detach().cpu().clone() if scaler.is_cuda else torch.clone(scaler)
+        groups = self.groups.detach().cpu() if self.groups.is_cuda else self.groups
         for gi in range(self.group_num):
-            member = self.groups == gi
+            member = groups == gi
             shared[member] = shared[member].mean(dim=0)
-        return shared
+        return shared.to(scaler.device)
 
     def forward(self, tensor, bits, scaler, channel_index=-1, **kwargs):
         if self.t >= self.group_timeout and self.group_num > 0 and scaler.numel() > self.group_num:
@@ -532,7 +536,7 @@ class AdaptiveQuantizer(DecimalQuantizer):
             if weight is None:
                 return bounds
             assert bounds.shape == weight.shape
-            return (weight * (self.t - 1) + bounds) / self.t
+            return _hip.true_div(weight * (self.t - 1) + bounds, self.t)
 
 
 # ----------------------------------------------------------------------------------------------

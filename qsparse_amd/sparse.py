@@ -255,7 +255,7 @@ class MagnitudePruningCallback(nn.Module):
                 _hip.running_mean(self.magnitude.data, imp, t, t_dev=t_dev)
             else:
                 _hip.refuse_capture(x, "the running magnitude")
-                self.magnitude.data[:] = (t * self.magnitude + imp) / (t + 1)
+                self.magnitude.data[:] = _hip.true_div(t * self.magnitude + imp, t + 1)
 
     def receive_input(self, x: torch.Tensor):
         if not self.use_gradient:

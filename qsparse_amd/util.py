@@ -243,11 +243,11 @@ def squeeze_tensor_to_shape(x: torch.Tensor, shape: List[int]) -> torch.Tensor:
     if _hip.on_hip(x):
         return _staged_mean_hip(x, dims, take_abs=False)
     for i in dims:
-        if x.is_cuda:
+        if x.is_cuda and x.is_floating_point():
             # a GPU tensor of a dtype the kernels are not written for (float64): ATen's CPU mean is sum(x) -> div_(n); its device
-            # kernel multiplies by 1/n instead, a last-bit difference that decides the rounding whenever the exact mean is a
+            # kernels multiply by 1/n instead, a last-bit difference that decides the rounding whenever the exact mean is a
             # midpoint of the float32 state it ends in (float32-valued data in a float64 tensor: 0.2 % of the entries)
-            x = x.sum(i, keepdim=True) / x.shape[i]
+            x = _hip.true_div(x.sum(i, keepdim=True), x.shape[i])
         else:
             x = x.mean(i, keepdim=True)
     return x

@@ -98,8 +98,11 @@ def test_folded_activation_sites_equal_the_cpu_path(kind, act, inplace, dtype, f
     assert cpu_state.keys() == gpu_state.keys()
     for k in cpu_state:
         assert same(cpu_state[k], gpu_state[k]), k
-    # steps 0 and 1: the operators are inactive (module by module: 2 calls); afterwards everything is folded
-    assert len(calls) == 2, calls
+    # steps 0 and 1: the operators are inactive (module by module: 2 calls); afterwards everything is folded -- except an
+    # IN-PLACE clamp whose bounds the dtype cannot represent: its saturated values (0.10009765625, 0.69921875 in bf16) lie inside
+    # (0.1, 0.7), so the gate cannot be read off the rectified tensor and the module keeps running by itself (fused._foldable_relu)
+    unfolded = act == "hardtanh_odd" and inplace and dtype != torch.float32
+    assert len(calls) == (8 if unfolded else 2), calls
 
 
 @pytest.mark.parametrize("quantizer", [DecimalQuantizer])
