@@ -136,6 +136,14 @@ def _timed_loop(fn, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def _steady_ms(fn, steps, rounds=3):
+    """eager step time of a network in steady state: the best of `rounds` timed loops.  (A single loop right after the warm-up
+    steps reads 5-12 % high on host-bound networks -- allocator pools, MIOpen's per-shape caches and the sites' fast paths are
+    still settling: round 5's first record had the default ResNet-18 at 7.51 ms and the SAME kernels, measured a minute later as
+    the `elide_off` variant, at 6.71.)  Plain and converted networks are measured the same way."""
+    return min(_timed_loop(fn, steps) for _ in range(rounds))
+
+
 def config2(device, steps=200, nbuf=4):
     """BASELINE config 2: QuantizeLayer(bits=8, tensor-wise) alone, training step (abs-max + running scale + apply
     forward + STE backward = 14 B/elem) on 256x64x56x56 bf16, `nbuf` rotating buffer sets (4 x 103 MB of inputs + 4 x 206 MB
@@ -341,7 +349,7 @@ def resnet_config(arch, batch, device, steps):
     model, step = build(False)
     for _ in range(6):
         step()
-    out["plain_ms"] = round(_timed_loop(step, steps), 3)
+    out["plain_ms"] = round(_steady_ms(step, steps), 3)
     gr = capture(step)
     out["plain_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
     del model, step, gr
@@ -353,7 +361,7 @@ def resnet_config(arch, batch, device, steps):
         model, step = build(True)
         for _ in range(8):
             step()
-        out["pq_ms"] = round(_timed_loop(step, steps), 3)
+        out["pq_ms"] = round(_steady_ms(step, steps), 3)
         out["library_kernels"] = library_kernel_accounting(step)
         lib_ms = out["library_kernels"]["ms_per_step"]
         ref = kernel_trace_reference("config3" if arch == "resnet18" else "config4")
@@ -380,7 +388,7 @@ def resnet_config(arch, batch, device, steps):
                 model, step = build(True)
                 for _ in range(8):
                     step()
-                rec = {"options": label, "pq_ms": round(_timed_loop(step, steps), 3)}
+                rec = {"options": label, "pq_ms": round(_steady_ms(step, steps), 3)}
                 if graph and graphs.steady_state(model):
                     gr = capture(step)
                     rec["pq_graph_ms"] = round(_timed_loop(lambda i: gr.replay(), steps), 3)
