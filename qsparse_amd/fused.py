@@ -269,6 +269,26 @@ def _image_consumers():
 
 _IMAGE_CONSUMERS = _image_consumers()
 _GRADIENT_OBSERVERS = frozenset([torch.Tensor.register_hook, torch.Tensor.retain_grad])
+# calls that read a tensor's metadata (or alias it without a gradient path): they do not make the tensor's gradient a sum of one
+# more term.  EVERYTHING else that touches a site's output before its image consumer does cancels the image -- the image consumer is
+# then always the FIRST consumer, whose backward autograd runs last: its share is the last term of the float32 accumulation in both
+# routes, so sums of three and more gradient streams keep the reference's grouping (found by tests/fuzz/fuzz_image.py: a residual
+# read BEFORE the convolution gave (g_cat + g_res) + g_conv against autograd's (g_cat + g_conv) + g_res, one float32 ulp apart)
+_NON_CONSUMING = frozenset(getattr(torch.Tensor, n) for n in (
+    "size", "dim", "ndimension", "stride", "numel", "nelement", "is_contiguous", "data_ptr", "storage_offset", "element_size",
+    "is_floating_point", "is_complex", "get_device", "dim_order", "detach", "__len__", "__repr__", "__str__", "__format__",
+    "is_shared", "is_pinned", "has_names", "untyped_storage") if hasattr(torch.Tensor, n))
+
+
+def _cancel_images(args):
+    """drop the image of every site output among `args` (one level of lists / tuples deep: torch.cat([y, z]))"""
+    for a in args:
+        if type(a) is AutocastImageTensor:
+            a.__dict__.pop("_qs_image", None)
+        elif isinstance(a, (list, tuple)):
+            for b in a:
+                if type(b) is AutocastImageTensor:
+                    b.__dict__.pop("_qs_image", None)
 
 
 def _whole(g, g16):
@@ -294,9 +314,10 @@ def _late_hook(dual, fn):
         if r is None:
             return None
         if g is None:
-            raise RuntimeError("a gradient hook registered on a site's output after its autocast image was consumed cannot REPLACE a "
-                               "gradient that only the image's consumer delivers: register the hook before the consumer runs, or "
-                               "set_qsparse_options(autocast_image=False)")
+            # (a pre-hook cannot put a gradient where autograd has none: the replacement rides on the node itself -- for a Python
+            #  Function the node IS the ctx -- and `_SiteStep.backward` takes it in place of both streams)
+            node._qs_override = r
+            return None
         return (r, None)
 
     return node.register_prehook(pre)
@@ -376,6 +397,8 @@ class AutocastImageTensor(torch.Tensor):
                         args = (img,) + tuple(args[1:])
             elif func is torch.autograd.grad:
                 return _grad_through_duals(args, kwargs)
+            elif func not in _NON_CONSUMING and getattr(func, "__name__", "") != "__get__":
+                _cancel_images(args)          # another consumer comes first: the image's would not be the last term of the sum
             return func(*args, **(kwargs or {}))
 
     def __repr__(self):
@@ -468,6 +491,9 @@ class _SiteStep(torch.autograd.Function):
     def backward(ctx, g, g16=None):
         plan, flags = ctx.plan, ctx.flags
         n_in = 13
+        override = ctx.__dict__.pop("_qs_override", None) if hasattr(ctx, "__dict__") else None
+        if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
+            g, g16 = override, None
         if g is None and g16 is None:
             return (None,) * n_in
         mask_c, scale, third = ctx.saved_tensors

@@ -388,3 +388,22 @@ def test_under_distributed_data_parallel_the_gradients_are_those_of_the_plain_ro
     finally:
         qs.set_qsparse_options(autocast_image=True)
         dist.destroy_process_group()
+
+
+def test_a_consumer_that_reads_the_output_before_the_convolution_cancels_the_image():
+    """three gradient streams (a residual read BEFORE the convolution, the convolution, a `cat` after it): autograd sums them in
+    reverse order of creation; only a FIRST consumer's share is the last term in both routes, so anything that touches the output
+    before the image consumer cancels the image (found by tests/fuzz/fuzz_image.py: one float32 ulp in the summed gradient)"""
+    site = _pair().to(DEV).train()
+    conv = nn.Conv2d(16, 16, 1, bias=False).to(DEV)
+    for s in range(4):
+        x = torch.randn(4, 16, 8, 8, generator=gen(s)).bfloat16().to(DEV).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = site(x)
+            if s == 3:
+                assert type(y) is AutocastImageTensor and "_qs_image" in y.__dict__
+                assert y.shape[1] == 16 and y.dim() == 4 and y.is_contiguous() and y.dtype == torch.float32       # metadata: no consumer
+                assert "_qs_image" in y.__dict__
+                r = y * 0.5                                     # a consumer
+                assert "_qs_image" not in y.__dict__
+            conv(y).float().sum().backward()

@@ -76,3 +76,15 @@ def test_modules_with_steady_state_steps_replayed_from_a_hipgraph():
     bad = [r for r in (fz.one_case(rng, i) for i in range(120)) if r not in ("ok", None)]
     assert not bad, bad[:3]
     assert fz.GRAPHED[0] >= 10, fz.GRAPHED[0]
+
+
+def test_autocast_image_route_against_the_plain_route():
+    """tests/fuzz/fuzz_image.py: random sites in front of real autocast consumers, with the image (the default) against
+    `autocast_image=False`, everything the user can observe bit for bit -- consumer orders, late hooks, replacing hooks,
+    retained gradients, autograd.grad with respect to the output, evaluation steps, in-place activations, fp16 autocast"""
+    fz = _load("fuzz_image")
+    fz.USED[0] = 0
+    rng = random.Random(2029)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(150)) if r != "ok"]
+    assert not bad, bad[:3]
+    assert fz.USED[0] >= 60, fz.USED[0]

@@ -3,7 +3,7 @@
 # The randomised differential campaigns of tests/fuzz/ on the tree as it is (keep the summaries of the final
 # kernels): CPU path vs HIP path of modules (NaN / Inf / -Inf in 30 % of the cases), of converted weight networks, of the functional
 # API; sites vs the oracle's state machines; the same with the statistics exchange live on a one-rank RCCL group; with steady-state
-# steps replayed from a hipGraph.
+# steps replayed from a hipGraph; the autocast image route against the plain route under torch.autocast.
 tag=${1:-r05}; scale=${2:-1}
 out=gpurun_out/profiles; mkdir -p $out
 sha=$(cat .tree_sha 2>/dev/null || echo unknown)
@@ -21,3 +21,4 @@ run functional        QS_FUZZ_MODE=functional python3 tests/fuzz/fuzz_cpu_gpu.py
 run oracle_sites      QS_X=1 python3 tests/fuzz/fuzz_parity.py $((2000*scale)) 13
 run exchange          QS_FUZZ_EXCHANGE=1 python3 tests/fuzz/fuzz_cpu_gpu.py $((2000*scale)) 14
 run graph             QS_FUZZ_GRAPH=1 python3 tests/fuzz/fuzz_cpu_gpu.py $((2000*scale)) 15
+run image             QS_X=1 python3 tests/fuzz/fuzz_image.py $((3000*scale)) 16
