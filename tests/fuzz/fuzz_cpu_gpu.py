@@ -118,20 +118,24 @@ def build(rng):
                 "no_avg_refresh": dict(running_average=False, mask_refresh_interval=2),
                 "freeze": dict(running_average=False, mask_refresh_interval=2, stop_mask_refresh=3)}[policy]
         with_quant = rng.random() < 0.75
+        # (quantize-only networks reach the steady-state fast path of the weight path, batch._Steady: every tensor quantized on every
+        #  read, the launch table re-issued after identity checks -- with the roll-backs of the skipped layers on top)
+        with_prune = not with_quant or rng.random() < 0.8
         cw = rng.choice([-1, 0, 1, 1])
         bias_bits = rng.choice([-1, -1, 8])
         c1, c2, c3 = rng.choice([4, 8, 12, 33]), rng.choice([4, 8, 16]), rng.choice([3, 8, 10])
         c0 = min(c, 33)
-        desc.update(dimensions=sorted(dims), policy=policy, with_quant=with_quant, channelwise=cw, bias_bits=bias_bits,
-                    widths=(c0, c1, c2, c3))
+        desc.update(dimensions=sorted(dims), policy=policy, with_quant=with_quant, with_prune=with_prune, channelwise=cw,
+                    bias_bits=bias_bits, widths=(c0, c1, c2, c3))
 
         def net_factory():
             torch.manual_seed(1234)
             net = WeightReader([nn.Conv2d(c0, c1, 3, padding=1), nn.Conv2d(c1, c2, 3, bias=False), nn.Conv2d(c2, c2, 1),
                                 nn.Conv2d(c2, c2, (1, 3)), nn.Linear(c2, c3)])
-            net = qs.convert(net, qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
-                                           callback=qs.MagnitudePruningCallback(**cbkw)),
-                             weight_layers=[nn.Conv2d, nn.Linear], log=False)
+            if with_prune:
+                net = qs.convert(net, qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
+                                               callback=qs.MagnitudePruningCallback(**cbkw)),
+                                 weight_layers=[nn.Conv2d, nn.Linear], log=False)
             if with_quant:
                 net = qs.convert(net, qs.quantize(bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb), bias_bits=bias_bits),
                                  weight_layers=[nn.Conv2d, nn.Linear], log=False)
@@ -325,6 +329,7 @@ GRAPH = bool(os.environ.get("QS_FUZZ_GRAPH"))            # steady-state steps of
 GRAPHED = [0]
 COLLECTIVES = [0]
 ENGAGED = [0]      # cases in which the multi-tensor weight path actually took the layer
+STEADY = [0]       # ... and in which its steady-state fast path (batch._Steady) was armed at some step
 
 
 def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False,
@@ -343,6 +348,7 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             m = m.to(memory_format=torch.channels_last)
         if device == "cuda" and len(getattr(m.__dict__.get("_qs_weight_batcher"), "layers", ())) > 0:
             ENGAGED[0] += 1
+        steady_seen = False
         for s in range(steps):
             m.train(s < eval_from)
             for p in m.parameters():
@@ -368,6 +374,10 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
                 for name, p in m.named_parameters():
                     if p.requires_grad:
                         p.add_((torch.randn(p.shape, generator=g) * 0.05).to(device))
+            wb_ = m.__dict__.get("_qs_weight_batcher")
+            if device == "cuda" and wb_ is not None and getattr(wb_, "_steady", None) is not None and not steady_seen:
+                steady_seen = True
+                STEADY[0] += 1
         for k, v in m.state_dict().items():
             outs.append(("state:" + k, v.detach().cpu().contiguous()))
         return outs
@@ -500,7 +510,7 @@ def one_case(rng, idx, dry=False):
     routes = dict(fold_relu=rng.random() < 0.8, relu_gate=rng.random() < 0.8, elide_pruned=rng.choice(["forward", "forward", "off"]),
                   graph_safe=rng.random() < 0.2)
     if desc["what"] == "net":
-        steps = rng.choice([6, 8, 10])
+        steps = rng.choice([6, 8, 10, 12])
         eval_from = rng.choice([steps, steps - 1])
         routes["batch_weights"] = batcher = rng.random() < 0.85      # (off: the same network layer by layer)
         if nonfinite is not None:
@@ -578,6 +588,7 @@ def main():
             fails += 1
             print("FAIL", r, flush=True)
     print(f"fuzz cpu-vs-gpu: {ran} cases, {fails} failures (seed {seed}); weight batcher engaged in {ENGAGED[0]}"
+          + (f" (steady-state fast path armed in {STEADY[0]})" if STEADY[0] else "")
           + (f"; {COLLECTIVES[0]} collectives on the one-rank group" if EXCHANGE else "")
           + (f"; {GRAPHED[0]} cases captured into a hipGraph" if GRAPH else ""))
     sys.exit(1 if fails else 0)
