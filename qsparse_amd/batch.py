@@ -112,7 +112,13 @@ class _GroupSte(torch.autograd.Function):
         k = len(meta)
         ctx.meta, ctx.dead = meta, dead                     # per tensor: (is_decimal, lo_mul, hi_mul, passthrough, channel index, mask); rolled back?
         ctx.shapes = [(w.shape, w.stride()) for w in tensors[:k]]
-        ctx.save_for_backward(*tensors[2 * k:])             # the steps (scales or decimals: one per channel)
+        ctx.n_inputs = 2 + len(tensors)
+        # autocast images (fused.py "Autocast image"; batch.py `_hand_out`): tensors[3k:4k], None where a member has none -- the
+        # low-precision copy of the quantized weight its convolution takes instead of casting the float32 one, whose
+        # low-precision weight gradient then arrives here directly (the outputs k, k+1, ... of this node)
+        imgs = tensors[3 * k:4 * k] if len(tensors) >= 4 * k else (None,) * k
+        ctx.img_slot = [None] * k
+        ctx.save_for_backward(*tensors[2 * k:3 * k])        # the steps (scales or decimals: one per channel)
         # a member whose tensor is never read gets NO gradient, exactly like the layer the reference never evaluated
         # (zero_grad(set_to_none=True) + weight decay would otherwise start to move a parameter the forward did not use)
         ctx.set_materialize_grads(False)
@@ -120,15 +126,23 @@ class _GroupSte(torch.autograd.Function):
         # a frozen parameter (requires_grad=False: fine-tuning a head on a frozen backbone) hands out a quantized tensor that
         # does not require grad either, as layer by layer -- its convolution then skips the weight-gradient pass altogether
         frozen = [ys[i] for i in range(k) if not ctx.needs_input_grad[2 + i]]
+        extra = []
+        for i, img in enumerate(imgs):
+            if img is not None:
+                ctx.img_slot[i] = k + len(extra)
+                extra.append(img.view_as(img))
+                if not ctx.needs_input_grad[2 + i]:
+                    frozen.append(extra[-1])
         if frozen:
             ctx.mark_non_differentiable(*frozen)
-        return ys
+        return ys + tuple(extra)
 
     @staticmethod
     def backward(ctx, *grads):
         meta, steps = ctx.meta, ctx.saved_tensors
         k = len(meta)
         out = [None] * k
+        grads = _merge_image_gradients(ctx, list(grads), k, steps[0].device)
         if any(ctx.dead):
             # the one combination in which "no gradient" is not an option: DistributedDataParallel counts this parameter as
             # used (it is reachable through the group's node) and waits for its gradient -- there a rolled-back member
@@ -180,7 +194,44 @@ class _GroupSte(torch.autograd.Function):
         for i in range(k):
             if out[i] is None and grads[i] is not None and meta[i][3]:
                 out[i] = grads[i] if meta[i][5] is None else grads[i] * meta[i][5][0]      # backward_passthrough
-        return (None, None) + tuple(out) + (None,) * (2 * k)
+        return (None, None) + tuple(out) + (None,) * (ctx.n_inputs - 2 - k)
+
+
+def _merge_image_gradients(ctx, grads, k, device):
+    """the gradient of member i = what reached its float32 tensor + float32(what reached its image), autograd's own accumulation
+    (`ToCopyBackward` + add) -- the images' low-precision gradients of a group converted by ONE multi-tensor copy into a flat
+    float32 buffer laid out like the weights (what `qs_multi_ste_bwd` reads), instead of one cast launch per layer"""
+    override = ctx.__dict__.pop("_qs_override", None)          # a late hook replaced a member's whole gradient (fused._late_hook)
+    gy = grads[:k]
+    need = []
+    for i in range(k):
+        j = ctx.img_slot[i]
+        g16 = grads[j] if j is not None else None
+        if override is not None and i in override:
+            gy[i] = override[i]
+            continue
+        if g16 is None:
+            continue
+        if gy[i] is None:
+            need.append((i, g16))
+        else:
+            gy[i] = gy[i] + g16.float()
+    if need:
+        offs, total = [], 0
+        for i, _ in need:
+            offs.append(total)
+            n = 1
+            for sdim in ctx.shapes[i][0]:
+                n *= sdim
+            total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        views = [flat.as_strided(ctx.shapes[i][0], ctx.shapes[i][1], flat.storage_offset() + o) for (i, _), o in zip(need, offs)]
+        ok = all(v.shape == g.shape for v, (_, g) in zip(views, need))
+        if ok:
+            torch._foreach_copy_(views, [g for _, g in need])
+        for v, (i, g) in zip(views, need):
+            gy[i] = v if ok else g.float()
+    return gy
 
 
 def _operators(layer: nn.Module) -> List[str]:
@@ -525,6 +576,45 @@ def _no_steady():
     return None
 
 
+class _ImageStat:
+    """what `fused.AutocastImageTensor` expects of the object that made an image"""
+    __slots__ = ("image_made", "image_used")
+
+    def __init__(self):
+        self.image_made = self.image_used = False
+
+    def __deepcopy__(self, memo):
+        return _ImageStat()
+
+
+def _weight_images(flat, units_attr, weights, offsets):
+    """the autocast images of a step's quantized weights: ONE cast of the flat float32 buffer (instead of the cast autocast puts
+    in front of every convolution / linear), viewed per weight like the float32 outputs; None for biases and outside autocast.
+    Value-identical: RNE(y), exactly what that cast produces (fused.py "Autocast image")."""
+    from qsparse_amd.fused import autocast_image_dtype
+    dt = autocast_image_dtype()
+    if dt is None or flat is None:
+        return None
+    flat16 = flat.to(dt)
+    so = flat16.storage_offset()
+    return [flat16.as_strided(w.shape, w.stride(), so + o) if (attr == "weight" and w.dim() >= 2) else None
+            for attr, w, o in zip(units_attr, weights, offsets)]
+
+
+def _dual_outputs(ys, imgs, k, stat):
+    """the group's outputs as the layers receive them: a weight that has an image goes out as the Tensor subclass that carries it
+    to its first autocast consumer (gradient slots: output i, image k + j of the hand-out node)"""
+    from qsparse_amd.fused import _as_dual
+    out, j = [], 0
+    for i in range(k):
+        if imgs is not None and imgs[i] is not None:
+            out.append(_as_dual(ys[i], ys[k + j], stat, slots=(i, k + j)))
+            j += 1
+        else:
+            out.append(ys[i])
+    return out
+
+
 class WeightBatcher:
     def __init__(self, model: nn.Module):
         for m in model.modules():                # one batcher per tree: an earlier one (convert installs one) steps aside
@@ -554,6 +644,8 @@ class WeightBatcher:
         self._eval_decimals = None
         self._plan = None
         self._steady = None
+        self._eval_flat = self._eval_offsets = None
+        self._image_stat = _ImageStat()
         for layer in self.layers:
             if "_qs_batcher_base" not in type(layer).__dict__:
                 layer.__class__ = _patched_class(type(layer))
@@ -579,7 +671,7 @@ class WeightBatcher:
         parameter and no scale has been written -- detected through ``Tensor._version``, which optimizers,
         ``load_state_dict`` and any in-place op bump; writes through ``param.data`` do not: call this (or
         ``qs.resync_host_state(model)``, which does) after such a write between two no-grad evaluation forwards."""
-        self._eval_key = self._eval_outs = self._eval_decimals = None
+        self._eval_key = self._eval_outs = self._eval_decimals = self._eval_flat = self._eval_offsets = None
 
     def remove(self):
         self._rollback_all()
@@ -738,7 +830,8 @@ class WeightBatcher:
                              + ((u.p.mask.data_ptr(), u.p.mask._version) if u.p is not None else ())
                              for u, w, sat in zip(todo, weights, sats))
             if eval_key == self._eval_key:
-                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals, prune_steps, plain)
+                self._hand_out(todo, weights, self._eval_outs, {}, self._eval_decimals, prune_steps, plain, flat=self._eval_flat,
+                               offsets=self._eval_offsets)
                 return
         self._eval_key = None
         undo = {}
@@ -821,7 +914,8 @@ class WeightBatcher:
             decimals = self._decimals.clone() if plan["any_decimal"] else self._decimals
         if eval_key is not None:
             self._eval_key, self._eval_outs, self._eval_decimals = eval_key, outs, decimals
-        self._hand_out(todo, weights, outs, undo, decimals, prune_steps, plain)
+            self._eval_flat, self._eval_offsets = flat, plan["offsets"]
+        self._hand_out(todo, weights, outs, undo, decimals, prune_steps, plain, flat=flat, offsets=plan["offsets"])
         if (train and len(train) == len(self.units) and not frozen and not plain and not any(ps is not None for ps in psteps)
                 and not get_option("log_during_train") and os.environ.get("QS_NO_FAST_PATH", "0") != "1"):
             self._steady = self._arm_steady(train, weights, t_devs, plan, dev)
@@ -910,12 +1004,16 @@ class WeightBatcher:
             decimals = self._decimals.clone() if plan["any_decimal"] else self._decimals
         self._eval_key = None
         todo, weights = st.todo, st.weights
+        imgs = _weight_images(flat, [c.attr for c in st.units], weights, plan["offsets"])
         for gi, base in enumerate(range(0, len(todo), _GROUP)):
             group = st.units[base:base + _GROUP]
             steps = [s if s is not None else decimals[c.unit.slot:c.unit.slot + c.unit.channels].view(-1, 1)
                      for s, c in zip(st.static_steps[gi], group)]
             dead = [False] * len(group)
-            ys = _GroupSte.apply(st.metas[gi], dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
+            gimgs = imgs[base:base + _GROUP] if imgs is not None else None
+            ys = _GroupSte.apply(st.metas[gi], dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps,
+                                 *(gimgs if gimgs is not None else ()))
+            ys = _dual_outputs(ys, gimgs, len(group), self._image_stat)
             for i, (c, y) in enumerate(zip(group, ys)):
                 pending = undo[c.key]
                 pending.dead, pending.index = dead, i
@@ -1021,9 +1119,10 @@ class WeightBatcher:
                            train_bytes=4 * sum(w.numel() for w in weights[:n_train]), all_bytes=8 * sum(w.numel() for w in weights),
                            any_decimal=any(u not in plain and not u.q.callback.use_float_scaler for u in todo))
 
-    def _hand_out(self, todo, weights, outs, undo, decimals, prune_steps=None, plain=()):
+    def _hand_out(self, todo, weights, outs, undo, decimals, prune_steps=None, plain=(), flat=None, offsets=None):
         """park every quantized tensor on its layer, `_GROUP` consecutive tensors per autograd node (a node per layer in
         evaluation mode under no_grad costs nothing either way)"""
+        imgs = _weight_images(flat, [u.attr for u in todo], weights, offsets) if offsets is not None else None
         for base in range(0, len(todo), _GROUP):
             group = todo[base:base + _GROUP]
             meta, steps = [], []
@@ -1041,7 +1140,10 @@ class WeightBatcher:
                 meta.append((is_decimal, -limit + notch, limit - 1 + notch, bool(qc.backward_passthrough), q.channelwise, mask))
                 steps.append(decimals[u.slot:u.slot + u.channels].view(-1, 1) if is_decimal else q.weight.data)
             dead = [False] * len(group)
-            ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps)
+            gimgs = imgs[base:base + _GROUP] if imgs is not None else None
+            ys = _GroupSte.apply(tuple(meta), dead, *weights[base:base + _GROUP], *outs[base:base + _GROUP], *steps,
+                                 *(gimgs if gimgs is not None else ()))
+            ys = _dual_outputs(ys, gimgs, len(group), self._image_stat)
             for i, (u, w, y) in enumerate(zip(group, weights[base:base + _GROUP], ys)):
                 pending = undo.get((id(u.layer), u.attr))
                 if pending is None:

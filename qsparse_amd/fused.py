@@ -304,9 +304,10 @@ def _late_hook(dual, fn):
     holds both streams.  A hook that only looks (returns None) leaves the fast route untouched; one that returns a
     replacement turns the step into the plain one: (replacement, no second stream)."""
     node = dual.__dict__["_qs_node"]
+    i0, i1 = dual.__dict__.get("_qs_slots", (0, 1))       # the node's gradient slots of the output and of its image
 
     def pre(grads):
-        g, g16 = grads
+        g, g16 = grads[i0], grads[i1]
         full = _whole(g, g16)
         if full is None:
             return None
@@ -315,10 +316,12 @@ def _late_hook(dual, fn):
             return None
         if g is None:
             # (a pre-hook cannot put a gradient where autograd has none: the replacement rides on the node itself -- for a Python
-            #  Function the node IS the ctx -- and `_SiteStep.backward` takes it in place of both streams)
-            node._qs_override = r
+            #  Function the node IS the ctx -- and the node's backward takes it in place of both streams)
+            node.__dict__.setdefault("_qs_override", {})[i0] = r
             return None
-        return (r, None)
+        out = list(grads)
+        out[i0], out[i1] = r, None
+        return tuple(out)
 
     return node.register_prehook(pre)
 
@@ -327,12 +330,13 @@ def _late_retain_grad(dual):
     import weakref
     torch.Tensor.retain_grad(dual)
     ref, node = weakref.ref(dual), dual.__dict__["_qs_node"]
+    i0, i1 = dual.__dict__.get("_qs_slots", (0, 1))
 
     def pre(grads):
         d = ref()
-        if d is not None and grads[1] is not None:
+        if d is not None and grads[i1] is not None:
             with torch.no_grad():
-                d.grad = _whole(grads[0], grads[1])      # (the tensor's own retain-grad hook has stored the float32 share by now)
+                d.grad = _whole(grads[i0], grads[i1])    # (the tensor's own retain-grad hook has stored the float32 share by now)
         return None
 
     node.register_prehook(pre)
@@ -384,17 +388,23 @@ class AutocastImageTensor(torch.Tensor):
                     if func is torch.Tensor.retain_grad:
                         return _late_retain_grad(args[0])
                     return _late_hook(args[0], *args[1:], **(kwargs or {}))
-            elif func in _IMAGE_CONSUMERS and args and type(args[0]) is cls:
-                held = args[0].__dict__.get("_qs_image")
-                if held is not None:
+            elif func in _IMAGE_CONSUMERS and args and (type(args[0]) is cls or (len(args) > 1 and type(args[1]) is cls)):
+                # the input (an activation site's output) and / or the weight (the weight path's quantized tensor, batch.py)
+                for pos in (0, 1):
+                    a = args[pos] if pos < len(args) else None
+                    if type(a) is not cls:
+                        continue
+                    held = a.__dict__.pop("_qs_image", None)    # one consumer only: a second one casts for itself, as before
+                    if held is None:
+                        continue
                     img, version, plan = held
-                    if (args[0]._version == version and torch.is_autocast_enabled("cuda")
+                    if (a._version == version and torch.is_autocast_enabled("cuda")
                             and torch.get_autocast_dtype("cuda") == img.dtype):
-                        del args[0].__dict__["_qs_image"]       # one consumer only: a second one casts for itself, as before
                         if img.requires_grad:
-                            args[0].__dict__["_qs_image_taken"] = img
+                            a.__dict__["_qs_image_taken"] = img
                         plan.image_used = True
-                        args = (img,) + tuple(args[1:])
+                        args = tuple(args[:pos]) + (img,) + tuple(args[pos + 1:])
+                _cancel_images(args[2:])
             elif func is torch.autograd.grad:
                 return _grad_through_duals(args, kwargs)
             elif func not in _NON_CONSUMING and getattr(func, "__name__", "") != "__get__":
@@ -415,13 +425,25 @@ class AutocastImageTensor(torch.Tensor):
             return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
 
 
-def _as_dual(y, img, plan):
-    """the site's float32 output as the subclass that carries its image to the first autocast consumer"""
+def _as_dual(y, img, plan, slots=None):
+    """the site's float32 output as the subclass that carries its image to the first autocast consumer.  `slots`: the gradient
+    slots of (output, image) at the backward node when they are not (0, 1) -- the weight path's hand-out groups"""
     plan.image_made = True
     dual = y.as_subclass(AutocastImageTensor)
     dual.__dict__["_qs_image"] = (img, y._version, plan)
-    dual.__dict__["_qs_node"] = y.grad_fn        # the site's backward node: both gradient streams arrive there (None: no grad)
+    dual.__dict__["_qs_node"] = y.grad_fn        # the backward node: both gradient streams arrive there (None: no grad)
+    if slots is not None:
+        dual.__dict__["_qs_slots"] = slots
     return dual
+
+
+def autocast_image_dtype():
+    """dtype of the images this forward should make, or None: the option is on, autocast to bf16 / fp16 is active, and tensors
+    have version counters (not inference mode)"""
+    if not get_option("autocast_image") or not torch.is_autocast_enabled("cuda") or torch.is_inference_mode_enabled():
+        return None
+    dt = torch.get_autocast_dtype("cuda")
+    return dt if dt in (torch.bfloat16, torch.float16) else None
 
 
 def _image_dtype(plan, training_needs_gate: bool):
@@ -491,9 +513,9 @@ class _SiteStep(torch.autograd.Function):
     def backward(ctx, g, g16=None):
         plan, flags = ctx.plan, ctx.flags
         n_in = 13
-        override = ctx.__dict__.pop("_qs_override", None) if hasattr(ctx, "__dict__") else None
+        override = ctx.__dict__.pop("_qs_override", None)
         if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
-            g, g16 = override, None
+            g, g16 = override[0], None
         if g is None and g16 is None:
             return (None,) * n_in
         mask_c, scale, third = ctx.saved_tensors

@@ -407,3 +407,98 @@ def test_a_consumer_that_reads_the_output_before_the_convolution_cancels_the_ima
                 r = y * 0.5                                     # a consumer
                 assert "_qs_image" not in y.__dict__
             conv(y).float().sum().backward()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The weight side of the same mechanism (batch.py `_weight_images`): the multi-tensor weight path hands every layer its quantized
+# weight together with the low-precision image its convolution / linear would cast it to -- ONE cast of the flat buffer for all
+# layers -- and takes the low-precision weight gradients directly (one multi-tensor copy per hand-out group).
+# ----------------------------------------------------------------------------------------------------------------------
+class _Mlp(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(4)
+        self.a, self.b, self.c = nn.Linear(24, 32), nn.Linear(32, 32, bias=False), nn.Linear(32, 5)
+        self.skip_b = False
+
+    def forward(self, x):
+        h = F.relu(self.a(x))
+        if not self.skip_b:
+            h = F.relu(self.b(h))
+        return self.c(h)
+
+
+@pytest.mark.parametrize("quant", [dict(channelwise=-1), dict(channelwise=1), dict(channelwise=0, bias_bits=8, callback="decimal")])
+@pytest.mark.parametrize("pruned", [False, True])
+def test_weight_images_are_value_identical(quant, pruned):
+    """linear layers (deterministic GEMMs) under bf16 autocast, with and without the images: outputs, input gradients, raw weight
+    and bias gradients, quantizer and prune state -- bit for bit; through a skipped layer (roll-back), an evaluation step and a
+    late hook on a handed-out weight"""
+    import copy
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            net = _Mlp()
+            if pruned:
+                net = qs.convert(net, qs.prune(sparsity=0.5, start=1, interval=1, repetition=1), weight_layers=[nn.Linear], log=False)
+            kw = dict(quant)
+            cb = qs.DecimalQuantizer() if kw.pop("callback", None) == "decimal" else None
+            net = qs.convert(net, qs.quantize(bits=4, timeout=1, callback=cb, **kw), weight_layers=[nn.Linear], log=False).to(DEV).train()
+            seen, kinds, trace = [], [], []
+            for s in range(8):
+                net.skip_b = s == 3
+                x = torch.randn(16, 24, generator=gen(70 + s)).to(DEV).requires_grad_(True)
+                if s == 5:
+                    net.eval()
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                        trace.append(net(x).clone())
+                    net.train()
+                    continue
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    if s == 6:          # a late observer on a handed-out weight: read it by hand, use it, then hook it
+                        w = net.c.weight
+                        kinds.append(type(w))
+                        h = F.relu(net.b(F.relu(net.a(x))))
+                        out = F.linear(h, w, net.c._parameters["bias"] if isinstance(getattr(net.c, "quantize_bias", None), type(None)) else net.c.bias)
+                        w.register_hook(lambda g: seen.append(g.detach().clone()))
+                    else:
+                        out = net(x)
+                out.float().sum().backward()
+                trace += [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters() if p.grad is not None]
+                net.zero_grad()
+            runs.append((trace, seen, kinds, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    (ta, sa_, ka, sta), (tb, sb_, kb, stb) = runs
+    assert len(ta) == len(tb) and len(sa_) == len(sb_) == 1
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
+    assert sa_[0].dtype == sb_[0].dtype == torch.float32 and same(sa_[0].cpu(), sb_[0].cpu())      # the hook saw the WHOLE weight gradient
+    assert ka == [torch.Tensor] and kb == [AutocastImageTensor]
+    for k in sta:
+        assert same(sta[k].cpu(), stb[k].cpu()), k
+
+
+def test_weight_images_cost_one_cast_per_forward(monkeypatch):
+    """the cast launches autocast puts in front of every layer are gone: no `aten::_to_copy` of a weight-sized float32 tensor
+    inside the layers' forwards once the images are handed out"""
+    net = qs.convert(_Mlp(), qs.quantize(bits=4, timeout=1, channelwise=-1), weight_layers=[nn.Linear], log=False).to(DEV).train()
+    x = torch.randn(16, 24, device=DEV)
+    for _ in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            net(x).float().sum().backward()
+    from torch.profiler import profile, ProfilerActivity
+    counts = {}
+    for image in (True, False):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                net(x).float().sum().backward()          # (the option epoch changed: one full-path step)
+            with profile(activities=[ProfilerActivity.CPU]) as prof:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    net(x).float().sum().backward()
+            counts[image] = sum(e.count for e in prof.key_averages() if e.key == "aten::_to_copy")
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    assert counts[True] < counts[False], counts
