@@ -420,12 +420,20 @@ class _Mlp(nn.Module):
         torch.manual_seed(4)
         self.a, self.b, self.c = nn.Linear(24, 32), nn.Linear(32, 32, bias=False), nn.Linear(32, 5)
         self.skip_b = False
+        self.observe = None          # a list: read c's weight by hand, use it, THEN hook it (a late observer)
+        self.kinds = []
 
     def forward(self, x):
         h = F.relu(self.a(x))
         if not self.skip_b:
             h = F.relu(self.b(h))
-        return self.c(h)
+        if self.observe is None:
+            return self.c(h)
+        w, b = self.c.weight, self.c.bias
+        self.kinds.append(type(w))
+        out = F.linear(h, w, b)
+        w.register_hook(lambda g: self.observe.append(g.detach().clone()))
+        return out
 
 
 @pytest.mark.parametrize("quant", [dict(channelwise=-1), dict(channelwise=1), dict(channelwise=0, bias_bits=8, callback="decimal")])
@@ -455,19 +463,13 @@ def test_weight_images_are_value_identical(quant, pruned):
                         trace.append(net(x).clone())
                     net.train()
                     continue
+                net.observe = seen if s == 6 else None
                 with torch.autocast("cuda", dtype=torch.bfloat16):
-                    if s == 6:          # a late observer on a handed-out weight: read it by hand, use it, then hook it
-                        w = net.c.weight
-                        kinds.append(type(w))
-                        h = F.relu(net.b(F.relu(net.a(x))))
-                        out = F.linear(h, w, net.c._parameters["bias"] if isinstance(getattr(net.c, "quantize_bias", None), type(None)) else net.c.bias)
-                        w.register_hook(lambda g: seen.append(g.detach().clone()))
-                    else:
-                        out = net(x)
+                    out = net(x)
                 out.float().sum().backward()
                 trace += [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters() if p.grad is not None]
                 net.zero_grad()
-            runs.append((trace, seen, kinds, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+            runs.append((trace, seen, net.kinds, {k: v.detach().clone() for k, v in net.state_dict().items()}))
         finally:
             qs.set_qsparse_options(autocast_image=True)
     (ta, sa_, ka, sta), (tb, sb_, kb, stb) = runs
