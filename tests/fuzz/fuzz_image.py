@@ -45,7 +45,9 @@ def build(rng):
                 saturate=rng.random() < 0.2, cl=len(shape) == 4 and rng.random() < 0.5, steps=rng.choice([5, 7, 9]),
                 consumers=rng.sample(["conv", "conv2", "residual", "cat", "view", "pool"], k=rng.choice([1, 1, 2, 3])),
                 observer=rng.choice([None, None, "hook_before", "hook_after", "hook_replace", "retain_after", "grad_wrt_output"]),
-                eval_at=rng.choice([None, None, 3]), consumer_first=rng.random() < 0.8)
+                eval_at=rng.choice([None, None, 3]), consumer_first=rng.random() < 0.8,
+                # the consumers' own weights read through quantizers: the weight path hands them out with THEIR images (batch.py)
+                quant_weights=rng.choice([None, None, -1, 0, 1]))
     return desc
 
 
@@ -122,7 +124,10 @@ class Net(nn.Module):
 def run(d, image, seed):
     qs.set_qsparse_options(autocast_image=image)
     try:
-        net = Net(d).to(DEV).train()
+        net = Net(d)
+        if d["quant_weights"] is not None:
+            net = qs.convert(net, qs.quantize(bits=8, timeout=1, channelwise=d["quant_weights"]), weight_layers=[nn.Conv2d, nn.Linear], log=False)
+        net = net.to(DEV).train()
         g = torch.Generator().manual_seed(seed)
         C = d["shape"][1]
         xdt = getattr(torch, d["xdt"])
@@ -150,12 +155,13 @@ def run(d, image, seed):
                 trace += [("gy", None if gy is None else gy.as_subclass(torch.Tensor).clone()), ("gx", gx.clone())]
             else:
                 loss.backward()
-                trace += [("out", out.detach().clone()), ("gx", x.grad.clone()), ("gw", None if net.main.weight.grad is None else net.main.weight.grad.clone())]
+                gw = net.main._parameters["weight"].grad
+                trace += [("out", out.detach().clone()), ("gx", x.grad.clone()), ("gw", None if gw is None else gw.clone())]
                 if d["observer"] == "retain_after" and net.held is not None:
                     gr = net.held.grad
                     trace.append(("retained", None if gr is None else gr.as_subclass(torch.Tensor).clone()))
             net.zero_grad()
-        state = {k: v.detach().clone() for k, v in net.site.state_dict().items()}
+        state = {k: v.detach().clone() for k, v in net.state_dict().items() if not k.endswith((".weight", ".bias")) or "quantize" in k or "site" in k}
         return trace, net.observed, net.kinds, state
     finally:
         qs.set_qsparse_options(autocast_image=True)
