@@ -2,7 +2,7 @@
 """BASELINE.json configs 3-5 as a runnable recipe: ResNet-18 (CIFAR shape) / ResNet-50 (ImageNet shape) with 4-bit
 weights and activations + channel pruning of every activation, synthetic data, bf16 autocast, one process per GPU.
 
-    python examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last --graph [--autocast-image]      # 1 GPU
+    python examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last --graph [--no-autocast-image]      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/resnet_pq_ddp.py --arch resnet50 --batch 64 --channels-last                                   # 8 GPUs
 
@@ -39,8 +39,9 @@ def main(argv=None):
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--no-batch-weights", action="store_true", help="layer-by-layer weight quantizers (the multi-tensor path is the default)")
     ap.add_argument("--preserve-dtype", action="store_true")
-    ap.add_argument("--autocast-image", action="store_true",
-                    help="value-identical opt-in: sites hand their first convolution the bf16 image of their float32 output")
+    ap.add_argument("--no-autocast-image", action="store_true",
+                    help="opt out of the (value-identical, default) autocast image: sites and the weight path then hand out plain "
+                         "float32 tensors and autocast casts them in front of every convolution")
     ap.add_argument("--inplace-relu", action="store_true", help="build the network with nn.ReLU(inplace=True) modules (torchvision style)")
     args = ap.parse_args(argv)
 
@@ -51,7 +52,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     qs.set_qsparse_options(log_on_created=False, log_during_train=False, preserve_dtype=args.preserve_dtype,
-                           batch_weights=not args.no_batch_weights, autocast_image=args.autocast_image)
+                           batch_weights=not args.no_batch_weights, autocast_image=not args.no_autocast_image)
 
     torch.manual_seed(0)                      # identical initial weights on every rank
     if args.arch == "resnet18":
