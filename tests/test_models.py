@@ -108,9 +108,8 @@ def test_resnet_recipe_example_runs(capsys):
     import qsparse_amd as qs
     from examples import resnet_pq_ddp
     try:
-        resnet_pq_ddp.main(["--arch", "resnet18", "--batch", "16", "--steps", "3", "--warmup", "14", "--channels-last", "--graph",
-                            "--autocast-image"])
+        resnet_pq_ddp.main(["--arch", "resnet18", "--batch", "16", "--steps", "3", "--warmup", "14", "--channels-last", "--graph"])
     finally:
-        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, log_on_created=True, log_during_train=True)
+        qs.set_qsparse_options(graph_safe=False, preserve_dtype=False, log_on_created=True, log_during_train=True, autocast_image=True)
     out = capsys.readouterr().out
     assert "images/s" in out and "graphed" in out
