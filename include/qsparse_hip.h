@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 20
+#define QS_ABI_VERSION 21
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -449,7 +449,9 @@ int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, vo
  *     qs_absmax(x, amax_lines, tensor-wise, accumulate, pre_relu, lines)  ->  qs_scale_update(amax_lines, lines, scale, 1, t,
  *     t_dev, advance, bits, clear, n_updates, xdt)  ->  qs_quant_scaler_fwd(x, y, scale, pre_relu, gate_out)
  * and with `update` == 0 the last of them alone (evaluation).  amax_lines: [lines][QS_AMAX_LINE_STRIDE] floats, zero on entry,
- * re-zeroed by the update; n_updates (nullable) is incremented; t_dev (nullable) is read instead of t and incremented. */
+ * re-zeroed by the update; n_updates (nullable) is incremented; t_dev (nullable) is read instead of t and incremented.
+ * image_out / imgdt (ABI v21): the autocast image of qs_quant_scaler_fwd -- RNE(y) in bf16 / fp16 from the same pass, for the
+ * convolution behind a quantize-only activation site (needs pre_relu, gate_out and qs_quant_image_ok(1, 1, numel, ...)). */
 #define QS_QSTEP_APPLY 0      /* `update` of qs_quantize_step: quantize only (evaluation) */
 #define QS_QSTEP_ALL 1        /* abs-max, running scale, quantize */
 #define QS_QSTEP_ABSMAX 2     /* the abs-max launch alone (y may be NULL): a data-parallel step all-reduces (MAX) the accumulator
@@ -457,7 +459,7 @@ int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, vo
 #define QS_QSTEP_FINISH 3     /* running scale from the (reduced) accumulator lines, then quantize */
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, qs_stream_t stream);
+                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, void* image_out, int imgdt, qs_stream_t stream);
 
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 

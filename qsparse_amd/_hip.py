@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 20          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 21          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -68,7 +68,7 @@ SIGNATURES = {
     "qs_multi_stage_plan": (c_int, [_P, _I, _P]),
     "qs_multi_stage_mean": (c_int, [_P, _I, _I, _P]),
     "qs_multi_ste_bwd": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P]),
+    "qs_quantize_step": (c_int, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _L, _P, _P, _I, _I, _I, c_int32, c_int32, _P, _P, _I, _P]),
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
     "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P, _P]),
@@ -1048,7 +1048,7 @@ def logging_events() -> bool:
 
 def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Tensor], amax_lines: Optional[torch.Tensor],
                   scale: torch.Tensor, bits: int, t: int, t_dev: Optional[torch.Tensor], n_updates: Optional[torch.Tensor],
-                  pre_relu: bool, update, saturate=None, xback: bool = False):
+                  pre_relu: bool, update, saturate=None, xback: bool = False, image: Optional[torch.Tensor] = None):
     """x: dense (any memory order: the quantizer is tensor-wise), 16-byte aligned; y: same layout; saturate: None or the
     (code_lo, code_hi) pair of the opt-in saturation; update: False / True or one of QSTEP_* (ABSMAX: the abs-max launch alone,
     y may be None; FINISH: running scale from the -- meanwhile all-reduced -- accumulator lines, then quantize)"""
@@ -1057,7 +1057,8 @@ def quantize_step(x: torch.Tensor, y: torch.Tensor, gate_bits: Optional[torch.Te
                                  None if amax_lines is None else amax_lines.data_ptr(), TENSOR_AMAX_LINES, scale.data_ptr(),
                                  x.numel(), _DT[x.dtype], _DT[(y if y is not None else x).dtype], int(bits), int(t),
                                  None if t_dev is None else t_dev.data_ptr(), None if n_updates is None else n_updates.data_ptr(),
-                                 _act(pre_relu), int(update), sat, lo, hi, x.data_ptr() if xback else None, _stream(x))
+                                 _act(pre_relu), int(update), sat, lo, hi, x.data_ptr() if xback else None,
+                                 None if image is None else image.data_ptr(), 0 if image is None else _DT[image.dtype], _stream(x))
     if st:
         _check(st, "qs_quantize_step")
 

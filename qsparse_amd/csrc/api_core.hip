@@ -357,8 +357,13 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
 
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
-                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, qs_stream_t stream) {
+                     int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, void* image_out, int imgdt,
+                     qs_stream_t stream) {
     if (!x || (!y && update != QS_QSTEP_ABSMAX) || !scale || numel < 0 || update < 0 || update > QS_QSTEP_FINISH) return QS_ERR_ARG;
+    // (validated before the statistics launches advance the scale and the counters, as in qs_site_fwd)
+    if (image_out && (!gate_out || !pre_relu || ydt != QS_F32 || (imgdt != QS_BF16 && imgdt != QS_F16) || (((uintptr_t)image_out) & 15u) ||
+                      !qs_quant_image_ok(1, 1, numel, 0, 0, 1, xdt)))
+        return QS_ERR_ARG;
     if (numel == 0) return QS_OK;
     if (update != QS_QSTEP_APPLY) {
         if (!amax_lines) return QS_ERR_ARG;
@@ -370,7 +375,7 @@ int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_line
         if (st) return st;
     }
     return qs_quant_scaler_fwd(x, y, nullptr, scale, 1, 0.0f, nullptr, 1, 1, numel, xdt, ydt, QS_F32, saturate, code_lo, code_hi,
-                               pre_relu, 0, gate_out, nullptr, 0, xback_out, stream);
+                               pre_relu, 0, gate_out, image_out, imgdt, xback_out, stream);
 }
 
 // ---- multi-tensor weight path (qs_multi.h) ----------------------------------------------------------------------

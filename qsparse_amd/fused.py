@@ -437,6 +437,21 @@ def _as_dual(y, img, plan, slots=None):
     return dual
 
 
+class ImageStat:
+    """bookkeeping of a maker of images that is not a `_SitePlan` (a lone quantizer behind its activation): whether the last image
+    was taken, whether to keep making them"""
+    __slots__ = ("image_ok", "image_made", "image_used")
+
+    def __init__(self):
+        self.image_ok, self.image_made, self.image_used = True, False, False
+
+    def __deepcopy__(self, memo):
+        return ImageStat()
+
+    def __reduce__(self):
+        return (ImageStat, ())
+
+
 def autocast_image_dtype():
     """dtype of the images this forward should make, or None: the option is on, autocast to bf16 / fp16 is active, and tensors
     have version counters (not inference mode)"""

@@ -547,38 +547,52 @@ class _QuantStep(torch.autograd.Function):
     quantization -- or the quantization alone); backward = the STE clamp, with the gate of a folded ReLU when `pre_relu`"""
 
     @staticmethod
-    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None):
+    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None, image_dtype=None):
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
         # an owned nn.ReLU(inplace=True) in front of this quantizer: the apply kernel writes relu(x) back into x itself
         cell = _hip.owned_relu_cell() if pre_relu else None
-        xback = bool(cell is not None and out_dtype == torch.float32
-                     and _hip.load().qs_quant_image_ok(1, 1, x.numel(), 0, 0, 1, _hip.dt(x)))
-        gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if (want_gate or xback) else None
+        widen = bool(pre_relu and out_dtype == torch.float32 and _hip.load().qs_quant_image_ok(1, 1, x.numel(), 0, 0, 1, _hip.dt(x)))
+        xback = bool(cell is not None and widen)
+        # the autocast image (fused.py): RNE(y) in the autocast dtype from the same pass, for the convolution behind this site --
+        # when its gradient can come back the same way (a recorded gate) or no gradient is needed at all
+        make_image = bool(image_dtype is not None and widen and (want_gate or not ctx.needs_input_grad[0]))
+        gate_bits = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device) if (want_gate or xback or make_image) else None
         if want_gate:
             _hip.note_gate(gate_bits)
-        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update, saturate, xback=xback)
+        img = torch.empty_like(x, dtype=image_dtype) if make_image else None
+        _hip.quantize_step(x, y, gate_bits, amax, scale, bits, t, t_dev, n_updates, pre_relu, update, saturate, xback=xback, image=img)
         if xback:
             cell["done"] = True
         ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.channels_last = x.dim() in (4, 5) and not x.is_contiguous()
         ctx.save_for_backward(scale, gate_bits if want_gate else (x if pre_relu else x.new_empty(0)))
+        if make_image:
+            ctx.set_materialize_grads(False)
+            return y, img
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g16=None):
+        override = ctx.__dict__.pop("_qs_override", None)
+        if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
+            g, g16 = override[0], None
+        if g is None and g16 is None:
+            return (None,) * 13
         scale, second = ctx.saved_tensors
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(second, ctx.x_shape, ctx.x_dtype, ctx.channels_last) if ctx.has_gate else None
+            if g16 is not None and gate is None:          # (cannot happen: an image is only made with a gate; stay correct anyway)
+                g, g16 = (g16.float() if g is None else g + g16.float()), None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else second, scale, False, lo_mul, hi_mul, None, gate=gate,
-                                   act=ctx.pre_relu)
+                                   act=ctx.pre_relu, **({"g2": g16} if g16 is not None else {}))
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)
-        return (gx,) + (None,) * 11
+        return (gx,) + (None,) * 12
 
 
 def _callback_hooked(cb: nn.Module) -> bool:
@@ -669,9 +683,22 @@ class QuantizeLayer(nn.Module):
             _hip.quantize_step(x, None, None, acc, self.weight.data, self.bits, cb.t, None, None, pre_relu, _hip.QSTEP_ABSMAX)
             qdist.allreduce_max_(acc.view(torch.int32))
             mode = _hip.QSTEP_FINISH
+        image_dtype, stat = None, None
+        if pre_relu:                # a quantize-only activation site (convert's Sequential(act, QuantizeLayer)): the autocast image
+            from qsparse_amd import fused
+            stat = self.__dict__.get("_qs_image_stat")
+            if stat is None:
+                stat = self.__dict__["_qs_image_stat"] = fused.ImageStat()
+            if stat.image_made and not stat.image_used:
+                stat.image_ok = False           # nobody took the last image (no autocast matmul behind this site): stop making them
+            stat.image_made = stat.image_used = False
+            if stat.image_ok and (not (torch.is_grad_enabled() and x.requires_grad) or get_option("relu_gate")):
+                image_dtype = fused.autocast_image_dtype()
         y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
                              self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
-                             cb.code_range(self.bits))
+                             cb.code_range(self.bits), image_dtype)
+        if type(y) is tuple:
+            y = fused._as_dual(y[0], y[1], stat)
         self.__dict__["_qs_accumulator_armed"] = False
         if update:
             if t == self.timeout and get_option("log_during_train"):

@@ -47,7 +47,11 @@ def build(rng):
                 observer=rng.choice([None, None, "hook_before", "hook_after", "hook_replace", "retain_after", "grad_wrt_output"]),
                 eval_at=rng.choice([None, None, 3]), consumer_first=rng.random() < 0.8,
                 # the consumers' own weights read through quantizers: the weight path hands them out with THEIR images (batch.py)
-                quant_weights=rng.choice([None, None, -1, 0, 1]))
+                quant_weights=rng.choice([None, None, -1, 0, 1]),
+                # a quantize-only site (convert's Sequential(act, QuantizeLayer)): its image comes from qs_quantize_step (ABI v21)
+                site=rng.choice(["pair", "pair", "act_q"]))
+    if desc["site"] == "act_q":
+        desc["quantizer"] = "scaler"
     return desc
 
 
@@ -61,8 +65,9 @@ class Net(nn.Module):
         cbkw = {"default": {}, "freeze": dict(mask_refresh_interval=1, stop_mask_refresh=2), "no_avg": dict(running_average=False)}[d["policy"]]
         net = nn.Sequential(a)
         types = [type(a)]
-        net = qs.convert(net, qs.prune(sparsity=d["sparsity"], dimensions={1}, start=d["start"], interval=1, repetition=2,
-                                       callback=qs.MagnitudePruningCallback(**cbkw)), activation_layers=types, log=False)
+        if d["site"] == "pair":
+            net = qs.convert(net, qs.prune(sparsity=d["sparsity"], dimensions={1}, start=d["start"], interval=1, repetition=2,
+                                           callback=qs.MagnitudePruningCallback(**cbkw)), activation_layers=types, log=False)
         qcb = qs.ScalerQuantizer() if d["quantizer"] == "scaler" else qs.DecimalQuantizer()
         if d["saturate"]:
             qcb.saturate = True

@@ -504,3 +504,39 @@ def test_weight_images_cost_one_cast_per_forward(monkeypatch):
         finally:
             qs.set_qsparse_options(autocast_image=True)
     assert counts[True] < counts[False], counts
+
+
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+@pytest.mark.parametrize("cl", [False, True])
+def test_quantize_only_sites_hand_out_images_too(act, cl):
+    """`convert(model, quantize(...), activation_layers=[nn.ReLU])` -- quantization without pruning: the site is
+    Sequential(act, QuantizeLayer), one qs_quantize_step call per forward, which writes the image in the same pass (ABI v21)"""
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            torch.manual_seed(3)
+            net = nn.Sequential(nn.ReLU() if act == "relu" else nn.ReLU6())
+            site = qs.convert(net, qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[type(net[0])], log=False).to(DEV).train()
+            w = torch.randn(12, 8, device=DEV)
+            trace, kinds = [], []
+            for s in range(6):
+                x = (torch.randn(6, 16, 5, 8, generator=gen(90 + s)) * 2).bfloat16().to(DEV)
+                if cl:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                x.requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = site(x)
+                    kinds.append(type(y))
+                    out = F.linear(y, w).float().sum(-1) + ((y * 0.5).sum(-1) if s % 2 else 0)
+                out.sum().backward()
+                trace += [y.detach().as_subclass(torch.Tensor).clone(), out.detach().clone(), x.grad.clone()]
+            runs.append((trace, kinds, {k: v.detach().clone() for k, v in site.state_dict().items()}))
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    (ta, ka, sa), (tb, kb, sb) = runs
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
+    assert all(k is torch.Tensor for k in ka) and all(k is AutocastImageTensor for k in kb[2:]), kb
+    for k in sa:
+        assert same(sa[k].cpu(), sb[k].cpu()), k
