@@ -461,7 +461,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
         y = m(xd.clone() if site else xd)       # (an in-place activation needs a non-leaf input, as behind a convolution)
         y_dtype = y.dtype
         if twin and m.training:         # a second forward before the first one's backward
-            x2 = (x.detach().float() * 4).to(dtype).to(device).requires_grad_(True)
+            # (float64: stay genuinely double-precision, see above -- a float32 round trip would put the means on midpoints again)
+            x2 = ((x.detach() * 4.000000000345) if dtype == torch.float64 else (x.detach().float() * 4).to(dtype)).to(device).requires_grad_(True)
             y2 = m(x2.clone() if site else x2)
             y2.backward((torch.randn(y2.shape, generator=g) * 3).to(y2.dtype).to(device))
             outs.append(("y2", y2.detach().cpu()))
