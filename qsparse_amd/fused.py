@@ -308,13 +308,15 @@ def _late_hook(dual, fn):
 
     def pre(grads):
         g, g16 = grads[i0], grads[i1]
-        full = _whole(g, g16)
+        earlier = node.__dict__.get("_qs_override")
+        replaced = earlier is not None and i0 in earlier        # an earlier late hook already replaced this gradient: chain on it
+        full = earlier[i0] if replaced else _whole(g, g16)
         if full is None:
             return None
         r = fn(full)
         if r is None:
             return None
-        if g is None:
+        if g is None or replaced:
             # (a pre-hook cannot put a gradient where autograd has none: the replacement rides on the node itself -- for a Python
             #  Function the node IS the ctx -- and the node's backward takes it in place of both streams)
             node.__dict__.setdefault("_qs_override", {})[i0] = r

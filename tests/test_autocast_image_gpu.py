@@ -540,3 +540,28 @@ def test_quantize_only_sites_hand_out_images_too(act, cl):
     assert all(k is torch.Tensor for k in ka) and all(k is AutocastImageTensor for k in kb[2:]), kb
     for k in sa:
         assert same(sa[k].cpu(), sb[k].cpu()), k
+
+
+def test_two_replacing_hooks_registered_after_the_consumer_chain_like_ordinary_hooks():
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            site = _pair().to(DEV).train()
+            torch.manual_seed(1)
+            lin = nn.Linear(8, 6, bias=False).to(DEV)
+            trace = []
+            for s in range(4):
+                x = torch.randn(4, 16, 8, 8, generator=gen(s)).bfloat16().to(DEV).requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = site(x)
+                    out = lin(y)
+                    y.register_hook(lambda g: g * 0.5)
+                    y.register_hook(lambda g: g + 1.0)
+                out.float().sum().backward()
+                trace.append(x.grad.clone())
+            runs.append(trace)
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    for a, b in zip(*runs):
+        assert same(a.cpu(), b.cpu())
