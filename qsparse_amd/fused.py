@@ -280,6 +280,19 @@ _NON_CONSUMING = frozenset(getattr(torch.Tensor, n) for n in (
     "is_shared", "is_pinned", "has_names", "untyped_storage") if hasattr(torch.Tensor, n))
 
 
+# ... and the attribute reads that are metadata (`y.T`, `y.mT`, `y.real` are views with a gradient path: consumers)
+_METADATA_ATTRS = frozenset(("shape", "dtype", "device", "requires_grad", "is_cuda", "is_cpu", "grad", "grad_fn", "is_leaf", "ndim", "layout",
+                             "names", "_version", "output_nr", "is_quantized", "is_sparse", "is_sparse_csr", "is_meta", "is_mkldnn",
+                             "is_xpu", "is_mps", "is_nested", "itemsize", "nbytes", "retains_grad", "_base", "_grad", "_backward_hooks",
+                             "is_ipu", "is_xla", "is_mtia", "is_maia", "is_vulkan", "is_ort", "volatile", "name"))
+
+
+def _non_consuming(func) -> bool:
+    if func in _NON_CONSUMING:
+        return True
+    return getattr(func, "__name__", "") == "__get__" and getattr(getattr(func, "__self__", None), "__name__", None) in _METADATA_ATTRS
+
+
 def _cancel_images(args):
     """drop the image of every site output among `args` (one level of lists / tuples deep: torch.cat([y, z]))"""
     for a in args:
@@ -409,7 +422,7 @@ class AutocastImageTensor(torch.Tensor):
                 _cancel_images(args[2:])
             elif func is torch.autograd.grad:
                 return _grad_through_duals(args, kwargs)
-            elif func not in _NON_CONSUMING and getattr(func, "__name__", "") != "__get__":
+            elif not _non_consuming(func):
                 _cancel_images(args)          # another consumer comes first: the image's would not be the last term of the sum
             return func(*args, **(kwargs or {}))
 
