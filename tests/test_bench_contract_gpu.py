@@ -68,6 +68,7 @@ def test_two_ranks_through_torch_distributed_run():
     rec = json.loads(lines[0])
     _check(rec, 2, 12)
     assert "exchange" in rec["config"] and "cpu_baseline" not in rec
+    assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"      # (an all-reduce of ones: the group saw both ranks)
     # BASELINE config 5 rides on the N > 1 line: ResNet-50 --pq under DistributedDataParallel (here batch 8 per rank)
     c5 = rec["configs"]["config5_resnet50_ddp"]
     assert "error" not in c5, c5
