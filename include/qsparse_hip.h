@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 21
+#define QS_ABI_VERSION 22
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -259,6 +259,20 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
  * contiguous NCHW row).  flags / l0_flag as for qs_mean_dim.  (ABI v20) */
 int qs_mean_cl_w(const void* x, void* out, int64_t N, int64_t H, int64_t W, int64_t C, int xdt, int odt, int flags,
                  const int32_t* l0_flag, qs_stream_t stream);
+
+/* The FIRST stage of squeeze_tensor_to_shape (qsparse/util.py:92-99) for a dense tensor laid out in any dim order other than the
+ * ones above (a transposed weight, a permuted activation, NDHWC with the batch kept ...): the mean over one dim of `n` elements
+ * `stride` elements apart, read where the tensor lies (x needs element alignment only), written to the contiguous result
+ * Tensor.mean(dim, keepdim=True) returns.  The caller describes the kept dims (nkept <= 6, after merging what merges) by size,
+ * input stride and output stride, the one the lane index should run fastest over first, and names the summation order ATen's
+ * TensorIterator + SumKernel.cpp arrive at for this layout (host logic, qsparse_amd/util.py `aten_reduce_plan`):
+ *   order 0  vectorised inner sum (needs stride == 1, n >= 8): 8 interleaved row-sums, the n % 8 tail, then the 8 lanes in turn
+ *   order 1  row-sum for every output (four interleaved cascade sums, ((p0 + p1) + p2) + p3)
+ *   order 2  cascade sum for outputs whose coordinate in kept dim `split_dim` is < `split`, row-sum for the rest
+ * flags / l0_flag as for qs_mean_dim (no abs-max rider).  (ABI v22) */
+int qs_mean_strided(const void* x, void* out, int64_t n, int64_t stride, int nkept, const int64_t* kept_size,
+                    const int64_t* kept_in_stride, const int64_t* kept_out_stride, int order, int split_dim, int64_t split,
+                    int xdt, int odt, int flags, const int32_t* l0_flag, qs_stream_t stream);
 
 /* The last two stages of squeeze_tensor_to_shape fused for a contiguous [pre, H, W] tensor whose trailing
  * two dims are both reduced: mean over H (rounded to xdt), then mean over W (rounded to odt) -> out[pre].

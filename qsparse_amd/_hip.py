@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 21          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 22          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_mean_cl_w": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "qs_mean_strided": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
     "qs_multi_scale_update": (c_int, [_P, _I, _I, _P]),
@@ -244,6 +245,63 @@ def on_hip(t: torch.Tensor) -> bool:
     by line (type promotion included: a float64 input is divided in float64 and still comes out as float32).  Never the
     oracle, never a host round trip."""
     return t.is_cuda and t.dtype in HIP_DTYPES
+
+
+def dense_any_order(x: torch.Tensor) -> bool:
+    """non-overlapping and dense: some permutation of the dims is contiguous"""
+    expect = 1
+    for st, size in sorted((st, size) for st, size in zip(x.stride(), x.shape) if size != 1):
+        if st != expect:
+            return False
+        expect *= size
+    return True
+
+
+class _Relayout(torch.autograd.Function):
+    """the same values in another dense layout (strides given); the gradient passes through as it comes"""
+
+    @staticmethod
+    def forward(ctx, y, strides):
+        out = torch.empty_strided(y.shape, strides, dtype=y.dtype, device=y.device)
+        out.copy_(y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _same_layout(a, b, shape) -> bool:
+    return all(sa == sb or n == 1 for sa, sb, n in zip(a, b, shape))        # (the stride of an extent-1 dim means nothing)
+
+
+def laid_out_like(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """`y` in the layout the reference's element-wise chain gives the result for the input `x` (`x * mask`, sparse.py:116;
+    `(x / s).round() * s`, quantize.py:109-117): TensorIterator lays an output out densely in its input's stride order.  The kernels
+    address contiguous and channels_last tensors where they lie and return that layout by construction; a tensor in any other
+    order (a transpose, a permute, a channels_last tensor whose channel index is not 1) went through its contiguous copy, and the
+    result is copied once more into the order the reference would have returned -- which matters to whatever reduces it next."""
+    if _same_layout(y.stride(), x.stride(), x.shape):
+        return y
+    want = x.stride() if dense_any_order(x) else torch.empty_like(x).stride()
+    if _same_layout(y.stride(), want, x.shape):
+        return y
+    return _Relayout.apply(y, tuple(want))
+
+
+def keeps_layout(forward):
+    """decorator of the operators' `forward(self, x, ...)`: the result of a GPU tensor that is not contiguous comes back in the
+    layout the reference returns for it (`laid_out_like`); one `is_contiguous()` for every other input"""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        y = forward(self, x, *args, **kwargs)
+        if (isinstance(x, torch.Tensor) and not x.is_contiguous() and x.is_cuda and isinstance(y, torch.Tensor) and y is not x
+                and y.stride() != x.stride() and y.shape == x.shape):
+            return laid_out_like(y, x)
+        return y
+    return wrapped
 
 
 def true_div(a: torch.Tensor, n) -> torch.Tensor:
@@ -902,6 +960,28 @@ def mean_cl_w(x_nhwc: torch.Tensor, out_dtype: torch.dtype, flags: int, l0_flag:
         st = load().qs_mean_cl_w(_ptr(x_nhwc), _ptr(out), N, H, W, C, dt(x_nhwc), _DT[out_dtype], int(flags), _ptr(l0_flag),
                                  _stream(x_nhwc))
     _check(st, "qs_mean_cl_w")
+    return out
+
+
+STRIDED_MAX_KEPT = 6     # kStridedMaxKept of qs_reduce.h
+
+
+def mean_strided(x: torch.Tensor, plan, out_dtype: torch.dtype, flags: int, l0_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """first squeeze stage of a dense tensor in any dim order, read in place: `plan` = (n, stride, kept, order, split_dim, split)
+    from util.aten_reduce_plan, kept = [(size, input stride, output stride)] with the lane dim first -> flat contiguous result
+    (qs_mean_strided)"""
+    n, stride, kept, order, split_dim, split = plan
+    numel = 1
+    for size, _, _ in kept:
+        numel *= size
+    out = torch.empty(numel, dtype=out_dtype, device=x.device)
+    k = len(kept)
+    arr = (ctypes.c_int64 * (3 * max(k, 1)))(*([s for s, _, _ in kept] + [i for _, i, _ in kept] + [o for _, _, o in kept]))
+    base = ctypes.addressof(arr)
+    with _timed("mean_dim", x, out):
+        st = load().qs_mean_strided(_ptr(x), _ptr(out), n, stride, k, base, base + 8 * k, base + 16 * k, order, split_dim, split,
+                                    dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag), _stream(x))
+    _check(st, "qs_mean_strided")
     return out
 
 

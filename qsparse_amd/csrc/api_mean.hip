@@ -243,6 +243,39 @@ int qs_mean_cl_w(const void* x, void* out, int64_t N, int64_t H, int64_t W, int6
     });
 }
 
+int qs_mean_strided(const void* x, void* out, int64_t n, int64_t stride, int nkept, const int64_t* kept_size,
+                    const int64_t* kept_in_stride, const int64_t* kept_out_stride, int order, int split_dim, int64_t split, int xdt,
+                    int odt, int flags, const int32_t* l0_flag, qs_stream_t stream) {
+    if (!x || !out || n < 1 || stride < 0 || nkept < 0 || nkept > kStridedMaxKept || order < 0 || order > 2) return QS_ERR_ARG;
+    if (nkept > 0 && (!kept_size || !kept_in_stride || !kept_out_stride)) return QS_ERR_ARG;
+    if (order == 2 && (split_dim < 0 || split_dim >= nkept || split < 0)) return QS_ERR_ARG;
+    if (order == 0 && (stride != 1 || n < 8)) return QS_ERR_ARG;      // ATen's vectorised inner loop needs both
+    if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
+    ActSpec act;
+    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    flags &= 0xff;
+    StridedPlan p{};
+    p.n = n; p.stride = stride; p.nkept = nkept; p.order = order; p.split_dim = order == 2 ? split_dim : -1; p.split = split;
+    int64_t total = 1;
+    for (int k = 0; k < nkept; ++k) {
+        if (kept_size[k] < 1 || kept_in_stride[k] < 0 || kept_out_stride[k] < 0) return QS_ERR_ARG;
+        p.size[k] = kept_size[k]; p.in_stride[k] = kept_in_stride[k]; p.out_stride[k] = kept_out_stride[k];
+        if (total > (int64_t)0x7fffffff * kBlock / kept_size[k]) return QS_ERR_ARG;
+        total *= kept_size[k];
+    }
+    return with_dtype(xdt, [&](auto X) {
+        constexpr int XD = decltype(X)::value;
+        const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+        if (odt == QS_F32)
+            hipLaunchKernelGGL((mean_strided_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, total, p, flags,
+                               l0_flag, act);
+        else
+            hipLaunchKernelGGL((mean_strided_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, total, p, flags,
+                               l0_flag, act);
+        return launch_status();
+    });
+}
+
 int qs_mean_last2(const void* x, void* out, int64_t pre, int64_t H, int64_t W, int xdt, int odt, const float* amax_part,
                   float* absmax_out, int64_t absmax_stride, float* record, qs_stream_t stream) {
     if (!x || !out || pre < 1 || H < 1 || W < 1) return QS_ERR_ARG;

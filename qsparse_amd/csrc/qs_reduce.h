@@ -1142,6 +1142,54 @@ __global__ __launch_bounds__(kBlock) void mean_cl_w_kernel(const void* __restric
     store1<ODT>(out, (n * C + c) * H + h, s / (float)W);
 }
 
+// ---- first stage of a dense tensor laid out in ANY dim order (transposed weights, permuted activations, NDHWC with the batch
+// kept ...) ---------------------------------------------------------------------------------------------------------------------
+// ATen reduces such a tensor where it lies; which of SumKernel.cpp's four loops it takes, and which of the kept coordinates fall in
+// the cascade ("multi-row") part of an outer loop, follows from TensorIterator's dim reordering and coalescing -- host logic
+// (qsparse_amd/util.py: `aten_reduce_plan`, pinned against Tensor.mean on the CPU in tests/test_aten_contract.py).  This kernel only
+// executes the plan: one lane per output element; the lane index runs fastest over the kept dim with the smallest input stride, so a
+// wave's loads are as contiguous as the layout allows.  order 0: the vectorised inner sum (8 interleaved row-sums + tail); 1: row-sum
+// for every output; 2: cascade for outputs whose coordinate in kept dim `split_dim` is below `split`, row-sum for the others.
+constexpr int kStridedMaxKept = 6;
+struct StridedPlan {
+    int64_t n, stride;                                   // the reduced dim
+    int64_t size[kStridedMaxKept], in_stride[kStridedMaxKept], out_stride[kStridedMaxKept];
+    int64_t split;
+    int nkept, order, split_dim;
+};
+
+template <int DT, int ODT>
+__global__ __launch_bounds__(kBlock) void mean_strided_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t total,
+                                                               StridedPlan p, int flags, const int32_t* __restrict__ l0_flag,
+                                                               ActSpec act) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= total) return;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    int64_t rest = t, in0 = 0, o = 0, split_coord = 0;
+    for (int k = 0; k < p.nkept; ++k) {
+        const int64_t q = rest / p.size[k], c = rest - q * p.size[k];
+        in0 += c * p.in_stride[k];
+        o += c * p.out_stride[k];
+        if (k == p.split_dim) split_coord = c;
+        rest = q;
+    }
+    const int64_t n = p.n, st = p.stride;
+    auto get = [&](int64_t i) { return mean_prep<DT>(load1<DT>(x, in0 + i * st), flags, l0, act); };
+    float s;
+    if (p.order == 0) {
+        const int64_t nv = n / 8;
+        float fin = 0.f;
+        for (int64_t i = nv * 8; i < n; ++i) fin += get(i);         // the tail first, then the 8 vector lanes in turn
+        for (int k = 0; k < 8; ++k) fin += sum_row_sum(nv, [&](int64_t i) { return get(8 * i + k); });
+        s = fin;
+    } else if (p.order == 2 && split_coord < p.split) {
+        s = sum_multi_row(n, get);
+    } else {
+        s = sum_row_sum(n, get);
+    }
+    store1<ODT>(out, o, s / (float)n);
+}
+
 // ---- the same stage for tensors with FEW columns: rows split over R waves of one workgroup -------------------
 // With C*H*W small (late ResNet stages, small batches of small maps) one wave per 512 columns leaves most CUs
 // with one or two waves and the kernel becomes latency-bound.  Here the R waves of a workgroup own the SAME

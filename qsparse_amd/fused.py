@@ -690,8 +690,10 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 # in front of the channel dim (the batch); with a batch of one there is no such stage and the
                 # abs-max is a pass of its own
                 rides = update_scale and bool(dims) and dims[0] < 1
-                if rides and hd.dim() == 5 and not hd.is_contiguous():
-                    rides = False      # channels_last_3d: the in-place first stage (ATen's order for that layout) carries no abs-max
+                if rides and not hd.is_contiguous() and not (hd.dim() == 4 and hd.is_contiguous(memory_format=torch.channels_last)):
+                    # channels_last_3d, and every other dense layout (a transposed / permuted activation): the in-place first
+                    # stage -- ATen's order for that layout, qs_mean_dim_cl / qs_mean_strided -- carries no abs-max
+                    rides = False
                 if rides:
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 elif update_scale:
@@ -1065,6 +1067,7 @@ class FusedPruneQuantize(nn.Sequential):
     """``Sequential(Sequential(act, PruneLayer), QuantizeLayer)`` with a fused GPU forward/backward.
     Children, parameter names and ``str()`` are those of the plain ``Sequential`` it replaces."""
 
+    @_hip.keeps_layout
     def forward(self, x):
         fast = self.__dict__.get("_qs_fast")
         if fast is not None:
@@ -1141,6 +1144,7 @@ class FusedActQuantize(nn.Sequential):
     folded into the quantizer's kernels (24 -> 16 B/elem per training step for bf16 activations); anything else runs
     module by module.  Children, parameter names and ``str()`` are those of the plain ``Sequential``."""
 
+    @_hip.keeps_layout
     def forward(self, x):
         act, q = self[0], self[1]
         fold, handle = _foldable_relu(act, x)
@@ -1160,6 +1164,7 @@ class FusedActPrune(nn.Sequential):
     y = max(x, 0) * mask, backward gate(x) * g * mask -- 20 -> 12 B/elem per training step for bf16
     activations.  Children, parameter names and ``str()`` are those of the plain ``Sequential``."""
 
+    @_hip.keeps_layout
     def forward(self, x):
         act, p = self[0], self[1]
         fold, handle = _foldable_relu(act, x)

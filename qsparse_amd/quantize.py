@@ -53,6 +53,21 @@ def _int32(t: torch.Tensor) -> torch.Tensor:
     return torch.where(ok, t, torch.full_like(t, -2147483648.0)).int()
 
 
+def _pow2(d):
+    """``2.0 ** d`` as the reference's CPU evaluates it (quantize.py:52-53: libm's pow, exact for an integer exponent).  ATen's
+    device pow is not -- powf(2, 16) is 65535.996 on gfx950, one code off at x = -0.5 with 16 fractional bits -- so a GPU exponent
+    tensor that takes the ATen expression (float64 / integer inputs, `_hip.on_hip`) gets its integer-valued entries as exact powers
+    of two, assembled from the exponent bits; on the CPU, and for a Python number, it is the operator."""
+    if not (isinstance(d, torch.Tensor) and d.is_cuda):
+        return 2.0 ** d
+    p = 2.0 ** d
+    wide = p.dtype == torch.float64
+    whole = d.round() if d.is_floating_point() else d
+    lim, bias, shift, idt, fdt = (1022, 1023, 52, torch.int64, torch.float64) if wide else (126, 127, 23, torch.int32, torch.float32)
+    exact = ((whole.clamp(-lim, lim).to(idt) + bias) << shift).view(fdt).to(p.dtype)
+    return torch.where((d == whole) & (whole.abs() <= lim), exact, p)
+
+
 def _out_dtype(x: torch.Tensor) -> torch.dtype:
     """float32 like the reference (type promotion), or the input dtype with the ``preserve_dtype`` extension"""
     if get_option("preserve_dtype") and x.dtype in (torch.bfloat16, torch.float16):
@@ -113,7 +128,7 @@ class _SteFunction(torch.autograd.Function):
             out_dtype = ctx.x_dtype if grad_output.dtype == torch.float32 else grad_output.dtype
             gx = _hip.ste_bwd(grad_output, step, step_is_decimal, ctx.channel_index, lo_mul, hi_mul, False, out_dtype)
             return (gx,) + (None,) * 8
-        s = torch.pow(2.0, -step) if step_is_decimal else step
+        s = _pow2(-step) if step_is_decimal else step
         if s.numel() > 1:
             s = _on_channel(s, grad_output.dim(), ctx.channel_index, grad_output.shape[ctx.channel_index])
         # values are clamped; the reference's masked assignment `v[v != grad_output] = 0` compares v with ITSELF (clamp_ returned
@@ -179,8 +194,8 @@ class DecimalQuantization(_SteFunction):
             y, codes = _hip.quant_fwd("decimal", input, decimal, channel_index, qd, out_dtype=_out_dtype(input),
                                       want_codes=return_codes, saturate=sat)
             return _with_codes(ctx, _reference_shape(y, input, decimal), codes, return_codes)
-        to_int = _on_channel(2.0 ** decimal, input.dim(), channel_index, input.shape[channel_index])
-        to_float = _on_channel(2.0 ** -decimal, input.dim(), channel_index, input.shape[channel_index])
+        to_int = _on_channel(_pow2(decimal), input.dim(), channel_index, input.shape[channel_index])
+        to_float = _on_channel(_pow2(-decimal), input.dim(), channel_index, input.shape[channel_index])
         codes = _int32(input * to_int)
         if sat is not None:
             codes = codes.clamp(sat[0], sat[1])
@@ -708,6 +723,7 @@ class QuantizeLayer(nn.Module):
             self._steps.note_device_add(self._n_updates, 1)
         return y
 
+    @_hip.keeps_layout
     def forward(self, x):
         if not self.initted:
             self._lazy_init(x)

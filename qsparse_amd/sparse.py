@@ -488,6 +488,7 @@ class PruneLayer(nn.Module):
             return False
         return (not self.training) or self.mask.numel() == 1 or self._steps.read(self._n_updates) >= self.start
 
+    @_hip.keeps_layout
     def forward(self, x: torch.Tensor, pre_relu: bool = False) -> torch.Tensor:
         """prune ``x`` according to the schedule; raises ``RuntimeError`` when a full-shape mask meets a
         different input shape in evaluation mode.  ``pre_relu``: see MagnitudePruningCallback.forward."""

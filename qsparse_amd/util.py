@@ -108,6 +108,83 @@ def _reduction_plan(xshape: Sequence[int], shape: Sequence[int]) -> List[int]:
     return dims
 
 
+def aten_reduce_plan(shape: Sequence[int], strides: Sequence[int], d: int):
+    """How ATen's CPU ``x.mean(d, keepdim=True)`` walks a dense tensor of `shape` / `strides` (elements) -- the host half of
+    qs_mean_strided.  TensorIterator (reorder_dimensions, coalesce_dimensions) puts the reduced dim first, sorts the kept dims by
+    the stride they have in the contiguous result and merges neighbours that merge in both operands; SumKernel.cpp then picks by
+    the strides of the two innermost dims: reduced dim unit-strided and >= 8 long -> vectorised inner sum; next dim unit-strided and
+    >= 8 long -> vectorised outer sum (blocks of 32 of its coordinates in cascade order, the rest row-sum); else the scalar inner
+    sum (row-sum) when the reduced dim has the smaller stride, the scalar outer sum (blocks of 4 in cascade order, rest row-sum)
+    when not.  Returns (n, stride, kept, order, split_dim, split): kept = [(size, input stride, output stride)] sorted by input
+    stride (the lane dim first), order / split_dim / split as include/qsparse_hip.h describes them.  Pinned against Tensor.mean on
+    the CPU, one intra-op thread, in tests/test_aten_contract.py."""
+    nd = len(shape)
+    out_strides, acc = [0] * nd, 1
+    for i in range(nd - 1, -1, -1):
+        out_strides[i] = acc
+        acc *= 1 if i == d else shape[i]
+    out_strides[d] = 0
+    live = [i for i in range(nd) if shape[i] != 1]
+    size = [shape[i] for i in live]
+    ins = [strides[i] for i in live]
+    outs = [out_strides[i] for i in live]
+    n = len(live)
+    if d not in live:
+        raise ValueError("the reduced dim has one element")
+
+    def goes_after(a, b):          # TensorIterator::reorder_dimensions' should_swap(a, b): > 0 when a belongs outside b
+        # operand 0, the output: a reduced dim (stride 0) goes inside every kept one; two kept dims by output stride
+        if (outs[a] == 0) != (outs[b] == 0):
+            return 1 if outs[b] == 0 else -1
+        for st in (outs, ins):
+            if st[a] == 0 or st[b] == 0:
+                continue
+            if st[a] != st[b]:
+                return 1 if st[a] > st[b] else -1
+            if size[a] > size[b]:
+                return 1
+        return 0
+
+    perm = list(range(n - 1, -1, -1))
+    for i in range(1, n):
+        hi = i
+        for lo in range(i - 1, -1, -1):
+            c = goes_after(perm[lo], perm[hi])
+            if c > 0:
+                perm[lo], perm[hi] = perm[hi], perm[lo]
+                hi = lo
+            elif c < 0:
+                break
+    size, ins, outs = ([v[k] for k in perm] for v in (size, ins, outs))
+    last = 0
+    for k in range(1, n):          # coalesce_dimensions
+        if size[last] * ins[last] == ins[k] and size[last] * outs[last] == outs[k]:
+            size[last] *= size[k]
+        else:
+            last += 1
+            size[last], ins[last], outs[last] = size[k], ins[k], outs[k]
+    n = last + 1
+    assert outs[0] == 0 and (n == 1 or outs[1] != 0)
+    n0, s0 = size[0], ins[0]
+    n1, s1 = (size[1], ins[1]) if n > 1 else (1, 0)
+    if s0 == 1 and n0 >= 8:
+        order, split = 0, 0
+    elif s1 == 1 and n1 >= 8:
+        order, split = 2, (n1 // 32) * 32
+    elif s0 < s1:
+        order, split = 1, 0
+    else:
+        order, split = 2, (n1 // 4) * 4
+    if order == 2 and split == 0:      # no full block: row-sum for every output
+        order = 1
+    kept = sorted(range(1, n), key=lambda k: ins[k])
+    split_dim = kept.index(1) if order == 2 else -1
+    return n0, s0, [(size[k], ins[k], outs[k]) for k in kept], order, split_dim, split
+
+
+_dense_any_order = _hip.dense_any_order
+
+
 def _record_for(record, slices: int):
     """the exchange-record buffer if the fused last-two-dims launch can fill it (one slice per channel)"""
     if record is None or record["buf"].numel() != 2 * slices:
@@ -192,6 +269,18 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
             flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
             cur = _hip.mean_cl_w(xm, torch.float32 if l0_flag is not None else x.dtype, flags, l0_flag).view(N, C, H, 1)
             dims, first = dims[1:], False
+    if cur is None and dims and absmax_out is None and not x.is_contiguous() and x.numel() > 0:
+        # any other layout (a transposed weight, a permuted activation, NDHWC with the batch kept ...): the reference's importance
+        # is `x.abs()`, a dense tensor in x's stride order, which ATen reduces where it lies -- in the order aten_reduce_plan
+        # derives, executed by qs_mean_strided on x itself (a view that is not dense is first copied into that dense layout, as
+        # `x.abs()` would lay it out); the result is contiguous like ATen's, the later stages are the usual ones
+        xs = x if _dense_any_order(x) else torch.empty_like(x).copy_(x)
+        d = dims[0]
+        plan = aten_reduce_plan(list(xs.shape), list(xs.stride()), d) if x.shape[d] > 1 else None
+        if plan is not None and len(plan[2]) <= _hip.STRIDED_MAX_KEPT:
+            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
+            stage = _hip.mean_strided(xs, plan, torch.float32 if l0_flag is not None else x.dtype, flags, l0_flag)
+            cur, dims, first = stage.view([1 if i == d else s for i, s in enumerate(x.shape)]), dims[1:], False
     if cur is None:
         cur = _hip.dense(x)
     shape = list(cur.shape)

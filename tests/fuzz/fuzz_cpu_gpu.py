@@ -333,7 +333,7 @@ STEADY = [0]       # ... and in which its steady-state fast path (batch._Steady)
 
 
 def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False, channels_last=False, batcher=False, twin=False,
-        site=False, nonfinite=None, graph=False):
+        site=False, nonfinite=None, graph=False, permute=None):
     np.random.seed(seed)
     torch.manual_seed(seed)
     m = factory().to(device)
@@ -435,6 +435,8 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
             x.view(-1)[(seed * 7919 + s * 31) % x.numel()] = nonfinite[0]
         if channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
+        if permute is not None:      # the same values, dense in memory in another dim order (a transposed / permuted activation)
+            x = x.permute(permute).contiguous().permute([permute.index(i) for i in range(x.dim())])
         if (graph and device == "cuda" and captured is None and m.training and not twin and s >= 2 and y_dtype is not None
                 and qs.graphs.steady_state(m)):
             sx = torch.empty_like(x.to(device)).requires_grad_(True)
@@ -491,12 +493,17 @@ def one_case(rng, idx, dry=False):
     steps = rng.choice([3, 5, 6]) if desc["what"] != "site" else rng.choice([6, 8, 10])
     eval_from = rng.choice([steps, steps - 1])
     channels_last = rng.random() < 0.4
+    # (statistics of channels_last inputs follow ATen's own order for that layout whichever dim leads the reduced ones -- N: the
+    # multi-row / row-sum split; C or H with the batch dim kept; W: the scalar inner sum, qs_mean_cl_w since ABI v20; W with H == 1,
+    # where "channels_last" strides say nothing about the order: the general route, qs_mean_strided, since ABI v22)
     if desc["what"] in ("act_p", "act_pq"):
-        # statistics of channels_last inputs follow ATen's own order for that layout whichever dim leads the reduced ones (N: the
-        # multi-row / row-sum split; C or H with the batch dim kept; W: the scalar inner sum, qs_mean_cl_w since ABI v20).  The one
-        # layout left to its NCHW copy: W leading with H == 1, where "channels_last" strides say nothing about the order
-        reduced = [d for d in range(len(shape)) if d not in desc.get("dimensions", [1]) and shape[d] > 1]
-        channels_last = channels_last and len(shape) == 4 and (not reduced or reduced[0] != 3 or shape[2] > 1)
+        channels_last = channels_last and len(shape) == 4
+    permute = None
+    if desc["what"] in ("site", "act_q", "act_p", "act_pq") and not channels_last and len(shape) >= 2 and rng.random() < 0.25:
+        # any other dense layout: statistics in ATen's order for it (qs_mean_strided, ABI v22), results back in the input's layout
+        permute = list(range(len(shape)))
+        while permute == sorted(permute):
+            rng.shuffle(permute)
     batcher = rng.random() < 0.6
     twin = rng.random() < 0.25
     nonfinite = None
@@ -522,8 +529,8 @@ def one_case(rng, idx, dry=False):
         routes["graph_safe"] = True
     if EXCHANGE and rng.random() < 0.6:     # the statistics exchange of a data-parallel run, live on a one-rank group (same values)
         routes["sync_statistics"] = "always"
-    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, batcher=batcher, twin=twin, nonfinite=nonfinite,
-                routes=routes)
+    desc.update(i=idx, steps=steps, eval_from=eval_from, channels_last=channels_last, permute=permute, batcher=batcher, twin=twin,
+                nonfinite=nonfinite, routes=routes)
     if dry:
         return None
     if VERBOSE:
@@ -534,7 +541,7 @@ def one_case(rng, idx, dry=False):
             if device == "cuda":
                 qs.set_qsparse_options(**routes)
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite, graph)
+                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite, graph, permute)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
         finally:

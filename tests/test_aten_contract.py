@@ -12,6 +12,55 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 import probe_aten_threads as probe
 
+import numpy as np
+
+
+def multi_row(v):
+    """SumKernel.cpp's cascade sum of the rows of v [n, columns], float32"""
+    n = v.shape[0]
+    lp = max(4, (0 if n <= 1 else (n - 1).bit_length()) // 4)
+    step, lmask = 1 << lp, (1 << lp) - 1
+    a = [np.zeros(v.shape[1], np.float32) for _ in range(4)]
+    i = 0
+    while i + step <= n:
+        for j in range(step):
+            a[0] = a[0] + v[i + j]
+        i += step
+        a[1] = a[1] + a[0]
+        a[0] = np.zeros_like(a[0])
+        if (i & (lmask << lp)) == 0:
+            a[2] = a[2] + a[1]
+            a[1] = np.zeros_like(a[1])
+            if (i & (lmask << (2 * lp))) == 0:
+                a[3] = a[3] + a[2]
+                a[2] = np.zeros_like(a[2])
+    while i < n:
+        a[0] = a[0] + v[i]
+        i += 1
+    return ((a[0] + a[1]) + a[2]) + a[3]
+
+
+def row_sum(v):
+    """four interleaved cascade sums, the n % 4 last rows added to the first, ((p0 + p1) + p2) + p3"""
+    n4 = v.shape[0] // 4
+    p = [multi_row(v[k:n4 * 4:4]) if n4 else np.zeros(v.shape[1], np.float32) for k in range(4)]
+    for i in range(n4 * 4, v.shape[0]):
+        p[0] = p[0] + v[i]
+    return ((p[0] + p[1]) + p[2]) + p[3]
+
+
+def vector_inner(v):
+    """the vectorised inner sum: 8 interleaved row-sums, the n % 8 tail, then the 8 lanes in turn"""
+    n = v.shape[0]
+    nv = n // 8
+    fin = np.zeros(v.shape[1], np.float32)
+    for i in range(nv * 8, n):
+        fin = fin + v[i]
+    for k in range(8):
+        fin = fin + row_sum(v[k:nv * 8:8])
+    return fin
+
+
 
 def test_aten_staged_mean_vs_intra_op_threads():
     before = torch.get_num_threads()
@@ -68,38 +117,6 @@ def test_aten_reduces_w_of_a_channels_last_tensor_in_row_sum_order():
     """`x.mean(3, keepdim=True)` of a channels_last tensor (a mask that keeps N, C and H): ATen's scalar inner sum -- four
     interleaved cascade sums over w, the W % 4 last elements added to the first, ((p0 + p1) + p2) + p3 -- which is what
     qs_mean_cl_w restates (qsparse_amd/csrc/qs_reduce.h); NOT the order of the contiguous NCHW row"""
-    import numpy as np
-
-    def multi_row(v):
-        n = v.shape[0]
-        lp = max(4, (0 if n <= 1 else (n - 1).bit_length()) // 4)
-        step, lmask = 1 << lp, (1 << lp) - 1
-        a = [np.zeros(v.shape[1], np.float32) for _ in range(4)]
-        i = 0
-        while i + step <= n:
-            for j in range(step):
-                a[0] = a[0] + v[i + j]
-            i += step
-            a[1] = a[1] + a[0]
-            a[0] = np.zeros_like(a[0])
-            if (i & (lmask << lp)) == 0:
-                a[2] = a[2] + a[1]
-                a[1] = np.zeros_like(a[1])
-                if (i & (lmask << (2 * lp))) == 0:
-                    a[3] = a[3] + a[2]
-                    a[2] = np.zeros_like(a[2])
-        while i < n:
-            a[0] = a[0] + v[i]
-            i += 1
-        return ((a[0] + a[1]) + a[2]) + a[3]
-
-    def row_sum(v):
-        n4 = v.shape[0] // 4
-        p = [multi_row(v[k:n4 * 4:4]) if n4 else np.zeros(v.shape[1], np.float32) for k in range(4)]
-        for i in range(n4 * 4, v.shape[0]):
-            p[0] = p[0] + v[i]
-        return ((p[0] + p[1]) + p[2]) + p[3]
-
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
@@ -114,5 +131,56 @@ def test_aten_reduces_w_of_a_channels_last_tensor_in_row_sum_order():
             assert torch.equal(a, b.contiguous()), (N, C, H, W)
             differs_from_nchw += int(not torch.equal(a, x.abs().contiguous().mean(3, keepdim=True)))
         assert differs_from_nchw >= 3          # (which is why the NCHW copy's order was a deviation)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def test_aten_reduce_plan_names_the_order_aten_takes_for_any_dense_layout():
+    """`util.aten_reduce_plan` -- the host half of qs_mean_strided -- against Tensor.mean on the CPU: dense tensors in a random
+    dim order (transposes, permutes, channels_last(_3d) among them), every reducible dim, float32 / bfloat16 / float16; the plan is
+    executed here exactly as the kernel executes it (one output at a time, the order it names)"""
+    import itertools
+    import random
+
+    from qsparse_amd.util import _dense_any_order, aten_reduce_plan
+
+    def execute(x, d):
+        n, s0, kept, order, split_dim, split = aten_reduce_plan(list(x.shape), list(x.stride()), d)
+        mem = torch.as_strided(x, (x.untyped_storage().nbytes() // x.element_size(),), (1,), 0).float().numpy()
+        out_shape = [1 if i == d else s for i, s in enumerate(x.shape)]
+        out = np.zeros(int(np.prod(out_shape)), np.float32)
+        for coords in itertools.product(*[range(k[0]) for k in kept]):
+            at = x.storage_offset() + sum(c * k[1] for c, k in zip(coords, kept))
+            v = mem[at + np.arange(n) * s0][:, None]
+            r = vector_inner(v) if order == 0 else (multi_row(v) if order == 2 and coords[split_dim] < split else row_sum(v))
+            out[sum(c * k[2] for c, k in zip(coords, kept))] = r[0] / np.float32(n)
+        return torch.from_numpy(out).view(out_shape).to(x.dtype), order
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        rng, g = random.Random(0), torch.Generator().manual_seed(0)
+        seen, differs = set(), 0
+        for it in range(260):
+            nd = rng.choice([1, 2, 3, 4, 4, 5])
+            shape = [rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 33, 40]) for _ in range(nd)]
+            while int(np.prod(shape)) > 12000:
+                shape[rng.randrange(nd)] = 2
+            perm = list(range(nd))
+            rng.shuffle(perm)
+            dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])
+            x = (torch.randn([shape[p] for p in perm], generator=g) * 3).abs().to(dtype).permute([perm.index(i) for i in range(nd)])
+            assert _dense_any_order(x) and list(x.shape) == shape
+            reducible = [i for i in range(nd) if shape[i] > 1]
+            if not reducible:
+                continue
+            d = rng.choice(reducible)
+            want = x.mean(d, keepdim=True)
+            got, order = execute(x, d)
+            assert want.is_contiguous() and torch.equal(want, got), (shape, x.stride(), d, dtype)
+            seen.add(order)
+            differs += int(not torch.equal(want, x.contiguous().mean(d, keepdim=True)))
+        assert seen == {0, 1, 2} and differs >= 20       # (the contiguous copy's order is a different one for many of them)
+        assert not _dense_any_order(torch.zeros(4, 6)[:, ::2]) and not _dense_any_order(torch.zeros(4, 1).expand(4, 3))
     finally:
         torch.set_num_threads(threads)

@@ -138,3 +138,25 @@ def test_supported_dtypes_still_take_the_kernels(monkeypatch):
         for s in range(3):
             q(torch.randn(4, 8, 4, 4, generator=gen(s)).to(dtype).cuda())
     assert torch.float64 not in calls and {torch.float32, torch.bfloat16, torch.float16} <= set(calls)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.int32])
+def test_power_of_two_steps_are_exact_on_the_device(dtype):
+    """`2.0 ** decimal` (reference quantize.py:52-53) is exact on the CPU; ATen's device pow is not (powf(2, 16) = 65535.996 on
+    gfx950: x = -0.5 with 16 fractional bits came out one code short, found by the float64 cases of the fuzz) -- `quantize._pow2`"""
+    for d in range(-20, 31):
+        dec = torch.tensor([float(d), float(d + 1)])
+        x = (torch.tensor([[-0.5, 3.0], [0.75, -7.0]]) if dtype.is_floating_point else torch.tensor([[-1, 3], [5, -7]])).to(dtype)
+        g = torch.tensor([[1e-9, -1e9], [0.5, 2.0 ** (7 - d - 1)]])
+        res = []
+        for dev in ("cpu", "cuda"):
+            xi = x.detach().clone().to(dev).requires_grad_(dtype.is_floating_point)
+            y = qs.quantize_with_decimal(xi, 8 if d > -20 else 16, dec.to(dev), channel_index=1)
+            res.append(y.detach().cpu())
+            if dtype.is_floating_point:
+                y.backward(g.to(dev))
+                res.append(xi.grad.cpu())
+        half = len(res) // 2
+        for a, b in zip(res[:half], res[half:]):
+            assert torch.equal(a, b), (d, a, b)
