@@ -102,7 +102,11 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                     else by_mode(IC<8>{});
                 }
             }
-            if (vcols < post) {
+            if (post == 1 && n >= 64 && !am && (pre + 1) / 2 <= 0x7fffffff && env_int("QS_MEAN_INNER_WAVE", 1)) {
+                // long rows reduced along their own direction: half a wave per row (QS_MEAN_INNER_WAVE=0: one lane per row)
+                hipLaunchKernelGGL((mean_inner_wave_kernel<XD, OD>), dim3((unsigned)((pre + 1) / 2)), dim3(64), 0, s, x, out, pre, n,
+                                   flags, l0_flag, act);
+            } else if (vcols < post) {
                 const int64_t total = pre * (post - vcols);
                 hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
                                    0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1,

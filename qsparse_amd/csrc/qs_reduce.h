@@ -1304,6 +1304,38 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
     }
 }
 
+// ---- inner reduction of LONG rows (post == 1, n >= 64): half a wave per row ------------------------------------------------
+// ATen's vectorised inner sum is 32 interleaved cascade sums: element e feeds the chain of vector lane e % 8 and row-sum part
+// (e / 8) % 4 -- chain e % 32 -- at position e / 32, for the first 32 * floor(n / 32) elements.  Lane c of a half-wave runs chain c
+// (its loads and its neighbours' are one contiguous 128-byte line of fp32); then, per vector lane k, the n / 8 % 4 leftover vectors
+// go to part 0, the parts are added ((p0 + p1) + p2) + p3, and the row's first lane adds the n % 8 tail from zero and the 8 vector
+// lanes in turn.  Same bits as mean_generic_kernel's one-lane-per-row loop, which read a 4096-long row at 48 GB/s.
+template <int DT, int ODT>
+__global__ __launch_bounds__(64) void mean_inner_wave_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t rows,
+                                                              int64_t n, int flags, const int32_t* __restrict__ l0_flag,
+                                                              ActSpec act) {
+    const int lane = threadIdx.x & 31, half = threadIdx.x >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 2 + half;
+    const bool live = row < rows;
+    const int l0 = (flags & QS_MEAN_L0) && l0_flag && *l0_flag;
+    const int64_t base = (live ? row : 0) * n;          // (an odd row count: the idle half re-reads row 0, uniform control flow)
+    auto get = [&](int64_t e) { return mean_prep<DT>(load1<DT>(x, base + e), flags, l0, act); };
+    const int64_t nv = n / 8, n4 = nv / 4;
+    const float chain = sum_multi_row(n4, [&](int64_t m) { return get(32 * m + lane); });
+    const int k0 = half * 32 + (lane & 7);
+    float p0 = __shfl(chain, k0, 64);
+    const float p1 = __shfl(chain, k0 + 8, 64), p2 = __shfl(chain, k0 + 16, 64), p3 = __shfl(chain, k0 + 24, 64);
+    if (lane < 8)
+        for (int64_t i = n4 * 4; i < nv; ++i) p0 += get(8 * i + lane);
+    const float vec_lane = ((p0 + p1) + p2) + p3;
+    float fin = 0.f;
+    if (lane == 0)
+        for (int64_t i = nv * 8; i < n; ++i) fin += get(i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fin += __shfl(vec_lane, half * 32 + k, 64);
+    if (lane == 0 && live) store1<ODT>(out, row, fin / (float)n);
+}
+
 // ---- generic stage: one thread per output element, either order -------------------------------------
 template <int DT, int ODT>
 __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __restrict__ x, void* __restrict__ out,

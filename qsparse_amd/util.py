@@ -277,9 +277,21 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
         xs = x if _dense_any_order(x) else torch.empty_like(x).copy_(x)
         d = dims[0]
         plan = aten_reduce_plan(list(xs.shape), list(xs.stride()), d) if x.shape[d] > 1 else None
+        flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
+        odt = torch.float32 if l0_flag is not None else x.dtype
+        if plan is not None and plan[3] == 0:
+            # the reduced dim is the unit-stride one and ATen takes its vectorised inner sum: the memory-order view of x is a
+            # contiguous tensor whose LAST dim is reduced -- the coalesced last-dim stage on that view; only the (n times smaller)
+            # result is put into the logical order
+            order = sorted((i for i in range(x.dim()) if i != d), key=lambda i: (xs.shape[i] != 1, -xs.stride(i))) + [d]
+            mem = xs.permute(order)
+            if mem.is_contiguous():
+                kw = {"l0_flag": l0_flag} if l0_flag is not None else {}
+                stage = _hip.mean_dim(mem, mem.numel() // x.shape[d], x.shape[d], 1, odt, flags, **kw)
+                stage = stage.view(tuple(mem.shape[:-1]) + (1,)).permute([order.index(i) for i in range(x.dim())]).contiguous()
+                cur, dims, first, plan = stage, dims[1:], False, None
         if plan is not None and len(plan[2]) <= _hip.STRIDED_MAX_KEPT:
-            flags = _hip.mean_flags(take_abs, pre_relu, l0_flag is not None)
-            stage = _hip.mean_strided(xs, plan, torch.float32 if l0_flag is not None else x.dtype, flags, l0_flag)
+            stage = _hip.mean_strided(xs, plan, odt, flags, l0_flag)
             cur, dims, first = stage.view([1 if i == d else s for i, s in enumerate(x.shape)]), dims[1:], False
     if cur is None:
         cur = _hip.dense(x)

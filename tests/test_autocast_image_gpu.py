@@ -565,3 +565,39 @@ def test_two_replacing_hooks_registered_after_the_consumer_chain_like_ordinary_h
             qs.set_qsparse_options(autocast_image=True)
     for a, b in zip(*runs):
         assert same(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize("site_kind", ["pair", "act_quantize"])
+def test_inputs_in_other_layouts_come_back_in_their_layout_with_or_without_the_image(site_kind):
+    """a transposed / permuted activation under autocast: the site runs on its contiguous copy, `_hip.keeps_layout` puts the
+    result into the layout the reference returns (dense in the input's stride order) -- whether or not the site handed out an
+    image on the way, the values, the layout and the gradients are those of the plain route"""
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        try:
+            torch.manual_seed(3)
+            if site_kind == "pair":
+                site = _pair().to(DEV).train()
+            else:
+                site = qs.convert(nn.Sequential(nn.ReLU()), qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU],
+                                  log=False).to(DEV).train()
+            w = torch.randn(12, 24, device=DEV)
+            trace = []
+            for s in range(6):
+                x = (torch.randn(6, 24, 16, generator=gen(40 + s)) * 2).bfloat16().to(DEV).transpose(1, 2)    # [B, C, T] view of [B, T, C]
+                x.requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = site(x)
+                    assert y.stride() == x.stride(), (y.stride(), x.stride())
+                    out = F.linear(y, w).float().sum(-1) + ((y * 0.5).sum(-1) if s % 2 else 0)
+                out.sum().backward()
+                trace += [y.detach().as_subclass(torch.Tensor).clone(), out.detach().clone(), x.grad.clone()]
+            runs.append((trace, {k: v.detach().clone() for k, v in site.state_dict().items()}))
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    (ta, sa), (tb, sb) = runs
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
+    for k in sa:
+        assert same(sa[k].cpu(), sb[k].cpu()), k

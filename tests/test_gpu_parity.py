@@ -1561,3 +1561,30 @@ def test_results_come_back_in_the_layout_the_reference_returns():
                 res.append(rec)
             for i, (a, b) in enumerate(zip(*res)):
                 assert torch.equal(a, b), (name, shape, perm, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_long_rows_reduced_along_their_own_direction(dtype):
+    """the inner reduction (the last dim of a contiguous tensor: a row mask over a Linear weight, the W stage of maps too large
+    for the fused last-two-dims launch, the unit-stride dim of a transposed tensor) with half a wave per row
+    (mean_inner_wave_kernel, n >= 64): ATen's vectorised inner sum, bit for bit (reference util.py:92-99)"""
+    from qsparse_amd.util import squeeze_tensor_to_shape
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        g = torch.Generator().manual_seed(4)
+        for pre in (1, 2, 3, 64, 257):
+            for n in (63, 64, 65, 71, 96, 127, 128, 255, 256, 1000, 4096, 5003, 70000):
+                if pre * n > 3_000_000:
+                    continue
+                x = (torch.randn(pre, n, generator=g) * 3).to(dtype)
+                want = squeeze_tensor_to_shape(x.abs(), [pre, 1])
+                got = squeeze_tensor_to_shape(x.cuda().abs(), [pre, 1])
+                assert got.dtype == want.dtype and torch.equal(got.cpu(), want), (pre, n)
+        # inside a 4-d staged mean: W = 300 maps do not fit the fused last-two-dims launch (LDS), the W stage is an inner reduction
+        x = (torch.randn(2, 3, 230, 300, generator=g) * 3).to(dtype)
+        for target in ([1, 3, 1, 1], [2, 3, 230, 1], [2, 1, 1, 1]):
+            assert torch.equal(squeeze_tensor_to_shape(x.cuda().abs(), target).cpu(), squeeze_tensor_to_shape(x.abs(), target)), target
+    finally:
+        torch.set_num_threads(threads)
