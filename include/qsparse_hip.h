@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 22
+#define QS_ABI_VERSION 23
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -239,6 +239,15 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
 int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
                 int xdt, int odt, int flags, const int32_t* l0_flag,
                 float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C, qs_stream_t stream);
+
+/* qs_mean_dim for a [pre, n, post] tensor that is the MEMORY of a permuted one (post >= 2): ATen decides between cascade and
+ * row-sum order per output from the coordinates of the dim its TensorIterator puts innermost, which for such a tensor need not be
+ * the flattened post (qsparse_amd/util.py `aten_reduce_plan`).  Where that set is a prefix of the columns -- the usual case, e.g. a
+ * [B, T, C] activation seen as [B, C, T] and reduced over B: t < 4 * floor(T / 4) -- the caller names it: columns [0, mr_cols) of
+ * every slice in cascade order, the others in row-sum order, through the same kernels as qs_mean_dim (16-byte loads, 8 columns per
+ * lane).  No abs-max rider.  (ABI v23) */
+int qs_mean_dim_split(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int64_t mr_cols, int xdt, int odt, int flags,
+                      const int32_t* l0_flag, qs_stream_t stream);
 
 /* The first stage for a channels_last (NHWC in memory) activation x[n][hw][C]: mean over n ->
  * out[C][hw], NCHW-contiguous like the result of Tensor.mean(0, keepdim=True) on a channels_last tensor, in the

@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 22          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 23          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_mean_cl_w": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "qs_mean_dim_split": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_mean_strided": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),
@@ -907,10 +908,18 @@ def amax_values(t: torch.Tensor) -> torch.Tensor:
 
 def mean_dim(x: torch.Tensor, pre: int, n: int, post: int, out_dtype: torch.dtype, flags: int = 0,
              l0_flag: Optional[torch.Tensor] = None, absmax_out: Optional[torch.Tensor] = None, chan_div: int = 1,
-             C: int = 1) -> torch.Tensor:
-    """x: contiguous storage viewed as [pre, n, post]; returns a flat [pre*post] tensor."""
+             C: int = 1, mr_cols: Optional[int] = None) -> torch.Tensor:
+    """x: contiguous storage viewed as [pre, n, post]; returns a flat [pre*post] tensor.  `mr_cols`: the cascade prefix of a
+    permuted tensor's memory view (qs_mean_dim_split) instead of ATen's rule for a contiguous tensor."""
     x = dense(x)
     out = torch.empty(pre * post, dtype=out_dtype, device=x.device)
+    if mr_cols is not None:
+        assert absmax_out is None
+        with _timed("mean_dim", x, out):
+            st = load().qs_mean_dim_split(_ptr(x), _ptr(out), pre, n, post, int(mr_cols), dt(x), _DT[out_dtype], int(flags),
+                                          _ptr(l0_flag), _stream(x))
+        _check(st, "qs_mean_dim_split")
+        return out
     with _timed("mean_dim" + ("+absmax" if absmax_out is not None else ""), x, out):
         st = load().qs_mean_dim(_ptr(x), _ptr(out), pre, n, post, dt(x), _DT[out_dtype], int(flags), _ptr(l0_flag),
                                 _ptr(absmax_out), amax_stride(absmax_out), int(chan_div), int(C), _stream(x))

@@ -5,11 +5,11 @@
 #include "qs_host.h"
 #include "qs_reduce.h"
 
-extern "C" {
-
-int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
-                const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
-                qs_stream_t stream) {
+// mr_cols < 0: ATen's rule for a contiguous [pre, n, post] tensor; >= 0 (post > 1): columns [0, mr_cols) of every slice in cascade
+// order, the others in row-sum order
+static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
+                         const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
+                         int64_t mr_cols, qs_stream_t stream) {
     if (!x || !out || pre < 1 || n < 1 || post < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
     if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
@@ -24,7 +24,11 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
     int64_t vcols = 0;
     const bool ragged_absmax = absmax_out && (chan_div % 8 != 0);
     if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!ragged_absmax || chan_div >= 8))
-        vcols = (post / 32) * 32;
+        vcols = mr_cols >= 0 ? (mr_cols / 8) * 8 : (post / 32) * 32;
+    // float32 without the abs-max rider: one lane per output (mean_generic_kernel, 4-byte loads, four times the waves) is as fast as
+    // the 8-columns-per-lane kernels on the largest tensors and faster below (256 x 150528: 25 against 35 us, 1024 x 65536: 56 against
+    // 100; only very short columns, n < 32, lose) -- QS_MEAN_F32_GENERIC=0 restores the vector kernels
+    if (xdt == QS_F32 && !absmax_out && n >= 32 && env_int("QS_MEAN_F32_GENERIC", 1)) vcols = 0;
     uint32_t* am = (uint32_t*)absmax_out;
     // rows are split over R waves per workgroup when there are too few column groups to fill the chip
     const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
@@ -35,8 +39,11 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
         const int want = env_int("QS_MEAN_SPLIT", 0);
         if (want > 0) R = want;
         else if (waves < 128 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 8;   // with narrow waves, see below
-        else if (waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
-        else if (waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
+        // (the next two with the abs-max rider only: without it the one-wave kernel with 32 rows in flight is the faster one from 128
+        //  waves on -- 256 x 768 x 14 x 14 bf16: 20.0 us against 30.8 split four ways, 256 x 512 x 14 x 14: 18.9 against 27.0;
+        //  with the rider it is the other way round, 31.4 against 21.9)
+        else if (am && waves < 256 && nchunks >= 2 && nchunks <= kMaxSplitChunks) R = 4;   // measured: tools/bench_stats.py
+        else if (am && waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
         while (R > 1 && R > nchunks) R >>= 1;
         if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
         if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
@@ -102,20 +109,38 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, 
                     else by_mode(IC<8>{});
                 }
             }
-            if (post == 1 && n >= 64 && !am && (pre + 1) / 2 <= 0x7fffffff && env_int("QS_MEAN_INNER_WAVE", 1)) {
+            if (post == 1 && mr_cols < 0 && n >= 64 && !am && (pre + 1) / 2 <= 0x7fffffff && env_int("QS_MEAN_INNER_WAVE", 1)) {
                 // long rows reduced along their own direction: half a wave per row (QS_MEAN_INNER_WAVE=0: one lane per row)
                 hipLaunchKernelGGL((mean_inner_wave_kernel<XD, OD>), dim3((unsigned)((pre + 1) / 2)), dim3(64), 0, s, x, out, pre, n,
                                    flags, l0_flag, act);
             } else if (vcols < post) {
                 const int64_t total = pre * (post - vcols);
-                hipLaunchKernelGGL((mean_generic_kernel<XD, OD>), dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock),
-                                   0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1,
-                                   (uint32_t)(C > 0 ? C : 1), act);
+                const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+                if (am)
+                    hipLaunchKernelGGL((mean_generic_kernel<XD, OD, true>), grid, dim3(kBlock), 0, s, x, out, pre, n, post, vcols, flags,
+                                       l0_flag, am, as, chan_div > 0 ? chan_div : 1, (uint32_t)(C > 0 ? C : 1), act, mr_cols);
+                else
+                    hipLaunchKernelGGL((mean_generic_kernel<XD, OD, false>), grid, dim3(kBlock), 0, s, x, out, pre, n, post, vcols, flags,
+                                       l0_flag, am, as, chan_div > 0 ? chan_div : 1, (uint32_t)(C > 0 ? C : 1), act, mr_cols);
             }
             return launch_status();
         };
         return (odt == QS_F32) ? run(IC<QS_F32>{}) : run(X);
     });
+}
+
+extern "C" {
+
+int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
+                const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
+                qs_stream_t stream) {
+    return mean_dim_impl(x, out, pre, n, post, xdt, odt, flags, l0_flag, absmax_out, absmax_stride, chan_div, C, -1, stream);
+}
+
+int qs_mean_dim_split(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int64_t mr_cols, int xdt, int odt, int flags,
+                      const int32_t* l0_flag, qs_stream_t stream) {
+    if (post < 2 || mr_cols < 0 || mr_cols > post) return QS_ERR_ARG;
+    return mean_dim_impl(x, out, pre, n, post, xdt, odt, flags, l0_flag, nullptr, 1, 1, 1, mr_cols, stream);
 }
 
 int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, int xdt, int odt, int flags,
@@ -135,12 +160,12 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
         return with_dtype(xdt, [&](auto X) {
             constexpr int XD = decltype(X)::value;
             const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-            if (odt == QS_F32)
-                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw,
-                                   C, flags, l0_flag, (uint32_t*)amax_part, act);
-            else
-                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw, C,
-                                   flags, l0_flag, (uint32_t*)amax_part, act);
+            auto launch = [&](auto O, auto A) {
+                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, decltype(O)::value, decltype(A)::value>), grid, dim3(kBlock), 0,
+                                   (hipStream_t)stream, x, out, n, hw, C, flags, l0_flag, (uint32_t*)amax_part, act);
+            };
+            if (odt == QS_F32) { if (amax_part) launch(IC<QS_F32>{}, std::true_type{}); else launch(IC<QS_F32>{}, std::false_type{}); }
+            else { if (amax_part) launch(X, std::true_type{}); else launch(X, std::false_type{}); }
             return launch_status();
         });
     }

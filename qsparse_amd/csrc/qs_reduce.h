@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict
 // rest in row-sum order (checked against ATen's CPU result for C = 3 ... 100, tests/test_gpu_parity.py).  Serves
 // channels_last activations whose C is not a multiple of 8 and the L0 variant (sparse.py:85-86), which used to be
 // copied to NCHW first -- and were then summed in NCHW order, i.e. not in the order the reference's CPU path uses.
-template <int DT, int ODT>
+template <int DT, int ODT, bool AMAX>
 __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                   int64_t n, int64_t hw, int64_t C, int flags,
                                                                   const int32_t* __restrict__ l0_flag,
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
     uint32_t amax = 0u;
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, i * sample + t);
-        if (amax_part) {
+        if constexpr (AMAX) {      // (compile time: see mean_generic_kernel)
             const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
     const float s = (pos < (hw / 4) * 4) ? sum_multi_row(n, get) : sum_row_sum(n, get);
     const int64_t o = c * hw + pos;                       // the result is NCHW-contiguous, as ATen's is
     store1<ODT>(out, o, s / (float)n);
-    if (amax_part) amax_part[o] = amax;
+    if constexpr (AMAX) amax_part[o] = amax;
 }
 
 // ---- channels_last activation whose FIRST reduced dim is W (a mask that keeps N, C and H: `prune(dimensions={0, 1, 2})`) ------
@@ -1337,12 +1337,14 @@ __global__ __launch_bounds__(64) void mean_inner_wave_kernel(const void* __restr
 }
 
 // ---- generic stage: one thread per output element, either order -------------------------------------
-template <int DT, int ODT>
+// AMAX (compile time): with the abs-max rider.  A RUNTIME test of the rider's pointer inside `get` puts control flow between the
+// sixteen loads sum_multi_row requests ahead of its ordered adds and serialises them: 74 us instead of 25 on 256 x 150528 fp32
+template <int DT, int ODT, bool AMAX>
 __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                int64_t pre, int64_t n, int64_t post, int64_t col0,
                                                                int flags, const int32_t* __restrict__ l0_flag,
                                                                uint32_t* __restrict__ absmax, int64_t astride,
-                                                               int64_t chan_div, uint32_t C, ActSpec act) {
+                                                               int64_t chan_div, uint32_t C, ActSpec act, int64_t mr_override) {
     const int64_t ncols = post - col0;
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= pre * ncols) return;
@@ -1352,7 +1354,7 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
     uint32_t amax = 0u;
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, base + i * post);
-        if (absmax) {
+        if constexpr (AMAX) {
             const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
@@ -1375,11 +1377,12 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
             s = sum_row_sum(n, get);
         }
     } else {
-        const int64_t mr_cols = (post >= 8) ? (post / 32) * 32 : (post / 4) * 4;
+        // (mr_override >= 0: the caller names the cascade prefix -- qs_mean_dim_split, a permuted tensor's memory view)
+        const int64_t mr_cols = mr_override >= 0 ? mr_override : ((post >= 8) ? (post / 32) * 32 : (post / 4) * 4);
         s = (col < mr_cols) ? sum_multi_row(n, get) : sum_row_sum(n, get);
     }
     store1<ODT>(out, p * post + col, s / (float)n);
-    if (absmax) atomicMax(absmax + (size_t)(uint32_t)((col / chan_div) % C) * astride, amax);
+    if constexpr (AMAX) atomicMax(absmax + (size_t)(uint32_t)((col / chan_div) % C) * astride, amax);
 }
 
 // =================================================================================================

@@ -290,6 +290,31 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
                 stage = _hip.mean_dim(mem, mem.numel() // x.shape[d], x.shape[d], 1, odt, flags, **kw)
                 stage = stage.view(tuple(mem.shape[:-1]) + (1,)).permute([order.index(i) for i in range(x.dim())]).contiguous()
                 cur, dims, first, plan = stage, dims[1:], False, None
+        if plan is not None and plan[3] == 2 and plan[2][0][1] == 1 and xs.element_size() == 2:
+            # a cascade / row-sum split whose cascade part is a PREFIX of the memory-contiguous columns behind the reduced dim (the
+            # split dim is the outermost of them): the memory-order view is a contiguous [pre, n, post] tensor that the tuned
+            # outer-reduction kernels take with that prefix named (qs_mean_dim_split: 16-byte loads, 8 columns per lane) -- a
+            # [B, T, C] activation seen as [B, C, T] and reduced over B, a transposed matrix reduced over its strided dim
+            # (2-byte dtypes only, measured: [256, 768, 196] bf16 82 -> 43 us, a transposed 4096 x 4096 bf16 matrix 477 -> 187; in float32
+            # one lane per output already reads 256 bytes per wave and row and is the faster of the two, 31 against 43 us)
+            n0, s0, kept, _, split_dim, split = plan
+            npost = sum(1 for k in kept if k[1] < s0)
+            post = 1
+            for k in kept[:npost]:
+                post *= k[0]
+            order = sorted(range(x.dim()), key=lambda i: (xs.shape[i] != 1, -xs.stride(i)))
+            mem = xs.permute(order)
+            at = order.index(d)
+            if (split_dim == npost - 1 and post >= 64 and post % 8 == 0 and mem.is_contiguous()
+                    and all(xs.shape[i] == 1 or xs.stride(i) > s0 for i in order[:at])
+                    and all(xs.shape[i] == 1 or xs.stride(i) < s0 for i in order[at + 1:])):
+                pre = mem.numel() // (n0 * post)
+                kw = {"l0_flag": l0_flag} if l0_flag is not None else {}
+                stage = _hip.mean_dim(mem, pre, n0, post, odt, flags, mr_cols=split * (post // kept[split_dim][0]), **kw)
+                shape = list(mem.shape)
+                shape[at] = 1
+                stage = stage.view(shape).permute([order.index(i) for i in range(x.dim())]).contiguous()
+                cur, dims, first, plan = stage, dims[1:], False, None
         if plan is not None and len(plan[2]) <= _hip.STRIDED_MAX_KEPT:
             stage = _hip.mean_strided(xs, plan, odt, flags, l0_flag)
             cur, dims, first = stage.view([1 if i == d else s for i, s in enumerate(x.shape)]), dims[1:], False
