@@ -5,6 +5,14 @@
 #include "qs_host.h"
 #include "qs_reduce.h"
 
+// compile-time operand preparation of the one-lane-per-output kernels (mean_prep_t): 1 |x|, 2 |max(x, 0)|, 3 x, 0 run-time flags
+static int prep_code(int flags, const int32_t* l0_flag, const ActSpec& act) {
+    if (l0_flag || (flags & QS_MEAN_L0)) return 0;
+    if (flags == QS_MEAN_ABS) return 1;
+    if (flags == (QS_MEAN_ABS | QS_MEAN_RELU) && act.kind == QS_ACT_RELU) return 2;
+    return flags == 0 ? 3 : 0;
+}
+
 // mr_cols < 0: ATen's rule for a contiguous [pre, n, post] tensor; >= 0 (post > 1): columns [0, mr_cols) of every slice in cascade
 // order, the others in row-sum order
 static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
@@ -28,7 +36,9 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
     // float32 without the abs-max rider: one lane per output (mean_generic_kernel, 4-byte loads, four times the waves) is as fast as
     // the 8-columns-per-lane kernels on the largest tensors and faster below (256 x 150528: 25 against 35 us, 1024 x 65536: 56 against
     // 100; only very short columns, n < 32, lose) -- QS_MEAN_F32_GENERIC=0 restores the vector kernels
-    if (xdt == QS_F32 && !absmax_out && n >= 32 && env_int("QS_MEAN_F32_GENERIC", 1)) vcols = 0;
+    // (only with a compile-time operand preparation: |x|, |max(x, 0)| or x -- a folded nn.ReLU6 / nn.LeakyReLU has its own modes in
+    //  the vector kernels and none here)
+    if (xdt == QS_F32 && !absmax_out && n >= 32 && prep_code(flags, l0_flag, act) != 0 && env_int("QS_MEAN_F32_GENERIC", 1)) vcols = 0;
     uint32_t* am = (uint32_t*)absmax_out;
     // rows are split over R waves per workgroup when there are too few column groups to fill the chip
     const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
@@ -63,8 +73,11 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
                 const uint32_t Cc = (uint32_t)(C > 0 ? C : 1);
                 const size_t lds = (size_t)nchunks * 8 * 64 * sizeof(float);
                 if (R == 1) {
-                    const int mode = (l0_flag || general_act) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
-                                                                     (flags == 0 && !am ? 3 : 0)));
+                    // (a folded nn.Hardtanh / nn.ReLU6 / nn.LeakyReLU with |.|: its own compile-time mode, 7 / 8 -- through the run-time
+                    //  mode 0 the statistics of such a site took 377 us where nn.ReLU's take 80, 256 x 256 x 56 x 56 bf16)
+                    const int act_mode = act.kind == QS_ACT_HARDTANH ? 7 : (act.kind == QS_ACT_LEAKY ? 8 : 0);
+                    const int mode = l0_flag ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? (general_act ? act_mode : 2) :
+                                                    (flags == 0 && !am ? 3 : 0)));
                     // few waves per CU: keep more rows in flight per wave instead (latency-, not bandwidth-bound)
                     // (2-byte inputs only: 32 fp32 rows of 8 columns do not fit the register file)
                     int depth = env_int("QS_MEAN_DEPTH", 0);
@@ -78,6 +91,8 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
                         if (mode == 3) launch(D, IC<3>{});
                         else if (mode == 1) launch(D, IC<1>{});
                         else if (mode == 2) launch(D, IC<2>{});
+                        else if (mode == 7) launch(D, IC<7>{});
+                        else if (mode == 8) launch(D, IC<8>{});
                         else launch(D, IC<0>{});
                     };
                     if constexpr (XD != QS_F32) {
@@ -90,8 +105,9 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
                 else {
                     const int64_t cd = chan_div > 0 ? chan_div : 1;
                     const bool rag = am && cd % 8 != 0;         // a lane's 8 columns may straddle two channels
-                    const int smode = (l0_flag || !am || general_act) ? 0 : (flags == QS_MEAN_ABS ? 1 :
-                                      (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 : 0));
+                    const int smode = (l0_flag || !am) ? 0 : (flags == QS_MEAN_ABS ? 1 :
+                                      (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? (act.kind == QS_ACT_HARDTANH ? 7 : (act.kind == QS_ACT_LEAKY ? 8 :
+                                                                                (general_act ? 0 : 2))) : 0));
                     auto launch = [&](auto RR, auto M, auto RG) {
                         constexpr int kR = decltype(RR)::value;
                         hipLaunchKernelGGL((mean_outer_split_kernel<XD, OD, kR, decltype(M)::value, decltype(RG)::value>), dim3(blocks),
@@ -100,8 +116,12 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
                     auto by_mode = [&](auto RR) {
                         if (smode == 1 && rag) launch(RR, IC<1>{}, std::true_type{});
                         else if (smode == 2 && rag) launch(RR, IC<2>{}, std::true_type{});
+                        else if (smode == 7 && rag) launch(RR, IC<7>{}, std::true_type{});
+                        else if (smode == 8 && rag) launch(RR, IC<8>{}, std::true_type{});
                         else if (smode == 1) launch(RR, IC<1>{}, std::false_type{});
                         else if (smode == 2) launch(RR, IC<2>{}, std::false_type{});
+                        else if (smode == 7) launch(RR, IC<7>{}, std::false_type{});
+                        else if (smode == 8) launch(RR, IC<8>{}, std::false_type{});
                         else launch(RR, IC<0>{}, std::false_type{});
                     };
                     if (R == 2) by_mode(IC<2>{});
@@ -116,12 +136,20 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
             } else if (vcols < post) {
                 const int64_t total = pre * (post - vcols);
                 const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-                if (am)
-                    hipLaunchKernelGGL((mean_generic_kernel<XD, OD, true>), grid, dim3(kBlock), 0, s, x, out, pre, n, post, vcols, flags,
-                                       l0_flag, am, as, chan_div > 0 ? chan_div : 1, (uint32_t)(C > 0 ? C : 1), act, mr_cols);
-                else
-                    hipLaunchKernelGGL((mean_generic_kernel<XD, OD, false>), grid, dim3(kBlock), 0, s, x, out, pre, n, post, vcols, flags,
-                                       l0_flag, am, as, chan_div > 0 ? chan_div : 1, (uint32_t)(C > 0 ? C : 1), act, mr_cols);
+                auto launch = [&](auto A, auto P) {
+                    hipLaunchKernelGGL((mean_generic_kernel<XD, OD, decltype(A)::value, decltype(P)::value>), grid, dim3(kBlock), 0, s, x, out,
+                                       pre, n, post, vcols, flags, l0_flag, am, as, chan_div > 0 ? chan_div : 1, (uint32_t)(C > 0 ? C : 1), act,
+                                       mr_cols);
+                };
+                const int prep = prep_code(flags, l0_flag, act);
+                auto by_prep = [&](auto A) {
+                    if (prep == 1) launch(A, IC<1>{});
+                    else if (prep == 2) launch(A, IC<2>{});
+                    else if (prep == 3) launch(A, IC<3>{});
+                    else launch(A, IC<0>{});
+                };
+                if (am) by_prep(std::true_type{});
+                else by_prep(std::false_type{});
             }
             return launch_status();
         };
@@ -152,7 +180,8 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
     flags &= 0xff;
     int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
                                            (flags == 0 ? 3 : 0)));
-    if (mode == 2 && act.kind > QS_ACT_RELU) mode = 4;     // |act(x)| of a folded activation other than nn.ReLU
+    // |act(x)| of a folded activation other than nn.ReLU: its kind as a compile-time mode (4 stays for kinds without one)
+    if (mode == 2 && act.kind > QS_ACT_RELU) mode = act.kind == QS_ACT_HARDTANH ? 5 : (act.kind == QS_ACT_LEAKY ? 6 : 4);
     if (C % 8 != 0 || mode == 0 || (mode == 3 && amax_part) || !aligned16(x)) {
         // any channel count, the L0 variant, unaligned views: one lane per element of a sample, same summation order
         const int64_t total = hw * C;
@@ -160,9 +189,16 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
         return with_dtype(xdt, [&](auto X) {
             constexpr int XD = decltype(X)::value;
             const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+            const int prep = prep_code(flags, l0_flag, act);
             auto launch = [&](auto O, auto A) {
-                hipLaunchKernelGGL((mean_cl_generic_kernel<XD, decltype(O)::value, decltype(A)::value>), grid, dim3(kBlock), 0,
-                                   (hipStream_t)stream, x, out, n, hw, C, flags, l0_flag, (uint32_t*)amax_part, act);
+                auto go = [&](auto P) {
+                    hipLaunchKernelGGL((mean_cl_generic_kernel<XD, decltype(O)::value, decltype(A)::value, decltype(P)::value>), grid,
+                                       dim3(kBlock), 0, (hipStream_t)stream, x, out, n, hw, C, flags, l0_flag, (uint32_t*)amax_part, act);
+                };
+                if (prep == 1) go(IC<1>{});
+                else if (prep == 2) go(IC<2>{});
+                else if (prep == 3) go(IC<3>{});
+                else go(IC<0>{});
             };
             if (odt == QS_F32) { if (amax_part) launch(IC<QS_F32>{}, std::true_type{}); else launch(IC<QS_F32>{}, std::false_type{}); }
             else { if (amax_part) launch(X, std::true_type{}); else launch(X, std::false_type{}); }
@@ -243,6 +279,8 @@ int qs_mean_dim_cl(const void* x, void* out, int64_t n, int64_t hw, int64_t C, i
             if (mode == 1) launch(IC<1>{});
             else if (mode == 2) launch(IC<2>{});
             else if (mode == 4) launch(IC<4>{});
+            else if (mode == 5) launch(IC<5>{});
+            else if (mode == 6) launch(IC<6>{});
             else launch(IC<3>{});
             return launch_status();
         };
@@ -295,12 +333,19 @@ int qs_mean_strided(const void* x, void* out, int64_t n, int64_t stride, int nke
     return with_dtype(xdt, [&](auto X) {
         constexpr int XD = decltype(X)::value;
         const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-        if (odt == QS_F32)
-            hipLaunchKernelGGL((mean_strided_kernel<XD, QS_F32>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, total, p, flags,
-                               l0_flag, act);
-        else
-            hipLaunchKernelGGL((mean_strided_kernel<XD, XD>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, out, total, p, flags,
-                               l0_flag, act);
+        const int prep = prep_code(flags, l0_flag, act);
+        auto launch = [&](auto O) {
+            auto go = [&](auto P) {
+                hipLaunchKernelGGL((mean_strided_kernel<XD, decltype(O)::value, decltype(P)::value>), grid, dim3(kBlock), 0,
+                                   (hipStream_t)stream, x, out, total, p, flags, l0_flag, act);
+            };
+            if (prep == 1) go(IC<1>{});
+            else if (prep == 2) go(IC<2>{});
+            else if (prep == 3) go(IC<3>{});
+            else go(IC<0>{});
+        };
+        if (odt == QS_F32) launch(IC<QS_F32>{});
+        else launch(X);
         return launch_status();
     });
 }

@@ -74,6 +74,19 @@ __device__ __forceinline__ float act_apply(float v, const ActSpec& s, int dt) {
     if (s.kind == QS_ACT_LEAKY) return (v > 0.0f) ? v : round_to_dtype(v * s.a, dt);
     return v;
 }
+// the same with the kind known at compile time: straight-line code (the bounds' rounding is loop-invariant), for the statistics
+// kernels whose batched loads a run-time switch on the kind would serialise
+template <int KIND>
+__device__ __forceinline__ float act_apply_k(float v, const ActSpec& s, int dt) {
+    if constexpr (KIND == QS_ACT_RELU) return relu_aten(v);
+    if constexpr (KIND == QS_ACT_HARDTANH) {
+        const float a = round_to_dtype(s.a, dt), b = round_to_dtype(s.b, dt);
+        const float t = (v < a) ? a : v;
+        return (t > b) ? b : t;
+    }
+    if constexpr (KIND == QS_ACT_LEAKY) return (v > 0.0f) ? v : round_to_dtype(v * s.a, dt);
+    return v;
+}
 // whether the activation's backward lets the gradient through unchanged at input v (the gate bit a forward records)
 __device__ __forceinline__ bool act_open(float v, const ActSpec& s) {
     // (ATen's CPU hardtanh_backward treats a NaN input differently in its vector body -- (x > a) & (x < b): closed -- and in its

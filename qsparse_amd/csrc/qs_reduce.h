@@ -580,6 +580,17 @@ __device__ __forceinline__ float mean_prep(float v, int flags, int l0, const Act
     return (flags & QS_MEAN_ABS) ? fabsf(v) : v;    // x.abs()           (sparse.py:87)
 }
 
+// the same with the common flag combinations fixed at compile time (PREP 1: |x|, 2: |max(x, 0)|, 3: x; 0: whatever the flags say):
+// the one-lane-per-output kernels request sixteen loads ahead of their ordered adds, and run-time tests between them serialise
+// those loads (256 x 150528 fp32 with a folded ReLU: 81 us with the run-time flags, 25 with PREP 2)
+template <int DT, int PREP>
+__device__ __forceinline__ float mean_prep_t(float v, int flags, int l0, const ActSpec& act) {
+    if constexpr (PREP == 1) return fabsf(v);
+    else if constexpr (PREP == 2) return fabsf(relu_aten(v));
+    else if constexpr (PREP == 3) return v;
+    else return mean_prep<DT>(v, flags, l0, act);
+}
+
 // multi-row order of element sequence get(0..n-1)
 template <typename F>
 __device__ __forceinline__ float sum_multi_row(int64_t n, F get) {
@@ -727,12 +738,13 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                     acc[j].add(mean_prep<DT>(v[j], flags, l0, act));
                 } else if constexpr (MODE == 6) {   // min / max ONLY, no sum, no output: the column walk of a per-channel min/max
                     mm.add(v[j]);
-                } else if constexpr (MODE >= 4) {   // abs-max ONLY (4: |x|, 5: max(x, 0)): no sum, no output -- the column walk
+                } else if constexpr (MODE == 4 || MODE == 5) {   // abs-max ONLY (4: |x|, 5: max(x, 0)): no sum, no output -- the column walk
                     const float w = (MODE == 5) ? relu_aten(v[j]) : v[j];     // as the per-channel abs-max of a big tensor
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
                     amax = k > amax ? k : amax;
-                } else {
-                    const float w = (MODE == 2) ? relu_aten(v[j]) : v[j];
+                } else {                            // MODE 1, 2 and -- a folded nn.Hardtanh / nn.ReLU6 (7), nn.LeakyReLU (8) -- |act(x)|
+                    const float w = (MODE == 2) ? relu_aten(v[j]) : (MODE == 7) ? act_apply_k<QS_ACT_HARDTANH>(v[j], act, DT)
+                                  : (MODE == 8) ? act_apply_k<QS_ACT_LEAKY>(v[j], act, DT) : v[j];
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
                     amax = k > amax ? k : amax;
                     acc[j].add(__uint_as_float(k));
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                         for (int u = 0; u < 16; ++u) consume(r[c * 16 + u]);
                         i += 16;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if constexpr (MODE < 4) acc[j].carry(i, lp, lmask);
+                        for (int j = 0; j < 8; ++j) if constexpr (MODE < 4 || MODE >= 7) acc[j].carry(i, lp, lmask);
                     }
                 }
             }
@@ -777,11 +789,11 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
             }
             i += step;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if constexpr (MODE < 4) acc[j].carry(i, lp, lmask);
+            for (int j = 0; j < 8; ++j) if constexpr (MODE < 4 || MODE >= 7) acc[j].carry(i, lp, lmask);
         }
         for (; i < n; ++i) consume(load8_raw<DT, false>(x, g_base + i * row_groups));
 
-        if constexpr (MODE < 4) {
+        if constexpr (MODE < 4 || MODE >= 7) {
             float m[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] = acc[j].total() / fn;   // .div_(n) in fp32, then one rounding to ODT
@@ -837,7 +849,9 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
 template <int MODE>
 __device__ __forceinline__ float mean_cl_prep(float v, uint32_t& am, const ActSpec& act, int dt) {
     if constexpr (MODE == 3) return v;
-    const float w = (MODE == 4) ? act_apply(v, act, dt) : ((MODE == 2) ? relu_aten(v) : v);
+    // (5 / 6: the kind fixed at compile time -- nn.Hardtanh / nn.ReLU6, nn.LeakyReLU; 4 is left for kinds to come)
+    const float w = (MODE == 4) ? act_apply(v, act, dt) : (MODE == 5) ? act_apply_k<QS_ACT_HARDTANH>(v, act, dt)
+                  : (MODE == 6) ? act_apply_k<QS_ACT_LEAKY>(v, act, dt) : ((MODE == 2) ? relu_aten(v) : v);
     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
     am = k > am ? k : am;
     return __uint_as_float(k);
@@ -1095,7 +1109,7 @@ __global__ __launch_bounds__(64) void mean_cl_tail_kernel(const void* __restrict
 // rest in row-sum order (checked against ATen's CPU result for C = 3 ... 100, tests/test_gpu_parity.py).  Serves
 // channels_last activations whose C is not a multiple of 8 and the L0 variant (sparse.py:85-86), which used to be
 // copied to NCHW first -- and were then summed in NCHW order, i.e. not in the order the reference's CPU path uses.
-template <int DT, int ODT, bool AMAX>
+template <int DT, int ODT, bool AMAX, int PREP>
 __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                   int64_t n, int64_t hw, int64_t C, int flags,
                                                                   const int32_t* __restrict__ l0_flag,
@@ -1109,11 +1123,11 @@ __global__ __launch_bounds__(kBlock) void mean_cl_generic_kernel(const void* __r
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, i * sample + t);
         if constexpr (AMAX) {      // (compile time: see mean_generic_kernel)
-            const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
+            const float av = (PREP == 2) ? relu_aten(v) : (PREP == 1 || PREP == 3) ? v : ((flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v);
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }
-        return mean_prep<DT>(v, flags, l0, act);
+        return mean_prep_t<DT, PREP>(v, flags, l0, act);
     };
     const float s = (pos < (hw / 4) * 4) ? sum_multi_row(n, get) : sum_row_sum(n, get);
     const int64_t o = c * hw + pos;                       // the result is NCHW-contiguous, as ATen's is
@@ -1158,7 +1172,7 @@ struct StridedPlan {
     int nkept, order, split_dim;
 };
 
-template <int DT, int ODT>
+template <int DT, int ODT, int PREP>
 __global__ __launch_bounds__(kBlock) void mean_strided_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t total,
                                                                StridedPlan p, int flags, const int32_t* __restrict__ l0_flag,
                                                                ActSpec act) {
@@ -1174,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) void mean_strided_kernel(const void* __rest
         rest = q;
     }
     const int64_t n = p.n, st = p.stride;
-    auto get = [&](int64_t i) { return mean_prep<DT>(load1<DT>(x, in0 + i * st), flags, l0, act); };
+    auto get = [&](int64_t i) { return mean_prep_t<DT, PREP>(load1<DT>(x, in0 + i * st), flags, l0, act); };
     float s;
     if (p.order == 0) {
         const int64_t nv = n / 8;
@@ -1240,10 +1254,11 @@ __global__ __launch_bounds__(64 * R) void mean_outer_split_kernel(const void* __
     auto consume = [&](const Raw8<DT>& r, auto add) {
         float v[8];
         unpack8<DT>(r, v);
-        if constexpr (MODE == 1 || MODE == 2) {
+        if constexpr (MODE == 1 || MODE == 2 || MODE == 7 || MODE == 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float w = (MODE == 2) ? relu_aten(v[k]) : v[k];
+                const float w = (MODE == 2) ? relu_aten(v[k]) : (MODE == 7) ? act_apply_k<QS_ACT_HARDTANH>(v[k], act, DT)
+                              : (MODE == 8) ? act_apply_k<QS_ACT_LEAKY>(v[k], act, DT) : v[k];
                 const uint32_t key = __float_as_uint(w) & 0x7fffffffu;
                 if (!RAGGED || k < first_col_next) amax0 = key > amax0 ? key : amax0;
                 else amax1 = key > amax1 ? key : amax1;
@@ -1339,7 +1354,7 @@ __global__ __launch_bounds__(64) void mean_inner_wave_kernel(const void* __restr
 // ---- generic stage: one thread per output element, either order -------------------------------------
 // AMAX (compile time): with the abs-max rider.  A RUNTIME test of the rider's pointer inside `get` puts control flow between the
 // sixteen loads sum_multi_row requests ahead of its ordered adds and serialises them: 74 us instead of 25 on 256 x 150528 fp32
-template <int DT, int ODT, bool AMAX>
+template <int DT, int ODT, bool AMAX, int PREP>
 __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                                int64_t pre, int64_t n, int64_t post, int64_t col0,
                                                                int flags, const int32_t* __restrict__ l0_flag,
@@ -1355,11 +1370,11 @@ __global__ __launch_bounds__(kBlock) void mean_generic_kernel(const void* __rest
     auto get = [&](int64_t i) {
         const float v = load1<DT>(x, base + i * post);
         if constexpr (AMAX) {
-            const float av = (flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v;
+            const float av = (PREP == 2) ? relu_aten(v) : (PREP == 1 || PREP == 3) ? v : ((flags & QS_MEAN_RELU) ? act_apply(v, act, DT) : v);
             const uint32_t k = __float_as_uint(av) & 0x7fffffffu;
             amax = k > amax ? k : amax;
         }
-        return mean_prep<DT>(v, flags, l0, act);
+        return mean_prep_t<DT, PREP>(v, flags, l0, act);
     };
     float s;
     if (post == 1) {
