@@ -45,6 +45,18 @@ def test_argument_validation_without_a_gpu():
     assert lib.qs_quant_scaler_fwd(20, 32, None, None, 1, 0.1, None, 1, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 0, None, None) == -3
     assert lib.qs_kth_value(16, 10, 10, 32, None, 0, None) == -2          # k out of range
     assert lib.qs_pq_select(16, None, 0, 70000, 0, 0, 0, 0, 32, None, 1, 0, 0, 4, None, None, None, None, None, None, None, 0, None, 1, None, None) == -2
+    # the stage entry points of ABI v22 / v23: a plan that names no order, more kept dims than the kernel takes, the vectorised inner
+    # order on a strided dim, a split coordinate outside the kept dims, a cascade prefix longer than the row
+    import ctypes
+    kept = (ctypes.c_int64 * 3)(8, 1, 1)
+    base = ctypes.addressof(kept)
+    assert lib.qs_mean_strided(16, 32, 8, 4, 1, base, base + 8, base + 16, 3, -1, 0, 0, 0, 0, None, None) == -2
+    assert lib.qs_mean_strided(16, 32, 8, 4, 7, base, base + 8, base + 16, 1, -1, 0, 0, 0, 0, None, None) == -2
+    assert lib.qs_mean_strided(16, 32, 8, 4, 1, base, base + 8, base + 16, 0, -1, 0, 0, 0, 0, None, None) == -2
+    assert lib.qs_mean_strided(16, 32, 8, 4, 1, base, base + 8, base + 16, 2, 1, 4, 0, 0, 0, None, None) == -2
+    assert lib.qs_mean_strided(16, 32, 8, 4, 1, base, base + 8, base + 16, 1, -1, 0, 0, 1, 0, None, None) == -1       # bf16 result of an fp32 input
+    assert lib.qs_mean_dim_split(16, 32, 1, 8, 64, 65, 0, 0, 0, None, None) == -2
+    assert lib.qs_mean_dim_split(16, 32, 1, 8, 1, 0, 0, 0, 0, None, None) == -2
 
 
 def test_product_never_imports_the_oracle_or_the_reference():
