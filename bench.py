@@ -494,6 +494,19 @@ def exchange_live_config(arch, device, steps=None):
     out["pq_over_plain"] = round(live / out["plain_ddp_ms"], 4)
     sites = sum(1 for m in model.modules() if isinstance(m, qs.sparse.PruneLayer))
     out["collectives_per_step"] = f"{sites} record all-gathers (2C floats each) + all-reduces of the quantize-only sites"
+    # the prototype without a host collective for the pair sites: records published into peer-mapped mailboxes (one rank here: its
+    # own), two launches per site instead of the all-gather (include/qsparse_hip.h, "peer-mapped mailboxes"; off by default)
+    try:
+        qs.set_qsparse_options(sync_statistics="mailbox")
+        for _ in range(4):
+            step()
+        out["pq_ddp_mailbox_ms"] = round(_timed_loop(step, steps), 3)
+        out["mailbox_over_no_exchange"] = round(out["pq_ddp_mailbox_ms"] / out["pq_ddp_no_exchange_ms"], 4)
+        torch.cuda.synchronize()
+        qdist.close_mailboxes()
+    except Exception as e:      # noqa: BLE001 -- a prototype must not cost the record
+        out["mailbox_error"] = f"{type(e).__name__}: {e}"[:200]
+    qs.set_qsparse_options(sync_statistics="always")
     torch.cuda.synchronize()
     dist.destroy_process_group()
     return out

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 23
+#define QS_ABI_VERSION 24
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -600,6 +600,30 @@ int qs_multi_mask_refresh(const qs_multi_row* rows_dev, int n, int hist_blocks, 
 int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* const* step, const int64_t* numel,
                      const int32_t* C, const int64_t* inner, const float* lo_mul, const float* hi_mul, int step_is_decimal,
                      const uint8_t* const* mask, const int32_t* mask_C, const int64_t* mask_inner, qs_stream_t stream);
+
+/* ---- data-parallel statistics exchange through peer-mapped mailboxes (prototype, ABI v24) -----------------------------------
+ * The collective form of the exchange (qs_stats_pack / the record written by the last statistics launch -> all-gather ->
+ * qs_pq_select / qs_site_fwd with `gathered`) costs a host-bound network ~40 us of host time per site and step.  The mailbox form
+ * replaces the collective by two launches.  Every rank allocates one mailbox per site (qs_mailbox_bytes / qs_mailbox_alloc:
+ * fine-grained device memory, zeroed), exports it (qs_mailbox_export: a 64-byte hipIpcMemHandle_t the caller ships to the peers by
+ * whatever means it has) and maps its peers' (qs_mailbox_open).  Per step, after the statistics launches have written this rank's
+ * n-float record: qs_mailbox_publish stores the record into slot `rank` of EVERY mailbox in `boxes` (host array of `world` device
+ * pointers, this rank's own included; one-sided stores over xGMI), fences system-wide and raises flag `rank` there to `step`;
+ * qs_mailbox_wait spins -- at most max_spins polls per rank, then *status = 1 + the missing rank, never a hang -- until every flag
+ * of the local mailbox shows `step`, and returns in *records the [world][n] float records of this step (a device pointer into the
+ * mailbox: the `gathered` argument of qs_pq_select / qs_site_fwd, combined in rank order there as after the all-gather).
+ * `step` counts from 1 and alternates between the mailbox's two halves; no rank can be more than one step ahead of the slowest
+ * (its next publish is ordered behind its own select), so a half is never written while it is read.  qs_mailbox_alloc / _free /
+ * _open / _close are set-up calls: they allocate, map and synchronise like the hip calls they wrap. */
+size_t qs_mailbox_bytes(int world, int64_t n);
+int qs_mailbox_alloc(size_t bytes, void** ptr);
+int qs_mailbox_free(void* ptr);
+int qs_mailbox_export(void* ptr, void* handle64);
+int qs_mailbox_open(const void* handle64, void** ptr);
+int qs_mailbox_close(void* ptr);
+int qs_mailbox_publish(const float* rec, int64_t n, void* const* boxes, int world, int rank, uint32_t step, qs_stream_t stream);
+int qs_mailbox_wait(void* box, int world, int64_t n, uint32_t step, int32_t* status, uint32_t max_spins, const float** records,
+                    qs_stream_t stream);
 
 #ifdef __cplusplus
 }

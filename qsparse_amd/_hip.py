@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 23          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 24          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -60,6 +60,14 @@ SIGNATURES = {
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
     "qs_mean_cl_w": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_mean_dim_split": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "qs_mailbox_bytes": (c_size_t, [_I, _L]),
+    "qs_mailbox_alloc": (c_int, [c_size_t, _P]),
+    "qs_mailbox_free": (c_int, [_P]),
+    "qs_mailbox_export": (c_int, [_P, _P]),
+    "qs_mailbox_open": (c_int, [_P, _P]),
+    "qs_mailbox_close": (c_int, [_P]),
+    "qs_mailbox_publish": (c_int, [_P, _L, _P, _I, _I, ctypes.c_uint32, _P]),
+    "qs_mailbox_wait": (c_int, [_P, _I, _L, ctypes.c_uint32, _P, ctypes.c_uint32, _P, _P]),
     "qs_mean_strided": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),

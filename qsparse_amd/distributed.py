@@ -30,7 +30,7 @@ def stats_world_size() -> int:
 
 def exchange_active(world: Optional[int] = None) -> bool:
     world = world or stats_world_size()
-    return world > 1 or (get_option("sync_statistics") == "always" and dist.is_available() and dist.is_initialized())
+    return world > 1 or (get_option("sync_statistics") in ("always", "mailbox") and dist.is_available() and dist.is_initialized())
 
 
 def allreduce_mean(t: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
@@ -80,6 +80,116 @@ def all_gather_records(gathered: torch.Tensor, record: torch.Tensor):
             work.wait()
             return
     dist.all_gather_into_tensor(gathered, record)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The mailbox form of the composite site's exchange (a prototype: `set_qsparse_options(sync_statistics="mailbox")`, the
+# collective stays the default).  include/qsparse_hip.h, "peer-mapped mailboxes", has the protocol; this is its host side: one
+# mailbox per site and rank, the 64-byte IPC handles shipped once through the process group's object collective, then two
+# launches per step and no host collective at all.  Validated with two processes sharing one GPU (tests/test_distributed.py);
+# on a multi-GPU node the peers' stores travel over xGMI into fine-grained memory, which this container cannot exercise.
+# ----------------------------------------------------------------------------------------------------------------------
+class _RawView:
+    """device memory behind a raw pointer as a tensor (the CUDA array interface torch.as_tensor understands)"""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class Mailbox:
+    MAX_SPINS = 1 << 24        # ~seconds of polling before a missing peer is reported instead of waited for
+
+    def __init__(self, n: int, device):
+        import ctypes
+
+        from qsparse_amd import _hip
+        self.lib, self.n, self.world, self.rank = _hip.load(), n, dist.get_world_size(), dist.get_rank()
+        self.step = 0
+        nbytes = self.lib.qs_mailbox_bytes(self.world, n)
+        if nbytes == 0:
+            raise RuntimeError(f"mailbox exchange: world size {self.world} is not supported")
+        local = ctypes.c_void_p()
+        _hip._check(self.lib.qs_mailbox_alloc(nbytes, ctypes.byref(local)), "qs_mailbox_alloc")
+        self.local = local.value
+        handle = ctypes.create_string_buffer(64)
+        _hip._check(self.lib.qs_mailbox_export(self.local, handle), "qs_mailbox_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw))         # once per site
+        self.opened = []
+        boxes = (ctypes.c_void_p * self.world)()
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                boxes[r] = self.local
+                continue
+            peer = ctypes.c_void_p()
+            _hip._check(self.lib.qs_mailbox_open(ctypes.create_string_buffer(h, 64), ctypes.byref(peer)), "qs_mailbox_open")
+            boxes[r] = peer.value
+            self.opened.append(peer.value)
+        self.boxes = boxes
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.views = [torch.as_tensor(_RawView(self.local + 4 * (64 + half * self.world * n), self.world * n), device=device)
+                      for half in (0, 1)]
+        dist.barrier()          # every mailbox is mapped before anybody publishes into one
+
+    def exchange(self, rec: torch.Tensor) -> torch.Tensor:
+        """publish this rank's record, wait for everybody's: the [world * n] records of this step, in rank order (a view of the
+        local mailbox, valid until the step after next)"""
+        import ctypes
+
+        from qsparse_amd import _hip
+        self.step += 1
+        stream = _hip._stream(rec)
+        _hip._check(self.lib.qs_mailbox_publish(rec.data_ptr(), self.n, self.boxes, self.world, self.rank, self.step, stream),
+                    "qs_mailbox_publish")
+        out = ctypes.c_void_p()
+        _hip._check(self.lib.qs_mailbox_wait(self.local, self.world, self.n, self.step, self.status.data_ptr(), self.MAX_SPINS,
+                                             ctypes.byref(out), stream), "qs_mailbox_wait")
+        if self.step % 256 == 0:
+            self.check()
+        return self.views[self.step & 1]
+
+    def check(self):
+        missing = int(self.status.item())
+        if missing:
+            raise RuntimeError(f"mailbox exchange: rank {missing - 1} did not publish its statistics in time")
+
+    def close(self):
+        for p in self.opened:
+            self.lib.qs_mailbox_close(p)
+        self.opened = []
+        if self.local:
+            self.lib.qs_mailbox_free(self.local)
+            self.local = None
+
+
+def mailbox_enabled() -> bool:
+    return get_option("sync_statistics") == "mailbox" and dist.is_available() and dist.is_initialized()
+
+
+_mailboxes = None     # owner (the site's QuantizeLayer) -> Mailbox; weak keys: a mailbox goes with its site, never into a copy or pickle
+
+
+def mailbox_exchange(owner, rec: torch.Tensor) -> torch.Tensor:
+    """`owner`: the module the mailbox belongs to; it is created at the site's first exchange -- on every rank at the same one"""
+    global _mailboxes
+    if _mailboxes is None:
+        import weakref
+        _mailboxes = weakref.WeakKeyDictionary()
+    box = _mailboxes.get(owner)
+    if box is None or box.n != rec.numel() or box.status.device != rec.device:
+        if box is not None:
+            box.close()
+        box = _mailboxes[owner] = Mailbox(rec.numel(), rec.device)
+    return box.exchange(rec)
+
+
+def close_mailboxes():
+    """unmap and free every mailbox (before destroy_process_group; every rank)"""
+    global _mailboxes
+    for box in list((_mailboxes or {}).values()):
+        box.check()
+        box.close()
+    _mailboxes = None
 
 
 def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int,

@@ -666,7 +666,10 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                     # this rank's record), the all-gather, and -- in `_SiteStep` below -- select + apply on the gathered records
                     rec, site_gathered = _exchange_buffers(site, C, world, h.device)
                     _hip.site_stats(site.ref, h, _hip.SITE_PRE_RELU if pre_relu else 0, rec)
-                    qdist.all_gather_records(site_gathered, rec)
+                    if qdist.mailbox_enabled():      # (prototype: peers' records arrive in a mapped mailbox, no host collective)
+                        site_gathered = qdist.mailbox_exchange(q, rec)
+                    else:
+                        qdist.all_gather_records(site_gathered, rec)
         elif update_scale and not prune_on:
             # pruning not started yet: the scale follows max|h| of the whole tensor (quantize.py:329-348)
             am = qdist.allreduce_max_(_hip.absmax(hd, -1, pre_relu=pre_relu), world)

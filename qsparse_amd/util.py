@@ -26,7 +26,9 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
                 autocast_image: Optional[bool] = None, saturate: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
-    cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py);
+    cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py; ``"always"``: also in a
+    one-rank group; ``"mailbox"``: the prototype that moves the pair sites' records through peer-mapped mailboxes instead of
+    an all-gather, DESIGN section 7);
     ``graph_safe`` (extension, default False) makes GPU layers feed their running-mean counters to the kernels
     from device memory so that a training step can be captured into a hipGraph and replayed (see graphs.py);
     ``preserve_dtype`` (extension, default False) makes the Scaler/Decimal quantizers return the input's dtype

@@ -427,3 +427,72 @@ def test_rccl_one_rank_graph_capture_with_live_exchange_and_collective_counter_w
     assert res["seen_after_resync"] is True                      # the documented route always works
     assert res["seen_without_resync"] == res["collective_bumped_version"], res
     assert res["n_updates_after"] >= 10, res
+
+
+def _mailbox_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share cuda:0; gloo only ships the 64-byte handles
+    import torch.nn as nn
+    import qsparse_amd as qs
+    from qsparse_amd import distributed as qdist
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    res = {}
+    for mode in ("collective", "mailbox"):
+        qs.set_qsparse_options(sync_statistics="mailbox" if mode == "mailbox" else None)
+        for layout in ("nchw", "channels_last"):
+            torch.manual_seed(0)
+            pair = fuse_prune_quantize_pairs(nn.Sequential(
+                nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2)),
+                qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train())
+            ys = []
+            for step in range(9):
+                g = torch.Generator().manual_seed(100 + step)
+                full = (torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16()
+                shard = (full[rank * 4:(rank + 1) * 4].float() * (1.0 + 0.5 * rank)).bfloat16().cuda()
+                if layout == "channels_last":
+                    shard = shard.contiguous(memory_format=torch.channels_last)
+                shard.requires_grad_(True)
+                y = pair(shard)
+                y.backward(torch.ones_like(y))
+                ys.append(y.detach().float().cpu().numpy().copy())
+            torch.cuda.synchronize()
+            steps = sum(b.step for b in (qdist._mailboxes or {}).values())
+            res[(mode, layout)] = (tuple(t.detach().cpu().numpy().copy() for t in (pair[0][1].mask, pair[0][1].callback.magnitude, pair[1].weight)),
+                                   ys, steps)
+            if mode == "mailbox":
+                qdist.close_mailboxes()          # (checks the status word: nobody was waited for in vain)
+    qs.set_qsparse_options(sync_statistics=None)
+    from qsparse_amd import util
+    util._options_["sync_statistics"] = None
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_mailbox_exchange_equals_the_collective_two_ranks_one_gpu():
+    """the prototype of the exchange without a host collective (include/qsparse_hip.h, "peer-mapped mailboxes";
+    `set_qsparse_options(sync_statistics="mailbox")`): two processes on one GPU map each other's mailbox through hipIpc, publish
+    their statistics records into it and combine them in rank order -- masks, magnitudes, scales and outputs are those of the
+    all-gather route, on both ranks, step by step (rank-order combine, bit-identical on every rank)"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mailbox_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(out.get(timeout=300) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for layout in ("nchw", "channels_last"):
+        for rank in (0, 1):
+            (state_c, ys_c, steps_c), (state_m, ys_m, steps_m) = res[rank][("collective", layout)], res[rank][("mailbox", layout)]
+            assert steps_c == 0 and steps_m >= 6, (steps_c, steps_m)          # the mailbox served the live steps of the second run only
+            for a, b in zip(state_c, state_m):
+                assert np.array_equal(a, b), (layout, rank)
+            for s, (a, b) in enumerate(zip(ys_c, ys_m)):
+                assert np.array_equal(a, b), (layout, rank, s)
+        for a, b in zip(res[0][("mailbox", layout)][0], res[1][("mailbox", layout)][0]):
+            assert np.array_equal(a, b), layout                              # ranks agree
