@@ -57,6 +57,16 @@ def test_argument_validation_without_a_gpu():
     assert lib.qs_mean_strided(16, 32, 8, 4, 1, base, base + 8, base + 16, 1, -1, 0, 0, 1, 0, None, None) == -1       # bf16 result of an fp32 input
     assert lib.qs_mean_dim_split(16, 32, 1, 8, 64, 65, 0, 0, 0, None, None) == -2
     assert lib.qs_mean_dim_split(16, 32, 1, 8, 1, 0, 0, 0, 0, None, None) == -2
+    # the mailbox exchange (ABI v24): sizes, a world the flag header cannot hold, missing pointers, step 0 (steps count from 1)
+    assert lib.qs_mailbox_bytes(2, 32) == (64 + 2 * 2 * 32) * 4 and lib.qs_mailbox_bytes(33, 32) == 0 and lib.qs_mailbox_bytes(2, 0) == 0
+    assert lib.qs_mailbox_alloc(0, None) == -2 and lib.qs_mailbox_export(None, None) == -2 and lib.qs_mailbox_open(None, None) == -2
+    boxes = (ctypes.c_void_p * 2)(16, None)
+    assert lib.qs_mailbox_publish(16, 32, boxes, 2, 0, 1, None) == -2          # a peer that was never mapped
+    boxes[1] = 32
+    assert lib.qs_mailbox_publish(16, 32, boxes, 2, 2, 1, None) == -2          # rank outside the world
+    assert lib.qs_mailbox_publish(16, 32, boxes, 2, 0, 0, None) == -2
+    assert lib.qs_mailbox_wait(16, 2, 32, 1, None, 1000, None, None) == -2      # no status word
+    assert lib.qs_mailbox_wait(16, 2, 32, 1, 48, 0, None, None) == -2           # a wait that may not poll at all
 
 
 def test_product_never_imports_the_oracle_or_the_reference():
