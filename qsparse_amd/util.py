@@ -187,6 +187,38 @@ def aten_reduce_plan(shape: Sequence[int], strides: Sequence[int], d: int):
 _dense_any_order = _hip.dense_any_order
 
 
+def split_view_plan(shape: Sequence[int], strides: Sequence[int], d: int, plan):
+    """For a cascade / row-sum plan of `aten_reduce_plan` (order 2) whose cascade part is a PREFIX of the memory-contiguous columns
+    behind the reduced dim -- the split dim is the outermost of the kept dims with a stride below the reduced one's: (order, pre, n,
+    post, mr_cols), i.e. the permutation that makes the tensor a contiguous [pre, n, post] one in memory order and the number of
+    leading columns of every slice that ATen sums in cascade order (qs_mean_dim_split); None when the plan has no such form.
+    Pinned against Tensor.mean on the CPU in tests/test_aten_contract.py."""
+    n0, s0, kept, kind, split_dim, split = plan
+    if kind != 2 or not kept or kept[0][1] != 1:
+        return None
+    npost = sum(1 for k in kept if k[1] < s0)
+    if split_dim != npost - 1:
+        return None
+    post = 1
+    for k in kept[:npost]:
+        post *= k[0]
+    order = sorted(range(len(shape)), key=lambda i: (shape[i] != 1, -strides[i]))
+    at = order.index(d)
+    expect = 1
+    for i in reversed(order):           # the memory-order view must be contiguous ...
+        if shape[i] != 1:
+            if strides[i] != expect:
+                return None
+            expect *= shape[i]
+    # ... with every dim in front of the reduced one above its stride and every dim behind it below
+    if any(shape[i] != 1 and strides[i] <= s0 for i in order[:at]) or any(shape[i] != 1 and strides[i] >= s0 for i in order[at + 1:]):
+        return None
+    numel = 1
+    for v in shape:
+        numel *= v
+    return order, numel // (n0 * post), n0, post, split * (post // kept[split_dim][0])
+
+
 def _record_for(record, slices: int):
     """the exchange-record buffer if the fused last-two-dims launch can fill it (one slice per channel)"""
     if record is None or record["buf"].numel() != 2 * slices:
@@ -299,22 +331,14 @@ def _staged_mean_hip(x: torch.Tensor, dims: List[int], take_abs: bool, l0_flag=N
             # [B, T, C] activation seen as [B, C, T] and reduced over B, a transposed matrix reduced over its strided dim
             # (2-byte dtypes only, measured: [256, 768, 196] bf16 82 -> 43 us, a transposed 4096 x 4096 bf16 matrix 477 -> 187; in float32
             # one lane per output already reads 256 bytes per wave and row and is the faster of the two, 31 against 43 us)
-            n0, s0, kept, _, split_dim, split = plan
-            npost = sum(1 for k in kept if k[1] < s0)
-            post = 1
-            for k in kept[:npost]:
-                post *= k[0]
-            order = sorted(range(x.dim()), key=lambda i: (xs.shape[i] != 1, -xs.stride(i)))
-            mem = xs.permute(order)
-            at = order.index(d)
-            if (split_dim == npost - 1 and post >= 64 and post % 8 == 0 and mem.is_contiguous()
-                    and all(xs.shape[i] == 1 or xs.stride(i) > s0 for i in order[:at])
-                    and all(xs.shape[i] == 1 or xs.stride(i) < s0 for i in order[at + 1:])):
-                pre = mem.numel() // (n0 * post)
+            view = split_view_plan(list(xs.shape), list(xs.stride()), d, plan)
+            if view is not None and view[3] >= 64 and view[3] % 8 == 0:
+                order, pre, n0, post, mr_cols = view
+                mem = xs.permute(order)
                 kw = {"l0_flag": l0_flag} if l0_flag is not None else {}
-                stage = _hip.mean_dim(mem, pre, n0, post, odt, flags, mr_cols=split * (post // kept[split_dim][0]), **kw)
+                stage = _hip.mean_dim(mem, pre, n0, post, odt, flags, mr_cols=mr_cols, **kw)
                 shape = list(mem.shape)
-                shape[at] = 1
+                shape[order.index(d)] = 1
                 stage = stage.view(shape).permute([order.index(i) for i in range(x.dim())]).contiguous()
                 cur, dims, first, plan = stage, dims[1:], False, None
         if plan is not None and len(plan[2]) <= _hip.STRIDED_MAX_KEPT:

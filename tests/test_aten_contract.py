@@ -142,7 +142,7 @@ def test_aten_reduce_plan_names_the_order_aten_takes_for_any_dense_layout():
     import itertools
     import random
 
-    from qsparse_amd.util import _dense_any_order, aten_reduce_plan
+    from qsparse_amd.util import _dense_any_order, aten_reduce_plan, split_view_plan
 
     def execute(x, d):
         n, s0, kept, order, split_dim, split = aten_reduce_plan(list(x.shape), list(x.stride()), d)
@@ -160,7 +160,7 @@ def test_aten_reduce_plan_names_the_order_aten_takes_for_any_dense_layout():
     torch.set_num_threads(1)
     try:
         rng, g = random.Random(0), torch.Generator().manual_seed(0)
-        seen, differs = set(), 0
+        seen, differs, views = set(), 0, 0
         for it in range(260):
             nd = rng.choice([1, 2, 3, 4, 4, 5])
             shape = [rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 33, 40]) for _ in range(nd)]
@@ -179,8 +179,28 @@ def test_aten_reduce_plan_names_the_order_aten_takes_for_any_dense_layout():
             got, order = execute(x, d)
             assert want.is_contiguous() and torch.equal(want, got), (shape, x.stride(), d, dtype)
             seen.add(order)
+            # the same plan as a contiguous [pre, n, post] tensor in memory order with a cascade PREFIX (qs_mean_dim_split), where it
+            # has that form: executed here as the stage kernels execute it
+            view = split_view_plan(list(x.shape), list(x.stride()), d, aten_reduce_plan(list(x.shape), list(x.stride()), d))
+            if view is not None:
+                perm, pre, n, post, mr_cols = view
+                mem = x.permute(perm)
+                assert mem.is_contiguous() and mem.numel() == pre * n * post and 0 <= mr_cols <= post
+                v = mem.float().reshape(pre, n, post).numpy()
+                res = np.empty((pre, post), np.float32)
+                for p in range(pre):
+                    if mr_cols:
+                        res[p, :mr_cols] = multi_row(v[p][:, :mr_cols]) / np.float32(n)
+                    if mr_cols < post:
+                        res[p, mr_cols:] = row_sum(v[p][:, mr_cols:]) / np.float32(n)
+                shape_mem = list(mem.shape)
+                shape_mem[perm.index(d)] = 1
+                back = torch.from_numpy(res).view(shape_mem).permute([perm.index(i) for i in range(nd)]).contiguous().to(dtype)
+                assert torch.equal(want, back), (shape, x.stride(), d, dtype, view)
+                views += 1
             differs += int(not torch.equal(want, x.contiguous().mean(d, keepdim=True)))
         assert seen == {0, 1, 2} and differs >= 20       # (the contiguous copy's order is a different one for many of them)
+        assert views >= 15, views
         assert not _dense_any_order(torch.zeros(4, 6)[:, ::2]) and not _dense_any_order(torch.zeros(4, 1).expand(4, 3))
     finally:
         torch.set_num_threads(threads)
