@@ -2,7 +2,7 @@
 """Headline benchmark: Gelem/s of the prune(0.75, dims={1}) -> quantize(4-bit, tensor-wise) training
 step (forward + backward, live statistics every step) on a 256x256x56x56 bf16 activation per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -98,7 +98,7 @@ def _cpu_steps(batch, reps, threads):
     for i in range(reps + 2):   # 2 warm-up steps bring both operators live (t > 0)
         t0 = time.perf_counter()
         y = qsim.step(ps.step(x, True), True)
-        gx = ps.grad(qsim.grad(gout.clone(), torch.bfloat16), True)
+        gx = ps.grad(qsim.grad(gout, torch.bfloat16), True)      # (O.ste_bwd works on its own copy of gout)
         dt = time.perf_counter() - t0
         if i >= 2:
             best = min(best, dt)
@@ -115,9 +115,11 @@ def cpu_baseline(batch=None, reps=3, threads=None):
     batch = batch or int(os.environ.get("QS_CPU_BATCH", "0")) or SHAPE[0]
     multi = _cpu_steps(batch, reps, cores)
     single = _cpu_steps(min(32, batch), 2, 1)
+    host = os.cpu_count() or 1
+    allcores = multi if host == cores else _cpu_steps(batch, 2, host)      # BASELINE.md section 3's all-cores figure
     what = "the headline tensor itself" if batch == SHAPE[0] else f"a {batch}-sample slice of the headline tensor"
     return {"value": round(multi, 4), "unit": "Gelem/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": "port",
-            "value_1thread": round(single, 4),
+            "value_1thread": round(single, 4), "value_allcores": round(allcores, 4),
             "sample": f"{batch}x256x56x56 bf16 ({what}), oracle PruneSim->QuantizeSim train fwd+bwd, min of {reps}, {cores} thr",
             "sample_detail": f"oracle/qs_oracle.py PruneSim->QuantizeSim fwd+bwd (train mode, live stats) on {what} "
                              f"({batch}x256x56x56 bf16), min of {reps} after 2 warm-up steps ({cores} threads of {os.cpu_count()} "
@@ -738,6 +740,41 @@ def config5(device, world, rank, steps=5):
 
 
 # ---------------------------------------------------------------------------------------------------
+def self_launch_command(n, argv, port=None):
+    """the command `python bench.py --gpus N ...` re-issues itself as when no launcher set WORLD_SIZE: one rank per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), a free port unless given"""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """run the N ranks as a child process group and relay rank 0's ONE JSON line; returns the launcher's exit code.
+    The launcher's and the ranks' other output (torchrun banners, warnings) goes to stderr, so stdout stays one line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    child = subprocess.Popen(self_launch_command(n, argv), stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    try:
+        for raw in child.stdout:
+            line = raw.decode(errors="replace")
+            if line.lstrip().startswith("{"):
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+        return child.wait()
+    except BaseException:
+        child.terminate()          # the exact child this process started (torchrun forwards the signal to its ranks)
+        child.wait()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -760,6 +797,10 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(threads=args.cpu_baseline_only)))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  Nothing above touched the
+        # GPU (importing torch does not), and nothing below does in THIS process: the ranks are children.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if args.exchange_live:
         sys.stdout.flush()
         real_stdout = os.dup(1)
@@ -805,7 +846,9 @@ def main():
         if force_exchange:
             import qsparse_amd as qs
             qs.set_qsparse_options(sync_statistics="always")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: pass --gpus {world}, or run "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher (it starts its own ranks)")
 
     import qsparse_amd as qs
     from qsparse_amd import _hip

@@ -77,6 +77,21 @@ def test_two_ranks_through_torch_distributed_run():
     assert c5["operator_state_identical_across_ranks"] is True
 
 
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the docstring advertises it: no torchrun, WORLD_SIZE unset -- bench.py starts its own ranks
+    (before anything touches the GPU in the parent) and relays rank 0's single line and the exit code"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", QS_BENCH_NO_DDP_CONFIG="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    _check(rec, 2, 8)
+    assert rec["config"]["ranks_seen"] == 2
+
+
 def test_config5_watchdog_keeps_the_headline_marks_it_degraded_and_fails_the_run():
     """a rank that hangs in config 5's collectives must not cost the headline record, and must not look like success:
     the line carries a top-level `degraded: true` and every rank exits non-zero (here the deadline is simply too short)"""
