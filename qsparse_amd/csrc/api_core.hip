@@ -185,7 +185,15 @@ int qs_stats_combine(const float* gathered, int world, int64_t C, float* stage_o
 // ---- one activation site per call: the fine-grained entry points in sequence (no arithmetic of its own) --------------
 static int site_plan_ok(const qs_site_plan* p) {
     if (!p || p->N < 1 || p->C < 2 || p->H < 1 || p->W < 1) return 0;
-    return p->layout == 0 || p->layout == 1 || (p->layout == 2 && p->H == 1 && p->W == 1);
+    return p->layout == 0 || p->layout == 1 || (p->layout == 2 && p->H == 1 && p->W == 1) || (p->layout == 3 && p->H >= 2 && p->W == 1);
+}
+
+// layout 3, token-major [N][T][C] with the mask on the last dim (T = plan->H): squeeze_tensor_to_shape's two stages (util.py:92-99),
+// mean over N of the [N][T*C] matrix, then mean over T of the [T][C] stage, each rounded to xdt; channel of column j is j % C
+static int site_token_means(const qs_site_plan* p, const void* x, int mflags, float* absmax, int64_t absmax_stride, qs_stream_t stream) {
+    int st = qs_mean_dim(x, p->stage, 1, p->N, p->H * p->C, p->xdt, p->xdt, mflags, nullptr, absmax, absmax_stride, 1, p->C, stream);
+    if (st) return st;
+    return qs_mean_dim(p->stage, p->stage_mean, 1, p->H, p->C, p->xdt, p->xdt, 0, nullptr, nullptr, 1, 1, p->C, stream);
 }
 
 // the statistics launches of a live site step; `record` (nullable): the rank's exchange record, written by the last of them
@@ -196,6 +204,11 @@ static int site_statistics(const qs_site_plan* p, const void* x, int pre_relu, f
     if (p->layout == 2) {      // [N][C]: one stage, the per-channel abs-max rides in it; the record is a launch of its own
         int st = qs_mean_dim(x, p->stage_mean, 1, p->N, p->C, p->xdt, p->xdt, mflags, nullptr, p->chan_absmax, p->absmax_stride, 1,
                              p->C, stream);
+        if (st || !record) return st;
+        return qs_stats_pack(p->stage_mean, p->xdt, p->chan_absmax, p->absmax_stride, p->C, record, stream);
+    }
+    if (p->layout == 3) {
+        int st = site_token_means(p, x, mflags, p->chan_absmax, p->absmax_stride, stream);
         if (st || !record) return st;
         return qs_stats_pack(p->stage_mean, p->xdt, p->chan_absmax, p->absmax_stride, p->C, record, stream);
     }
@@ -243,6 +256,8 @@ static int site_prune_only_fwd(const qs_site_plan* p, const void* x, void* y, ui
         int st;
         if (p->layout == 2) {
             st = qs_mean_dim(x, p->stage_mean, 1, p->N, p->C, p->xdt, p->xdt, mflags, nullptr, nullptr, 1, 1, p->C, stream);
+        } else if (p->layout == 3) {
+            st = site_token_means(p, x, mflags, nullptr, 1, stream);
         } else {
             st = p->layout == 0 ? qs_mean_dim(x, p->stage, 1, p->N, p->C * hw, p->xdt, p->xdt, mflags, nullptr, nullptr, 1, hw, p->C, stream)
                                 : qs_mean_dim_cl(x, p->stage, p->N, hw, p->C, p->xdt, p->xdt, mflags, nullptr, nullptr, stream);

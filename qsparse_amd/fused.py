@@ -33,13 +33,24 @@ from qsparse_amd.util import _options_epoch, _reduction_plan, _staged_mean_hip, 
 from qsparse_amd import distributed as qdist
 
 
+def _chan_dim(p: PruneLayer, h: torch.Tensor):
+    """the channel dim of a site the pair kernels serve -- 1 for (N, C, ...) activations with `dimensions={1}`, the LAST dim of a 3-d
+    token-major (B, T, C) activation with `dimensions={2}` -- or None (reference sparse.py:231-239 builds the mask for any set)"""
+    if p.dimensions == {1}:
+        return 1
+    if h.dim() == 3 and p.dimensions == {2}:
+        return 2
+    return None
+
+
 def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
     if not h.is_cuda or h.dim() < 2 or h.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return False
     cb, qc = p.callback, q.callback
     if type(cb) is not MagnitudePruningCallback or cb.use_gradient or not cb.running_average or cb.l0:
         return False
-    if p.dimensions != {1} or h.shape[1] > 65536 or h.shape[1] < 2:
+    cd = _chan_dim(p, h)
+    if cd is None or h.shape[cd] > 65536 or h.shape[cd] < 2:
         return False
     if type(qc) not in (ScalerQuantizer, DecimalQuantizer) or qc.group_num > 0 or q.channelwise != -1:
         return False
@@ -104,9 +115,11 @@ class _FusedApply(torch.autograd.Function):
     """y = Q(relu?(x) * mask) forward, gx = gate * clamp(g) * mask backward, each one pass over the tensor."""
 
     @staticmethod
-    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False, saturate=None, elision=None):
+    def forward(ctx, h, mask_c, scale, kind, bits, notch, quant_on, pre_relu=False, saturate=None, elision=None, cd=1):
         # elision: the elision mask the select wrote from THIS input's statistics (see _hip.elide_mode), or None
+        # cd: the dim of h the channel mask runs along (`_chan_dim`)
         ctx.kind, ctx.bits, ctx.notch, ctx.quant_on, ctx.x_dtype = kind, bits, notch, quant_on, h.dtype
+        ctx.cd = cd
         ctx.pre_relu = pre_relu
         ctx.has_mask = mask_c is not None
         ctx.gate_meta = None
@@ -116,14 +129,14 @@ class _FusedApply(torch.autograd.Function):
         empty = h.new_empty(0)
         if not quant_on:
             ctx.save_for_backward(mask_c if mask_c is not None else empty, scale, h if pre_relu else empty)
-            return _hip.mask_apply(h, mask_c.view([1, -1] + [1] * (h.dim() - 2)))
+            return _hip.mask_apply(h, mask_c.view([-1 if i == cd else 1 for i in range(h.dim())]))
         out_dtype = _out_dtype(h)
         # what the backward clamps with is what the reference's Function saved: the scale PARAMETER itself for a
         # ScalerQuantizer (quantize.py:108 -- a later statistics update is seen by an earlier forward's backward), the
         # decimal computed at THIS forward for a DecimalQuantizer (a fresh tensor, quantize.py:312-325 -> :41)
         param = scale if kind == "scaler" else _hip.decimal_from_scale(scale)
         res = _hip.quant_fwd(kind, h, param, -1, torch.float32, chan_mask=mask_c if elision is None else elision,
-                             mask_channel_index=1, out_dtype=out_dtype, elision_mask=elision is not None,
+                             mask_channel_index=cd, out_dtype=out_dtype, elision_mask=elision is not None,
                              pre_relu=pre_relu, want_gate=want_gate, saturate=saturate,
                              xback=_hip.owned_relu_cell() if (want_gate and h.data_ptr() % 16 == 0) else None)
         # the bitmap travels through save_for_backward like any saved activation (released with the graph, visible to
@@ -141,17 +154,17 @@ class _FusedApply(torch.autograd.Function):
         mask_c, step, x = ctx.saved_tensors
         mask_c = mask_c if ctx.has_mask else None
         if not ctx.quant_on:
-            return (_hip.mask_apply(g, mask_c.view([1, -1] + [1] * (g.dim() - 2))),) + (None,) * 9
+            return (_hip.mask_apply(g, mask_c.view([-1 if i == ctx.cd else 1 for i in range(g.dim())])),) + (None,) * 10
         limit = 2.0 ** (ctx.bits - 1)
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(x, *ctx.gate_meta) if ctx.gate_meta is not None else None
             gx = _hip.ste_relu_bwd(g, None if gate is not None else x, step, ctx.kind == "decimal", -limit + ctx.notch,
-                                   limit - 1 + ctx.notch, mask_c, gate=gate, act=ctx.pre_relu)
-            return (gx,) + (None,) * 9
+                                   limit - 1 + ctx.notch, mask_c, mask_channel_index=ctx.cd, gate=gate, act=ctx.pre_relu)
+            return (gx,) + (None,) * 10
         out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
         gx = _hip.ste_bwd(g, step, ctx.kind == "decimal", -1, -limit + ctx.notch, limit - 1 + ctx.notch, False,
-                          out_dtype, chan_mask=mask_c, mask_channel_index=1)
-        return (gx,) + (None,) * 9
+                          out_dtype, chan_mask=mask_c, mask_channel_index=ctx.cd)
+        return (gx,) + (None,) * 10
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -162,7 +175,7 @@ class _FusedApply(torch.autograd.Function):
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
     __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused",
-                 "xbuf", "widen_nomask", "decimal")
+                 "xbuf", "widen_nomask", "decimal", "cd", "interleaved")
 
     def __init__(self):
         self.key = None
@@ -178,19 +191,25 @@ class _SitePlan:
 
 def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     """the cached plan of this site for inputs like `h`, or None when the site is not one the composite call covers
-    (4-d NCHW / channels_last or 2-d [N, C] activation with a batch of at least two, tensor-wise Scaler / Decimal quantizer,
-    state on h's device)"""
+    (4-d NCHW / channels_last, 2-d [N, C] or contiguous 3-d token-major [B, T, C] activation -- mask on the last dim -- with a
+    batch of at least two, tensor-wise Scaler / Decimal quantizer, state on h's device)"""
     cb, qc = p.callback, q.callback
-    if h.dim() not in (2, 4) or h.shape[0] < 2 or type(qc) not in (ScalerQuantizer, DecimalQuantizer) or not hasattr(cb, "magnitude"):
+    token = h.dim() == 3 and p.dimensions == {2}
+    if (h.dim() not in (2, 4) and not token) or h.shape[0] < 2 or type(qc) not in (ScalerQuantizer, DecimalQuantizer) or not hasattr(cb, "magnitude"):
         return None
     flat = h.dim() == 2
-    N, C, H, W = (h.shape[0], h.shape[1], 1, 1) if flat else h.shape
-    if not flat and (H < 2 or W < 2):
+    if token:                            # qs_site_plan layout 3: N = B, H = T, W = 1 (two staged means: over B, then over T)
+        N, C, H, W = h.shape[0], h.shape[2], h.shape[1], 1
+        if H < 2 or not h.is_contiguous():
+            return None                  # (T == 1 has one stage less: the fine-grained route)
+    else:
+        N, C, H, W = (h.shape[0], h.shape[1], 1, 1) if flat else h.shape
+    if not flat and not token and (H < 2 or W < 2):
         return None                      # (an extent of 1 is not reduced -- and turns its neighbour into an inner reduction)
     cl = not h.is_contiguous()
     if cl and (flat or not h.is_contiguous(memory_format=torch.channels_last)):
         return None
-    if h.data_ptr() % 16 or (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES:
+    if h.data_ptr() % 16 or (not token and (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES):
         return None
     if cl and C % 8:
         return None                      # (any channel count works through the fine-grained path's generic kernel)
@@ -203,7 +222,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     t_q_dev = qc.device_t(h.device) if graph_safe else None
     out_dtype = _out_dtype(h)
     sat = qc.code_range(q.bits)
-    key = (N, C, H, W, flat, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat, act, type(qc)) + tuple(t.data_ptr() for t in state) + \
+    key = (N, C, H, W, flat, token, h.dtype, cl, h.device, out_dtype, graph_safe, q.bits, sat, act, type(qc)) + tuple(t.data_ptr() for t in state) + \
         ((t_q_dev.data_ptr(),) if t_q_dev is not None else ())
     plan = q.__dict__.get("_qs_site_plan")
     if plan is not None and plan.key == key:
@@ -211,20 +230,22 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     plan = _SitePlan()
     plan.key, plan.out_dtype, plan.channels_last, plan.xdt = key, out_dtype, cl, h.dtype
     plan.decimal = type(qc) is DecimalQuantizer
+    plan.cd = 2 if token else 1          # the dim of h the mask runs along
+    plan.interleaved = cl or token       # channels are the fastest-running index in memory: eliding pruned ones saves no traffic
     acc = _absmax_accumulator(q, C, h.device)
     stage = None if flat else torch.empty(C * H * W, dtype=h.dtype, device=h.device)
     part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
     # a frozen-mask step (QS_SITE_SCALE_ONLY): dense [C] abs-max accumulator + the reduction's scratch for this geometry
     dense = _absmax_accumulator_dense(q, C, h.device)
-    so, si = (N * H * W, 1) if (cl or flat) else (N, H * W)
+    so, si = (N * H * W, 1) if (cl or flat or token) else (N, H * W)
     ws_bytes = _hip.reduce_workspace_bytes(1, so, C, si)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device) if ws_bytes else None
     elide = torch.empty(C, dtype=torch.uint8, device=h.device)     # the select's elision mask (see _hip.elide_mode)
     plan.keep = (acc, stage, part, stage_mean, t_q_dev, dense, ws, elide) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
-    c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
+    c.layout, c.xdt, c.ydt, c.bits = (3 if token else 2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
     c.magnitude, c.mask, c.scale = cb.magnitude.data_ptr(), p.mask.data_ptr(), q.weight.data_ptr()
     c.chan_absmax, c.absmax_stride = acc.data_ptr(), _hip.amax_stride(acc)
     c.stage, c.amax_part, c.stage_mean = (None if flat else stage.data_ptr()), (part.data_ptr() if cl else None), stage_mean.data_ptr()
@@ -236,7 +257,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     c.elide_mask = elide.data_ptr()
     c.absmax_dense, c.reduce_ws, c.reduce_ws_bytes = dense.data_ptr(), (ws.data_ptr() if ws is not None else None), ws_bytes
     # whether the forward kernel of this geometry can write the autocast image itself (else it is a cast of y)
-    outer, inner = (N * H * W, 1) if cl else (N, H * W)
+    outer, inner = (N * H * W, 1) if (cl or token) else (N, H * W)
     plan.image_fused = bool(_hip.load().qs_quant_image_ok(outer, C, inner, 0, 1, int(p.mask.data_ptr() % 8 == 0), _hip.dt(h)))
     # (the same kernels write an owned in-place ReLU's result back into x; without the mask the launch is tensor-wise)
     plan.widen_nomask = bool(_hip.load().qs_quant_image_ok(1, 1, outer * C * inner, 0, 0, 1, _hip.dt(h)))
@@ -518,7 +539,7 @@ class _SiteStep(torch.autograd.Function):
         if want_gate:
             _hip.note_gate(bits_t)
         img = torch.empty_like(h, dtype=image_dtype) if fused_image else None
-        if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.channels_last, bits_t is not None, bool(flags & _hip.SITE_LIVE)):
+        if (flags & _hip.SITE_ELIDE) and not _hip._elide_fwd(plan.interleaved, bits_t is not None, bool(flags & _hip.SITE_LIVE)):
             flags &= ~_hip.SITE_ELIDE          # elision only where it saves traffic and is exact (see _hip.elide_mode)
         # a DecimalQuantizer's power-of-two step of THIS call (the backward clamps with it; two forwards may precede a backward)
         dec = torch.empty(1, dtype=torch.float32, device=h.device) if plan.decimal else None
@@ -579,10 +600,11 @@ class _SiteStep(torch.autograd.Function):
         scale = ctx.dec if is_dec else scale.detach()
         if pre_relu:
             gate = _hip.ReluGate.from_saved(third, ctx.x_shape, ctx.x_dtype, plan.channels_last) if ctx.has_gate else None
-            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, is_dec, lo_mul, hi_mul, mask, gate=gate, act=ctx.act)
+            gx = _hip.ste_relu_bwd(g, None if gate is not None else third, scale, is_dec, lo_mul, hi_mul, mask, mask_channel_index=plan.cd,
+                                   gate=gate, act=ctx.act)
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
-            gx = _hip.ste_bwd(g, scale, is_dec, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=1)
+            gx = _hip.ste_bwd(g, scale, is_dec, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=plan.cd)
         return (gx,) + (None,) * (n_in - 1)
 
 
@@ -591,7 +613,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
     folded nn.ReLU, or the handle of another folded activation (``_fold_handle``; the caller guarantees that the quantizer is
     active this step, so the activation is applied inside the kernels)."""
     cb, qc = p.callback, q.callback
-    C = h.shape[1]
+    cd = _chan_dim(p, h) or 1            # the dim the channel mask runs along (the caller checked `_eligible`)
+    C = h.shape[cd]
 
     # ---- PruneLayer.forward bookkeeping (reference sparse.py:228-273) ----
     if not p.initted:
@@ -692,7 +715,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 # the per-channel abs-max rides along in the first statistics stage when that stage reduces a dim
                 # in front of the channel dim (the batch); with a batch of one there is no such stage and the
                 # abs-max is a pass of its own
-                rides = update_scale and bool(dims) and dims[0] < 1
+                rides = update_scale and bool(dims) and dims[0] < cd
                 if rides and not hd.is_contiguous() and not (hd.dim() == 4 and hd.is_contiguous(memory_format=torch.channels_last)):
                     # channels_last_3d, and every other dense layout (a transposed / permuted activation): the in-place first
                     # stage -- ATen's order for that layout, qs_mean_dim_cl / qs_mean_strided -- carries no abs-max
@@ -700,14 +723,14 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                 if rides:
                     chan_absmax = _absmax_accumulator(q, C, h.device)   # zero on entry, re-zeroed by the select
                 elif update_scale:
-                    chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
+                    chan_absmax = _hip.absmax(hd, cd, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
                 if qdist.exchange_active(world) and h.is_cuda:   # the last statistics launch writes the exchange record
                     record = {"buf": torch.empty(2 * C, dtype=torch.float32, device=h.device), "filled": False}
                 stage = _staged_mean_hip(hd, dims, take_abs=True, absmax_out=chan_absmax if rides else None,
-                                         absmax_channel_dim=1, pre_relu=pre_relu, record=record,
+                                         absmax_channel_dim=cd, pre_relu=pre_relu, record=record,
                                          record_absmax=chan_absmax).contiguous().view(-1)
             elif update_scale:
-                chan_absmax = _hip.absmax(hd, 1, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
+                chan_absmax = _hip.absmax(hd, cd, pre_relu=pre_relu, accumulate_into=_absmax_accumulator_dense(q, C, h.device))
             gathered = None
             if qdist.exchange_active(world) and (stage is not None or chan_absmax is not None):
                 if h.is_cuda:     # one collective; the select kernel combines the ranks' records in rank order
@@ -780,7 +803,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
                              1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits),
-                             elision if (prune_on and quant_on) else None)
+                             elision if (prune_on and quant_on) else None, cd)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -978,7 +1001,7 @@ class _FastPair:
         f.state = (cb.magnitude, p.mask, q.weight, p._n_updates, q._n_updates, cb.t)
         f.ptrs = tuple(t.data_ptr() for t in f.state)
         f.plan, f.pre_relu, f.fold = plan, handle, fold
-        f.max_schedule, f.C = max(p.schedules), x.shape[1]
+        f.max_schedule, f.C = max(p.schedules), plan.c.C
         f.graph_safe, f.notch = bool(get_option("graph_safe")), (1 if qc.flip_axis else 0)
         f.k_of = {}
         return f

@@ -65,7 +65,7 @@ class _MaskApply(torch.autograd.Function):
 # from one ctypes call with a cached plan instead of three or four -- the same launches, the same arithmetic.
 # ----------------------------------------------------------------------------------------------------------------------
 class _PrunePlan:
-    __slots__ = ("key", "c", "ref", "keep", "channels_last")
+    __slots__ = ("key", "c", "ref", "keep", "channels_last", "cd")
 
     def __init__(self):
         self.key = None
@@ -79,35 +79,43 @@ class _PrunePlan:
 
 def _prune_plan(cb, x: torch.Tensor, mask: torch.Tensor, step_counter, act: int):
     """the cached `qs_site_plan` of a prune-only site for inputs like `x`, or None when the composite does not cover it (then the
-    fine-grained launches run): 4-d NCHW / channels_last or 2-d activation with a batch of at least two, a channel mask, state on
-    x's device"""
-    if x.dim() not in (2, 4) or x.shape[0] < 2 or step_counter is None or not hasattr(cb, "magnitude"):
+    fine-grained launches run): 4-d NCHW / channels_last, 2-d, or contiguous 3-d token-major [B, T, C] activation (mask on the last
+    dim: qs_site_plan layout 3) with a batch of at least two, a channel mask, state on x's device"""
+    if x.dim() not in (2, 3, 4) or x.shape[0] < 2 or step_counter is None or not hasattr(cb, "magnitude"):
         return None
-    flat = x.dim() == 2
-    N, C, H, W = (x.shape[0], x.shape[1], 1, 1) if flat else x.shape
-    if mask.numel() != C or _channel_dim(mask) != 1 or (not flat and (H < 2 or W < 2)):
+    flat, token = x.dim() == 2, x.dim() == 3
+    cd = 2 if token else 1
+    if token:
+        N, C, H, W = x.shape[0], x.shape[2], x.shape[1], 1
+    else:
+        N, C, H, W = (x.shape[0], x.shape[1], 1, 1) if flat else x.shape
+    if mask.numel() != C or _channel_dim(mask) != cd or (not flat and not token and (H < 2 or W < 2)):
+        return None
+    if token and (H < 2 or not x.is_contiguous()):
         return None
     cl = not x.is_contiguous()
     if cl and (flat or not x.is_contiguous(memory_format=torch.channels_last) or C % 8):
         return None
-    if x.data_ptr() % 16 or (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+    if x.data_ptr() % 16 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return None
+    if not token and (H * W + W) * 4 > _hip.LAST2_MAX_TILE_BYTES:
         return None
     state = (cb.magnitude, mask, step_counter, cb.t)
     if any((not t.is_cuda) or t.device != x.device for t in state) or cb.magnitude.numel() != C:
         return None
     graph_safe = bool(get_option("graph_safe"))
-    key = (N, C, H, W, flat, x.dtype, cl, x.device, graph_safe, act) + tuple(t.data_ptr() for t in state)
+    key = (N, C, H, W, flat, token, x.dtype, cl, x.device, graph_safe, act) + tuple(t.data_ptr() for t in state)
     plan = cb.__dict__.get("_qs_prune_plan")
     if plan is not None and plan.key == key:
         return plan
     plan = _PrunePlan()
-    plan.key, plan.channels_last = key, cl
+    plan.key, plan.channels_last, plan.cd = key, cl, cd
     stage = None if flat else torch.empty(C * H * W, dtype=x.dtype, device=x.device)
     stage_mean = torch.empty(C, dtype=x.dtype, device=x.device)
     plan.keep = (stage, stage_mean) + state
     c = _hip.SitePlanStruct()
     c.N, c.C, c.H, c.W = N, C, H, W
-    c.layout, c.xdt, c.ydt, c.bits = (2 if flat else int(cl)), _hip.dt(x), _hip.dt(x), 8
+    c.layout, c.xdt, c.ydt, c.bits = (3 if token else 2 if flat else int(cl)), _hip.dt(x), _hip.dt(x), 8
     c.magnitude, c.mask = cb.magnitude.data_ptr(), mask.data_ptr()
     c.stage, c.stage_mean = (None if flat else stage.data_ptr()), stage_mean.data_ptr()
     c.absmax_stride = 1
@@ -149,7 +157,7 @@ class _PruneSiteStep(torch.autograd.Function):
         if ctx.has_gate:
             inf = float("inf")
             gate = _hip.ReluGate.from_saved(bits, shape, dtype, plan.channels_last)
-            return (_hip.ste_relu_bwd(g, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=1, gate=gate, act=plan.c.act),
+            return (_hip.ste_relu_bwd(g, None, 1.0, False, -inf, inf, mask.reshape(-1), mask_channel_index=plan.cd, gate=gate, act=plan.c.act),
                     None, None, None, None, None)
         return _hip.mask_apply(g, mask), None, None, None, None, None
 

@@ -65,11 +65,64 @@ def make_quantizer(rng):
     return kind, cb
 
 
+def build_token_major(rng):
+    """activation sites whose channel dim is not dim 1: token-major (B, T, C) and 5-d activations, masks over {last}, {1, 2}, {1},
+    ... (the reference builds the mask for any dim set, sparse.py:231-239, and averages dim by dim, util.py:92-99), tensor-wise or
+    last-dim channel-wise quantizers (quantize.py:100-107; batch of one for Scaler / Decimal, :341-343) -- as lone operators, as the
+    pair, and behind an activation module as `convert` builds them.  (B, T, C) + dimensions={2} is the composite's layout 3."""
+    dtype = rng.choice([torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
+    rank = rng.choice([3, 3, 3, 5])
+    if rank == 3:
+        shape = (rng.choice([1, 2, 4, 8, 17, 64]), rng.choice([1, 2, 5, 16, 49, 197]), rng.choice([2, 6, 16, 33, 64, 96, 256]))
+        dims = rng.choice([{2}, {2}, {2}, {1, 2}, {1}, {0, 2}, {0, 1, 2}])
+    else:
+        shape = (rng.choice([1, 2, 4]), rng.choice([2, 6, 16]), rng.choice([1, 3, 4]), rng.choice([2, 5]), rng.choice([3, 8]))
+        dims = rng.choice([{1}, {4}, {1, 2}, {0, 1}])
+    last = rank - 1
+    bits = rng.choice([2, 4, 8])
+    timeout = rng.choice([0, 1, 2])
+    kind, qcb = make_quantizer(rng)
+    start, interval, rep = rng.choice([0, 1, 2]), rng.choice([1, 2]), rng.choice([1, 2])
+    sparsity = rng.choice([0.3, 0.5, 0.75])
+    site = rng.choice(["pair", "pair", "act_p", "act_q"])
+    act = rng.choice(["relu", "relu", "relu6", "leaky", "identity", "identity"])
+    inplace = act != "identity" and rng.random() < 0.3
+    if act == "leaky" and dtype == torch.float16:
+        dtype = torch.bfloat16               # (ATen's own fp16 leaky_relu_backward differs between its CPU and GPU kernels)
+    cw = rng.choice([-1, -1, -1, last])
+    if site == "pair":
+        cw = -1 if rng.random() < 0.8 else cw
+    if cw >= 0 and kind != "adaptive":
+        shape = (1,) + shape[1:]             # batched channel-wise Scaler / Decimal raises in the reference
+    policy = rng.choice(["default", "default", "no_avg", "refresh", "l0"])
+    cbkw = {"default": {}, "no_avg": dict(running_average=False), "refresh": dict(mask_refresh_interval=2, stop_mask_refresh=4),
+            "l0": dict(l0=True)}[policy]
+    desc = dict(what="tok", dtype=str(dtype)[6:], shape=shape, dimensions=sorted(dims), bits=bits, timeout=timeout, quantizer=kind,
+                start=start, interval=interval, rep=rep, sparsity=sparsity, site=site, act=act, inplace=inplace, channelwise=cw,
+                policy=policy)
+    make_act = {"relu": lambda: nn.ReLU(inplace=inplace), "relu6": lambda: nn.ReLU6(inplace=inplace),
+                "leaky": lambda: nn.LeakyReLU(0.1, inplace=inplace), "identity": lambda: nn.Identity()}[act]
+
+    def factory():
+        net = nn.Sequential(make_act())
+        types = [type(net[0])]
+        if site in ("pair", "act_p"):
+            net = qs.convert(net, qs.prune(sparsity=sparsity, dimensions=dims, start=start, interval=interval, repetition=rep,
+                                           callback=qs.MagnitudePruningCallback(**cbkw)), activation_layers=types, log=False)
+        if site in ("pair", "act_q"):
+            net = qs.convert(net, qs.quantize(bits=bits, channelwise=cw, timeout=timeout, callback=copy.deepcopy(qcb)),
+                             activation_layers=types, log=False)
+        return net
+    return desc, factory, shape, dtype
+
+
 def build(rng):
     """returns (description, module factory, input shape, dtype)"""
-    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear", "site", "site", "site", "net", "net"])
+    what = rng.choice(["act_q", "act_q", "act_p", "act_p", "act_pq", "conv", "linear", "site", "site", "site", "net", "net", "tok", "tok"])
     if FORCE_WHAT:
         what = FORCE_WHAT
+    if what == "tok":
+        return build_token_major(rng)
     dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.bfloat16, torch.float16])
     if rng.random() < 0.08 and what in ("act_q", "act_p", "act_pq"):
         # a dtype the kernels are not written for: the GPU side evaluates the package's ATen expression on the device (_hip.on_hip)
@@ -490,7 +543,7 @@ def run(factory, shape, dtype, device, seed, steps, eval_from, weight_mode=False
 
 def one_case(rng, idx, dry=False):
     desc, factory, shape, dtype = build(rng)
-    steps = rng.choice([3, 5, 6]) if desc["what"] != "site" else rng.choice([6, 8, 10])
+    steps = rng.choice([3, 5, 6]) if desc["what"] not in ("site", "tok") else rng.choice([6, 8, 10])
     eval_from = rng.choice([steps, steps - 1])
     channels_last = rng.random() < 0.4
     # (statistics of channels_last inputs follow ATen's own order for that layout whichever dim leads the reduced ones -- N: the
@@ -499,7 +552,7 @@ def one_case(rng, idx, dry=False):
     if desc["what"] in ("act_p", "act_pq"):
         channels_last = channels_last and len(shape) == 4
     permute = None
-    if desc["what"] in ("site", "act_q", "act_p", "act_pq") and not channels_last and len(shape) >= 2 and rng.random() < 0.25:
+    if desc["what"] in ("site", "tok", "act_q", "act_p", "act_pq") and not channels_last and len(shape) >= 2 and rng.random() < 0.25:
         # any other dense layout: statistics in ATen's order for it (qs_mean_strided, ABI v22), results back in the input's layout
         permute = list(range(len(shape)))
         while permute == sorted(permute):
@@ -509,7 +562,7 @@ def one_case(rng, idx, dry=False):
     nonfinite = None
     if desc["what"] in ("conv", "linear", "net") and rng.random() < 0.25:
         nonfinite = (rng.choice([float("nan"), float("inf"), float("-inf")]), rng.choice([steps - 2, steps - 1]))
-    if desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.3:
+    if desc["what"] in ("site", "tok", "act_q", "act_p", "act_pq") and rng.random() < 0.3:
         # (ATen's CPU hardtanh_backward gates a NaN input differently in its vector body and its scalar tail -- qs_common.h,
         # act_open -- so the clamping activations get infinities only)
         values = [float("inf"), float("-inf")] + ([] if desc.get("act") in ("relu6", "hardtanh", "hardtanh_odd") else [float("nan")] * 2)
@@ -524,7 +577,7 @@ def one_case(rng, idx, dry=False):
         if nonfinite is not None:
             nonfinite = (nonfinite[0], rng.choice([steps - 3, steps - 2]))
     # (float64: the ATen-on-device route keeps its running means on the host, as the CPU path does -- not capturable, refused)
-    graph = GRAPH and desc["what"] in ("site", "act_q", "act_p", "act_pq") and rng.random() < 0.7 and desc["dtype"] != "float64"
+    graph = GRAPH and desc["what"] in ("site", "tok", "act_q", "act_p", "act_pq") and rng.random() < 0.7 and desc["dtype"] != "float64"
     if graph:
         routes["graph_safe"] = True
     if EXCHANGE and rng.random() < 0.6:     # the statistics exchange of a data-parallel run, live on a one-rank group (same values)
@@ -541,7 +594,7 @@ def one_case(rng, idx, dry=False):
             if device == "cuda":
                 qs.set_qsparse_options(**routes)
             results[device] = run(factory, shape, dtype, device, 4000 + idx, steps, eval_from, desc['what'] in ('conv', 'linear'),
-                                  channels_last, batcher, twin, desc['what'] == 'site', nonfinite, graph, permute)
+                                  channels_last, batcher, twin, desc['what'] in ('site', 'tok'), nonfinite, graph, permute)
         except Exception as e:      # noqa: BLE001 -- both paths must fail alike
             results[device] = ("raised", type(e).__name__)
         finally:

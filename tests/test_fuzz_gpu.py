@@ -59,6 +59,17 @@ def test_converted_weight_networks_cpu_path_against_hip_path():
     assert fz.ENGAGED[0] >= 30, fz.ENGAGED[0]     # (Adaptive quantizers and timeout=0 layers keep the inline path)
 
 
+def test_token_major_and_rank5_sites_cpu_path_against_hip_path():
+    """sites whose channel dim is not dim 1 -- (B, T, C) with masks over {last} / {1, 2} / {1} / ..., 5-d activations, last-dim
+    channel-wise quantizers -- as `convert` builds them (reference sparse.py:231-239, util.py:92-99, quantize.py:100-107); the
+    (B, T, C) + {last} ones take the composite's layout 3"""
+    fz = _load("fuzz_cpu_gpu")
+    fz.FORCE_WHAT = "tok"
+    rng = random.Random(2029)
+    bad = [r for r in (fz.one_case(rng, i) for i in range(150)) if r not in ("ok", None)]
+    assert not bad, bad[:3]
+
+
 def test_functional_api_cpu_path_against_hip_path():
     fz = _load("fuzz_cpu_gpu")
     rng = random.Random(2026)
