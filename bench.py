@@ -537,20 +537,27 @@ def host_overhead(device, steps=300):
     import qsparse_amd as qs
     from qsparse_amd.fused import fuse_prune_quantize_pairs
 
-    def pair(act):
+    def pair(act, dim=1):
         return fuse_prune_quantize_pairs(nn.Sequential(
-            nn.Sequential(act, qs.prune(sparsity=0.75, dimensions={1}, start=0, interval=1, repetition=1)),
+            nn.Sequential(act, qs.prune(sparsity=0.75, dimensions={dim}, start=0, interval=1, repetition=1)),
             qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train())
 
-    sites = {"plain_relu": nn.ReLU().to(device),
-             "relu_prune_quantize_pair": pair(nn.ReLU()),
-             "prune_quantize_pair": pair(nn.Identity()),
-             "relu_quantize": fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train()),
-             "quantize_alone": qs.quantize(bits=8, channelwise=-1, timeout=1).to(device).train()}
-    x = torch.randn(8, 64, 16, 16, device=device, dtype=torch.bfloat16, requires_grad=True)
-    gs = {torch.float32: torch.randn(8, 64, 16, 16, device=device), torch.bfloat16: torch.randn(8, 64, 16, 16, device=device).bfloat16()}
-    out = {"shape": [8, 64, 16, 16], "steps": steps, "unit": "us of host time per site step (forward + backward)"}
-    for name, site in sites.items():
+    shape4, shape2, shape3 = (8, 64, 16, 16), (2048, 64), (8, 256, 64)       # the same element count, 64 channels
+    sites = {"plain_relu": (nn.ReLU().to(device), shape4),
+             "relu_prune_quantize_pair": (pair(nn.ReLU()), shape4),
+             "prune_quantize_pair": (pair(nn.Identity()), shape4),
+             "relu_quantize": (fuse_prune_quantize_pairs(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train()), shape4),
+             "quantize_alone": (qs.quantize(bits=8, channelwise=-1, timeout=1).to(device).train(), shape4),
+             # a 2-d [N, C] site (behind an nn.Linear) and a token-major [B, T, C] one with the mask on the last dim (qs_site_plan
+             # layouts 2 and 3): the composite serves both
+             "relu_prune_quantize_pair_2d": (pair(nn.ReLU()), shape2),
+             "relu_prune_quantize_pair_token_major": (pair(nn.ReLU(), 2), shape3)}
+    out = {"shape": list(shape4), "shape_2d": list(shape2), "shape_token_major": list(shape3), "steps": steps,
+           "unit": "us of host time per site step (forward + backward)"}
+    for name, (site, shape) in sites.items():
+        x = torch.randn(shape, device=device, dtype=torch.bfloat16, requires_grad=True)
+        gs = {torch.float32: torch.randn(shape, device=device), torch.bfloat16: torch.randn(shape, device=device).bfloat16()}
+
         def step(_=0):
             y = site(x)
             torch.autograd.grad(y, x, gs[y.dtype])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 24
+#define QS_ABI_VERSION 25
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -164,6 +164,44 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
                           float lo_mul, float hi_mul, const uint8_t* chan_mask,
                           int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, int act,
                           const void* g2, int g2dt, qs_stream_t stream);
+
+/* (ABI v25) The same entry point with its operands in a size-prefixed descriptor (see "Descriptor entry points" at the top of
+ * this header): fields are only ever appended, a caller compiled against an older header sets a smaller struct_size and the
+ * fields it does not know read as 0 / NULL.  The fields up to g2dt are the positional arguments above, one for one.
+ *   g3      (v25; nullable; dtype g2dt; needs g2, gdt == xdt == QS_F32) a THIRD gradient of the same geometry, added between g
+ *           and g2: gx = gate * clamp((g + f32(g3)) + f32(g2)) * mask, each term optional from the left.  Autograd accumulates
+ *           the shares of a tensor's consumers in REVERSE order of the consumers' creation: with float32 consumers created
+ *           last, the second 2-byte consumer (g3) before them and the first 2-byte consumer (g2) first of all, this is the
+ *           reference's grouping bit for bit -- the site in front of a ResNet block whose down-sampling convolution reads the same
+ *           activation as the block's first convolution.
+ *   gx_image / gx_image_dt  (v25; nullable; QS_BF16 / QS_F16; needs gdt == xdt == QS_F32, 16-byte aligned) RNE(gx), written by the
+ *           same pass next to gx (+2 B/elem): the gradient of the 2-byte operand of a type-promoting add in front of the site
+ *           (`bn(conv(h)) + identity` under autocast: bf16 + float32 -> float32), which ATen's AddBackward0 produces with a
+ *           cast pass of gx of its own (6 B/elem). */
+typedef struct qs_ste_relu_bwd_args {
+    uint32_t struct_size;        /* sizeof(qs_ste_relu_bwd_args) as the caller compiled it */
+    int32_t gdt, xdt, g2dt;
+    const void* g;
+    const void* x;
+    const uint8_t* gate;
+    void* gx;
+    const float* step;
+    int64_t nstep;
+    float step_host;
+    int32_t step_is_decimal;
+    float lo_mul, hi_mul;
+    const uint8_t* chan_mask;
+    int64_t outer, C, inner;
+    int32_t elide_masked, act;
+    const void* g2;
+    qs_stream_t stream;
+    /* ---- v25 ---- */
+    const void* g3;
+    void* gx_image;
+    int32_t gx_image_dt;
+    int32_t reserved0;
+} qs_ste_relu_bwd_args;
+int qs_quant_ste_relu_bwd_v(const qs_ste_relu_bwd_args* args);
 
 /* ---- statistics ---------------------------------------------------------------------------------- */
 
@@ -466,6 +504,27 @@ int qs_site_stats(const qs_site_plan* plan, const void* x, int flags, float* rec
  * forward call filled (DecimalQuantizer: the clamp follows 2^-decimal). */
 int qs_site_bwd(const qs_site_plan* plan, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
                 float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream);
+
+/* (ABI v25) qs_site_bwd with its operands in a size-prefixed descriptor; g3 / gx_image / gx_image_dt as in
+ * qs_ste_relu_bwd_args (they need `gate` and a float32 site: plan->xdt == gdt == QS_F32). */
+typedef struct qs_site_bwd_args {
+    uint32_t struct_size;        /* sizeof(qs_site_bwd_args) as the caller compiled it */
+    int32_t flags;
+    int32_t gdt, g2dt;
+    const void* g;
+    const uint8_t* gate;
+    void* gx;
+    float lo_mul, hi_mul;
+    const void* g2;
+    const float* decimal;
+    qs_stream_t stream;
+    /* ---- v25 ---- */
+    const void* g3;
+    void* gx_image;
+    int32_t gx_image_dt;
+    int32_t reserved0;
+} qs_site_bwd_args;
+int qs_site_bwd_v(const qs_site_plan* plan, const qs_site_bwd_args* args);
 
 /* A lone tensor-wise ScalerQuantizer step -- QuantizeLayer.forward in training (reference quantize.py:473-518 with
  * optimize :327-349 and ScalerQuantization.forward :100-117) -- from ONE call: with `update` != 0

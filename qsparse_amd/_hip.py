@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 24          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 25          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -82,6 +82,8 @@ SIGNATURES = {
     "qs_site_fwd": (c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P, _P]),
     "qs_site_stats": (c_int, [_P, _P, _I, _P, _P]),
     "qs_site_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _I, _P, _P]),
+    "qs_site_bwd_v": (c_int, [_P, _P]),
+    "qs_quant_ste_relu_bwd_v": (c_int, [_P]),
     "qs_stats_pack": (c_int, [_P, _I, _P, _L, _L, _P, _P]),
     "qs_stats_combine": (c_int, [_P, _I, _L, _P, _P, _L, _P]),
 }
@@ -98,6 +100,24 @@ class SitePlanStruct(ctypes.Structure):
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
                 ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32),
                 ("elide_mask", c_void_p), ("absmax_dense", c_void_p), ("reduce_ws", c_void_p), ("reduce_ws_bytes", c_int64)]
+
+
+class SiteBwdArgs(ctypes.Structure):
+    """`qs_site_bwd_args` of include/qsparse_hip.h (size-prefixed: `struct_size` is what THIS binding knows)"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", c_int32), ("gdt", c_int32), ("g2dt", c_int32),
+                ("g", c_void_p), ("gate", c_void_p), ("gx", c_void_p), ("lo_mul", c_float), ("hi_mul", c_float),
+                ("g2", c_void_p), ("decimal", c_void_p), ("stream", c_void_p),
+                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32)]
+
+
+class SteReluBwdArgs(ctypes.Structure):
+    """`qs_ste_relu_bwd_args` of include/qsparse_hip.h"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("gdt", c_int32), ("xdt", c_int32), ("g2dt", c_int32),
+                ("g", c_void_p), ("x", c_void_p), ("gate", c_void_p), ("gx", c_void_p), ("step", c_void_p), ("nstep", c_int64),
+                ("step_host", c_float), ("step_is_decimal", c_int32), ("lo_mul", c_float), ("hi_mul", c_float),
+                ("chan_mask", c_void_p), ("outer", c_int64), ("C", c_int64), ("inner", c_int64),
+                ("elide_masked", c_int32), ("act", c_int32), ("g2", c_void_p), ("stream", c_void_p),
+                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32)]
 
 
 class MultiRow(ctypes.Structure):
@@ -1183,8 +1203,25 @@ def site_stats(plan_ref, x: torch.Tensor, flags: int, record: torch.Tensor):
 
 
 def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
-             hi_mul: float, g2: Optional[torch.Tensor] = None, decimal: Optional[torch.Tensor] = None):
-    """g2: a second, 2-byte gradient added to g in float32 (g may then be None), see qs_quant_ste_relu_bwd"""
+             hi_mul: float, g2: Optional[torch.Tensor] = None, decimal: Optional[torch.Tensor] = None,
+             g3: Optional[torch.Tensor] = None, gx_image: Optional[torch.Tensor] = None):
+    """g2: a second, 2-byte gradient added to g in float32 (g may then be None), see qs_quant_ste_relu_bwd; g3 / gx_image: the
+    riders of the all-float32 backward (qs_site_bwd_v): a third gradient stream of g2's dtype added between g and g2, and a 2-byte
+    tensor of gx's shape and layout that receives RNE(gx) from the same pass"""
+    if g3 is not None or gx_image is not None:
+        a = SiteBwdArgs()
+        a.struct_size = ctypes.sizeof(SiteBwdArgs)
+        a.flags, a.gdt, a.g2dt = flags, (F32 if g is None else _DT[g.dtype]), (0 if g2 is None else _DT[g2.dtype])
+        a.g, a.gate, a.gx = (None if g is None else g.data_ptr()), (None if gate_bits is None else gate_bits.data_ptr()), gx.data_ptr()
+        a.lo_mul, a.hi_mul = lo_mul, hi_mul
+        a.g2, a.decimal, a.stream = (None if g2 is None else g2.data_ptr()), (None if decimal is None else decimal.data_ptr()), _stream(gx)
+        a.g3 = None if g3 is None else g3.data_ptr()
+        if gx_image is not None:
+            a.gx_image, a.gx_image_dt = gx_image.data_ptr(), _DT[gx_image.dtype]
+        st = load().qs_site_bwd_v(plan_ref, ctypes.byref(a))
+        if st:
+            _check(st, "qs_site_bwd_v")
+        return
     st = load().qs_site_bwd(plan_ref, None if g is None else g.data_ptr(), None if gate_bits is None else gate_bits.data_ptr(),
                             gx.data_ptr(), F32 if g is None else _DT[g.dtype], flags, lo_mul, hi_mul,
                             None if g2 is None else g2.data_ptr(), 0 if g2 is None else _DT[g2.dtype],

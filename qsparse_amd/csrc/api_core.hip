@@ -344,9 +344,15 @@ int qs_site_fwd(const qs_site_plan* p, const void* x, void* y, uint8_t* gate_out
                                p->code_hi, pre_relu, elide, gate_out, image_out, imgdt, xback_out, stream);
 }
 
-int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
-                float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream) {
+static int site_bwd_impl(const qs_site_plan* p, const qs_site_bwd_args& a) {
+    const void *g = a.g, *g2 = a.g2;
+    const uint8_t* gate = a.gate;
+    void* gx = a.gx;
+    const int flags = a.flags, gdt = a.gdt;
+    const float* decimal = a.decimal;
+    qs_stream_t stream = a.stream;
     if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate)) return QS_ERR_ARG;
+    if ((a.g3 || a.gx_image) && (!gate || (flags & QS_SITE_NO_QUANT))) return QS_ERR_ARG;      // riders of the gated quantizer backward
     if (flags & QS_SITE_NO_QUANT) {          // a PruneLayer alone: the backward of act?(x) * mask
         if (!g || !p->mask || g2 || decimal) return QS_ERR_ARG;
         const int64_t hw0 = p->H * p->W;
@@ -364,10 +370,35 @@ int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void*
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
-    if (gate)
-        return qs_quant_ste_relu_bwd(g, nullptr, gate, gx, step, 1, 0.0f, is_decimal, lo_mul, hi_mul, cm, o, c, in, gdt, p->xdt,
-                                     g2 ? 0 : elide, p->act > 0 ? p->act : 1, g2, g2dt, stream);
-    return qs_quant_ste_bwd(g, gx, step, 1, 0.0f, is_decimal, lo_mul, hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
+    if (gate) {
+        qs_ste_relu_bwd_args r{};
+        r.struct_size = sizeof(r);
+        r.gdt = gdt, r.xdt = p->xdt, r.g2dt = a.g2dt;
+        r.g = g, r.gate = gate, r.gx = gx;
+        r.step = step, r.nstep = 1, r.step_host = 0.0f, r.step_is_decimal = is_decimal;
+        r.lo_mul = a.lo_mul, r.hi_mul = a.hi_mul, r.chan_mask = cm;
+        r.outer = o, r.C = c, r.inner = in;
+        r.elide_masked = g2 ? 0 : elide, r.act = p->act > 0 ? p->act : 1, r.g2 = g2, r.stream = stream;
+        r.g3 = a.g3, r.gx_image = a.gx_image, r.gx_image_dt = a.gx_image_dt;
+        return qs_quant_ste_relu_bwd_v(&r);
+    }
+    return qs_quant_ste_bwd(g, gx, step, 1, 0.0f, is_decimal, a.lo_mul, a.hi_mul, 0, cm, o, c, in, gdt, p->xdt, elide, stream);
+}
+
+int qs_site_bwd_v(const qs_site_plan* p, const qs_site_bwd_args* args) {
+    qs_site_bwd_args a;
+    if (!take_args(args, &a)) return QS_ERR_ARG;
+    return site_bwd_impl(p, a);
+}
+
+// the positional form (ABI <= v24 callers)
+int qs_site_bwd(const qs_site_plan* p, const void* g, const uint8_t* gate, void* gx, int gdt, int flags, float lo_mul,
+                float hi_mul, const void* g2, int g2dt, const float* decimal, qs_stream_t stream) {
+    qs_site_bwd_args a{};
+    a.struct_size = sizeof(a);
+    a.flags = flags, a.gdt = gdt, a.g2dt = g2dt;
+    a.g = g, a.gate = gate, a.gx = gx, a.lo_mul = lo_mul, a.hi_mul = hi_mul, a.g2 = g2, a.decimal = decimal, a.stream = stream;
+    return site_bwd_impl(p, a);
 }
 
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,

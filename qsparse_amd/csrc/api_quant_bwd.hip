@@ -27,25 +27,32 @@ int qs_quant_ste_bwd(const void* g, void* gx, const float* step, int64_t nstep, 
     });
 }
 
-int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx, const float* step, int64_t nstep,
-                          float step_host, int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask,
-                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, int act_handle, const void* g2,
-                          int g2dt, qs_stream_t stream) {
+static int ste_relu_bwd_impl(const qs_ste_relu_bwd_args& a) {
+    const void *g = a.g, *x = a.x, *g2 = a.g2;
+    const uint8_t* gate = a.gate;
+    void* gx = a.gx;
+    const int gdt = a.gdt, xdt = a.xdt, g2dt = a.g2dt;
     if ((!g && !g2) || (!x && !gate) || !gx) return QS_ERR_ARG;
     ActSpec act;
-    if (qs_act_resolve(act_handle > 0 ? act_handle : 1, &act) != QS_OK) return QS_ERR_ARG;
+    if (qs_act_resolve(a.act > 0 ? a.act : 1, &act) != QS_OK) return QS_ERR_ARG;
     if (!dt_ok(gdt) || !dt_ok(xdt) || !(gdt == QS_F32 || gdt == xdt)) return QS_ERR_DTYPE;
     if (g2 && (!gate || gdt != QS_F32 || (g2dt != QS_BF16 && g2dt != QS_F16))) return QS_ERR_DTYPE;
     if ((g && !aligned16(g)) || (!gate && !aligned16(x)) || !aligned16(gx) || (g2 && !aligned16(g2))) return QS_ERR_ALIGN;
-    int st = check_param(step, nstep, C);
+    // the riders of the all-fp32 kernel form (BwdRiders, qs_elementwise.h)
+    if (a.g3 && (!g2 || gdt != QS_F32 || xdt != QS_F32)) return QS_ERR_ARG;
+    if (a.gx_image && (gdt != QS_F32 || xdt != QS_F32 || (a.gx_image_dt != QS_BF16 && a.gx_image_dt != QS_F16))) return QS_ERR_DTYPE;
+    if ((a.g3 && !aligned16(a.g3)) || (a.gx_image && !aligned16(a.gx_image))) return QS_ERR_ALIGN;
+    const BwdRiders rd{a.g3, a.gx_image, a.gx_image_dt};
+    int st = check_param(a.step, a.nstep, a.C);
     if (st) return st;
-    const bool ppc = nstep > 1;
+    const bool ppc = a.nstep > 1;
+    const uint8_t* chan_mask = a.chan_mask;
     EwPlan plan;
-    st = plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
+    st = plan_ew(a.outer, a.C, a.inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask));
     if (st) return st;
     if (plan.geo.numel == 0) return QS_OK;
-    hipStream_t s = (hipStream_t)stream;
-    SteBwdOp op{step, step_host, step_is_decimal, lo_mul, hi_mul, 0, chan_mask};
+    hipStream_t s = (hipStream_t)a.stream;
+    SteBwdOp op{a.step, a.step_host, a.step_is_decimal, a.lo_mul, a.hi_mul, 0, chan_mask};
     const int grid = grid_for(plan.geo.ngroups, 1);
     constexpr bool NT = QS_EW_NT != 0;
     const void* second = gate ? (const void*)gate : x;       // the gate bitmap replaces the ReLU's input (GATE kernels)
@@ -58,19 +65,19 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
             switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_SCALAR, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2, rd);
                     break;
                 case CM_ROW:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ROW, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2, rd);
                     break;
                 case CM_LAST:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_LAST, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2, rd);
                     break;
                 default:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<QS_F32, XD, CM_ELEM, NT, false, true, G2D>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act, g2);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, g2, rd);
                     break;
             }
             return launch_status();
@@ -84,31 +91,31 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
             constexpr bool GATE = decltype(GT)::value;
             int cm = plan.cm;
             if (GD == QS_F32 && XD == QS_F32 && cm == CM_ELEM && plan.geo.inner % 4 == 0) cm = CM_ROW;   // 4 elements per lane
-            const bool el = elide_masked != 0 && chan_mask != nullptr;
+            const bool el = a.elide_masked != 0 && chan_mask != nullptr;
             switch (cm) {
                 case CM_SCALAR:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_SCALAR, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     break;
                 case CM_ROW:
                     if (el)
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx, act);
+                                           op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     else
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ROW, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx, act);
+                                           op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     break;
                 case CM_LAST:
                     if (el)
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, true, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx, act);
+                                           op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     else
                         hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_LAST, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                           op, plan.geo, (int)ppc, g, second, gx, act);
+                                           op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     break;
                 default:
                     hipLaunchKernelGGL((ste_relu_bwd_kernel<GD, XD, CM_ELEM, NT, false, GATE>), dim3(grid), dim3(kBlock), 0, s,
-                                       op, plan.geo, (int)ppc, g, second, gx, act);
+                                       op, plan.geo, (int)ppc, g, second, gx, act, nullptr, rd);
                     break;
             }
             return launch_status();
@@ -116,6 +123,28 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
         if (gate) return gdt == QS_F32 ? go(IC<QS_F32>{}, std::true_type{}) : go(X, std::true_type{});
         return gdt == QS_F32 ? go(IC<QS_F32>{}, std::false_type{}) : go(X, std::false_type{});
     });
+}
+
+int qs_quant_ste_relu_bwd_v(const qs_ste_relu_bwd_args* args) {
+    qs_ste_relu_bwd_args a;
+    if (!take_args(args, &a)) return QS_ERR_ARG;
+    return ste_relu_bwd_impl(a);
+}
+
+// the positional form (ABI <= v24 callers): the descriptor's first 21 fields
+int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, void* gx, const float* step, int64_t nstep,
+                          float step_host, int step_is_decimal, float lo_mul, float hi_mul, const uint8_t* chan_mask,
+                          int64_t outer, int64_t C, int64_t inner, int gdt, int xdt, int elide_masked, int act_handle, const void* g2,
+                          int g2dt, qs_stream_t stream) {
+    qs_ste_relu_bwd_args a{};
+    a.struct_size = sizeof(a);
+    a.gdt = gdt, a.xdt = xdt, a.g2dt = g2dt;
+    a.g = g, a.x = x, a.gate = gate, a.gx = gx;
+    a.step = step, a.nstep = nstep, a.step_host = step_host, a.step_is_decimal = step_is_decimal;
+    a.lo_mul = lo_mul, a.hi_mul = hi_mul, a.chan_mask = chan_mask;
+    a.outer = outer, a.C = C, a.inner = inner;
+    a.elide_masked = elide_masked, a.act = act_handle, a.g2 = g2, a.stream = stream;
+    return ste_relu_bwd_impl(a);
 }
 
 // ------------------------------------------------------------------------------------------------

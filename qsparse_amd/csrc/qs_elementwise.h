@@ -869,10 +869,25 @@ __device__ __forceinline__ void gate_to_floats(uint32_t bits, float* vx) {
 // NULL (then g2 alone is the gradient).  This is autograd's accumulation of the two gradients a site's float32 output
 // receives under autocast -- float32 from its float32 consumers, bf16 / fp16 from the convolution that consumed its
 // low-precision image (see fused.py, "autocast image") -- evaluated in the kernel instead of by a cast pass plus an add pass.
+//
+// Riders of the ALL-fp32 form (GDT == XDT == fp32: the site behind a residual add whose result type promotion made float32), both
+// nullable and wave-uniform:
+//   g3      a THIRD gradient stream of g2's dtype, added BEFORE g2: (g + float(g3)) + float(g2) -- the SECOND autocast consumer of
+//           the site's output (a down-sampling convolution next to the block's first one) handed its 2-byte gradient over as
+//           well; autograd accumulates the consumers' shares in reverse order of their creation, so the first consumer's (g2)
+//           is the last term (fused.py, "second image")
+//   gx_img  RNE(gx) in img_dt (bf16 / fp16), written next to gx by the same pass (+2 B/elem): the gradient of the 2-byte operand
+//           of the promoting add in front of the site, which ATen's AddBackward would produce with a 6 B/elem cast pass of gx
+struct BwdRiders {
+    const void* g3;
+    void* gx_img;
+    int img_dt;
+};
 template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false, int G2DT = -1>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
-                                                              void* __restrict__ gx, ActSpec act, const void* __restrict__ g2 = nullptr) {
+                                                              void* __restrict__ gx, ActSpec act, const void* __restrict__ g2 = nullptr,
+                                                              BwdRiders rd = BwdRiders{nullptr, nullptr, 0}) {
     static_assert(G2DT < 0 || (!ELIDE && GDT == QS_F32 && G2DT != QS_F32), "the second gradient is a 2-byte stream next to an fp32 one");
     // the activation's backward at one element: `xv` is the activation's input -- or, with GATE, the recorded bit as 1.0 / 0.0;
     // `applied` the clamped, masked gradient.  Open gate: it passes; closed: 0 (rectifiers) or applied * slope (leaky)
@@ -910,12 +925,22 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                 if (need) {
                     if (G2DT < 0 || g) rg4 = ld16<NT>((const u32x4*)((const float*)g + e));
                     if constexpr (G2DT >= 0) {      // 4 two-byte values of the second gradient: g + float(g2), or float(g2) alone
+                        const bool has3 = rd.g3 != nullptr;
+                        if (has3) {                  // ... with the third stream in between: (g + float(g3)) + float(g2)
+                            const u32x2 r3 = *(const u32x2*)((const uint16_t*)rd.g3 + e);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t h = (j & 1) ? (r3[j >> 1] >> 16) : (r3[j >> 1] & 0xffffu);
+                                const float v3 = (G2DT == QS_BF16) ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
+                                rg4[j] = __float_as_uint(g ? __uint_as_float(rg4[j]) + v3 : v3);
+                            }
+                        }
                         const u32x2 r2 = *(const u32x2*)((const uint16_t*)g2 + e);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const uint32_t h = (j & 1) ? (r2[j >> 1] >> 16) : (r2[j >> 1] & 0xffffu);
                             const float v2 = (G2DT == QS_BF16) ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
-                            rg4[j] = __float_as_uint(g ? __uint_as_float(rg4[j]) + v2 : v2);
+                            rg4[j] = __float_as_uint((g || has3) ? __uint_as_float(rg4[j]) + v2 : v2);
                         }
                     }
                     if constexpr (GATE) {
@@ -964,6 +989,10 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
                         out[j] = __float_as_uint(gated(__uint_as_float(rx4[j]), op.apply(__uint_as_float(rg4[j]), p, dummy)));
                 }
                 st16<NT>((u32x4*)((float*)gx + e), out);
+                if (rd.gx_img) {
+                    const float r[4] = {__uint_as_float(out[0]), __uint_as_float(out[1]), __uint_as_float(out[2]), __uint_as_float(out[3])};
+                    image_store<4>(rd.gx_img, rd.img_dt, e, r);
+                }
             }
         }
     } else
@@ -1064,11 +1093,20 @@ __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeo
         else xe = load1<XDT>(x, e);
         float ge = (G2DT < 0 || g) ? load1<GDT>(g, e) : 0.0f;
         if constexpr (G2DT >= 0) {
+            const bool has3 = rd.g3 != nullptr;
+            if (has3) {
+                const float v3 = load1<G2DT>(rd.g3, e);
+                ge = g ? ge + v3 : v3;
+            }
             const float v2 = load1<G2DT>(g2, e);
-            ge = g ? ge + v2 : v2;
+            ge = (g || has3) ? ge + v2 : v2;
         }
         const float r = gated(xe, op.apply(ge, p, dummy));
         store1<XDT>(gx, e, r);
+        if (rd.gx_img) {
+            if (rd.img_dt == QS_BF16) store1<QS_BF16>(rd.gx_img, e, r);
+            else store1<QS_F16>(rd.gx_img, e, r);
+        }
     }
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -107,5 +108,16 @@ inline int grid_for(int64_t ngroups, int unroll) {
 }
 
 inline bool aligned8(const void* p) { return (((uintptr_t)p) & 7u) == 0; }
+
+// Descriptor entry points (qs_*_v, include/qsparse_hip.h): the caller's struct -- possibly shorter (compiled against an older
+// header) or longer (a newer one) than this library's -- into a zero-initialised local one.  Fields are only ever appended, so
+// what the caller did not know about reads as 0 / NULL and what this library does not know about is ignored.
+template <class T>
+inline bool take_args(const T* in, T* out) {
+    if (!in || in->struct_size < sizeof(uint32_t)) return false;
+    *out = T{};
+    memcpy(out, in, in->struct_size < sizeof(T) ? in->struct_size : sizeof(T));
+    return true;
+}
 
 }  // namespace

@@ -67,6 +67,12 @@ def _eligible(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor) -> bool:
 # the first launch and clears it after the last; a step that finds the flag set re-zeroes the buffers first.
 # ----------------------------------------------------------------------------------------------------------------------
 _ARMED = "_qs_accumulators_armed"
+# which of the optional routes ran (benchmarks and tests read it; `collections.Counter`, never reset by the library):
+#   image / second_image   an autocast consumer took a site's first / second image
+#   grad_image             a promoting add's backward used the gradient image the consuming site's backward kernel wrote
+#   grad_image_cast        ... or had to cast (another consumer of the sum contributed, or the site took a route without the rider)
+#   image_disarmed         a site stopped making images because nobody took the last one (re-armed when the options change)
+ROUTES = __import__("collections").Counter()
 
 
 def _arm_accumulators(q: QuantizeLayer):
@@ -276,10 +282,27 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
 # sum is autograd's own accumulation (the first consumer's backward is the last to arrive, so even the grouping of more
 # than two terms is kept).  What changes is the TYPE of the site's output: a `torch.Tensor` subclass that carries the image
 # until a convolution / linear / matmul under autocast takes it; every other operation sees a plain float32 tensor.
-# Opt-in, because one thing is observable: the image consumer's gradient reaches the site's backward directly, NOT through
-# the output tensor -- `register_hook` / `retain_grad` on the output before the consumer ran simply cancel the image (the
-# whole gradient then flows through the tensor as usual), but a hook registered AFTER the consumer took it, or
-# `torch.autograd.grad(loss, y)`, sees only the float32 consumers' share.
+# The DEFAULT under autocast (option `autocast_image`, on since round 5).  The image consumer's gradient reaches the site's backward
+# directly, NOT through the output tensor; what can observe that is handled: `register_hook` / `retain_grad` on the output before
+# the consumer ran cancel the image (the whole gradient then flows through the tensor as usual); registered AFTER the consumer took
+# it they run as pre-hooks of the site's backward node, which holds every stream (`_late_hook`); `torch.autograd.grad(loss, y)`
+# differentiates with respect to the images as well and adds the shares (`_grad_through_duals`).
+#
+# Second image (round 6).  A block output that feeds the next block's first convolution AND its down-sampling convolution has two
+# autocast consumers; the second used to cast for itself (6 B/elem forward, 6 B/elem for the cast's backward).  The site's forward
+# returns the image TWICE -- two tensors on one storage, two gradient slots of the backward node -- and the second consumer gets
+# the second one, provided NOTHING touched the output between the two (`_qs_image_b` is armed by the first take and dropped by
+# any other consumer).  Autograd delivers the consumers' shares in reverse order of the consumers' creation, so the reference's
+# float32 accumulation at the output is ((float32 consumers, created last) + f32(second)) + f32(first): exactly what the backward
+# kernel evaluates from the three streams (qs_site_bwd_v g / g3 / g2) for a float32 site; elsewhere the second share is added the
+# way autograd would (a cast and an add), before the kernel.
+#
+# Promoting add (round 6).  `bn(conv(h)) + identity` under autocast is bf16 + float32 -> float32 (the identity is a site's
+# output); ATen's AddBackward0 hands the bf16 operand its gradient as a CAST of the sum's gradient, a 6 B/elem pass per residual
+# block.  The sum's only consumer is the next site, whose backward kernel produces that gradient: when the add involves a site's
+# output the library runs the same ATen add inside a node of its own (`_PromotingAdd`), tags the sum, and the consuming site's
+# backward writes RNE(gx) next to gx in the same pass (qs_site_bwd_v gx_image, +2 B/elem) -- which the add's backward hands to the
+# bf16 operand when the gradient it receives IS that gx (no other consumer of the sum contributed), and casts itself otherwise.
 # ----------------------------------------------------------------------------------------------------------------------
 def _image_consumers():
     import torch.nn.functional as F
@@ -314,22 +337,37 @@ def _non_consuming(func) -> bool:
     return getattr(func, "__name__", "") == "__get__" and getattr(getattr(func, "__self__", None), "__name__", None) in _METADATA_ATTRS
 
 
+def _drop_images(d):
+    d.pop("_qs_image", None)
+    d.pop("_qs_image_b", None)
+    d.pop("_qs_image_b_pending", None)
+
+
 def _cancel_images(args):
-    """drop the image of every site output among `args` (one level of lists / tuples deep: torch.cat([y, z]))"""
+    """drop the images (not yet taken) of every site output among `args` (one level of lists / tuples deep: torch.cat([y, z]))"""
     for a in args:
         if type(a) is AutocastImageTensor:
-            a.__dict__.pop("_qs_image", None)
+            _drop_images(a.__dict__)
         elif isinstance(a, (list, tuple)):
             for b in a:
                 if type(b) is AutocastImageTensor:
-                    b.__dict__.pop("_qs_image", None)
+                    _drop_images(b.__dict__)
 
 
-def _whole(g, g16):
-    """autograd's own accumulation of the two gradient streams of a site's output: float32 consumers + the image's consumer"""
+def _whole(g, g16, g16b=None):
+    """autograd's own accumulation of the gradient streams of a site's output: float32 consumers, then the second image's
+    consumer, then the first image's (the order in which their backward nodes run: reverse order of creation)"""
+    if g16b is not None:
+        g = g16b.float() if g is None else g + g16b.float()
     if g16 is None:
         return g
     return g16.float() if g is None else g + g16.float()
+
+
+def _slots(dual):
+    """the backward node's gradient slots of (output, image, second image | None)"""
+    sl = dual.__dict__.get("_qs_slots", (0, 1, 2))
+    return sl if len(sl) == 3 else (sl[0], sl[1], None)
 
 
 def _late_hook(dual, fn):
@@ -338,13 +376,14 @@ def _late_hook(dual, fn):
     holds both streams.  A hook that only looks (returns None) leaves the fast route untouched; one that returns a
     replacement turns the step into the plain one: (replacement, no second stream)."""
     node = dual.__dict__["_qs_node"]
-    i0, i1 = dual.__dict__.get("_qs_slots", (0, 1))       # the node's gradient slots of the output and of its image
+    i0, i1, i2 = _slots(dual)       # the node's gradient slots of the output, of its image and of the second image
 
     def pre(grads):
         g, g16 = grads[i0], grads[i1]
+        g16b = grads[i2] if (i2 is not None and i2 < len(grads)) else None
         earlier = node.__dict__.get("_qs_override")
         replaced = earlier is not None and i0 in earlier        # an earlier late hook already replaced this gradient: chain on it
-        full = earlier[i0] if replaced else _whole(g, g16)
+        full = earlier[i0] if replaced else _whole(g, g16, g16b)
         if full is None:
             return None
         r = fn(full)
@@ -357,6 +396,8 @@ def _late_hook(dual, fn):
             return None
         out = list(grads)
         out[i0], out[i1] = r, None
+        if g16b is not None:
+            out[i2] = None
         return tuple(out)
 
     return node.register_prehook(pre)
@@ -366,13 +407,14 @@ def _late_retain_grad(dual):
     import weakref
     torch.Tensor.retain_grad(dual)
     ref, node = weakref.ref(dual), dual.__dict__["_qs_node"]
-    i0, i1 = dual.__dict__.get("_qs_slots", (0, 1))
+    i0, i1, i2 = _slots(dual)
 
     def pre(grads):
         d = ref()
-        if d is not None and grads[i1] is not None:
+        g16b = grads[i2] if (i2 is not None and i2 < len(grads)) else None
+        if d is not None and (grads[i1] is not None or g16b is not None):
             with torch.no_grad():
-                d.grad = _whole(grads[i0], grads[i1])    # (the tensor's own retain-grad hook has stored the float32 share by now)
+                d.grad = _whole(grads[i0], grads[i1], g16b)    # (the tensor's own retain-grad hook has stored the float32 share by now)
         return None
 
     node.register_prehook(pre)
@@ -387,8 +429,9 @@ def _grad_through_duals(args, kwargs):
     outputs = kwargs.pop("outputs") if "outputs" in kwargs else args.pop(0)
     single = isinstance(inputs, torch.Tensor)
     ins = [inputs] if single else list(inputs)
-    extra = [(i, t.__dict__["_qs_image_taken"]) for i, t in enumerate(ins)
-             if type(t) is AutocastImageTensor and t.__dict__.get("_qs_image_taken") is not None]
+    # (second image first: its consumer's share is added before the first consumer's, as autograd's own accumulation would)
+    extra = [(i, t.__dict__[key]) for i, t in enumerate(ins) if type(t) is AutocastImageTensor
+             for key in ("_qs_image_taken_b", "_qs_image_taken") if t.__dict__.get(key) is not None]
     if not extra:
         return torch.autograd.grad(outputs, inputs, *args, **kwargs)
     allow_unused = kwargs.pop("allow_unused", None)
@@ -419,6 +462,7 @@ class AutocastImageTensor(torch.Tensor):
             if func in _GRADIENT_OBSERVERS and args and type(args[0]) is cls:
                 # someone wants to SEE this tensor's gradient: it must be the whole one
                 d = args[0].__dict__
+                d.pop("_qs_image_b_pending", None)
                 if d.pop("_qs_image", None) is None and d.get("_qs_image_taken") is not None and d.get("_qs_node") is not None:
                     # ... and a consumer has already bypassed the tensor: observe at the site's backward node instead
                     if func is torch.Tensor.retain_grad:
@@ -430,19 +474,34 @@ class AutocastImageTensor(torch.Tensor):
                     a = args[pos] if pos < len(args) else None
                     if type(a) is not cls:
                         continue
-                    held = a.__dict__.pop("_qs_image", None)    # one consumer only: a second one casts for itself, as before
+                    d = a.__dict__
+                    held, second = d.pop("_qs_image", None), False
                     if held is None:
-                        continue
+                        # the second image: armed when the first consumer took the first one, still there if nothing has touched
+                        # the output since (a third autocast consumer casts for itself)
+                        held, second = d.pop("_qs_image_b", None), True
+                        if held is None:
+                            _drop_images(d)
+                            continue
                     img, version, plan = held
+                    pending = d.pop("_qs_image_b_pending", None)
                     if (a._version == version and torch.is_autocast_enabled("cuda")
                             and torch.get_autocast_dtype("cuda") == img.dtype):
                         if img.requires_grad:
-                            a.__dict__["_qs_image_taken"] = img
+                            d["_qs_image_taken_b" if second else "_qs_image_taken"] = img
                         plan.image_used = True
+                        ROUTES["second_image" if second else "image"] += 1
                         args = tuple(args[:pos]) + (img,) + tuple(args[pos + 1:])
+                        if pending is not None and not second:
+                            d["_qs_image_b"] = (pending, version, plan)
                 _cancel_images(args[2:])
             elif func is torch.autograd.grad:
                 return _grad_through_duals(args, kwargs)
+            elif func in _PROMOTING_ADDS and len(args) == 2 and not kwargs:
+                _cancel_images(args)          # (a float32 consumer like any other)
+                s = _promoting_add(args[0], args[1])
+                if s is not None:
+                    return s
             elif not _non_consuming(func):
                 _cancel_images(args)          # another consumer comes first: the image's would not be the last term of the sum
             return func(*args, **(kwargs or {}))
@@ -461,12 +520,68 @@ class AutocastImageTensor(torch.Tensor):
             return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
 
 
-def _as_dual(y, img, plan, slots=None):
+# ---- the promoting add in front of a site (see "Promoting add" above) ----------------------------------------------------------
+class _PromotingAdd(torch.autograd.Function):
+    """`a + b` of a 2-byte tensor and a float32 site output: ATen's own add forward; backward hands the 2-byte operand the image
+    of the gradient the consuming site's backward kernel wrote (cell["g16"]) when the gradient arriving here IS that site's"""
+
+    @staticmethod
+    def forward(ctx, a, b, cell):
+        ctx.cell, ctx.dtypes = cell, (a.dtype, b.dtype)
+        return torch.add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        cell = ctx.cell
+        gx, g16 = cell.pop("gx", None), cell.pop("g16", None)
+        out = []
+        for i, dt in enumerate(ctx.dtypes):
+            if not ctx.needs_input_grad[i]:
+                out.append(None)
+            elif dt == g.dtype:
+                out.append(g)
+            elif g16 is not None and gx is not None and g is gx and g16.dtype == dt:
+                out.append(g16)
+                ROUTES["grad_image"] += 1
+            else:
+                out.append(g.to(dt))
+                ROUTES["grad_image_cast"] += 1
+        return out[0], out[1], None
+
+
+_PROMOTING_ADDS = frozenset((torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__))
+_GRAD_IMAGE_CELL = "_qs_grad_image_cell"
+
+
+def _promoting_add(a, b):
+    """the sum through `_PromotingAdd`, tagged for the site that consumes it -- or None when this is not the case the node serves:
+    a float32 site output plus a bf16 / fp16 CUDA tensor that requires grad, same shape (no broadcast to undo in the backward)"""
+    if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)) or not torch.is_grad_enabled() or not get_option("autocast_image"):
+        return None
+    lo, hi = (a, b) if a.dtype != torch.float32 else (b, a)
+    if (hi.dtype != torch.float32 or lo.dtype not in (torch.bfloat16, torch.float16) or not lo.requires_grad or not lo.is_cuda
+            or lo.shape != hi.shape or lo.device != hi.device or type(hi) is not AutocastImageTensor):
+        return None
+    cell = {"dtype": lo.dtype}
+    s = _PromotingAdd.apply(a, b, cell)
+    s.__dict__[_GRAD_IMAGE_CELL] = cell
+    return s
+
+
+def grad_image_cell(h):
+    """the cell of the promoting add that produced `h` (the consuming site's backward fills it), or None"""
+    return h.__dict__.get(_GRAD_IMAGE_CELL) if h.dtype == torch.float32 else None
+
+
+def _as_dual(y, img, plan, slots=None, img_b=None):
     """the site's float32 output as the subclass that carries its image to the first autocast consumer.  `slots`: the gradient
-    slots of (output, image) at the backward node when they are not (0, 1) -- the weight path's hand-out groups"""
+    slots of (output, image) at the backward node when they are not (0, 1) -- the weight path's hand-out groups.  `img_b`: the
+    second image (the same storage, the node's third gradient slot) for a second autocast consumer"""
     plan.image_made = True
     dual = y.as_subclass(AutocastImageTensor)
     dual.__dict__["_qs_image"] = (img, y._version, plan)
+    if img_b is not None:
+        dual.__dict__["_qs_image_b_pending"] = img_b
     dual.__dict__["_qs_node"] = y.grad_fn        # the backward node: both gradient streams arrive there (None: no grad)
     if slots is not None:
         dual.__dict__["_qs_slots"] = slots
@@ -523,7 +638,8 @@ class _SiteStep(torch.autograd.Function):
     """the whole site through qs_site_fwd / qs_site_bwd; same results as the statistics + select + `_FusedApply` route"""
 
     @staticmethod
-    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None, gathered=None, world=1):
+    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None, gathered=None, world=1, add_cell=None):
+        # add_cell: of the promoting add that produced h (`grad_image_cell`), or None
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
         make_image = image_dtype is not None and (want_gate or not ctx.needs_input_grad[0])
@@ -550,23 +666,26 @@ class _SiteStep(torch.autograd.Function):
         if _hip.image_byte_delta is not None and img is not None:
             _hip.image_byte_delta["apply_fwd"] += img.numel() * img.element_size()
         ctx.plan, ctx.flags, ctx.bits, ctx.notch, ctx.has_gate = plan, flags, bits, notch, want_gate
-        ctx.act, ctx.dec = plan.c.act, dec
+        ctx.act, ctx.dec, ctx.add_cell = plan.c.act, dec, add_cell
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
                               bits_t if want_gate else (h if keep_x else h.new_empty(0)))
         ctx.set_materialize_grads(False)
         if make_image:
-            return y, (img if fused_image else y.to(image_dtype))      # RNE(y): the cast autocast would apply in front of a convolution
+            im = img if fused_image else y.to(image_dtype)      # RNE(y): the cast autocast would apply in front of a convolution
+            return y, im, im.detach()     # ... twice: the same storage, a gradient slot of its own for a second autocast consumer
         return y
 
     @staticmethod
-    def backward(ctx, g, g16=None):
+    def backward(ctx, g, g16=None, g16b=None):
         plan, flags = ctx.plan, ctx.flags
-        n_in = 13
+        n_in = 14
         override = ctx.__dict__.pop("_qs_override", None)
         if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
-            g, g16 = override[0], None
+            g, g16, g16b = override[0], None, None
+        if g16 is None and g16b is not None:
+            g16, g16b = g16b, None       # (only the second consumer's share exists: it is the one 2-byte stream)
         if g is None and g16 is None:
             return (None,) * n_in
         mask_c, scale, third = ctx.saved_tensors
@@ -578,22 +697,42 @@ class _SiteStep(torch.autograd.Function):
         def dense(t):
             return t.is_contiguous(memory_format=fmt) and t.data_ptr() % 16 == 0 and tuple(t.shape) == tuple(ctx.x_shape)
 
+        # the riders of the all-float32 backward kernel (qs_site_bwd_v): the second image consumer's share as a third stream, and
+        # the image of gx for the promoting add that produced this site's input
+        f32_gated = ctx.has_gate and ctx.x_dtype == torch.float32
+        cell = ctx.add_cell if f32_gated else None
+
+        def grad_image(gx):
+            if cell is None:
+                return None
+            gimg = torch.empty(ctx.x_shape, dtype=cell["dtype"], device=gx.device, memory_format=fmt)
+            # (the cell holds gx until the add's backward ran: that also keeps the engine from accumulating INTO it)
+            cell["gx"], cell["g16"] = gx, gimg
+            return gimg
+
         if g16 is not None:
             # the image's consumer delivered its low-precision gradient: g + float(g16) inside the kernel (qs_site_bwd g2)
-            if (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
-                    and _hip.elide_mode != "all" and not _hip.logging_events()):
+            dual_ok = (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
+                       and _hip.elide_mode != "all" and not _hip.logging_events())
+            if g16b is not None and not (dual_ok and f32_gated and g16b.dtype == g16.dtype and dense(g16b)):
+                g = g16b.float() if g is None else g + g16b.float()    # the second consumer's share as autograd would add it
+                g16b = None
+                dual_ok = dual_ok and g.dtype == torch.float32 and dense(g)
+            if dual_ok:
                 gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g16.device, memory_format=fmt)
                 if _hip.image_byte_delta is not None:
                     _hip.image_byte_delta["apply_bwd"] += g16.numel() * g16.element_size() - (g16.numel() * 4 if g is None else 0)
-                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec)
+                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec, g3=g16b,
+                              gx_image=grad_image(gx))
                 return (gx,) + (None,) * (n_in - 1)
-            g = g16.float() if g is None else g + g16.float()          # autograd's own accumulation, then the usual routes
+            g = _whole(g, g16, g16b)          # autograd's own accumulation, then the usual routes
         fast = (dense(g) and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype)
                 and not _hip.logging_events())
         if fast:
             gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g.device, memory_format=fmt)
             bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
-            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul, decimal=ctx.dec)
+            gimg = grad_image(gx) if (g.dtype == torch.float32 and not (bflags & _hip.SITE_ELIDE)) else None
+            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul, decimal=ctx.dec, gx_image=gimg)
             return (gx,) + (None,) * (n_in - 1)
         mask = mask_c.detach().view(-1) if mask_c.numel() else None      # (the layers' own parameters were saved, not aliases)
         is_dec = ctx.dec is not None
@@ -788,18 +927,19 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
                  | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0) | (0 if prune_on else _hip.SITE_NO_MASK))
         if site.image_made and not site.image_used:
             site.image_ok = False        # nobody took the last image (the consumer is not an autocast matmul / convolution): stop making them
+            ROUTES["image_disarmed"] += 1
         site.image_made = site.image_used = False
         image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
         if site_gathered is not None:
             flags |= _hip.SITE_STATS_DONE
         out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
-                              p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world)
+                              p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world, grad_image_cell(h))
         if live or frozen:
             _disarm_accumulators(q)
         # (what `_FastPair.arm` looks at: a steady-state step of the composite route, no exchange)
         q.__dict__["_qs_last_route"] = ("live" if live else "frozen") if ((live or frozen) and site_gathered is None) else None
         if type(out) is tuple:
-            return _as_dual(out[0], out[1], site)
+            return _as_dual(out[0], out[1], site, img_b=out[2])
         return out
     return _FusedApply.apply(h, p.mask.data.view(-1) if prune_on else None, q.weight.data, kind, q.bits,
                              1 if qc.flip_axis else 0, quant_on, pre_relu, qc.code_range(q.bits),
@@ -1076,12 +1216,14 @@ class _FastPair:
                      | (_hip.SITE_PRE_RELU if pre_relu else 0) | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0))
             if plan.image_made and not plan.image_used:
                 plan.image_ok = False        # nobody took the last image: stop making them (as the full path)
+                ROUTES["image_disarmed"] += 1
             plan.image_made = plan.image_used = False
             image_dtype = _image_dtype(plan, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
-            out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1)
+            out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1,
+                                  grad_image_cell(h))
             _disarm_accumulators(q)
             if type(out) is tuple:
-                return _as_dual(out[0], out[1], plan)
+                return _as_dual(out[0], out[1], plan, img_b=out[2])
             return out
 
         if self.fold == 2:

@@ -601,3 +601,164 @@ def test_inputs_in_other_layouts_come_back_in_their_layout_with_or_without_the_i
         assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), ("trace", i)
     for k in sa:
         assert same(sa[k].cpu(), sb[k].cpu()), k
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# round 6: the second image (a second autocast consumer with a gradient slot of its own) and the promoting add in front of a site
+# ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("g2dt", [torch.bfloat16, torch.float16])
+def test_all_float32_backward_kernel_riders_equal_autograd_arithmetic(g2dt):
+    """qs_site_bwd_v's riders on the all-float32 form: (g + f32(g3)) + f32(g2) with each term optional from the left, and the image
+    RNE(gx) written next to gx -- against torch's own float32 adds, clamp, mask, gate and cast, bit for bit"""
+    from qsparse_amd import fused
+    for shape in ((6, 16, 8, 8), (3, 24, 7, 7), (2, 40, 3, 5), (5, 64)):
+        for cl in ((False, True) if len(shape) == 4 else (False,)):
+            for with_g32 in (True, False):
+                C = shape[1]
+                fmt = torch.channels_last if cl else torch.contiguous_format
+                view = (1, -1) + (1,) * (len(shape) - 2)
+                p = qs.prune(sparsity=0.5, dimensions={1}, start=0, interval=1, repetition=1).to(DEV).train()
+                q = qs.quantize(bits=4, channelwise=-1, timeout=1).to(DEV).train()
+                site = fuse_prune_quantize_pairs(nn.Sequential(nn.Sequential(nn.Sequential(nn.ReLU(), p), q)))[0]
+                for s in range(3):          # into the live regime: plan built, mask and scale set
+                    site((torch.randn(shape, generator=gen(40 + s)) * torch.linspace(0.3, 3, C).view(view)).to(DEV).contiguous(memory_format=fmt))
+                plan = q.__dict__["_qs_site_plan"]
+                assert plan is not None and plan.xdt == torch.float32
+                x = (torch.randn(shape, generator=gen(1)) * 2)
+                x.view(-1)[:3] = torch.tensor([0.0, -0.0, float("nan")])
+                x = x.to(DEV).contiguous(memory_format=fmt)
+                _, _, gate = _hip.quant_fwd("scaler", x, q.weight.detach(), -1, torch.float32, chan_mask=p.mask.detach().view(-1),
+                                            mask_channel_index=1, pre_relu=True, want_gate=True)
+                def mk(seed, dt, nan_at=None):
+                    t = (torch.randn(shape, generator=gen(seed)) * 3).to(dt)
+                    if nan_at is not None:
+                        t.view(-1)[nan_at] = float("nan")
+                    return t.to(DEV).contiguous(memory_format=fmt)
+
+                g32 = mk(3, torch.float32, 5) if with_g32 else None
+                g2, g3 = mk(4, g2dt), mk(5, g2dt)
+                gx = torch.empty_like(x)
+                gimg = torch.empty_like(x, dtype=g2dt)
+                _hip.site_bwd(plan.ref, g32, gate.bits, gx, 0, -8.0, 7.0, g2=g2, g3=g3, gx_image=gimg)
+                total = g3.float() if g32 is None else g32 + g3.float()              # autograd's accumulation, in arrival order
+                total = total + g2.float()
+                scale = q.weight.detach().view(())
+                lo_b, hi_b = (scale * -8.0).item(), (scale * 7.0).item()
+                clamped = torch.clamp(total, lo_b, hi_b) * p.mask.detach().view(view)
+                ref = torch.where(x > 0, clamped, torch.zeros_like(clamped))
+                ref = torch.where(x != x, clamped, ref)
+                a, b = gx.cpu(), ref.cpu()
+                tag = (shape, cl, with_g32, g2dt)
+                assert torch.equal(a.isnan(), b.isnan()), tag
+                assert same(torch.where(a.isnan(), torch.zeros_like(a), a), torch.where(b.isnan(), torch.zeros_like(b), b)), tag
+                ia, ib = gimg.cpu(), gx.to(g2dt).cpu()                                # the image is ATen's cast of gx
+                assert torch.equal(ia.isnan(), ib.isnan()), tag
+                assert same(torch.where(ia.isnan(), torch.zeros_like(ia), ia), torch.where(ib.isnan(), torch.zeros_like(ib), ib)), tag
+                # without the third stream, and the image alone
+                gx2 = torch.empty_like(x)
+                _hip.site_bwd(plan.ref, g32, gate.bits, gx2, 0, -8.0, 7.0, g2=g2, gx_image=gimg)
+                gx3 = torch.empty_like(x)
+                _hip.site_bwd(plan.ref, g32, gate.bits, gx3, 0, -8.0, 7.0, g2=g2)
+                assert same(gx2.cpu().nan_to_num(7.0), gx3.cpu().nan_to_num(7.0)), tag
+
+
+class Bottleneckish(nn.Module):
+    """a ResNet bottleneck's data flow around two sites: y0 = site0(x) feeds a first convolution, a down-sampling convolution (the
+    SECOND autocast consumer) or the residual add (`conv(...) + y0`: bf16 + float32), whose sum is site1's input"""
+
+    def __init__(self, C, down):
+        super().__init__()
+        def site():
+            return fuse_prune_quantize_pairs(nn.Sequential(
+                nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                qs.quantize(bits=4, channelwise=-1, timeout=1)))
+        self.site0, self.site1 = site(), site()
+        torch.manual_seed(11)
+        self.conv1 = nn.Conv2d(C, C, 1, bias=False)
+        self.bn = nn.BatchNorm2d(C)
+        self.down = nn.Conv2d(C, C, 1, bias=False) if down else None
+        self.head = nn.Conv2d(C, 8, 1, bias=False)
+
+    def forward(self, x):
+        y0 = self.site0(x)
+        out = self.bn(self.conv1(y0))
+        y1 = self.site1(out + (y0 if self.down is None else self.down(y0)))
+        return self.head(y1).float().mean((2, 3))
+
+
+@pytest.mark.parametrize("down", [False, True])
+@pytest.mark.parametrize("cl", [False, True])
+def test_bottleneck_data_flow_second_image_and_promoting_add_are_value_identical(down, cl):
+    from qsparse_amd.fused import ROUTES
+    shape = (6, 16, 8, 8)
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        before = dict(ROUTES)
+        try:
+            net = Bottleneckish(16, down).to(DEV).train()
+            if cl:
+                net = net.to(memory_format=torch.channels_last)
+            trace = []
+            for s in range(6):
+                x = (torch.randn(shape, generator=gen(60 + s)) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).to(DEV)
+                if cl:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                x.requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = net(x)
+                (out * torch.linspace(-1, 1, 8, device=DEV)).sum().backward()
+                trace += [out.detach().clone(), x.grad.clone(), net.bn.weight.grad.clone(), net.bn.bias.grad.clone()]
+                net.zero_grad()
+            runs.append((trace, {k: ROUTES[k] - before.get(k, 0) for k in ROUTES}))
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    (ta, ra), (tb, rb) = runs
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), (down, cl, i)
+    assert not any(ra.get(k) for k in ("image", "second_image", "grad_image")), ra
+    if down:
+        assert rb.get("second_image", 0) >= 4 and not rb.get("grad_image"), rb      # conv1 took the first image, the down conv the second
+    else:
+        assert rb.get("grad_image", 0) >= 4 and not rb.get("grad_image_cast"), rb    # the add's bf16 operand got the kernel's image
+
+
+def test_second_image_is_dropped_when_anything_touches_the_output_in_between():
+    """conv(y); y * 0.5; conv2(y): the float32 consumer between the two convolutions would be added AFTER the second convolution's
+    share in autograd's order -- the second convolution casts for itself, the values stay the reference's"""
+    from qsparse_amd.fused import ROUTES
+
+    class N(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.site = fuse_prune_quantize_pairs(nn.Sequential(
+                nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+                qs.quantize(bits=4, channelwise=-1, timeout=1)))
+            torch.manual_seed(3)
+            self.a, self.b = nn.Conv2d(16, 8, 1, bias=False), nn.Conv2d(16, 8, 1, bias=False)
+
+        def forward(self, x):
+            y = self.site(x)
+            o = self.a(y).float().mean((2, 3))
+            o = o + (y * 0.5).mean((2, 3))[:, :8]
+            return o + self.b(y).float().mean((2, 3))
+
+    runs = []
+    for image in (False, True):
+        qs.set_qsparse_options(autocast_image=image)
+        before = ROUTES["second_image"]
+        try:
+            net = N().to(DEV).train()
+            trace = []
+            for s in range(5):
+                x = (torch.randn(4, 16, 8, 8, generator=gen(80 + s)) * 2).to(DEV).requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = net(x)
+                out.sum().backward()
+                trace += [out.detach().clone(), x.grad.clone()]
+            runs.append(trace)
+            assert ROUTES["second_image"] == before
+        finally:
+            qs.set_qsparse_options(autocast_image=True)
+    for a, b in zip(*runs):
+        assert same(a.cpu(), b.cpu())
