@@ -708,6 +708,8 @@ class _SiteStep(torch.autograd.Function):
             gimg = torch.empty(ctx.x_shape, dtype=cell["dtype"], device=gx.device, memory_format=fmt)
             # (the cell holds gx until the add's backward ran: that also keeps the engine from accumulating INTO it)
             cell["gx"], cell["g16"] = gx, gimg
+            if _hip.image_byte_delta is not None:
+                _hip.image_byte_delta["apply_bwd"] += gimg.numel() * gimg.element_size()
             return gimg
 
         if g16 is not None:
@@ -722,6 +724,8 @@ class _SiteStep(torch.autograd.Function):
                 gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g16.device, memory_format=fmt)
                 if _hip.image_byte_delta is not None:
                     _hip.image_byte_delta["apply_bwd"] += g16.numel() * g16.element_size() - (g16.numel() * 4 if g is None else 0)
+                    if g16b is not None:
+                        _hip.image_byte_delta["apply_bwd"] += g16b.numel() * g16b.element_size()
                 _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec, g3=g16b,
                               gx_image=grad_image(gx))
                 return (gx,) + (None,) * (n_in - 1)

@@ -37,7 +37,7 @@ def build(pq, ddp):
     if pq:
         model = convert_pq(model, sparsity=sp, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
     model = model.to(dev).to(memory_format=torch.channels_last).train()
-    net = nn.parallel.DistributedDataParallel(model, device_ids=[0]) if ddp else model
+    net = nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=os.environ.get("QS_BCAST", "1") == "1") if ddp else model
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.randn(shape, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
@@ -62,6 +62,17 @@ def measure(name, step, n=30, top=18):
         step()
     torch.cuda.synchronize()
     print(f"{name:40s} {(time.perf_counter() - t0) / n * 1e3:7.2f} ms/step")
+    if os.environ.get("QS_NO_PROFILE"):
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / n * 1e3)
+        print(f"{name:40s} best of 5 x {n}: {min(ts):7.3f} ms/step")
+        return
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(10):
@@ -69,8 +80,14 @@ def measure(name, step, n=30, top=18):
     torch.cuda.synchronize()
     pr.disable()
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(top)
+    st = pstats.Stats(pr, stream=s).sort_stats("tottime")
+    st.print_stats(top)
     print("\n".join(l[:150] for l in s.getvalue().splitlines()[4:4 + top + 6]))
+    if os.environ.get("QS_CALLERS"):          # who calls a function by that name (regular expression)
+        s2 = io.StringIO()
+        st.stream = s2
+        st.print_callers(os.environ["QS_CALLERS"])
+        print("\n".join(l[:300] for l in s2.getvalue().splitlines()[:40]))
 
 
 for pq in (False, True):
