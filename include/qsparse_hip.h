@@ -668,9 +668,16 @@ int qs_multi_ste_bwd(int n, const float* const* g, float* const* gx, float* cons
  * whatever means it has) and maps its peers' (qs_mailbox_open).  Per step, after the statistics launches have written this rank's
  * n-float record: qs_mailbox_publish stores the record into slot `rank` of EVERY mailbox in `boxes` (host array of `world` device
  * pointers, this rank's own included; one-sided stores over xGMI), fences system-wide and raises flag `rank` there to `step`;
- * qs_mailbox_wait spins -- at most max_spins polls per rank, then *status = 1 + the missing rank, never a hang -- until every flag
- * of the local mailbox shows `step`, and returns in *records the [world][n] float records of this step (a device pointer into the
- * mailbox: the `gathered` argument of qs_pq_select / qs_site_fwd, combined in rank order there as after the all-gather).
+ * qs_mailbox_wait spins -- at most max_spins polls per rank, never a hang -- until every flag of the local mailbox shows `step`,
+ * and returns in *records the [world][n] float records of this step (a device pointer into the mailbox: the `gathered` argument
+ * of qs_pq_select / qs_site_fwd, combined in rank order there as after the all-gather).  A rank whose flag did not arrive in time
+ * is FATAL FOR THE STEP (ABI v25): *status = 1 + that rank and its record of this step is overwritten with NaNs before anything
+ * reads it, so the statistics -- magnitude, scale, output -- of a rank that missed a peer turn NaN at once instead of drifting on a
+ * stale record; the caller polls *status (one word; asynchronously is enough) and stops.
+ * qs_mailbox_alloc returns fine-grained memory or an error (ABI v25: no coarse-grained fall-back -- a peer's stores would not be
+ * guaranteed visible to the local acquire loads); the caller then keeps the collective exchange.
+ * qs_records_max (ABI v25): out[i] = max over ranks of records[r][i] as uint32 keys -- the all-reduce (MAX) of a quantize-only
+ * site's abs-max accumulator lines (qs_quantize_step, QS_QSTEP_ABSMAX / _FINISH) taken from the mailbox.
  * `step` counts from 1 and alternates between the mailbox's two halves; no rank can be more than one step ahead of the slowest
  * (its next publish is ordered behind its own select), so a half is never written while it is read.  qs_mailbox_alloc / _free /
  * _open / _close are set-up calls: they allocate, map and synchronise like the hip calls they wrap. */
@@ -683,6 +690,7 @@ int qs_mailbox_close(void* ptr);
 int qs_mailbox_publish(const float* rec, int64_t n, void* const* boxes, int world, int rank, uint32_t step, qs_stream_t stream);
 int qs_mailbox_wait(void* box, int world, int64_t n, uint32_t step, int32_t* status, uint32_t max_spins, const float** records,
                     qs_stream_t stream);
+int qs_records_max(const float* records, int world, int64_t n, float* out, qs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "qs_mailbox_close": (c_int, [_P]),
     "qs_mailbox_publish": (c_int, [_P, _L, _P, _I, _I, ctypes.c_uint32, _P]),
     "qs_mailbox_wait": (c_int, [_P, _I, _L, ctypes.c_uint32, _P, ctypes.c_uint32, _P, _P]),
+    "qs_records_max": (c_int, [_P, _I, _L, _P, _P]),
     "qs_mean_strided": (c_int, [_P, _P, _L, _L, _I, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P, _P]),
     "qs_multi_plan": (c_int, [_P, _I, _P, _P, _P, _P]),
     "qs_multi_absmax": (c_int, [_P, _I, _I, _P]),

@@ -34,8 +34,12 @@ static __global__ __launch_bounds__(256) void mailbox_publish_kernel(const float
     if (threadIdx.x == 0) __hip_atomic_store(box + parity * world + rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// one thread per rank; status (device int32, 0 on entry) receives 1 + the first rank whose flag did not arrive within max_spins
-static __global__ void mailbox_wait_kernel(uint32_t* box, int world, uint32_t step, int32_t* status, uint32_t max_spins) {
+// one thread per rank; status (device int32, 0 on entry) receives 1 + the first rank whose flag did not arrive within max_spins.
+// A timeout is FATAL FOR THE STEP: the missing rank's record of this step is overwritten with NaNs before the select reads it, so
+// the masks and scales of a rank that missed a peer cannot silently drift on a stale record (the NaN reaches the running magnitude
+// and the scale, i.e. the output, of this very step); the host side raises as soon as it sees the status word
+// (distributed.py `_StatusWatch`, polled without a sync at every exchange).
+static __global__ void mailbox_wait_kernel(uint32_t* box, int world, int64_t n, uint32_t step, int32_t* status, uint32_t max_spins) {
     const int r = threadIdx.x;
     if (r >= world) return;
     const int parity = (int)(step & 1u);
@@ -45,7 +49,25 @@ static __global__ void mailbox_wait_kernel(uint32_t* box, int world, uint32_t st
         if ((int32_t)(seen - step) >= 0) break;
         __builtin_amdgcn_s_sleep(8);
     } while (++spins < max_spins);
-    if ((int32_t)(seen - step) < 0) atomicCAS((int*)status, 0, 1 + r);
+    if ((int32_t)(seen - step) < 0) {
+        uint32_t* rec = box + kMailboxHeader + ((size_t)parity * world + r) * n;
+        for (int64_t i = 0; i < n; ++i) rec[i] = 0x7fc00000u;
+        atomicCAS((int*)status, 0, 1 + r);
+    }
+}
+
+// out[i] <- max over ranks of records[r][i], compared as uint32 keys (non-negative floats keep their order, a NaN stays the
+// maximum): the all-reduce (MAX) of a quantize-only site's abs-max accumulator lines, from the mailbox
+static __global__ void records_max_kernel(const uint32_t* __restrict__ rec, int world, int64_t n, uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint32_t mx = 0u;
+        for (int r = 0; r < world; ++r) {
+            const uint32_t k = rec[(int64_t)r * n + i];
+            mx = k > mx ? k : mx;
+        }
+        out[i] = mx;
+    }
 }
 
 }  // namespace qs
@@ -61,12 +83,13 @@ size_t qs_mailbox_bytes(int world, int64_t n) {
 
 int qs_mailbox_alloc(size_t bytes, void** ptr) {
     if (!ptr || bytes == 0) return QS_ERR_ARG;
-    // fine-grained: a peer's stores must not be hidden from this device's loads by its own L2
+    // fine-grained, or not at all: a peer's stores and flags must not be hidden from this device's acquire loads by its own L2,
+    // which coarse-grained memory does not guarantee -- a caller that gets an error here keeps the collective exchange
     hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        e = hipMalloc(ptr, bytes);
-        if (e != hipSuccess) return hip_status(e);
+        *ptr = nullptr;
+        return hip_status(e);
     }
     return hip_status(hipMemset(*ptr, 0, bytes));
 }
@@ -102,9 +125,16 @@ int qs_mailbox_publish(const float* rec, int64_t n, void* const* boxes, int worl
 int qs_mailbox_wait(void* box, int world, int64_t n, uint32_t step, int32_t* status, uint32_t max_spins, const float** records,
                     qs_stream_t stream) {
     if (!box || !status || n < 1 || world < 1 || world > kMailboxMaxWorld || step == 0 || max_spins == 0) return QS_ERR_ARG;
-    hipLaunchKernelGGL(mailbox_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(box), world, step,
+    hipLaunchKernelGGL(mailbox_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<uint32_t*>(box), world, n, step,
                        status, max_spins);
     if (records) *records = reinterpret_cast<const float*>(reinterpret_cast<uint32_t*>(box) + kMailboxHeader) + (size_t)(step & 1u) * world * n;
+    return launch_status();
+}
+
+int qs_records_max(const float* records, int world, int64_t n, float* out, qs_stream_t stream) {
+    if (!records || !out || world < 1 || n < 1) return QS_ERR_ARG;
+    hipLaunchKernelGGL(records_max_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t*>(records), world, n, reinterpret_cast<uint32_t*>(out));
     return launch_status();
 }
 

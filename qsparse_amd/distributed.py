@@ -70,11 +70,13 @@ def all_gather_records(gathered: torch.Tensor, record: torch.Tensor):
     global _PRIVATE_ALLGATHER
     if _PRIVATE_ALLGATHER:
         # the process group's own entry point: the public wrapper's argument checks cost ~7 us per call, seventeen times a step.
-        # A private name: any surprise (another torch, a wrapped or fake process group, a changed signature) switches to the
-        # public call for good -- BEFORE anything was exchanged, so the step's statistics are still those of this rank alone
+        # A private name: a surprise in its AVAILABILITY or SIGNATURE (another torch, a wrapped or fake process group) switches to
+        # the public call for good -- such errors are raised before anything was exchanged.  A RuntimeError is not one of them: an
+        # aborted communicator or an asynchronous RCCL error surfaces as that, possibly after this rank took part, and must
+        # propagate instead of being answered with a second collective on this rank alone
         try:
             work = dist.group.WORLD._allgather_base(gathered, record)
-        except (TypeError, AttributeError, NotImplementedError, RuntimeError):
+        except (TypeError, AttributeError, NotImplementedError):
             _PRIVATE_ALLGATHER = False
         else:
             work.wait()
@@ -96,8 +98,59 @@ class _RawView:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+class MailboxTimeout(RuntimeError):
+    """a peer's record did not arrive within the wait kernel's bound: this rank's statistics of that step are NaN (poisoned by
+    the kernel) -- training must stop"""
+
+
+class _StatusWatch:
+    """One status word per device for every mailbox on it, watched WITHOUT a sync: the wait kernels write 1 + the missing rank
+    into it; every exchange polls -- if the previous asynchronous copy of the word into pinned host memory has landed, its value
+    is looked at (no device access) and the next copy is enqueued.  A timeout is therefore raised within an exchange or two of
+    the step it happened in (`check()` reads the word with a sync: end of a step, shutdown)."""
+
+    def __init__(self, device):
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.in_flight = False
+
+    @staticmethod
+    def _raise(value):
+        raise MailboxTimeout(f"mailbox exchange: rank {value - 1} did not publish its statistics in time; this rank's records of "
+                             "that step were poisoned (NaN)")
+
+    def poll(self):
+        if self.in_flight:
+            if not self.event.query():
+                return
+            self.in_flight = False
+            if int(self.host[0]):
+                self._raise(int(self.host[0]))
+        self.host.copy_(self.status, non_blocking=True)
+        self.event.record()
+        self.in_flight = True
+
+    def check(self):
+        value = int(self.status.item())
+        if value:
+            self._raise(value)
+
+
+_watches = {}
+
+
+def _watch(device) -> _StatusWatch:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    w = _watches.get(key)
+    if w is None:
+        w = _watches[key] = _StatusWatch(device)
+    return w
+
+
 class Mailbox:
-    MAX_SPINS = 1 << 24        # ~seconds of polling before a missing peer is reported instead of waited for
+    # ~seconds of polling before a missing peer is reported instead of waited for (QS_MAILBOX_MAX_SPINS: tests shorten it)
+    MAX_SPINS = int(__import__("os").environ.get("QS_MAILBOX_MAX_SPINS", str(1 << 24)))
 
     def __init__(self, n: int, device):
         import ctypes
@@ -105,17 +158,18 @@ class Mailbox:
         from qsparse_amd import _hip
         self.lib, self.n, self.world, self.rank = _hip.load(), n, dist.get_world_size(), dist.get_rank()
         self.step = 0
+        self.local, self.opened = None, []
         nbytes = self.lib.qs_mailbox_bytes(self.world, n)
         if nbytes == 0:
             raise RuntimeError(f"mailbox exchange: world size {self.world} is not supported")
         local = ctypes.c_void_p()
-        _hip._check(self.lib.qs_mailbox_alloc(nbytes, ctypes.byref(local)), "qs_mailbox_alloc")
+        # (fine-grained memory or an error -- every rank must then agree to keep the collective: the error is raised, not hidden)
+        _hip._check(self.lib.qs_mailbox_alloc(nbytes, ctypes.byref(local)), "qs_mailbox_alloc (fine-grained device memory)")
         self.local = local.value
         handle = ctypes.create_string_buffer(64)
         _hip._check(self.lib.qs_mailbox_export(self.local, handle), "qs_mailbox_export")
         handles = [None] * self.world
         dist.all_gather_object(handles, bytes(handle.raw))         # once per site
-        self.opened = []
         boxes = (ctypes.c_void_p * self.world)()
         for r, h in enumerate(handles):
             if r == self.rank:
@@ -126,7 +180,8 @@ class Mailbox:
             boxes[r] = peer.value
             self.opened.append(peer.value)
         self.boxes = boxes
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.watch = _watch(device)
+        self.status = self.watch.status
         self.views = [torch.as_tensor(_RawView(self.local + 4 * (64 + half * self.world * n), self.world * n), device=device)
                       for half in (0, 1)]
         dist.barrier()          # every mailbox is mapped before anybody publishes into one
@@ -137,6 +192,11 @@ class Mailbox:
         import ctypes
 
         from qsparse_amd import _hip
+        if torch.cuda.is_current_stream_capturing():
+            # a captured step would bake this step's number into the publish / wait launches: every replay would raise the same
+            # flag value and read the same half
+            raise RuntimeError("the mailbox exchange cannot be captured into a hipGraph: its launches carry the step number")
+        self.watch.poll()        # (raises MailboxTimeout if an earlier wait on this device ran out of spins)
         self.step += 1
         stream = _hip._stream(rec)
         _hip._check(self.lib.qs_mailbox_publish(rec.data_ptr(), self.n, self.boxes, self.world, self.rank, self.step, stream),
@@ -144,14 +204,10 @@ class Mailbox:
         out = ctypes.c_void_p()
         _hip._check(self.lib.qs_mailbox_wait(self.local, self.world, self.n, self.step, self.status.data_ptr(), self.MAX_SPINS,
                                              ctypes.byref(out), stream), "qs_mailbox_wait")
-        if self.step % 256 == 0:
-            self.check()
         return self.views[self.step & 1]
 
     def check(self):
-        missing = int(self.status.item())
-        if missing:
-            raise RuntimeError(f"mailbox exchange: rank {missing - 1} did not publish its statistics in time")
+        self.watch.check()
 
     def close(self):
         for p in self.opened:
@@ -161,6 +217,12 @@ class Mailbox:
             self.lib.qs_mailbox_free(self.local)
             self.local = None
 
+    def __del__(self):           # a mailbox dropped without close() (its site was garbage-collected): unmap and free, never raise
+        try:
+            self.close()
+        except Exception:        # noqa: BLE001
+            pass
+
 
 def mailbox_enabled() -> bool:
     return get_option("sync_statistics") == "mailbox" and dist.is_available() and dist.is_initialized()
@@ -169,27 +231,54 @@ def mailbox_enabled() -> bool:
 _mailboxes = None     # owner (the site's QuantizeLayer) -> Mailbox; weak keys: a mailbox goes with its site, never into a copy or pickle
 
 
-def mailbox_exchange(owner, rec: torch.Tensor) -> torch.Tensor:
-    """`owner`: the module the mailbox belongs to; it is created at the site's first exchange -- on every rank at the same one"""
+def _mailbox_of(owner, n: int, device) -> Mailbox:
     global _mailboxes
     if _mailboxes is None:
         import weakref
         _mailboxes = weakref.WeakKeyDictionary()
     box = _mailboxes.get(owner)
-    if box is None or box.n != rec.numel() or box.status.device != rec.device:
+    if box is None or box.n != n or box.status.device != device:
         if box is not None:
             box.close()
-        box = _mailboxes[owner] = Mailbox(rec.numel(), rec.device)
-    return box.exchange(rec)
+        box = _mailboxes[owner] = Mailbox(n, device)
+    return box
+
+
+def mailbox_exchange(owner, rec: torch.Tensor) -> torch.Tensor:
+    """`owner`: the module the mailbox belongs to; it is created at the site's first exchange -- on every rank at the same one"""
+    return _mailbox_of(owner, rec.numel(), rec.device).exchange(rec)
+
+
+def mailbox_max_(owner, acc: torch.Tensor) -> torch.Tensor:
+    """the all-reduce (MAX) of a quantize-only site's abs-max accumulator lines through the site's mailbox: every rank publishes
+    its lines, waits for everybody's, and takes the maximum as integer keys in place (qs_records_max) -- no host collective"""
+    from qsparse_amd import _hip
+    flat = acc.view(-1)
+    rec = flat.view(torch.float32) if flat.dtype != torch.float32 else flat
+    gathered = _mailbox_of(owner, rec.numel(), rec.device).exchange(rec)
+    _hip._check(_hip.load().qs_records_max(gathered.data_ptr(), dist.get_world_size(), rec.numel(), rec.data_ptr(), _hip._stream(rec)),
+                "qs_records_max")
+    return acc
+
+
+def check_mailboxes():
+    """read the status word of every device that has mailboxes (one 4-byte device read each, with a sync): raises MailboxTimeout
+    if any wait since the last check ran out of spins.  Cheap enough for the end of every step -- behind `optimizer.step()`, which
+    syncs nothing but is where a training loop can afford it; the exchanges themselves poll without a sync."""
+    for w in list(_watches.values()):
+        w.check()
 
 
 def close_mailboxes():
-    """unmap and free every mailbox (before destroy_process_group; every rank)"""
+    """check, then unmap and free every mailbox (before destroy_process_group; every rank)"""
     global _mailboxes
-    for box in list((_mailboxes or {}).values()):
-        box.check()
-        box.close()
-    _mailboxes = None
+    try:
+        check_mailboxes()
+    finally:
+        for box in list((_mailboxes or {}).values()):
+            box.close()
+        _mailboxes = None
+        _watches.clear()
 
 
 def gather_pair_statistics(stage: Optional[torch.Tensor], chan_absmax: Optional[torch.Tensor], world: int,

@@ -696,7 +696,10 @@ class QuantizeLayer(nn.Module):
                 acc.zero_()              # an earlier step died between the two calls (failed collective): stale maxima
             self.__dict__["_qs_accumulator_armed"] = True
             _hip.quantize_step(x, None, None, acc, self.weight.data, self.bits, cb.t, None, None, pre_relu, _hip.QSTEP_ABSMAX)
-            qdist.allreduce_max_(acc.view(torch.int32))
+            if qdist.mailbox_enabled():        # (the lines travel through the site's mailbox: no host collective)
+                qdist.mailbox_max_(self, acc)
+            else:
+                qdist.allreduce_max_(acc.view(torch.int32))
             mode = _hip.QSTEP_FINISH
         image_dtype, stat = None, None
         if pre_relu:                # a quantize-only activation site (convert's Sequential(act, QuantizeLayer)): the autocast image

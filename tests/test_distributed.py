@@ -445,6 +445,8 @@ def _mailbox_worker(rank, world, port, out):
             pair = fuse_prune_quantize_pairs(nn.Sequential(
                 nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2)),
                 qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train())
+            # a quantize-only site (convert's Sequential(act, QuantizeLayer)): its abs-max lines travel through a mailbox as well
+            actq = fuse_prune_quantize_pairs(nn.Sequential(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1))))[0].cuda().train()
             ys = []
             for step in range(9):
                 g = torch.Generator().manual_seed(100 + step)
@@ -456,10 +458,13 @@ def _mailbox_worker(rank, world, port, out):
                 y = pair(shard)
                 y.backward(torch.ones_like(y))
                 ys.append(y.detach().float().cpu().numpy().copy())
+                ys.append(actq(shard.detach()).detach().float().cpu().numpy().copy())
             torch.cuda.synchronize()
             steps = sum(b.step for b in (qdist._mailboxes or {}).values())
-            res[(mode, layout)] = (tuple(t.detach().cpu().numpy().copy() for t in (pair[0][1].mask, pair[0][1].callback.magnitude, pair[1].weight)),
-                                   ys, steps)
+            n_boxes = len(qdist._mailboxes or {})
+            res[(mode, layout)] = (tuple(t.detach().cpu().numpy().copy() for t in (pair[0][1].mask, pair[0][1].callback.magnitude, pair[1].weight,
+                                                                                    actq[1].weight)),
+                                   ys, steps, n_boxes)
             if mode == "mailbox":
                 qdist.close_mailboxes()          # (checks the status word: nobody was waited for in vain)
     qs.set_qsparse_options(sync_statistics=None)
@@ -488,11 +493,105 @@ def test_mailbox_exchange_equals_the_collective_two_ranks_one_gpu():
         assert pr.exitcode == 0
     for layout in ("nchw", "channels_last"):
         for rank in (0, 1):
-            (state_c, ys_c, steps_c), (state_m, ys_m, steps_m) = res[rank][("collective", layout)], res[rank][("mailbox", layout)]
-            assert steps_c == 0 and steps_m >= 6, (steps_c, steps_m)          # the mailbox served the live steps of the second run only
+            (state_c, ys_c, steps_c, _), (state_m, ys_m, steps_m, boxes_m) = res[rank][("collective", layout)], res[rank][("mailbox", layout)]
+            assert steps_c == 0 and steps_m >= 12, (steps_c, steps_m)         # the mailboxes served the live steps of the second run only
+            assert boxes_m == 2                                               # ... one for the pair, one for the quantize-only site
             for a, b in zip(state_c, state_m):
                 assert np.array_equal(a, b), (layout, rank)
             for s, (a, b) in enumerate(zip(ys_c, ys_m)):
                 assert np.array_equal(a, b), (layout, rank, s)
         for a, b in zip(res[0][("mailbox", layout)][0], res[1][("mailbox", layout)][0]):
             assert np.array_equal(a, b), layout                              # ranks agree
+
+
+def _mailbox_timeout_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["QS_MAILBOX_MAX_SPINS"] = str(1 << 16)          # ~tens of milliseconds instead of seconds (read at import)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn as nn
+    import qsparse_amd as qs
+    from qsparse_amd import distributed as qdist
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, sync_statistics="mailbox")
+    pair = fuse_prune_quantize_pairs(nn.Sequential(
+        nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=2)),
+        qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train())
+
+    def step(s):
+        g = torch.Generator().manual_seed(200 + s)
+        x = (torch.randn(4, 16, 8, 8, generator=g) * (1.0 + rank)).bfloat16().cuda()
+        return pair(x)
+
+    res = {}
+    for s in range(5):
+        y = step(s)
+    torch.cuda.synchronize()
+    qdist.check_mailboxes()                                     # everybody published so far
+    res["finite_before"] = bool(torch.isfinite(y.float()).all())
+    dist.barrier()
+    if rank == 0:
+        # rank 1 sits this step out: rank 0's wait runs out of spins, poisons the missing record and raises the status word
+        y = step(5)
+        torch.cuda.synchronize()
+        res["nan_in_step"] = bool(torch.isnan(y.float()).any())
+        try:
+            qdist.check_mailboxes()
+            res["check"] = "no error"
+        except qdist.MailboxTimeout as e:
+            res["check"] = str(e)
+        # ... and without an explicit check: the next exchanges poll the word and raise by themselves
+        res["poll"] = "no error"
+        try:
+            for s in range(6, 10):
+                step(s)
+                torch.cuda.synchronize()
+        except qdist.MailboxTimeout as e:
+            res["poll"] = str(e)
+    dist.barrier()
+    try:
+        qdist.close_mailboxes()
+    except qdist.MailboxTimeout:
+        res["close_raised"] = True
+    # a captured step must be refused
+    if rank == 1:
+        qs.set_qsparse_options(sync_statistics="mailbox")
+        box = qdist.Mailbox.__new__(qdist.Mailbox)
+        box.local, box.opened = None, []
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                try:
+                    qdist.Mailbox.exchange(box, torch.zeros(4, device="cuda"))
+                    res["capture"] = "no error"
+                except RuntimeError as e:
+                    res["capture"] = str(e)
+        except Exception as e:      # noqa: BLE001  (the capture itself may be invalidated by the refusal: fine)
+            res.setdefault("capture", f"outer {type(e).__name__}")
+    from qsparse_amd import util
+    util._options_["sync_statistics"] = None
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_mailbox_timeout_is_fatal_for_the_step_and_names_the_rank():
+    """ADVICE r05 (medium) / VERDICT r05 item 5: a rank that misses a peer must not keep training on a stale record -- the wait
+    kernel poisons the missing record (the step's output turns NaN) and the host raises MailboxTimeout naming the rank, from an
+    explicit `check_mailboxes()` and, without one, from the polling of the following exchanges; a captured exchange is refused"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mailbox_timeout_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(out.get(timeout=300) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert res[0]["finite_before"] and res[1]["finite_before"]
+    assert res[0]["nan_in_step"] is True
+    assert "rank 1 did not publish" in res[0]["check"], res[0]
+    assert "rank 1 did not publish" in res[0]["poll"], res[0]
+    assert res[0].get("close_raised") is True and not res[1].get("close_raised")
+    assert "cannot be captured" in res[1]["capture"], res[1]
