@@ -5,10 +5,12 @@
   python3 tools/pmc_stats_kernels.py run            the workload alone: channels_last (`qs_mean_dim_cl`) and NCHW (`qs_mean_dim`,
                                                     the control) statistics of three ResNet-50 batch-256 activation shapes,
                                                     rotating inputs past the Infinity Cache
-  python3 tools/pmc_stats_kernels.py                (GPU box, repo root) one `rocprofv3 --pmc` pass per counter group over that
-                                                    workload (program directly after `--`, never combined with other trace
-                                                    domains) + a kernel-trace pass for the durations; writes the per-kernel table
-                                                    to gpurun_out/profiles/<tag>_stats_kernels_pmc.txt
+  python3 tools/pmc_stats_kernels.py [tag]          (GPU box, repo root) one `rocprofv3 --pmc` pass per counter group over that
+                                                    workload (the program directly after `--`, NO trace domain next to the
+                                                    counters) + a separate kernel-trace pass for the durations; writes the
+                                                    per-kernel table to gpurun_out/profiles/<tag>_stats_kernels_pmc.txt.  A group
+                                                    that fails marks the table INCOMPLETE and the tool exits non-zero.
+  QS_PMC_DTYPE=f32: the float32 inputs of the sites behind residual adds instead of bf16.
 """
 import csv
 import glob
@@ -18,7 +20,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14)]
+F32 = os.environ.get("QS_PMC_DTYPE", "bf16") == "f32"
+SHAPES = [(256, 256, 56, 56), (256, 512, 28, 28)] if F32 else [(256, 256, 56, 56), (256, 512, 28, 28), (256, 1024, 14, 14)]
 GROUPS = {
     "sq": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
            "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU"],
@@ -38,17 +41,18 @@ def workload():
     lib = _hip.load()
     for shp in SHAPES:
         N, C, H, W = shp
-        nrot = max(2, min(6, int(9e8 // (N * C * H * W * 2))))
-        xs = [torch.randn(shp, device="cuda").bfloat16() for _ in range(nrot)]
-        stage = torch.empty(C * H * W, device="cuda", dtype=torch.bfloat16)
+        dt, code, size = (torch.float32, 0, 4) if F32 else (torch.bfloat16, 1, 2)
+        nrot = max(2, min(6, int(9e8 // (N * C * H * W * size))))
+        xs = [torch.randn(shp, device="cuda").to(dt) for _ in range(nrot)]
+        stage = torch.empty(C * H * W, device="cuda", dtype=dt)
         part = torch.empty(C * H * W, device="cuda")
         amax = torch.zeros(C * 32, device="cuda")
         for it in range(12):
             x = xs[it % nrot]
-            assert lib.qs_mean_dim_cl(x.data_ptr(), stage.data_ptr(), N, H * W, C, 1, 1, 1 | 4, None, part.data_ptr(), None) == 0
+            assert lib.qs_mean_dim_cl(x.data_ptr(), stage.data_ptr(), N, H * W, C, code, code, 1 | 4, None, part.data_ptr(), None) == 0
         for it in range(12):
             x = xs[it % nrot]
-            assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, 1, 1, 1 | 4, None, amax.data_ptr(), 32, H * W, C, None) == 0
+            assert lib.qs_mean_dim(x.data_ptr(), stage.data_ptr(), 1, N, C * H * W, code, code, 1 | 4, None, amax.data_ptr(), 32, H * W, C, None) == 0
         torch.cuda.synchronize()
         del xs
 
@@ -70,7 +74,7 @@ def main():
     for group, counters in GROUPS.items():
         d = f"/tmp/pmc_stats_{group}"
         shutil.rmtree(d, ignore_errors=True)
-        cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", me, "run"]
+        cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3", me, "run"]
         print("+", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, cwd="/tmp", env=env, text=True, capture_output=True)
         if r.returncode != 0:
@@ -104,10 +108,13 @@ def main():
             if "qs::" in row["Kernel_Name"]:
                 key = (short(row["Kernel_Name"]), row.get("Grid_Size", row.get("Grid_Size_X", "")))
                 dur.setdefault(key, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    lines = ["rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_stats_kernels.py run   (one pass per group; averages over the last 8 of 12 launches)",
-             "shapes (bf16, batch 256): " + ", ".join("x".join(map(str, s)) for s in SHAPES) + "; channels_last = mean_cl_*, NCHW control = mean_outer_vec_kernel",
+    lines = ["rocprofv3 --pmc <group> -- python3 tools/pmc_stats_kernels.py run   (one pass per group, no trace domain next to the counters; "
+             "durations from a separate --kernel-trace pass; averages over the last 8 of 12 launches)",
+             f"shapes ({'float32' if F32 else 'bf16'}, batch 256): " + ", ".join("x".join(map(str, s)) for s in SHAPES) + "; channels_last = mean_cl_*, NCHW control = mean_outer_vec_kernel",
              "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md); per-wave = / SQ_WAVES", ""]
-    lines += notes
+    if notes:
+        lines += ["INCOMPLETE: a counter group failed -- its counters are missing below"] + notes + [""]
+    counts = {key: len(per[key]) for key in order}
     for key in order:
         launches = per[key]
         idxs = sorted(launches)[4:] or sorted(launches)
@@ -135,6 +142,8 @@ def main():
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    if notes:
+        sys.exit(1)
 
 
 if __name__ == "__main__":
