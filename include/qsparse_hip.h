@@ -32,6 +32,18 @@ extern "C" {
 #endif
 
 #define QS_ABI_VERSION 25
+/* ABI compatibility (from v25 on).
+ *   - Every positional prototype in this header is FROZEN as of v25: a later version never changes the argument list of an
+ *     existing symbol.  qs_abi_floor() returns the oldest version whose prototypes this library still honours (25); a binding
+ *     written against version V works with any library with qs_abi_floor() <= V <= qs_version().
+ *   - New operands arrive through the DESCRIPTOR entry points (qs_*_v): the operands of a call in a struct whose first field,
+ *     `struct_size`, is sizeof(the struct) AS THE CALLER COMPILED IT.  Fields are only ever appended.  The library copies
+ *     min(struct_size, its own sizeof) bytes into a zeroed struct: a caller built against an older header leaves the newer fields
+ *     0 / NULL (every appended field is optional with that default), a caller built against a newer header is understood up to
+ *     what this library knows.  The fields are the positional arguments of the entry point of the same name, one for one, followed
+ *     by the appended ones, each marked with the version that introduced it.
+ *   - The positional entry points remain: thin wrappers that fill the descriptor.  qs_site_plan / qs_multi_row / qs_multi_stage
+ *     are caller-built tables whose layout is likewise append-only from v25 on. */
 
 enum qs_dtype { QS_F32 = 0, QS_BF16 = 1, QS_F16 = 2 };
 
@@ -63,6 +75,7 @@ enum qs_act_kind { QS_ACT_NONE = 0, QS_ACT_RELU = 1, QS_ACT_HARDTANH = 2, QS_ACT
 int qs_activation(int kind, float a, float b);
 
 int qs_version(void);
+int qs_abi_floor(void);      /* (v25) see "ABI compatibility" above */
 const char* qs_status_string(int status);
 size_t qs_workspace_bytes(int op, int64_t n);
 
@@ -105,6 +118,29 @@ int qs_quant_decimal_fwd(const void* x, void* y, int32_t* codes,
                          int xdt, int ydt, int qdt,
                          int saturate, int32_t code_lo, int32_t code_hi, int pre_relu, int elide_masked,
                          uint8_t* gate_out, void* image_out, int imgdt, void* xback_out, qs_stream_t stream);
+
+/* (ABI v25) qs_quant_scaler_fwd / qs_quant_decimal_fwd as ONE descriptor entry point; `kind` selects the quantizer, `param` /
+ * `nparam` / `param_host` are scale / nscale / scale_host or decimal / ndecimal / decimal_host. */
+enum qs_quant_kind { QS_QUANT_SCALER = 0, QS_QUANT_DECIMAL = 1 };
+typedef struct qs_quant_fwd_args {
+    uint32_t struct_size;        /* sizeof(qs_quant_fwd_args) as the caller compiled it */
+    int32_t kind;                /* enum qs_quant_kind */
+    const void* x;
+    void* y;
+    int32_t* codes;
+    const float* param;
+    int64_t nparam;
+    float param_host;
+    int32_t xdt, ydt, qdt;
+    const uint8_t* chan_mask;
+    int64_t outer, C, inner;
+    int32_t saturate, code_lo, code_hi, pre_relu, elide_masked, imgdt;
+    uint8_t* gate_out;
+    void* image_out;
+    void* xback_out;
+    qs_stream_t stream;
+} qs_quant_fwd_args;
+int qs_quant_fwd_v(const qs_quant_fwd_args* args);
 
 /* image_out (nullable; qs_quant_scaler_fwd / qs_quant_decimal_fwd, with gate_out, ydt == QS_F32 and codes == NULL): the same
  * pass also writes RNE(y) in imgdt (QS_BF16 / QS_F16) -- the low-precision image autocast would make of y in front of a
@@ -402,6 +438,30 @@ int qs_pq_select(float* magnitude, const void* stage_mean, int sdt, int64_t C,
                  const int64_t* t_mag_dev, const int64_t* t_q_dev, int stat_dt, const float* gathered, int world,
                  uint8_t* elide_mask_out, qs_stream_t stream);
 
+/* (ABI v25) qs_pq_select with its operands in a descriptor */
+typedef struct qs_pq_select_args {
+    uint32_t struct_size;        /* sizeof(qs_pq_select_args) as the caller compiled it */
+    int32_t sdt, stat_dt, bits, world;
+    int32_t update_magnitude, refresh_mask, update_scale;
+    float* magnitude;
+    const void* stage_mean;
+    int64_t C, t_mag, k, t_q;
+    uint8_t* mask;
+    float* chan_absmax;
+    int64_t chan_absmax_stride;
+    float* scale;
+    int32_t* bump_i32_a;
+    int32_t* bump_i32_b;
+    int64_t* bump_i64_a;
+    int64_t* bump_i64_b;
+    const int64_t* t_mag_dev;
+    const int64_t* t_q_dev;
+    const float* gathered;
+    uint8_t* elide_mask_out;
+    qs_stream_t stream;
+} qs_pq_select_args;
+int qs_pq_select_v(const qs_pq_select_args* args);
+
 /* ---- data-parallel statistics exchange (no counterpart in the reference, whose masks and scales drift per rank) -- */
 
 /* record[0..C) = f32(stage[i]) (0 when stage == NULL), record[C..2C) = absmax[i * absmax_stride] (0 when NULL):
@@ -490,6 +550,22 @@ int qs_site_fwd(const qs_site_plan* plan, const void* x, void* y, uint8_t* gate_
                 int64_t t_q, void* image_out, int imgdt, const float* gathered, int world, void* xback_out, float* decimal,
                 qs_stream_t stream);
 
+/* (ABI v25) qs_site_fwd with its per-call operands in a descriptor */
+typedef struct qs_site_fwd_args {
+    uint32_t struct_size;        /* sizeof(qs_site_fwd_args) as the caller compiled it */
+    int32_t flags, imgdt, world;
+    const void* x;
+    void* y;
+    uint8_t* gate_out;
+    int64_t t_mag, k, t_q;
+    void* image_out;
+    const float* gathered;
+    void* xback_out;
+    float* decimal;
+    qs_stream_t stream;
+} qs_site_fwd_args;
+int qs_site_fwd_v(const qs_site_plan* plan, const qs_site_fwd_args* args);
+
 /* The statistics half of a live qs_site_fwd on its own -- qs_mean_dim | qs_mean_dim_cl, then qs_mean_last2, which also writes
  * this rank's exchange record (record: device float[2*C] = importance | per-channel abs-max, qs_stats_pack's layout) -- for a
  * data-parallel step: the caller all-gathers the records of all ranks (RCCL / any transport) and passes them to
@@ -542,6 +618,24 @@ int qs_site_bwd_v(const qs_site_plan* plan, const qs_site_bwd_args* args);
 int qs_quantize_step(const void* x, void* y, uint8_t* gate_out, float* amax_lines, int lines, float* scale, int64_t numel,
                      int xdt, int ydt, int bits, int64_t t, int64_t* t_dev, int32_t* n_updates, int pre_relu, int update,
                      int saturate, int32_t code_lo, int32_t code_hi, void* xback_out, void* image_out, int imgdt, qs_stream_t stream);
+
+/* (ABI v25) qs_quantize_step with its operands in a descriptor */
+typedef struct qs_quantize_step_args {
+    uint32_t struct_size;        /* sizeof(qs_quantize_step_args) as the caller compiled it */
+    int32_t lines, xdt, ydt, bits, pre_relu, update, saturate, code_lo, code_hi, imgdt;
+    const void* x;
+    void* y;
+    uint8_t* gate_out;
+    float* amax_lines;
+    float* scale;
+    int64_t numel, t;
+    int64_t* t_dev;
+    int32_t* n_updates;
+    void* xback_out;
+    void* image_out;
+    qs_stream_t stream;
+} qs_quantize_step_args;
+int qs_quantize_step_v(const qs_quantize_step_args* args);
 
 /* ---- multi-tensor weight path ---------------------------------------------------------------------- */
 

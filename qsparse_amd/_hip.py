@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 25          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against
+ABI_VERSION = 25          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against: the version it NEEDS
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -35,6 +35,11 @@ def lib_path() -> str:
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "qs_version": (c_int, []),
+    "qs_abi_floor": (c_int, []),
+    "qs_quant_fwd_v": (c_int, [_P]),
+    "qs_pq_select_v": (c_int, [_P]),
+    "qs_site_fwd_v": (c_int, [_P, _P]),
+    "qs_quantize_step_v": (c_int, [_P]),
     "qs_status_string": (c_char_p, [_I]),
     "qs_workspace_bytes": (c_size_t, [_I, _L]),
     "qs_quant_scaler_fwd": (c_int, [_P, _P, _P, _P, _L, _F, _P, _L, _L, _L, _I, _I, _I, _I, c_int32, c_int32, _I, _I, _P, _P, _I, _P, _P]),
@@ -101,6 +106,41 @@ class SitePlanStruct(ctypes.Structure):
                 ("quantizer_t_dev", c_void_p), ("callback_t_from_device", c_int32),
                 ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("act", c_int32),
                 ("elide_mask", c_void_p), ("absmax_dense", c_void_p), ("reduce_ws", c_void_p), ("reduce_ws_bytes", c_int64)]
+
+
+class QuantFwdArgs(ctypes.Structure):
+    """`qs_quant_fwd_args` of include/qsparse_hip.h"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("kind", c_int32), ("x", c_void_p), ("y", c_void_p), ("codes", c_void_p),
+                ("param", c_void_p), ("nparam", c_int64), ("param_host", c_float), ("xdt", c_int32), ("ydt", c_int32), ("qdt", c_int32),
+                ("chan_mask", c_void_p), ("outer", c_int64), ("C", c_int64), ("inner", c_int64),
+                ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32), ("pre_relu", c_int32), ("elide_masked", c_int32),
+                ("imgdt", c_int32), ("gate_out", c_void_p), ("image_out", c_void_p), ("xback_out", c_void_p), ("stream", c_void_p)]
+
+
+class PqSelectArgs(ctypes.Structure):
+    """`qs_pq_select_args` of include/qsparse_hip.h"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("sdt", c_int32), ("stat_dt", c_int32), ("bits", c_int32), ("world", c_int32),
+                ("update_magnitude", c_int32), ("refresh_mask", c_int32), ("update_scale", c_int32),
+                ("magnitude", c_void_p), ("stage_mean", c_void_p), ("C", c_int64), ("t_mag", c_int64), ("k", c_int64), ("t_q", c_int64),
+                ("mask", c_void_p), ("chan_absmax", c_void_p), ("chan_absmax_stride", c_int64), ("scale", c_void_p),
+                ("bump_i32_a", c_void_p), ("bump_i32_b", c_void_p), ("bump_i64_a", c_void_p), ("bump_i64_b", c_void_p),
+                ("t_mag_dev", c_void_p), ("t_q_dev", c_void_p), ("gathered", c_void_p), ("elide_mask_out", c_void_p), ("stream", c_void_p)]
+
+
+class SiteFwdArgs(ctypes.Structure):
+    """`qs_site_fwd_args` of include/qsparse_hip.h"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", c_int32), ("imgdt", c_int32), ("world", c_int32),
+                ("x", c_void_p), ("y", c_void_p), ("gate_out", c_void_p), ("t_mag", c_int64), ("k", c_int64), ("t_q", c_int64),
+                ("image_out", c_void_p), ("gathered", c_void_p), ("xback_out", c_void_p), ("decimal", c_void_p), ("stream", c_void_p)]
+
+
+class QuantizeStepArgs(ctypes.Structure):
+    """`qs_quantize_step_args` of include/qsparse_hip.h"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("lines", c_int32), ("xdt", c_int32), ("ydt", c_int32), ("bits", c_int32),
+                ("pre_relu", c_int32), ("update", c_int32), ("saturate", c_int32), ("code_lo", c_int32), ("code_hi", c_int32),
+                ("imgdt", c_int32), ("x", c_void_p), ("y", c_void_p), ("gate_out", c_void_p), ("amax_lines", c_void_p), ("scale", c_void_p),
+                ("numel", c_int64), ("t", c_int64), ("t_dev", c_void_p), ("n_updates", c_void_p), ("xback_out", c_void_p),
+                ("image_out", c_void_p), ("stream", c_void_p)]
 
 
 class SiteBwdArgs(ctypes.Structure):
@@ -236,19 +276,34 @@ def load(path: Optional[str] = None):
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). GPU tensors cannot be processed without it.")
     lib = ctypes.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here == ABI mismatch
-        fn.restype, fn.argtypes = res, args
-    # same symbol names with different argument lists across ABI versions: a stale library would be called with shifted
-    # arguments (ints in pointer slots), so the version is part of loading, not of the tests
+    # Up to v24 symbol names kept their names while their argument lists changed: a stale library would be called with shifted
+    # arguments (ints in pointer slots), so the version is part of loading, not of the tests.  From v25 on the positional
+    # prototypes are frozen and new operands arrive through size-prefixed descriptors (include/qsparse_hip.h, "ABI
+    # compatibility"): ANY library that still honours the prototypes of the version this binding was written against and is at
+    # least that new will do -- qs_abi_floor() <= ABI_VERSION <= qs_version().
+    lib.qs_version.restype, lib.qs_version.argtypes = c_int, []
     found = lib.qs_version()
-    if found != ABI_VERSION:
+    floor = found
+    if hasattr(lib, "qs_abi_floor"):
+        lib.qs_abi_floor.restype, lib.qs_abi_floor.argtypes = c_int, []
+        floor = lib.qs_abi_floor()
+    if not abi_compatible(found, floor):
         raise QsparseHipError(
-            f"{p} is ABI v{found}, this package needs v{ABI_VERSION}: rebuild it with "
+            f"{p} is ABI v{found} (prototypes frozen since v{floor}), this package needs v{ABI_VERSION}: rebuild it with "
             "`python -c 'import __graft_entry__ as g; g.build()'`")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == a symbol this binding needs is missing
+        fn.restype, fn.argtypes = res, args
     if path is None:
         _lib = lib
     return lib
+
+
+def abi_compatible(found: int, floor: int, needed: Optional[int] = None) -> bool:
+    """whether a library reporting `qs_version() == found` and `qs_abi_floor() == floor` serves a binding written against ABI
+    `needed`: new enough to have every symbol and field the binding uses, and still honouring that version's prototypes"""
+    needed = ABI_VERSION if needed is None else needed
+    return floor <= needed <= found
 
 
 def available() -> bool:
