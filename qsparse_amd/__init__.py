@@ -19,4 +19,7 @@ from qsparse_amd.util import (auto_name_prune_quantize_layers, calculate_mask_gi
 from qsparse_amd.util import get_option as get_qsparse_option
 from qsparse_amd.util import set_options as set_qsparse_options
 
+from qsparse_amd.util import PINNED_TORCH, check_torch_pin
+
 __version__ = "2.0.1+mi355x.1"
+check_torch_pin()      # warns once under a torch other than the one the staged means' summation order was taken from

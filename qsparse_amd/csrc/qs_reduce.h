@@ -1,5 +1,10 @@
 // Reductions: abs-max / min-max statistics, staged means in ATen's CPU summation order, k-th order
 // statistic (radix select) and the C-sized "select" step of the fused prune->quantize pair.
+//
+// SUMMATION-ORDER PIN: the staged-mean kernels restate SumKernel.cpp's order (cascade / 4-way row-sum / vectorised inner sum, one
+// intra-op thread) as torch 2.10 computes it -- the version recorded in the golden fixtures' meta (tests/golden/*.npz).  A torch
+// upgrade that changes that order moves the target of every `mean_*` kernel in this file: tests/test_aten_contract.py (CPU) and
+// tests/test_aten_contract_gpu.py (`-m gpu`) detect it, qsparse_amd.util.check_torch_pin warns at import.
 #pragma once
 #include "qs_common.h"
 

@@ -71,7 +71,8 @@ _ARMED = "_qs_accumulators_armed"
 #   image / second_image   an autocast consumer took a site's first / second image
 #   grad_image             a promoting add's backward used the gradient image the consuming site's backward kernel wrote
 #   grad_image_cast        ... or had to cast (another consumer of the sum contributed, or the site took a route without the rider)
-#   image_disarmed         a site stopped making images because nobody took the last one (re-armed when the options change)
+#   image_disarmed         a site stopped making images because nobody took the last one
+#   image_rearmed          ... and offered one again (after REARM_EVERY steps, or when an option changed)
 ROUTES = __import__("collections").Counter()
 
 
@@ -181,12 +182,13 @@ class _FusedApply(torch.autograd.Function):
 class _SitePlan:
     """`qs_site_plan` of one site and input signature plus what keeps its pointers alive"""
     __slots__ = ("key", "c", "ref", "keep", "out_dtype", "channels_last", "xdt", "image_ok", "image_made", "image_used", "image_fused",
-                 "xbuf", "widen_nomask", "decimal", "cd", "interleaved")
+                 "xbuf", "widen_nomask", "decimal", "cd", "interleaved", "idle", "epoch")
 
     def __init__(self):
         self.key = None
         self.xbuf = None
         self.image_ok, self.image_made, self.image_used, self.image_fused = True, False, False, False
+        self.idle, self.epoch = 0, 0
 
     def __deepcopy__(self, memo):        # a cache of raw pointers never travels: copies and pickles rebuild their own
         return _SitePlan()
@@ -591,16 +593,36 @@ def _as_dual(y, img, plan, slots=None, img_b=None):
 class ImageStat:
     """bookkeeping of a maker of images that is not a `_SitePlan` (a lone quantizer behind its activation): whether the last image
     was taken, whether to keep making them"""
-    __slots__ = ("image_ok", "image_made", "image_used")
+    __slots__ = ("image_ok", "image_made", "image_used", "idle", "epoch")
 
     def __init__(self):
         self.image_ok, self.image_made, self.image_used = True, False, False
+        self.idle, self.epoch = 0, 0
 
     def __deepcopy__(self, memo):
         return ImageStat()
 
     def __reduce__(self):
         return (ImageStat, ())
+
+
+REARM_EVERY = 1024      # steps after which a maker whose image nobody took offers one again
+
+
+def image_bookkeeping(stat):
+    """once per step of an image maker (a `_SitePlan` / `ImageStat`), before it decides whether to make one: an image nobody took
+    (the consumer is not an autocast matmul / convolution -- or a hook touched the output first, or an evaluation pass fed another
+    consumer) stops the making; it is offered again after REARM_EVERY steps or as soon as an option changes (the options epoch), so
+    ONE odd forward cannot bring the 2 x 6 B/elem cast passes back for the rest of the process.  `ROUTES` counts both."""
+    if stat.image_made and not stat.image_used:
+        stat.image_ok, stat.idle, stat.epoch = False, 0, _options_epoch[0]
+        ROUTES["image_disarmed"] += 1
+    elif not stat.image_ok:
+        stat.idle += 1
+        if stat.idle >= REARM_EVERY or stat.epoch != _options_epoch[0]:
+            stat.image_ok = True
+            ROUTES["image_rearmed"] += 1
+    stat.image_made = stat.image_used = False
 
 
 def autocast_image_dtype():
@@ -929,10 +951,7 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         flags = ((_hip.SITE_LIVE if (live or frozen) else 0) | (_hip.SITE_SCALE_ONLY if frozen else 0)
                  | (_hip.SITE_REFRESH if refresh else 0) | (_hip.SITE_PRE_RELU if pre_relu else 0)
                  | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0) | (0 if prune_on else _hip.SITE_NO_MASK))
-        if site.image_made and not site.image_used:
-            site.image_ok = False        # nobody took the last image (the consumer is not an autocast matmul / convolution): stop making them
-            ROUTES["image_disarmed"] += 1
-        site.image_made = site.image_used = False
+        image_bookkeeping(site)
         image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
         if site_gathered is not None:
             flags |= _hip.SITE_STATS_DONE
@@ -1218,10 +1237,7 @@ class _FastPair:
             q._steps.note_device_add(state[4], 1)
             flags = (_hip.SITE_LIVE | (0 if live else _hip.SITE_SCALE_ONLY) | (_hip.SITE_REFRESH if refresh else 0)
                      | (_hip.SITE_PRE_RELU if pre_relu else 0) | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0))
-            if plan.image_made and not plan.image_used:
-                plan.image_ok = False        # nobody took the last image: stop making them (as the full path)
-                ROUTES["image_disarmed"] += 1
-            plan.image_made = plan.image_used = False
+            image_bookkeeping(plan)
             image_dtype = _image_dtype(plan, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
             out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1,
                                   grad_image_cell(h))

@@ -707,9 +707,7 @@ class QuantizeLayer(nn.Module):
             stat = self.__dict__.get("_qs_image_stat")
             if stat is None:
                 stat = self.__dict__["_qs_image_stat"] = fused.ImageStat()
-            if stat.image_made and not stat.image_used:
-                stat.image_ok = False           # nobody took the last image (no autocast matmul behind this site): stop making them
-            stat.image_made = stat.image_used = False
+            fused.image_bookkeeping(stat)       # (nobody took the last image -- no autocast matmul behind this site: stop making them)
             if stat.image_ok and (not (torch.is_grad_enabled() and x.requires_grad) or get_option("relu_gate")):
                 image_dtype = fused.autocast_image_dtype()
         y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,

@@ -19,6 +19,28 @@ _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics"
 _options_epoch = [0]       # bumped by every set_options call: cached per-site decisions that depend on an option are keyed on it
 
 
+# The staged-mean kernels (csrc/qs_reduce.h) reproduce the summation ORDER of ATen's CPU SumKernel.cpp with one intra-op thread --
+# cascade / 4-way row-sum / vectorised inner sum, chosen per output by TensorIterator's dimension order (`aten_reduce_plan`) -- as
+# torch PINNED_TORCH computes it: that is the version the reference was run under when the golden fixtures were recorded
+# (tests/golden/*.npz, meta["torch"]) and the one the bit-for-bit claims of DESIGN section 5 hold for.  Another torch may sum in
+# another order: results stay within north_star's 1e-6 but masks can differ in a tie; tests/test_aten_contract*.py tell.
+PINNED_TORCH = "2.10"
+_torch_pin_warned = False
+
+
+def check_torch_pin(version: Optional[str] = None) -> bool:
+    """True when `version` (default: the running torch) is the pinned minor version; warns ONCE otherwise"""
+    global _torch_pin_warned
+    version = version or torch.__version__
+    ok = ".".join(version.split("+")[0].split(".")[:2]) == PINNED_TORCH
+    if not ok and not _torch_pin_warned:
+        _torch_pin_warned = True
+        import warnings
+        warnings.warn(f"qsparse_amd: torch {version} is not the version ({PINNED_TORCH}) whose CPU summation order the staged-mean "
+                      "kernels reproduce bit for bit; run tests/test_aten_contract.py (CPU) to see whether the order moved", stacklevel=2)
+    return ok
+
+
 def set_options(log_on_created: Optional[bool] = None, log_during_train: Optional[bool] = None,
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,

@@ -75,6 +75,9 @@ def put(store, key, t):
 
 def save(name, store, meta):
     store = dict(store)
+    # the torch whose ATen produced these bits: the staged means follow THAT version's summation order (SumKernel.cpp), which the
+    # HIP kernels reproduce -- qsparse_amd warns at import when it runs under another one (`PINNED_TORCH`)
+    meta = dict(meta, torch=torch.__version__, intra_op_threads=torch.get_num_threads())
     store["meta"] = np.array(json.dumps(meta))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **store)

@@ -204,3 +204,32 @@ def test_aten_reduce_plan_names_the_order_aten_takes_for_any_dense_layout():
         assert not _dense_any_order(torch.zeros(4, 6)[:, ::2]) and not _dense_any_order(torch.zeros(4, 1).expand(4, 3))
     finally:
         torch.set_num_threads(threads)
+
+
+def test_fixtures_record_the_torch_they_were_generated_with_and_it_is_the_pinned_one():
+    """the golden fixtures carry `meta["torch"]` / `meta["intra_op_threads"]`, the package pins the same minor
+    version (`PINNED_TORCH`, stated in include/qsparse_hip.h and csrc/qs_reduce.h) and warns once under another"""
+    import glob
+    import json
+    import warnings
+
+    import qsparse_amd as qs
+    from qsparse_amd import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tests", "golden", "*.npz")))
+    assert len(files) >= 16
+    for f in files:
+        meta = json.loads(str(np.load(f)["meta"]))
+        assert ".".join(meta["torch"].split("+")[0].split(".")[:2]) == qs.PINNED_TORCH, f
+        assert meta["intra_op_threads"] == 1, f
+    assert f"torch {qs.PINNED_TORCH}" in open(os.path.join(root, "include", "qsparse_hip.h")).read()
+    assert f"torch {qs.PINNED_TORCH}" in open(os.path.join(root, "qsparse_amd", "csrc", "qs_reduce.h")).read()
+    util._torch_pin_warned = False
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert util.check_torch_pin("2.12.1+rocm9") is False and util.check_torch_pin("2.12.1+rocm9") is False
+        assert len(w) == 1 and "summation order" in str(w[0].message)
+        assert util.check_torch_pin(qs.PINNED_TORCH + ".0") is True
+    finally:
+        util._torch_pin_warned = False

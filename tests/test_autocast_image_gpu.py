@@ -762,3 +762,39 @@ def test_second_image_is_dropped_when_anything_touches_the_output_in_between():
             qs.set_qsparse_options(autocast_image=True)
     for a, b in zip(*runs):
         assert same(a.cpu(), b.cpu())
+
+
+def test_a_site_whose_image_nobody_took_offers_it_again(monkeypatch):
+    """one forward whose consumer is not an autocast matmul (an evaluation pass into a pooling layer, a hook that touched
+    the output first) used to switch the image off for the rest of the process; now the site offers it again after REARM_EVERY steps
+    or as soon as an option changes"""
+    from qsparse_amd import fused
+    from qsparse_amd.fused import ROUTES
+    monkeypatch.setattr(fused, "REARM_EVERY", 3)
+    site = fuse_prune_quantize_pairs(nn.Sequential(
+        nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
+        qs.quantize(bits=4, channelwise=-1, timeout=1))).to(DEV).train()
+    conv = nn.Conv2d(16, 8, 1, bias=False).to(DEV)
+
+    def step(use_conv):
+        x = (torch.randn(4, 16, 8, 8, generator=gen(1)) * 2).to(DEV).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = site(x)
+            out = conv(y).float().sum() if use_conv else (y * 2.0).sum()
+        out.backward()
+        return type(y)
+
+    for _ in range(4):
+        assert step(True) in (torch.Tensor, AutocastImageTensor)
+    assert step(True) is AutocastImageTensor
+    before = dict(ROUTES)
+    assert step(False) is AutocastImageTensor              # made, not taken ...
+    assert step(True) is torch.Tensor                       # ... so the next step makes none
+    assert ROUTES["image_disarmed"] == before.get("image_disarmed", 0) + 1
+    kinds = [step(True) for _ in range(5)]
+    assert AutocastImageTensor in kinds                    # offered again after REARM_EVERY steps -- and taken: it stays
+    assert kinds[-1] is AutocastImageTensor and ROUTES["image_rearmed"] == before.get("image_rearmed", 0) + 1
+    assert step(False) is AutocastImageTensor
+    assert step(True) is torch.Tensor
+    qs.set_qsparse_options(relu_gate=True)                 # any option change re-arms at once
+    assert step(True) is AutocastImageTensor
