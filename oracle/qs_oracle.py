@@ -173,6 +173,9 @@ def adaptive_lines(x: torch.Tensor, channel_index: int = -1, batched: bool = Fal
     if channel_index >= 0:
         if batched:
             if channel_index != 1:
+                # (:399-401 `.view` the transposed tensor: a RuntimeError for every batch of more than one sample -- restated on a
+                #  contiguous stand-in so that the verdict does not depend on the layout x happens to have)
+                torch.empty(tuple(x.shape), device="meta").transpose(1, channel_index).view(-1, math.prod(tuple(x.transpose(1, channel_index).shape)[2:]))
                 x = x.transpose(1, channel_index)
             shape = tuple(x.shape)
             x = x.reshape(-1, math.prod(shape[2:]))

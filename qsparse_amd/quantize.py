@@ -520,6 +520,13 @@ class AdaptiveQuantizer(DecimalQuantizer):
 
     def optimize(self, x, bits, weight=None, channel_index=-1, batched=False, **kwargs):
         with torch.no_grad():
+            if batched and channel_index >= 0 and channel_index != 1:
+                # reference quantize.py:398-401: the channel dim is transposed next to the batch dim and the result is `.view`ed as
+                # rows -- which raises for every batch of more than one sample (an ARGUMENT error: it fails for the contiguous tensor
+                # too, like the batched channel-wise Scaler of :341-343; layouts the reference cannot `.view`, e.g. channels_last,
+                # are a different matter and are served).  The same call on a meta tensor of x's shape raises the same error.
+                probe = torch.empty(tuple(x.shape), device="meta", dtype=x.dtype).transpose(1, channel_index)
+                probe.view(-1, math.prod(tuple(probe.shape)[2:]))
             if _hip.on_hip(x):
                 # nothing to exchange between the reduction and the update (one process, or a weight): ONE reduction launch
                 # into persistent key buffers, which the running-mean launch converts and resets -- two launches instead of

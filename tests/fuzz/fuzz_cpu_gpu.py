@@ -92,8 +92,10 @@ def build_token_major(rng):
     cw = rng.choice([-1, -1, -1, last])
     if site == "pair":
         cw = -1 if rng.random() < 0.8 else cw
-    if cw >= 0 and kind != "adaptive":
-        shape = (1,) + shape[1:]             # batched channel-wise Scaler / Decimal raises in the reference
+    if cw >= 0 and (kind != "adaptive" or rng.random() < 0.7):
+        # batched channel-wise Scaler / Decimal raises in the reference (quantize.py:341-343), and so does the Adaptive quantizer on
+        # a channel dim other than 1 (:398-401 `.view` a transposed tensor): mostly a batch of one; the rest must raise alike
+        shape = (1,) + shape[1:]
     policy = rng.choice(["default", "default", "no_avg", "refresh", "l0"])
     cbkw = {"default": {}, "no_avg": dict(running_average=False), "refresh": dict(mask_refresh_interval=2, stop_mask_refresh=4),
             "l0": dict(l0=True)}[policy]

@@ -188,7 +188,8 @@ QUANTS = [
     ("adaptive", (4, 9, 40), torch.float16, -1, "identity"),
     ("scaler", (1, 12, 24), torch.bfloat16, 2, "identity"),          # last-dim channel-wise: batch of one (B > 1 raises, below)
     ("decimal", (1, 12, 24), torch.float32, 2, "relu"),
-    ("adaptive", (4, 9, 40), torch.bfloat16, 2, "identity"),         # the adaptive quantizer takes a batch
+    ("adaptive", (1, 9, 40), torch.bfloat16, 2, "identity"),
+    ("adaptive", (4, 9, 40), torch.bfloat16, 1, "relu"),             # (B, C, L): the adaptive quantizer takes a batch on channel dim 1
     ("scaler", (1, 9, 40), torch.float16, 1, "identity"),
     ("scaler", (2, 8, 3, 5, 6), torch.bfloat16, -1, "relu"),
     ("scaler", (64, 197, 768), torch.bfloat16, -1, "gelu"),
@@ -228,6 +229,22 @@ def test_batched_last_dim_channelwise_scaler_raises_like_the_reference():
     q(x)
     with pytest.raises(RuntimeError):
         q(x)
+
+
+def test_batched_last_dim_channelwise_adaptive_raises_like_the_reference():
+    """quantize.py:398-401: the batched channel-wise Adaptive statistics transpose the channel dim next to the batch and `.view` the
+    result -- a RuntimeError for every channel dim other than 1 once the batch has more than one sample (an argument error: it
+    fails for the contiguous tensor), reproduced on both devices; a batch of one is served"""
+    for dev in ("cpu", "cuda"):
+        q = qs.quantize(bits=4, timeout=1, channelwise=2, callback=qs.AdaptiveQuantizer()).to(dev).train()
+        x = torch.randn(4, 6, 8, device=dev)
+        q(x)
+        with pytest.raises(RuntimeError, match="view size is not compatible"):
+            q(x)
+        q1 = qs.quantize(bits=4, timeout=1, channelwise=2, callback=qs.AdaptiveQuantizer()).to(dev).train()
+        x1 = torch.randn(1, 6, 8, device=dev)
+        q1(x1)
+        assert q1(x1).shape == x1.shape
 
 
 def test_token_major_site_through_convert_cpu_path_equals_hip_path():
