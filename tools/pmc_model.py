@@ -4,8 +4,8 @@ statistics kernels had no counters, their traffic ratio was asserted, not measur
 
     python3 tools/pmc_model.py <tag> <arch> <batch> [steps]      ->  gpurun_out/profiles/<tag>_pmc_model.json / .txt
 
-Two rocprofv3 passes over tools/profile_config.py, one counter each (FETCH_SIZE, WRITE_SIZE -- never combined with another trace
-domain), the last `steps` steady-state steps of each.  Bytes per kernel = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024: on gfx950
+Two rocprofv3 passes over tools/profile_config.py, one counter each (FETCH_SIZE, WRITE_SIZE; `--kernel-trace` is the only
+trace domain next to `--pmc`, the combination the pool's gpurun permits), the last `steps` steady-state steps of each.  Bytes per kernel = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024: on gfx950
 FETCH_SIZE tallies a wide coalesced streaming read (16 bytes per lane, what every kernel here issues) at half its bytes
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section; checked on the headline statistics kernel's known input in
 profiles/rNN_pmc_traffic.json).  Set against the algorithmic bytes of the step's kernel families (every data operand of a launch
