@@ -4,7 +4,7 @@
 # kernels): CPU path vs HIP path of modules (NaN / Inf / -Inf in 30 % of the cases), of converted weight networks, of the functional
 # API; sites vs the oracle's state machines; the same with the statistics exchange live on a one-rank RCCL group; with steady-state
 # steps replayed from a hipGraph; the autocast image route against the plain route under torch.autocast.
-tag=${1:-r05}; scale=${2:-1}
+tag=${1:-r06}; scale=${2:-1}
 out=gpurun_out/profiles; mkdir -p $out
 sha=$(cat .tree_sha 2>/dev/null || echo unknown)
 run() {  # name, env..., -- command
@@ -16,6 +16,7 @@ run() {  # name, env..., -- command
 }
 run cpu_gpu_4242      QS_X=1 python3 tests/fuzz/fuzz_cpu_gpu.py $((3000*scale)) 4242
 run cpu_gpu_7         QS_X=1 python3 tests/fuzz/fuzz_cpu_gpu.py $((3000*scale)) 7
+run token_major       QS_FUZZ_WHAT=tok python3 tests/fuzz/fuzz_cpu_gpu.py $((2000*scale)) 17
 run nets              QS_FUZZ_WHAT=net python3 tests/fuzz/fuzz_cpu_gpu.py $((2000*scale)) 11
 run functional        QS_FUZZ_MODE=functional python3 tests/fuzz/fuzz_cpu_gpu.py $((4000*scale)) 12
 run oracle_sites      QS_X=1 python3 tests/fuzz/fuzz_parity.py $((2000*scale)) 13
