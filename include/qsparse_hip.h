@@ -295,7 +295,7 @@ int qs_decimal_from_scale(const float* scale, float* decimal, int64_t n, qs_stre
 /* SUMMATION-ORDER PIN.  The staged-mean entry points below (qs_mean_dim, qs_mean_dim_split, qs_mean_dim_cl, qs_mean_cl_w,
  * qs_mean_strided, qs_mean_last2, qs_multi_stage_mean) restate the summation order of ATen's CPU SumKernel.cpp with ONE intra-op
  * thread as torch 2.10 computes it -- the version the reference ran under when the golden fixtures were recorded
- * (tests/golden/*.npz: meta["torch"], meta["intra_op_threads"]).  The host package warns once at import under another torch
+ * (the .npz files under tests/golden: meta["torch"], meta["intra_op_threads"]).  The host package warns once at import under another torch
  * (qsparse_amd.util.PINNED_TORCH / check_torch_pin); tests/test_aten_contract.py (CPU) and tests/test_aten_contract_gpu.py (the
  * same probes in the `-m gpu` set) detect a moved order. */
 

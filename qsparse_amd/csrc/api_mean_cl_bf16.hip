@@ -1,0 +1,4 @@
+// libqsparse_hip.so -- the channels_last staged-mean kernels for bf16 inputs (qs_mean_cl_host.h; entry points: api_mean_cl.hip)
+#include "qs_mean_cl_host.h"
+
+QS_MEAN_CL_DTYPE_UNIT(bf16, QS_BF16)

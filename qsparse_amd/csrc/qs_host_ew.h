@@ -118,3 +118,23 @@ int check_param(const float* p, int64_t nparam, int64_t C) {
 }
 
 }  // namespace
+
+namespace {
+// (shared by the forward units api_quant_fwd.hip / api_quant_fwd2.hip)
+// the image of a quantizer's float32 output is written by the gate-recording widening kernels only (ew_widen_kernel<GateOp<..>>):
+// float32 output, no codes, a gate bitmap, and a geometry those kernels serve (launch_ew_impl's own conditions)
+// (the same kernels write relu(x) back: xback_out)
+inline bool widen_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
+                    const uint8_t* gate_out, int xdt, int ydt) {
+    if (!gate_out || codes || ydt != QS_F32) return false;
+    EwPlan plan;
+    if (plan_ew(outer, C, inner, ppc || chan_mask != nullptr, &plan, !ppc && aligned8(chan_mask)) != QS_OK) return false;
+    const int cm_w = (plan.cm == CM_ELEM && plan.geo.inner % 4 == 0) ? CM_ROW : plan.cm;
+    return ew_widen() >= (xdt == QS_F32 ? 2 : 1) && cm_w != CM_ELEM;
+}
+inline bool image_route_ok(int64_t outer, int64_t C, int64_t inner, bool ppc, const uint8_t* chan_mask, const int32_t* codes,
+                    const uint8_t* gate_out, int xdt, int ydt, int imgdt, const void* image_out) {
+    if ((imgdt != QS_BF16 && imgdt != QS_F16) || !aligned16(image_out)) return false;
+    return widen_route_ok(outer, C, inner, ppc, chan_mask, codes, gate_out, xdt, ydt);
+}
+}  // namespace

@@ -26,6 +26,14 @@ from golden_io import same
 from qsparse_amd.fused import AutocastImageTensor
 
 DEV = "cuda"
+# MIOpen is asked for deterministic algorithms and the consumers' weight gradients are compared bit for bit like everything else
+# (QS_FUZZ_STRICT_GW=0: MIOpen's default algorithms, whose fp16 weight-gradient kernels are not run-to-run deterministic -- the
+#  weight gradients are then held to a bound relative to their largest entry; round 6: every mismatch seen under that setting
+#  disappeared under this one, 3,000 cases)
+STRICT_GW = os.environ.get("QS_FUZZ_STRICT_GW", "1") == "1"
+if STRICT_GW:
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
 USED = [0]          # cases in which an image was really handed to a consumer
 
 
@@ -214,7 +222,7 @@ def one_case(rng, idx):
     if len(ta) != len(tb) or len(oa) != len(ob):
         return dict(d, mismatch="number of outputs / hook calls")
     for i, ((ka_, va), (kb_, vb)) in enumerate(zip(ta, tb)):
-        if ka_ == kb_ == "gw" and va is not None and vb is not None:
+        if ka_ == kb_ == "gw" and va is not None and vb is not None and not STRICT_GW:
             # the CONSUMER's weight gradient: MIOpen's fp16 weight-gradient kernels are not run-to-run deterministic (two runs of
             # the plain route differ as well) -- the operands it gets are compared bit for bit through `out` and `gx`
             # (... and where large terms cancel, one fp16 ulp of a partial sum is large against the element itself: the bound is

@@ -1,6 +1,6 @@
 #!/bin/bash
 # builds tuning variants of libqsparse_hip.so into build_variants/ (development tool); every variant goes through
-# __graft_entry__.build_hip (the seven translation units in parallel, objects cached under build/hip/<variant>)
+# __graft_entry__.build_hip (the translation units in parallel, objects cached under build/hip/<variant>)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_variants
