@@ -776,10 +776,13 @@ def ste_bwd(g: torch.Tensor, step, step_is_decimal: bool, channel_index: int, lo
 
 def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
                  chan_mask: Optional[torch.Tensor], mask_channel_index: int = 1, gate: Optional[ReluGate] = None,
-                 g2: Optional[torch.Tensor] = None, act=1):
+                 g2: Optional[torch.Tensor] = None, act=1, g3: Optional[torch.Tensor] = None,
+                 gx_image_dtype: Optional[torch.dtype] = None):
     """gx = (x <= 0 ? 0 : clamp(g) * mask) in x's dtype: STE backward + channel mask + folded-ReLU gate.  With `gate` (the
     bitmap `quant_fwd(want_gate=True)` recorded) x is not needed.  `g2` (with `gate`; bf16 / fp16): a second gradient that
-    is added to the float32 `g` in float32 before the clamp; `g` may then be None."""
+    is added to the float32 `g` in float32 before the clamp; `g` may then be None.
+    The riders of the all-float32 form (with `gate`, a float32 x, through qs_quant_ste_relu_bwd_v): `g3`, a third stream of g2's
+    dtype added between g and g2; `gx_image_dtype`: also write RNE(gx) in that dtype -- the call then returns (gx, image)."""
     lib = load()
     ref = g if g is not None else g2
     pt, n, host = _f32param(step, ref.device)
@@ -801,6 +804,7 @@ def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, ste
 
         gm, ci_mem = as_mem(g)
         g2m, ci2 = as_mem(g2)
+        g3m, _ = as_mem(g3)
         refm = gm if gm is not None else g2m
         ci_mem = ci_mem if gm is not None else ci2
         if gate.channels_last:
@@ -812,6 +816,22 @@ def ste_relu_bwd(g: Optional[torch.Tensor], x: Optional[torch.Tensor], step, ste
         if numel == 0:
             return gx
         cm = _chan_mask_bytes(chan_mask, C)
+        if g3m is not None or gx_image_dtype is not None:
+            assert gate.dtype == torch.float32 and (gm is None or gm.dtype == torch.float32), "the riders belong to the all-float32 form"
+            gimg = torch.empty_like(gx, dtype=gx_image_dtype) if gx_image_dtype is not None else None
+            a = SteReluBwdArgs()
+            a.struct_size = ctypes.sizeof(SteReluBwdArgs)
+            a.gdt, a.xdt, a.g2dt = F32, F32, (0 if g2m is None else dt(g2m))
+            a.g, a.gate, a.gx, a.step, a.nstep, a.step_host = _ptr(gm), _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host
+            a.step_is_decimal, a.lo_mul, a.hi_mul, a.chan_mask = int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm)
+            a.outer, a.C, a.inner, a.elide_masked, a.act = outer, C, inner, 0, _act(act) or 1
+            a.g2, a.stream, a.g3 = _ptr(g2m), _stream(refm), _ptr(g3m)
+            if gimg is not None:
+                a.gx_image, a.gx_image_dt = _ptr(gimg), _DT[gx_image_dtype]
+            with _timed("quant_ste_relu_bwd", gm, g2m, g3m, gate.bits, gx, gimg):
+                st = lib.qs_quant_ste_relu_bwd_v(ctypes.byref(a))
+            _check(st, "qs_quant_ste_relu_bwd_v")
+            return (gx, gimg) if gx_image_dtype is not None else gx
         with _timed("quant_ste_relu_bwd", gm, g2m, gate.bits, gx):
             st = lib.qs_quant_ste_relu_bwd(_ptr(gm), None, _ptr(gate.bits), _ptr(gx), _ptr(pt), n, host,
                                            int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm), outer, C, inner,

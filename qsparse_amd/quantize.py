@@ -569,7 +569,10 @@ class _QuantStep(torch.autograd.Function):
     quantization -- or the quantization alone); backward = the STE clamp, with the gate of a folded ReLU when `pre_relu`"""
 
     @staticmethod
-    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None, image_dtype=None):
+    def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None, image_dtype=None,
+                add_cell=None):
+        # add_cell: of the promoting add that produced x (fused.grad_image_cell), or None
+        ctx.add_cell = add_cell
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
         # an owned nn.ReLU(inplace=True) in front of this quantizer: the apply kernel writes relu(x) back into x itself
@@ -592,29 +595,51 @@ class _QuantStep(torch.autograd.Function):
         ctx.save_for_backward(scale, gate_bits if want_gate else (x if pre_relu else x.new_empty(0)))
         if make_image:
             ctx.set_materialize_grads(False)
-            return y, img
+            return y, img, img.detach()      # (twice: a gradient slot of its own for a second autocast consumer, fused.py "Second image")
         return y
 
     @staticmethod
-    def backward(ctx, g, g16=None):
+    def backward(ctx, g, g16=None, g16b=None):
+        n_in = 14
         override = ctx.__dict__.pop("_qs_override", None)
         if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
-            g, g16 = override[0], None
+            g, g16, g16b = override[0], None, None
+        if g16 is None and g16b is not None:
+            g16, g16b = g16b, None
         if g is None and g16 is None:
-            return (None,) * 13
+            return (None,) * n_in
         scale, second = ctx.saved_tensors
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(second, ctx.x_shape, ctx.x_dtype, ctx.channels_last) if ctx.has_gate else None
+            from qsparse_amd import fused
             if g16 is not None and gate is None:          # (cannot happen: an image is only made with a gate; stay correct anyway)
-                g, g16 = (g16.float() if g is None else g + g16.float()), None
+                g, g16, g16b = fused._whole(g, g16, g16b), None, None
+            # the riders of the all-float32 kernel form: the second consumer's 2-byte share as a third stream, the image of gx for
+            # the promoting add that produced this site's input (fused.py)
+            f32_gated = gate is not None and ctx.x_dtype == torch.float32 and (g is None or g.dtype == torch.float32)
+            if g16b is not None and not (f32_gated and g16 is not None and g16b.dtype == g16.dtype and g16b.shape == g16.shape):
+                g, g16b = (g16b.float() if g is None else g + g16b.float()), None
+            cell = ctx.add_cell if (f32_gated and not _hip.logging_events() and (g is None or g.dtype == torch.float32)) else None
+            kw = {}
+            if g16 is not None:
+                kw["g2"] = g16
+            if g16b is not None:
+                kw["g3"] = g16b
+            if cell is not None:
+                kw["gx_image_dtype"] = cell["dtype"]
             gx = _hip.ste_relu_bwd(g, None if gate is not None else second, scale, False, lo_mul, hi_mul, None, gate=gate,
-                                   act=ctx.pre_relu, **({"g2": g16} if g16 is not None else {}))
+                                   act=ctx.pre_relu, **kw)
+            if cell is not None:
+                gx, gimg = gx
+                cell["gx"], cell["g16"] = gx, gimg
+                if _hip.image_byte_delta is not None:
+                    _hip.image_byte_delta["apply_bwd"] += gimg.numel() * gimg.element_size()
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)
-        return (gx,) + (None,) * 12
+        return (gx,) + (None,) * (n_in - 1)
 
 
 def _callback_hooked(cb: nn.Module) -> bool:
@@ -717,11 +742,15 @@ class QuantizeLayer(nn.Module):
             fused.image_bookkeeping(stat)       # (nobody took the last image -- no autocast matmul behind this site: stop making them)
             if stat.image_ok and (not (torch.is_grad_enabled() and x.requires_grad) or get_option("relu_gate")):
                 image_dtype = fused.autocast_image_dtype()
+        cell = None
+        if pre_relu:
+            from qsparse_amd import fused
+            cell = fused.grad_image_cell(x)
         y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
                              self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
-                             cb.code_range(self.bits), image_dtype)
+                             cb.code_range(self.bits), image_dtype, cell)
         if type(y) is tuple:
-            y = fused._as_dual(y[0], y[1], stat)
+            y = fused._as_dual(y[0], y[1], stat, img_b=y[2])
         self.__dict__["_qs_accumulator_armed"] = False
         if update:
             if t == self.timeout and get_option("log_during_train"):

@@ -666,9 +666,11 @@ class Bottleneckish(nn.Module):
     """a ResNet bottleneck's data flow around two sites: y0 = site0(x) feeds a first convolution, a down-sampling convolution (the
     SECOND autocast consumer) or the residual add (`conv(...) + y0`: bf16 + float32), whose sum is site1's input"""
 
-    def __init__(self, C, down):
+    def __init__(self, C, down, kind="pair"):
         super().__init__()
         def site():
+            if kind == "act_q":          # a quantize-only recipe: convert(model, quantize(...), activation_layers=[nn.ReLU])
+                return fuse_prune_quantize_pairs(nn.Sequential(nn.Sequential(nn.ReLU(), qs.quantize(bits=4, channelwise=-1, timeout=1))))[0]
             return fuse_prune_quantize_pairs(nn.Sequential(
                 nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1, repetition=1)),
                 qs.quantize(bits=4, channelwise=-1, timeout=1)))
@@ -686,9 +688,10 @@ class Bottleneckish(nn.Module):
         return self.head(y1).float().mean((2, 3))
 
 
+@pytest.mark.parametrize("kind", ["pair", "act_q"])
 @pytest.mark.parametrize("down", [False, True])
 @pytest.mark.parametrize("cl", [False, True])
-def test_bottleneck_data_flow_second_image_and_promoting_add_are_value_identical(down, cl):
+def test_bottleneck_data_flow_second_image_and_promoting_add_are_value_identical(down, cl, kind):
     from qsparse_amd.fused import ROUTES
     shape = (6, 16, 8, 8)
     runs = []
@@ -696,7 +699,7 @@ def test_bottleneck_data_flow_second_image_and_promoting_add_are_value_identical
         qs.set_qsparse_options(autocast_image=image)
         before = dict(ROUTES)
         try:
-            net = Bottleneckish(16, down).to(DEV).train()
+            net = Bottleneckish(16, down, kind).to(DEV).train()
             if cl:
                 net = net.to(memory_format=torch.channels_last)
             trace = []
@@ -715,7 +718,7 @@ def test_bottleneck_data_flow_second_image_and_promoting_add_are_value_identical
             qs.set_qsparse_options(autocast_image=True)
     (ta, ra), (tb, rb) = runs
     for i, (a, b) in enumerate(zip(ta, tb)):
-        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), (down, cl, i)
+        assert a.dtype == b.dtype and same(a.cpu(), b.cpu()), (down, cl, kind, i)
     assert not any(ra.get(k) for k in ("image", "second_image", "grad_image")), ra
     if down:
         assert rb.get("second_image", 0) >= 4 and not rb.get("grad_image"), rb      # conv1 took the first image, the down conv the second

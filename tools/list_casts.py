@@ -46,7 +46,12 @@ def main():
     dev = torch.device("cuda", 0)
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     torch.manual_seed(0)
-    if arch == "resnet50":
+    if os.environ.get("QS_RECIPE") == "q":      # the quantize-ONLY recipe: every activation site is Sequential(act, QuantizeLayer)
+        import torch.nn as nn
+        base, shape, classes = (resnet50(1000, False), (batch, 3, 224, 224), 1000) if arch == "resnet50" else (resnet18(10, True), (batch, 3, 32, 32), 10)
+        net = qs.convert(base, qs.quantize(bits=4, channelwise=-1, timeout=1), activation_layers=[nn.ReLU], weight_layers=[nn.Conv2d, nn.Linear],
+                         input=True, log=False)
+    elif arch == "resnet50":
         net, shape, classes = convert_pq(resnet50(1000, False), sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1), (batch, 3, 224, 224), 1000
     else:
         net, shape, classes = convert_pq(resnet18(10, True), sparsity=0.5, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1), (batch, 3, 32, 32), 10
