@@ -44,7 +44,7 @@ def main():
     arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if arch == "resnet50" else 128)
     dev = torch.device("cuda", 0)
-    qs.set_qsparse_options(log_on_created=False, log_during_train=False)
+    qs.set_qsparse_options(log_on_created=False, log_during_train=False, autocast_image=os.environ.get("QS_IMAGE", "1") == "1")
     torch.manual_seed(0)
     if os.environ.get("QS_RECIPE") == "q":      # the quantize-ONLY recipe: every activation site is Sequential(act, QuantizeLayer)
         import torch.nn as nn
@@ -73,6 +73,17 @@ def main():
 
     for _ in range(6):
         step()
+    if os.environ.get("QS_TIME"):            # step time (best of 3 x 10 steps) next to the table
+        import time
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+        print(f"{arch} batch {batch} recipe {os.environ.get('QS_RECIPE', 'pq')} autocast_image={qs.get_qsparse_option('autocast_image')}: {best:.2f} ms per step")
     log = CastLog()
     with log:
         step(log)
