@@ -72,22 +72,25 @@ def _gpu_worker(rank, world, port, out):
     from qsparse_amd.fused import fuse_prune_quantize_pairs
     qs.set_qsparse_options(log_on_created=False, log_during_train=False)
     res = {}
-    # nchw / channels_last: the last statistics launch writes the exchange record itself; 2-d: qs_stats_pack does
-    for layout in ("nchw", "channels_last", "2d"):
+    # nchw / channels_last: the last statistics launch writes the exchange record itself; 2-d and token-major: qs_stats_pack does
+    per = 4 if world <= 2 else 2          # samples per rank (the composite serves batches of at least two)
+    for layout in ("nchw", "channels_last", "2d", "token"):
         for fused in (False, True):
-            pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.5, dimensions={1}, start=1, interval=1,
-                                                                        repetition=2)),
+            pair = nn.Sequential(nn.Sequential(nn.Identity(), qs.prune(sparsity=0.5, dimensions={2 if layout == "token" else 1}, start=1,
+                                                                        interval=1, repetition=2)),
                                  qs.quantize(bits=4, channelwise=-1, timeout=1)).cuda().train()
             if fused:
                 fuse_prune_quantize_pairs(pair)
             for step in range(6):
                 g = torch.Generator().manual_seed(100 + step)
-                full = (torch.randn(8, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16()
-                shard = (full[rank * 4:(rank + 1) * 4].float() * (1.0 + 0.5 * rank)).bfloat16().cuda()
+                full = (torch.randn(world * per, 16, 8, 8, generator=g) * torch.linspace(0.3, 3, 16).view(1, -1, 1, 1)).bfloat16()
+                shard = (full[rank * per:(rank + 1) * per].float() * (1.0 + 0.5 * (rank % 3))).bfloat16().cuda()
                 if layout == "channels_last":
                     shard = shard.contiguous(memory_format=torch.channels_last)
                 elif layout == "2d":
                     shard = shard[:, :, 0, 0].contiguous()
+                elif layout == "token":       # (B, T, C) with the mask on the last dim: qs_site_plan layout 3
+                    shard = shard.flatten(2).transpose(1, 2).contiguous()
                 shard.requires_grad_(True)
                 y = pair(shard)
                 y.backward(torch.ones_like(y))
@@ -110,14 +113,38 @@ def test_fused_pair_exchange_on_gpu_two_ranks():
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    for layout in ("nchw", "channels_last", "2d"):
+    _check_exchange_results(res, 2)
+
+
+def _check_exchange_results(res, world):
+    for layout in ("nchw", "channels_last", "2d", "token"):
         for fused in (False, True):
-            for a, b in zip(res[0][(layout, fused)], res[1][(layout, fused)]):
-                assert np.array_equal(a, b), (layout, fused)      # ranks agree
+            for r in range(1, world):
+                for a, b in zip(res[0][(layout, fused)], res[r][(layout, fused)]):
+                    assert np.array_equal(a, b), (layout, fused, r)      # ranks agree
+            assert 0 < int(res[0][(layout, fused)][0].sum()) < 16        # a real mask
         if layout == "channels_last":
             continue    # (the unfused layers sum a channels_last shard in NCHW order after a copy: 1 ulp apart in bf16)
         for a, b in zip(res[0][(layout, False)], res[0][(layout, True)]):
             assert np.array_equal(a, b), layout                   # fused exchange == unfused exchange
+
+
+@pytest.mark.gpu
+def test_fused_pair_exchange_on_gpu_eight_ranks():
+    """the world size the driver's scaling run ends at: eight processes (here sharing the box's one GPU over gloo) exchange their
+    records every step; the select combines eight records in rank order -- all eight ranks end with the same mask, magnitude and
+    scale, on every layout incl. token-major, through the composite calls and through the fine-grained route"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 8, port, out)) for r in range(8)]
+    for pr in procs:
+        pr.start()
+    res = dict(out.get(timeout=600) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    _check_exchange_results(res, 8)
 
 
 def _ddp_worker(rank, world, port, out):
