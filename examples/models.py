@@ -107,3 +107,40 @@ def convert_pq(model, sparsity=0.75, bits=4, prune_start=2, prune_interval=2, re
     model = qs.convert(model, qs.quantize(bits=bits, channelwise=-1, timeout=quant_timeout), activation_layers=[nn.ReLU],
                        weight_layers=[nn.Conv2d, nn.Linear], input=True, log=log, fuse=fuse)
     return model
+
+
+class TokenBlock(nn.Module):
+    """the MLP half of a transformer encoder block on token-major (B, T, C) activations: LayerNorm -> Linear -> act -> Linear,
+    residual.  One activation module per site."""
+
+    def __init__(self, dim, hidden, act=nn.GELU):
+        super().__init__()
+        self.norm, self.fc1, self.act, self.fc2 = nn.LayerNorm(dim), nn.Linear(dim, hidden), act(), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return x + self.fc2(self.act(self.fc1(self.norm(x))))
+
+
+class TokenNet(nn.Module):
+    """patch embedding (a strided convolution, flattened to tokens) -> `depth` TokenBlocks -> mean over tokens -> classifier"""
+
+    def __init__(self, num_classes=10, dim=64, hidden=128, depth=2, patch=4, act=nn.GELU):
+        super().__init__()
+        self.embed = nn.Conv2d(3, dim, patch, patch)
+        self.blocks = nn.Sequential(*[TokenBlock(dim, hidden, act) for _ in range(depth)])
+        self.norm, self.head = nn.LayerNorm(dim), nn.Linear(dim, num_classes)
+
+    def forward(self, x):
+        t = self.embed(x).flatten(2).transpose(1, 2).contiguous()      # (B, T, C)
+        return self.head(self.norm(self.blocks(t)).mean(1))
+
+
+def convert_pq_tokens(model, act=nn.GELU, sparsity=0.5, bits=4, prune_start=2, prune_interval=2, repetition=2, quant_timeout=1,
+                      log=False, fuse=True):
+    """the --pq recipe on token-major activations: the hidden activations of every block pruned along their LAST dim
+    (`dimensions={2}`: (B, T, hidden) -> hidden channels) and quantized tensor-wise, Linear / Conv2d weights quantized"""
+    model = qs.convert(model, qs.prune(sparsity=sparsity, dimensions={2}, start=prune_start, interval=prune_interval,
+                                       repetition=repetition), activation_layers=[act], log=log, fuse=fuse)
+    model = qs.convert(model, qs.quantize(bits=bits, channelwise=-1, timeout=quant_timeout), activation_layers=[act],
+                       weight_layers=[nn.Conv2d, nn.Linear], log=log, fuse=fuse)
+    return model

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import qsparse_amd as qs
-from examples.models import MnistNet, convert_pq, resnet18, resnet50
+from examples.models import MnistNet, TokenNet, convert_pq, convert_pq_tokens, resnet18, resnet50
 from qsparse_amd.quantize import QuantizeLayer
 from qsparse_amd.sparse import PruneLayer
 
@@ -82,6 +82,34 @@ def test_resnet_pq_fused_equals_unfused_on_gpu(arch):
     masks = [v for k, v in s0.items() if k.endswith(".mask")]
     assert masks and all(abs(m.float().mean().item() - 0.5) < 0.26 for m in masks)
     assert all(torch.isfinite(torch.tensor(l0)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", [nn.GELU, nn.ReLU])
+def test_token_major_network_pq_fused_equals_unfused_on_gpu(act, monkeypatch):
+    """a transformer-style MLP encoder on (B, T, C) activations, hidden activations pruned along the last dim and quantized
+    (reference sparse.py:231-239 builds that mask; convert.py:214-218 the sites): the fused sites -- qs_site_plan layout 3 on the
+    composite calls -- against the same network module by module, whole training trajectories bit for bit (GEMMs are deterministic)"""
+    from qsparse_amd import _hip
+    calls = []
+    real = _hip.site_fwd
+    monkeypatch.setattr(_hip, "site_fwd", lambda plan_ref, *a, **k: (calls.append(plan_ref._obj.layout), real(plan_ref, *a, **k))[1])
+    torch.manual_seed(0)
+    base = TokenNet(num_classes=10, dim=32, hidden=64, depth=2, patch=4, act=act)
+    runs = []
+    for fuse in (False, True):
+        model = convert_pq_tokens(copy.deepcopy(base), act=act, sparsity=0.5, bits=4, prune_start=2, prune_interval=2, repetition=2,
+                                  quant_timeout=3, fuse=fuse).cuda()
+        losses = _train(model, 9, (8, 3, 16, 16), 10, "cuda")
+        runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    assert l0 == l1, (l0, l1)
+    assert s0.keys() == s1.keys()
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    masks = [v for k, v in s1.items() if k.endswith(".mask") and v.numel() > 1]
+    assert len(masks) == 2 and all(m.shape == (1, 1, 64) and 16 <= int(m.sum()) <= 48 for m in masks)
+    assert calls and set(calls) == {3}, calls          # the fused run's sites went through the composite, token-major layout
 
 
 @pytest.mark.gpu

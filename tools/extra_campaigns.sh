@@ -1,3 +1,5 @@
+# Fresh-seed randomised campaigns next to tools/run_campaigns.sh (GPU box, repo root): seeds no earlier round used -> gpurun_out/extra/*.txt
+# (round 6: 18,000 cases, 0 failures; summaries in profiles/r06_extra_campaigns/)
 mkdir -p gpurun_out/extra
 run() { name=$1; shift; env "$@" 2>&1 | grep -E "^FAIL|^fuzz" | cut -c1-900 > gpurun_out/extra/$name.txt; tail -1 gpurun_out/extra/$name.txt; }
 run cpu_gpu_101   QS_X=1 python3 tests/fuzz/fuzz_cpu_gpu.py 3000 101
