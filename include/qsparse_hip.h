@@ -330,6 +330,18 @@ int qs_mean_dim(const void* x, void* out, int64_t pre, int64_t n, int64_t post,
 int qs_mean_dim_split(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int64_t mr_cols, int xdt, int odt, int flags,
                       const int32_t* l0_flag, qs_stream_t stream);
 
+/* (ABI v25) The statistics of a token-major activation x[N][T][C] whose mask runs along the LAST dim (`prune(dimensions={2})` on a
+ * transformer block's hidden activation; qsparse/sparse.py:231-239, util.py:92-99): the two stages of squeeze_tensor_to_shape --
+ * stage[T][C] = mean over N (rounded to xdt), stage_mean[C] = mean over T of that (rounded) -- in ATen's order for the contiguous
+ * tensor, i.e. exactly two qs_mean_dim calls, plus the per-channel abs-max of the mean's operand (|x|, or |act(x)| with
+ * QS_MEAN_RELU / QS_MEAN_ACT) max-accumulated into chan_absmax[c * absmax_stride] (nullable; zero on entry as for qs_mean_dim).
+ * Every column of a row is a channel of its own here, so the abs-max cannot ride per wave as in the NCHW stage: the first stage
+ * stores one key per COLUMN into amax_part (nullable workspace, float[T * C], 16-byte aligned; no atomics) and a small third
+ * launch folds it per channel.  Without amax_part -- or for widths / flags the per-column kernels do not serve -- the abs-max rides
+ * in qs_mean_dim's atomic form (same values).  flags: QS_MEAN_ABS [| QS_MEAN_RELU | QS_MEAN_ACT(handle)]. */
+int qs_token_stats(const void* x, void* stage, void* stage_mean, float* amax_part, float* chan_absmax, int64_t absmax_stride, int64_t N,
+                   int64_t T, int64_t C, int xdt, int flags, qs_stream_t stream);
+
 /* The first stage for a channels_last (NHWC in memory) activation x[n][hw][C]: mean over n ->
  * out[C][hw], NCHW-contiguous like the result of Tensor.mean(0, keepdim=True) on a channels_last tensor, in the
  * summation order ATen uses for that layout (per channel, positions hw < 4*floor(hw/4) in cascade order, the rest
@@ -509,7 +521,7 @@ typedef struct qs_site_plan {
     float* chan_absmax;          /* [C * absmax_stride] scratch accumulator */
     int64_t absmax_stride;
     void* stage;                 /* [C*H*W] xdt scratch: first-stage means (unused, nullable, for layout 2) */
-    float* amax_part;            /* [C*H*W] scratch (layout 1), NULL for layout 0 */
+    float* amax_part;            /* [C*H*W] scratch (layout 1; layout 3, nullable there: qs_token_stats' per-column keys), NULL for layout 0 */
     void* stage_mean;            /* [C] xdt scratch: the importance of this step */
     int32_t* prune_n_updates;    /* nullable: PruneLayer._n_updates, incremented by the select */
     int32_t* quant_n_updates;    /* nullable: QuantizeLayer._n_updates, incremented by the select */

@@ -63,6 +63,7 @@ SIGNATURES = {
     "qs_pq_select": (c_int, [_P, _P, _I, _L, _I, _L, _I, _L, _P, _P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "qs_mean_last2": (c_int, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _L, _P, _P]),
     "qs_mean_dim_cl": (c_int, [_P, _P, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
+    "qs_token_stats": (c_int, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _P]),
     "qs_mean_cl_w": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_mean_dim_split": (c_int, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     "qs_mailbox_bytes": (c_size_t, [_I, _L]),

@@ -190,10 +190,10 @@ static int site_plan_ok(const qs_site_plan* p) {
 
 // layout 3, token-major [N][T][C] with the mask on the last dim (T = plan->H): squeeze_tensor_to_shape's two stages (util.py:92-99),
 // mean over N of the [N][T*C] matrix, then mean over T of the [T][C] stage, each rounded to xdt; channel of column j is j % C
+// (qs_token_stats: the abs-max per column into plan->amax_part -- no atomics -- and folded per channel by a third launch)
 static int site_token_means(const qs_site_plan* p, const void* x, int mflags, float* absmax, int64_t absmax_stride, qs_stream_t stream) {
-    int st = qs_mean_dim(x, p->stage, 1, p->N, p->H * p->C, p->xdt, p->xdt, mflags, nullptr, absmax, absmax_stride, 1, p->C, stream);
-    if (st) return st;
-    return qs_mean_dim(p->stage, p->stage_mean, 1, p->H, p->C, p->xdt, p->xdt, 0, nullptr, nullptr, 1, 1, p->C, stream);
+    return qs_token_stats(x, p->stage, p->stage_mean, absmax ? p->amax_part : nullptr, absmax, absmax_stride, p->N, p->H, p->C, p->xdt, mflags,
+                          stream);
 }
 
 // the statistics launches of a live site step; `record` (nullable): the rank's exchange record, written by the last of them

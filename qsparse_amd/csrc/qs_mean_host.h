@@ -19,7 +19,7 @@ static inline int prep_code(int flags, const int32_t* l0_flag, const ActSpec& ac
 template <int XD>
 static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, int odt, int flags,
                          const int32_t* l0_flag, float* absmax_out, int64_t absmax_stride, int64_t chan_div, int64_t C,
-                         int64_t mr_cols, qs_stream_t stream) {
+                         int64_t mr_cols, int percol_part, qs_stream_t stream) {
     if (!x || !out || pre < 1 || n < 1 || post < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !dt_ok(odt)) return QS_ERR_DTYPE;
     if (!(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
@@ -33,7 +33,17 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
     hipStream_t s = (hipStream_t)stream;
     int64_t vcols = 0;
     const bool ragged_absmax = absmax_out && (chan_div % 8 != 0);
-    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!ragged_absmax || chan_div >= 8))
+    // percol_part (internal: qs_token_stats): `absmax_out` is a [pre][post] array that receives the abs-max of every COLUMN (the
+    // PERCOL form of the vector kernel, no atomics); the caller guarantees post % 32 == 0 (no generic tail) and the |x| / |max(x, 0)|
+    // flags
+    const bool percol = absmax_out && (percol_part & 1) != 0;
+    // bit 1 (internal: the second stage of qs_token_stats, a [T][C] matrix of a few thousand columns): one lane per output for
+    // 2-byte inputs as well -- 197 x 3072 bf16: 7 us against 10 (one-wave kernel) / 15 (rows split eight ways); 1024 x 4096: 21 against 42
+    const bool prefer_generic = (percol_part & 2) != 0;
+    if (percol && (post % 32 != 0 || l0_flag || !(flags == QS_MEAN_ABS || (flags == (QS_MEAN_ABS | QS_MEAN_RELU) && !general_act)) || mr_cols >= 0))
+        return QS_ERR_ARG;
+    if (percol && !(post >= 64 && aligned16(x) && aligned16(out) && aligned16(absmax_out))) return QS_ERR_ARG;
+    if (post >= 64 && post % 8 == 0 && aligned16(x) && aligned16(out) && (!ragged_absmax || chan_div >= 8 || percol))
         vcols = mr_cols >= 0 ? (mr_cols / 8) * 8 : (post / 32) * 32;
     // float32 without the abs-max rider: one lane per output (mean_generic_kernel, 4-byte loads, four times the waves) is as fast as
     // the 8-columns-per-lane kernels on the largest tensors and faster below (256 x 150528: 25 against 35 us, 1024 x 65536: 56 against
@@ -41,6 +51,7 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
     // (only with a compile-time operand preparation: |x|, |max(x, 0)| or x -- a folded nn.ReLU6 / nn.LeakyReLU has its own modes in
     //  the vector kernels and none here)
     if (xdt == QS_F32 && !absmax_out && n >= 32 && prep_code(flags, l0_flag, act) != 0 && env_int("QS_MEAN_F32_GENERIC", 1)) vcols = 0;
+    if (prefer_generic && !absmax_out && n >= 32 && prep_code(flags, l0_flag, act) != 0 && env_int("QS_TOKEN_STAGE2_GENERIC", 1)) vcols = 0;
     uint32_t* am = (uint32_t*)absmax_out;
     // rows are split over R waves per workgroup when there are too few column groups to fill the chip
     const int lp = std::max(4, (n <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(n - 1))) / 4);
@@ -58,7 +69,8 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
         else if (am && waves < 512 && xdt != QS_F32 && nchunks >= 8 && nchunks <= kMaxSplitChunks) R = 4;   // long columns of 2-byte values
         while (R > 1 && R > nchunks) R >>= 1;
         if (nchunks > kMaxSplitChunks || nchunks < 2) R = 1;
-        if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
+        if (percol) R = 1;          // (the one-wave kernel: the split kernel has no per-column form)
+        else if (ragged_absmax && R == 1) R = (nchunks >= 2 && nchunks <= kMaxSplitChunks) ? 2 : 0;   // only the split kernel tracks two channels
         if (R == 0) vcols = 0;
     }
     if (xdt != XD) return QS_ERR_DTYPE;
@@ -91,6 +103,15 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
                                            dim3(64), 0, s, x, out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes, act);
                     };
                     auto by_mode = [&](auto D) {
+                        if (percol) {
+                            if (mode == 1)
+                                hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, decltype(D)::value, 1, true>), dim3(blocks), dim3(64), 0, s, x,
+                                                   out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes, act);
+                            else
+                                hipLaunchKernelGGL((mean_outer_vec_kernel<XD, OD, decltype(D)::value, 2, true>), dim3(blocks), dim3(64), 0, s, x,
+                                                   out, pre, n, post, vcols, flags, l0_flag, am, as, chan_div, Cc, lanes, act);
+                            return;
+                        }
                         if (mode == 3) launch(D, IC<3>{});
                         else if (mode == 1) launch(D, IC<1>{});
                         else if (mode == 2) launch(D, IC<2>{});
@@ -185,8 +206,9 @@ static int mean_strided_launch(const void* x, void* out, int64_t total, const St
     __attribute__((visibility("hidden"))) int qs_mean_dim_##SUFFIX(const void* x, void* out, int64_t pre, int64_t n, int64_t post, int xdt, \
                                                                    int odt, int flags, const int32_t* l0_flag, float* absmax_out,         \
                                                                    int64_t absmax_stride, int64_t chan_div, int64_t C, int64_t mr_cols,   \
-                                                                   qs_stream_t stream) {                                                  \
-        return mean_dim_impl<DT>(x, out, pre, n, post, xdt, odt, flags, l0_flag, absmax_out, absmax_stride, chan_div, C, mr_cols, stream); \
+                                                                   int percol_part, qs_stream_t stream) {                                 \
+        return mean_dim_impl<DT>(x, out, pre, n, post, xdt, odt, flags, l0_flag, absmax_out, absmax_stride, chan_div, C, mr_cols,         \
+                                 percol_part, stream);                                                                                    \
     }                                                                                                                                     \
     __attribute__((visibility("hidden"))) int qs_mean_strided_##SUFFIX(const void* x, void* out, int64_t total, const StridedPlan* p,     \
                                                                        int odt, int flags, const int32_t* l0_flag, const ActSpec* act,    \

@@ -699,7 +699,12 @@ __device__ __forceinline__ float inner_sum_lds(const float* v, int W, float* lan
 // the host picks `lanes` such that the number of waves is (close to) a multiple of the 256 CUs -- e.g.
 // 100352 column groups -> 56 lanes x 1792 waves = exactly 7 waves per CU instead of 64 x 1568 (6.1, i.e.
 // 7 on some CUs and 6 on others).
-template <int DT, int ODT, int ROWS_IN_FLIGHT, int MODE>
+// PERCOL (MODE 1 / 2 only): every column has a channel of its own (a token-major [B][T][C] activation reduced over B: channel =
+// column % C, a lane's 8 columns are 8 channels).  The abs-max is kept per COLUMN and stored -- no atomics -- into `absmax`, which
+// is then a [pre][post] array of keys ("amax_part", as the channels_last kernels leave one); token_amax_fold_kernel folds it per
+// channel.  (Max-accumulating per column with atomics, T of them per channel, cost 11 us on 256 x 197 x 3072 and 100 us on
+// 64 x 1024 x 4096 -- more than the 97 us the whole column walk takes there.)
+template <int DT, int ODT, int ROWS_IN_FLIGHT, int MODE, bool PERCOL = false>
 __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restrict__ x, void* __restrict__ out,
                                                              int64_t pre, int64_t n, int64_t post, int64_t vcols,
                                                              int flags, const int32_t* __restrict__ l0_flag,
@@ -720,6 +725,8 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
     const int64_t row_groups = post / 8;             // 16-byte groups per row (post % 8 == 0 guaranteed)
     const int64_t g_base = p * n * row_groups + gc;
     uint32_t amax = 0u;
+    uint32_t amaxc[PERCOL ? 8 : 1] = {};
+    static_assert(!PERCOL || MODE == 1 || MODE == 2, "per-column abs-max: the |x| / max(x, 0) modes");
     RedAcc<DT, true> mm;                             // MODE 6: per-channel min and max (qs_minmax's column walk)
 
     if (active) {
@@ -751,7 +758,8 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
                     const float w = (MODE == 2) ? relu_aten(v[j]) : (MODE == 7) ? act_apply_k<QS_ACT_HARDTANH>(v[j], act, DT)
                                   : (MODE == 8) ? act_apply_k<QS_ACT_LEAKY>(v[j], act, DT) : v[j];
                     const uint32_t k = __float_as_uint(w) & 0x7fffffffu;
-                    amax = k > amax ? k : amax;
+                    if constexpr (PERCOL) amaxc[j] = k > amaxc[j] ? k : amaxc[j];
+                    else amax = k > amax ? k : amax;
                     acc[j].add(__uint_as_float(k));
                 }
             }
@@ -825,6 +833,14 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
         }
         return;
     }
+    if constexpr (PERCOL) {
+        if (absmax && active) {
+            u32x4* dst = (u32x4*)(absmax + p * post + gc * 8);
+            dst[0] = u32x4{amaxc[0], amaxc[1], amaxc[2], amaxc[3]};
+            dst[1] = u32x4{amaxc[4], amaxc[5], amaxc[6], amaxc[7]};
+        }
+        return;
+    }
     if (absmax) {   // whole wave takes part: idle lanes contribute 0
         if (chan_div % 8 == 0) {   // all 8 columns of a lane share a channel
             const uint32_t c = (uint32_t)(((gc * 8) / chan_div) % C);
@@ -838,6 +854,36 @@ __global__ __launch_bounds__(64) void mean_outer_vec_kernel(const void* __restri
         } else if (active) {       // ragged rows (e.g. 7x7 maps): handled per column by the caller's generic kernel
             atomicMax(absmax + (size_t)(uint32_t)(((gc * 8) / chan_div) % C) * astride, amax);
         }
+    }
+}
+
+// chan_absmax[c * astride] <- max(chan_absmax[c * astride], max over t of part[t][c]) for a [T][C] array of per-column keys (the PERCOL
+// form above).  grid (ceil(C / 64), ceil(T / 32)), 256 threads: wave w of a workgroup takes 8 tokens of its 32-token slice for
+// 64 channels (coalesced 256-byte rows, eight loads in flight), the four waves meet in LDS, one atomic per channel and slice
+// (slices of 128 tokens, four dependent batches per wave: 11.4 us on 197 x 3072; of 32: one batch).
+static __global__ __launch_bounds__(256) void token_amax_fold_kernel(const uint32_t* __restrict__ part, int64_t T, int64_t C,
+                                                                      uint32_t* __restrict__ chan_absmax, int64_t astride) {
+    __shared__ uint32_t sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t t0 = (int64_t)blockIdx.y * 32 + w * 8;
+    uint32_t m = 0u;
+    if (c < C) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t t = t0 + u;
+            v[u] = t < T ? part[t * C + c] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = v[u] > m ? v[u] : m;
+    }
+    sh[w][lane] = m;
+    __syncthreads();
+    if (w == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) m = sh[k][lane] > m ? sh[k][lane] : m;
+        atomicMax(chan_absmax + (size_t)c * astride, m);
     }
 }
 
@@ -1463,9 +1509,12 @@ static __global__ void select_init_kernel(SelectState* st, uint32_t k) {
 //   larger n:      4-pass radix select, bins scanned in parallel (one bin per thread, wave prefix sums).
 constexpr int kSelectThreads = 1024;
 constexpr int kRankMax = 2048;
+// pq_select holds up to this many channels in registers + LDS (round 6: 2048 -> 8192, the hidden widths of transformer blocks --
+// a token-major site with C = 3072 took the global-memory passes: 22.8 us)
+constexpr int kSelectLdsMax = 8192;
 
 struct SelectShared {
-    alignas(16) uint32_t keys[kRankMax];
+    alignas(16) uint32_t keys[kSelectLdsMax];
     uint32_t hist[256];
     uint32_t wsum[4];
     uint32_t state[2];
@@ -1713,7 +1762,7 @@ __device__ __forceinline__ void pq_select_small(const PqArgs& a, const void* sta
             if (a.update_scale) amax[it] = pq_amax_key(a, i);
             keep[it] = a.mask[i];
             sh.keys[i] = f32_to_key(mag[it]);
-        } else if (i < kRankMax) {
+        } else if (i < ITEMS * nthreads) {
             sh.keys[i] = 0xffffffffu;   // padding for the 4-wide rank loop
         }
     }
@@ -1763,10 +1812,15 @@ __global__ __launch_bounds__(THREADS) void pq_select_kernel(PqArgs a0, const voi
     const PqArgs a = pq_live_counters(a0);   // every thread reads the counters before thread 0 bumps them (barriers in between)
     __shared__ SelectShared sh;
     __shared__ uint32_t sh_max[THREADS / 64];
-    static_assert(THREADS == 256 || kRankMax % THREADS == 0, "items per thread must cover kRankMax");
-    if (THREADS == 256) pq_select_small<SDT, 1>(a, stage, sh, sh_max);                       // host guarantees C <= 256
-    else if (a.C <= kRankMax) pq_select_small<SDT, kRankMax / THREADS>(a, stage, sh, sh_max);
-    else pq_select_body<SDT>(a, stage, sh, sh_max);
+    static_assert(THREADS == 256 || (kRankMax % THREADS == 0 && kSelectLdsMax == 8 * THREADS), "items per thread must cover the LDS-resident sizes");
+    if constexpr (THREADS == 256) {
+        pq_select_small<SDT, 1>(a, stage, sh, sh_max);                       // host guarantees C <= 256
+    } else {
+        if (a.C <= kRankMax) pq_select_small<SDT, kRankMax / THREADS>(a, stage, sh, sh_max);
+        else if (a.C <= 4 * THREADS) pq_select_small<SDT, 4>(a, stage, sh, sh_max);
+        else if (a.C <= kSelectLdsMax) pq_select_small<SDT, 8>(a, stage, sh, sh_max);
+        else pq_select_body<SDT>(a, stage, sh, sh_max);
+    }
 }
 
 // =================================================================================================

@@ -242,7 +242,9 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     plan.interleaved = cl or token       # channels are the fastest-running index in memory: eliding pruned ones saves no traffic
     acc = _absmax_accumulator(q, C, h.device)
     stage = None if flat else torch.empty(C * H * W, dtype=h.dtype, device=h.device)
-    part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if cl else None
+    # per-element abs-max keys of the first statistics stage: channels_last (reduced per channel by qs_mean_last2) and token-major
+    # (qs_token_stats: per column, folded per channel by its third launch)
+    part = torch.empty(C * H * W, dtype=torch.float32, device=h.device) if (cl or token) else None
     stage_mean = torch.empty(C, dtype=h.dtype, device=h.device)
     # a frozen-mask step (QS_SITE_SCALE_ONLY): dense [C] abs-max accumulator + the reduction's scratch for this geometry
     dense = _absmax_accumulator_dense(q, C, h.device)
@@ -256,7 +258,7 @@ def _site_plan(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, act: int = 1):
     c.layout, c.xdt, c.ydt, c.bits = (3 if token else 2 if flat else int(cl)), _hip.dt(h), _hip._DT[out_dtype], int(q.bits)
     c.magnitude, c.mask, c.scale = cb.magnitude.data_ptr(), p.mask.data_ptr(), q.weight.data_ptr()
     c.chan_absmax, c.absmax_stride = acc.data_ptr(), _hip.amax_stride(acc)
-    c.stage, c.amax_part, c.stage_mean = (None if flat else stage.data_ptr()), (part.data_ptr() if cl else None), stage_mean.data_ptr()
+    c.stage, c.amax_part, c.stage_mean = (None if flat else stage.data_ptr()), (part.data_ptr() if part is not None else None), stage_mean.data_ptr()
     c.prune_n_updates, c.quant_n_updates, c.callback_t = p._n_updates.data_ptr(), q._n_updates.data_ptr(), cb.t.data_ptr()
     c.quantizer_t_dev = t_q_dev.data_ptr() if t_q_dev is not None else None
     c.callback_t_from_device = int(graph_safe)

@@ -68,6 +68,8 @@ CASES = [
     ("decimal", (17, 40), torch.bfloat16, False, True),
     ("scaler", (64, 1000), torch.float32, False, False),
     ("decimal", (5, 36), torch.float16, False, True),
+    ("scaler", (16, 5000), torch.bfloat16, False, True),            # C in (4096, 8192]: the LDS-resident select, 8 channels per thread
+    ("scaler", (4, 3000, 2, 2), torch.float32, False, False),       # C in (2048, 4096]
 ]
 # the recipe's steady state: mask frozen (stop_mask_refresh passed), the scale still follows the data (QS_SITE_SCALE_ONLY)
 FROZEN_CASES = [

@@ -60,6 +60,9 @@ PAIRS = [
     ("scaler", (16, 50, 64), torch.bfloat16, "gelu", False),
     ("decimal", (6, 10, 16), torch.float32, "gelu", True),
     ("scaler", (300, 3, 48), torch.bfloat16, "relu", True),         # many rows: the frozen step's two-stage abs-max
+    ("scaler", (4, 6, 3072), torch.bfloat16, "relu", False),         # C in (2048, 4096]: the select keeps 4 channels per thread in LDS
+    ("decimal", (3, 4, 6000), torch.float32, "identity", False),     # C in (4096, 8192]: 8 per thread; T * C % 32 != 0: the atomics rider
+    ("scaler", (2, 3, 9000), torch.float16, "relu", True),           # C > 8192: the select's global-memory passes
     ("scaler", (64, 197, 768), torch.bfloat16, "gelu", False),       # ViT-B/16 token grid
     ("scaler", (8, 128, 1024), torch.float16, "relu", False),
 ]
