@@ -615,11 +615,40 @@ def weights_pruned_config(device):
     return out
 
 
+def token_major_site(device, steps=40):
+    """SURVEY 8f widened (round 6): the pair on a TOKEN-MAJOR activation -- (B, T, C) = 256 x 197 x 3072 bf16, the hidden activation of
+    a ViT-B MLP block, prune(0.75, dimensions={2}) -> quantize(4b) behind a folded nn.ReLU, training step with live statistics
+    through the composite site calls (qs_site_plan layout 3: qs_token_stats, select, apply).  Algorithmic bytes per element:
+    statistics 2 + forward 2 + 4 + 1/8 (x, y, gate bitmap) + backward 4 + 1/8 + 2 (g, gate, gx) = 14.25."""
+    import qsparse_amd as qs
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+
+    shape = (256, 197, 3072)
+    g = torch.Generator(device=device).manual_seed(3)
+    x = (torch.randn(shape, generator=g, device=device) * torch.linspace(0.25, 4.0, shape[2], device=device)).to(torch.bfloat16).requires_grad_(True)
+    gout = torch.randn(shape, generator=g, device=device)
+    site = fuse_prune_quantize_pairs(nn.Sequential(
+        nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.75, dimensions={2}, start=0, interval=1, repetition=1)),
+        qs.quantize(bits=4, channelwise=-1, timeout=1)).to(device).train())
+
+    def step(_=0):
+        torch.autograd.grad(site(x), x, gout)
+
+    for _ in range(10):
+        step()
+    ms = _steady_ms(step, steps)
+    n = x.numel()
+    return {"workload": "256x197x3072 bf16 (B, T, C): relu -> prune(0.75, {2}) -> quantize(4b) train fwd+bwd, live mask+scale",
+            "ms_per_step": round(ms, 4), "Gelem/s": round(n / ms / 1e6, 1), "bytes_per_elem": 14.25,
+            "frac_of_hbm_peak": round(14.25 * n / ms / 1e6 / HBM_PEAK_GBS, 4), "kept_channel_fraction": round(site[0][1].mask.float().mean().item(), 4)}
+
+
 def extra_configs(device, only=None):
     """configs 2-4 of BASELINE.json; a failure in one of them is recorded, it never costs the headline line"""
     out = {}
     for name, fn in (("host_overhead_per_site", lambda: host_overhead(device)),
                      ("weights_pruned_quantized", lambda: weights_pruned_config(device)),
+                     ("token_major_site_256x197x3072", lambda: token_major_site(device)),
                      ("config2_quantize8_256x64x56x56", lambda: config2(device)),
                      ("config3_resnet18_cifar_b128", lambda: resnet_config("resnet18", 128, device, 10)),
                      ("config4_resnet50_imagenet_b256", lambda: resnet_config("resnet50", 256, device, 5))):
