@@ -69,6 +69,7 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     me = os.path.abspath(__file__)
     per = {}        # kernel -> launch index -> counter -> value
+    dispatches = {}  # kernel -> counter group -> launches seen in that pass
     order = []
     notes = []
     for group, counters in GROUPS.items():
@@ -95,6 +96,8 @@ def main():
                 order.append(key)
             idx = seen.setdefault(key, {}).setdefault(did, len(seen[key]))
             per.setdefault(key, {}).setdefault(idx, {})[row["Counter_Name"]] = float(row["Counter_Value"])
+        for key, dids in seen.items():           # every pass must have seen the same launches: the averages pair them by position
+            dispatches.setdefault(key, {})[group] = len(dids)
         shutil.rmtree(d, ignore_errors=True)
     # durations from a plain kernel trace
     d = "/tmp/pmc_stats_trace"
@@ -112,9 +115,11 @@ def main():
              "durations from a separate --kernel-trace pass; averages over the last 8 of 12 launches)",
              f"shapes ({'float32' if F32 else 'bf16'}, batch 256): " + ", ".join("x".join(map(str, s)) for s in SHAPES) + "; channels_last = mean_cl_*, NCHW control = mean_outer_vec_kernel",
              "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md); per-wave = / SQ_WAVES", ""]
+    for key, by_group in dispatches.items():
+        if len(set(by_group.values())) > 1:
+            notes.append(f"{key[0]} grid={key[1]}: the passes saw different launch counts {by_group} -- its per-position averages mix launches")
     if notes:
-        lines += ["INCOMPLETE: a counter group failed -- its counters are missing below"] + notes + [""]
-    counts = {key: len(per[key]) for key in order}
+        lines += ["INCOMPLETE: a counter group failed or the passes disagree -- see the notes"] + notes + [""]
     for key in order:
         launches = per[key]
         idxs = sorted(launches)[4:] or sorted(launches)
