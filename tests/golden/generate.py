@@ -26,6 +26,7 @@ Reference entry points exercised (file:line in /root/reference):
   F14 counters written through ``.data``       qsparse/quantize.py:495, qsparse/sparse.py:251-269,104-118
   F15 MagnitudePruningCallback(use_gradient=True)  qsparse/sparse.py:69-80 (tensor hook -> update_magnitude(grad), :82-89)
   F16 the MNIST --pq recipe with devise_layerwise_pruning_schedule  examples/mnist.py:17-44,193-199; qsparse/sparse.py:343-359
+  F18 error behaviour: misuse scenarios (tests/golden/error_scenarios.py) -> exception type / message or "ok"
   F17 the prune->quantize pair with NaN / Inf / -Inf on PRUNED channels  qsparse/sparse.py:263 (x * mask: NaN there),
       qsparse/quantize.py:109 (.int() of NaN: INT_MIN), :329-347 (x.abs().max() carries the NaN into a live scale),
       :126-130 (clamp with NaN bounds), :316 (nan_to_num in the decimal)
@@ -1013,6 +1014,24 @@ def f16():
     save("f16_mnist_layerwise_recipe", store, dict(cases=cases))
 
 
+def f18():
+    """F18 error behaviour: what the reference does for the misuse scenarios of tests/golden/error_scenarios.py (argument errors:
+    exception type and first line of the message, or "ok")"""
+    sys.path.insert(0, HERE)
+    import error_scenarios as E
+    cases = []
+    for fn in E.SCENARIOS:
+        torch.manual_seed(0)
+        try:
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                fn(qsparse, "cpu")
+            outcome = ["ok"]
+        except BaseException as e:      # noqa: BLE001  (AssertionError, KeyError, ... are the point)
+            outcome = ["raised", type(e).__name__, (str(e).splitlines() or [""])[0][:120]]
+        cases.append({"name": fn.__name__, "outcome": outcome})
+    save("f18_error_behaviour", {"count": np.array(len(cases))}, {"cases": cases})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if len(sys.argv) > 1:                                   # regenerate chosen fixtures only: generate.py f16 ...
@@ -1034,3 +1053,4 @@ if __name__ == "__main__":
     f15()
     f16()
     f17()
+    f18()
