@@ -149,3 +149,43 @@ def test_multi_tensor_weight_path_stays_inside_its_flat_buffer(guarded, monkeypa
         net(x)
         guarded.check()
     assert guarded.count > 3
+
+
+def test_composite_sites_images_and_token_statistics_stay_inside_their_buffers(guarded, monkeypatch):
+    """the buffers the HOST modules allocate for the composite calls -- outputs, gate bitmaps, autocast images, the round-6 riders'
+    gradient image, the token-major statistics' per-column keys and stages -- guarded the same way: ragged maps, channel counts
+    that are no multiple of 8 / 32, token-major sites on both statistics routes, a bottleneck data flow under autocast"""
+    import torch.nn as nn
+    from qsparse_amd import fused, quantize, sparse
+    from qsparse_amd.fused import fuse_prune_quantize_pairs
+    for mod in (fused, quantize, sparse):
+        monkeypatch.setattr(mod, "torch", guarded)
+
+    def pair(dim=1):
+        return fuse_prune_quantize_pairs(nn.Sequential(
+            nn.Sequential(nn.ReLU(), qs.prune(sparsity=0.5, dimensions={dim}, start=1, interval=1, repetition=1)),
+            qs.quantize(bits=4, channelwise=-1, timeout=1))).cuda().train()
+
+    g = torch.Generator().manual_seed(5)
+    for shape, dim, dtype in (((4, 7, 40), 2, torch.bfloat16), ((3, 5, 96), 2, torch.float32), ((6, 3, 33), 2, torch.float16),
+                              ((5, 24, 7, 7), 1, torch.bfloat16), ((4, 40, 3, 5), 1, torch.float32), ((9, 48), 1, torch.bfloat16)):
+        site = pair(dim)
+        for step in range(5):
+            x = (torch.randn(shape, generator=g) * 2).to(dtype).cuda().requires_grad_(True)
+            y = site(x)
+            y.backward(torch.randn(shape, generator=g).to(y.dtype).cuda())
+            guarded.check()
+    # a bottleneck's data flow under autocast: first / second image, promoting add with the gradient image, ragged 7 x 7 maps
+    for down in (False, True):
+        s0, s1 = pair(), pair()
+        conv1, conv2, head = (nn.Conv2d(24, 24, 1, bias=False).cuda() for _ in range(3))
+        for step in range(5):
+            x = (torch.randn(4, 24, 7, 7, generator=g) * 2).cuda().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y0 = s0(x)
+                out = conv1(y0)
+                y1 = s1(out + (conv2(y0) if down else y0))
+                loss = head(y1).float().sum()
+            loss.backward()
+            guarded.check()
+    assert guarded.count > 300
