@@ -50,6 +50,12 @@ int qs_token_stats(const void* x, void* stage, void* stage_mean, float* amax_par
     if (!x || !stage || !stage_mean || N < 1 || T < 1 || C < 1) return QS_ERR_ARG;
     if (chan_absmax && absmax_stride < 1) return QS_ERR_ARG;
     const int64_t post = T * C;
+    {       // (a folded identity is no activation: mean_act_resolve)
+        ActSpec probe;
+        int low = flags;
+        if (mean_act_resolve(&low, &probe) != QS_OK) return QS_ERR_ARG;
+        if (probe.kind == QS_ACT_NONE) flags = low;
+    }
     const int f = flags & 0xff;
     // the per-column form serves |x| and |max(x, 0)| of nn.ReLU on rows that are whole 32-column blocks (no generic tail); everything
     // else -- other folded activations, odd widths, unaligned views -- takes the atomics rider of qs_mean_dim (same results)
@@ -87,7 +93,7 @@ int qs_mean_strided(const void* x, void* out, int64_t n, int64_t stride, int nke
     if (order == 0 && (stride != 1 || n < 8)) return QS_ERR_ARG;      // ATen's vectorised inner loop needs both
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     ActSpec act;
-    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    if (mean_act_resolve(&flags, &act) != QS_OK) return QS_ERR_ARG;
     flags &= 0xff;
     StridedPlan p{};
     p.n = n; p.stride = stride; p.nkept = nkept; p.order = order; p.split_dim = order == 2 ? split_dim : -1; p.split = split;

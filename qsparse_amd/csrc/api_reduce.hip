@@ -127,6 +127,7 @@ int qs_absmax(const void* x, float* out, int per_channel, int64_t outer, int64_t
     if (out_lines < 1 || out_lines > 64 || (out_lines > 1 && (per_channel || !accumulate))) return QS_ERR_ARG;
     ActSpec act;
     if (qs_act_resolve(pre_relu, &act) != QS_OK) return QS_ERR_ARG;
+    if (act.kind == QS_ACT_LEAKY && act.a == 1.0f) act = ActSpec{0, 0.f, 0.f};      // a folded identity: |x * 1| is |x| (mean_act_resolve)
     return reduce_impl(x, out, nullptr, false, per_channel, outer, C, inner, xdt, (hipStream_t)stream, accumulate != 0, act, ws,
                        ws_bytes, out_lines);
 }

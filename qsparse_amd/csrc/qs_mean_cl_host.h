@@ -21,7 +21,7 @@ static int qs_mean_dim_cl_impl(const void* x, void* out, int64_t n, int64_t hw, 
     if (!x || !out || n < 1 || hw < 1 || C < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     ActSpec act;
-    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    if (mean_act_resolve(&flags, &act) != QS_OK) return QS_ERR_ARG;
     flags &= 0xff;
     int mode = (flags & QS_MEAN_L0) ? 0 : (flags == QS_MEAN_ABS ? 1 : (flags == (QS_MEAN_ABS | QS_MEAN_RELU) ? 2 :
                                            (flags == 0 ? 3 : 0)));
@@ -143,7 +143,7 @@ static int qs_mean_cl_w_impl(const void* x, void* out, int64_t N, int64_t H, int
     if (!x || !out || N < 1 || H < 1 || W < 1 || C < 1) return QS_ERR_ARG;
     if (!dt_ok(xdt) || !(odt == xdt || odt == QS_F32)) return QS_ERR_DTYPE;
     ActSpec act;
-    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    if (mean_act_resolve(&flags, &act) != QS_OK) return QS_ERR_ARG;
     flags &= 0xff;
     const int64_t total = N * H * C;
     if ((total + kBlock - 1) / kBlock > 0x7fffffff) return QS_ERR_ARG;

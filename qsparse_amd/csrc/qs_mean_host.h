@@ -26,7 +26,7 @@ static int mean_dim_impl(const void* x, void* out, int64_t pre, int64_t n, int64
     if (absmax_out && (chan_div < 1 || C < 1 || absmax_stride < 1)) return QS_ERR_ARG;
     // the folded activation: nn.ReLU, or the descriptor whose handle rides in the flags' upper bits (QS_MEAN_ACT)
     ActSpec act;
-    if (qs_act_resolve((flags & QS_MEAN_RELU) ? std::max(flags >> 8, 1) : 0, &act) != QS_OK) return QS_ERR_ARG;
+    if (mean_act_resolve(&flags, &act) != QS_OK) return QS_ERR_ARG;
     const bool general_act = act.kind > QS_ACT_RELU;      // (takes the generic modes: every flag tested per element)
     flags &= 0xff;
     const int64_t as = absmax_out ? absmax_stride : 1;

@@ -636,6 +636,27 @@ def autocast_image_dtype():
     return dt if dt in (torch.bfloat16, torch.float16) else None
 
 
+_IDENTITY = [None]
+_IDENTITY_FOLD = os.environ.get("QS_NO_IDENTITY_FOLD", "0") != "1"      # (development switch for A/B measurements)
+
+
+def identity_fold_handle(h) -> int:
+    """The autocast image is written by the kernels that record a folded activation's gate (and its gradient comes back through the
+    gated backward), so a site WITHOUT a foldable activation in front -- nn.GELU, nn.SiLU, nn.Identity, a lone QuantizeLayer on an
+    activation -- had no image: its float32 output was cast by its consumer, 12 B/elem of cast passes per step (a ViT MLP encoder
+    converted with nn.GELU sites: 1.23 x plain, with nn.ReLU sites 1.085).  Such a site folds the IDENTITY instead:
+    nn.LeakyReLU(negative_slope=1.0), `x > 0 ? x : x * 1.0`, is x bit for bit in every dtype, its backward `g * 1.0` is g -- the
+    kernels run as for a folded nn.LeakyReLU, record a gate nobody needs (1/8 B/elem each way) and write the image.  Returns that
+    activation's handle when an image is wanted for `h` right now (autocast on, option on, float32 promotion in place), else 0."""
+    if autocast_image_dtype() is None or not get_option("relu_gate") or not isinstance(h, torch.Tensor) or not h.is_cuda or not _IDENTITY_FOLD:
+        return 0
+    if h.dtype not in (torch.float32, torch.bfloat16, torch.float16) or _out_dtype(h) != torch.float32 or h.data_ptr() % 16:
+        return 0
+    if _IDENTITY[0] is None:
+        _IDENTITY[0] = _hip.try_activation(_hip.ACT_LEAKY, 1.0)
+    return _IDENTITY[0] or 0
+
+
 def _image_dtype(plan, training_needs_gate: bool):
     """dtype of the image this step should produce, or None"""
     if not get_option("autocast_image") or not plan.image_ok or plan.out_dtype != torch.float32:
@@ -1121,7 +1142,7 @@ def _pair_config(act, p, q, cb, qc):
 
 class _FastPair:
     __slots__ = ("epoch", "mods", "hooks", "config", "xsig", "state", "ptrs", "plan", "pre_relu", "fold", "max_schedule", "C",
-                 "graph_safe", "notch", "k_of")
+                 "graph_safe", "notch", "k_of", "autocast")
 
     def __deepcopy__(self, memo):        # raw pointers and object identities: a copied network arms its own
         return None
@@ -1141,8 +1162,10 @@ class _FastPair:
         cb, qc = p.callback, q.callback
         if not _FAST_PATH:
             return None
+        # fold: 1 / 2 a foldable activation (out of place / owned in place), 0 nn.Identity, 3 any other activation module (applied by
+        # ATen in front of the site); for 0 and 3 `handle` is 0 or the identity fold (`identity_fold_handle`)
         if type(act) is nn.Identity:
-            fold, handle = 0, 0
+            fold = 0
         elif not fold:
             return None
         if get_option("log_during_train") or not (seq.training and inner.training):
@@ -1169,7 +1192,13 @@ class _FastPair:
         f.max_schedule, f.C = max(p.schedules), plan.c.C
         f.graph_safe, f.notch = bool(get_option("graph_safe")), (1 if qc.flip_axis else 0)
         f.k_of = {}
+        f.autocast = cls._autocast()         # (the identity fold is chosen per autocast state)
         return f
+
+    @staticmethod
+    def _autocast():
+        on = torch.is_autocast_enabled("cuda")
+        return (on, torch.get_autocast_dtype("cuda") if on else None)
 
     def try_run(self, seq, x):
         """the step, or _MISS (nothing has been touched then)"""
@@ -1192,6 +1221,8 @@ class _FastPair:
             if d:
                 return _MISS
         if not isinstance(x, torch.Tensor) or self._xsig(x) != self.xsig or _pair_config(act, p, q, cb, qc) != self.config:
+            return _MISS
+        if self.fold in (0, 3) and self._autocast() != self.autocast:
             return _MISS
         pp, qp, cp = p._parameters, q._parameters, cb._parameters
         state = (cp.get("magnitude"), pp.get("mask"), qp.get("weight"), pp.get("_n_updates"), qp.get("_n_updates"), cp.get("t"))
@@ -1250,6 +1281,8 @@ class _FastPair:
 
         if self.fold == 2:
             return _with_owned_relu(x, site, pre_relu)
+        if self.fold == 3:
+            return site(act(x))          # an activation the kernels do not fold: ATen applies it, the site follows
         return site(x)
 
 
@@ -1283,9 +1316,13 @@ class FusedPruneQuantize(nn.Sequential):
             return out
         h = act(x)
         if _eligible(p, q, h):
-            out = fused_prune_quantize(p, q, h)
+            # (under autocast an active site folds the identity: it then writes its image like a site behind a foldable activation)
+            ident = identity_fold_handle(h) if q.is_active() else 0
+            out = fused_prune_quantize(p, q, h, pre_relu=ident) if ident else fused_prune_quantize(p, q, h)
             if h is x:
-                self.__dict__["_qs_fast"] = _FastPair.arm(self, x, 0, 0)
+                self.__dict__["_qs_fast"] = _FastPair.arm(self, x, 0, ident)
+            elif isinstance(h, torch.Tensor) and not getattr(act, "inplace", False):
+                self.__dict__["_qs_fast"] = _FastPair.arm(self, x, 3, ident)
             return out
         return q(p(h))
 

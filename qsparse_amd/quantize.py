@@ -717,6 +717,11 @@ class QuantizeLayer(nn.Module):
         update = self.training
         if not update and not self._quantized:
             return None
+        if not pre_relu and self.batch_dimension == 0:
+            # an activation quantizer with no foldable activation in front (nn.GELU, nothing at all, the network input): under
+            # autocast it folds the identity so that it can hand out its image like the others (fused.identity_fold_handle)
+            from qsparse_amd import fused
+            pre_relu = fused.identity_fold_handle(x)
         t_dev = cb.device_t(x.device) if (update and get_option("graph_safe")) else None
         mode = _hip.QSTEP_ALL if update else _hip.QSTEP_APPLY
         if update and self.batch_dimension == 0 and qdist.exchange_active():
