@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 25
+#define QS_ABI_VERSION 26
 /* ABI compatibility (from v25 on).
  *   - Every positional prototype in this header is FROZEN as of v25: a later version never changes the argument list of an
  *     existing symbol.  qs_abi_floor() returns the oldest version whose prototypes this library still honours (25); a binding
@@ -214,6 +214,15 @@ int qs_quant_ste_relu_bwd(const void* g, const void* x, const uint8_t* gate, voi
  *           same pass next to gx (+2 B/elem): the gradient of the 2-byte operand of a type-promoting add in front of the site
  *           (`bn(conv(h)) + identity` under autocast: bf16 + float32 -> float32), which ATen's AddBackward0 produces with a
  *           cast pass of gx of its own (6 B/elem). */
+/* (v26) The caller's activation.  convert(..., activation_layers=[nn.GELU]) puts the operators behind an activation the kernels do
+ * not fold: its forward value is the caller's (ATen's) pass, the site reads that.  Its BACKWARD needs only the site's input gradient
+ * and the activation's input, so the site's backward evaluates it on the way out:
+ *   act_x / act_x_kind   (nullable; QS_DACT_GELU: nn.GELU(approximate='none')) the activation's INPUT, of dtype xdt, gx's shape and
+ *           layout, 16-byte aligned.  gx = gelu_backward(RNE_xdt(gx_site), act_x) with gx_site the site's own result (clamp(g [+ g3]
+ *           [+ g2]) * mask), in ATen's GPU arithmetic bit for bit (float32 opmath, dy * fma(x, pdf, cdf)).  `x` and `gate` are not
+ *           read (the site has no folded activation of its own then, or the identity's); `elide_masked` is ignored; g2 is allowed
+ *           without a gate. */
+enum qs_dact_kind { QS_DACT_NONE = 0, QS_DACT_GELU = 1 };
 typedef struct qs_ste_relu_bwd_args {
     uint32_t struct_size;        /* sizeof(qs_ste_relu_bwd_args) as the caller compiled it */
     int32_t gdt, xdt, g2dt;
@@ -236,6 +245,10 @@ typedef struct qs_ste_relu_bwd_args {
     void* gx_image;
     int32_t gx_image_dt;
     int32_t reserved0;
+    /* ---- v26 ---- */
+    const void* act_x;           /* see "the caller's activation" above; NULL: none */
+    int32_t act_x_kind;          /* QS_DACT_GELU */
+    int32_t reserved1;
 } qs_ste_relu_bwd_args;
 int qs_quant_ste_relu_bwd_v(const qs_ste_relu_bwd_args* args);
 
@@ -618,6 +631,10 @@ typedef struct qs_site_bwd_args {
     void* gx_image;
     int32_t gx_image_dt;
     int32_t reserved0;
+    /* ---- v26 ---- */
+    const void* act_x;           /* the caller's activation, as in qs_ste_relu_bwd_args (needs a quantizing site; `gate` is not read) */
+    int32_t act_x_kind;
+    int32_t reserved1;
 } qs_site_bwd_args;
 int qs_site_bwd_v(const qs_site_plan* plan, const qs_site_bwd_args* args);
 

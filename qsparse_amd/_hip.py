@@ -18,7 +18,7 @@ MEAN_ABS, MEAN_L0, MEAN_RELU = 1, 2, 4
 WS_KTH_VALUE = 1
 MAX_DIMS = 6
 
-ABI_VERSION = 25          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against: the version it NEEDS
+ABI_VERSION = 26          # QS_ABI_VERSION of include/qsparse_hip.h this binding was written against: the version it NEEDS
 _LIB_NAME = "libqsparse_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -149,7 +149,8 @@ class SiteBwdArgs(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("flags", c_int32), ("gdt", c_int32), ("g2dt", c_int32),
                 ("g", c_void_p), ("gate", c_void_p), ("gx", c_void_p), ("lo_mul", c_float), ("hi_mul", c_float),
                 ("g2", c_void_p), ("decimal", c_void_p), ("stream", c_void_p),
-                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32)]
+                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32),
+                ("act_x", c_void_p), ("act_x_kind", c_int32), ("reserved1", c_int32)]         # v26
 
 
 class SteReluBwdArgs(ctypes.Structure):
@@ -159,7 +160,8 @@ class SteReluBwdArgs(ctypes.Structure):
                 ("step_host", c_float), ("step_is_decimal", c_int32), ("lo_mul", c_float), ("hi_mul", c_float),
                 ("chan_mask", c_void_p), ("outer", c_int64), ("C", c_int64), ("inner", c_int64),
                 ("elide_masked", c_int32), ("act", c_int32), ("g2", c_void_p), ("stream", c_void_p),
-                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32)]
+                ("g3", c_void_p), ("gx_image", c_void_p), ("gx_image_dt", c_int32), ("reserved0", c_int32),
+                ("act_x", c_void_p), ("act_x_kind", c_int32), ("reserved1", c_int32)]         # v26
 
 
 class MultiRow(ctypes.Structure):
@@ -1293,13 +1295,17 @@ def site_stats(plan_ref, x: torch.Tensor, flags: int, record: torch.Tensor):
         _check(st, "qs_site_stats")
 
 
+DACT_GELU = 1             # qs_dact_kind: the caller's activation whose backward a site's backward evaluates (v26)
+
+
 def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tensor], gx: torch.Tensor, flags: int, lo_mul: float,
              hi_mul: float, g2: Optional[torch.Tensor] = None, decimal: Optional[torch.Tensor] = None,
-             g3: Optional[torch.Tensor] = None, gx_image: Optional[torch.Tensor] = None):
+             g3: Optional[torch.Tensor] = None, gx_image: Optional[torch.Tensor] = None, act_x: Optional[torch.Tensor] = None):
     """g2: a second, 2-byte gradient added to g in float32 (g may then be None), see qs_quant_ste_relu_bwd; g3 / gx_image: the
     riders of the all-float32 backward (qs_site_bwd_v): a third gradient stream of g2's dtype added between g and g2, and a 2-byte
-    tensor of gx's shape and layout that receives RNE(gx) from the same pass"""
-    if g3 is not None or gx_image is not None:
+    tensor of gx's shape and layout that receives RNE(gx) from the same pass; act_x (v26): the input of the nn.GELU the caller
+    applied in front of the site -- gx comes out as gelu_backward(the site's gradient, act_x); the gate is not read"""
+    if g3 is not None or gx_image is not None or act_x is not None:
         a = SiteBwdArgs()
         a.struct_size = ctypes.sizeof(SiteBwdArgs)
         a.flags, a.gdt, a.g2dt = flags, (F32 if g is None else _DT[g.dtype]), (0 if g2 is None else _DT[g2.dtype])
@@ -1309,6 +1315,9 @@ def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tens
         a.g3 = None if g3 is None else g3.data_ptr()
         if gx_image is not None:
             a.gx_image, a.gx_image_dt = gx_image.data_ptr(), _DT[gx_image.dtype]
+        if act_x is not None:
+            assert act_x.dtype == gx.dtype and act_x.shape == gx.shape and act_x.stride() == gx.stride()
+            a.act_x, a.act_x_kind = act_x.data_ptr(), DACT_GELU
         st = load().qs_site_bwd_v(plan_ref, ctypes.byref(a))
         if st:
             _check(st, "qs_site_bwd_v")
@@ -1319,6 +1328,33 @@ def site_bwd(plan_ref, g: Optional[torch.Tensor], gate_bits: Optional[torch.Tens
                             None if decimal is None else decimal.data_ptr(), _stream(gx))
     if st:
         _check(st, "qs_site_bwd")
+
+
+def ste_act_bwd(g: Optional[torch.Tensor], act_x: torch.Tensor, step, step_is_decimal: bool, lo_mul: float, hi_mul: float,
+                chan_mask: Optional[torch.Tensor] = None, mask_channel_index: int = 1, g2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gelu_backward(RNE(clamp(g [+ float(g2)]) * mask), act_x) from one pass (qs_quant_ste_relu_bwd_v with act_x, ABI v26): the STE
+    backward of a site whose input was produced by an nn.GELU the caller applied to `act_x`.  Contiguous operands (the fine-grained
+    form of what `site_bwd(act_x=...)` does for every layout of a site plan)."""
+    ref = g if g is not None else g2
+    assert act_x.is_contiguous() and ref.is_contiguous() and tuple(ref.shape) == tuple(act_x.shape)
+    assert (g is None or g.dtype in (torch.float32, act_x.dtype)) and (g2 is None or (g2.is_contiguous() and (g is None or g.dtype == torch.float32)))
+    pt, n, host = _f32param(step, ref.device)
+    outer, C, inner, numel = split3(ref.shape, mask_channel_index if chan_mask is not None else -1)
+    gx = torch.empty_like(act_x)
+    if numel == 0:
+        return gx
+    cm = _chan_mask_bytes(chan_mask, C)
+    a = SteReluBwdArgs()
+    a.struct_size = ctypes.sizeof(SteReluBwdArgs)
+    a.gdt, a.xdt, a.g2dt = (F32 if g is None else dt(g)), dt(act_x), (0 if g2 is None else dt(g2))
+    a.g, a.gx, a.step, a.nstep, a.step_host = _ptr(g), _ptr(gx), _ptr(pt), n, host
+    a.step_is_decimal, a.lo_mul, a.hi_mul, a.chan_mask = int(bool(step_is_decimal)), float(lo_mul), float(hi_mul), _ptr(cm)
+    a.outer, a.C, a.inner, a.g2, a.stream = outer, C, inner, _ptr(g2), _stream(ref)
+    a.act_x, a.act_x_kind = _ptr(act_x), DACT_GELU
+    with _timed("quant_ste_act_bwd", g, g2, act_x, gx):
+        st = load().qs_quant_ste_relu_bwd_v(ctypes.byref(a))
+    _check(st, "qs_quant_ste_relu_bwd_v")
+    return gx
 
 
 # ----------------------------------------------------------------------------------------------

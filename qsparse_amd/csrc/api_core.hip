@@ -351,8 +351,10 @@ static int site_bwd_impl(const qs_site_plan* p, const qs_site_bwd_args& a) {
     const int flags = a.flags, gdt = a.gdt;
     const float* decimal = a.decimal;
     qs_stream_t stream = a.stream;
-    if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate)) return QS_ERR_ARG;
-    if ((a.g3 || a.gx_image) && (!gate || (flags & QS_SITE_NO_QUANT))) return QS_ERR_ARG;      // riders of the gated quantizer backward
+    const bool dact = a.act_x != nullptr || a.act_x_kind != 0;      // (v26) the caller's activation: its input replaces the gate
+    if (!p || (!g && !g2) || !gx || p->N < 1 || p->C < 1 || p->H < 1 || p->W < 1 || (g2 && !gate && !dact)) return QS_ERR_ARG;
+    if (dact && (!a.act_x || (flags & QS_SITE_NO_QUANT))) return QS_ERR_ARG;
+    if ((a.g3 || a.gx_image) && ((!gate && !dact) || (flags & QS_SITE_NO_QUANT))) return QS_ERR_ARG;      // riders of the gated quantizer backward
     if (flags & QS_SITE_NO_QUANT) {          // a PruneLayer alone: the backward of act?(x) * mask
         if (!g || !p->mask || g2 || decimal) return QS_ERR_ARG;
         const int64_t hw0 = p->H * p->W;
@@ -370,11 +372,12 @@ static int site_bwd_impl(const qs_site_plan* p, const qs_site_bwd_args& a) {
     const int64_t outer = p->layout == 0 ? p->N : p->N * hw, inner = p->layout == 0 ? hw : 1;
     const int64_t o = cm ? outer : 1, c = cm ? p->C : 1, in = cm ? inner : outer * p->C * inner;
     const int elide = (cm && (flags & QS_SITE_ELIDE)) ? 1 : 0;
-    if (gate) {
+    if (gate || dact) {
         qs_ste_relu_bwd_args r{};
         r.struct_size = sizeof(r);
         r.gdt = gdt, r.xdt = p->xdt, r.g2dt = a.g2dt;
-        r.g = g, r.gate = gate, r.gx = gx;
+        r.g = g, r.gate = dact ? nullptr : gate, r.gx = gx;
+        r.act_x = a.act_x, r.act_x_kind = a.act_x_kind;
         r.step = step, r.nstep = 1, r.step_host = 0.0f, r.step_is_decimal = is_decimal;
         r.lo_mul = a.lo_mul, r.hi_mul = a.hi_mul, r.chan_mask = cm;
         r.outer = o, r.C = c, r.inner = in;

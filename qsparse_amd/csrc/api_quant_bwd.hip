@@ -128,6 +128,7 @@ static int ste_relu_bwd_impl(const qs_ste_relu_bwd_args& a) {
 int qs_quant_ste_relu_bwd_v(const qs_ste_relu_bwd_args* args) {
     qs_ste_relu_bwd_args a;
     if (!take_args(args, &a)) return QS_ERR_ARG;
+    if (a.act_x || a.act_x_kind) return qs_ste_act_bwd_impl(a);      // (v26) the caller's activation: api_quant_bwd_act.hip
     return ste_relu_bwd_impl(a);
 }
 

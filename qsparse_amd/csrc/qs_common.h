@@ -101,6 +101,21 @@ __device__ __forceinline__ float act_closed(float applied, const ActSpec& s, int
     return (s.kind == QS_ACT_LEAKY) ? round_to_dtype(applied, dt) * s.a : 0.0f;
 }
 
+// ---- an activation applied by the CALLER in front of a site, whose backward the site's backward kernel evaluates ----------
+// convert(..., activation_layers=[nn.GELU]) puts the operators behind an activation the kernels do not fold (its forward value is
+// ATen's own pass); its BACKWARD, gelu_backward(gh, x) with gh the site's input gradient in x's dtype, needs nothing but that
+// gradient and x -- the site's backward kernel has the former in registers.  The factor below is ATen's GPU kernel
+// (ActivationGeluKernel.cu, GeluBackwardCUDAKernelImpl, erf form: dy * (cdf + x * pdf), the sum contracted to an fma by its build;
+// opmath float for every dtype), reproduced bit for bit: tools/probes/probe_gelu_bits.py compares every bf16 and fp16 input
+// pattern and 2^24 float32 values (0 differing with the fma, 1.76 M of 16.8 M float32 without), tests/test_act_grad_gpu.py repeats it.
+__device__ __forceinline__ float gelu_grad_factor(float x) {
+    const float kBeta = (float)(1.12837916709551257390 * 0.70710678118654752440 * 0.5);      // M_2_SQRTPI * M_SQRT1_2 * 0.5
+    const float kAlpha = (float)0.70710678118654752440;                                     // M_SQRT1_2
+    const float cdf = 0.5f * (1.0f + erff(x * kAlpha));
+    const float pdf = expf(-0.5f * x * x) * kBeta;
+    return fmaf(x, pdf, cdf);
+}
+
 // ---- scalar element access ---------------------------------------------------------------------
 template <int DT>
 __device__ __forceinline__ float load1(const void* p, int64_t i) {

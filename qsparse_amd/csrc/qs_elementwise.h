@@ -883,15 +883,20 @@ struct BwdRiders {
     void* gx_img;
     int img_dt;
 };
-template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false, int G2DT = -1>
+// DACT (QS_DACT_GELU): `x` is the input of an activation the CALLER applied in front of the site (nn.GELU by ATen); the site's own
+// gradient -- clamp(g) * mask, rounded to x's dtype as autograd hands it on -- is multiplied by that activation's derivative at x
+// (gelu_grad_factor): gelu_backward(gx_site, x) without a pass of its own.  No gate, no folded activation of the site's own.
+template <int GDT, int XDT, int CM, bool NT, bool ELIDE = false, bool GATE = false, int G2DT = -1, int DACT = 0>
 __global__ __launch_bounds__(kBlock) void ste_relu_bwd_kernel(SteBwdOp op, EwGeom geo, int param_per_channel,
                                                               const void* __restrict__ g, const void* __restrict__ x,
                                                               void* __restrict__ gx, ActSpec act, const void* __restrict__ g2 = nullptr,
                                                               BwdRiders rd = BwdRiders{nullptr, nullptr, 0}) {
     static_assert(G2DT < 0 || (!ELIDE && GDT == QS_F32 && G2DT != QS_F32), "the second gradient is a 2-byte stream next to an fp32 one");
+    static_assert(DACT == 0 || (!GATE && !ELIDE), "the caller's activation: its input is the second stream, every lane loads it");
     // the activation's backward at one element: `xv` is the activation's input -- or, with GATE, the recorded bit as 1.0 / 0.0;
     // `applied` the clamped, masked gradient.  Open gate: it passes; closed: 0 (rectifiers) or applied * slope (leaky)
     auto gated = [&](float xv, float applied) -> float {
+        if constexpr (DACT == QS_DACT_GELU) return round_to_dtype(applied, XDT) * gelu_grad_factor(xv);
         const bool open = GATE ? (xv > 0.0f) : act_open(xv, act);
         return open ? applied : act_closed(applied, act, XDT);
     };

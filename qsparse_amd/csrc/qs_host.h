@@ -34,6 +34,8 @@ using namespace qs;
 // folded activations: `pre_relu` arguments of the ABI are 0, 1 (nn.ReLU) or a qs_activation() handle; defined in api_core.hip
 // (one table for every translation unit).  Returns QS_OK and the descriptor, or QS_ERR_ARG for an unknown handle.
 int qs_act_resolve(int pre_relu, ActSpec* out);
+// the STE backward with the caller's activation's backward (qs_ste_relu_bwd_args::act_x, v26); defined in api_quant_bwd_act.hip
+int qs_ste_act_bwd_impl(const qs_ste_relu_bwd_args& a);
 
 // statistics flags (QS_MEAN_*) -> the folded activation's descriptor and the flags' low byte.  The IDENTITY -- nn.LeakyReLU(1.0),
 // `x > 0 ? x : x * 1.0f`, what a site without a foldable activation folds to obtain its autocast image -- is dropped here: |x * 1| is

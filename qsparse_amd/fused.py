@@ -683,8 +683,14 @@ class _SiteStep(torch.autograd.Function):
     """the whole site through qs_site_fwd / qs_site_bwd; same results as the statistics + select + `_FusedApply` route"""
 
     @staticmethod
-    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None, gathered=None, world=1, add_cell=None):
+    def forward(ctx, h, plan, flags, t_mag, k, t_q, bits, notch, mask_c, scale, image_dtype=None, gathered=None, world=1, add_cell=None,
+                act_out=None):
         # add_cell: of the promoting add that produced h (`grad_image_cell`), or None
+        # act_out: the caller applied an nn.GELU under no_grad -- act_out = gelu(h) is what the site reads, h (the first, differentiable
+        # argument) is the GELU's INPUT, kept for the backward, whose kernel multiplies by the GELU's derivative (`act_backward`)
+        act_in = None
+        if act_out is not None:
+            act_in, h = h, act_out
         want_gate = bool((flags & _hip.SITE_PRE_RELU) and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(h, dtype=plan.out_dtype)
         make_image = image_dtype is not None and (want_gate or not ctx.needs_input_grad[0])
@@ -714,8 +720,9 @@ class _SiteStep(torch.autograd.Function):
         ctx.act, ctx.dec, ctx.add_cell = plan.c.act, dec, add_cell
         ctx.x_shape, ctx.x_dtype = h.shape, h.dtype
         keep_x = bool(flags & _hip.SITE_PRE_RELU) and not want_gate
+        ctx.has_act_x = act_in is not None
         ctx.save_for_backward(mask_c if mask_c is not None else h.new_empty(0), scale,
-                              bits_t if want_gate else (h if keep_x else h.new_empty(0)))
+                              bits_t if want_gate else (h if keep_x else h.new_empty(0)), act_in if act_in is not None else h.new_empty(0))
         ctx.set_materialize_grads(False)
         if make_image:
             im = img if fused_image else y.to(image_dtype)      # RNE(y): the cast autocast would apply in front of a convolution
@@ -725,7 +732,7 @@ class _SiteStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g16=None, g16b=None):
         plan, flags = ctx.plan, ctx.flags
-        n_in = 14
+        n_in = 15
         override = ctx.__dict__.pop("_qs_override", None)
         if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
             g, g16, g16b = override[0], None, None
@@ -733,7 +740,9 @@ class _SiteStep(torch.autograd.Function):
             g16, g16b = g16b, None       # (only the second consumer's share exists: it is the one 2-byte stream)
         if g is None and g16 is None:
             return (None,) * n_in
-        mask_c, scale, third = ctx.saved_tensors
+        mask_c, scale, third, act_x = ctx.saved_tensors
+        if not ctx.has_act_x:
+            act_x = None
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
         pre_relu = bool(flags & _hip.SITE_PRE_RELU)
@@ -759,7 +768,7 @@ class _SiteStep(torch.autograd.Function):
 
         if g16 is not None:
             # the image's consumer delivered its low-precision gradient: g + float(g16) inside the kernel (qs_site_bwd g2)
-            dual_ok = (ctx.has_gate and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
+            dual_ok = ((ctx.has_gate or act_x is not None) and dense(g16) and (g is None or (g.dtype == torch.float32 and dense(g)))
                        and _hip.elide_mode != "all" and not _hip.logging_events())
             if g16b is not None and not (dual_ok and f32_gated and g16b.dtype == g16.dtype and dense(g16b)):
                 g = g16b.float() if g is None else g + g16b.float()    # the second consumer's share as autograd would add it
@@ -771,8 +780,10 @@ class _SiteStep(torch.autograd.Function):
                     _hip.image_byte_delta["apply_bwd"] += g16.numel() * g16.element_size() - (g16.numel() * 4 if g is None else 0)
                     if g16b is not None:
                         _hip.image_byte_delta["apply_bwd"] += g16b.numel() * g16b.element_size()
-                _hip.site_bwd(plan.ref, g, third, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16, decimal=ctx.dec, g3=g16b,
-                              gx_image=grad_image(gx))
+                if act_x is not None:
+                    ROUTES["act_backward"] += 1
+                _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, flags & _hip.SITE_NO_MASK, lo_mul, hi_mul, g2=g16,
+                              decimal=ctx.dec, g3=g16b, gx_image=grad_image(gx), act_x=act_x)
                 return (gx,) + (None,) * (n_in - 1)
             g = _whole(g, g16, g16b)          # autograd's own accumulation, then the usual routes
         fast = (dense(g) and (ctx.has_gate or not pre_relu) and g.dtype in (torch.float32, ctx.x_dtype)
@@ -781,7 +792,10 @@ class _SiteStep(torch.autograd.Function):
             gx = torch.empty(ctx.x_shape, dtype=ctx.x_dtype, device=g.device, memory_format=fmt)
             bflags = (flags & _hip.SITE_NO_MASK) | (_hip.SITE_ELIDE if _hip.elide_mode == "all" else 0)
             gimg = grad_image(gx) if (g.dtype == torch.float32 and not (bflags & _hip.SITE_ELIDE)) else None
-            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul, decimal=ctx.dec, gx_image=gimg)
+            if act_x is not None:
+                ROUTES["act_backward"] += 1
+            _hip.site_bwd(plan.ref, g, third if ctx.has_gate else None, gx, bflags, lo_mul, hi_mul, decimal=ctx.dec, gx_image=gimg,
+                          act_x=act_x)
             return (gx,) + (None,) * (n_in - 1)
         mask = mask_c.detach().view(-1) if mask_c.numel() else None      # (the layers' own parameters were saved, not aliases)
         is_dec = ctx.dec is not None
@@ -793,6 +807,8 @@ class _SiteStep(torch.autograd.Function):
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, is_dec, -1, lo_mul, hi_mul, False, out_dtype, chan_mask=mask, mask_channel_index=plan.cd)
+        if act_x is not None:            # the caller's nn.GELU, as autograd's GeluBackward0 would evaluate it on this gradient
+            gx = torch.ops.aten.gelu_backward(gx if gx.dtype == act_x.dtype else gx.to(act_x.dtype), act_x)
         return (gx,) + (None,) * (n_in - 1)
 
 
@@ -1142,7 +1158,7 @@ def _pair_config(act, p, q, cb, qc):
 
 class _FastPair:
     __slots__ = ("epoch", "mods", "hooks", "config", "xsig", "state", "ptrs", "plan", "pre_relu", "fold", "max_schedule", "C",
-                 "graph_safe", "notch", "k_of", "autocast")
+                 "graph_safe", "notch", "k_of", "autocast", "dact")
 
     def __deepcopy__(self, memo):        # raw pointers and object identities: a copied network arms its own
         return None
@@ -1193,6 +1209,9 @@ class _FastPair:
         f.graph_safe, f.notch = bool(get_option("graph_safe")), (1 if qc.flip_axis else 0)
         f.k_of = {}
         f.autocast = cls._autocast()         # (the identity fold is chosen per autocast state)
+        # `act_backward`: an nn.GELU (erf form) in front of the site -- its forward stays ATen's pass, its backward rides in the site's
+        # backward kernel (qs_site_bwd_args::act_x)
+        f.dact = fold == 3 and type(act) is nn.GELU and getattr(act, "approximate", "none") == "none"
         return f
 
     @staticmethod
@@ -1259,7 +1278,7 @@ class _FastPair:
         # ---- from here on as `fused_prune_quantize` does for a steady-state step of the composite route ----
         pre_relu = self.pre_relu
 
-        def site(h):
+        def site(h, act_in=None):
             _arm_accumulators(q)
             if self.graph_safe:
                 qc._advance_t(qc.__dict__["_t_dev"], bumped_by_kernel=True)
@@ -1272,8 +1291,12 @@ class _FastPair:
                      | (_hip.SITE_PRE_RELU if pre_relu else 0) | (_hip.SITE_ELIDE if _hip.elide_mode != "off" else 0))
             image_bookkeeping(plan)
             image_dtype = _image_dtype(plan, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
-            out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1,
-                                  grad_image_cell(h))
+            if act_in is None:
+                out = _SiteStep.apply(h, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1,
+                                      grad_image_cell(h))
+            else:
+                out = _SiteStep.apply(act_in, plan, flags, t_mag, k, t_q, q.bits, self.notch, state[1], state[2], image_dtype, None, 1,
+                                      None, h)
             _disarm_accumulators(q)
             if type(out) is tuple:
                 return _as_dual(out[0], out[1], plan, img_b=out[2])
@@ -1282,6 +1305,17 @@ class _FastPair:
         if self.fold == 2:
             return _with_owned_relu(x, site, pre_relu)
         if self.fold == 3:
+            # (not float16: ATen's fp16 gelu / gelu_backward kernels give different bits in a full block of their vectorised kernel
+            #  and in its tail block -- 2 of 20,000 (dy, x) pairs, tools/probes/probe_gelu_tail.py; the kernel here equals the full-block
+            #  result everywhere, so a tensor whose size is not a multiple of ATen's block would differ from the module-by-module route.
+            #  bf16 and float32 are one function of (dy, x) in ATen and here.)
+            if (self.dact and x.requires_grad and torch.is_grad_enabled() and get_option("act_backward") and x.data_ptr() % 16 == 0
+                    and x.dtype in (torch.float32, torch.bfloat16) and _hip.dense_any_order(x)):
+                with torch.no_grad():
+                    h = act(x)           # ATen's own forward; the graph sees one node, x -> y, whose backward kernel knows the GELU
+                if h.stride() == x.stride() and h.dtype == x.dtype and h.data_ptr() % 16 == 0:
+                    return site(h, x)
+                del h
             return site(act(x))          # an activation the kernels do not fold: ATen applies it, the site follows
         return site(x)
 

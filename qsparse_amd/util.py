@@ -13,7 +13,7 @@ from qsparse_amd import _hip
 
 _options_ = {"log_on_created": True, "log_during_train": True, "sync_statistics": None, "graph_safe": False, "preserve_dtype": False, "fold_relu": True,
              "elide_pruned": "forward", "relu_gate": True, "batch_weights": True, "autocast_image": True,
-             "saturate": False}
+             "saturate": False, "act_backward": True}
 
 
 _options_epoch = [0]       # bumped by every set_options call: cached per-site decisions that depend on an option are keyed on it
@@ -45,7 +45,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
                 sync_statistics: Optional[bool] = None, graph_safe: Optional[bool] = None,
                 preserve_dtype: Optional[bool] = None, fold_relu: Optional[bool] = None,
                 elide_pruned: Optional[str] = None, relu_gate: Optional[bool] = None, batch_weights: Optional[bool] = None,
-                autocast_image: Optional[bool] = None, saturate: Optional[bool] = None):
+                autocast_image: Optional[bool] = None, saturate: Optional[bool] = None, act_backward: Optional[bool] = None):
     """update the global options; ``None`` leaves an option untouched (reference util.py:13-26).
     Exported as ``set_qsparse_options``.  ``sync_statistics`` (extension, default auto) controls the
     cross-rank exchange of mask/scale statistics under ``torch.distributed`` (see distributed.py; ``"always"``: also in a
@@ -71,7 +71,7 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     ``batch_weights`` (default True, bit-identical): the weight quantizers of a network built by ``convert`` are evaluated
     with three multi-tensor launches at the start of the root's forward instead of three per layer (see batch.py; a
     layer the forward never reaches is rolled back, so the state machines advance exactly as layer by layer);
-    ``autocast_image`` (extension, default False; value-identical): under ``torch.autocast`` a fused ReLU -> prune -> quantize
+    ``autocast_image`` (extension, default True since round 5; value-identical): under ``torch.autocast`` a fused ReLU -> prune -> quantize
     site hands the first convolution / linear that consumes its float32 output the bf16 image directly and takes that
     consumer's bf16 gradient as it is -- no ``fp32 <-> bf16`` cast passes around the site (see fused.py, "Autocast image");
     the site's output is then a ``torch.Tensor`` subclass;
@@ -80,7 +80,10 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     the reference's forward spells out but loses (its ``q.float().clamp_(...)`` acts on a temporary, quantize.py:56-62,
     110-116, so its tensor's largest element maps to code ``+2^(bits-1)``, one above the range).  Per quantizer:
     ``ScalerQuantizer(saturate=True)`` / ``quantize_with_scaler(..., saturate=True)``; ``None`` there follows this option.
-    With it every code fits its bit width, so ``export_integer(...)`` yields int8 / packed int4 tensors directly."""
+    With it every code fits its bit width, so ``export_integer(...)`` yields int8 / packed int4 tensors directly;
+    ``act_backward`` (default True, bit-identical): an ``nn.GELU()`` (erf form) that ``convert`` put in front of a prune -> quantize
+    site keeps ATen's forward pass, but its backward -- ``gelu_backward(g, x)`` -- is evaluated by the site's backward kernel on the
+    gradient it has in registers instead of by a pass of its own (8 -> 2 B/elem; ATen's GPU arithmetic reproduced bit for bit)."""
     _options_epoch[0] += 1
     if elide_pruned is not None:
         if elide_pruned not in ("off", "forward", "all"):
@@ -90,7 +93,8 @@ def set_options(log_on_created: Optional[bool] = None, log_during_train: Optiona
     for key, val in (("log_on_created", log_on_created), ("log_during_train", log_during_train),
                      ("sync_statistics", sync_statistics), ("graph_safe", graph_safe),
                      ("preserve_dtype", preserve_dtype), ("fold_relu", fold_relu), ("relu_gate", relu_gate),
-                     ("batch_weights", batch_weights), ("autocast_image", autocast_image), ("saturate", saturate)):
+                     ("batch_weights", batch_weights), ("autocast_image", autocast_image), ("saturate", saturate),
+                     ("act_backward", act_backward)):
         if val is not None:
             _options_[key] = val
 

@@ -154,7 +154,8 @@ class Net(nn.Module):
 
 
 def run(d, image, seed):
-    qs.set_qsparse_options(autocast_image=image)
+    # (the run without the image is also the run without the fused backward of an nn.GELU in front of the site: ATen's own pass there)
+    qs.set_qsparse_options(autocast_image=image, act_backward=image)
     try:
         net = Net(d)
         if d["quant_weights"] is not None:
@@ -199,7 +200,7 @@ def run(d, image, seed):
         state = {k: v.detach().clone() for k, v in net.state_dict().items() if not k.endswith((".weight", ".bias")) or "quantize" in k or "site" in k}
         return trace, net.observed, net.kinds, state
     finally:
-        qs.set_qsparse_options(autocast_image=True)
+        qs.set_qsparse_options(autocast_image=True, act_backward=True)
 
 
 def one_case(rng, idx):
