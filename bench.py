@@ -643,12 +643,55 @@ def token_major_site(device, steps=40):
             "frac_of_hbm_peak": round(14.25 * n / ms / 1e6 / HBM_PEAK_GBS, 4), "kept_channel_fraction": round(site[0][1].mask.float().mean().item(), 4)}
 
 
+def token_net(device, batch=128, steps=10):
+    """SURVEY 8f widened (late round 6): a whole token-major network -- examples/models.py::TokenNet (patch embedding, 12 blocks of
+    LayerNorm -> Linear(768, 3072) -> nn.GELU -> Linear + residual; 196 tokens) plain against the --pq recipe on its hidden activations
+    (prune(0.75, dimensions={2}) + 4-bit quantization behind the nn.GELU, 4-bit Linear / Conv2d weights), bf16 autocast, SGD.  The
+    sites sit behind an activation the kernels do not fold: identity fold for the autocast image, GELU backward in the site's
+    backward kernel (`act_backward`, ABI v26)."""
+    import qsparse_amd as qs
+    from examples.models import TokenNet, convert_pq_tokens
+    from qsparse_amd.fused import ROUTES
+
+    x = torch.randn(batch, 3, 224, 224, device=device)
+    y = torch.randint(0, 1000, (batch,), device=device)
+
+    def measure(pq):
+        torch.manual_seed(0)
+        net = TokenNet(num_classes=1000, dim=768, hidden=3072, depth=12, patch=16, act=nn.GELU)
+        if pq:
+            net = convert_pq_tokens(net, act=nn.GELU, sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1)
+        net = net.to(device).train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+
+        def step(_=0):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = F.cross_entropy(net(x).float(), y)
+            loss.backward()
+            opt.step()
+
+        for _ in range(8):
+            step()
+        return _steady_ms(step, steps)
+
+    plain = measure(False)
+    before = dict(ROUTES)
+    pq = measure(True)
+    torch.cuda.empty_cache()
+    return {"model": "TokenNet dim 768 / hidden 3072 / depth 12 / patch 16 (196 tokens), nn.GELU sites", "input_shape": [batch, 3, 224, 224],
+            "dtype": "bf16 autocast, fp32 master weights", "optimizer": "SGD momentum 0.9", "steps": steps, "plain_ms": round(plain, 3),
+            "pq_ms": round(pq, 3), "pq_over_plain": round(pq / plain, 4),
+            "routes": {k: ROUTES[k] - before.get(k, 0) for k in ROUTES if ROUTES[k] - before.get(k, 0)}}
+
+
 def extra_configs(device, only=None):
     """configs 2-4 of BASELINE.json; a failure in one of them is recorded, it never costs the headline line"""
     out = {}
     for name, fn in (("host_overhead_per_site", lambda: host_overhead(device)),
                      ("weights_pruned_quantized", lambda: weights_pruned_config(device)),
                      ("token_major_site_256x197x3072", lambda: token_major_site(device)),
+                     ("token_net_gelu_b128", lambda: token_net(device)),
                      ("config2_quantize8_256x64x56x56", lambda: config2(device)),
                      ("config3_resnet18_cifar_b128", lambda: resnet_config("resnet18", 128, device, 10)),
                      ("config4_resnet50_imagenet_b256", lambda: resnet_config("resnet50", 256, device, 5))):
