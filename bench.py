@@ -678,11 +678,32 @@ def token_net(device, batch=128, steps=10):
     plain = measure(False)
     before = dict(ROUTES)
     pq = measure(True)
+    routes = {k: ROUTES[k] - before.get(k, 0) for k in ROUTES if ROUTES[k] - before.get(k, 0)}
     torch.cuda.empty_cache()
-    return {"model": "TokenNet dim 768 / hidden 3072 / depth 12 / patch 16 (196 tokens), nn.GELU sites", "input_shape": [batch, 3, 224, 224],
+    variants = {}
+    for key, label, opts, restore in (
+            ("opt_in_extensions", "preserve_dtype=True, elide_pruned='all'", dict(preserve_dtype=True, elide_pruned="all"),
+             dict(preserve_dtype=False, elide_pruned="forward")),
+            ("without_identity_fold_and_act_backward", "round 6 before the GELU work: no image for sites behind nn.GELU, ATen's gelu_backward pass",
+             dict(act_backward=False), dict(act_backward=True))):
+        try:
+            qs.set_qsparse_options(**opts)
+            if key.startswith("without"):
+                import qsparse_amd.fused as _f
+                _f._IDENTITY_FOLD = False
+            v = measure(True)
+            variants[key] = {"options": label, "pq_ms": round(v, 3), "pq_over_plain": round(v / plain, 4)}
+        except Exception as e:      # noqa: BLE001  (recorded verbatim in the JSON line)
+            variants[key] = {"options": label, "error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            qs.set_qsparse_options(**restore)
+            import qsparse_amd.fused as _f
+            _f._IDENTITY_FOLD = os.environ.get("QS_NO_IDENTITY_FOLD", "0") != "1"
+            torch.cuda.empty_cache()
+    return {"variants": variants, "model": "TokenNet dim 768 / hidden 3072 / depth 12 / patch 16 (196 tokens), nn.GELU sites", "input_shape": [batch, 3, 224, 224],
             "dtype": "bf16 autocast, fp32 master weights", "optimizer": "SGD momentum 0.9", "steps": steps, "plain_ms": round(plain, 3),
             "pq_ms": round(pq, 3), "pq_over_plain": round(pq / plain, 4),
-            "routes": {k: ROUTES[k] - before.get(k, 0) for k in ROUTES if ROUTES[k] - before.get(k, 0)}}
+            "routes": routes}
 
 
 def extra_configs(device, only=None):
