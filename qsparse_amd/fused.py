@@ -812,10 +812,42 @@ class _SiteStep(torch.autograd.Function):
         return (gx,) + (None,) * (n_in - 1)
 
 
-def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu=False) -> torch.Tensor:
+class _ActGrad(torch.autograd.Function):
+    """h = gelu(x) was computed under no_grad (`act_rider`): this node puts it back into the graph -- its backward is autograd's own
+    GeluBackward0, `gelu_backward(g, x)` -- for the routes whose backward kernel does not evaluate the GELU itself"""
+
+    @staticmethod
+    def forward(ctx, x, h):
+        ctx.save_for_backward(x)
+        return h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return torch.ops.aten.gelu_backward(g if g.dtype == x.dtype else g.to(x.dtype), x), None
+
+
+def act_rider(act, x):
+    """`act_backward`: the nn.GELU (erf form) `act` in front of a site keeps ATen's forward, evaluated here under no_grad, and hands its
+    backward to the site (`_SiteStep(act_out=)`, qs_site_bwd_args::act_x; `_ActGrad` elsewhere).  Returns h = act(x) detached from the
+    graph, or None when the site should run `act` as an ordinary module (not a GELU, option off, nothing to differentiate, float16 --
+    see `_FastPair.try_run` --, a layout the kernels do not address in place)."""
+    if not (type(act) is nn.GELU and getattr(act, "approximate", "none") == "none" and isinstance(x, torch.Tensor) and x.is_cuda
+            and x.requires_grad and torch.is_grad_enabled() and get_option("act_backward") and x.data_ptr() % 16 == 0
+            and x.dtype in (torch.float32, torch.bfloat16) and _hip.dense_any_order(x)):
+        return None
+    with torch.no_grad():
+        h = act(x)           # ATen's own forward; the graph sees one node, x -> y, whose backward knows the GELU
+    if h.stride() == x.stride() and h.dtype == x.dtype and h.data_ptr() % 16 == 0:
+        return h
+    return None
+
+
+def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_relu=False, act_in=None) -> torch.Tensor:
     """one training / evaluation step of ``q(p(h))`` on a GPU tensor -- or of ``q(p(act(h)))`` with ``pre_relu``: True for a
     folded nn.ReLU, or the handle of another folded activation (``_fold_handle``; the caller guarantees that the quantizer is
-    active this step, so the activation is applied inside the kernels)."""
+    active this step, so the activation is applied inside the kernels).  ``act_in``: h is `act_rider(gelu, act_in)` -- detached;
+    the result's gradient flows to act_in through the GELU's backward."""
     cb, qc = p.callback, q.callback
     cd = _chan_dim(p, h) or 1            # the dim the channel mask runs along (the caller checked `_eligible`)
     C = h.shape[cd]
@@ -981,6 +1013,8 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
             q._steps.add(q._n_updates, 1)
 
     # ---- apply: one read of h, one write ----
+    if act_in is not None and site is None:
+        h = _ActGrad.apply(act_in, h)          # (only the composite's backward kernel evaluates the GELU itself)
     if not prune_on and not quant_on:
         return _hip.act_torch(pre_relu, h) if pre_relu else h
     if pre_relu and not quant_on:      # cannot happen when the caller checked q.is_active(); stay correct anyway
@@ -994,8 +1028,12 @@ def fused_prune_quantize(p: PruneLayer, q: QuantizeLayer, h: torch.Tensor, pre_r
         image_dtype = _image_dtype(site, training_needs_gate=torch.is_grad_enabled() and h.requires_grad) if pre_relu else None
         if site_gathered is not None:
             flags |= _hip.SITE_STATS_DONE
-        out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
-                              p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world, grad_image_cell(h))
+        if act_in is None:
+            out = _SiteStep.apply(h, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
+                                  p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world, grad_image_cell(h))
+        else:
+            out = _SiteStep.apply(act_in, site, flags, t_mag, k, t_q, q.bits, 1 if qc.flip_axis else 0,
+                                  p.mask if prune_on else None, q.weight, image_dtype, site_gathered, world, None, h)
         if live or frozen:
             _disarm_accumulators(q)
         # (what `_FastPair.arm` looks at: a steady-state step of the composite route, no exchange)
@@ -1309,13 +1347,9 @@ class _FastPair:
             #  and in its tail block -- 2 of 20,000 (dy, x) pairs, tools/probes/probe_gelu_tail.py; the kernel here equals the full-block
             #  result everywhere, so a tensor whose size is not a multiple of ATen's block would differ from the module-by-module route.
             #  bf16 and float32 are one function of (dy, x) in ATen and here.)
-            if (self.dact and x.requires_grad and torch.is_grad_enabled() and get_option("act_backward") and x.data_ptr() % 16 == 0
-                    and x.dtype in (torch.float32, torch.bfloat16) and _hip.dense_any_order(x)):
-                with torch.no_grad():
-                    h = act(x)           # ATen's own forward; the graph sees one node, x -> y, whose backward kernel knows the GELU
-                if h.stride() == x.stride() and h.dtype == x.dtype and h.data_ptr() % 16 == 0:
-                    return site(h, x)
-                del h
+            h = act_rider(act, x) if self.dact else None
+            if h is not None:
+                return site(h, x)
             return site(act(x))          # an activation the kernels do not fold: ATen applies it, the site follows
         return site(x)
 
@@ -1348,17 +1382,20 @@ class FusedPruneQuantize(nn.Sequential):
                 out = fused_prune_quantize(p, q, x, pre_relu=handle)
             self.__dict__["_qs_fast"] = _FastPair.arm(self, x, fold, handle)
             return out
-        h = act(x)
+        h = act_rider(act, x) if q.is_active() else None
+        act_in = x if h is not None else None
+        if h is None:
+            h = act(x)
         if _eligible(p, q, h):
             # (under autocast an active site folds the identity: it then writes its image like a site behind a foldable activation)
             ident = identity_fold_handle(h) if q.is_active() else 0
-            out = fused_prune_quantize(p, q, h, pre_relu=ident) if ident else fused_prune_quantize(p, q, h)
+            out = fused_prune_quantize(p, q, h, pre_relu=ident or False, act_in=act_in)
             if h is x:
                 self.__dict__["_qs_fast"] = _FastPair.arm(self, x, 0, ident)
             elif isinstance(h, torch.Tensor) and not getattr(act, "inplace", False):
                 self.__dict__["_qs_fast"] = _FastPair.arm(self, x, 3, ident)
             return out
-        return q(p(h))
+        return q(p(h if act_in is None else _ActGrad.apply(act_in, h)))
 
 
 FusedPruneQuantize.__name__ = "Sequential"   # keep str(model) identical to the reference's tree

@@ -180,3 +180,40 @@ def test_converted_site_trains_to_the_same_bits(kind, autocast, monkeypatch):
             assert same(u, v), (s, name, int((u != v).sum()), u.numel())
     for k in runs[False][1]:
         assert same(runs[False][1][k], runs[True][1][k]), k
+
+
+def test_with_the_statistics_exchange_live_the_slow_route_carries_the_gelu_too():
+    """a data-parallel step (`sync_statistics="always"` in a one-rank group) never takes the steady-state fast path: the full route
+    (`fused_prune_quantize(act_in=)`: two calls around the record exchange) hands the GELU's backward to the site as well"""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        qs.set_qsparse_options(sync_statistics="always")
+        runs = {}
+        for on in (False, True):
+            qs.set_qsparse_options(act_backward=on)
+            before = fused.ROUTES["act_backward"]
+            net = build("tokens")
+            outs = []
+            for step in range(6):
+                x = torch.randn((6, 10, 32), generator=gen(300 + step)).to(DEV).requires_grad_(True)
+                net.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = net(x)
+                y.float().square().mean().backward()
+                outs.append([("y", y.detach().float().cpu()), ("gx", x.grad.cpu())] + [(n, p.grad.cpu()) for n, p in net.named_parameters() if p.grad is not None])
+            assert (fused.ROUTES["act_backward"] - before > 0) == on
+            runs[on] = (outs, {k: v.cpu() for k, v in net.state_dict().items()})
+        for s, (a, b) in enumerate(zip(runs[False][0], runs[True][0])):
+            for (name, u), (_, v) in zip(a, b):
+                assert same(u, v), (s, name)
+        for k in runs[False][1]:
+            assert same(runs[False][1][k], runs[True][1][k]), k
+    finally:
+        qs.set_qsparse_options(act_backward=True)
+        from qsparse_amd import util
+        util._options_["sync_statistics"] = None          # (set_qsparse_options(x=None) leaves x untouched)
+        dist.destroy_process_group()
