@@ -1450,6 +1450,12 @@ class FusedActQuantize(nn.Sequential):
             if fold == 2:
                 return _with_owned_relu(x, lambda h: fused_relu_quantize(q, h, handle), handle)
             return fused_relu_quantize(q, x, handle)
+        if type(act) is nn.GELU and q.is_active() and _quantizer_foldable(q, x) and not _hooked(act, q, q.callback):
+            # `act_backward`: ATen's GELU forward under no_grad, its backward in the quantizer's backward kernel (`_QuantStep(act_out=)`)
+            h = act_rider(act, x)
+            if h is not None:
+                y = q.single_call_step(h, q._steps.read(q._n_updates), act_in=x) if q.initted else None
+                return y if y is not None else q(_ActGrad.apply(x, h))
         return q(act(x))
 
 
@@ -1490,7 +1496,7 @@ def _is_pair(m: nn.Module) -> bool:
 
 
 def _is_act_quantize(m: nn.Module) -> bool:
-    return len(m) == 2 and type(m[0]) in _FOLDABLE and isinstance(m[1], QuantizeLayer)
+    return len(m) == 2 and (type(m[0]) in _FOLDABLE or type(m[0]) is nn.GELU) and isinstance(m[1], QuantizeLayer)
 
 
 def fuse_prune_quantize_pairs(model: nn.Module) -> nn.Module:

@@ -570,9 +570,14 @@ class _QuantStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale, amax, bits, t, t_dev, n_updates, pre_relu, update, notch, out_dtype, saturate=None, image_dtype=None,
-                add_cell=None):
+                add_cell=None, act_out=None):
         # add_cell: of the promoting add that produced x (fused.grad_image_cell), or None
+        # act_out: the caller applied an nn.GELU under no_grad (fused.act_rider) -- act_out = gelu(x) is what the quantizer reads, x (the
+        # differentiable argument) is the GELU's input: kept, and the backward kernel multiplies by the GELU's derivative there
         ctx.add_cell = add_cell
+        act_in = None
+        if act_out is not None:
+            act_in, x = x, act_out
         want_gate = bool(pre_relu and ctx.needs_input_grad[0] and get_option("relu_gate"))
         y = torch.empty_like(x, dtype=out_dtype)
         # an owned nn.ReLU(inplace=True) in front of this quantizer: the apply kernel writes relu(x) back into x itself
@@ -592,7 +597,9 @@ class _QuantStep(torch.autograd.Function):
         ctx.bits, ctx.notch, ctx.pre_relu, ctx.has_gate = bits, notch, pre_relu, want_gate
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         ctx.channels_last = x.dim() in (4, 5) and not x.is_contiguous()
-        ctx.save_for_backward(scale, gate_bits if want_gate else (x if pre_relu else x.new_empty(0)))
+        ctx.has_act_x = act_in is not None
+        ctx.save_for_backward(scale, gate_bits if want_gate else (x if pre_relu else x.new_empty(0)),
+                              act_in if act_in is not None else x.new_empty(0))
         if make_image:
             ctx.set_materialize_grads(False)
             return y, img, img.detach()      # (twice: a gradient slot of its own for a second autocast consumer, fused.py "Second image")
@@ -600,7 +607,7 @@ class _QuantStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, g16=None, g16b=None):
-        n_in = 14
+        n_in = 15
         override = ctx.__dict__.pop("_qs_override", None)
         if override is not None:         # a late hook on the output replaced its whole gradient (fused._late_hook)
             g, g16, g16b = override[0], None, None
@@ -608,9 +615,33 @@ class _QuantStep(torch.autograd.Function):
             g16, g16b = g16b, None
         if g is None and g16 is None:
             return (None,) * n_in
-        scale, second = ctx.saved_tensors
+        scale, second, act_x = ctx.saved_tensors
         limit = 2.0 ** (ctx.bits - 1)
         lo_mul, hi_mul = -limit + ctx.notch, limit - 1 + ctx.notch
+        if ctx.has_act_x:
+            # the caller's nn.GELU: one pass -- STE clamp of (g [+ g16]), rounded to x's dtype, times the GELU's derivative at act_x
+            # (qs_ste_relu_bwd_args::act_x) -- when every operand lies in memory like act_x; else the ordinary routes below, then
+            # ATen's gelu_backward as autograd's GeluBackward0 would run it.  (The site's own activation is none or the folded
+            # identity: its gate changes nothing.)
+            from qsparse_amd import fused
+            if g16b is not None:
+                g, g16b = (g16b.float() if g is None else g + g16b.float()), None
+
+            def like_x(t_):
+                return t_ is None or (t_.shape == act_x.shape and t_.stride() == act_x.stride() and t_.data_ptr() % 16 == 0)
+
+            if (like_x(g) and like_x(g16) and (g is None or g.dtype in (torch.float32, act_x.dtype)) and (g16 is None or g is None or g.dtype == torch.float32)
+                    and _hip.dense_any_order(act_x) and not _hip.logging_events()):
+                n = act_x.numel()
+
+                def flat(t_):
+                    return None if t_ is None else t_.as_strided((n,), (1,))
+
+                out = _hip.ste_act_bwd(flat(g), flat(act_x), scale, False, lo_mul, hi_mul, g2=flat(g16))
+                fused.ROUTES["act_backward"] += 1
+                return (out.as_strided(act_x.shape, act_x.stride()),) + (None,) * (n_in - 1)
+            if g16 is not None:
+                g, g16 = fused._whole(g, g16, None), None
         if ctx.pre_relu:
             gate = _hip.ReluGate.from_saved(second, ctx.x_shape, ctx.x_dtype, ctx.channels_last) if ctx.has_gate else None
             from qsparse_amd import fused
@@ -639,6 +670,8 @@ class _QuantStep(torch.autograd.Function):
         else:
             out_dtype = ctx.x_dtype if g.dtype == torch.float32 else g.dtype
             gx = _hip.ste_bwd(g, scale, False, -1, lo_mul, hi_mul, False, out_dtype)
+        if ctx.has_act_x:
+            gx = torch.ops.aten.gelu_backward(gx if gx.dtype == act_x.dtype else gx.to(act_x.dtype), act_x)
         return (gx,) + (None,) * (n_in - 1)
 
 
@@ -704,7 +737,7 @@ class QuantizeLayer(nn.Module):
         t = self._steps.read(self._n_updates)
         return t >= self.timeout and (self.training or self._quantized)
 
-    def single_call_step(self, x: torch.Tensor, t: int, pre_relu: bool = False):
+    def single_call_step(self, x: torch.Tensor, t: int, pre_relu: bool = False, act_in=None):
         """the active step of a tensor-wise ScalerQuantizer on a dense GPU tensor through one call into the library
         (qs_quantize_step); None when this layer / input is not one it covers -- the caller then takes the protocol route
         (callback.optimize, callback.forward), which the composite reproduces launch for launch"""
@@ -745,15 +778,21 @@ class QuantizeLayer(nn.Module):
             if stat is None:
                 stat = self.__dict__["_qs_image_stat"] = fused.ImageStat()
             fused.image_bookkeeping(stat)       # (nobody took the last image -- no autocast matmul behind this site: stop making them)
-            if stat.image_ok and (not (torch.is_grad_enabled() and x.requires_grad) or get_option("relu_gate")):
+            if stat.image_ok and (not (torch.is_grad_enabled() and (x.requires_grad or act_in is not None)) or get_option("relu_gate")):
                 image_dtype = fused.autocast_image_dtype()
         cell = None
         if pre_relu:
             from qsparse_amd import fused
-            cell = fused.grad_image_cell(x)
-        y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
-                             self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
-                             cb.code_range(self.bits), image_dtype, cell)
+            cell = fused.grad_image_cell(x) if act_in is None else None
+        # (act_in: x is fused.act_rider(gelu, act_in) -- detached; the gradient flows to act_in through the GELU's backward)
+        if act_in is None:
+            y = _QuantStep.apply(x, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
+                                 self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
+                                 cb.code_range(self.bits), image_dtype, cell)
+        else:
+            y = _QuantStep.apply(act_in, self.weight.data, cb.tensor_accumulator(x.device) if update else None, self.bits, cb.t, t_dev,
+                                 self._n_updates.data if update else None, pre_relu, mode, 1 if cb.flip_axis else 0, _out_dtype(x),
+                                 cb.code_range(self.bits), image_dtype, None, x)
         if type(y) is tuple:
             y = fused._as_dual(y[0], y[1], stat, img_b=y[2])
         self.__dict__["_qs_accumulator_armed"] = False

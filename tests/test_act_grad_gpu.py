@@ -133,7 +133,9 @@ class TokenSite(nn.Module):
 
 def build(kind):
     torch.manual_seed(0)
-    if kind == "tokens":
+    if kind == "tokens_q":               # the quantize-only recipe: Sequential(nn.GELU, QuantizeLayer)
+        net = TokenSite(32, 64, {2})
+    elif kind == "tokens":
         net = TokenSite(32, 64, {2})
         net = qs.convert(net, qs.prune(sparsity=0.5, dimensions={2}, start=1, interval=1, repetition=1), activation_layers=[nn.GELU], log=False)
     else:
@@ -143,7 +145,7 @@ def build(kind):
     return net.to(DEV).train()
 
 
-@pytest.mark.parametrize("kind", ["tokens", "nchw", "nchw_cl"])
+@pytest.mark.parametrize("kind", ["tokens", "nchw", "nchw_cl", "tokens_q"])
 @pytest.mark.parametrize("autocast", [None, torch.bfloat16, torch.float16])
 def test_converted_site_trains_to_the_same_bits(kind, autocast, monkeypatch):
     # (MIOpen's default weight-gradient algorithms are not run-to-run deterministic: ask for the deterministic ones, as fuzz_image.py does)
@@ -153,13 +155,13 @@ def test_converted_site_trains_to_the_same_bits(kind, autocast, monkeypatch):
     for on in (False, True):
         qs.set_qsparse_options(act_backward=on)
         before = fused.ROUTES["act_backward"]
-        net = build("tokens" if kind == "tokens" else "nchw")
+        net = build(kind if kind.startswith("tokens") else "nchw")
         if kind == "nchw_cl":
             net = net.to(memory_format=torch.channels_last)
         opt = torch.optim.SGD(net.parameters(), lr=0.05)
         outs = []
         for step in range(8):
-            shape = (6, 10, 32) if kind == "tokens" else (4, 8, 12, 12)
+            shape = (6, 10, 32) if kind.startswith("tokens") else (4, 8, 12, 12)
             x = torch.randn(shape, generator=gen(100 + step)).to(DEV)
             if kind == "nchw_cl":
                 x = x.contiguous(memory_format=torch.channels_last)
