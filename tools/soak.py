@@ -11,12 +11,16 @@ from qsparse_amd.fused import ROUTES
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 qs.set_qsparse_options(log_on_created=False, log_during_train=False)
 dev = torch.device("cuda", 0)
-for name in ("tokennet_gelu", "resnet18"):
+for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("tokennet_gelu", "resnet18")):
     torch.manual_seed(0)
     if name == "tokennet_gelu":
         net = convert_pq_tokens(TokenNet(num_classes=100, dim=192, hidden=768, depth=4, patch=16, act=nn.GELU), act=nn.GELU, sparsity=0.75, bits=4,
                                 prune_start=1, prune_interval=1, repetition=1, quant_timeout=1).to(dev).train()
         x = torch.randn(32, 3, 224, 224, device=dev); y = torch.randint(0, 100, (32,), device=dev)
+    elif name == "resnet50":          # BASELINE config 4's network and recipe at batch 64
+        from examples.models import resnet50
+        net = convert_pq(resnet50(1000, False), sparsity=0.75, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1).to(dev).to(memory_format=torch.channels_last).train()
+        x = torch.randn(64, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last); y = torch.randint(0, 1000, (64,), device=dev)
     else:
         net = convert_pq(resnet18(10, True), sparsity=0.5, bits=4, prune_start=1, prune_interval=1, repetition=1, quant_timeout=1).to(dev).to(memory_format=torch.channels_last).train()
         x = torch.randn(64, 3, 32, 32, device=dev).contiguous(memory_format=torch.channels_last); y = torch.randint(0, 10, (64,), device=dev)
